@@ -1,0 +1,38 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    return {k: z[k] for k in z.files}
+
+
+def sub(d, prefix):
+    """{'sd/a': x} -> {'a': tensor(x)} for one prefix."""
+    return {k[len(prefix):]: torch.from_numpy(np.asarray(v)) for k, v in d.items() if k.startswith(prefix)}
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def opt_mask(a):
+    return None if a.size == 0 else torch.from_numpy(a).bool()
+
+
+@pytest.fixture
+def golden():
+    return load_golden
