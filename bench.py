@@ -1,0 +1,167 @@
+#!/usr/bin/env python
+"""Headline benchmark: graphs/s of one full training step (fwd + bwd + gradient all-reduce + clip + Adam) of the gtos
+Generator on synthetic 100-node AMR graphs, batch 64 per GPU, bf16 activations (BASELINE.json configs[1] = "C2").
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Prints ONE JSON line (rank 0).  Also reports
+  roofline      relation-attention forward kernel: algorithmic bytes per launch (P*2d*s + 4*n*B*d*s + n*B,
+                SURVEY.md section 8d) / average launch duration measured with HIP events on the launch stream inside the
+                timed region, against 8 TB/s HBM3E;
+  cpu_baseline  the CPU oracle (a port of the reference pinned to its golden vectors) timed on the host cores on a
+                bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C2")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dense", action="store_true", help="dense relation[n,n,B,d] signature instead of the factored form")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-graphs", type=int, default=2)
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg_name, graphs):
+    """Oracle (kind 'port') full training step on the host cores, fp32, on `graphs` graphs of the same config."""
+    from oracle import gtos_oracle as O
+    from gtos_amd import synth
+    from gtos_amd.config import generator_args
+    from gtos_amd.flat import inverse_sqrt_lr
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = synth.CONFIGS[cfg_name]
+    vocabs = {k: O.VocabSpec(v, 0) for k, v in synth.DEFAULT_VOCAB.items()}
+    torch.manual_seed(19940117)
+    model = O.Generator(vocabs, depth_size=256 if cfg["kind"] == "dep" else 32, **generator_args(cfg))
+    model.train()
+    batch, stats = synth.make_config_batch(cfg_name, B=graphs)
+    params = [p for p in model.parameters()]
+    m = [torch.zeros_like(p) for p in params]
+    v = [torch.zeros_like(p) for p in params]
+    names = [n for n, _ in model.named_parameters()]
+
+    def step(i):
+        loss = model(batch)
+        loss.backward()
+        grads = [p.grad for p in params]
+        coef, _ = O.clip_coef(grads, 1.0)
+        lr = inverse_sqrt_lr(cfg["d"], i, 2000)
+        with torch.no_grad():
+            for k, p in enumerate(params):
+                np_, m[k], v[k] = O.adam_step(p, p.grad * coef, m[k], v[k], lr, 0.0 if O.is_no_decay(names[k]) else 1e-4)
+                p.copy_(np_)
+                p.grad = None
+        return loss.item()
+    step(1)
+    t0 = time.time()
+    n_timed = 2
+    for i in range(n_timed):
+        step(2 + i)
+    dt_ = (time.time() - t0) / n_timed
+    return {"value": graphs / dt_, "unit": "graphs/s", "cores": cores, "kind": "port",
+            "sample": "%d graphs of %s (n=%d, R=%d), fp32, full train step, %d timed steps, %.1f s/step" % (
+                graphs, cfg_name, stats["n"], stats["R"], n_timed, dt_)}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world)   # RCCL on ROCm
+
+    from gtos_amd import ops, synth
+    from gtos_amd.config import build_generator
+    from gtos_amd.generator import Generator
+    from gtos_amd.train import Trainer
+
+    cfg = synth.CONFIGS[a.config]
+    cd = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    model = build_generator(Generator, a.config, dev, factored_relation=not a.dense).to(dev)
+    model.set_compute_dtype(cd)
+    model.train()
+    trainer = Trainer(model, cfg["d"], warmup_steps=2000, compute_dtype=cd, world_size=world)
+    batch, stats = synth.make_config_batch(a.config, rank=rank)        # weak scaling: B graphs per GPU
+    batch = {k: v.to(dev) for k, v in batch.items()}
+    ops.set_seed(19940117 + rank)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        trainer.step(batch)
+    sync()
+    ops.PROFILE = {}
+    t0 = time.perf_counter()
+    losses = []
+    for _ in range(a.steps):
+        losses.append(trainer.step(batch))
+    sync()
+    elapsed = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    # ---- roofline of the relation-attention forward kernel (launches inside the timed region)
+    n, B, d = stats["n"], stats["B"], cfg["d"]
+    s_el = 2 if cd == torch.bfloat16 else 4
+    P = n * n * B
+    alg_bytes = P * 2 * d * s_el + 4 * n * B * d * s_el + n * B
+    key = "rel_attn_fwd_mode1" if a.dense else "rel_attn_fwd_mode2"
+    evs = prof.get(key, [])
+    avg_ms = sum(s.elapsed_time(e) for s, e in evs) / max(1, len(evs))
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if evs else 0.0
+    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "kernel": "rel_attn_fwd_kernel (%s relation operand)" % ("dense" if a.dense else "factored"),
+                "launches": len(evs), "avg_us": round(avg_ms * 1e3, 1), "algorithmic_bytes": alg_bytes}
+
+    if rank == 0:
+        out = {"metric": "graphs/sec training step (100-node AMR, batch 64)", "value": world * B * a.steps / elapsed,
+               "unit": "graphs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+               "config": {"workload": "%s: generator/ %dx%d-node synthetic AMR graphs per GPU, %d-layer d=%d %d-head, "
+                                      "full train step (fwd+bwd+allreduce+clip+Adam), dropout 0.2" % (
+                                          a.config, B, cfg["N"], cfg["layers"], d, cfg["H"]),
+                          "n": n, "B_per_gpu": B, "global_batch": world * B, "P": P, "R": stats["R"],
+                          "mean_path_len": round(stats["mean_path_len"], 2), "T": stats["T"],
+                          "relation_operand": "dense" if a.dense else "factored", "parallelism": "dp%d" % world,
+                          "loss_first": losses[0], "loss_last": losses[-1]},
+               "roofline": roofline}
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.config, a.cpu_graphs)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

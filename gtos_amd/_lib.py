@@ -1,0 +1,88 @@
+"""ctypes binding of libgtos_hip.so (the C ABI declared in include/gtos_hip.h).
+
+PyTorch only supplies device memory and the current HIP stream; every call passes raw device pointers.
+There is NO fallback: if the library is missing or a kernel rejects a shape, an exception is raised.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgtos_hip.so")
+ABI_VERSION = 1
+
+c_p, c_i, c_l, c_f, c_u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_uint64
+
+# name -> argument ctypes (return type is always int); mirrors include/gtos_hip.h one to one
+SIGNATURES = {
+    "gtos_abi_version": [],
+    "gtos_gemm": [c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_i, c_f, c_u64, c_i, c_i, c_p],
+    "gtos_rel_attn_fwd": [c_i] * 7 + [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_f, c_f, c_u64, c_p, c_l, c_p, c_p, c_p],
+    "gtos_rel_attn_bwd": [c_i] * 7 + [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_u64,
+                                      c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p],
+    "gtos_rel_attn_bwd_bank": [c_i] * 5 + [c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p],  # ... nchunks, d_bank, heavy, stream
+    "gtos_ln_residual_fwd": [c_i, c_i, c_i, c_p, c_p, c_f, c_u64, c_p, c_p, c_f, c_p, c_p, c_p, c_p],
+    "gtos_ln_residual_bwd": [c_i, c_i, c_i, c_p, c_p, c_p, c_f, c_u64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "gtos_relu_dropout_bwd": [c_i, c_l, c_p, c_p, c_f, c_p],
+    "gtos_colsum": [c_i, c_i, c_i, c_l, c_p, c_p, c_p],
+    "gtos_gru_cell_fwd": [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_l, c_p, c_p, c_f, c_u64, c_l, c_p],
+    "gtos_gru_cell_bwd": [c_i, c_i, c_i, c_p, c_p, c_p, c_l, c_p, c_p, c_p, c_f, c_u64, c_l, c_p],
+    "gtos_relation_gather_mean": [c_i, c_l, c_i, c_i, c_p, c_p, c_i, c_p, c_p],
+    "gtos_sqnorm": [c_l, c_p, c_p, c_p],
+    "gtos_adam_step": [c_l, c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_f, c_p, c_p],
+    "gtos_cast_f32_to_bf16": [c_l, c_p, c_p, c_p],
+}
+
+_lib = None
+
+
+class GtosHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once).  Raises GtosHipError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GtosHipError("%s is missing: run `python -m gtos_amd.build` (or __graft_entry__.build()); "
+                               "there is no CPU fallback for the gtos hot path" % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = args
+            fn.restype = ctypes.c_int
+        if lib.gtos_abi_version() != ABI_VERSION:
+            raise GtosHipError("libgtos_hip.so ABI %d != binding ABI %d: rebuild" % (lib.gtos_abi_version(), ABI_VERSION))
+        _lib = lib
+    return _lib
+
+
+def call(name, *args):
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise GtosHipError("%s failed with code %d (%s)" % (
+            name, rc, "HIP launch error" if rc > 0 else "unsupported argument/shape"))
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dt(t):
+    if t.dtype == torch.float32:
+        return 0
+    if t.dtype == torch.bfloat16:
+        return 1
+    raise GtosHipError("unsupported dtype %s" % t.dtype)
+
+
+def require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise GtosHipError("gtos_amd ops run on the GPU only (got a %s tensor); there is no CPU fallback" % t.device)

@@ -1,0 +1,42 @@
+"""Builds libgtos_hip.so (gfx950) in-tree with hipcc.  No torch in the build: the library is plain C ABI."""
+import os
+import subprocess
+import sys
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB = os.path.join(CSRC, "libgtos_hip.so")
+SOURCES = ["gemm.hip", "rel_attn.hip", "rowops.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    hdr = os.path.join(CSRC, "common.h")
+    objs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s, hdr]):
+            cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+    if force or _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

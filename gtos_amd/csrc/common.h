@@ -1,0 +1,80 @@
+// Shared device helpers for the gtos MI355X (gfx950) kernels.  wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define GTOS_F32 0
+#define GTOS_BF16 1
+
+typedef uint16_t bf16_t;   // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+struct alignas(16) U128 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);      // round to nearest even (NaN payloads are not a concern here)
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float lo_bf(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float hi_bf(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ uint32_t pack_bf(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+
+// 8 consecutive elements <-> 8 floats (one lane's slice of a row)
+template <typename T> struct Vec8;
+template <> struct Vec8<float> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[8]) {
+        const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[8]) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+};
+template <> struct Vec8<bf16_t> {
+    static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
+        const uint4 a = *reinterpret_cast<const uint4*>(p);
+        v[0] = lo_bf(a.x); v[1] = hi_bf(a.x); v[2] = lo_bf(a.y); v[3] = hi_bf(a.y);
+        v[4] = lo_bf(a.z); v[5] = hi_bf(a.z); v[6] = lo_bf(a.w); v[7] = hi_bf(a.w);
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
+        *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf(v[0], v[1]), pack_bf(v[2], v[3]),
+                                                  pack_bf(v[4], v[5]), pack_bf(v[6], v[7]));
+    }
+};
+
+template <typename T> __device__ __forceinline__ float to_f(T v);
+template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f<bf16_t>(bf16_t v) { return bf2f(v); }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float v) { return f2bf(v); }
+
+// Counter-based dropout RNG: keep(seed, idx) is a pure function, so backward regenerates the mask.
+__device__ __forceinline__ uint32_t mix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x7feb352dU; h ^= h >> 15; h *= 0x846ca68bU; h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ float rand01(uint64_t seed, uint64_t idx) {
+    uint32_t h = mix32((uint32_t)idx ^ (uint32_t)seed);
+    h = mix32(h + (uint32_t)(idx >> 32) * 0x9E3779B9U + (uint32_t)(seed >> 32));
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+__device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, float p) { return rand01(seed, idx) >= p; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+#define GTOS_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

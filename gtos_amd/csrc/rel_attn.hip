@@ -1,0 +1,523 @@
+// Fused relation-aware graph attention for gfx950 (forward + backward), wave-per-query streaming kernels.
+//
+// Replaces the reference op sequence of RelationMultiheadAttention.forward
+// (/root/reference/generator/graph_transformer.py:122-165: q.unsqueeze(1)+ra, k.unsqueeze(0)+rb, scaling,
+// einsum scores, two masked_fill_, softmax over keys, weight dropout, einsum with v) and, with mode 0,
+// MultiheadAttention.forward (/root/reference/generator/transformer.py:120-162).  Nothing of size
+// [n,n,B*H,hd] is materialised:
+//
+//   s[i,j,b,h] = scale * sum_e (q[i,b,h,e] + ra[j,i,b,h,e]) * (k[j,b,h,e] + rb[j,i,b,h,e])
+//   p = softmax_j(mask(s)),  o[i,b,h,:] = sum_j drop(p)[i,j,b,h] * v[j,b,h,:]
+//
+// relation operand (mode):
+//   0  none            plain multi-head attention (decoder self / cross attention)
+//   1  dense           rarb[S,T,B,2d]  = relation_in_proj(relation), memory order [key j][query i]
+//   2  factored        bank[R,2d] = relation_in_proj(relation_encoder output) + int32 type ids,
+//                      idx_q[T,B,S] (query-major) / idx_k[S,B,T] (key-major); the per-pair row is gathered
+//                      inside the kernel, which fuses away the reference's index_select
+//                      (/root/reference/generator/generator.py:79).
+//
+// Mapping: one 64-lane wave owns one (query i, graph b).  A row of d channels is spread over LR = d/8 lanes,
+// 8 channels (16 B bf16 / 32 B fp32) per lane, so one wave-instruction streams a whole 2d-wide relation row
+// with fully coalesced 16-byte loads; the per-head dot product is a shuffle reduction over the LH = hd/8 lanes
+// of a head and the softmax over keys is an online (running max / sum) update, i.e. the per-head softmax
+// reduction is wavefront shuffles only.  If d < 512 the wave processes G = 64/LR keys at once and merges the
+// G partial softmax states at the end.  K/V rows come through L2: the block->(i,b) map keeps every graph's
+// K/V on one XCD (8 XCDs, private L2s).
+#include "common.h"
+#include <type_traits>
+
+namespace {
+
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16_t> {
+    uint4 a;
+    __device__ __forceinline__ void load(const bf16_t* p) { a = *reinterpret_cast<const uint4*>(p); }
+    __device__ __forceinline__ void zero() { a = make_uint4(0, 0, 0, 0); }
+    __device__ __forceinline__ void get(float (&v)[8]) const {
+        v[0] = lo_bf(a.x); v[1] = hi_bf(a.x); v[2] = lo_bf(a.y); v[3] = hi_bf(a.y);
+        v[4] = lo_bf(a.z); v[5] = hi_bf(a.z); v[6] = lo_bf(a.w); v[7] = hi_bf(a.w);
+    }
+};
+template <> struct Raw8<float> {
+    float4 a, b;
+    __device__ __forceinline__ void load(const float* p) {
+        a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4);
+    }
+    __device__ __forceinline__ void zero() { a = make_float4(0, 0, 0, 0); b = a; }
+    __device__ __forceinline__ void get(float (&v)[8]) const {
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+};
+
+template <typename T> struct Unroll { static constexpr int U = 4; };
+template <> struct Unroll<float> { static constexpr int U = 2; };
+
+struct AttnArgs {
+    const void *q, *k, *v; int64_t ldq, ldk, ldv;          // rows (t*B+b)*ld, element units
+    const void* rel;            // mode 1: rarb [S,T,B,2d]; mode 2: bank [R,2d]
+    const int* idx_q;           // mode 2: [T,B,S]
+    const int* idx_k;           // mode 2: [S,B,T]   (backward, key-major pass)
+    const uint8_t* key_pad;     // [S,B] or null
+    const uint8_t* attn_mask;   // [T,S] or null
+    void* o; int64_t ldo;       // fwd out / bwd in [T,B,d]
+    float* lse;                 // [T,B,H]
+    float* w;                   // optional [T,S,B,H] post-dropout weights (fwd out; bwd in when dw given)
+    // backward
+    const void* d_o; int64_t lddo;
+    const float* dw;            // optional upstream grad on w, [T,S,B,H]
+    void *dq, *dk, *dv; int64_t lddq, lddk, lddv;
+    void* d_rel;                // mode 1: d_rarb [S,T,B,2d] (type T)
+    float* pd;                  // scratch [T,S,B,H]: post-dropout probabilities
+    float* gs;                  // scratch [T,S,B,H]: scale * dS
+    int T, S, B, H, d, mode;
+    float scale, p_drop; uint64_t seed;
+};
+
+template <int LH> __device__ __forceinline__ float head_sum(float v) {
+#pragma unroll
+    for (int o = 1; o < LH; o <<= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// block -> (row index, graph).  4 waves of a block take 4 consecutive graphs of one row; blocks are dealt to
+// XCDs round-robin by the dispatcher (block id % 8), so give each XCD a fixed subset of graphs.
+__device__ __forceinline__ bool map_block(int rows, int B, int& row, int& b) {
+    const int nbg = (B + 3) >> 2;
+    const int blk = blockIdx.x;
+    int bg;
+    if ((nbg & 7) == 0) { const int x = blk & 7, w = blk >> 3, gpx = nbg >> 3; bg = x * gpx + (w % gpx); row = w / gpx; }
+    else { bg = blk % nbg; row = blk / nbg; }
+    b = bg * 4 + (threadIdx.x >> 6);
+    return b < B && row < rows;
+}
+
+__device__ __forceinline__ bool is_masked(const AttnArgs& a, int i, int j, int b) {
+    bool m = false;
+    if (a.key_pad) m = a.key_pad[(int64_t)j * a.B + b] != 0;
+    if (a.attn_mask) m = m || (a.attn_mask[(int64_t)i * a.S + j] != 0);
+    return m;
+}
+
+// ------------------------------------------------------------------------------------------- forward
+template <typename T, int LH>
+__global__ __launch_bounds__(256) void rel_attn_fwd_kernel(AttnArgs a) {
+    constexpr int U = Unroll<T>::U;
+    int i, b;
+    if (!map_block(a.T, a.B, i, b)) return;
+    const int lane = threadIdx.x & 63;
+    const int d = a.d, LR = d >> 3, G = 64 / LR, g = lane / LR, cl = lane % LR, c = cl * 8, h = cl / LH;
+    const T* qp = static_cast<const T*>(a.q) + ((int64_t)i * a.B + b) * a.ldq + c;
+    const T* kb = static_cast<const T*>(a.k) + (int64_t)b * a.ldk + c;
+    const T* vb = static_cast<const T*>(a.v) + (int64_t)b * a.ldv + c;
+    const T* rel = static_cast<const T*>(a.rel);
+    const int* iq = a.mode == 2 ? a.idx_q + ((int64_t)i * a.B + b) * a.S : nullptr;
+    const float keep_scale = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
+
+    float qf[8];
+    { Raw8<T> r; r.load(qp); r.get(qf); }
+    float m = -INFINITY, l = 0.f, o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    int tn[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { const int j = u * G + g; tn[u] = (iq && j < a.S) ? iq[j] : 0; }
+
+    for (int jb = 0; jb < a.S; jb += G * U) {
+        Raw8<T> rra[U], rrb[U], rk[U], rv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = jb + u * G + g;
+            rra[u].zero(); rrb[u].zero(); rk[u].zero(); rv[u].zero();
+            if (j < a.S) {
+                rk[u].load(kb + (int64_t)j * a.B * a.ldk);
+                rv[u].load(vb + (int64_t)j * a.B * a.ldv);
+                if (a.mode == 1) {
+                    const T* p = rel + (((int64_t)j * a.T + i) * a.B + b) * (2 * d) + c;
+                    rra[u].load(p); rrb[u].load(p + d);
+                } else if (a.mode == 2) {
+                    const T* p = rel + (int64_t)tn[u] * (2 * d) + c;
+                    rra[u].load(p); rrb[u].load(p + d);
+                }
+            }
+        }
+        if (iq) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const int j = jb + G * U + u * G + g; tn[u] = j < a.S ? iq[j] : 0; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = jb + u * G + g;
+            float ra[8], rb[8], kf[8], vf[8];
+            rra[u].get(ra); rrb[u].get(rb); rk[u].get(kf); rv[u].get(vf);
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s = fmaf(qf[e] + ra[e], kf[e] + rb[e], s);
+            s = head_sum<LH>(s) * a.scale;
+            const bool dead = (j >= a.S) || is_masked(a, i, j, b);
+            if (dead) s = -INFINITY;
+            if (a.w && j < a.S && (cl % LH) == 0) a.w[(((int64_t)i * a.S + j) * a.B + b) * a.H + h] = s;
+            const float mn = fmaxf(m, s);
+            float alpha = 1.f, pe = 0.f;
+            if (mn != -INFINITY) { alpha = __expf(m - mn); pe = __expf(s - mn); }
+            l = l * alpha + pe;
+            float pv = pe;
+            if (a.p_drop > 0.f && !dead)
+                pv = drop_keep(a.seed, (((uint64_t)i * a.S + j) * a.B + b) * a.H + h, a.p_drop) ? pe * keep_scale : 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = fmaf(o[e], alpha, pv * vf[e]);
+            m = mn;
+        }
+    }
+    // merge the G key-groups (lanes with equal cl, different g)
+    for (int off = LR; off < 64; off <<= 1) {
+        const float m2 = __shfl_xor(m, off), l2 = __shfl_xor(l, off);
+        const float mn = fmaxf(m, m2);
+        float a1 = 1.f, a2 = 1.f;
+        if (mn != -INFINITY) { a1 = __expf(m - mn); a2 = __expf(m2 - mn); }
+        l = l * a1 + l2 * a2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float o2 = __shfl_xor(o[e], off); o[e] = o[e] * a1 + o2 * a2; }
+        m = mn;
+    }
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    if (g == 0) {
+        float r[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = o[e] * inv;
+        Vec8<T>::store(static_cast<T*>(a.o) + ((int64_t)i * a.B + b) * a.ldo + c, r);
+        if ((cl % LH) == 0) a.lse[((int64_t)i * a.B + b) * a.H + h] = (l > 0.f) ? m + __logf(l) : -INFINITY;
+    }
+    if (a.w && (cl % LH) == 0) {   // normalise the raw scores this same lane wrote above
+        for (int j = g; j < a.S; j += G) {
+            const int64_t off = (((int64_t)i * a.S + j) * a.B + b) * a.H + h;
+            const float s = a.w[off];
+            float p = (s == -INFINITY || l <= 0.f) ? 0.f : __expf(s - m) * inv;
+            if (a.p_drop > 0.f && p > 0.f) p = drop_keep(a.seed, (uint64_t)off, a.p_drop) ? p * keep_scale : 0.f;
+            a.w[off] = p;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- backward, query-major
+// per (i,b): recompute p from lse; dS; dq_i = sum_j scale*dS*(k_j+rb); dense mode writes d_rarb rows;
+// stores pd (post-dropout p) and gs (= scale*dS) for the key-major and bank passes.
+template <typename T, int LH>
+__global__ __launch_bounds__(256) void rel_attn_bwd_q_kernel(AttnArgs a) {
+    constexpr int U = Unroll<T>::U;
+    int i, b;
+    if (!map_block(a.T, a.B, i, b)) return;
+    const int lane = threadIdx.x & 63;
+    const int d = a.d, LR = d >> 3, G = 64 / LR, g = lane / LR, cl = lane % LR, c = cl * 8, h = cl / LH;
+    const int64_t row = (int64_t)i * a.B + b;
+    const T* kb = static_cast<const T*>(a.k) + (int64_t)b * a.ldk + c;
+    const T* vb = static_cast<const T*>(a.v) + (int64_t)b * a.ldv + c;
+    const T* rel = static_cast<const T*>(a.rel);
+    const int* iq = a.mode == 2 ? a.idx_q + row * a.S : nullptr;
+    const float keep_scale = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
+
+    float qf[8], dof[8], of[8];
+    { Raw8<T> r; r.load(static_cast<const T*>(a.q) + row * a.ldq + c); r.get(qf); }
+    { Raw8<T> r; r.load(static_cast<const T*>(a.d_o) + row * a.lddo + c); r.get(dof); }
+    { Raw8<T> r; r.load(static_cast<const T*>(a.o) + row * a.ldo + c); r.get(of); }
+    float D = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) D = fmaf(dof[e], of[e], D);
+    D = head_sum<LH>(D);
+    if (a.dw) {     // upstream gradient on the returned weights: D += sum_j w_ij * dw_ij
+        float acc = 0.f;
+        for (int j = g; j < a.S; j += G) {
+            const int64_t off = ((row / a.B * a.S + j) * a.B + b) * a.H + h;   // [i,j,b,h]
+            acc = fmaf(a.w[off], a.dw[off], acc);
+        }
+        for (int off = LR; off < 64; off <<= 1) acc += __shfl_xor(acc, off);
+        D += acc;
+    }
+    const float lse = a.lse[row * a.H + h];
+    float dq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    int tn[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { const int j = u * G + g; tn[u] = (iq && j < a.S) ? iq[j] : 0; }
+
+    for (int jb = 0; jb < a.S; jb += G * U) {
+        Raw8<T> rra[U], rrb[U], rk[U], rv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = jb + u * G + g;
+            rra[u].zero(); rrb[u].zero(); rk[u].zero(); rv[u].zero();
+            if (j < a.S) {
+                rk[u].load(kb + (int64_t)j * a.B * a.ldk);
+                rv[u].load(vb + (int64_t)j * a.B * a.ldv);
+                if (a.mode == 1) {
+                    const T* p = rel + (((int64_t)j * a.T + i) * a.B + b) * (2 * d) + c;
+                    rra[u].load(p); rrb[u].load(p + d);
+                } else if (a.mode == 2) {
+                    const T* p = rel + (int64_t)tn[u] * (2 * d) + c;
+                    rra[u].load(p); rrb[u].load(p + d);
+                }
+            }
+        }
+        if (iq) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const int j = jb + G * U + u * G + g; tn[u] = j < a.S ? iq[j] : 0; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = jb + u * G + g;
+            if (j >= a.S) continue;
+            float ra[8], rb[8], kf[8], vf[8];
+            rra[u].get(ra); rrb[u].get(rb); rk[u].get(kf); rv[u].get(vf);
+            float s = 0.f, dpv = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                ra[e] += qf[e]; rb[e] += kf[e];                 // ra := q+ra, rb := k+rb
+                s = fmaf(ra[e], rb[e], s);
+                dpv = fmaf(dof[e], vf[e], dpv);
+            }
+            s = head_sum<LH>(s) * a.scale;
+            dpv = head_sum<LH>(dpv);
+            const int64_t off = (((int64_t)i * a.S + j) * a.B + b) * a.H + h;
+            const bool dead = is_masked(a, i, j, b) || lse == -INFINITY;
+            const float p = dead ? 0.f : __expf(s - lse);
+            float keep = 1.f;
+            if (a.p_drop > 0.f) keep = drop_keep(a.seed, (uint64_t)off, a.p_drop) ? keep_scale : 0.f;
+            float dp = dpv;
+            if (a.dw) dp += a.dw[off];
+            const float gsc = a.scale * p * (keep * dp - D);
+            if ((cl % LH) == 0) { a.pd[off] = p * keep; a.gs[off] = gsc; }
+            float dra[8], drb[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { dra[e] = gsc * rb[e]; drb[e] = gsc * ra[e]; dq[e] += dra[e]; }
+            if (a.mode == 1) {
+                T* p2 = static_cast<T*>(a.d_rel) + (((int64_t)j * a.T + i) * a.B + b) * (2 * d) + c;
+                Vec8<T>::store(p2, dra);
+                Vec8<T>::store(p2 + d, drb);
+            }
+        }
+    }
+    for (int off = LR; off < 64; off <<= 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dq[e] += __shfl_xor(dq[e], off);
+    }
+    if (g == 0) Vec8<T>::store(static_cast<T*>(a.dq) + row * a.lddq + c, dq);
+}
+
+// ------------------------------------------------------------------------------------------- backward, key-major
+// per (j,b): dv_j = sum_i pd_ij do_i ; dk_j = sum_i gs_ij (q_i + ra_ji)
+template <typename T, int LH>
+__global__ __launch_bounds__(256) void rel_attn_bwd_kv_kernel(AttnArgs a) {
+    constexpr int U = Unroll<T>::U;
+    int j, b;
+    if (!map_block(a.S, a.B, j, b)) return;
+    const int lane = threadIdx.x & 63;
+    const int d = a.d, LR = d >> 3, G = 64 / LR, g = lane / LR, cl = lane % LR, c = cl * 8, h = cl / LH;
+    const int64_t row = (int64_t)j * a.B + b;
+    const T* qb = static_cast<const T*>(a.q) + (int64_t)b * a.ldq + c;
+    const T* dob = static_cast<const T*>(a.d_o) + (int64_t)b * a.lddo + c;
+    const T* rel = static_cast<const T*>(a.rel);
+    const int* ik = a.mode == 2 ? a.idx_k + row * a.T : nullptr;
+    float dk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    for (int ib = 0; ib < a.T; ib += G * U) {
+        Raw8<T> rq[U], rdo[U], rra[U];
+        float pdv[U], gsv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = ib + u * G + g;
+            rq[u].zero(); rdo[u].zero(); rra[u].zero(); pdv[u] = 0.f; gsv[u] = 0.f;
+            if (i < a.T) {
+                rq[u].load(qb + (int64_t)i * a.B * a.ldq);
+                rdo[u].load(dob + (int64_t)i * a.B * a.lddo);
+                const int64_t off = (((int64_t)i * a.S + j) * a.B + b) * a.H + h;
+                pdv[u] = a.pd[off]; gsv[u] = a.gs[off];
+                if (a.mode == 1) rra[u].load(rel + (((int64_t)j * a.T + i) * a.B + b) * (2 * d) + c);
+                else if (a.mode == 2) rra[u].load(rel + (int64_t)ik[i] * (2 * d) + c);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float qf[8], dof[8], ra[8];
+            rq[u].get(qf); rdo[u].get(dof); rra[u].get(ra);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { dv[e] = fmaf(pdv[u], dof[e], dv[e]); dk[e] = fmaf(gsv[u], qf[e] + ra[e], dk[e]); }
+        }
+    }
+    for (int off = LR; off < 64; off <<= 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { dk[e] += __shfl_xor(dk[e], off); dv[e] += __shfl_xor(dv[e], off); }
+    }
+    if (g == 0) {
+        Vec8<T>::store(static_cast<T*>(a.dk) + row * a.lddk + c, dk);
+        Vec8<T>::store(static_cast<T*>(a.dv) + row * a.lddv + c, dv);
+    }
+}
+
+// ------------------------------------------------------------------------------------------- backward, bank (factored)
+// Work item = one chunk of <= chunk_len pairs that share a relation type t (pairs sorted by type on the host):
+//   d_bank[t, 0:d]  += sum_pairs gs * (k_j + RB[t]) ;  d_bank[t, d:2d] += sum_pairs gs * (q_i + RA[t])
+// pair id = (j*T + i)*B + b (the memory order of relation[j][i][b]).  A type that fits one chunk stores its row of
+// d_bank (type T) directly; a type spanning several chunks ("heavy": <CLS>, <rCLS>, <SELF>, <TL>, frequent short
+// paths) accumulates with fp32 atomics into its slot of a small side buffer that the caller folds back.
+struct BankArgs {
+    const void *q, *k; int64_t ldq, ldk;
+    const void* bank; const float* gs;
+    const int* pair_sorted;      // [P] pair ids sorted by type
+    const int* chunk_type;       // [C]
+    const int* chunk_start;      // [C]
+    const int* chunk_count;      // [C]
+    const int* chunk_slot;       // [C] -1 -> store d_bank[t] directly; >= 0 -> atomicAdd into heavy[slot]
+    void* d_bank;                // [R,2d] type T
+    float* heavy;                // [n_heavy,2d] fp32, zero-initialised by the caller
+    int nchunks, T, S, B, H, d;
+};
+
+template <typename T, int LH>
+__global__ __launch_bounds__(256) void rel_attn_bwd_bank_kernel(BankArgs a) {
+    const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ch >= a.nchunks) return;
+    const int lane = threadIdx.x & 63;
+    const int d = a.d, LR = d >> 3, G = 64 / LR, g = lane / LR, cl = lane % LR, c = cl * 8, h = cl / LH;
+    const int t = a.chunk_type[ch], start = a.chunk_start[ch], cnt = a.chunk_count[ch];
+    float da[8] = {0, 0, 0, 0, 0, 0, 0, 0}, db[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gsum = 0.f;
+    for (int p = g; p < cnt; p += G) {
+        const int pid = a.pair_sorted[start + p];
+        const int b = pid % a.B, ji = pid / a.B, i = ji % a.T, j = ji / a.T;
+        const float gsc = a.gs[(((int64_t)i * a.S + j) * a.B + b) * a.H + h];
+        float kf[8], qf[8];
+        { Raw8<T> r; r.load(static_cast<const T*>(a.k) + ((int64_t)j * a.B + b) * a.ldk + c); r.get(kf); }
+        { Raw8<T> r; r.load(static_cast<const T*>(a.q) + ((int64_t)i * a.B + b) * a.ldq + c); r.get(qf); }
+        gsum += gsc;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { da[e] = fmaf(gsc, kf[e], da[e]); db[e] = fmaf(gsc, qf[e], db[e]); }
+    }
+    for (int off = LR; off < 64; off <<= 1) {
+        gsum += __shfl_xor(gsum, off);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { da[e] += __shfl_xor(da[e], off); db[e] += __shfl_xor(db[e], off); }
+    }
+    if (g != 0) return;
+    float RA[8], RB[8];
+    const T* bp = static_cast<const T*>(a.bank) + (int64_t)t * (2 * d) + c;
+    { Raw8<T> r; r.load(bp); r.get(RA); }
+    { Raw8<T> r; r.load(bp + d); r.get(RB); }
+    const int slot = a.chunk_slot[ch];
+    if (slot >= 0) {
+        float* out = a.heavy + (int64_t)slot * (2 * d) + c;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { atomicAdd(out + e, fmaf(gsum, RB[e], da[e])); atomicAdd(out + d + e, fmaf(gsum, RA[e], db[e])); }
+    } else {
+        T* out = static_cast<T*>(a.d_bank) + (int64_t)t * (2 * d) + c;
+        float r1[8], r2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { r1[e] = fmaf(gsum, RB[e], da[e]); r2[e] = fmaf(gsum, RA[e], db[e]); }
+        Vec8<T>::store(out, r1);
+        Vec8<T>::store(out + d, r2);
+    }
+}
+
+template <typename K> int dispatch_lh(int lh, K&& f) {
+    switch (lh) {
+        case 1: return f(std::integral_constant<int, 1>());
+        case 2: return f(std::integral_constant<int, 2>());
+        case 4: return f(std::integral_constant<int, 4>());
+        case 8: return f(std::integral_constant<int, 8>());
+        case 16: return f(std::integral_constant<int, 16>());
+        case 32: return f(std::integral_constant<int, 32>());
+        case 64: return f(std::integral_constant<int, 64>());
+    }
+    return -11;
+}
+
+int check_shape(int d, int H) {
+    if (H <= 0 || d % H) return -10;
+    const int hd = d / H;
+    if (d % 8 || d > 512 || (d & (d - 1)) || hd % 8 || (hd & (hd - 1))) return -10;   // d, hd powers of two, hd >= 8
+    return 0;
+}
+
+int nblocks(int rows, int B) { return rows * ((B + 3) / 4); }
+
+}  // namespace
+
+static int fill_args(AttnArgs& a, int T_, int S, int B, int H, int d, int mode, float scale, float p_drop, uint64_t seed) {
+    a.T = T_; a.S = S; a.B = B; a.H = H; a.d = d; a.mode = mode; a.scale = scale; a.p_drop = p_drop; a.seed = seed;
+    if (mode != 0 && T_ != S) return -12;
+    return check_shape(d, H);
+}
+
+extern "C" int gtos_rel_attn_fwd(int dtype, int mode, int T_, int S, int B, int H, int d,
+                                 const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                                 const void* rel, const int* idx_q, const uint8_t* key_pad, const uint8_t* attn_mask,
+                                 float scale, float p_drop, uint64_t seed,
+                                 void* o, int64_t ldo, float* lse, float* w, void* stream) {
+    AttnArgs a = {};
+    int rc = fill_args(a, T_, S, B, H, d, mode, scale, p_drop, seed);
+    if (rc) return rc;
+    a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.rel = rel; a.idx_q = idx_q;
+    a.key_pad = key_pad; a.attn_mask = attn_mask; a.o = o; a.ldo = ldo; a.lse = lse; a.w = w;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int grid = nblocks(T_, B);
+    return dispatch_lh(d / H / 8, [&](auto lh) {
+        constexpr int LH = decltype(lh)::value;
+        if (dtype == GTOS_BF16) hipLaunchKernelGGL((rel_attn_fwd_kernel<bf16_t, LH>), dim3(grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((rel_attn_fwd_kernel<float, LH>), dim3(grid), dim3(256), 0, s, a);
+        GTOS_CHECK_LAUNCH();
+        return 0;
+    });
+}
+
+extern "C" int gtos_rel_attn_bwd(int dtype, int mode, int T_, int S, int B, int H, int d,
+                                 const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                                 const void* rel, const int* idx_q, const int* idx_k,
+                                 const uint8_t* key_pad, const uint8_t* attn_mask,
+                                 float scale, float p_drop, uint64_t seed,
+                                 const void* o, int64_t ldo, const float* lse, const float* w,
+                                 const void* d_o, int64_t lddo, const float* dw,
+                                 void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv,
+                                 void* d_rel, float* pd, float* gs, void* stream) {
+    AttnArgs a = {};
+    int rc = fill_args(a, T_, S, B, H, d, mode, scale, p_drop, seed);
+    if (rc) return rc;
+    a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.rel = rel; a.idx_q = idx_q; a.idx_k = idx_k;
+    a.key_pad = key_pad; a.attn_mask = attn_mask; a.o = const_cast<void*>(o); a.ldo = ldo;
+    a.lse = const_cast<float*>(lse); a.w = const_cast<float*>(w); a.d_o = d_o; a.lddo = lddo; a.dw = dw;
+    a.dq = dq; a.dk = dk; a.dv = dv; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv; a.d_rel = d_rel; a.pd = pd; a.gs = gs;
+    if (dw && !w) return -13;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return dispatch_lh(d / H / 8, [&](auto lh) {
+        constexpr int LH = decltype(lh)::value;
+        if (dtype == GTOS_BF16) {
+            hipLaunchKernelGGL((rel_attn_bwd_q_kernel<bf16_t, LH>), dim3(nblocks(T_, B)), dim3(256), 0, s, a);
+            hipLaunchKernelGGL((rel_attn_bwd_kv_kernel<bf16_t, LH>), dim3(nblocks(S, B)), dim3(256), 0, s, a);
+        } else {
+            hipLaunchKernelGGL((rel_attn_bwd_q_kernel<float, LH>), dim3(nblocks(T_, B)), dim3(256), 0, s, a);
+            hipLaunchKernelGGL((rel_attn_bwd_kv_kernel<float, LH>), dim3(nblocks(S, B)), dim3(256), 0, s, a);
+        }
+        GTOS_CHECK_LAUNCH();
+        return 0;
+    });
+}
+
+extern "C" int gtos_rel_attn_bwd_bank(int dtype, int n, int B, int H, int d,
+                                      const void* q, int64_t ldq, const void* k, int64_t ldk,
+                                      const void* bank, const float* gs,
+                                      const int* pair_sorted, const int* chunk_type, const int* chunk_start,
+                                      const int* chunk_count, const int* chunk_slot, int nchunks,
+                                      void* d_bank, float* heavy, void* stream) {
+    int rc = check_shape(d, H);
+    if (rc) return rc;
+    if (nchunks <= 0) return 0;
+    BankArgs a;
+    a.q = q; a.k = k; a.ldq = ldq; a.ldk = ldk; a.bank = bank; a.gs = gs; a.pair_sorted = pair_sorted;
+    a.chunk_type = chunk_type; a.chunk_start = chunk_start; a.chunk_count = chunk_count; a.chunk_slot = chunk_slot;
+    a.d_bank = d_bank; a.heavy = heavy; a.nchunks = nchunks; a.T = n; a.S = n; a.B = B; a.H = H; a.d = d;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int grid = (nchunks + 3) / 4;
+    return dispatch_lh(d / H / 8, [&](auto lh) {
+        constexpr int LH = decltype(lh)::value;
+        if (dtype == GTOS_BF16) hipLaunchKernelGGL((rel_attn_bwd_bank_kernel<bf16_t, LH>), dim3(grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((rel_attn_bwd_bank_kernel<float, LH>), dim3(grid), dim3(256), 0, s, a);
+        GTOS_CHECK_LAUNCH();
+        return 0;
+    });
+}

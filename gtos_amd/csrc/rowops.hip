@@ -1,0 +1,459 @@
+// Row-wise / element-wise HBM-bound kernels for gfx950: fused dropout+residual+LayerNorm (fwd/bwd),
+// ReLU+dropout backward, bias-gradient column sums, the GRU cell (fwd/bwd), relation gather-mean,
+// flat Adam + gradient square-norm, fp32->bf16 weight mirror.  All use 16/32-byte per-lane vector accesses.
+#include "common.h"
+
+namespace {
+
+// =========================================================================== LayerNorm(x + dropout(r))
+// Replaces  x = F.dropout(x); x = layer_norm(residual + x)
+// (/root/reference/generator/graph_transformer.py:57-58,64-65, generator/transformer.py:57-58,63-64,70-71).
+// One wave per row; d % 8 == 0, d <= 1024 (each lane holds up to 2 chunks of 8 channels).
+constexpr int LN_MAXC = 2;
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int d, const T* __restrict__ x, const T* __restrict__ r,
+                                                     float p_drop, uint64_t seed, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float eps, T* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float ks = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    float z[LN_MAXC][8];
+    float s = 0.f;
+#pragma unroll
+    for (int cI = 0; cI < LN_MAXC; ++cI) {
+        const int c = (cI * 64 + lane) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[cI][e] = 0.f;
+        if (c < d) {
+            Vec8<T>::load(x + (int64_t)row * d + c, z[cI]);
+            if (r) {
+                float rv[8];
+                Vec8<T>::load(r + (int64_t)row * d + c, rv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float t = rv[e];
+                    if (p_drop > 0.f) t = drop_keep(seed, (uint64_t)row * d + c + e, p_drop) ? t * ks : 0.f;
+                    z[cI][e] += t;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += z[cI][e];
+        }
+    }
+    const float mu = wave_sum(s) / d;
+    float v = 0.f;
+#pragma unroll
+    for (int cI = 0; cI < LN_MAXC; ++cI) {
+        const int c = (cI * 64 + lane) * 8;
+        if (c < d) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float t = z[cI][e] - mu; v = fmaf(t, t, v); }
+        }
+    }
+    const float rs = rsqrtf(wave_sum(v) / d + eps);
+#pragma unroll
+    for (int cI = 0; cI < LN_MAXC; ++cI) {
+        const int c = (cI * 64 + lane) * 8;
+        if (c < d) {
+            float gm[8], bt[8], o[8];
+            Vec8<float>::load(gamma + c, gm);
+            Vec8<float>::load(beta + c, bt);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = fmaf((z[cI][e] - mu) * rs, gm[e], bt[e]);
+            Vec8<T>::store(y + (int64_t)row * d + c, o);
+        }
+    }
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+// backward: dz = rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dy*gamma; dx = dz; dr = dz * dropmask.
+// Each wave walks rows grid-stride and keeps dgamma/dbeta partials in registers -> one atomicAdd per lane-channel.
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int d, const T* __restrict__ dy, const T* __restrict__ x,
+                                                     const T* __restrict__ r, float p_drop, uint64_t seed,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, T* __restrict__ dx, T* __restrict__ dr,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+    const float ks = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    float dg[LN_MAXC][8], db[LN_MAXC][8], gm[LN_MAXC][8];
+#pragma unroll
+    for (int cI = 0; cI < LN_MAXC; ++cI) {
+        const int c = (cI * 64 + lane) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { dg[cI][e] = 0.f; db[cI][e] = 0.f; gm[cI][e] = 0.f; }
+        if (c < d) Vec8<float>::load(gamma + c, gm[cI]);
+    }
+    for (int row = wid; row < rows; row += nw) {
+        const float mu = mean[row], rs = rstd[row];
+        float g[LN_MAXC][8], xh[LN_MAXC][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int cI = 0; cI < LN_MAXC; ++cI) {
+            const int c = (cI * 64 + lane) * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { g[cI][e] = 0.f; xh[cI][e] = 0.f; }
+            if (c < d) {
+                float z[8], dyv[8];
+                Vec8<T>::load(x + (int64_t)row * d + c, z);
+                Vec8<T>::load(dy + (int64_t)row * d + c, dyv);
+                if (r) {
+                    float rv[8];
+                    Vec8<T>::load(r + (int64_t)row * d + c, rv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float t = rv[e];
+                        if (p_drop > 0.f) t = drop_keep(seed, (uint64_t)row * d + c + e, p_drop) ? t * ks : 0.f;
+                        z[e] += t;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    xh[cI][e] = (z[e] - mu) * rs;
+                    g[cI][e] = dyv[e] * gm[cI][e];
+                    s1 += g[cI][e]; s2 = fmaf(g[cI][e], xh[cI][e], s2);
+                    dg[cI][e] = fmaf(dyv[e], xh[cI][e], dg[cI][e]); db[cI][e] += dyv[e];
+                }
+            }
+        }
+        s1 = wave_sum(s1) / d; s2 = wave_sum(s2) / d;
+#pragma unroll
+        for (int cI = 0; cI < LN_MAXC; ++cI) {
+            const int c = (cI * 64 + lane) * 8;
+            if (c < d) {
+                float dz[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dz[e] = rs * (g[cI][e] - s1 - xh[cI][e] * s2);
+                Vec8<T>::store(dx + (int64_t)row * d + c, dz);
+                if (dr) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (p_drop > 0.f) dz[e] = drop_keep(seed, (uint64_t)row * d + c + e, p_drop) ? dz[e] * ks : 0.f;
+                    Vec8<T>::store(dr + (int64_t)row * d + c, dz);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int cI = 0; cI < LN_MAXC; ++cI) {
+        const int c = (cI * 64 + lane) * 8;
+        if (c < d) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { atomicAdd(dgamma + c + e, dg[cI][e]); atomicAdd(dbeta + c + e, db[cI][e]); }
+        }
+    }
+}
+
+// =========================================================================== relu+dropout backward (in place)
+// dh *= (h > 0) * 1/(1-p): h is the saved post-ReLU post-dropout activation, zero wherever either killed it.
+template <typename T>
+__global__ void relu_drop_bwd_kernel(int64_t n8, T* __restrict__ dh, const T* __restrict__ h, float ks) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        float a[8], b[8];
+        Vec8<T>::load(dh + i * 8, a);
+        Vec8<T>::load(h + i * 8, b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = b[e] > 0.f ? a[e] * ks : 0.f;
+        Vec8<T>::store(dh + i * 8, a);
+    }
+}
+
+// =========================================================================== bias gradient: out[n] += sum_rows dy[row, n]
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(int rows, int N, int64_t ld, const T* __restrict__ dy, float* __restrict__ out,
+                                                     int rows_per_block) {
+    const int c = (blockIdx.x * 256 + threadIdx.x) * 8;
+    if (c >= N) return;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool full = (c + 8 <= N) && (ld % 8 == 0);
+    for (int r = r0; r < r1; ++r) {
+        const T* p = dy + (int64_t)r * ld + c;
+        if (full) {
+            float v[8];
+            Vec8<T>::load(p, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += v[e];
+        } else {
+            for (int e = 0; e < 8 && c + e < N; ++e) acc[e] += to_f<T>(p[e]);
+        }
+    }
+    for (int e = 0; e < 8 && c + e < N; ++e) atomicAdd(out + c + e, acc[e]);
+}
+
+// =========================================================================== GRU cell (PyTorch gate order r,z,n)
+// Restates nn.GRU's cell as used by RelationEncoder (/root/reference/generator/encoder.py:76-82,101-105):
+//   r = sig(xg_r + hg_r), z = sig(xg_z + hg_z), n = tanh(xg_n + r*hg_n), h' = (1-z)*n + z*h
+// xg = x W_ih^T + b_ih and hg = h W_hh^T + b_hh come from the MFMA GEMM.  Rows are the active prefix of the
+// length-sorted sequences.  Writes h' in place, the layer output y (optionally with inter-layer dropout),
+// the previous state (for dW_hh) and the gate activations (for backward).
+template <typename T>
+__global__ void gru_fwd_kernel(int rows, int hs, const T* __restrict__ xg, const T* __restrict__ hg, T* __restrict__ h,
+                               T* __restrict__ y, int64_t ldy, T* __restrict__ hprev_save, T* __restrict__ gates,
+                               float p_drop, uint64_t seed, int64_t drop_base) {
+    const int hv = hs / 8;
+    const float ks = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < (int64_t)rows * hv; t += (int64_t)gridDim.x * blockDim.x) {
+        const int row = (int)(t / hv), c = (int)(t % hv) * 8;
+        float xr[8], xz[8], xn[8], hr[8], hz[8], hn[8], hp[8], o[8], gr[8], gz[8], gn[8];
+        const T* xp = xg + (int64_t)row * 3 * hs + c;
+        const T* hp_ = hg + (int64_t)row * 3 * hs + c;
+        Vec8<T>::load(xp, xr); Vec8<T>::load(xp + hs, xz); Vec8<T>::load(xp + 2 * hs, xn);
+        Vec8<T>::load(hp_, hr); Vec8<T>::load(hp_ + hs, hz); Vec8<T>::load(hp_ + 2 * hs, hn);
+        Vec8<T>::load(h + (int64_t)row * hs + c, hp);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            gr[e] = 1.f / (1.f + __expf(-(xr[e] + hr[e])));
+            gz[e] = 1.f / (1.f + __expf(-(xz[e] + hz[e])));
+            gn[e] = tanhf(xn[e] + gr[e] * hn[e]);
+            o[e] = (1.f - gz[e]) * gn[e] + gz[e] * hp[e];
+        }
+        Vec8<T>::store(h + (int64_t)row * hs + c, o);
+        Vec8<T>::store(hprev_save + (int64_t)row * hs + c, hp);
+        T* gp = gates + (int64_t)row * 4 * hs + c;
+        Vec8<T>::store(gp, gr); Vec8<T>::store(gp + hs, gz); Vec8<T>::store(gp + 2 * hs, gn); Vec8<T>::store(gp + 3 * hs, hn);
+        if (y) {
+            if (p_drop > 0.f) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    o[e] = drop_keep(seed, (uint64_t)(drop_base + (int64_t)row * ldy + c + e), p_drop) ? o[e] * ks : 0.f;
+            }
+            Vec8<T>::store(y + (int64_t)row * ldy + c, o);
+        }
+    }
+}
+
+// backward of one step.  dh (in/out, [rows,hs]): on entry the gradient flowing back through time; the kernel adds
+// the gradient arriving through the layer output (dy, masked by the same dropout), writes d(xg) [rows,3hs],
+// d(hg) [rows,3hs] and leaves dh = dh_total * z (the direct path); the caller then adds d(hg) W_hh with the GEMM.
+template <typename T>
+__global__ void gru_bwd_kernel(int rows, int hs, const T* __restrict__ gates, const T* __restrict__ hprev,
+                               const T* __restrict__ dy, int64_t ldy, float* __restrict__ dh,
+                               T* __restrict__ dxg, T* __restrict__ dhg, float p_drop, uint64_t seed, int64_t drop_base) {
+    const int hv = hs / 8;
+    const float ks = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < (int64_t)rows * hv; t += (int64_t)gridDim.x * blockDim.x) {
+        const int row = (int)(t / hv), c = (int)(t % hv) * 8;
+        float gr[8], gz[8], gn[8], hn[8], hp[8], g[8], dyv[8];
+        const T* gp = gates + (int64_t)row * 4 * hs + c;
+        Vec8<T>::load(gp, gr); Vec8<T>::load(gp + hs, gz); Vec8<T>::load(gp + 2 * hs, gn); Vec8<T>::load(gp + 3 * hs, hn);
+        Vec8<T>::load(hprev + (int64_t)row * hs + c, hp);
+        Vec8<float>::load(dh + (int64_t)row * hs + c, g);
+        if (dy) {
+            Vec8<T>::load(dy + (int64_t)row * ldy + c, dyv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float t2 = dyv[e];
+                if (p_drop > 0.f) t2 = drop_keep(seed, (uint64_t)(drop_base + (int64_t)row * ldy + c + e), p_drop) ? t2 * ks : 0.f;
+                g[e] += t2;
+            }
+        }
+        float dr_[8], dz_[8], dn_[8], dhn[8], dhp[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float dn = g[e] * (1.f - gz[e]);
+            const float dz = g[e] * (hp[e] - gn[e]);
+            dhp[e] = g[e] * gz[e];
+            dn_[e] = dn * (1.f - gn[e] * gn[e]);
+            dhn[e] = dn_[e] * gr[e];
+            dr_[e] = dn_[e] * hn[e] * gr[e] * (1.f - gr[e]);
+            dz_[e] = dz * gz[e] * (1.f - gz[e]);
+        }
+        Vec8<float>::store(dh + (int64_t)row * hs + c, dhp);
+        T* xp = dxg + (int64_t)row * 3 * hs + c;
+        T* hp2 = dhg + (int64_t)row * 3 * hs + c;
+        Vec8<T>::store(xp, dr_); Vec8<T>::store(xp + hs, dz_); Vec8<T>::store(xp + 2 * hs, dn_);
+        Vec8<T>::store(hp2, dr_); Vec8<T>::store(hp2 + hs, dz_); Vec8<T>::store(hp2 + 2 * hs, dhn);
+    }
+}
+
+// =========================================================================== relation gather-mean (eval lookup)
+// out[p,:] = sum_k bank[idx[p,k]] (row 0 treated as zero) / max(1, #{k: idx[p,k] != 0})
+// (/root/reference/generator/generator.py:83-88).  K == 1 without the row-0 rule is the train lookup (:79).
+template <typename T>
+__global__ __launch_bounds__(256) void gather_mean_kernel(int64_t P, int K, int d, const T* __restrict__ bank,
+                                                          const int64_t* __restrict__ idx, int zero_row0, T* __restrict__ out) {
+    const int dv = d / 8;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < P * dv; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = t / dv; const int c = (int)(t % dv) * 8;
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int cnt = 0;
+        for (int k = 0; k < K; ++k) {
+            const int64_t id = idx[p * K + k];
+            if (zero_row0 && id == 0) continue;
+            ++cnt;
+            float v[8];
+            Vec8<T>::load(bank + id * d + c, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += v[e];
+        }
+        if (zero_row0) {
+            const float s = 1.f / (float)max(cnt, 1);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] *= s;
+        }
+        Vec8<T>::store(out + p * d + c, acc);
+    }
+}
+
+// =========================================================================== optimizer (flat buffers)
+// sum of squares of g (for clip_grad_norm_, /root/reference/generator/train.py:151)
+__global__ __launch_bounds__(256) void sqnorm_kernel(int64_t n, const float* __restrict__ g, float* __restrict__ out) {
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) s = fmaf(g[i], g[i], s);
+    s = wave_sum(s);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
+// AdamWeightDecayOptimizer.step (/root/reference/generator/adam.py:66-87): no bias correction, decoupled decay added
+// to the update before the lr multiply.  g is first scaled by gscale (1/world_size) and by the clip coefficient
+// min(1, max_norm / (gscale*sqrt(sqnorm) + 1e-6)) read from device memory (no host sync).
+__global__ void adam_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, float lr, float b1, float b2, float eps, float wd, float gscale,
+                            const float* __restrict__ sqnorm, float max_norm, bf16_t* __restrict__ mirror) {
+    float coef = gscale;
+    if (sqnorm) { const float nrm = gscale * sqrtf(*sqnorm); coef *= fminf(1.f, max_norm / (nrm + 1e-6f)); }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * coef;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        const float pi = p[i] - lr * (mi / (sqrtf(vi) + eps) + wd * p[i]);
+        m[i] = mi; v[i] = vi; p[i] = pi;
+        if (mirror) mirror[i] = f2bf(pi);
+    }
+}
+
+__global__ void cast_bf16_kernel(int64_t n, const float* __restrict__ src, bf16_t* __restrict__ dst) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = f2bf(src[i]);
+}
+
+inline int grid_for(int64_t work, int block) { int64_t g = (work + block - 1) / block; return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g)); }
+
+}  // namespace
+
+extern "C" int gtos_ln_residual_fwd(int dtype, int rows, int d, const void* x, const void* r, float p_drop, uint64_t seed,
+                                    const float* gamma, const float* beta, float eps, void* y, float* mean, float* rstd,
+                                    void* stream) {
+    if (d % 8 || d > 512 * LN_MAXC) return -20;
+    if (rows <= 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    dim3 grid((rows + 3) / 4), block(256);
+    if (dtype == GTOS_BF16)
+        hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, block, 0, s, rows, d, (const bf16_t*)x, (const bf16_t*)r, p_drop, seed, gamma, beta, eps, (bf16_t*)y, mean, rstd);
+    else
+        hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, block, 0, s, rows, d, (const float*)x, (const float*)r, p_drop, seed, gamma, beta, eps, (float*)y, mean, rstd);
+    GTOS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gtos_ln_residual_bwd(int dtype, int rows, int d, const void* dy, const void* x, const void* r, float p_drop,
+                                    uint64_t seed, const float* gamma, const float* mean, const float* rstd,
+                                    void* dx, void* dr, float* dgamma, float* dbeta, void* stream) {
+    if (d % 8 || d > 512 * LN_MAXC) return -20;
+    if (rows <= 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int nb = (rows + 3) / 4; if (nb > 1024) nb = 1024;
+    dim3 grid(nb), block(256);
+    if (dtype == GTOS_BF16)
+        hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, grid, block, 0, s, rows, d, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)r, p_drop, seed, gamma, mean, rstd, (bf16_t*)dx, (bf16_t*)dr, dgamma, dbeta);
+    else
+        hipLaunchKernelGGL(ln_bwd_kernel<float>, grid, block, 0, s, rows, d, (const float*)dy, (const float*)x, (const float*)r, p_drop, seed, gamma, mean, rstd, (float*)dx, (float*)dr, dgamma, dbeta);
+    GTOS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gtos_relu_dropout_bwd(int dtype, int64_t n, void* dh, const void* h, float p_drop, void* stream) {
+    if (n % 8) return -21;
+    if (n == 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const float ks = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    dim3 grid(grid_for(n / 8, 256)), block(256);
+    if (dtype == GTOS_BF16) hipLaunchKernelGGL(relu_drop_bwd_kernel<bf16_t>, grid, block, 0, s, n / 8, (bf16_t*)dh, (const bf16_t*)h, ks);
+    else hipLaunchKernelGGL(relu_drop_bwd_kernel<float>, grid, block, 0, s, n / 8, (float*)dh, (const float*)h, ks);
+    GTOS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gtos_colsum(int dtype, int rows, int N, int64_t ld, const void* dy, float* out, void* stream) {
+    if (rows <= 0 || N <= 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int gx = (N + 2047) / 2048;
+    int rpb = (rows + 511) / 512; if (rpb < 32) rpb = 32;
+    dim3 grid(gx, (rows + rpb - 1) / rpb), block(256);
+    if (dtype == GTOS_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, block, 0, s, rows, N, ld, (const bf16_t*)dy, out, rpb);
+    else hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, s, rows, N, ld, (const float*)dy, out, rpb);
+    GTOS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gtos_gru_cell_fwd(int dtype, int rows, int hs, const void* xg, const void* hg, void* h, void* y, int64_t ldy,
+                                 void* hprev_save, void* gates, float p_drop, uint64_t seed, int64_t drop_base, void* stream) {
+    if (hs % 8) return -22;
+    if (rows <= 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    dim3 grid(grid_for((int64_t)rows * hs / 8, 256)), block(256);
+    if (dtype == GTOS_BF16) hipLaunchKernelGGL(gru_fwd_kernel<bf16_t>, grid, block, 0, s, rows, hs, (const bf16_t*)xg, (const bf16_t*)hg, (bf16_t*)h, (bf16_t*)y, ldy, (bf16_t*)hprev_save, (bf16_t*)gates, p_drop, seed, drop_base);
+    else hipLaunchKernelGGL(gru_fwd_kernel<float>, grid, block, 0, s, rows, hs, (const float*)xg, (const float*)hg, (float*)h, (float*)y, ldy, (float*)hprev_save, (float*)gates, p_drop, seed, drop_base);
+    GTOS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gtos_gru_cell_bwd(int dtype, int rows, int hs, const void* gates, const void* hprev, const void* dy, int64_t ldy,
+                                 float* dh, void* dxg, void* dhg, float p_drop, uint64_t seed, int64_t drop_base, void* stream) {
+    if (hs % 8) return -22;
+    if (rows <= 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    dim3 grid(grid_for((int64_t)rows * hs / 8, 256)), block(256);
+    if (dtype == GTOS_BF16) hipLaunchKernelGGL(gru_bwd_kernel<bf16_t>, grid, block, 0, s, rows, hs, (const bf16_t*)gates, (const bf16_t*)hprev, (const bf16_t*)dy, ldy, dh, (bf16_t*)dxg, (bf16_t*)dhg, p_drop, seed, drop_base);
+    else hipLaunchKernelGGL(gru_bwd_kernel<float>, grid, block, 0, s, rows, hs, (const float*)gates, (const float*)hprev, (const float*)dy, ldy, dh, (float*)dxg, (float*)dhg, p_drop, seed, drop_base);
+    GTOS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gtos_relation_gather_mean(int dtype, int64_t P, int K, int d, const void* bank, const int64_t* idx, int zero_row0,
+                                         void* out, void* stream) {
+    if (d % 8) return -23;
+    if (P <= 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    dim3 grid(grid_for(P * (d / 8), 256)), block(256);
+    if (dtype == GTOS_BF16) hipLaunchKernelGGL(gather_mean_kernel<bf16_t>, grid, block, 0, s, P, K, d, (const bf16_t*)bank, idx, zero_row0, (bf16_t*)out);
+    else hipLaunchKernelGGL(gather_mean_kernel<float>, grid, block, 0, s, P, K, d, (const float*)bank, idx, zero_row0, (float*)out);
+    GTOS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gtos_sqnorm(int64_t n, const float* g, float* out, void* stream) {
+    if (n <= 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(sqnorm_kernel, dim3(grid_for(n, 256 * 8)), dim3(256), 0, s, n, g, out);
+    GTOS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gtos_adam_step(int64_t n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2,
+                              float eps, float weight_decay, float gscale, const float* sqnorm, float max_norm,
+                              void* bf16_mirror, void* stream) {
+    if (n <= 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256 * 4)), dim3(256), 0, s, n, p, g, m, v, lr, beta1, beta2, eps, weight_decay,
+                       gscale, sqnorm, max_norm, (bf16_t*)bf16_mirror);
+    GTOS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gtos_cast_f32_to_bf16(int64_t n, const float* src, void* dst, void* stream) {
+    if (n <= 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(n, 256 * 4)), dim3(256), 0, s, n, src, (bf16_t*)dst);
+    GTOS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gtos_abi_version(void) { return 1; }

@@ -1,0 +1,83 @@
+"""DecodeLayer / TokenGenerator (/root/reference/generator/decoder.py) on the gfx950 kernels.
+
+The decoder's self- and cross-attention, LayerNorms, FFN and vocabulary projections run on the HIP kernels;
+the copy/generate mixture (softmax over the vocabulary, scatter_add_, log, NLL gather) stays on PyTorch-ROCm
+device ops in fp32 -- adjacent to the hot path, not a roofline target.
+"""
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+from . import ops
+from .transformer import MultiheadAttention, Transformer
+
+
+def _padded_linear(x, lin):
+    """Linear whose input width is not a multiple of 8 (token_size 300 is; small test sizes may not be)."""
+    pad = (-x.shape[-1]) % 8
+    w = lin.weight
+    if pad:
+        x, w = F.pad(x, (0, pad)), F.pad(w, (0, pad))
+    return ops.linear(x, w, lin.bias)
+
+
+class TokenGenerator(nn.Module):
+    def __init__(self, vocabs, embed_dim, token_size, dropout):
+        super().__init__()
+        self.alignment_layer = MultiheadAttention(embed_dim, 1, dropout, weights_dropout=False)
+        self.alignment_layer_norm = nn.LayerNorm(embed_dim)
+        self.transfer = nn.Linear(embed_dim, token_size)
+        self.generator = nn.Linear(token_size, vocabs['predictable_token'].size)
+        self.diverter = nn.Linear(token_size, 2)
+        self.vocabs, self.dropout = vocabs, dropout
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for l in (self.transfer, self.diverter, self.generator):
+            nn.init.normal_(l.weight, std=0.02)
+            nn.init.constant_(l.bias, 0.)
+
+    def forward(self, outs, graph_state, graph_padding_mask, copy_seq, target=None, work=False):
+        p = self.dropout if self.training else 0.0
+        x, alignment_weight = self.alignment_layer(outs, graph_state, graph_state,
+                                                   key_padding_mask=graph_padding_mask, need_weights=True)
+        ln = self.alignment_layer_norm
+        outs = ops.layer_norm_residual(outs.to(x.dtype), x, ln.weight, ln.bias, p, ln.eps)
+        seq_len, bsz, _ = outs.size()
+        outs_token = torch.tanh(ops.linear(outs, self.transfer.weight, self.transfer.bias))
+        outs_token = F.dropout(outs_token, p=self.dropout, training=self.training)
+        gate = F.softmax(_padded_linear(outs_token, self.diverter).float(), -1)
+        gen_gate, copy_gate = gate.chunk(2, dim=-1)
+        probs = gen_gate * F.softmax(_padded_linear(outs_token, self.generator).float(), -1)
+        tot_ext = 1 + int(copy_seq.max().item())
+        vocab_size = probs.size(-1)
+        if tot_ext - vocab_size > 0:
+            probs = torch.cat([probs, probs.new_zeros((seq_len, bsz, tot_ext - vocab_size))], -1)
+        index = copy_seq.transpose(0, 1).contiguous().view(1, bsz, -1).expand(seq_len, -1, -1)
+        copy_probs = (copy_gate * alignment_weight.float()).view(seq_len, bsz, -1)
+        probs = probs.scatter_add(-1, index, copy_probs)
+        ll = torch.log(probs + 1e-12)
+        if work:
+            return ll
+        token_loss = -ll.gather(dim=-1, index=target.unsqueeze(-1)).squeeze(-1)
+        token_mask = torch.eq(target, self.vocabs['predictable_token'].padding_idx)
+        return token_loss.masked_fill(token_mask, 0.).sum(0)
+
+
+class DecodeLayer(nn.Module):
+    def __init__(self, vocabs, inference_layers, embed_dim, ff_embed_dim, num_heads, token_size, rel_size, dropout):
+        super().__init__()
+        self.inference_core = Transformer(inference_layers, embed_dim, ff_embed_dim, num_heads, dropout, with_external=True)
+        self.token_generator = TokenGenerator(vocabs, embed_dim, token_size, dropout)
+        self.dropout, self.vocabs = dropout, vocabs
+
+    def forward(self, probe, graph_state, snt_state, graph_padding_mask, snt_padding_mask, attn_mask,
+                copy_seq, target=None, work=False):
+        outs = F.dropout(probe, p=self.dropout, training=self.training)
+        outs = self.inference_core(outs, kv=snt_state, self_padding_mask=snt_padding_mask, self_attn_mask=attn_mask,
+                                   external_memories=graph_state, external_padding_mask=graph_padding_mask)
+        if work:
+            return self.token_generator(outs, graph_state, graph_padding_mask, copy_seq, work=True)
+        token_loss = self.token_generator(outs, graph_state, graph_padding_mask, copy_seq, target=target, work=False)
+        token_tot = snt_padding_mask.size(0) - snt_padding_mask.float().sum(0)
+        return (token_loss / token_tot).mean()

@@ -1,0 +1,151 @@
+"""RelationEncoder / TokenEncoder / CNNEncoder / Highway on the gfx950 kernels.
+
+Drop-in for /root/reference/generator/encoder.py (same signatures and state_dict keys, including nn.GRU's
+native parameter names ``rnn.weight_ih_l0`` ...).  The pretrained-embedding file loader is out of scope.
+"""
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+from . import ops
+from .gru import bigru_final
+from .transformer import Embedding
+
+
+def AMREmbedding(vocab, embedding_dim, pretrained_file=None, amr=False, dump_file=None):
+    if pretrained_file is not None:
+        raise NotImplementedError("pretrained embedding files are outside the hot path (encoder.py:13-64)")
+    return Embedding(vocab.size, embedding_dim, vocab.padding_idx)
+
+
+class RelationEncoder(nn.Module):
+    """Label paths -> relation vectors: embedding -> dropout -> 2-layer bi-GRU (final states) -> Linear
+    (encoder.py:66-119).  Sequences are sorted by length and packed (the reference does the same for cuDNN);
+    the GRU itself is gtos_amd.gru (MFMA GEMMs + fused cell kernel)."""
+
+    def __init__(self, vocab, rel_dim, embed_dim, hidden_size, num_layers, dropout, bidirectional=True):
+        super().__init__()
+        assert bidirectional, "only the bidirectional encoder is ever built (generator.py:29)"
+        self.vocab, self.embed_dim, self.hidden_size = vocab, embed_dim, hidden_size
+        self.num_layers, self.dropout, self.bidirectional = num_layers, dropout, bidirectional
+        self.rel_embed = AMREmbedding(vocab, rel_dim)
+        self.rnn = nn.GRU(input_size=rel_dim, hidden_size=hidden_size, num_layers=num_layers,
+                          dropout=self.dropout if num_layers > 1 else 0., bidirectional=True)   # parameter container
+        self.out_proj = nn.Linear(2 * hidden_size, embed_dim)      # keeps torch's default init (reset never called)
+        self.compute_dtype = torch.float32
+
+    def reset_parameters(self):
+        nn.init.normal_(self.out_proj.weight, std=0.02)
+        nn.init.constant_(self.out_proj.bias, 0.)
+
+    def _weights(self, pad):
+        ws = []
+        for l in range(self.num_layers):
+            for suf in ("", "_reverse"):
+                w_ih = getattr(self.rnn, "weight_ih_l%d%s" % (l, suf))
+                if l == 0 and pad:
+                    w_ih = F.pad(w_ih, (0, pad))
+                ws += [w_ih, getattr(self.rnn, "weight_hh_l%d%s" % (l, suf)),
+                       getattr(self.rnn, "bias_ih_l%d%s" % (l, suf)), getattr(self.rnn, "bias_hh_l%d%s" % (l, suf))]
+        return ws
+
+    def forward(self, src_tokens, src_lengths):
+        seq_len, bsz = src_tokens.size()
+        sorted_len, indices = torch.sort(src_lengths, descending=True, stable=True)
+        toks = src_tokens.index_select(1, indices)                                  # [L, R] sorted
+        # packed layout: step t holds the sequences with length > t (a prefix of the sorted order)
+        batch_sizes = (sorted_len.unsqueeze(0) > torch.arange(seq_len, device=src_tokens.device).unsqueeze(1)).sum(1).tolist()
+        while batch_sizes and batch_sizes[-1] == 0:
+            batch_sizes.pop()
+        packed = torch.cat([toks[t, :a] for t, a in enumerate(batch_sizes)])       # [N]
+        x = F.dropout(self.rel_embed(packed), p=self.dropout, training=self.training)
+        pad = (-x.shape[1]) % 8                                                    # 16-byte rows for the GEMM
+        if pad:
+            x = F.pad(x, (0, pad))
+        x = x.to(self.compute_dtype)
+        p = self.dropout if (self.training and self.num_layers > 1) else 0.0
+        fin = bigru_final(x, batch_sizes, self.hidden_size, self.num_layers, p, self._weights(pad))   # [R, 2h] sorted
+        positions = torch.sort(indices)[1]
+        fin = fin.index_select(0, positions)
+        return ops.linear(fin, self.out_proj.weight, self.out_proj.bias)
+
+
+class Highway(nn.Module):
+    def __init__(self, input_dim, layers):
+        super().__init__()
+        self.input_dim = input_dim
+        self.layers = nn.ModuleList([nn.Linear(input_dim, input_dim * 2) for _ in range(layers)])
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for layer in self.layers:
+            nn.init.normal_(layer.weight, std=0.02)
+            nn.init.constant_(layer.bias[self.input_dim:], 1)
+            nn.init.constant_(layer.bias[:self.input_dim], 0)
+
+    def forward(self, x):
+        for layer in self.layers:
+            new_x, gate = ops.linear(x, layer.weight, layer.bias).chunk(2, dim=-1)
+            gate = torch.sigmoid(gate)
+            x = gate * x + (1 - gate) * F.relu(new_x)
+        return x
+
+
+class CNNEncoder(nn.Module):
+    """char CNN: Conv1d(k) -> max over time -> ReLU -> highway -> Linear (encoder.py:151-178).  The convolution is
+    evaluated as unfold + MFMA GEMM on the Conv1d weights (no MIOpen)."""
+
+    def __init__(self, filters, input_dim, output_dim, highway_layers=1):
+        super().__init__()
+        self.convolutions = nn.ModuleList()
+        for width, out_c in filters:
+            self.convolutions.append(nn.Conv1d(input_dim, out_c, kernel_size=width))
+        final_dim = sum(f[1] for f in filters)
+        self.highway = Highway(final_dim, highway_layers)
+        self.out_proj = nn.Linear(final_dim, output_dim)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.normal_(self.out_proj.weight, std=0.02)
+        nn.init.constant_(self.out_proj.bias, 0.)
+
+    def forward(self, input):                     # [N, chars, dim]
+        N, L, C = input.shape
+        feats = []
+        for conv in self.convolutions:
+            k = conv.kernel_size[0]
+            win = input.unfold(1, k, 1)                                   # [N, L-k+1, C, k]
+            y = ops.linear(win.reshape(N * (L - k + 1), C * k), conv.weight.view(conv.out_channels, C * k), conv.bias)
+            feats.append(F.relu(y.view(N, L - k + 1, -1).max(1)[0]))
+        x = self.highway(torch.cat(feats, dim=-1))
+        return ops.linear(x, self.out_proj.weight, self.out_proj.bias)
+
+
+class TokenEncoder(nn.Module):
+    def __init__(self, token_vocab, char_vocab, char_dim, token_dim, embed_dim, filters, char2token_dim, dropout,
+                 pretrained_file=None):
+        super().__init__()
+        self.char_embed = AMREmbedding(char_vocab, char_dim)
+        self.token_embed = AMREmbedding(token_vocab, token_dim, pretrained_file)
+        self.char2token = CNNEncoder(filters, char_dim, char2token_dim)
+        self.out_proj = nn.Linear(char2token_dim + token_dim, embed_dim)
+        self.char_dim, self.token_dim, self.dropout = char_dim, token_dim, dropout
+        self.compute_dtype = torch.float32
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.normal_(self.out_proj.weight, std=0.02)
+        nn.init.constant_(self.out_proj.bias, 0.)
+
+    def forward(self, token_input, char_input):
+        seq_len, bsz, _ = char_input.size()
+        cd = self.compute_dtype
+        char_repr = self.char_embed(char_input.view(seq_len * bsz, -1)).to(cd)
+        char_repr = self.char2token(char_repr).view(seq_len, bsz, -1)
+        token_repr = self.token_embed(token_input).to(cd)
+        token = F.dropout(torch.cat([char_repr, token_repr], -1), p=self.dropout, training=self.training)
+        pad = (-token.shape[-1]) % 8
+        w = self.out_proj.weight
+        if pad:                                   # 428 = 128+300 is not a multiple of 8: keep GEMM rows 16-byte aligned
+            token, w = F.pad(token, (0, pad)), F.pad(w, (0, pad))
+        return ops.linear(token, w, self.out_proj.bias)

@@ -1,0 +1,102 @@
+"""Generator: the model assembly of /root/reference/generator/generator.py (encode_step / forward) wired to the
+HIP-backed modules.  Same constructor arguments and state_dict keys, so reference checkpoints load.
+
+Train-mode ``encode_step`` hands the graph encoder the relation in FACTORED form (bank + type ids): it is the
+exact same function as the reference's ``relation.index_select(0, idx).view(n,n,B,d)`` (generator.py:79) but the
+[n,n,B,d] tensor is never built.  Eval mode aggregates alternative shortest paths with the gather-mean kernel
+(generator.py:83-88).  Beam search (work/decode_step) is outside the hot path.
+"""
+import math
+
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+from . import ops
+from .encoder import TokenEncoder, RelationEncoder
+from .decoder import DecodeLayer
+from .transformer import Transformer, SinusoidalPositionalEmbedding, SelfAttentionMask
+from .graph_transformer import GraphTransformer, set_compute_dtype
+
+
+class Generator(nn.Module):
+    def __init__(self, vocabs, word_char_dim, word_dim, concept_char_dim, concept_dim, cnn_filters, char2word_dim,
+                 char2concept_dim, rel_dim, rnn_hidden_size, rnn_num_layers, embed_dim, ff_embed_dim, num_heads,
+                 dropout, snt_layers, graph_layers, inference_layers, pretrained_file, device, depth_size=32,
+                 factored_relation=True):
+        super().__init__()
+        self.vocabs = vocabs
+        self.concept_encoder = TokenEncoder(vocabs['concept'], vocabs['concept_char'], concept_char_dim, concept_dim,
+                                            embed_dim, cnn_filters, char2concept_dim, dropout, pretrained_file)
+        self.relation_encoder = RelationEncoder(vocabs['relation'], rel_dim, embed_dim, rnn_hidden_size,
+                                                rnn_num_layers, dropout)
+        self.token_encoder = TokenEncoder(vocabs['token'], vocabs['token_char'], word_char_dim, word_dim, embed_dim,
+                                          cnn_filters, char2word_dim, dropout, pretrained_file)
+        self.graph_encoder = GraphTransformer(graph_layers, embed_dim, ff_embed_dim, num_heads, dropout)
+        self.snt_encoder = Transformer(snt_layers, embed_dim, ff_embed_dim, num_heads, dropout, with_external=True)
+        self.embed_dim = embed_dim
+        self.embed_scale = math.sqrt(embed_dim)
+        self.token_position = SinusoidalPositionalEmbedding(embed_dim, device)
+        self.concept_depth = nn.Embedding(depth_size, embed_dim)     # 32 (generator) / 256 (translator/generator.py:39)
+        self.token_embed_layer_norm = nn.LayerNorm(embed_dim)
+        self.concept_embed_layer_norm = nn.LayerNorm(embed_dim)
+        self.self_attn_mask = SelfAttentionMask(device)
+        self.decoder = DecodeLayer(vocabs, inference_layers, embed_dim, ff_embed_dim, num_heads, concept_dim, rel_dim, dropout)
+        self.dropout = dropout
+        self.probe_generator = nn.Linear(embed_dim, embed_dim)
+        self.device = device
+        self.factored_relation = factored_relation
+        self.compute_dtype = torch.float32
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.normal_(self.probe_generator.weight, std=0.02)
+        nn.init.constant_(self.probe_generator.bias, 0.)
+        nn.init.constant_(self.concept_depth.weight, 0.)
+
+    def set_compute_dtype(self, dtype):
+        return set_compute_dtype(self, dtype)
+
+    def _concepts(self, inp):
+        c = self.embed_scale * self.concept_encoder(inp['concept'], inp['concept_char']) \
+            + self.concept_depth(inp['concept_depth']).to(self.compute_dtype)
+        ln = self.concept_embed_layer_norm
+        c = ops.layer_norm_residual(c, None, ln.weight, ln.bias, 0.0, ln.eps)
+        return c, torch.eq(inp['concept'], self.vocabs['concept'].padding_idx)
+
+    def encode_step(self, inp, train=True):
+        concept_repr, concept_mask = self._concepts(inp)
+        bank = self.relation_encoder(inp['relation_bank'], inp['relation_length'])           # [R, d]
+        if train:
+            if self.factored_relation:
+                relation = ops.FactoredRelation(bank, inp['relation'])
+            else:
+                relation = bank.index_select(0, inp['relation'].reshape(-1)).view(*inp['relation'].size(), -1)
+        else:
+            relation = ops.relation_gather_mean(bank.detach(), inp['relation'], zero_row0=True)
+        concept_repr = self.graph_encoder(concept_repr, relation, self_padding_mask=concept_mask)
+        probe = torch.tanh(ops.linear(concept_repr[:1], self.probe_generator.weight, self.probe_generator.bias))
+        return concept_repr[1:], concept_mask[1:], probe
+
+    def encoder_attn(self, inp):
+        with torch.no_grad():
+            concept_repr, concept_mask = self._concepts(inp)
+            bank = self.relation_encoder(inp['relation_bank'], inp['relation_length'])
+            relation = ops.relation_gather_mean(bank, inp['relation'], zero_row0=True)
+            return self.graph_encoder.get_attn_weights(concept_repr, relation, self_padding_mask=concept_mask)
+
+    def forward(self, data):
+        concept_repr, concept_mask, probe = self.encode_step(data)
+        pos = self.token_position(data['token_in']).to(self.compute_dtype)
+        token_repr = self.embed_scale * self.token_encoder(data['token_in'], data['token_char_in']) + pos
+        ln = self.token_embed_layer_norm
+        token_repr = ops.layer_norm_residual(token_repr, None, ln.weight, ln.bias, 0.0, ln.eps)
+        token_repr = F.dropout(token_repr, p=self.dropout, training=self.training)
+        token_mask = torch.eq(data['token_in'], self.vocabs['token'].padding_idx)
+        attn_mask = self.self_attn_mask(data['token_in'].size(0))
+        concept_repr = concept_repr.contiguous()
+        token_repr = self.snt_encoder(token_repr, self_padding_mask=token_mask, self_attn_mask=attn_mask,
+                                      external_memories=concept_repr, external_padding_mask=concept_mask)
+        probe = probe.expand_as(token_repr)
+        return self.decoder(probe, concept_repr, token_repr, concept_mask, token_mask, attn_mask,
+                            data['cp_seq'], target=data['token_out'])

@@ -1,0 +1,123 @@
+"""Bidirectional multi-layer GRU over packed, length-sorted relation label paths (final states only).
+
+MI355X counterpart of ``nn.utils.rnn.pack_padded_sequence`` + ``nn.GRU`` as RelationEncoder uses them
+(/root/reference/generator/encoder.py:93-111): the input-gate products of ALL steps are one MFMA GEMM, each
+time step is one [active,h]x[h,3h] GEMM plus the fused gate kernel (gtos_gru_cell_fwd), and the backward pass
+is explicit BPTT with one weight-gradient GEMM per direction over all steps at once.
+"""
+import torch
+
+from . import _lib
+from ._lib import call, dt, ptr, stream
+from .ops import gemm, compute_weight, next_seed, _grad_target, _splitk
+
+
+def _cell_fwd(A, hs, xg, hg, h, y, y_off_elems, ldy, hprev, gates, p, seed, drop_base):
+    yp = None if y is None else y.data_ptr() + y_off_elems * y.element_size()
+    call("gtos_gru_cell_fwd", dt(xg), A, hs, ptr(xg), ptr(hg), ptr(h), yp, ldy, ptr(hprev), ptr(gates),
+         float(p), seed, drop_base, stream())
+
+
+def _cell_bwd(A, hs, gates, hprev, dy, dy_off_elems, ldy, dh, dxg, dhg, p, seed, drop_base):
+    dyp = None if dy is None else dy.data_ptr() + dy_off_elems * dy.element_size()
+    call("gtos_gru_cell_bwd", dt(gates), A, hs, ptr(gates), ptr(hprev), dyp, ldy, ptr(dh), ptr(dxg), ptr(dhg),
+         float(p), seed, drop_base, stream())
+
+
+class BiGRUFinalFn(torch.autograd.Function):
+    """x [N,in] packed time-major rows (step t occupies rows offs[t]:offs[t]+batch_sizes[t], sequences sorted by
+    decreasing length); returns the top layer's [fwd final ; bwd final] state per sequence, [R, 2*hs]."""
+
+    @staticmethod
+    def forward(ctx, x, batch_sizes, hs, num_layers, p_drop, *weights):
+        # weights: per layer [w_ih, w_hh, b_ih, b_hh, w_ih_rev, w_hh_rev, b_ih_rev, b_hh_rev]
+        L, R = len(batch_sizes), batch_sizes[0]
+        offs = [0]
+        for a in batch_sizes:
+            offs.append(offs[-1] + a)
+        N = offs[-1]
+        assert x.shape[0] == N
+        dev, dtp = x.device, x.dtype
+        inp = x.contiguous()
+        saved = []
+        finals = None
+        for l in range(num_layers):
+            last = l == num_layers - 1
+            Y = None if last else torch.empty((N, 2 * hs), dtype=dtp, device=dev)
+            seed = next_seed() if (p_drop > 0 and not last) else 0
+            pl = p_drop if not last else 0.0
+            finals = []
+            layer_saved = []
+            for direction in (0, 1):
+                w_ih, w_hh, b_ih, b_hh = weights[l * 8 + direction * 4: l * 8 + direction * 4 + 4]
+                wi, wh = compute_weight(w_ih, dtp), compute_weight(w_hh, dtp)
+                xg = gemm(inp, wi, trans_b=True, bias=b_ih.detach())
+                h = torch.zeros((R, hs), dtype=dtp, device=dev)
+                hg = torch.empty((R, 3 * hs), dtype=dtp, device=dev)
+                gates = torch.empty((N, 4 * hs), dtype=dtp, device=dev)
+                hprev = torch.empty((N, hs), dtype=dtp, device=dev)
+                steps = range(L) if direction == 0 else range(L - 1, -1, -1)
+                for t in steps:
+                    A, off = batch_sizes[t], offs[t]
+                    gemm(h[:A], wh, trans_b=True, bias=b_hh.detach(), out=hg[:A])
+                    _cell_fwd(A, hs, xg[off:off + A], hg, h, Y, off * 2 * hs + direction * hs, 2 * hs,
+                              hprev[off:off + A], gates[off:off + A], pl, seed, off * 2 * hs + direction * hs)
+                finals.append(h)
+                layer_saved.append((wi, wh, gates, hprev))
+            saved.append((inp, seed, pl, layer_saved))
+            inp = Y
+        ctx.cfg = (batch_sizes, offs, hs, num_layers, weights, saved)
+        return torch.cat(finals, 1)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        batch_sizes, offs, hs, num_layers, weights, saved = ctx.cfg
+        L, R, N = len(batch_sizes), batch_sizes[0], offs[-1]
+        d_out = d_out.contiguous()
+        dev = d_out.device
+        grads = [None] * len(weights)
+        dY = None                                   # gradient w.r.t. this layer's (dropped) output [N, 2hs]
+        for l in range(num_layers - 1, -1, -1):
+            inp, seed, pl, layer_saved = saved[l]
+            dtp = inp.dtype
+            d_inp = None
+            for direction in (0, 1):
+                wi, wh, gates, hprev = layer_saved[direction]
+                base = l * 8 + direction * 4
+                w_ih, w_hh, b_ih, b_hh = weights[base:base + 4]
+                if l == num_layers - 1:
+                    dh = d_out[:, direction * hs:(direction + 1) * hs].float().contiguous()
+                else:
+                    dh = torch.zeros((R, hs), dtype=torch.float32, device=dev)
+                dxg = torch.empty((N, 3 * hs), dtype=dtp, device=dev)
+                dhg = torch.empty((N, 3 * hs), dtype=dtp, device=dev)
+                steps = range(L - 1, -1, -1) if direction == 0 else range(L)
+                for t in steps:
+                    A, off = batch_sizes[t], offs[t]
+                    _cell_bwd(A, hs, gates[off:off + A], hprev[off:off + A], dY, off * 2 * hs + direction * hs, 2 * hs,
+                              dh, dxg[off:off + A], dhg[off:off + A], pl, seed, off * 2 * hs + direction * hs)
+                    gemm(dhg[off:off + A], wh, out=dh[:A], accumulate=True)          # dh += d(hg) W_hh
+                # parameter gradients over all steps at once
+                for (wt, dyv, xin, slot) in ((w_hh, dhg, hprev, 1), (w_ih, dxg, inp, 0)):
+                    if wt.requires_grad:
+                        tgt = _grad_target(wt)
+                        if tgt is None:
+                            tgt = grads[base + slot] = torch.zeros(wt.shape, dtype=torch.float32, device=dev)
+                        gemm(dyv, xin, trans_a=True, out=tgt, accumulate=True, splitk=_splitk(wt.shape[0], wt.shape[1], N))
+                for (bt, dyv, slot) in ((b_hh, dhg, 3), (b_ih, dxg, 2)):
+                    if bt.requires_grad:
+                        tgt = _grad_target(bt)
+                        if tgt is None:
+                            tgt = grads[base + slot] = torch.zeros(bt.shape, dtype=torch.float32, device=dev)
+                        call("gtos_colsum", dt(dyv), N, 3 * hs, 3 * hs, ptr(dyv), ptr(tgt), stream())
+                if l > 0 or ctx.needs_input_grad[0]:
+                    if d_inp is None:
+                        d_inp = gemm(dxg, wi)
+                    else:
+                        gemm(dxg, wi, out=d_inp, accumulate=True)
+            dY = d_inp
+        return (dY if ctx.needs_input_grad[0] else None, None, None, None, None) + tuple(grads)
+
+
+def bigru_final(x_packed, batch_sizes, hs, num_layers, p_drop, weights):
+    return BiGRUFinalFn.apply(x_packed, tuple(batch_sizes), hs, num_layers, float(p_drop), *weights)

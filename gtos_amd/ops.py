@@ -1,0 +1,338 @@
+"""Autograd glue between PyTorch tensors and the C-ABI HIP kernels (include/gtos_hip.h).
+
+Each ``torch.autograd.Function`` here is the MI355X counterpart of one ATen op sequence of the reference
+(cited per function).  Tensors provide device memory; kernels are enqueued on torch's current HIP stream.
+"""
+import torch
+
+from . import _lib
+from ._lib import call, dt, ptr, require_cuda, stream
+
+_seed_state = [0x5DEECE66D]
+
+# Optional kernel timing with HIP events on the launch stream (bench.py's roofline leg): name -> [(start, end)]
+PROFILE = None
+
+
+class _Timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+
+    def __exit__(self, *a):
+        if PROFILE is not None:
+            self.e.record()
+            PROFILE.setdefault(self.name, []).append((self.s, self.e))
+
+
+def next_seed():
+    """Dropout seeds: a host-side counter (replayed identically on every rank with the same start)."""
+    _seed_state[0] = (_seed_state[0] * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+    return _seed_state[0]
+
+
+def set_seed(s):
+    _seed_state[0] = s & 0xFFFFFFFFFFFFFFFF
+
+
+def _row_major(t):
+    """2-D view usable by the GEMM: unit inner stride; returns (tensor, leading dimension)."""
+    if t.dim() != 2:
+        raise _lib.GtosHipError("gemm operands must be 2-D")
+    if t.stride(1) != 1 and t.shape[1] != 1:
+        t = t.contiguous()
+    ld = t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
+    return t, ld
+
+
+def _splitk(M, N, K):
+    blocks = ((M + 127) // 128) * ((N + 127) // 128)
+    if blocks >= 512 or K < 1024:
+        return 1
+    return max(1, min(1024 // blocks, K // 512, 64))
+
+
+def gemm(a, b, trans_a=False, trans_b=False, out=None, bias=None, relu=False, p_drop=0.0, seed=0,
+         accumulate=False, out_dtype=None, splitk=1):
+    """out[M,N] (+)= act(op(a) @ op(b) + bias).  a,b share a dtype (fp32 or bf16)."""
+    require_cuda(a, b, out, bias)
+    a, lda = _row_major(a)
+    b, ldb = _row_major(b)
+    M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
+    N = b.shape[0] if trans_b else b.shape[1]
+    kb = b.shape[1] if trans_b else b.shape[0]
+    if kb != K or a.dtype != b.dtype:
+        raise _lib.GtosHipError("gemm shape/dtype mismatch: %s %s ta=%s tb=%s" % (tuple(a.shape), tuple(b.shape), trans_a, trans_b))
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype or a.dtype, device=a.device)
+        accumulate = False
+    if splitk > 1 and not accumulate:
+        out.zero_()
+        accumulate = True
+    ldc = out.stride(0) if M > 1 else max(N, out.stride(0))
+    if bias is not None and bias.dtype != torch.float32:
+        bias = bias.float()
+    call("gtos_gemm", dt(a), dt(out), int(trans_a), int(trans_b), M, N, K, ptr(a), lda, ptr(b), ldb, ptr(out), ldc,
+         ptr(bias), int(relu), float(p_drop), seed, int(accumulate), splitk, stream())
+    return out
+
+
+def compute_weight(w, dtype):
+    """Parameter in the compute dtype: fp32 master itself, or its bf16 mirror (kept fresh by the fused Adam
+    kernel when the parameters live in a FlatParams buffer; otherwise cast on the fly)."""
+    if w.dtype == dtype:
+        return w
+    mirror = getattr(w, "_gtos_mirror", None)
+    if mirror is not None and mirror.dtype == dtype:
+        return mirror
+    return w.detach().to(dtype)
+
+
+def _grad_target(p):
+    """Pre-allocated .grad (a view of the flat gradient bucket) to accumulate into, or None."""
+    if not p.is_leaf:
+        return None
+    g = p.grad
+    if g is not None and g.dtype == torch.float32 and g.is_contiguous():
+        return g
+    return None
+
+
+class LinearFn(torch.autograd.Function):
+    """y = dropout(relu(x W^T + b)) -- F.linear (+relu +dropout) of the reference's projections and FFN
+    (generator/graph_transformer.py:61-63,106-122,166).  Weight/bias gradients are accumulated straight into the
+    flat fp32 gradient bucket when one is attached (no per-parameter temporaries)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu, p_drop, rows):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        w = compute_weight(weight, x2.dtype)
+        b = bias.detach() if bias is not None else None
+        if rows is not None:           # a row block of a packed projection (in_proj_weight[r0:r1])
+            w = w[rows[0]:rows[1]]
+            b = b[rows[0]:rows[1]] if b is not None else None
+        seed = next_seed() if p_drop > 0 else 0
+        y = gemm(x2, w, trans_b=True, bias=b, relu=relu, p_drop=p_drop, seed=seed)
+        ctx.save_for_backward(x2, w, y if (relu or p_drop > 0) else None)
+        ctx.cfg = (relu, p_drop, shp, weight, bias, rows)
+        return y.view(*shp[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, y = ctx.saved_tensors
+        relu, p_drop, shp, weight, bias, rows = ctx.cfg
+        dy2 = dy.reshape(-1, w.shape[0])
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        if y is not None:
+            if relu:
+                dy2 = dy2.clone()
+                call("gtos_relu_dropout_bwd", dt(dy2), dy2.numel(), ptr(dy2), ptr(y), float(p_drop), stream())
+            else:
+                raise _lib.GtosHipError("dropout without relu is not fused in LinearFn")
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = gemm(dy2, w).view(shp)
+        if ctx.needs_input_grad[1]:
+            tgt = _grad_target(weight)
+            M, N, K = w.shape[0], w.shape[1], dy2.shape[0]
+            sk = _splitk(M, N, K)
+            if tgt is None:
+                tgt = dw = torch.zeros(weight.shape, dtype=torch.float32, device=dy2.device)
+            if rows is not None:
+                tgt = tgt[rows[0]:rows[1]]
+            gemm(dy2, x2, trans_a=True, out=tgt, accumulate=True, splitk=sk)
+        if bias is not None and ctx.needs_input_grad[2]:
+            tgt = _grad_target(bias)
+            if tgt is None:
+                tgt = db = torch.zeros(bias.shape, dtype=torch.float32, device=dy2.device)
+            if rows is not None:
+                tgt = tgt[rows[0]:rows[1]]
+            call("gtos_colsum", dt(dy2), dy2.shape[0], dy2.shape[1], dy2.stride(0), ptr(dy2), ptr(tgt), stream())
+        return dx, dw, db, None, None, None
+
+
+def linear(x, weight, bias=None, relu=False, p_drop=0.0, rows=None):
+    return LinearFn.apply(x, weight, bias, relu, float(p_drop), rows)
+
+
+class LayerNormResidualFn(torch.autograd.Function):
+    """y = LayerNorm(x + dropout(r)) (generator/graph_transformer.py:57-58,64-65)."""
+
+    @staticmethod
+    def forward(ctx, x, r, gamma, beta, p_drop, eps):
+        d = x.shape[-1]
+        x = x.contiguous()
+        r = r.contiguous() if r is not None else None
+        rows = x.numel() // d
+        y = torch.empty_like(x)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        seed = next_seed() if (p_drop > 0 and r is not None) else 0
+        call("gtos_ln_residual_fwd", dt(x), rows, d, ptr(x), ptr(r), float(p_drop), seed, ptr(gamma), ptr(beta),
+             float(eps), ptr(y), ptr(mean), ptr(rstd), stream())
+        ctx.save_for_backward(x, r, mean, rstd)
+        ctx.cfg = (p_drop, seed, gamma, beta)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, r, mean, rstd = ctx.saved_tensors
+        p_drop, seed, gamma, beta = ctx.cfg
+        d = x.shape[-1]
+        rows = x.numel() // d
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        need_dr = r is not None and ctx.needs_input_grad[1]
+        dr = torch.empty_like(x) if (need_dr and p_drop > 0) else None
+        tg, tb = _grad_target(gamma), _grad_target(beta)
+        dg = tg if tg is not None else torch.zeros(d, dtype=torch.float32, device=x.device)
+        db = tb if tb is not None else torch.zeros(d, dtype=torch.float32, device=x.device)
+        call("gtos_ln_residual_bwd", dt(x), rows, d, ptr(dy), ptr(x), ptr(r), float(p_drop), seed, ptr(gamma),
+             ptr(mean), ptr(rstd), ptr(dx), ptr(dr), ptr(dg), ptr(db), stream())
+        if need_dr and dr is None:
+            dr = dx
+        return dx, dr, (None if tg is not None else dg), (None if tb is not None else db), None, None
+
+
+def layer_norm_residual(x, r, gamma, beta, p_drop=0.0, eps=1e-5):
+    return LayerNormResidualFn.apply(x, r, gamma, beta, float(p_drop), eps)
+
+
+def _u8(mask):
+    if mask is None:
+        return None
+    return mask.to(torch.uint8).contiguous()
+
+
+class FactoredRelation:
+    """The relation operand in factored form: ``bank`` [R,d] (relation-encoder output, one row per distinct
+    label path) + ``relation`` [n,n,B] int64 type ids exactly as the reference batches carry them
+    (generator/data.py:164-176).  Equivalent to the dense ``bank.index_select(0, relation.view(-1)).view(n,n,B,d)``
+    of generator/generator.py:79, which is never materialised.  Index preparation happens once per batch."""
+
+    CHUNK = 32
+
+    def __init__(self, bank, relation):
+        require_cuda(bank, relation)
+        self.bank = bank
+        n, n2, B = relation.shape
+        assert n == n2
+        self.n, self.B = n, B
+        rel = relation.contiguous()
+        self.idx_q = rel.permute(1, 2, 0).contiguous().to(torch.int32)    # [i,b,j] = relation[j,i,b]
+        self.idx_k = rel.permute(0, 2, 1).contiguous().to(torch.int32)    # [j,b,i]
+        flat = rel.reshape(-1)
+        R = bank.shape[0]
+        order = torch.sort(flat, stable=True)[1]
+        counts = torch.bincount(flat, minlength=R)
+        starts = torch.cumsum(counts, 0) - counts
+        nch = (counts + self.CHUNK - 1) // self.CHUNK
+        ctype = torch.repeat_interleave(torch.arange(R, device=flat.device), nch)
+        first = torch.cumsum(nch, 0) - nch
+        local = torch.arange(ctype.numel(), device=flat.device) - first[ctype]
+        heavy_types = torch.nonzero(nch > 1).flatten()
+        slot_of_type = torch.full((R,), -1, dtype=torch.int64, device=flat.device)
+        slot_of_type[heavy_types] = torch.arange(heavy_types.numel(), device=flat.device)
+        self.pair_sorted = order.to(torch.int32)
+        self.chunk_type = ctype.to(torch.int32)
+        self.chunk_start = (starts[ctype] + local * self.CHUNK).to(torch.int32)
+        self.chunk_count = torch.clamp(counts[ctype] - local * self.CHUNK, max=self.CHUNK).to(torch.int32)
+        self.chunk_slot = slot_of_type[ctype].to(torch.int32)
+        self.heavy_types = heavy_types
+        self.nchunks = int(ctype.numel())
+
+
+class RelAttnFn(torch.autograd.Function):
+    """Fused (relation-aware) attention core.  qsrc [T,B,Cq] holds q at channel offset q_off; kvsrc [S,B,Ckv]
+    (or qsrc itself when None) holds k, v at k_off, v_off.  rel: None | rarb [S,T,B,2d] | bank-projection [R,2d].
+    Returns (o [T,B,d], w [T,S,B,H] or None)."""
+
+    @staticmethod
+    def forward(ctx, qsrc, kvsrc, rel, fact, offs, d, H, scale, key_pad, attn_mask, p_drop, need_w):
+        require_cuda(qsrc, kvsrc, rel)
+        q_off, k_off, v_off = offs
+        kv = qsrc if kvsrc is None else kvsrc
+        assert qsrc.is_contiguous() and kv.is_contiguous()
+        T_, B, Cq = qsrc.shape
+        S, _, Ckv = kv.shape
+        mode = 0 if rel is None else (2 if fact is not None else 1)
+        if mode == 1:
+            assert rel.is_contiguous() and tuple(rel.shape) == (S, T_, B, 2 * d)
+        o = torch.empty((T_, B, d), dtype=qsrc.dtype, device=qsrc.device)
+        lse = torch.empty((T_, B, H), dtype=torch.float32, device=qsrc.device)
+        w = torch.empty((T_, S, B, H), dtype=torch.float32, device=qsrc.device) if need_w else None
+        seed = next_seed() if p_drop > 0 else 0
+        es = qsrc.element_size()
+        with _Timed("rel_attn_fwd_mode%d" % mode):
+            call("gtos_rel_attn_fwd", dt(qsrc), mode, T_, S, B, H, d,
+                 qsrc.data_ptr() + q_off * es, Cq, kv.data_ptr() + k_off * es, Ckv, kv.data_ptr() + v_off * es, Ckv,
+                 ptr(rel), ptr(fact.idx_q) if fact is not None else None, ptr(key_pad), ptr(attn_mask),
+                 float(scale), float(p_drop), seed, ptr(o), d, ptr(lse), ptr(w), stream())
+        ctx.save_for_backward(qsrc, kvsrc, rel, o, lse, w, key_pad, attn_mask)
+        ctx.cfg = (fact, offs, d, H, scale, p_drop, seed, mode)
+        return o, w
+
+    @staticmethod
+    def backward(ctx, d_o, d_w):
+        qsrc, kvsrc, rel, o, lse, w, key_pad, attn_mask = ctx.saved_tensors
+        fact, (q_off, k_off, v_off), d, H, scale, p_drop, seed, mode = ctx.cfg
+        kv = qsrc if kvsrc is None else kvsrc
+        T_, B, Cq = qsrc.shape
+        S, _, Ckv = kv.shape
+        d_o = d_o.contiguous()
+        if d_w is not None:
+            d_w = d_w.contiguous().float()
+        # every channel of qsrc/kvsrc that is not q/k/v (none in practice) must come back zero
+        full_q = (Cq == d) if kvsrc is not None else (Cq == 3 * d)
+        dqsrc = (torch.empty_like if full_q else torch.zeros_like)(qsrc)
+        dkv = dqsrc if kvsrc is None else (torch.empty_like if Ckv == 2 * d else torch.zeros_like)(kvsrc)
+        d_rel = torch.empty_like(rel) if mode == 1 else None
+        pd = torch.empty((T_, S, B, H), dtype=torch.float32, device=qsrc.device)
+        gs = torch.empty_like(pd)
+        es = qsrc.element_size()
+        call("gtos_rel_attn_bwd", dt(qsrc), mode, T_, S, B, H, d,
+             qsrc.data_ptr() + q_off * es, Cq, kv.data_ptr() + k_off * es, Ckv, kv.data_ptr() + v_off * es, Ckv,
+             ptr(rel), ptr(fact.idx_q) if fact is not None else None, ptr(fact.idx_k) if fact is not None else None,
+             ptr(key_pad), ptr(attn_mask), float(scale), float(p_drop), seed,
+             ptr(o), d, ptr(lse), ptr(w), ptr(d_o), d, ptr(d_w),
+             dqsrc.data_ptr() + q_off * es, Cq, dkv.data_ptr() + k_off * es, Ckv, dkv.data_ptr() + v_off * es, Ckv,
+             ptr(d_rel), ptr(pd), ptr(gs), stream())
+        if mode == 2:
+            d_rel = torch.empty_like(rel)
+            nh = int(fact.heavy_types.numel())
+            heavy = torch.zeros((max(nh, 1), 2 * d), dtype=torch.float32, device=rel.device)
+            call("gtos_rel_attn_bwd_bank", dt(qsrc), T_, B, H, d,
+                 qsrc.data_ptr() + q_off * es, Cq, kv.data_ptr() + k_off * es, Ckv,
+                 ptr(rel), ptr(gs), ptr(fact.pair_sorted), ptr(fact.chunk_type), ptr(fact.chunk_start),
+                 ptr(fact.chunk_count), ptr(fact.chunk_slot), fact.nchunks, ptr(d_rel), ptr(heavy), stream())
+            if nh:
+                d_rel[fact.heavy_types] = heavy[:nh].to(d_rel.dtype)
+        return dqsrc, (dkv if kvsrc is not None else None), d_rel, None, None, None, None, None, None, None, None, None
+
+
+def attention_core(qsrc, kvsrc, offs, d, H, scale, rel=None, fact=None, key_pad=None, attn_mask=None,
+                   p_drop=0.0, need_weights=False):
+    return RelAttnFn.apply(qsrc, kvsrc, rel, fact, offs, d, H, scale, _u8(key_pad), _u8(attn_mask),
+                           float(p_drop), need_weights)
+
+
+def relation_gather_mean(bank, idx, zero_row0):
+    """Dense relation tensor from the bank: train lookup (idx [n,n,B], generator/generator.py:79) or the eval
+    mean over alternative shortest paths (idx [n,n,B,K], zero_row0=True, generator/generator.py:83-88).
+    Forward only (the train path with gradients uses FactoredRelation)."""
+    require_cuda(bank, idx)
+    K = idx.shape[-1] if zero_row0 else 1
+    lead = idx.shape[:-1] if zero_row0 else idx.shape
+    P = idx.numel() // K
+    bank = bank.contiguous()
+    out = torch.empty((P, bank.shape[1]), dtype=bank.dtype, device=bank.device)
+    call("gtos_relation_gather_mean", dt(bank), P, K, bank.shape[1], ptr(bank), ptr(idx.contiguous()), int(zero_row0),
+         ptr(out), stream())
+    return out.view(*lead, bank.shape[1])

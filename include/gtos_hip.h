@@ -1,0 +1,129 @@
+/* gtos_hip.h -- C ABI of libgtos_hip.so, the MI355X (gfx950) kernels behind the gtos graph-transformer hot path.
+ *
+ * The reference (jcyk/gtos) has no FFI: its hot path is plain PyTorch, every "kernel" being whatever ATen
+ * dispatches for an op sequence.  The entry points below are therefore what a binding for THIS path would
+ * bind: one entry per reference op sequence, taking raw device pointers, sizes, leading dimensions and a
+ * hipStream_t (as void*).  No torch types cross this boundary.  Each declaration cites the reference lines
+ * it replaces (paths relative to the reference repository root).  INTEGRATION.md shows the ctypes stubs.
+ *
+ * Conventions
+ *   dtype       GTOS_F32 (0) or GTOS_BF16 (1): storage type of activations; accumulation is always fp32.
+ *   layouts     time-major [T,B,C] activations like the reference; a "row" is one (t,b) pair and rows are
+ *               addressed as base + (t*B+b)*ld, so q/k/v may be views into one packed [T,B,3d] projection.
+ *   stream      the HIP stream to enqueue on (the caller's current stream); nothing here synchronises.
+ *   return      0 on success; >0 a hipError_t from the launch; <0 an argument error (shape the kernels do
+ *               not support).  Nothing falls back to a CPU path.
+ */
+#ifndef GTOS_HIP_H
+#define GTOS_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GTOS_F32 0
+#define GTOS_BF16 1
+
+int gtos_abi_version(void);
+
+/* C[M,N] (+)= act(opA(A)[M,K] . opB(B)[K,N] + bias[N]), row-major, MFMA (bf16: 16x16x32, fp32: 16x16x4).
+ * Supported (transA,transB): (0,1) Linear forward Y = X W^T; (0,0) dX = dY W; (1,0) dW = dY^T X.
+ * relu / p_drop>0 fuse ReLU and dropout(seed) into the epilogue; accumulate adds into C; splitk>1 splits K
+ * over grid.z with fp32 atomic accumulation (needs out_dtype F32, accumulate=1, no bias/relu/dropout).
+ * Replaces F.linear / nn.Linear and their autograd mm's: generator/graph_transformer.py:61-63 (fc1, relu,
+ * dropout, fc2), :106-122 (in_proj, relation_in_proj), :166 (out_proj), :176-197; generator/transformer.py:66-69,
+ * :109-119,:162,:175-196; generator/encoder.py:117 and the nn.GRU gate products (:76-82). */
+int gtos_gemm(int in_dtype, int out_dtype, int transA, int transB, int M, int N, int K,
+              const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+              const float* bias, int relu, float p_drop, uint64_t seed, int accumulate, int splitk, void* stream);
+
+/* Fused relation-aware attention forward: scores, both masks, softmax over keys, weight dropout, P.V.
+ *   mode 0: no relation (MultiheadAttention, generator/transformer.py:120-162; q is NOT pre-scaled: scale is
+ *           applied to the dot product, which equals the reference's q *= scaling);
+ *   mode 1: rel = rarb[S,T,B,2d] = relation_in_proj(relation) (generator/graph_transformer.py:122-133, note the
+ *           [key j][query i] order created by the transposes at :123-124);
+ *   mode 2: rel = bank[R,2d] = relation_in_proj(relation_encoder output), idx_q[T,B,S] int32 type ids
+ *           (idx_q[i,b,j] = relation[j,i,b]); fuses the index_select of generator/generator.py:79.
+ * key_pad[S,B] / attn_mask[T,S] are uint8 (non-zero = masked, generator/graph_transformer.py:136-149).
+ * Outputs o[T,B,d] (ldo), lse[T,B,H]; w (optional, [T,S,B,H] fp32) receives the post-dropout weights that
+ * the reference returns with need_weights (generator/graph_transformer.py:168-172).
+ * Requires d, d/H powers of two, d/H >= 8, d <= 512; modes 1,2 need T == S. */
+int gtos_rel_attn_fwd(int dtype, int mode, int T, int S, int B, int H, int d,
+                      const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                      const void* rel, const int* idx_q, const uint8_t* key_pad, const uint8_t* attn_mask,
+                      float scale, float p_drop, uint64_t seed,
+                      void* o, int64_t ldo, float* lse, float* w, void* stream);
+
+/* Backward of the above (two launches: query-major then key-major).  Recomputes the probabilities from lse.
+ * dw (optional) is an upstream gradient on the returned weights w (TokenGenerator's copy attention,
+ * generator/decoder.py:32-34,55); then w must be the forward's output.  Mode 1 writes d_rel = d(rarb) [S,T,B,2d];
+ * mode 2 leaves the bank gradient to gtos_rel_attn_bwd_bank.  pd/gs are caller-provided fp32 scratch [T,S,B,H]
+ * (post-dropout probabilities, scale*dS). */
+int gtos_rel_attn_bwd(int dtype, int mode, int T, int S, int B, int H, int d,
+                      const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                      const void* rel, const int* idx_q, const int* idx_k,
+                      const uint8_t* key_pad, const uint8_t* attn_mask,
+                      float scale, float p_drop, uint64_t seed,
+                      const void* o, int64_t ldo, const float* lse, const float* w,
+                      const void* d_o, int64_t lddo, const float* dw,
+                      void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv,
+                      void* d_rel, float* pd, float* gs, void* stream);
+
+/* Mode-2 bank gradient: d_bank[R,2d] (dtype) = scatter-add over pairs of [gs*(k_j + RB[t]) | gs*(q_i + RA[t])],
+ * i.e. the backward of generator/generator.py:79's index_select composed with the relation term of
+ * graph_transformer.py:126-127.  Pairs (id = (j*n+i)*B+b) arrive sorted by type and cut into chunks; a type that
+ * fits one chunk (chunk_slot = -1) stores its row directly, a type spanning several chunks accumulates with fp32
+ * atomics into heavy[chunk_slot] ([n_heavy,2d], zeroed by the caller, who folds it back into d_bank). */
+int gtos_rel_attn_bwd_bank(int dtype, int n, int B, int H, int d,
+                           const void* q, int64_t ldq, const void* k, int64_t ldk,
+                           const void* bank, const float* gs,
+                           const int* pair_sorted, const int* chunk_type, const int* chunk_start,
+                           const int* chunk_count, const int* chunk_slot, int nchunks,
+                           void* d_bank, float* heavy, void* stream);
+
+/* y = LayerNorm(x + dropout(r)) * gamma + beta (r may be NULL), saving mean/rstd per row.
+ * Replaces F.dropout + nn.LayerNorm(residual + x): generator/graph_transformer.py:57-58,64-65;
+ * generator/transformer.py:57-58,63-64,70-71; generator/decoder.py:35-36; generator/generator.py:73,172. */
+int gtos_ln_residual_fwd(int dtype, int rows, int d, const void* x, const void* r, float p_drop, uint64_t seed,
+                         const float* gamma, const float* beta, float eps, void* y, float* mean, float* rstd, void* stream);
+/* dx (residual branch), dr (dropout branch; pass NULL to skip), dgamma/dbeta accumulated with fp32 atomics. */
+int gtos_ln_residual_bwd(int dtype, int rows, int d, const void* dy, const void* x, const void* r, float p_drop,
+                         uint64_t seed, const float* gamma, const float* mean, const float* rstd,
+                         void* dx, void* dr, float* dgamma, float* dbeta, void* stream);
+
+/* In place dh *= (h > 0)/(1-p): backward of relu + dropout (generator/graph_transformer.py:61-62) given the saved output. */
+int gtos_relu_dropout_bwd(int dtype, int64_t n, void* dh, const void* h, float p_drop, void* stream);
+
+/* out[N] += column sums of dy[rows,N] (bias gradients of every Linear above). */
+int gtos_colsum(int dtype, int rows, int N, int64_t ld, const void* dy, float* out, void* stream);
+
+/* One GRU step over the active (length-sorted) prefix of the relation sequences; gate order r,z,n as in
+ * torch.nn.GRU, which RelationEncoder wraps (generator/encoder.py:76-82,101-105).  xg = x W_ih^T + b_ih and
+ * hg = h W_hh^T + b_hh come from gtos_gemm.  Updates h in place, writes the layer output y (with the
+ * inter-layer dropout of nn.GRU(dropout=...) when p_drop>0), saves h_prev and the gates [rows,4*hs]. */
+int gtos_gru_cell_fwd(int dtype, int rows, int hs, const void* xg, const void* hg, void* h, void* y, int64_t ldy,
+                      void* hprev_save, void* gates, float p_drop, uint64_t seed, int64_t drop_base, void* stream);
+/* Backward of one step: dh (fp32, in/out) carries the state gradient; writes d(xg), d(hg) [rows,3*hs]. */
+int gtos_gru_cell_bwd(int dtype, int rows, int hs, const void* gates, const void* hprev, const void* dy, int64_t ldy,
+                      float* dh, void* dxg, void* dhg, float p_drop, uint64_t seed, int64_t drop_base, void* stream);
+
+/* Relation lookup/aggregation: out[P,d] = mean over the K path ids of bank rows, row 0 zeroed, divisor
+ * clamp(#non-zero ids, 1) (generator/generator.py:83-88, :60-65); zero_row0=0,K=1 is the train lookup (:79). */
+int gtos_relation_gather_mean(int dtype, int64_t P, int K, int d, const void* bank, const int64_t* idx, int zero_row0,
+                              void* out, void* stream);
+
+/* Flat-buffer optimizer: sum of squares (clip_grad_norm_, generator/train.py:151) and the Adam variant of
+ * generator/adam.py:66-87 (no bias correction, decoupled weight decay), with the gradient averaging of
+ * generator/train.py:74-79 (gscale = 1/world_size) and the clip coefficient folded in; optionally refreshes a
+ * bf16 mirror of the parameters. */
+int gtos_sqnorm(int64_t n, const float* g, float* out, void* stream);
+int gtos_adam_step(int64_t n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, float gscale, const float* sqnorm, float max_norm,
+                   void* bf16_mirror, void* stream);
+int gtos_cast_f32_to_bf16(int64_t n, const float* src, void* dst, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

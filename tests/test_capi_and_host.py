@@ -1,0 +1,156 @@
+"""CPU-side checks: the C-ABI library builds/loads and exports every symbol include/gtos_hip.h declares (no compute
+calls without a GPU), the ctypes binding mirrors the header, the product refuses to run off-GPU, and the host logic
+(synthetic batches, lr schedule, flat buckets) behaves."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "gtos_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\bint\s+(gtos_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+        args = [a.strip() for a in m.group(2).replace("\n", " ").split(",")]
+        out[m.group(1)] = [] if args == ["void"] else args
+    return out
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    from gtos_amd import build
+    return build.build(verbose=False)
+
+
+def test_library_exports_every_declared_symbol(lib_path):
+    funcs = header_functions()
+    assert len(funcs) >= 15
+    lib = ctypes.CDLL(lib_path)
+    for name in funcs:
+        assert hasattr(lib, name), "libgtos_hip.so does not export %s" % name
+    lib.gtos_abi_version.restype = ctypes.c_int
+    assert lib.gtos_abi_version() == 1
+
+
+def test_ctypes_binding_mirrors_header(lib_path):
+    from gtos_amd import _lib
+    funcs = header_functions()
+    assert set(funcs) == set(_lib.SIGNATURES), set(funcs) ^ set(_lib.SIGNATURES)
+
+    def kind(arg):
+        if "*" in arg:
+            return ctypes.c_void_p
+        base = arg.split()[-2] if len(arg.split()) > 1 else arg
+        return {"int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float, "uint64_t": ctypes.c_uint64}[base]
+    for name, args in funcs.items():
+        want = [kind(a) for a in args]
+        assert want == _lib.SIGNATURES[name], name
+    _lib.load()
+
+
+def test_product_refuses_cpu_tensors(lib_path):
+    from gtos_amd import ops, _lib
+    with pytest.raises(_lib.GtosHipError):
+        ops.gemm(torch.randn(4, 4), torch.randn(4, 4))
+    from gtos_amd.graph_transformer import GraphTransformer
+    m = GraphTransformer(1, 16, 32, 2, 0.0)
+    with pytest.raises(_lib.GtosHipError):
+        m(torch.randn(3, 2, 16), torch.randn(3, 3, 2, 16))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "gtos_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            assert "oracle" not in open(os.path.join(pkg, fn)).read(), fn
+
+
+def test_state_dict_keys_match_reference_layout():
+    from gtos_amd.graph_transformer import GraphTransformer
+    from conftest import load_golden, sub
+    g = load_golden("gt_pad")
+    L, d, ff, H, n, B = [int(v) for v in g["cfg"]]
+    m = GraphTransformer(L, d, ff, H, 0.0)
+    sd = sub(g, "sd/")
+    assert set(m.state_dict()) == set(sd)
+    m.load_state_dict(sd)
+    assert m.layers[0].self_attn.in_proj_weight.shape == (3 * d, d)
+    assert m.layers[0].self_attn.relation_in_proj.weight.shape == (2 * d, d)
+
+
+def test_generator_loads_reference_checkpoint_layout():
+    from gtos_amd.generator import Generator
+    from oracle.gtos_oracle import VocabSpec
+    from conftest import load_golden, sub
+    from tests_support import SMALL_VOCAB, SMALL_GEN_ARGS
+    g = load_golden("gen_small")
+    d, ff, H, gl = [int(v) for v in g["cfg"]]
+    vocabs = {k: VocabSpec(v, 0) for k, v in SMALL_VOCAB.items()}
+    m = Generator(vocabs, *SMALL_GEN_ARGS, d, ff, H, 0.0, 1, gl, 2, None, torch.device("cpu"))
+    missing, unexpected = m.load_state_dict(sub(g, "sd/"), strict=True)
+    assert not missing and not unexpected
+
+
+# ---------------------------------------------------------------------------------------------- synthetic batches
+def test_synth_batch_layout_and_determinism():
+    from gtos_amd import synth
+    b1, s1 = synth.make_config_batch("C1")
+    b2, s2 = synth.make_config_batch("C1")
+    assert s1 == s2 and all(torch.equal(b1[k], b2[k]) for k in b1)
+    n, B = s1["n"], s1["B"]
+    assert (n, B) == (21, 8)
+    rel = b1["relation"]
+    assert rel.shape == (n, n, B) and rel.dtype == torch.int64
+    # <CLS> conventions of generator/data.py:138-147
+    assert int(rel[0, 0, 0]) == 2 and bool((rel[1:, 0, :] == 0).all()) and bool((rel[0, 1:, :] == 1).all())
+    bank, blen = b1["relation_bank"], b1["relation_length"]
+    R = s1["R"]
+    assert bank.shape[1] == R and blen.shape == (R,) and int(rel.max()) == R - 1
+    assert int(blen.max()) <= 8 and int(blen.min()) >= 1
+    assert bank[:, 0].tolist()[:1] == [synth.REL_CLS] and int(bank[0, 1]) == synth.REL_RCLS and int(bank[0, 2]) == synth.REL_SELF
+    for r in range(0, R, max(1, R // 50)):              # padding past the length is 0
+        assert bool((bank[int(blen[r]):, r] == 0).all()) and bool((bank[:int(blen[r]), r] != 0).all())
+    assert bool((torch.diagonal(rel[1:, 1:, 0]) == 2).all())      # self paths
+    assert b1["concept"].shape == (n, B) and bool((b1["concept"][0] == synth.CONCEPT_CLS).all())
+    assert int(b1["concept_depth"].max()) < 32
+    assert b1["token_in"].shape == b1["token_out"].shape and bool((b1["token_in"][0] == synth.TOK_STR).all())
+    assert b1["cp_seq"].shape == (n - 1, B)
+    # distinct ranks draw distinct graphs
+    b3, _ = synth.make_config_batch("C1", rank=1)
+    assert not torch.equal(b1["concept"], b3["concept"])
+
+
+def test_synth_padded_and_eval_batches():
+    from gtos_amd import synth
+    b, s = synth.make_batch(77, 5, 12, 9, padded=True)
+    lens = (b["concept"] != 0).sum(0)
+    assert int(lens.min()) < int(lens.max()) == s["n"]
+    for g in range(5):
+        L = int(lens[g])
+        assert bool((b["relation"][L:, :, g] == 0).all()) and bool((b["relation"][:, L:, g] == 0).all())
+    e, _ = synth.make_batch(77, 5, 12, 9, train=False, extra_frac=1.0)
+    assert e["relation"].dim() == 4 and int(e["relation"][0, 0, 0, 0]) == 3
+    assert bool((e["relation_bank"][:, 0] == 0).all())             # type 0 = <PAD> in eval batches
+
+
+def test_splitmix_reference_values():
+    from gtos_amd.synth import SplitMix64
+    # first outputs of splitmix64 seeded with 1234567 (published reference sequence)
+    r = SplitMix64(1234567)
+    got = [int(v) for v in r.u64(3)]
+    assert got == [6457827717110365317, 3203168211198807973, 9817491932198370423]
+
+
+def test_lr_schedule_and_decay_rule():
+    from gtos_amd.flat import inverse_sqrt_lr, is_no_decay
+    assert abs(inverse_sqrt_lr(512, 1, 2000) - 512 ** -0.5 * 2000 ** -1.5) < 1e-15
+    assert abs(inverse_sqrt_lr(512, 2000, 2000) - 512 ** -0.5 * 2000 ** -0.5) < 1e-15
+    assert inverse_sqrt_lr(512, 8000, 2000) < inverse_sqrt_lr(512, 2000, 2000)
+    assert is_no_decay("graph_encoder.layers.0.fc1.bias") and is_no_decay("token_embed_layer_norm.weight")
+    assert not is_no_decay("graph_encoder.layers.0.self_attn.in_proj_weight")

@@ -1,0 +1,355 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the golden vectors generated from the reference
+and against the pinned CPU oracle on the same seeded inputs.  Tolerances: 1e-3 fp32, 1e-2 bf16 (BASELINE.json)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, sub, T, opt_mask
+from tests_support import SMALL_VOCAB, SMALL_GEN_ARGS
+
+pytestmark = pytest.mark.gpu
+
+FP32 = dict(rtol=1e-3, atol=1e-3)
+GRAD = dict(rtol=2e-3, atol=1e-3)
+
+
+def dev():
+    assert torch.cuda.is_available(), "gpu-marked tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def to_dev(d):
+    return {k: v.to(dev()) for k, v in d.items()}
+
+
+def cmp_param_grads(module, g, tol=GRAD):
+    want = sub(g, "grad/")
+    got = {k: p.grad for k, p in module.named_parameters() if p.grad is not None}
+    assert set(want) == set(got)
+    for k in want:
+        torch.testing.assert_close(got[k].cpu().float(), want[k], msg=lambda m, k=k: "%s: %s" % (k, m), **tol)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, False)])
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (5, 7, 3), (130, 260, 100), (257, 129, 512), (64, 48, 1030)])
+def test_gemm(dtype, ta, tb, M, N, K):
+    from gtos_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn((K, M) if ta else (M, K), generator=g)
+    b = torch.randn((N, K) if tb else (K, N), generator=g)
+    bias = torch.randn(N, generator=g)
+    a_d, b_d = a.to(dev(), dtype), b.to(dev(), dtype)
+    ref = (a_d.float().t() if ta else a_d.float()) @ (b_d.float().t() if tb else b_d.float())
+    tol = dict(rtol=1e-4, atol=1e-3) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2 * math.sqrt(K))
+    out = ops.gemm(a_d, b_d, trans_a=ta, trans_b=tb)
+    torch.testing.assert_close(out.float(), ref, **tol)
+    out = ops.gemm(a_d, b_d, trans_a=ta, trans_b=tb, bias=bias.to(dev()), relu=True)
+    torch.testing.assert_close(out.float(), torch.relu(ref + bias.to(dev())), **tol)
+    acc = torch.ones((M, N), device=dev(), dtype=torch.float32)
+    ops.gemm(a_d, b_d, trans_a=ta, trans_b=tb, out=acc, accumulate=True, splitk=4)
+    torch.testing.assert_close(acc, ref + 1, **tol)
+
+
+def test_gemm_strided_views_and_dropout():
+    from gtos_amd import ops
+    x = torch.randn(50, 96, device=dev())
+    w = torch.randn(64, 32, device=dev())
+    out = ops.gemm(x[:, 32:64], w, trans_b=True)          # lda = 96
+    torch.testing.assert_close(out, x[:, 32:64] @ w.t(), rtol=1e-4, atol=1e-3)
+    big = torch.randn(512, 256, device=dev())
+    wb = torch.randn(256, 256, device=dev())
+    y0 = ops.gemm(big, wb, trans_b=True)
+    y1 = ops.gemm(big, wb, trans_b=True, p_drop=0.25, seed=123)
+    y2 = ops.gemm(big, wb, trans_b=True, p_drop=0.25, seed=123)
+    assert torch.equal(y1, y2)
+    kept = y1 != 0
+    assert abs(kept.float().mean().item() - 0.75) < 0.01
+    torch.testing.assert_close(y1[kept], (y0 / 0.75)[kept], rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ graph encoder
+def run_graph_transformer(g, dtype, factored_from=None):
+    from gtos_amd.graph_transformer import GraphTransformer, set_compute_dtype
+    L, d, ff, H, n, B = [int(v) for v in g["cfg"]]
+    m = GraphTransformer(L, d, ff, H, 0.0).to(dev())
+    m.load_state_dict(sub(g, "sd/"))
+    set_compute_dtype(m, dtype)
+    x = T(g["x"]).to(dev()).requires_grad_()
+    rel = T(g["relation"]).to(dev()).requires_grad_()
+    pad, am = opt_mask(g["pad"]), opt_mask(g["attn_mask"])
+    pad = pad.to(dev()) if pad is not None else None
+    am = am.to(dev()) if am is not None else None
+    out = m(x, rel, self_padding_mask=pad, self_attn_mask=am)
+    with torch.no_grad():
+        attn = m.get_attn_weights(x, rel, self_padding_mask=pad, self_attn_mask=am)
+    (out.float() * T(g["wout"]).to(dev())).sum().backward()
+    return m, out, attn, x.grad, rel.grad
+
+
+@pytest.mark.parametrize("name", ["gt_tiny", "gt_pad", "gt_mask", "gt_hd64", "gt_h8"])
+def test_graph_transformer_fp32_vs_golden(name):
+    g = load_golden(name)
+    m, out, attn, dx, drel = run_graph_transformer(g, torch.float32)
+    torch.testing.assert_close(out.cpu(), T(g["out"]), **FP32)
+    torch.testing.assert_close(attn.cpu(), T(g["attn"]), **FP32)
+    torch.testing.assert_close(dx.cpu(), T(g["dx"]), **GRAD)
+    torch.testing.assert_close(drel.cpu(), T(g["drelation"]), **GRAD)
+    cmp_param_grads(m, g)
+
+
+@pytest.mark.parametrize("name", ["gt_pad", "gt_hd64", "gt_h8"])
+def test_graph_transformer_bf16_vs_golden(name):
+    g = load_golden(name)
+    m, out, attn, dx, drel = run_graph_transformer(g, torch.bfloat16)
+    # post-LN outputs are O(1): 1e-2 absolute is the BASELINE.json bf16 bar (plus bf16 rounding of the output itself)
+    torch.testing.assert_close(out.float().cpu(), T(g["out"]), rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(attn.cpu(), T(g["attn"]), rtol=2e-2, atol=1e-2)
+    rel_err = (dx.float().cpu() - T(g["dx"])).norm() / T(g["dx"]).norm()
+    assert rel_err < 3e-2, rel_err
+
+
+def make_factored_case(seed, n, B, d, R):
+    g = torch.Generator().manual_seed(seed)
+    bank = 0.5 * torch.randn(R, d, generator=g)
+    idx = torch.randint(0, R, (n, n, B), generator=g)
+    idx[:, :, 0] = torch.randint(0, 3, (n, n), generator=g)      # a few very frequent types -> multi-chunk path
+    x = torch.randn(n, B, d, generator=g)
+    pad = torch.zeros(n, B, dtype=torch.bool)
+    pad[n - 2:, B - 1] = True
+    return bank, idx, x, pad
+
+
+@pytest.mark.parametrize("n,B,d,H,R", [(9, 3, 32, 4, 40), (40, 4, 128, 2, 700), (33, 8, 512, 8, 3000)])
+def test_factored_relation_matches_oracle(n, B, d, H, R):
+    """FactoredRelation(bank, idx) must equal the reference's dense index_select path, forward and backward."""
+    from gtos_amd.graph_transformer import GraphTransformer
+    from gtos_amd.ops import FactoredRelation
+    from oracle import gtos_oracle as O
+    bank, idx, x, pad = make_factored_case(n * 100 + d, n, B, d, R)
+    torch.manual_seed(5)
+    ref = O.GraphTransformer(2, d, 2 * d, H, 0.0)
+    for p in ref.parameters():
+        if p.dim() == 1:
+            p.data.add_(0.1 * torch.randn_like(p))
+    m = GraphTransformer(2, d, 2 * d, H, 0.0).to(dev())
+    m.load_state_dict(ref.state_dict())
+    wout = torch.randn(n, B, d)
+    bank_r = bank.clone().requires_grad_()
+    x_r = x.clone().requires_grad_()
+    out_r = ref(x_r, O.relation_lookup_train(bank_r, idx), self_padding_mask=pad)
+    (out_r * wout).sum().backward()
+    bank_d = bank.to(dev()).requires_grad_()
+    x_d = x.to(dev()).requires_grad_()
+    out_d = m(x_d, FactoredRelation(bank_d, idx.to(dev())), self_padding_mask=pad.to(dev()))
+    (out_d * wout.to(dev())).sum().backward()
+    torch.testing.assert_close(out_d.cpu(), out_r, **FP32)
+    torch.testing.assert_close(x_d.grad.cpu(), x_r.grad, **GRAD)
+    torch.testing.assert_close(bank_d.grad.cpu(), bank_r.grad, **GRAD)
+    for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        torch.testing.assert_close(p.grad.cpu(), q.grad, msg=lambda s, k=k: "%s: %s" % (k, s), **GRAD)
+
+
+def test_relation_gather_mean_eval_lookup():
+    from gtos_amd import ops
+    from oracle import gtos_oracle as O
+    g = torch.Generator().manual_seed(3)
+    bank = torch.randn(50, 64, generator=g)
+    idx = torch.randint(0, 50, (7, 7, 3, 4), generator=g)
+    idx[..., 2:] = torch.where(torch.rand(7, 7, 3, 2, generator=g) < 0.5, 0, idx[..., 2:])
+    idx[0, 0, 0] = 0
+    got = ops.relation_gather_mean(bank.to(dev()), idx.to(dev()), zero_row0=True)
+    torch.testing.assert_close(got.cpu(), O.relation_lookup_eval(bank, idx), rtol=1e-5, atol=1e-6)
+    got = ops.relation_gather_mean(bank.to(dev()), idx[..., 0].contiguous().to(dev()), zero_row0=False)
+    torch.testing.assert_close(got.cpu(), O.relation_lookup_train(bank, idx[..., 0]), rtol=0, atol=0)
+
+
+# ------------------------------------------------------------------------------------------------ relation encoder
+@pytest.mark.parametrize("name", ["relenc_small", "relenc_wide"])
+def test_relation_encoder_vs_golden(name):
+    from gtos_amd.encoder import RelationEncoder
+    from oracle.gtos_oracle import VocabSpec
+    g = load_golden(name)
+    V, rel_dim, d, hid, R, Lmax = [int(v) for v in g["cfg"]]
+    m = RelationEncoder(VocabSpec(V, 0), rel_dim, d, hid, 2, 0.0).to(dev())
+    m.load_state_dict(sub(g, "sd/"))
+    out = m(T(g["tokens"]).to(dev()), T(g["lengths"]).to(dev()))
+    torch.testing.assert_close(out.cpu(), T(g["out"]), **FP32)
+    (out * T(g["wout"]).to(dev())).sum().backward()
+    cmp_param_grads(m, g)
+
+
+# ------------------------------------------------------------------------------------------------ decoder blocks
+@pytest.mark.parametrize("name", ["tl_self", "tl_kv"])
+def test_transformer_layer_vs_golden(name):
+    from gtos_amd.transformer import TransformerLayer
+    g = load_golden(name)
+    d, ff, H, Tq, S, B, with_kv = [int(v) for v in g["cfg"]]
+    m = TransformerLayer(d, ff, H, 0.0, with_external=True).to(dev())
+    m.load_state_dict(sub(g, "sd/"))
+    x = T(g["x"]).to(dev()).requires_grad_()
+    ext = T(g["ext"]).to(dev()).requires_grad_()
+    kv = T(g["kv"]).to(dev()).requires_grad_() if with_kv else None
+    out, sw, ew = m(x, kv, T(g["self_pad"]).to(dev()), T(g["attn_mask"]).to(dev()), ext, T(g["ext_pad"]).to(dev()),
+                    need_weights=True)
+    torch.testing.assert_close(out.cpu(), T(g["out"]), **FP32)
+    torch.testing.assert_close(sw.cpu(), T(g["self_w"]), **FP32)
+    torch.testing.assert_close(ew.cpu(), T(g["ext_w"]), **FP32)
+    (out * T(g["wout"]).to(dev())).sum().backward()
+    torch.testing.assert_close(x.grad.cpu(), T(g["dx"]), **GRAD)
+    torch.testing.assert_close(ext.grad.cpu(), T(g["dext"]), **GRAD)
+    if with_kv:
+        torch.testing.assert_close(kv.grad.cpu(), T(g["dkv"]), **GRAD)
+    cmp_param_grads(m, g)
+
+
+# ------------------------------------------------------------------------------------------------ whole model
+def build_generator(g, factored):
+    from gtos_amd.generator import Generator
+    from oracle.gtos_oracle import VocabSpec
+    d, ff, H, gl = [int(v) for v in g["cfg"]]
+    vocabs = {k: VocabSpec(v, 0) for k, v in SMALL_VOCAB.items()}
+    m = Generator(vocabs, *SMALL_GEN_ARGS, d, ff, H, 0.0, 1, gl, 2, None, dev(), factored_relation=factored).to(dev())
+    m.load_state_dict(sub(g, "sd/"))
+    return m
+
+
+@pytest.mark.parametrize("name", ["gen_small", "gen_padded"])
+@pytest.mark.parametrize("factored", [True, False])
+def test_generator_vs_golden(name, factored):
+    g = load_golden(name)
+    m = build_generator(g, factored)
+    batch, ebatch = to_dev(sub(g, "batch/")), to_dev(sub(g, "ebatch/"))
+    m.train()
+    graph, gmask, probe = m.encode_step(batch)
+    torch.testing.assert_close(graph.cpu(), T(g["graph"]), **FP32)
+    torch.testing.assert_close(probe.cpu(), T(g["probe"]), **FP32)
+    assert torch.equal(gmask.cpu(), T(g["gmask"]))
+    loss = m(batch)
+    torch.testing.assert_close(loss.cpu(), T(g["loss"]), **FP32)
+    loss.backward()
+    cmp_param_grads(m, g)
+    m.eval()
+    with torch.no_grad():
+        egraph, _, eprobe = m.encode_step(ebatch, train=False)
+        eattn = m.encoder_attn(ebatch)
+    torch.testing.assert_close(egraph.cpu(), T(g["egraph"]), **FP32)
+    torch.testing.assert_close(eprobe.cpu(), T(g["eprobe"]), **FP32)
+    torch.testing.assert_close(eattn.cpu(), T(g["eattn"]), **FP32)
+
+
+def test_generator_bf16_loss_close():
+    g = load_golden("gen_small")
+    m = build_generator(g, True)
+    m.set_compute_dtype(torch.bfloat16)
+    m.train()
+    loss = m(to_dev(sub(g, "batch/")))
+    assert abs(loss.item() - float(g["loss"])) < 1e-2 * max(1.0, abs(float(g["loss"])))
+    loss.backward()
+    want = sub(g, "grad/")
+    for k, p in m.named_parameters():
+        if p.grad is not None and want[k].norm() > 1e-3:
+            rel = (p.grad.cpu().float() - want[k]).norm() / want[k].norm()
+            assert rel < 0.1, (k, rel)
+
+
+# ------------------------------------------------------------------------------------------------ optimizer
+def test_flat_adam_vs_golden():
+    from gtos_amd.flat import FlatParams, inverse_sqrt_lr
+    g = load_golden("adam_steps")
+    warmup, d = [int(v) for v in g["cfg"]]
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.weight = torch.nn.Parameter(T(g["p0_init"]).clone())
+            self.bias = torch.nn.Parameter(T(g["p1_init"]).clone())
+    m = M().to(dev())
+    flat = FlatParams(m)
+    for step in range(1, 4):
+        m.weight.grad.copy_(T(g["g0_%d" % step]))
+        m.bias.grad.copy_(T(g["g1_%d" % step]))
+        norm = flat.grad_norm()
+        torch.testing.assert_close(norm.cpu().squeeze(), T(g["norm_%d" % step]), rtol=1e-5, atol=1e-6)
+        lr = inverse_sqrt_lr(d, step, warmup)
+        assert abs(lr - float(g["lrs"][step - 1])) < 1e-12
+        flat.step(lr, gscale=1.0, max_norm=1.0)
+        flat.zero_grad()
+        torch.testing.assert_close(m.weight.detach().cpu(), T(g["p0_%d" % step]), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(m.bias.detach().cpu(), T(g["p1_%d" % step]), rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ dropout behaviour
+def test_attention_dropout_statistics_and_determinism():
+    from gtos_amd import ops
+    n, B, d, H = 64, 8, 512, 8
+    qkv = torch.randn(n, B, 3 * d, device=dev())
+    ops.set_seed(77)
+    o1, w1 = ops.attention_core(qkv, None, (0, d, 2 * d), d, H, 0.125, p_drop=0.2, need_weights=True)
+    ops.set_seed(77)
+    o2, w2 = ops.attention_core(qkv, None, (0, d, 2 * d), d, H, 0.125, p_drop=0.2, need_weights=True)
+    assert torch.equal(o1, o2) and torch.equal(w1, w2)
+    o0, w0 = ops.attention_core(qkv, None, (0, d, 2 * d), d, H, 0.125, p_drop=0.0, need_weights=True)
+    torch.testing.assert_close(w0.sum(1), torch.ones_like(w0.sum(1)), rtol=1e-4, atol=1e-4)
+    kept = w1 > 0
+    assert abs(kept.float().mean().item() - 0.8) < 0.01
+    torch.testing.assert_close(w1[kept], (w0 / 0.8)[kept], rtol=1e-4, atol=1e-6)
+    # o must be the dropped weights applied to v
+    v = qkv[:, :, 2 * d:].reshape(n, B, H, d // H)
+    torch.testing.assert_close(o1.view(n, B, H, d // H), torch.einsum("ijbh,jbhe->ibhe", w1, v), rtol=1e-3, atol=1e-3)
+
+
+def test_training_mode_dropout_backward_consistent():
+    """With dropout on, the analytic backward must match finite differences of the same (seeded) forward."""
+    from gtos_amd.graph_transformer import GraphTransformerLayer
+    from gtos_amd import ops
+    torch.manual_seed(0)
+    n, B, d = 6, 2, 32
+    m = GraphTransformerLayer(d, 64, 4, 0.3).to(dev()).double().float()
+    m.train()
+    x = torch.randn(n, B, d, device=dev())
+    rel = 0.5 * torch.randn(n, n, B, d, device=dev())
+    wout = torch.randn(n, B, d, device=dev())
+
+    def f(xx):
+        ops.set_seed(1234)
+        return (m(xx, rel)[0] * wout).sum()
+    xg = x.clone().requires_grad_()
+    f(xg).backward()
+    eps = 1e-2
+    for _ in range(5):
+        dirn = torch.randn_like(x)
+        dirn /= dirn.norm()
+        num = (f(x + eps * dirn) - f(x - eps * dirn)).item() / (2 * eps)
+        ana = (xg.grad * dirn).sum().item()
+        assert abs(num - ana) < 5e-2 * max(1.0, abs(ana)), (num, ana)
+
+
+# ------------------------------------------------------------------------------------------------ full-size properties
+def test_full_size_properties_c2_shape():
+    """BASELINE config-2 shape (n=101, B=64, d=512, H=8), bf16: softmax rows sum to one, padded keys get zero
+    weight, output is linear in V, factored == dense on identical inputs."""
+    from gtos_amd import ops
+    n, B, d, H = 101, 64, 512, 8
+    g = torch.Generator().manual_seed(11)
+    R = 5000
+    qkv = torch.randn(n, B, 3 * d, generator=g).to(dev(), torch.bfloat16)
+    bankp = (0.3 * torch.randn(R, 2 * d, generator=g)).to(dev(), torch.bfloat16)
+    idx = torch.randint(0, R, (n, n, B), generator=g).to(dev())
+    pad = torch.zeros(n, B, dtype=torch.bool)
+    pad[90:, ::3] = True
+    pad = pad.to(dev())
+    fact = ops.FactoredRelation(torch.zeros(R, d, device=dev()), idx)
+    o_f, w_f = ops.attention_core(qkv, None, (0, d, 2 * d), d, H, 0.125, rel=bankp, fact=fact, key_pad=pad, need_weights=True)
+    dense = bankp[idx.reshape(-1)].view(n, n, B, 2 * d)
+    o_d, w_d = ops.attention_core(qkv, None, (0, d, 2 * d), d, H, 0.125, rel=dense, key_pad=pad, need_weights=True)
+    assert torch.equal(o_f, o_d) and torch.equal(w_f, w_d)
+    torch.testing.assert_close(w_f.sum(1), torch.ones_like(w_f.sum(1)), rtol=1e-3, atol=1e-3)
+    assert float(w_f[:, 90:, ::3].abs().max()) == 0.0
+    qkv2 = qkv.clone()
+    qkv2[:, :, 2 * d:] *= 2
+    o2, _ = ops.attention_core(qkv2, None, (0, d, 2 * d), d, H, 0.125, rel=bankp, fact=fact, key_pad=pad)
+    torch.testing.assert_close(o2.float(), 2 * o_f.float(), rtol=2e-2, atol=2e-2)
