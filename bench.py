@@ -24,6 +24,24 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0
+T_START = time.time()
+
+
+def log(*a):
+    if os.environ.get("GTOS_BENCH_VERBOSE"):
+        print("[bench %7.1fs]" % (time.time() - T_START), *a, file=sys.stderr, flush=True)
+
+
+def host_cores():
+    """CPU threads this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
 
 
 def parse():
@@ -45,8 +63,9 @@ def cpu_baseline(cfg_name, graphs):
     from gtos_amd import synth
     from gtos_amd.config import generator_args
     from gtos_amd.flat import inverse_sqrt_lr
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
+    log("cpu_baseline: cores", cores, "os.cpu_count", os.cpu_count())
     cfg = synth.CONFIGS[cfg_name]
     vocabs = {k: O.VocabSpec(v, 0) for k, v in synth.DEFAULT_VOCAB.items()}
     torch.manual_seed(19940117)
@@ -71,10 +90,12 @@ def cpu_baseline(cfg_name, graphs):
                 p.grad = None
         return loss.item()
     step(1)
+    log("cpu_baseline: warm-up step done")
     t0 = time.time()
-    n_timed = 2
-    for i in range(n_timed):
-        step(2 + i)
+    n_timed = 0
+    while n_timed < 2 and (n_timed == 0 or time.time() - t0 < 15.0):
+        step(2 + n_timed)
+        n_timed += 1
     dt_ = (time.time() - t0) / n_timed
     return {"value": graphs / dt_, "unit": "graphs/s", "cores": cores, "kind": "port",
             "sample": "%d graphs of %s (n=%d, R=%d), fp32, full train step, %d timed steps, %.1f s/step" % (
@@ -99,11 +120,14 @@ def main():
 
     cfg = synth.CONFIGS[a.config]
     cd = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    log("building model")
     model = build_generator(Generator, a.config, dev, factored_relation=not a.dense).to(dev)
     model.set_compute_dtype(cd)
     model.train()
     trainer = Trainer(model, cfg["d"], warmup_steps=2000, compute_dtype=cd, world_size=world)
+    log("model on device; generating batch")
     batch, stats = synth.make_config_batch(a.config, rank=rank)        # weak scaling: B graphs per GPU
+    log("batch", stats)
     batch = {k: v.to(dev) for k, v in batch.items()}
     ops.set_seed(19940117 + rank)
 
@@ -113,9 +137,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        trainer.step(batch)
+    for i in range(a.warmup):
+        v = trainer.step(batch)
+        log("warmup step", i, "loss", v)
     sync()
+    log("warmup done")
     ops.PROFILE = {}
     t0 = time.perf_counter()
     losses = []
@@ -123,6 +149,7 @@ def main():
         losses.append(trainer.step(batch))
     sync()
     elapsed = time.perf_counter() - t0
+    log("timed region done", elapsed)
     prof, ops.PROFILE = ops.PROFILE, None
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:

@@ -11,7 +11,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
-struct alignas(16) U128 { uint32_t x, y, z, w; };
+typedef __attribute__((ext_vector_type(4))) uint32_t U128;   // 16 bytes as a first-class SSA value (never address-taken)
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {

@@ -8,21 +8,40 @@
 //   dX = dY W               -> TA=0, TB=0
 //   dW = dY^T X             -> TA=1, TB=0, split-K, fp32 atomic accumulate
 //
-// Tile 128x128xBK per 256-thread workgroup (4 waves, 2x2, 64x64 per wave = 4x4 MFMA 16x16 tiles).
-// bf16 inputs use v_mfma_f32_16x16x32_bf16, fp32 inputs the exact-fp32 v_mfma_f32_16x16x4_f32.
-// Both operands are staged K-contiguous in LDS (M/N-contiguous operands are transposed on the
-// LDS write) so fragments are 16-byte ds_reads; the next tile's global loads are issued before the
-// MFMAs of the current one.  MFMA operands are swapped (D = B.A^T) so each lane ends up with 4
-// consecutive output columns and stores 8/16-byte vectors.
+// Structure (one 256-thread workgroup = 4 waves, 2x2, per 128x128 output tile; each wave 64x64 = 4x4 MFMA tiles;
+// bf16 inputs: v_mfma_f32_16x16x32_bf16, fp32 inputs: the exact-fp32 v_mfma_f32_16x16x4_f32):
+//   * both operands live K-contiguous in LDS, 128-byte rows of 8 16-byte chunks, chunk index XOR-swizzled with
+//     (row ^ row>>3) & 7 so that fragment ds_read_b128s, row-wise tile writes and the transposed writes of
+//     M/N-contiguous operands are all (at most 2-way) bank-conflict free without padding;
+//   * two LDS stages; the next tile's global loads are issued BEFORE the MFMAs of the current tile and written to
+//     the other stage AFTER them, one barrier per K tile; the loads are branch-free (out-of-range vectors read a
+//     block of zeros) so they issue back to back;
+//   * M/N-contiguous operands (dY^T, X in dW; W in dX) are transposed in registers (4x8 bf16 blocks) and written
+//     with ds_write_b64 instead of 2-byte scatter writes;
+//   * MFMA operands are swapped (D = B.A^T) so a lane holds 4 consecutive output columns; bf16 outputs go through
+//     LDS and leave as full 128-byte row segments.
 #include "common.h"
 
 namespace {
 
 constexpr int BM = 128, BN = 128, NT = 256;
+constexpr int ROWB = 128;                       // bytes per LDS row (BK elements)
 
 template <typename T> struct GemmCfg;
-template <> struct GemmCfg<bf16_t> { static constexpr int BK = 64, VEC = 8, PAD = 8; };
-template <> struct GemmCfg<float>  { static constexpr int BK = 32, VEC = 4, PAD = 4; };
+template <> struct GemmCfg<bf16_t> { static constexpr int BK = 64, VEC = 8; };
+template <> struct GemmCfg<float>  { static constexpr int BK = 32, VEC = 4; };
+constexpr int ITERS = 4;                        // 16-byte vectors per thread per operand tile (128 rows x 128 B / 256 / 16)
+
+// 16 bytes of zeros in GLOBAL memory (allocated once per process): target of out-of-range tile loads.  A __device__
+// constant would make the selected pointer generic and turn the tile loads into flat loads.
+const void* zero_block() {
+    static void* z = nullptr;
+    if (!z) {
+        if (hipMalloc(&z, 256) != hipSuccess) return nullptr;
+        if (hipMemset(z, 0, 256) != hipSuccess) return nullptr;
+    }
+    return z;
+}
 
 struct GemmArgs {
     const void* A; const void* B; void* C; const float* bias;
@@ -30,76 +49,95 @@ struct GemmArgs {
     int vecA, vecB, vecC;     // 16-byte vector access allowed (alignment checked on the host)
     int relu, accumulate, splitk;
     float p_drop; uint64_t seed;
+    const void* zeros;        // 16 zero bytes in global memory
 };
 
-// ---- global -> register tile load.  KC=true: operand rows are K-contiguous ([rows, K], ld).
-//      KC=false: operand is stored [K, rows] (rows contiguous) and is transposed on the LDS write.
-template <typename T, bool KC>
-__device__ __forceinline__ void load_tile(const T* __restrict__ base, int64_t ld, int rows_total, int K,
-                                          int row0, int k0, int kend, int vec_ok, U128 (&regs)[(BM * GemmCfg<T>::BK / GemmCfg<T>::VEC) / NT]) {
-    constexpr int BK = GemmCfg<T>::BK, VEC = GemmCfg<T>::VEC;
-    constexpr int ITERS = (BM * BK / VEC) / NT;
+__device__ __forceinline__ int swz(int row) { return (row ^ (row >> 3)) & 7; }
+// byte offset of 16-byte chunk c of row r inside an operand tile
+__device__ __forceinline__ int lds_off(int r, int c) { return r * ROWB + ((c ^ swz(r)) << 4); }
+
+// ---- global -> register tile load.  KC=true: operand rows are K-contiguous ([rows, K], ld): thread vector v covers
+//      row v/8, chunk v%8.  KC=false: operand stored [K, rows] (rows contiguous): thread t covers 4 consecutive k
+//      and one chunk of VEC consecutive rows (to be transposed on the LDS write).
+template <typename T, bool KC, bool FAST>
+__device__ __forceinline__ void load_tile(const T* __restrict__ base, const U128* __restrict__ zeros, int64_t ld, int rows_total,
+                                          int row0, int k0, int kend, U128 (&regs)[ITERS]) {
+    constexpr int VEC = GemmCfg<T>::VEC;
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
-        const int v = it * NT + threadIdx.x;
         int r, k;
-        if (KC) { r = row0 + v / (BK / VEC); k = k0 + (v % (BK / VEC)) * VEC; }
-        else    { k = k0 + v / (BM / VEC);   r = row0 + (v % (BM / VEC)) * VEC; }
-        U128 val = {0u, 0u, 0u, 0u};
-        T* e = reinterpret_cast<T*>(&val);
-        if (KC) {
-            if (r < rows_total && k < kend) {
-                const T* p = base + (int64_t)r * ld + k;
-                if (vec_ok && k + VEC <= kend) val = *reinterpret_cast<const U128*>(p);
-                else {
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) if (k + i < kend) e[i] = p[i];
-                }
-            }
-        } else {
-            if (k < kend && r < rows_total) {
-                const T* p = base + (int64_t)k * ld + r;
-                if (vec_ok && r + VEC <= rows_total) val = *reinterpret_cast<const U128*>(p);
-                else {
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) if (r + i < rows_total) e[i] = p[i];
-                }
-            }
+        if (KC) { const int v = it * NT + threadIdx.x; r = row0 + (v >> 3); k = k0 + (v & 7) * VEC; }
+        else {  // bf16: 16 row chunks x 16 k quads; fp32: 32 row chunks x 8 k quads; each thread 4 consecutive k
+            const int rc = threadIdx.x % (BM / VEC), kq = threadIdx.x / (BM / VEC);
+            r = row0 + rc * VEC; k = k0 + kq * 4 + it;
         }
-        regs[it] = val;
+        if constexpr (FAST) {
+            // out-of-range vectors read a 16-byte block of zeros: the address is selected BEFORE the load, nothing is
+            // selected after it, so no wait is forced between the loads and the MFMA phase that hides their latency
+            const bool ok = KC ? (r < rows_total && k + VEC <= kend) : (k < kend && r + VEC <= rows_total);
+            const int64_t off = KC ? ((int64_t)r * ld + k) : ((int64_t)k * ld + r);
+            const U128* p = ok ? reinterpret_cast<const U128*>(base + off) : zeros;
+            regs[it] = *p;
+        } else {
+            U128 val = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const bool ok = KC ? (r < rows_total && k + i < kend) : (k < kend && r + i < rows_total);
+                uint32_t bits = 0u;
+                if (ok) {
+                    const T x = KC ? base[(int64_t)r * ld + k + i] : base[(int64_t)k * ld + r + i];
+                    if constexpr (sizeof(T) == 2) bits = (uint32_t)x; else bits = __float_as_uint(x);
+                }
+                if constexpr (sizeof(T) == 2) val[i >> 1] |= bits << (16 * (i & 1)); else val[i] = bits;
+            }
+            regs[it] = val;
+        }
     }
 }
 
+// ---- register -> LDS.  `lds` is the byte base of this operand's tile in the target stage.
 template <typename T, bool KC>
-__device__ __forceinline__ void store_tile(T* __restrict__ lds, const U128 (&regs)[(BM * GemmCfg<T>::BK / GemmCfg<T>::VEC) / NT]) {
-    constexpr int BK = GemmCfg<T>::BK, VEC = GemmCfg<T>::VEC, LDK = BK + GemmCfg<T>::PAD;
-    constexpr int ITERS = (BM * BK / VEC) / NT;
+__device__ __forceinline__ void store_tile(char* __restrict__ lds, const U128 (&regs)[ITERS]) {
+    constexpr int VEC = GemmCfg<T>::VEC;
+    if (KC) {
 #pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-        const int v = it * NT + threadIdx.x;
-        if (KC) {
-            const int r = v / (BK / VEC), k = (v % (BK / VEC)) * VEC;
-            *reinterpret_cast<U128*>(lds + r * LDK + k) = regs[it];
+        for (int it = 0; it < ITERS; ++it) {
+            const int v = it * NT + threadIdx.x;
+            *reinterpret_cast<U128*>(lds + lds_off(v >> 3, v & 7)) = regs[it];
+        }
+    } else {
+        const int rc = threadIdx.x % (BM / VEC), kq = threadIdx.x / (BM / VEC);
+        if constexpr (sizeof(T) == 2) {
+            // regs[j] = 8 rows (m) at k = kq*4 + j.  Transpose 4(k) x 8(m): row m gets its 4 k values = 8 bytes at
+            // chunk kq/2, half kq&1.
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int w = i >> 1;
+                uint32_t lo, hi;
+                if (i & 1) { lo = (regs[0][w] >> 16) | (regs[1][w] & 0xffff0000u); hi = (regs[2][w] >> 16) | (regs[3][w] & 0xffff0000u); }
+                else       { lo = (regs[0][w] & 0xffffu) | (regs[1][w] << 16);     hi = (regs[2][w] & 0xffffu) | (regs[3][w] << 16); }
+                *reinterpret_cast<uint2*>(lds + lds_off(rc * 8 + i, kq >> 1) + (kq & 1) * 8) = make_uint2(lo, hi);
+            }
         } else {
-            const int k = v / (BM / VEC), r = (v % (BM / VEC)) * VEC;
-            const T* e = reinterpret_cast<const T*>(&regs[it]);
+            // fp32: regs[j] = 4 rows at k = kq*4 + j; row m gets 4 k values = one 16-byte chunk kq
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) lds[(r + i) * LDK + k] = e[i];
+            for (int i = 0; i < 4; ++i) {
+                const U128 o = {regs[0][i], regs[1][i], regs[2][i], regs[3][i]};
+                *reinterpret_cast<U128*>(lds + lds_off(rc * 4 + i, kq)) = o;
+            }
         }
     }
 }
 
-template <typename T, typename TO, bool TA, bool TB>
-__global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs a) {
-    constexpr int BK = GemmCfg<T>::BK, VEC = GemmCfg<T>::VEC, LDK = BK + GemmCfg<T>::PAD;
-    constexpr int ITERS = (BM * BK / VEC) / NT;
-    __shared__ __attribute__((aligned(16))) T lds[(BM + BN) * LDK];
-    T* As = lds;
-    T* Bs = lds + BM * LDK;
+template <typename T, typename TO, bool TA, bool TB, bool FAST>
+__global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmArgs a) {
+    constexpr int BK = GemmCfg<T>::BK;
+    constexpr int STAGE = (BM + BN) * ROWB;                       // 32 KB
+    __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     // split-K range (whole BK tiles per split)
     const int ktiles = (a.K + BK - 1) / BK;
     const int tps = (ktiles + a.splitk - 1) / a.splitk;
@@ -109,6 +147,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs a) {
 
     const T* A = static_cast<const T*>(a.A);
     const T* B = static_cast<const T*>(a.B);
+    const U128* Z = static_cast<const U128*>(a.zeros);
 
     f32x4_t acc[4][4];
 #pragma unroll
@@ -116,28 +155,35 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    U128 ra[ITERS], rb[ITERS];
-    load_tile<T, !TA>(A, a.lda, a.M, a.K, m0, kbeg, kend, a.vecA, ra);
-    load_tile<T, TB>(B, a.ldb, a.N, a.K, n0, kbeg, kend, a.vecB, rb);
+    {
+        U128 ra[ITERS], rb[ITERS];
+        load_tile<T, !TA, FAST>(A, Z, a.lda, a.M, m0, kbeg, kend, ra);
+        load_tile<T, TB, FAST>(B, Z, a.ldb, a.N, n0, kbeg, kend, rb);
+        store_tile<T, !TA>(lds, ra);
+        store_tile<T, TB>(lds + BM * ROWB, rb);
+    }
+    __syncthreads();
 
     const int fr = lane & 15, fq = lane >> 4;
+    int cur = 0;
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        __syncthreads();                                   // previous tile's fragment reads are done
-        store_tile<T, !TA>(As, ra);
-        store_tile<T, TB>(Bs, rb);
-        __syncthreads();
-        if (k0 + BK < kend) {                              // prefetch next tile under the MFMAs
-            load_tile<T, !TA>(A, a.lda, a.M, a.K, m0, k0 + BK, kend, a.vecA, ra);
-            load_tile<T, TB>(B, a.ldb, a.N, a.K, n0, k0 + BK, kend, a.vecB, rb);
-        }
+        const char* As = lds + cur * STAGE;
+        const char* Bs = As + BM * ROWB;
+        char* An = lds + (cur ^ 1) * STAGE;
+        // issue next tile's loads; they fly under the MFMAs (past the last tile every vector is out of range and
+        // reads the zero block: unconditional code keeps the staging registers in VGPRs)
+        U128 ra[ITERS], rb[ITERS];
+        load_tile<T, !TA, FAST>(A, Z, a.lda, a.M, m0, k0 + BK, kend, ra);
+        load_tile<T, TB, FAST>(B, Z, a.ldb, a.N, n0, k0 + BK, kend, rb);
+        __builtin_amdgcn_sched_barrier(0);                 // keep the loads ahead of the MFMA block (hipcc sinks them)
         if constexpr (sizeof(T) == 2) {
 #pragma unroll
-            for (int ks = 0; ks < BK / 32; ++ks) {
+            for (int ks = 0; ks < 2; ++ks) {               // BK = 64 = 2 MFMA k-steps of 32; lane chunk = ks*4 + fq
                 bf16x8_t fa[4], fb[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    fa[t] = *reinterpret_cast<const bf16x8_t*>(As + (wm + t * 16 + fr) * LDK + ks * 32 + fq * 8);
-                    fb[t] = *reinterpret_cast<const bf16x8_t*>(Bs + (wn + t * 16 + fr) * LDK + ks * 32 + fq * 8);
+                    fa[t] = *reinterpret_cast<const bf16x8_t*>(As + lds_off(wm + t * 16 + fr, ks * 4 + fq));
+                    fb[t] = *reinterpret_cast<const bf16x8_t*>(Bs + lds_off(wn + t * 16 + fr, ks * 4 + fq));
                 }
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
@@ -147,12 +193,12 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs a) {
             }
         } else {
 #pragma unroll
-            for (int ks = 0; ks < BK / 4; ++ks) {
+            for (int ks = 0; ks < 8; ++ks) {               // BK = 32 = 8 MFMA k-steps of 4; element k = ks*4 + fq
                 float fa[4], fb[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    fa[t] = As[(wm + t * 16 + fr) * LDK + ks * 4 + fq];
-                    fb[t] = Bs[(wn + t * 16 + fr) * LDK + ks * 4 + fq];
+                    fa[t] = *reinterpret_cast<const float*>(As + lds_off(wm + t * 16 + fr, ks) + fq * 4);
+                    fb[t] = *reinterpret_cast<const float*>(Bs + lds_off(wn + t * 16 + fr, ks) + fq * 4);
                 }
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
@@ -161,11 +207,68 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs a) {
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        store_tile<T, !TA>(An, ra);                        // write late: the other stage is free since the last barrier
+        store_tile<T, TB>(An + BM * ROWB, rb);
+        __syncthreads();
+        cur ^= 1;
     }
 
     // ---- epilogue: lane holds C[m = .. + fr][n = .. + fq*4 + 0..3]
     TO* C = static_cast<TO*>(a.C);
     const float keep_scale = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
+
+    if constexpr (sizeof(TO) == 2) {
+        if (a.vecC && a.splitk == 1) {
+            // bf16 output: bias/act in registers, 64x64 wave tile -> LDS (8-byte writes) -> 16-byte row-contiguous stores
+            constexpr int CP = 144;                                    // bytes per staged row (64 bf16 + pad)
+            char* cs = lds + wave * 64 * CP;                           // 9 KB per wave, free since the last barrier
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int m = m0 + wm + mt * 16 + fr, n = n0 + wn + nt * 16 + fq * 4;
+                    float v[4] = {acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (a.bias && n + i < a.N) v[i] += a.bias[n + i];
+                        if (a.relu) v[i] = fmaxf(v[i], 0.f);
+                        if (a.p_drop > 0.f)
+                            v[i] = drop_keep(a.seed, (uint64_t)m * (uint64_t)a.N + (uint64_t)(n + i), a.p_drop) ? v[i] * keep_scale : 0.f;
+                    }
+                    *reinterpret_cast<uint2*>(cs + (mt * 16 + fr) * CP + (nt * 16 + fq * 4) * 2) =
+                        make_uint2(pack_bf(v[0], v[1]), pack_bf(v[2], v[3]));
+                }
+            __syncthreads();
+#pragma unroll
+            for (int pass = 0; pass < 8; ++pass) {
+                const int row = pass * 8 + (lane >> 3), col = (lane & 7) * 8;
+                const int m = m0 + wm + row, n = n0 + wn + col;
+                if (m >= a.M || n >= a.N) continue;
+                uint4 val = *reinterpret_cast<const uint4*>(cs + row * CP + col * 2);
+                bf16_t* cp = reinterpret_cast<bf16_t*>(C) + (int64_t)m * a.ldc + n;
+                if (n + 8 <= a.N) {
+                    if (a.accumulate) {
+                        const uint4 old = *reinterpret_cast<const uint4*>(cp);
+                        val = make_uint4(pack_bf(lo_bf(val.x) + lo_bf(old.x), hi_bf(val.x) + hi_bf(old.x)),
+                                         pack_bf(lo_bf(val.y) + lo_bf(old.y), hi_bf(val.y) + hi_bf(old.y)),
+                                         pack_bf(lo_bf(val.z) + lo_bf(old.z), hi_bf(val.z) + hi_bf(old.z)),
+                                         pack_bf(lo_bf(val.w) + lo_bf(old.w), hi_bf(val.w) + hi_bf(old.w)));
+                    }
+                    *reinterpret_cast<uint4*>(cp) = val;
+                } else {
+                    const bf16_t* e = reinterpret_cast<const bf16_t*>(cs + row * CP + col * 2);
+                    for (int i = 0; i < 8 && n + i < a.N; ++i) {
+                        float o = bf2f(e[i]);
+                        if (a.accumulate) o += bf2f(cp[i]);
+                        cp[i] = f2bf(o);
+                    }
+                }
+            }
+            return;
+        }
+    }
+
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         const int m = m0 + wm + mt * 16 + fr;
@@ -190,18 +293,10 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs a) {
                 if (a.p_drop > 0.f)
                     v[i] = drop_keep(a.seed, (uint64_t)m * (uint64_t)a.N + (uint64_t)(n + i), a.p_drop) ? v[i] * keep_scale : 0.f;
             }
-            if (a.vecC && n + 3 < a.N) {
-                if constexpr (sizeof(TO) == 4) {
-                    float4 o = make_float4(v[0], v[1], v[2], v[3]);
-                    if (a.accumulate) { const float4 c = *reinterpret_cast<const float4*>(cp); o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
-                    *reinterpret_cast<float4*>(cp) = o;
-                } else {
-                    if (a.accumulate) {
-                        const uint2 c = *reinterpret_cast<const uint2*>(cp);
-                        v[0] += lo_bf(c.x); v[1] += hi_bf(c.x); v[2] += lo_bf(c.y); v[3] += hi_bf(c.y);
-                    }
-                    *reinterpret_cast<uint2*>(cp) = make_uint2(pack_bf(v[0], v[1]), pack_bf(v[2], v[3]));
-                }
+            if (sizeof(TO) == 4 && a.vecC && n + 3 < a.N) {
+                float4 o = make_float4(v[0], v[1], v[2], v[3]);
+                if (a.accumulate) { const float4 c = *reinterpret_cast<const float4*>(cp); o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
+                *reinterpret_cast<float4*>(cp) = o;
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) if (n + i < a.N) {
@@ -216,11 +311,16 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs a) {
 
 template <typename T, typename TO>
 int launch(const GemmArgs& a, int transA, int transB, hipStream_t s) {
-    dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.splitk), block(NT);
-    if (!transA && transB)       hipLaunchKernelGGL((gemm_kernel<T, TO, false, true>), grid, block, 0, s, a);
-    else if (!transA && !transB) hipLaunchKernelGGL((gemm_kernel<T, TO, false, false>), grid, block, 0, s, a);
-    else if (transA && !transB)  hipLaunchKernelGGL((gemm_kernel<T, TO, true, false>), grid, block, 0, s, a);
+    dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.splitk), block(NT);
+    const bool fast = a.vecA && a.vecB;          // both operands 16-byte aligned with whole vectors in range
+#define GTOS_LAUNCH(TA_, TB_) do { \
+        if (fast) hipLaunchKernelGGL((gemm_kernel<T, TO, TA_, TB_, true>), grid, block, 0, s, a); \
+        else      hipLaunchKernelGGL((gemm_kernel<T, TO, TA_, TB_, false>), grid, block, 0, s, a); } while (0)
+    if (!transA && transB)       GTOS_LAUNCH(false, true);
+    else if (!transA && !transB) GTOS_LAUNCH(false, false);
+    else if (transA && !transB)  GTOS_LAUNCH(true, false);
     else return -2;
+#undef GTOS_LAUNCH
     GTOS_CHECK_LAUNCH();
     return 0;
 }
@@ -233,14 +333,18 @@ extern "C" int gtos_gemm(int in_dtype, int out_dtype, int transA, int transB, in
                          int splitk, void* stream) {
     if (M <= 0 || N <= 0) return 0;
     if (K <= 0) return -3;
+    if ((N + BN - 1) / BN > 65535) return -6;
     const int es = in_dtype == GTOS_BF16 ? 2 : 4, vec = 16 / es;
     const int eo = out_dtype == GTOS_BF16 ? 2 : 4;
     GemmArgs a;
     a.A = A; a.B = B; a.C = C; a.bias = bias; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
-    a.vecA = ((uintptr_t)A % 16 == 0) && (lda % vec == 0);
-    a.vecB = ((uintptr_t)B % 16 == 0) && (ldb % vec == 0);
-    a.vecC = ((uintptr_t)C % (4 * eo) == 0) && (ldc % 4 == 0);
+    // K-contiguous operands need K % vec == 0, M/N-contiguous ones need M (resp. N) % vec == 0 (whole vectors in range)
+    a.vecA = ((uintptr_t)A % 16 == 0) && (lda % vec == 0) && ((transA ? M : K) % vec == 0);
+    a.vecB = ((uintptr_t)B % 16 == 0) && (ldb % vec == 0) && ((transB ? K : N) % vec == 0);
+    a.vecC = ((uintptr_t)C % 16 == 0) && (ldc % (16 / eo) == 0);
     a.relu = relu; a.accumulate = accumulate; a.p_drop = p_drop; a.seed = seed;
+    a.zeros = zero_block();
+    if (!a.zeros) return -5;
     if (splitk < 1) splitk = 1;
     const int BKc = in_dtype == GTOS_BF16 ? GemmCfg<bf16_t>::BK : GemmCfg<float>::BK;
     const int ktiles = (K + BKc - 1) / BKc;

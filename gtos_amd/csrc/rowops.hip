@@ -138,13 +138,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int d, const T* _
             }
         }
     }
+    // 4 waves -> 1 through LDS, then one atomicAdd per channel per block
+    __shared__ float red[4][2][LN_MAXC * 512];
+    const int w = threadIdx.x >> 6;
 #pragma unroll
     for (int cI = 0; cI < LN_MAXC; ++cI) {
         const int c = (cI * 64 + lane) * 8;
-        if (c < d) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { atomicAdd(dgamma + c + e, dg[cI][e]); atomicAdd(dbeta + c + e, db[cI][e]); }
-        }
+        for (int e = 0; e < 8; ++e) { red[w][0][c + e] = dg[cI][e]; red[w][1][c + e] = db[cI][e]; }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += 256) {
+        atomicAdd(dgamma + c, red[0][0][c] + red[1][0][c] + red[2][0][c] + red[3][0][c]);
+        atomicAdd(dbeta + c, red[0][1][c] + red[1][1][c] + red[2][1][c] + red[3][1][c]);
     }
 }
 
@@ -163,26 +169,47 @@ __global__ void relu_drop_bwd_kernel(int64_t n8, T* __restrict__ dh, const T* __
 }
 
 // =========================================================================== bias gradient: out[n] += sum_rows dy[row, n]
+// Block = 4 waves; lane owns 8 consecutive columns of a 512-column chunk (one wave reads 1 KB of a row per load),
+// each wave walks its own rows of the block's slice 4 at a time; LDS reduce over the 4 waves, one atomic per column.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(int rows, int N, int64_t ld, const T* __restrict__ dy, float* __restrict__ out,
                                                      int rows_per_block) {
-    const int c = (blockIdx.x * 256 + threadIdx.x) * 8;
-    if (c >= N) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + lane) * 8;
     const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const bool full = (c + 8 <= N) && (ld % 8 == 0);
-    for (int r = r0; r < r1; ++r) {
-        const T* p = dy + (int64_t)r * ld + c;
+    const bool full = (c + 8 <= N) && (ld % 8 == 0) && (((uintptr_t)dy) % 16 == 0);
+    if (c < N) {
         if (full) {
-            float v[8];
-            Vec8<T>::load(p, v);
+            int r = r0 + w;
+            for (; r + 12 < r1; r += 16) {
+                float v0[8], v1[8], v2[8], v3[8];
+                Vec8<T>::load(dy + (int64_t)r * ld + c, v0);
+                Vec8<T>::load(dy + (int64_t)(r + 4) * ld + c, v1);
+                Vec8<T>::load(dy + (int64_t)(r + 8) * ld + c, v2);
+                Vec8<T>::load(dy + (int64_t)(r + 12) * ld + c, v3);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += v[e];
+                for (int e = 0; e < 8; ++e) acc[e] += (v0[e] + v1[e]) + (v2[e] + v3[e]);
+            }
+            for (; r < r1; r += 4) {
+                float v0[8];
+                Vec8<T>::load(dy + (int64_t)r * ld + c, v0);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += v0[e];
+            }
         } else {
-            for (int e = 0; e < 8 && c + e < N; ++e) acc[e] += to_f<T>(p[e]);
+            for (int r = r0 + w; r < r1; r += 4)
+                for (int e = 0; e < 8 && c + e < N; ++e) acc[e] += to_f<T>(dy[(int64_t)r * ld + c + e]);
         }
     }
-    for (int e = 0; e < 8 && c + e < N; ++e) atomicAdd(out + c + e, acc[e]);
+    __shared__ float red[4][512];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[w][lane * 8 + e] = acc[e];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 512; i += 256) {
+        const int col = blockIdx.x * 512 + i;
+        if (col < N) atomicAdd(out + col, red[0][i] + red[1][i] + red[2][i] + red[3][i]);
+    }
 }
 
 // =========================================================================== GRU cell (PyTorch gate order r,z,n)
@@ -300,6 +327,59 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(int64_t P, int K, int 
     }
 }
 
+
+// =========================================================================== relation-label embedding rows
+// out[n, 0:dim_pad] = dropout(table[tok[n], 0:dim]) zero-padded to dim_pad (a multiple of 8), in the compute dtype:
+// nn.Embedding + F.dropout of RelationEncoder (/root/reference/generator/encoder.py:99-100) plus the layout the GEMM wants.
+template <typename T>
+__global__ void embed_rows_fwd_kernel(int64_t n, int dim, int dim_pad, const int64_t* __restrict__ tok, const float* __restrict__ table,
+                                      T* __restrict__ out, float p_drop, uint64_t seed) {
+    const int vpr = dim_pad / 8;
+    const float ks = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n * vpr; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = t / vpr; const int c = (int)(t % vpr) * 8;
+        const float* src = table + tok[row] * dim;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float x = (c + e < dim) ? src[c + e] : 0.f;
+            if (p_drop > 0.f) x = drop_keep(seed, (uint64_t)row * dim_pad + c + e, p_drop) ? x * ks : 0.f;
+            v[e] = x;
+        }
+        Vec8<T>::store(out + row * dim_pad + c, v);
+    }
+}
+
+// dtable[tok[n], :] += dropmask * dout[n, 0:dim].  The table is small (relation vocabulary ~ 90 x 100): each block
+// accumulates a private copy in LDS (ds_add_f32) over its slice of rows and flushes it with global atomics.
+template <typename T>
+__global__ __launch_bounds__(256) void embed_rows_bwd_kernel(int64_t n, int V, int dim, int dim_pad, const int64_t* __restrict__ tok,
+                                                             const T* __restrict__ dout, float* __restrict__ dtable, float p_drop,
+                                                             uint64_t seed, int64_t rows_per_block) {
+    extern __shared__ float tab[];
+    for (int i = threadIdx.x; i < V * dim; i += 256) tab[i] = 0.f;
+    __syncthreads();
+    const float ks = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    const int vpr = dim_pad / 8;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(n, r0 + rows_per_block);
+    for (int64_t t = r0 * vpr + threadIdx.x; t < r1 * vpr; t += 256) {
+        const int64_t row = t / vpr; const int c = (int)(t % vpr) * 8;
+        float v[8];
+        Vec8<T>::load(dout + row * dim_pad + c, v);
+        float* dst = tab + tok[row] * dim;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (c + e < dim) {
+                float x = v[e];
+                if (p_drop > 0.f) x = drop_keep(seed, (uint64_t)row * dim_pad + c + e, p_drop) ? x * ks : 0.f;
+                atomicAdd(dst + c + e, x);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < V * dim; i += 256) { const float x = tab[i]; if (x != 0.f) atomicAdd(dtable + i, x); }
+}
+
 // =========================================================================== optimizer (flat buffers)
 // sum of squares of g (for clip_grad_norm_, /root/reference/generator/train.py:151)
 __global__ __launch_bounds__(256) void sqnorm_kernel(int64_t n, const float* __restrict__ g, float* __restrict__ out) {
@@ -359,7 +439,7 @@ extern "C" int gtos_ln_residual_bwd(int dtype, int rows, int d, const void* dy, 
     if (d % 8 || d > 512 * LN_MAXC) return -20;
     if (rows <= 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    int nb = (rows + 3) / 4; if (nb > 1024) nb = 1024;
+    int nb = (rows + 31) / 32; if (nb > 256) nb = 256; if (nb < 1) nb = 1;   // >= 8 rows per wave: few atomics
     dim3 grid(nb), block(256);
     if (dtype == GTOS_BF16)
         hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, grid, block, 0, s, rows, d, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)r, p_drop, seed, gamma, mean, rstd, (bf16_t*)dx, (bf16_t*)dr, dgamma, dbeta);
@@ -384,8 +464,8 @@ extern "C" int gtos_relu_dropout_bwd(int dtype, int64_t n, void* dh, const void*
 extern "C" int gtos_colsum(int dtype, int rows, int N, int64_t ld, const void* dy, float* out, void* stream) {
     if (rows <= 0 || N <= 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int gx = (N + 2047) / 2048;
-    int rpb = (rows + 511) / 512; if (rpb < 32) rpb = 32;
+    const int gx = (N + 511) / 512;
+    int rpb = (rows + 1023) / 1024; if (rpb < 64) rpb = 64;
     dim3 grid(gx, (rows + rpb - 1) / rpb), block(256);
     if (dtype == GTOS_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, block, 0, s, rows, N, ld, (const bf16_t*)dy, out, rpb);
     else hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, s, rows, N, ld, (const float*)dy, out, rpb);
@@ -425,6 +505,35 @@ extern "C" int gtos_relation_gather_mean(int dtype, int64_t P, int K, int d, con
     dim3 grid(grid_for(P * (d / 8), 256)), block(256);
     if (dtype == GTOS_BF16) hipLaunchKernelGGL(gather_mean_kernel<bf16_t>, grid, block, 0, s, P, K, d, (const bf16_t*)bank, idx, zero_row0, (bf16_t*)out);
     else hipLaunchKernelGGL(gather_mean_kernel<float>, grid, block, 0, s, P, K, d, (const float*)bank, idx, zero_row0, (float*)out);
+    GTOS_CHECK_LAUNCH();
+    return 0;
+}
+
+
+extern "C" int gtos_embed_rows_fwd(int dtype, int64_t n, int dim, int dim_pad, const int64_t* tok, const float* table, void* out,
+                                   float p_drop, uint64_t seed, void* stream) {
+    if (dim_pad % 8 || dim_pad < dim) return -24;
+    if (n <= 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    dim3 grid(grid_for(n * (dim_pad / 8), 256)), block(256);
+    if (dtype == GTOS_BF16) hipLaunchKernelGGL(embed_rows_fwd_kernel<bf16_t>, grid, block, 0, s, n, dim, dim_pad, tok, table, (bf16_t*)out, p_drop, seed);
+    else hipLaunchKernelGGL(embed_rows_fwd_kernel<float>, grid, block, 0, s, n, dim, dim_pad, tok, table, (float*)out, p_drop, seed);
+    GTOS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gtos_embed_rows_bwd(int dtype, int64_t n, int V, int dim, int dim_pad, const int64_t* tok, const void* dout,
+                                   float* dtable, float p_drop, uint64_t seed, void* stream) {
+    if (dim_pad % 8 || dim_pad < dim) return -24;
+    if ((size_t)V * dim * 4 > 60 * 1024) return -25;          // private LDS table; larger vocabularies are not on this path
+    if (n <= 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int64_t nb = (n + 2047) / 2048; if (nb > 1024) nb = 1024; if (nb < 1) nb = 1;
+    const int64_t rpb = (n + nb - 1) / nb;
+    dim3 grid((unsigned)((n + rpb - 1) / rpb)), block(256);
+    const size_t sh = (size_t)V * dim * 4;
+    if (dtype == GTOS_BF16) hipLaunchKernelGGL(embed_rows_bwd_kernel<bf16_t>, grid, block, sh, s, n, V, dim, dim_pad, tok, (const bf16_t*)dout, dtable, p_drop, seed, rpb);
+    else hipLaunchKernelGGL(embed_rows_bwd_kernel<float>, grid, block, sh, s, n, V, dim, dim_pad, tok, (const float*)dout, dtable, p_drop, seed, rpb);
     GTOS_CHECK_LAUNCH();
     return 0;
 }

@@ -58,11 +58,10 @@ class RelationEncoder(nn.Module):
         while batch_sizes and batch_sizes[-1] == 0:
             batch_sizes.pop()
         packed = torch.cat([toks[t, :a] for t, a in enumerate(batch_sizes)])       # [N]
-        x = F.dropout(self.rel_embed(packed), p=self.dropout, training=self.training)
-        pad = (-x.shape[1]) % 8                                                    # 16-byte rows for the GEMM
-        if pad:
-            x = F.pad(x, (0, pad))
-        x = x.to(self.compute_dtype)
+        rel_dim = self.rel_embed.weight.shape[1]
+        pad = (-rel_dim) % 8                                                       # 16-byte rows for the GEMM
+        x = ops.embed_rows(packed, self.rel_embed.weight, rel_dim + pad, self.dropout if self.training else 0.0,
+                           self.compute_dtype)
         p = self.dropout if (self.training and self.num_layers > 1) else 0.0
         fin = bigru_final(x, batch_sizes, self.hidden_size, self.num_layers, p, self._weights(pad))   # [R, 2h] sorted
         positions = torch.sort(indices)[1]

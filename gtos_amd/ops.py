@@ -233,7 +233,7 @@ class FactoredRelation:
         order = torch.sort(flat, stable=True)[1]
         counts = torch.bincount(flat, minlength=R)
         starts = torch.cumsum(counts, 0) - counts
-        nch = (counts + self.CHUNK - 1) // self.CHUNK
+        nch = torch.clamp((counts + self.CHUNK - 1) // self.CHUNK, min=1)   # empty types get one empty chunk (writes zeros)
         ctype = torch.repeat_interleave(torch.arange(R, device=flat.device), nch)
         first = torch.cumsum(nch, 0) - nch
         local = torch.arange(ctype.numel(), device=flat.device) - first[ctype]
@@ -243,7 +243,7 @@ class FactoredRelation:
         self.pair_sorted = order.to(torch.int32)
         self.chunk_type = ctype.to(torch.int32)
         self.chunk_start = (starts[ctype] + local * self.CHUNK).to(torch.int32)
-        self.chunk_count = torch.clamp(counts[ctype] - local * self.CHUNK, max=self.CHUNK).to(torch.int32)
+        self.chunk_count = torch.clamp(counts[ctype] - local * self.CHUNK, min=0, max=self.CHUNK).to(torch.int32)
         self.chunk_slot = slot_of_type[ctype].to(torch.int32)
         self.heavy_types = heavy_types
         self.nchunks = int(ctype.numel())
@@ -336,3 +336,38 @@ def relation_gather_mean(bank, idx, zero_row0):
     call("gtos_relation_gather_mean", dt(bank), P, K, bank.shape[1], ptr(bank), ptr(idx.contiguous()), int(zero_row0),
          ptr(out), stream())
     return out.view(*lead, bank.shape[1])
+
+
+class EmbedRowsFn(torch.autograd.Function):
+    """x[n, 0:dim_pad] = dropout(table[tokens[n]]) zero-padded, in the compute dtype: nn.Embedding + F.dropout of
+    RelationEncoder (generator/encoder.py:99-100).  Backward scatters into the (small) table through LDS."""
+
+    @staticmethod
+    def forward(ctx, tokens, table, dim_pad, p_drop, dtype):
+        require_cuda(tokens, table)
+        tokens = tokens.contiguous()
+        n, (V, dim) = tokens.numel(), table.shape
+        out = torch.empty((n, dim_pad), dtype=dtype, device=table.device)
+        seed = next_seed() if p_drop > 0 else 0
+        call("gtos_embed_rows_fwd", dt(out), n, dim, dim_pad, ptr(tokens), ptr(table), ptr(out), float(p_drop), seed, stream())
+        ctx.save_for_backward(tokens)
+        ctx.cfg = (table, dim_pad, p_drop, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        tokens, = ctx.saved_tensors
+        table, dim_pad, p_drop, seed = ctx.cfg
+        dout = dout.contiguous()
+        V, dim = table.shape
+        tgt = _grad_target(table)
+        dtab = None
+        if tgt is None:
+            tgt = dtab = torch.zeros(table.shape, dtype=torch.float32, device=table.device)
+        call("gtos_embed_rows_bwd", dt(dout), tokens.numel(), V, dim, dim_pad, ptr(tokens), ptr(dout), ptr(tgt),
+             float(p_drop), seed, stream())
+        return None, dtab, None, None, None
+
+
+def embed_rows(tokens, table, dim_pad, p_drop, dtype):
+    return EmbedRowsFn.apply(tokens, table, dim_pad, float(p_drop), dtype)

@@ -113,6 +113,14 @@ int gtos_gru_cell_bwd(int dtype, int rows, int hs, const void* gates, const void
 int gtos_relation_gather_mean(int dtype, int64_t P, int K, int d, const void* bank, const int64_t* idx, int zero_row0,
                               void* out, void* stream);
 
+/* Relation-label embedding rows for the packed GRU input: out[n, 0:dim_pad] = dropout(table[tok[n]]) zero-padded to
+ * dim_pad (multiple of 8) in `dtype` (nn.Embedding + F.dropout, generator/encoder.py:99-100), and its backward
+ * dtable[V,dim] += scatter of dout (the embedding's index_add backward) for small tables (V*dim*4 <= 60 KB). */
+int gtos_embed_rows_fwd(int dtype, int64_t n, int dim, int dim_pad, const int64_t* tok, const float* table, void* out,
+                        float p_drop, uint64_t seed, void* stream);
+int gtos_embed_rows_bwd(int dtype, int64_t n, int V, int dim, int dim_pad, const int64_t* tok, const void* dout,
+                        float* dtable, float p_drop, uint64_t seed, void* stream);
+
 /* Flat-buffer optimizer: sum of squares (clip_grad_norm_, generator/train.py:151) and the Adam variant of
  * generator/adam.py:66-87 (no bias correction, decoupled weight decay), with the gradient averaging of
  * generator/train.py:74-79 (gscale = 1/world_size) and the clip coefficient folded in; optionally refreshes a
