@@ -137,11 +137,19 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmArgs a) {
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    // XCD-aware tile order.  The dispatcher deals block ids round-robin to the 8 XCDs (private L2 each), so give every
+    // XCD its own M panels and let consecutive blocks of one XCD walk the N tiles of one panel: the streamed operand
+    // (A rows: activations, M up to millions) is then fetched from HBM once instead of once per N tile.
+    const int nN = (a.N + BN - 1) / BN, nM8 = ((a.M + BM - 1) / BM + 7) >> 3;
+    const int per_split = nM8 * 8 * nN;
+    const int bz = blockIdx.x / per_split, bt = blockIdx.x % per_split;
+    const int xcd = bt & 7, sq = bt >> 3;
+    const int m0 = ((sq / nN) * 8 + xcd) * BM, n0 = (sq % nN) * BN;
+    if (m0 >= a.M) return;
     // split-K range (whole BK tiles per split)
     const int ktiles = (a.K + BK - 1) / BK;
     const int tps = (ktiles + a.splitk - 1) / a.splitk;
-    const int kbeg = blockIdx.z * tps * BK;
+    const int kbeg = bz * tps * BK;
     const int kend = min(a.K, kbeg + tps * BK);
     if (kbeg >= kend && a.splitk > 1) return;
 
@@ -311,7 +319,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmArgs a) {
 
 template <typename T, typename TO>
 int launch(const GemmArgs& a, int transA, int transB, hipStream_t s) {
-    dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.splitk), block(NT);
+    const long long nblk = (long long)((((a.M + BM - 1) / BM + 7) / 8) * 8) * ((a.N + BN - 1) / BN) * a.splitk;
+    if (nblk > 0x7fffffffLL) return -6;
+    dim3 grid((unsigned)nblk), block(NT);
     const bool fast = a.vecA && a.vecB;          // both operands 16-byte aligned with whole vectors in range
 #define GTOS_LAUNCH(TA_, TB_) do { \
         if (fast) hipLaunchKernelGGL((gemm_kernel<T, TO, TA_, TB_, true>), grid, block, 0, s, a); \
@@ -333,7 +343,6 @@ extern "C" int gtos_gemm(int in_dtype, int out_dtype, int transA, int transB, in
                          int splitk, void* stream) {
     if (M <= 0 || N <= 0) return 0;
     if (K <= 0) return -3;
-    if ((N + BN - 1) / BN > 65535) return -6;
     const int es = in_dtype == GTOS_BF16 ? 2 : 4, vec = 16 / es;
     const int eo = out_dtype == GTOS_BF16 ? 2 : 4;
     GemmArgs a;

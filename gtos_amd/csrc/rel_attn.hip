@@ -378,17 +378,36 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_bank_kernel(BankArgs a) {
     const int lane = threadIdx.x & 63;
     const int d = a.d, LR = d >> 3, G = 64 / LR, g = lane / LR, cl = lane % LR, c = cl * 8, h = cl / LH;
     const int t = a.chunk_type[ch], start = a.chunk_start[ch], cnt = a.chunk_count[ch];
+    // the type's bank row does not depend on the pairs: issue its loads first so they overlap the pair walk
+    Raw8<T> rRA, rRB;
+    const T* bp = static_cast<const T*>(a.bank) + (int64_t)t * (2 * d) + c;
+    rRA.load(bp); rRB.load(bp + d);
+    // one coalesced load of the chunk's pair ids (<= 64 per chunk); pair p is then broadcast from lane p
+    const int my_pid = lane < cnt ? a.pair_sorted[start + lane] : 0;
     float da[8] = {0, 0, 0, 0, 0, 0, 0, 0}, db[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gsum = 0.f;
-    for (int p = g; p < cnt; p += G) {
-        const int pid = a.pair_sorted[start + p];
-        const int b = pid % a.B, ji = pid / a.B, i = ji % a.T, j = ji / a.T;
-        const float gsc = a.gs[(((int64_t)i * a.S + j) * a.B + b) * a.H + h];
-        float kf[8], qf[8];
-        { Raw8<T> r; r.load(static_cast<const T*>(a.k) + ((int64_t)j * a.B + b) * a.ldk + c); r.get(kf); }
-        { Raw8<T> r; r.load(static_cast<const T*>(a.q) + ((int64_t)i * a.B + b) * a.ldq + c); r.get(qf); }
-        gsum += gsc;
+    for (int p0 = 0; p0 < cnt; p0 += 2 * G) {            // two pairs per group in flight
+        Raw8<T> rk[2], rq[2];
+        float gsc[2];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { da[e] = fmaf(gsc, kf[e], da[e]); db[e] = fmaf(gsc, qf[e], db[e]); }
+        for (int u = 0; u < 2; ++u) {
+            const int p = p0 + u * G + g;
+            const int pid = __shfl(my_pid, p < cnt ? p : 0);
+            rk[u].zero(); rq[u].zero(); gsc[u] = 0.f;
+            if (p < cnt) {
+                const int b = pid % a.B, ji = pid / a.B, i = ji % a.T, j = ji / a.T;
+                gsc[u] = a.gs[(((int64_t)i * a.S + j) * a.B + b) * a.H + h];
+                rk[u].load(static_cast<const T*>(a.k) + ((int64_t)j * a.B + b) * a.ldk + c);
+                rq[u].load(static_cast<const T*>(a.q) + ((int64_t)i * a.B + b) * a.ldq + c);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float kf[8], qf[8];
+            rk[u].get(kf); rq[u].get(qf);
+            gsum += gsc[u];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { da[e] = fmaf(gsc[u], kf[e], da[e]); db[e] = fmaf(gsc[u], qf[e], db[e]); }
+        }
     }
     for (int off = LR; off < 64; off <<= 1) {
         gsum += __shfl_xor(gsum, off);
@@ -397,9 +416,7 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_bank_kernel(BankArgs a) {
     }
     if (g != 0) return;
     float RA[8], RB[8];
-    const T* bp = static_cast<const T*>(a.bank) + (int64_t)t * (2 * d) + c;
-    { Raw8<T> r; r.load(bp); r.get(RA); }
-    { Raw8<T> r; r.load(bp + d); r.get(RB); }
+    rRA.get(RA); rRB.get(RB);
     const int slot = a.chunk_slot[ch];
     if (slot >= 0) {
         float* out = a.heavy + (int64_t)slot * (2 * d) + c;
