@@ -140,12 +140,22 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmArgs a) {
     // XCD-aware tile order.  The dispatcher deals block ids round-robin to the 8 XCDs (private L2 each), so give every
     // XCD its own M panels and let consecutive blocks of one XCD walk the N tiles of one panel: the streamed operand
     // (A rows: activations, M up to millions) is then fetched from HBM once instead of once per N tile.
-    const int nN = (a.N + BN - 1) / BN, nM8 = ((a.M + BM - 1) / BM + 7) >> 3;
-    const int per_split = nM8 * 8 * nN;
-    const int bz = blockIdx.x / per_split, bt = blockIdx.x % per_split;
-    const int xcd = bt & 7, sq = bt >> 3;
-    const int m0 = ((sq / nN) * 8 + xcd) * BM, n0 = (sq % nN) * BN;
-    if (m0 >= a.M) return;
+    const int nN = (a.N + BN - 1) / BN;
+    int m0, n0, bz;
+    const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
+    if (a.splitk > 1) {
+        // weight-gradient shape (small MxN, huge K): all output tiles of ONE K split run together on one XCD, so the
+        // K-slice rows of both operands are fetched from HBM once and shared through that XCD's L2
+        const int nM = (a.M + BM - 1) / BM, tiles = nM * nN;
+        bz = (sq / tiles) * 8 + xcd;
+        const int t = sq % tiles;
+        m0 = (t / nN) * BM; n0 = (t % nN) * BN;
+        if (bz >= a.splitk) return;
+    } else {
+        bz = 0;
+        m0 = ((sq / nN) * 8 + xcd) * BM; n0 = (sq % nN) * BN;
+        if (m0 >= a.M) return;
+    }
     // split-K range (whole BK tiles per split)
     const int ktiles = (a.K + BK - 1) / BK;
     const int tps = (ktiles + a.splitk - 1) / a.splitk;
@@ -163,27 +173,21 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    {
-        U128 ra[ITERS], rb[ITERS];
-        load_tile<T, !TA, FAST>(A, Z, a.lda, a.M, m0, kbeg, kend, ra);
-        load_tile<T, TB, FAST>(B, Z, a.ldb, a.N, n0, kbeg, kend, rb);
-        store_tile<T, !TA>(lds, ra);
-        store_tile<T, TB>(lds + BM * ROWB, rb);
-    }
+    // Software pipeline, prefetch distance 2: while tile t is multiplied out of LDS stage `cur`, tile t+1 (loaded one
+    // step earlier) waits in one register set and tile t+2 is being issued into the other.  The step is written out
+    // twice so the two register sets are named, never indexed.  Only the OLDER set is waited for at the end of a step
+    // (s_waitcnt vmcnt(8) leaves the 8 newest loads in flight), so HBM latency has two steps of MFMAs to hide under.
+    const int fr = lane & 15, fq = lane >> 4;
+    U128 ra0[ITERS], rb0[ITERS], ra1[ITERS], rb1[ITERS];
+    load_tile<T, !TA, FAST>(A, Z, a.lda, a.M, m0, kbeg, kend, ra0);
+    load_tile<T, TB, FAST>(B, Z, a.ldb, a.N, n0, kbeg, kend, rb0);
+    store_tile<T, !TA>(lds, ra0);
+    store_tile<T, TB>(lds + BM * ROWB, rb0);
+    load_tile<T, !TA, FAST>(A, Z, a.lda, a.M, m0, kbeg + BK, kend, ra0);
+    load_tile<T, TB, FAST>(B, Z, a.ldb, a.N, n0, kbeg + BK, kend, rb0);
     __syncthreads();
 
-    const int fr = lane & 15, fq = lane >> 4;
-    int cur = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        const char* As = lds + cur * STAGE;
-        const char* Bs = As + BM * ROWB;
-        char* An = lds + (cur ^ 1) * STAGE;
-        // issue next tile's loads; they fly under the MFMAs (past the last tile every vector is out of range and
-        // reads the zero block: unconditional code keeps the staging registers in VGPRs)
-        U128 ra[ITERS], rb[ITERS];
-        load_tile<T, !TA, FAST>(A, Z, a.lda, a.M, m0, k0 + BK, kend, ra);
-        load_tile<T, TB, FAST>(B, Z, a.ldb, a.N, n0, k0 + BK, kend, rb);
-        __builtin_amdgcn_sched_barrier(0);                 // keep the loads ahead of the MFMA block (hipcc sinks them)
+    auto mma_stage = [&](const char* As, const char* Bs) {
         if constexpr (sizeof(T) == 2) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {               // BK = 64 = 2 MFMA k-steps of 32; lane chunk = ks*4 + fq
@@ -215,11 +219,37 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmArgs a) {
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
-        store_tile<T, !TA>(An, ra);                        // write late: the other stage is free since the last barrier
-        store_tile<T, TB>(An + BM * ROWB, rb);
-        __syncthreads();
-        cur ^= 1;
+    };
+
+    int cur = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += 2 * BK) {
+        {   // even step: tile k0 in stage cur, tile k0+BK in flight in set 0, issue tile k0+2BK into set 1
+            const char* As = lds + cur * STAGE;
+            char* An = lds + (cur ^ 1) * STAGE;
+            load_tile<T, !TA, FAST>(A, Z, a.lda, a.M, m0, k0 + 2 * BK, kend, ra1);
+            load_tile<T, TB, FAST>(B, Z, a.ldb, a.N, n0, k0 + 2 * BK, kend, rb1);
+            __builtin_amdgcn_sched_barrier(0);             // keep the loads ahead of the MFMA block (hipcc sinks them)
+            mma_stage(As, As + BM * ROWB);
+            __builtin_amdgcn_sched_barrier(0);
+            store_tile<T, !TA>(An, ra0);                   // write late: the other stage is free since the last barrier
+            store_tile<T, TB>(An + BM * ROWB, rb0);
+            __syncthreads();
+            cur ^= 1;
+        }
+        if (k0 + BK >= kend) break;
+        {   // odd step: roles of the register sets swapped
+            const char* As = lds + cur * STAGE;
+            char* An = lds + (cur ^ 1) * STAGE;
+            load_tile<T, !TA, FAST>(A, Z, a.lda, a.M, m0, k0 + 3 * BK, kend, ra0);
+            load_tile<T, TB, FAST>(B, Z, a.ldb, a.N, n0, k0 + 3 * BK, kend, rb0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_stage(As, As + BM * ROWB);
+            __builtin_amdgcn_sched_barrier(0);
+            store_tile<T, !TA>(An, ra1);
+            store_tile<T, TB>(An + BM * ROWB, rb1);
+            __syncthreads();
+            cur ^= 1;
+        }
     }
 
     // ---- epilogue: lane holds C[m = .. + fr][n = .. + fq*4 + 0..3]
@@ -319,7 +349,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmArgs a) {
 
 template <typename T, typename TO>
 int launch(const GemmArgs& a, int transA, int transB, hipStream_t s) {
-    const long long nblk = (long long)((((a.M + BM - 1) / BM + 7) / 8) * 8) * ((a.N + BN - 1) / BN) * a.splitk;
+    const long long nMt = (a.M + BM - 1) / BM, nNt = (a.N + BN - 1) / BN;
+    const long long nblk = a.splitk > 1 ? nMt * nNt * 8 * ((a.splitk + 7) / 8) : ((nMt + 7) / 8) * 8 * nNt;
     if (nblk > 0x7fffffffLL) return -6;
     dim3 grid((unsigned)nblk), block(NT);
     const bool fast = a.vecA && a.vecB;          // both operands 16-byte aligned with whole vectors in range
