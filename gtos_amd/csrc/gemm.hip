@@ -11,8 +11,8 @@
 // Structure (one 256-thread workgroup = 4 waves, 2x2, per 128x128 output tile; each wave 64x64 = 4x4 MFMA tiles;
 // bf16 inputs: v_mfma_f32_16x16x32_bf16, fp32 inputs: the exact-fp32 v_mfma_f32_16x16x4_f32):
 //   * both operands live K-contiguous in LDS, 128-byte rows of 8 16-byte chunks, chunk index XOR-swizzled with
-//     (row ^ row>>3) & 7 so that fragment ds_read_b128s, row-wise tile writes and the transposed writes of
-//     M/N-contiguous operands are all (at most 2-way) bank-conflict free without padding;
+//     ((row>>1)&7) ^ ((row>>4)&3) so that fragment ds_read_b128s and row-wise tile writes are bank-conflict free and
+//     the transposed writes of M/N-contiguous operands at most 2-way, without padding;
 //   * two LDS stages; the next tile's global loads are issued BEFORE the MFMAs of the current tile and written to
 //     the other stage AFTER them, one barrier per K tile; the loads are branch-free (out-of-range vectors read a
 //     block of zeros) so they issue back to back;
@@ -52,7 +52,10 @@ struct GemmArgs {
     const void* zeros;        // 16 zero bytes in global memory
 };
 
-__device__ __forceinline__ int swz(int row) { return (row ^ (row >> 3)) & 7; }
+// f(row) = ((row>>1)&7) ^ ((row>>4)&3).  ds_read_b128 is serviced in 16-lane groups that pair the rows {0-3,12-15} of one
+// 16-byte chunk with the rows {4-11} of the next one: (row>>1) makes those 16 accesses hit 16 distinct 16-byte slots of
+// the 256-byte bank row; the (row>>4) term spreads the 8-row-strided transposed ds_write_b64s (rows rc*8+i) over all chunks.
+__device__ __forceinline__ int swz(int row) { return ((row >> 1) & 7) ^ ((row >> 4) & 3); }
 // byte offset of 16-byte chunk c of row r inside an operand tile
 __device__ __forceinline__ int lds_off(int r, int c) { return r * ROWB + ((c ^ swz(r)) << 4); }
 

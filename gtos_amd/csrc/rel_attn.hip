@@ -373,10 +373,10 @@ struct BankArgs {
 
 template <typename T, int LH>
 __global__ __launch_bounds__(256) void rel_attn_bwd_bank_kernel(BankArgs a) {
-    const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (ch >= a.nchunks) return;
     const int lane = threadIdx.x & 63;
     const int d = a.d, LR = d >> 3, G = 64 / LR, g = lane / LR, cl = lane % LR, c = cl * 8, h = cl / LH;
+    // most chunks hold one or two pairs: walk them grid-stride so a wave amortises its launch over many chunks
+    for (int ch = blockIdx.x * 4 + (threadIdx.x >> 6); ch < a.nchunks; ch += gridDim.x * 4) {
     const int t = a.chunk_type[ch], start = a.chunk_start[ch], cnt = a.chunk_count[ch];
     // the type's bank row does not depend on the pairs: issue its loads first so they overlap the pair walk
     Raw8<T> rRA, rRB;
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_bank_kernel(BankArgs a) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) { da[e] += __shfl_xor(da[e], off); db[e] += __shfl_xor(db[e], off); }
     }
-    if (g != 0) return;
+    if (g != 0) continue;
     float RA[8], RB[8];
     rRA.get(RA); rRB.get(RB);
     const int slot = a.chunk_slot[ch];
@@ -429,6 +429,7 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_bank_kernel(BankArgs a) {
         for (int e = 0; e < 8; ++e) { r1[e] = fmaf(gsum, RB[e], da[e]); r2[e] = fmaf(gsum, RA[e], db[e]); }
         Vec8<T>::store(out, r1);
         Vec8<T>::store(out + d, r2);
+    }
     }
 }
 
@@ -529,7 +530,7 @@ extern "C" int gtos_rel_attn_bwd_bank(int dtype, int n, int B, int H, int d,
     a.chunk_type = chunk_type; a.chunk_start = chunk_start; a.chunk_count = chunk_count; a.chunk_slot = chunk_slot;
     a.d_bank = d_bank; a.heavy = heavy; a.nchunks = nchunks; a.T = n; a.S = n; a.B = B; a.H = H; a.d = d;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int grid = (nchunks + 3) / 4;
+    int grid = (nchunks + 3) / 4; if (grid > 4096) grid = 4096;
     return dispatch_lh(d / H / 8, [&](auto lh) {
         constexpr int LH = decltype(lh)::value;
         if (dtype == GTOS_BF16) hipLaunchKernelGGL((rel_attn_bwd_bank_kernel<bf16_t, LH>), dim3(grid), dim3(256), 0, s, a);
