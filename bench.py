@@ -165,11 +165,31 @@ def main():
     evs = prof.get(key, [])
     avg_ms = sum(s.elapsed_time(e) for s, e in evs) / max(1, len(evs))
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if evs else 0.0
+    traffic = None          # HBM bytes per launch from the PMC passes (separate rocprofv3 runs, see the json's "method")
+    pmc_file = os.path.join(ROOT, "profiles", "r1_rel_attn_pmc.json")
+    if a.config == "C2" and a.dtype == "bf16" and os.path.exists(pmc_file):
+        traffic = json.load(open(pmc_file))["traffic_bytes_per_launch"]
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "kernel": "rel_attn_fwd_kernel (%s relation operand)" % ("dense" if a.dense else "factored"),
                 "launches": len(evs), "avg_us": round(avg_ms * 1e3, 1), "algorithmic_bytes": alg_bytes}
 
+    if rank == 0 and not a.dense and a.config in ("C1", "C2", "C3"):
+        # the same kernel on the reference's dense relation signature (rarb[S,T,B,2d] materialised), outside the timed region
+        del trainer
+        torch.cuda.empty_cache()
+        g = torch.Generator().manual_seed(1)
+        qkv = torch.randn(n, B, 3 * d, generator=g).to(dev, cd)
+        rarb = (0.3 * torch.randn(n * n * B, 2 * d, generator=g)).to(dev, cd).view(n, n, B, 2 * d)
+        ops.PROFILE = {}
+        for _ in range(6):
+            ops.attention_core(qkv, None, (0, d, 2 * d), d, cfg["H"], (d // cfg["H"]) ** -0.5, rel=rarb)
+        torch.cuda.synchronize()
+        ev = ops.PROFILE["rel_attn_fwd_mode1"][1:]
+        ops.PROFILE = None
+        dms = sum(s_.elapsed_time(e_) for s_, e_ in ev) / len(ev)
+        roofline["dense_signature"] = {"avg_us": round(dms * 1e3, 1), "achieved": round(alg_bytes / dms / 1e6, 1),
+                                       "frac": round(alg_bytes / dms / 1e6 / HBM_PEAK_GBS, 4)}
     if rank == 0:
         out = {"metric": "graphs/sec training step (100-node AMR, batch 64)", "value": world * B * a.steps / elapsed,
                "unit": "graphs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
