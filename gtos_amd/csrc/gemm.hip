@@ -24,13 +24,18 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, NT = 256;
+constexpr int BM = 128, BN = 128;
+#ifndef GTOS_GEMM_THREADS
+#define GTOS_GEMM_THREADS 512
+#endif
+constexpr int NT = GTOS_GEMM_THREADS;          // 256: 4 waves (2x2, 64x64 each); 512: 8 waves (2x4, 64x32 each)
+constexpr int WAVES_N = NT / 128, WTN = BN / WAVES_N, NTW = WTN / 16;   // wave tile width, MFMA tiles per wave along N
 constexpr int ROWB = 128;                       // bytes per LDS row (BK elements)
 
 template <typename T> struct GemmCfg;
 template <> struct GemmCfg<bf16_t> { static constexpr int BK = 64, VEC = 8; };
 template <> struct GemmCfg<float>  { static constexpr int BK = 32, VEC = 4; };
-constexpr int ITERS = 4;                        // 16-byte vectors per thread per operand tile (128 rows x 128 B / 256 / 16)
+constexpr int ITERS = 1024 / NT;                // 16-byte vectors per thread per operand tile (128 rows x 128 B / NT / 16)
 
 // 16 bytes of zeros in GLOBAL memory (allocated once per process): target of out-of-range tile loads.  A __device__
 // constant would make the selected pointer generic and turn the tile loads into flat loads.
@@ -70,9 +75,9 @@ __device__ __forceinline__ void load_tile(const T* __restrict__ base, const U128
     for (int it = 0; it < ITERS; ++it) {
         int r, k;
         if (KC) { const int v = it * NT + threadIdx.x; r = row0 + (v >> 3); k = k0 + (v & 7) * VEC; }
-        else {  // bf16: 16 row chunks x 16 k quads; fp32: 32 row chunks x 8 k quads; each thread 4 consecutive k
+        else {  // BM/VEC row chunks x (NT*VEC/BM) k groups; each thread ITERS consecutive k of one row chunk
             const int rc = threadIdx.x % (BM / VEC), kq = threadIdx.x / (BM / VEC);
-            r = row0 + rc * VEC; k = k0 + kq * 4 + it;
+            r = row0 + rc * VEC; k = k0 + kq * ITERS + it;
         }
         if constexpr (FAST) {
             // out-of-range vectors read a 16-byte block of zeros: the address is selected BEFORE the load, nothing is
@@ -110,36 +115,49 @@ __device__ __forceinline__ void store_tile(char* __restrict__ lds, const U128 (&
         }
     } else {
         const int rc = threadIdx.x % (BM / VEC), kq = threadIdx.x / (BM / VEC);
+        const int kk = kq * ITERS;                               // first k of this thread inside the tile
         if constexpr (sizeof(T) == 2) {
-            // regs[j] = 8 rows (m) at k = kq*4 + j.  Transpose 4(k) x 8(m): row m gets its 4 k values = 8 bytes at
-            // chunk kq/2, half kq&1.
+            // regs[j] = 8 rows (m) at k = kk + j.  Transpose ITERS(k) x 8(m): row m gets its ITERS k values
+            // (ITERS*2 bytes) at chunk kk/8, byte (kk%8)*2.
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int w = i >> 1;
-                uint32_t lo, hi;
-                if (i & 1) { lo = (regs[0][w] >> 16) | (regs[1][w] & 0xffff0000u); hi = (regs[2][w] >> 16) | (regs[3][w] & 0xffff0000u); }
-                else       { lo = (regs[0][w] & 0xffffu) | (regs[1][w] << 16);     hi = (regs[2][w] & 0xffffu) | (regs[3][w] << 16); }
-                *reinterpret_cast<uint2*>(lds + lds_off(rc * 8 + i, kq >> 1) + (kq & 1) * 8) = make_uint2(lo, hi);
+                char* dst = lds + lds_off(rc * 8 + i, kk >> 3) + (kk & 7) * 2;
+                uint32_t lo, hi = 0u;
+                if (i & 1) lo = (regs[0][w] >> 16) | (regs[1][w] & 0xffff0000u);
+                else       lo = (regs[0][w] & 0xffffu) | (regs[1][w] << 16);
+                if constexpr (ITERS == 4) {
+                    if (i & 1) hi = (regs[2][w] >> 16) | (regs[3][w] & 0xffff0000u);
+                    else       hi = (regs[2][w] & 0xffffu) | (regs[3][w] << 16);
+                    *reinterpret_cast<uint2*>(dst) = make_uint2(lo, hi);
+                } else {
+                    *reinterpret_cast<uint32_t*>(dst) = lo;
+                }
             }
         } else {
-            // fp32: regs[j] = 4 rows at k = kq*4 + j; row m gets 4 k values = one 16-byte chunk kq
+            // fp32: regs[j] = 4 rows at k = kk + j; row m gets ITERS k values at chunk kk/4, byte (kk%4)*4
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const U128 o = {regs[0][i], regs[1][i], regs[2][i], regs[3][i]};
-                *reinterpret_cast<U128*>(lds + lds_off(rc * 4 + i, kq)) = o;
+                char* dst = lds + lds_off(rc * 4 + i, kk >> 2) + (kk & 3) * 4;
+                if constexpr (ITERS == 4) {
+                    const U128 o = {regs[0][i], regs[1][i], regs[2][i], regs[3][i]};
+                    *reinterpret_cast<U128*>(dst) = o;
+                } else {
+                    *reinterpret_cast<uint2*>(dst) = make_uint2(regs[0][i], regs[1][i]);
+                }
             }
         }
     }
 }
 
 template <typename T, typename TO, bool TA, bool TB, bool FAST>
-__global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmArgs a) {
+__global__ __launch_bounds__(NT, NT == 512 ? 4 : 2) void gemm_kernel(GemmArgs a) {
     constexpr int BK = GemmCfg<T>::BK;
     constexpr int STAGE = (BM + BN) * ROWB;                       // 32 KB
     __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int wm = (wave / WAVES_N) * 64, wn = (wave % WAVES_N) * WTN;
     // XCD-aware tile order.  The dispatcher deals block ids round-robin to the 8 XCDs (private L2 each), so give every
     // XCD its own M panels and let consecutive blocks of one XCD walk the N tiles of one panel: the streamed operand
     // (A rows: activations, M up to millions) is then fetched from HBM once instead of once per N tile.
@@ -170,11 +188,11 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmArgs a) {
     const T* B = static_cast<const T*>(a.B);
     const U128* Z = static_cast<const U128*>(a.zeros);
 
-    f32x4_t acc[4][4];
+    f32x4_t acc[4][NTW];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     // Software pipeline, prefetch distance 2: while tile t is multiplied out of LDS stage `cur`, tile t+1 (loaded one
     // step earlier) waits in one register set and tile t+2 is being issued into the other.  The step is written out
@@ -194,31 +212,31 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmArgs a) {
         if constexpr (sizeof(T) == 2) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {               // BK = 64 = 2 MFMA k-steps of 32; lane chunk = ks*4 + fq
-                bf16x8_t fa[4], fb[4];
+                bf16x8_t fa[4], fb[NTW];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
+                for (int t = 0; t < 4; ++t)
                     fa[t] = *reinterpret_cast<const bf16x8_t*>(As + lds_off(wm + t * 16 + fr, ks * 4 + fq));
+#pragma unroll
+                for (int t = 0; t < NTW; ++t)
                     fb[t] = *reinterpret_cast<const bf16x8_t*>(Bs + lds_off(wn + t * 16 + fr, ks * 4 + fq));
-                }
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt)   // swapped operands: rows of D <-> n, cols <-> m
+                    for (int nt = 0; nt < NTW; ++nt)   // swapped operands: rows of D <-> n, cols <-> m
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
             }
         } else {
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {               // BK = 32 = 8 MFMA k-steps of 4; element k = ks*4 + fq
-                float fa[4], fb[4];
+                float fa[4], fb[NTW];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    fa[t] = *reinterpret_cast<const float*>(As + lds_off(wm + t * 16 + fr, ks) + fq * 4);
-                    fb[t] = *reinterpret_cast<const float*>(Bs + lds_off(wn + t * 16 + fr, ks) + fq * 4);
-                }
+                for (int t = 0; t < 4; ++t) fa[t] = *reinterpret_cast<const float*>(As + lds_off(wm + t * 16 + fr, ks) + fq * 4);
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) fb[t] = *reinterpret_cast<const float*>(Bs + lds_off(wn + t * 16 + fr, ks) + fq * 4);
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt)
+                    for (int nt = 0; nt < NTW; ++nt)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
             }
         }
@@ -262,12 +280,13 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmArgs a) {
     if constexpr (sizeof(TO) == 2) {
         if (a.vecC && a.splitk == 1) {
             // bf16 output: bias/act in registers, 64x64 wave tile -> LDS (8-byte writes) -> 16-byte row-contiguous stores
-            constexpr int CP = 144;                                    // bytes per staged row (64 bf16 + pad)
-            char* cs = lds + wave * 64 * CP;                           // 9 KB per wave, free since the last barrier
+            constexpr int CP = WTN * 2 + 16;                           // bytes per staged row (WTN bf16 + pad)
+            constexpr int LPR = WTN / 8, RPP = 64 / LPR;               // lanes per row, rows per pass
+            char* cs = lds + wave * 64 * CP;                           // private to the wave, free since the last barrier
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
+                for (int nt = 0; nt < NTW; ++nt) {
                     const int m = m0 + wm + mt * 16 + fr, n = n0 + wn + nt * 16 + fq * 4;
                     float v[4] = {acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]};
 #pragma unroll
@@ -282,8 +301,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmArgs a) {
                 }
             __syncthreads();
 #pragma unroll
-            for (int pass = 0; pass < 8; ++pass) {
-                const int row = pass * 8 + (lane >> 3), col = (lane & 7) * 8;
+            for (int pass = 0; pass < 64 / RPP; ++pass) {
+                const int row = pass * RPP + lane / LPR, col = (lane % LPR) * 8;
                 const int m = m0 + wm + row, n = n0 + wn + col;
                 if (m >= a.M || n >= a.N) continue;
                 uint4 val = *reinterpret_cast<const uint4*>(cs + row * CP + col * 2);
@@ -315,7 +334,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmArgs a) {
         const int m = m0 + wm + mt * 16 + fr;
         if (m >= a.M) continue;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
+        for (int nt = 0; nt < NTW; ++nt) {
             const int n = n0 + wn + nt * 16 + fq * 4;
             if (n >= a.N) continue;
             float v[4] = {acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]};
