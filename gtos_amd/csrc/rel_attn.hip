@@ -99,12 +99,30 @@ __device__ __forceinline__ bool is_masked(const AttnArgs& a, int i, int j, int b
     return m;
 }
 
+// Combined key-padding / attention mask of this wave's (i,b) row staged once in LDS (one byte per key): the per-key
+// global byte loads in the streaming loop cost a VMEM issue each and showed up as ~25 % of the kernel time.
+constexpr int MAXS_LDS = 1024;
+__device__ __forceinline__ const unsigned char* stage_mask(const AttnArgs& a, bool ok, int i, int b, unsigned char (*smask)[MAXS_LDS]) {
+    const bool use = (a.key_pad || a.attn_mask) && a.S <= MAXS_LDS;
+    unsigned char* sm = smask[threadIdx.x >> 6];
+    if (use && ok) for (int j = threadIdx.x & 63; j < a.S; j += 64) sm[j] = is_masked(a, i, j, b) ? 1 : 0;
+    __syncthreads();                 // every wave of the block reaches this (the out-of-range ones return after it)
+    return use ? sm : nullptr;
+}
+__device__ __forceinline__ bool key_dead(const AttnArgs& a, const unsigned char* sm, int i, int j, int b) {
+    if (sm) return sm[j] != 0;
+    return (a.key_pad || a.attn_mask) ? is_masked(a, i, j, b) : false;
+}
+
 // ------------------------------------------------------------------------------------------- forward
 template <typename T, int LH>
 __global__ __launch_bounds__(256) void rel_attn_fwd_kernel(AttnArgs a) {
     constexpr int U = Unroll<T>::U;
+    __shared__ unsigned char smask[4][MAXS_LDS];
     int i, b;
-    if (!map_block(a.T, a.B, i, b)) return;
+    const bool ok = map_block(a.T, a.B, i, b);
+    const unsigned char* sm = stage_mask(a, ok, i, b, smask);
+    if (!ok) return;
     const int lane = threadIdx.x & 63;
     const int d = a.d, LR = d >> 3, G = 64 / LR, g = lane / LR, cl = lane % LR, c = cl * 8, h = cl / LH;
     const T* qp = static_cast<const T*>(a.q) + ((int64_t)i * a.B + b) * a.ldq + c;
@@ -153,7 +171,7 @@ __global__ __launch_bounds__(256) void rel_attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) s = fmaf(qf[e] + ra[e], kf[e] + rb[e], s);
             s = head_sum<LH>(s) * a.scale;
-            const bool dead = (j >= a.S) || is_masked(a, i, j, b);
+            const bool dead = (j >= a.S) || key_dead(a, sm, i, j, b);
             if (dead) s = -INFINITY;
             if (a.w && j < a.S && (cl % LH) == 0) a.w[(((int64_t)i * a.S + j) * a.B + b) * a.H + h] = s;
             const float mn = fmaxf(m, s);
@@ -204,8 +222,11 @@ __global__ __launch_bounds__(256) void rel_attn_fwd_kernel(AttnArgs a) {
 template <typename T, int LH>
 __global__ __launch_bounds__(256) void rel_attn_bwd_q_kernel(AttnArgs a) {
     constexpr int U = Unroll<T>::U;
+    __shared__ unsigned char smask[4][MAXS_LDS];
     int i, b;
-    if (!map_block(a.T, a.B, i, b)) return;
+    const bool ok = map_block(a.T, a.B, i, b);
+    const unsigned char* sm = stage_mask(a, ok, i, b, smask);
+    if (!ok) return;
     const int lane = threadIdx.x & 63;
     const int d = a.d, LR = d >> 3, G = 64 / LR, g = lane / LR, cl = lane % LR, c = cl * 8, h = cl / LH;
     const int64_t row = (int64_t)i * a.B + b;
@@ -277,7 +298,7 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_q_kernel(AttnArgs a) {
             s = head_sum<LH>(s) * a.scale;
             dpv = head_sum<LH>(dpv);
             const int64_t off = (((int64_t)i * a.S + j) * a.B + b) * a.H + h;
-            const bool dead = is_masked(a, i, j, b) || lse == -INFINITY;
+            const bool dead = key_dead(a, sm, i, j, b) || lse == -INFINITY;
             const float p = dead ? 0.f : __expf(s - lse);
             float keep = 1.f;
             if (a.p_drop > 0.f) keep = drop_keep(a.seed, (uint64_t)off, a.p_drop) ? keep_scale : 0.f;

@@ -354,3 +354,76 @@ def test_full_size_properties_c2_shape():
     qkv2[:, :, 2 * d:] *= 2
     o2, _ = ops.attention_core(qkv2, None, (0, d, 2 * d), d, H, 0.125, rel=bankp, fact=fact, key_pad=pad)
     torch.testing.assert_close(o2.float(), 2 * o_f.float(), rtol=2e-2, atol=2e-2)
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE configs vs the oracle
+def _full_model_pair(cfg_name, B, layers=None):
+    """Product Generator on the GPU and the pinned oracle on the CPU with identical weights (train.sh dims, dropout 0)."""
+    import copy
+    from gtos_amd import synth
+    from gtos_amd.config import default_vocabs, generator_args
+    from gtos_amd.generator import Generator
+    from oracle import gtos_oracle as O
+    cfg = dict(synth.CONFIGS[cfg_name])
+    if layers:
+        cfg["layers"] = layers
+    args = generator_args(cfg)
+    args["dropout"] = 0.0
+    depth = 256 if cfg["kind"] == "dep" else 32
+    torch.manual_seed(11)
+    ref = O.Generator({k: O.VocabSpec(v.size, 0) for k, v in default_vocabs().items()}, depth_size=depth, **args)
+    for p in ref.parameters():
+        if p.dim() == 1 or float(p.abs().sum()) == 0:
+            p.data.add_(0.02 * torch.randn_like(p))
+    m = Generator(default_vocabs(), device=dev(), depth_size=depth, **args).to(dev())
+    m.load_state_dict(ref.state_dict())
+    batch, stats = synth.make_config_batch(cfg_name, B=B, padded=True)
+    return ref, m, batch, stats
+
+
+@pytest.mark.parametrize("cfg_name,B", [("C1", 8), ("C3", 3)])
+def test_baseline_config_full_step_vs_oracle(cfg_name, B):
+    """C1 (the reference's own CPU-runnable case, full size) and a translator-flavour C3 slice: loss and every parameter
+    gradient of the full model against the oracle, fp32."""
+    ref, m, batch, stats = _full_model_pair(cfg_name, B, layers=2 if cfg_name == "C3" else None)
+    ref.train()
+    m.train()
+    loss_r = ref(batch)
+    loss_r.backward()
+    loss = m({k: v.to(dev()) for k, v in batch.items()})
+    loss.backward()
+    assert abs(loss.item() - loss_r.item()) < 1e-3 * max(1.0, abs(loss_r.item())), (loss.item(), loss_r.item())
+    for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        err = (p.grad.cpu() - q.grad).abs().max().item()
+        assert err < 1e-3 + 2e-3 * q.grad.abs().max().item(), (k, err, q.grad.abs().max().item())
+
+
+def test_baseline_config_c1_bf16_loss():
+    ref, m, batch, stats = _full_model_pair("C1", 8)
+    m.set_compute_dtype(torch.bfloat16)
+    ref.train()
+    m.train()
+    loss_r = ref(batch).item()
+    loss = m({k: v.to(dev()) for k, v in batch.items()}).item()
+    assert abs(loss - loss_r) < 1e-2 * max(1.0, abs(loss_r)), (loss, loss_r)
+
+
+def test_trainer_two_steps_reduce_loss_and_keep_mirror_in_sync():
+    """Flat-bucket trainer on C1 in bf16: loss is finite, parameters move, the bf16 mirror tracks the fp32 masters."""
+    from gtos_amd import synth
+    from gtos_amd.config import build_generator
+    from gtos_amd.generator import Generator
+    from gtos_amd.train import Trainer
+    m = build_generator(Generator, "C1", dev()).to(dev())
+    m.set_compute_dtype(torch.bfloat16)
+    m.train()
+    tr = Trainer(m, 256, warmup_steps=5, compute_dtype=torch.bfloat16)
+    batch, _ = synth.make_config_batch("C1")
+    batch = {k: v.to(dev()) for k, v in batch.items()}
+    before = tr.flat.param.clone()
+    losses = [tr.step(batch) for _ in range(6)]
+    assert all(l is not None and np.isfinite(l) for l in losses)
+    assert losses[-1] < losses[0]
+    assert float((tr.flat.param - before).abs().max()) > 0
+    torch.testing.assert_close(tr.flat.mirror.float(), tr.flat.param, rtol=1e-2, atol=1e-3)
+    assert float(tr.flat.grad.abs().max()) == 0.0
