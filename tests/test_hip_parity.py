@@ -373,7 +373,7 @@ def _full_model_pair(cfg_name, B, layers=None):
     torch.manual_seed(11)
     ref = O.Generator({k: O.VocabSpec(v.size, 0) for k, v in default_vocabs().items()}, depth_size=depth, **args)
     for p in ref.parameters():
-        if p.dim() == 1 or float(p.abs().sum()) == 0:
+        if p.dim() == 1 or float(p.detach().abs().sum()) == 0:
             p.data.add_(0.02 * torch.randn_like(p))
     m = Generator(default_vocabs(), device=dev(), depth_size=depth, **args).to(dev())
     m.load_state_dict(ref.state_dict())
@@ -417,11 +417,11 @@ def test_trainer_two_steps_reduce_loss_and_keep_mirror_in_sync():
     m = build_generator(Generator, "C1", dev()).to(dev())
     m.set_compute_dtype(torch.bfloat16)
     m.train()
-    tr = Trainer(m, 256, warmup_steps=5, compute_dtype=torch.bfloat16)
+    tr = Trainer(m, 256, warmup_steps=100, compute_dtype=torch.bfloat16)      # lr(step 8) = 5e-4
     batch, _ = synth.make_config_batch("C1")
     batch = {k: v.to(dev()) for k, v in batch.items()}
     before = tr.flat.param.clone()
-    losses = [tr.step(batch) for _ in range(6)]
+    losses = [tr.step(batch) for _ in range(8)]
     assert all(l is not None and np.isfinite(l) for l in losses)
     assert losses[-1] < losses[0]
     assert float((tr.flat.param - before).abs().max()) > 0
