@@ -25,17 +25,17 @@
 namespace {
 
 constexpr int BM = 128, BN = 128;
-#ifndef GTOS_GEMM_THREADS
-#define GTOS_GEMM_THREADS 512
-#endif
-constexpr int NT = GTOS_GEMM_THREADS;          // 256: 4 waves (2x2, 64x64 each); 512: 8 waves (2x4, 64x32 each)
-constexpr int WAVES_N = NT / 128, WTN = BN / WAVES_N, NTW = WTN / 16;   // wave tile width, MFMA tiles per wave along N
 constexpr int ROWB = 128;                       // bytes per LDS row (BK elements)
 
 template <typename T> struct GemmCfg;
 template <> struct GemmCfg<bf16_t> { static constexpr int BK = 64, VEC = 8; };
 template <> struct GemmCfg<float>  { static constexpr int BK = 32, VEC = 4; };
-constexpr int ITERS = 1024 / NT;                // 16-byte vectors per thread per operand tile (128 rows x 128 B / NT / 16)
+
+// Workgroup shapes: 256 threads = 4 waves (2x2, 64x64 per wave), 512 threads = 8 waves (2x4, 64x32 per wave).
+template <int NTH> struct TCfg {
+    static constexpr int NT = NTH, WAVES_N = NTH / 128, WTN = BN / WAVES_N, NTW = WTN / 16;
+    static constexpr int ITERS = 1024 / NTH;    // 16-byte vectors per thread per operand tile (128 rows x 128 B / NTH / 16)
+};
 
 // 16 bytes of zeros in GLOBAL memory (allocated once per process): target of out-of-range tile loads.  A __device__
 // constant would make the selected pointer generic and turn the tile loads into flat loads.
@@ -67,10 +67,10 @@ __device__ __forceinline__ int lds_off(int r, int c) { return r * ROWB + ((c ^ s
 // ---- global -> register tile load.  KC=true: operand rows are K-contiguous ([rows, K], ld): thread vector v covers
 //      row v/8, chunk v%8.  KC=false: operand stored [K, rows] (rows contiguous): thread t covers 4 consecutive k
 //      and one chunk of VEC consecutive rows (to be transposed on the LDS write).
-template <typename T, bool KC, bool FAST>
+template <typename T, bool KC, bool FAST, int NTH>
 __device__ __forceinline__ void load_tile(const T* __restrict__ base, const U128* __restrict__ zeros, int64_t ld, int rows_total,
-                                          int row0, int k0, int kend, U128 (&regs)[ITERS]) {
-    constexpr int VEC = GemmCfg<T>::VEC;
+                                          int row0, int k0, int kend, U128 (&regs)[TCfg<NTH>::ITERS]) {
+    constexpr int VEC = GemmCfg<T>::VEC, NT = NTH, ITERS = TCfg<NTH>::ITERS;
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         int r, k;
@@ -103,10 +103,31 @@ __device__ __forceinline__ void load_tile(const T* __restrict__ base, const U128
     }
 }
 
+// ---- global -> LDS directly (K-contiguous operands, fast path): global_load_lds_dwordx4 writes wave-uniform base +
+//      lane*16, i.e. 8 whole 128-byte rows per wave-instruction; the chunk swizzle is applied on the per-lane SOURCE
+//      address (lane p of a row fetches logical chunk p ^ f(row)).  No staging VGPRs, no ds_write issue slots.
+template <typename T, int NTH>
+__device__ __forceinline__ void glds_tile(const T* __restrict__ base, const U128* __restrict__ zeros, int64_t ld, int rows_total,
+                                          int row0, int k0, int kend, char* lds_tile) {
+    constexpr int VEC = GemmCfg<T>::VEC, NT = NTH, ITERS = TCfg<NTH>::ITERS;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int blk = it * (NT / 64) + wave;                    // 1 KB block = rows blk*8 .. blk*8+7
+        const int rl = blk * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ swz(rl);
+        const int r = row0 + rl, k = k0 + c * VEC;
+        const bool ok = r < rows_total && k + VEC <= kend;
+        const void* src = ok ? static_cast<const void*>(base + (int64_t)r * ld + k) : static_cast<const void*>(zeros);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds_tile + blk * 1024), 16, 0, 0);
+    }
+}
+
 // ---- register -> LDS.  `lds` is the byte base of this operand's tile in the target stage.
-template <typename T, bool KC>
-__device__ __forceinline__ void store_tile(char* __restrict__ lds, const U128 (&regs)[ITERS]) {
-    constexpr int VEC = GemmCfg<T>::VEC;
+template <typename T, bool KC, int NTH>
+__device__ __forceinline__ void store_tile(char* __restrict__ lds, const U128 (&regs)[TCfg<NTH>::ITERS]) {
+    constexpr int VEC = GemmCfg<T>::VEC, NT = NTH, ITERS = TCfg<NTH>::ITERS;
     if (KC) {
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
@@ -150,11 +171,15 @@ __device__ __forceinline__ void store_tile(char* __restrict__ lds, const U128 (&
     }
 }
 
-template <typename T, typename TO, bool TA, bool TB, bool FAST>
-__global__ __launch_bounds__(NT, NT == 512 ? 4 : 2) void gemm_kernel(GemmArgs a) {
+// NTH/STAGES: 512 threads + 2 LDS stages (register-staged or mixed operands), or 256 threads + ONE stage when both
+// operands go global->LDS directly (forward Linear): 32 KB of LDS and ~110 VGPRs let 4 workgroups share a CU, whose
+// interleaving hides the load latency, and a 64x64 wave tile needs a third fewer LDS fragment reads per MFMA.
+template <typename T, typename TO, bool TA, bool TB, bool FAST, int NTH, int STAGES>
+__global__ __launch_bounds__(NTH, 4) void gemm_kernel(GemmArgs a) {
     constexpr int BK = GemmCfg<T>::BK;
+    constexpr int NT = NTH, WAVES_N = TCfg<NTH>::WAVES_N, WTN = TCfg<NTH>::WTN, NTW = TCfg<NTH>::NTW, ITERS = TCfg<NTH>::ITERS;
     constexpr int STAGE = (BM + BN) * ROWB;                       // 32 KB
-    __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+    __shared__ __attribute__((aligned(16))) char lds[STAGES * STAGE];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = (wave / WAVES_N) * 64, wn = (wave % WAVES_N) * WTN;
@@ -199,15 +224,6 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 2) void gemm_kernel(GemmArgs a)
     // twice so the two register sets are named, never indexed.  Only the OLDER set is waited for at the end of a step
     // (s_waitcnt vmcnt(8) leaves the 8 newest loads in flight), so HBM latency has two steps of MFMAs to hide under.
     const int fr = lane & 15, fq = lane >> 4;
-    U128 ra0[ITERS], rb0[ITERS], ra1[ITERS], rb1[ITERS];
-    load_tile<T, !TA, FAST>(A, Z, a.lda, a.M, m0, kbeg, kend, ra0);
-    load_tile<T, TB, FAST>(B, Z, a.ldb, a.N, n0, kbeg, kend, rb0);
-    store_tile<T, !TA>(lds, ra0);
-    store_tile<T, TB>(lds + BM * ROWB, rb0);
-    load_tile<T, !TA, FAST>(A, Z, a.lda, a.M, m0, kbeg + BK, kend, ra0);
-    load_tile<T, TB, FAST>(B, Z, a.ldb, a.N, n0, kbeg + BK, kend, rb0);
-    __syncthreads();
-
     auto mma_stage = [&](const char* As, const char* Bs) {
         if constexpr (sizeof(T) == 2) {
 #pragma unroll
@@ -242,18 +258,43 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 2) void gemm_kernel(GemmArgs a)
         }
     };
 
+    if constexpr (STAGES == 1) {
+        // both operands by global_load_lds into the single stage; the other resident workgroups cover the wait
+        static_assert(!(STAGES == 1) || (FAST && !TA && TB), "single-stage variant is the all-DMA forward kernel");
+        for (int k0 = kbeg; k0 < kend; k0 += BK) {
+            glds_tile<T, NTH>(A, Z, a.lda, a.M, m0, k0, kend, lds);
+            glds_tile<T, NTH>(B, Z, a.ldb, a.N, n0, k0, kend, lds + BM * ROWB);
+            __syncthreads();                               // hipcc drains the DMA (vmcnt(0)) in front of the barrier
+            mma_stage(lds, lds + BM * ROWB);
+            __syncthreads();                               // every wave is done reading before the next tile lands
+        }
+    } else {
+    // K-contiguous operands on the fast path go global -> LDS directly (prefetch distance 1: the barrier drains the
+    // DMA); the others through the two register sets (distance 2).
+    constexpr bool GA = FAST && !TA, GB = FAST && TB;
+    U128 ra0[ITERS], rb0[ITERS], ra1[ITERS], rb1[ITERS];
+    if constexpr (GA) glds_tile<T, NTH>(A, Z, a.lda, a.M, m0, kbeg, kend, lds);
+    else { load_tile<T, !TA, FAST, NTH>(A, Z, a.lda, a.M, m0, kbeg, kend, ra0); store_tile<T, !TA, NTH>(lds, ra0);
+           load_tile<T, !TA, FAST, NTH>(A, Z, a.lda, a.M, m0, kbeg + BK, kend, ra0); }
+    if constexpr (GB) glds_tile<T, NTH>(B, Z, a.ldb, a.N, n0, kbeg, kend, lds + BM * ROWB);
+    else { load_tile<T, TB, FAST, NTH>(B, Z, a.ldb, a.N, n0, kbeg, kend, rb0); store_tile<T, TB, NTH>(lds + BM * ROWB, rb0);
+           load_tile<T, TB, FAST, NTH>(B, Z, a.ldb, a.N, n0, kbeg + BK, kend, rb0); }
+    __syncthreads();
+
     int cur = 0;
     for (int k0 = kbeg; k0 < kend; k0 += 2 * BK) {
         {   // even step: tile k0 in stage cur, tile k0+BK in flight in set 0, issue tile k0+2BK into set 1
             const char* As = lds + cur * STAGE;
             char* An = lds + (cur ^ 1) * STAGE;
-            load_tile<T, !TA, FAST>(A, Z, a.lda, a.M, m0, k0 + 2 * BK, kend, ra1);
-            load_tile<T, TB, FAST>(B, Z, a.ldb, a.N, n0, k0 + 2 * BK, kend, rb1);
+            if constexpr (GA) glds_tile<T, NTH>(A, Z, a.lda, a.M, m0, k0 + BK, kend, An);
+            else load_tile<T, !TA, FAST, NTH>(A, Z, a.lda, a.M, m0, k0 + 2 * BK, kend, ra1);
+            if constexpr (GB) glds_tile<T, NTH>(B, Z, a.ldb, a.N, n0, k0 + BK, kend, An + BM * ROWB);
+            else load_tile<T, TB, FAST, NTH>(B, Z, a.ldb, a.N, n0, k0 + 2 * BK, kend, rb1);
             __builtin_amdgcn_sched_barrier(0);             // keep the loads ahead of the MFMA block (hipcc sinks them)
             mma_stage(As, As + BM * ROWB);
             __builtin_amdgcn_sched_barrier(0);
-            store_tile<T, !TA>(An, ra0);                   // write late: the other stage is free since the last barrier
-            store_tile<T, TB>(An + BM * ROWB, rb0);
+            if constexpr (!GA) store_tile<T, !TA, NTH>(An, ra0); // write late: the other stage is free since the last barrier
+            if constexpr (!GB) store_tile<T, TB, NTH>(An + BM * ROWB, rb0);
             __syncthreads();
             cur ^= 1;
         }
@@ -261,16 +302,20 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 2) void gemm_kernel(GemmArgs a)
         {   // odd step: roles of the register sets swapped
             const char* As = lds + cur * STAGE;
             char* An = lds + (cur ^ 1) * STAGE;
-            load_tile<T, !TA, FAST>(A, Z, a.lda, a.M, m0, k0 + 3 * BK, kend, ra0);
-            load_tile<T, TB, FAST>(B, Z, a.ldb, a.N, n0, k0 + 3 * BK, kend, rb0);
+            if constexpr (GA) glds_tile<T, NTH>(A, Z, a.lda, a.M, m0, k0 + 2 * BK, kend, An);
+            else load_tile<T, !TA, FAST, NTH>(A, Z, a.lda, a.M, m0, k0 + 3 * BK, kend, ra0);
+            if constexpr (GB) glds_tile<T, NTH>(B, Z, a.ldb, a.N, n0, k0 + 2 * BK, kend, An + BM * ROWB);
+            else load_tile<T, TB, FAST, NTH>(B, Z, a.ldb, a.N, n0, k0 + 3 * BK, kend, rb0);
             __builtin_amdgcn_sched_barrier(0);
             mma_stage(As, As + BM * ROWB);
             __builtin_amdgcn_sched_barrier(0);
-            store_tile<T, !TA>(An, ra1);
-            store_tile<T, TB>(An + BM * ROWB, rb1);
+            if constexpr (!GA) store_tile<T, !TA, NTH>(An, ra1);
+            if constexpr (!GB) store_tile<T, TB, NTH>(An + BM * ROWB, rb1);
             __syncthreads();
             cur ^= 1;
         }
+    }
+
     }
 
     // ---- epilogue: lane holds C[m = .. + fr][n = .. + fq*4 + 0..3]
@@ -282,46 +327,51 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 2) void gemm_kernel(GemmArgs a)
             // bf16 output: bias/act in registers, 64x64 wave tile -> LDS (8-byte writes) -> 16-byte row-contiguous stores
             constexpr int CP = WTN * 2 + 16;                           // bytes per staged row (WTN bf16 + pad)
             constexpr int LPR = WTN / 8, RPP = 64 / LPR;               // lanes per row, rows per pass
-            char* cs = lds + wave * 64 * CP;                           // private to the wave, free since the last barrier
+            char* cs = lds + wave * 32 * CP;                           // private to the wave; 32 rows at a time so that
+#pragma unroll                                                         // 4 waves x 32 x 144 B fit the one-stage 32 KB
+            for (int half = 0; half < 2; ++half) {
+                if (half) __syncthreads();                             // the first half has been read back
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+                for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
-                for (int nt = 0; nt < NTW; ++nt) {
-                    const int m = m0 + wm + mt * 16 + fr, n = n0 + wn + nt * 16 + fq * 4;
-                    float v[4] = {acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]};
+                    for (int nt = 0; nt < NTW; ++nt) {
+                        const int mt = half * 2 + mh;
+                        const int m = m0 + wm + mt * 16 + fr, n = n0 + wn + nt * 16 + fq * 4;
+                        float v[4] = {acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]};
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        if (a.bias && n + i < a.N) v[i] += a.bias[n + i];
-                        if (a.relu) v[i] = fmaxf(v[i], 0.f);
-                        if (a.p_drop > 0.f)
-                            v[i] = drop_keep(a.seed, (uint64_t)m * (uint64_t)a.N + (uint64_t)(n + i), a.p_drop) ? v[i] * keep_scale : 0.f;
+                        for (int i = 0; i < 4; ++i) {
+                            if (a.bias && n + i < a.N) v[i] += a.bias[n + i];
+                            if (a.relu) v[i] = fmaxf(v[i], 0.f);
+                            if (a.p_drop > 0.f)
+                                v[i] = drop_keep(a.seed, (uint64_t)m * (uint64_t)a.N + (uint64_t)(n + i), a.p_drop) ? v[i] * keep_scale : 0.f;
+                        }
+                        *reinterpret_cast<uint2*>(cs + (mh * 16 + fr) * CP + (nt * 16 + fq * 4) * 2) =
+                            make_uint2(pack_bf(v[0], v[1]), pack_bf(v[2], v[3]));
                     }
-                    *reinterpret_cast<uint2*>(cs + (mt * 16 + fr) * CP + (nt * 16 + fq * 4) * 2) =
-                        make_uint2(pack_bf(v[0], v[1]), pack_bf(v[2], v[3]));
-                }
-            __syncthreads();
+                __syncthreads();
 #pragma unroll
-            for (int pass = 0; pass < 64 / RPP; ++pass) {
-                const int row = pass * RPP + lane / LPR, col = (lane % LPR) * 8;
-                const int m = m0 + wm + row, n = n0 + wn + col;
-                if (m >= a.M || n >= a.N) continue;
-                uint4 val = *reinterpret_cast<const uint4*>(cs + row * CP + col * 2);
-                bf16_t* cp = reinterpret_cast<bf16_t*>(C) + (int64_t)m * a.ldc + n;
-                if (n + 8 <= a.N) {
-                    if (a.accumulate) {
-                        const uint4 old = *reinterpret_cast<const uint4*>(cp);
-                        val = make_uint4(pack_bf(lo_bf(val.x) + lo_bf(old.x), hi_bf(val.x) + hi_bf(old.x)),
-                                         pack_bf(lo_bf(val.y) + lo_bf(old.y), hi_bf(val.y) + hi_bf(old.y)),
-                                         pack_bf(lo_bf(val.z) + lo_bf(old.z), hi_bf(val.z) + hi_bf(old.z)),
-                                         pack_bf(lo_bf(val.w) + lo_bf(old.w), hi_bf(val.w) + hi_bf(old.w)));
-                    }
-                    *reinterpret_cast<uint4*>(cp) = val;
-                } else {
-                    const bf16_t* e = reinterpret_cast<const bf16_t*>(cs + row * CP + col * 2);
-                    for (int i = 0; i < 8 && n + i < a.N; ++i) {
-                        float o = bf2f(e[i]);
-                        if (a.accumulate) o += bf2f(cp[i]);
-                        cp[i] = f2bf(o);
+                for (int pass = 0; pass < 32 / RPP; ++pass) {
+                    const int row = pass * RPP + lane / LPR, col = (lane % LPR) * 8;
+                    const int m = m0 + wm + half * 32 + row, n = n0 + wn + col;
+                    if (m >= a.M || n >= a.N) continue;
+                    uint4 val = *reinterpret_cast<const uint4*>(cs + row * CP + col * 2);
+                    bf16_t* cp = reinterpret_cast<bf16_t*>(C) + (int64_t)m * a.ldc + n;
+                    if (n + 8 <= a.N) {
+                        if (a.accumulate) {
+                            const uint4 old = *reinterpret_cast<const uint4*>(cp);
+                            val = make_uint4(pack_bf(lo_bf(val.x) + lo_bf(old.x), hi_bf(val.x) + hi_bf(old.x)),
+                                             pack_bf(lo_bf(val.y) + lo_bf(old.y), hi_bf(val.y) + hi_bf(old.y)),
+                                             pack_bf(lo_bf(val.z) + lo_bf(old.z), hi_bf(val.z) + hi_bf(old.z)),
+                                             pack_bf(lo_bf(val.w) + lo_bf(old.w), hi_bf(val.w) + hi_bf(old.w)));
+                        }
+                        *reinterpret_cast<uint4*>(cp) = val;
+                    } else {
+                        const bf16_t* e = reinterpret_cast<const bf16_t*>(cs + row * CP + col * 2);
+                        for (int i = 0; i < 8 && n + i < a.N; ++i) {
+                            float o = bf2f(e[i]);
+                            if (a.accumulate) o += bf2f(cp[i]);
+                            cp[i] = f2bf(o);
+                        }
                     }
                 }
             }
@@ -374,16 +424,18 @@ int launch(const GemmArgs& a, int transA, int transB, hipStream_t s) {
     const long long nMt = (a.M + BM - 1) / BM, nNt = (a.N + BN - 1) / BN;
     const long long nblk = a.splitk > 1 ? nMt * nNt * 8 * ((a.splitk + 7) / 8) : ((nMt + 7) / 8) * 8 * nNt;
     if (nblk > 0x7fffffffLL) return -6;
-    dim3 grid((unsigned)nblk), block(NT);
+    dim3 grid((unsigned)nblk);
     const bool fast = a.vecA && a.vecB;          // both operands 16-byte aligned with whole vectors in range
-#define GTOS_LAUNCH(TA_, TB_) do { \
-        if (fast) hipLaunchKernelGGL((gemm_kernel<T, TO, TA_, TB_, true>), grid, block, 0, s, a); \
-        else      hipLaunchKernelGGL((gemm_kernel<T, TO, TA_, TB_, false>), grid, block, 0, s, a); } while (0)
-    if (!transA && transB)       GTOS_LAUNCH(false, true);
-    else if (!transA && !transB) GTOS_LAUNCH(false, false);
-    else if (transA && !transB)  GTOS_LAUNCH(true, false);
-    else return -2;
-#undef GTOS_LAUNCH
+    if (!transA && transB) {
+        if (fast) hipLaunchKernelGGL((gemm_kernel<T, TO, false, true, true, 256, 1>), grid, dim3(256), 0, s, a);
+        else      hipLaunchKernelGGL((gemm_kernel<T, TO, false, true, false, 512, 2>), grid, dim3(512), 0, s, a);
+    } else if (!transA && !transB) {
+        if (fast) hipLaunchKernelGGL((gemm_kernel<T, TO, false, false, true, 512, 2>), grid, dim3(512), 0, s, a);
+        else      hipLaunchKernelGGL((gemm_kernel<T, TO, false, false, false, 512, 2>), grid, dim3(512), 0, s, a);
+    } else if (transA && !transB) {
+        if (fast) hipLaunchKernelGGL((gemm_kernel<T, TO, true, false, true, 512, 2>), grid, dim3(512), 0, s, a);
+        else      hipLaunchKernelGGL((gemm_kernel<T, TO, true, false, false, 512, 2>), grid, dim3(512), 0, s, a);
+    } else return -2;
     GTOS_CHECK_LAUNCH();
     return 0;
 }
