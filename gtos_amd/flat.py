@@ -79,3 +79,5 @@ class FlatParams:
                  self.m.data_ptr() + lo * es, self.v.data_ptr() + lo * es, float(lr), b1, b2, self.eps, wd,
                  float(gscale), ptr(self.sqnorm), float(max_norm), mir, stream())
         self.steps += 1
+        from . import ops
+        ops.PARAM_EPOCH[0] += 1

@@ -9,7 +9,7 @@ import torch
 
 from . import _lib
 from ._lib import call, dt, ptr, stream
-from .ops import gemm, compute_weight, next_seed, _grad_target, _splitk
+from .ops import gemm, compute_weight, next_seed, weight_t, _grad_target, _splitk
 
 
 def _cell_fwd(A, hs, xg, hg, h, y, y_off_elems, ldy, hprev, gates, p, seed, drop_base):
@@ -92,11 +92,12 @@ class BiGRUFinalFn(torch.autograd.Function):
                 dxg = torch.empty((N, 3 * hs), dtype=dtp, device=dev)
                 dhg = torch.empty((N, 3 * hs), dtype=dtp, device=dev)
                 steps = range(L - 1, -1, -1) if direction == 0 else range(L)
+                wh_t, wi_t = weight_t(wh), weight_t(wi)
                 for t in steps:
                     A, off = batch_sizes[t], offs[t]
                     _cell_bwd(A, hs, gates[off:off + A], hprev[off:off + A], dY, off * 2 * hs + direction * hs, 2 * hs,
                               dh, dxg[off:off + A], dhg[off:off + A], pl, seed, off * 2 * hs + direction * hs)
-                    gemm(dhg[off:off + A], wh, out=dh[:A], accumulate=True)          # dh += d(hg) W_hh
+                    gemm(dhg[off:off + A], wh_t, trans_b=True, out=dh[:A], accumulate=True)   # dh += d(hg) W_hh
                 # parameter gradients over all steps at once
                 for (wt, dyv, xin, slot) in ((w_hh, dhg, hprev, 1), (w_ih, dxg, inp, 0)):
                     if wt.requires_grad:
@@ -112,9 +113,9 @@ class BiGRUFinalFn(torch.autograd.Function):
                         call("gtos_colsum", dt(dyv), N, 3 * hs, 3 * hs, ptr(dyv), ptr(tgt), stream())
                 if l > 0 or ctx.needs_input_grad[0]:
                     if d_inp is None:
-                        d_inp = gemm(dxg, wi)
+                        d_inp = gemm(dxg, wi_t, trans_b=True)
                     else:
-                        gemm(dxg, wi, out=d_inp, accumulate=True)
+                        gemm(dxg, wi_t, trans_b=True, out=d_inp, accumulate=True)
             dY = d_inp
         return (dY if ctx.needs_input_grad[0] else None, None, None, None, None) + tuple(grads)
 

@@ -93,6 +93,26 @@ def compute_weight(w, dtype):
     return w.detach().to(dtype)
 
 
+PARAM_EPOCH = [0]          # bumped by FlatParams.step(): invalidates cached weight transposes
+
+
+_WT_CACHE = {}
+
+
+def weight_t(w):
+    """Contiguous transpose of a (compute-dtype) weight, cached until the parameters change.  dX = dY W is then run as
+    dY (W^T)^T through the all-DMA forward GEMM kernel instead of the slower transposing NN variant."""
+    key = (w.data_ptr(), w._version, tuple(w.shape), w.dtype)
+    ent = _WT_CACHE.get(key)
+    if ent is not None and ent[0] == PARAM_EPOCH[0]:
+        return ent[1]
+    if len(_WT_CACHE) > 4096:
+        _WT_CACHE.clear()
+    t = w.detach().t().contiguous()
+    _WT_CACHE[key] = (PARAM_EPOCH[0], t)
+    return t
+
+
 def _grad_target(p):
     """Pre-allocated .grad (a view of the flat gradient bucket) to accumulate into, or None."""
     if not p.is_leaf:
@@ -138,7 +158,7 @@ class LinearFn(torch.autograd.Function):
                 raise _lib.GtosHipError("dropout without relu is not fused in LinearFn")
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = gemm(dy2, w).view(shp)
+            dx = gemm(dy2, weight_t(w), trans_b=True).view(shp)
         if ctx.needs_input_grad[1]:
             tgt = _grad_target(weight)
             M, N, K = w.shape[0], w.shape[1], dy2.shape[0]
