@@ -63,7 +63,7 @@ class BiGRUFinalFn(torch.autograd.Function):
                     _cell_fwd(A, hs, xg[off:off + A], hg, h, Y, off * 2 * hs + direction * hs, 2 * hs,
                               hprev[off:off + A], gates[off:off + A], pl, seed, off * 2 * hs + direction * hs)
                 finals.append(h)
-                layer_saved.append((wi, wh, gates, hprev))
+                layer_saved.append((weight_t(w_ih, wi), weight_t(w_hh, wh), gates, hprev))
             saved.append((inp, seed, pl, layer_saved))
             inp = Y
         ctx.cfg = (batch_sizes, offs, hs, num_layers, weights, saved)
@@ -82,7 +82,7 @@ class BiGRUFinalFn(torch.autograd.Function):
             dtp = inp.dtype
             d_inp = None
             for direction in (0, 1):
-                wi, wh, gates, hprev = layer_saved[direction]
+                wi_t, wh_t, gates, hprev = layer_saved[direction]
                 base = l * 8 + direction * 4
                 w_ih, w_hh, b_ih, b_hh = weights[base:base + 4]
                 if l == num_layers - 1:
@@ -92,7 +92,6 @@ class BiGRUFinalFn(torch.autograd.Function):
                 dxg = torch.empty((N, 3 * hs), dtype=dtp, device=dev)
                 dhg = torch.empty((N, 3 * hs), dtype=dtp, device=dev)
                 steps = range(L - 1, -1, -1) if direction == 0 else range(L)
-                wh_t, wi_t = weight_t(wh), weight_t(wi)
                 for t in steps:
                     A, off = batch_sizes[t], offs[t]
                     _cell_bwd(A, hs, gates[off:off + A], hprev[off:off + A], dY, off * 2 * hs + direction * hs, 2 * hs,

@@ -96,20 +96,23 @@ def compute_weight(w, dtype):
 PARAM_EPOCH = [0]          # bumped by FlatParams.step(): invalidates cached weight transposes
 
 
-_WT_CACHE = {}
-
-
-def weight_t(w):
-    """Contiguous transpose of a (compute-dtype) weight, cached until the parameters change.  dX = dY W is then run as
-    dY (W^T)^T through the all-DMA forward GEMM kernel instead of the slower transposing NN variant."""
-    key = (w.data_ptr(), w._version, tuple(w.shape), w.dtype)
-    ent = _WT_CACHE.get(key)
-    if ent is not None and ent[0] == PARAM_EPOCH[0]:
+def weight_t(param, w, rows=None):
+    """Contiguous transpose of the compute-dtype weight ``w`` derived from ``param`` (optionally its row block), cached
+    ON the parameter object until the parameters change.  dX = dY W then runs as dY (W^T)^T through the all-DMA
+    forward GEMM kernel instead of the slower transposing NN variant."""
+    stamp = (PARAM_EPOCH[0], param._version, param.data_ptr())
+    cache = getattr(param, "_gtos_wt", None)
+    if cache is None:
+        cache = {}
+        try:
+            param._gtos_wt = cache
+        except Exception:
+            pass
+    ent = cache.get((w.dtype, rows))
+    if ent is not None and ent[0] == stamp:
         return ent[1]
-    if len(_WT_CACHE) > 4096:
-        _WT_CACHE.clear()
     t = w.detach().t().contiguous()
-    _WT_CACHE[key] = (PARAM_EPOCH[0], t)
+    cache[(w.dtype, rows)] = (stamp, t)
     return t
 
 
@@ -139,15 +142,16 @@ class LinearFn(torch.autograd.Function):
             b = b[rows[0]:rows[1]] if b is not None else None
         seed = next_seed() if p_drop > 0 else 0
         y = gemm(x2, w, trans_b=True, bias=b, relu=relu, p_drop=p_drop, seed=seed)
-        ctx.save_for_backward(x2, w, y if (relu or p_drop > 0) else None)
-        ctx.cfg = (relu, p_drop, shp, weight, bias, rows)
+        wt = weight_t(weight, w, rows) if ctx.needs_input_grad[0] else None       # [in, out], for dX
+        ctx.save_for_backward(x2, wt, y if (relu or p_drop > 0) else None)
+        ctx.cfg = (relu, p_drop, shp, weight, bias, rows, w.shape[0])
         return y.view(*shp[:-1], w.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
-        x2, w, y = ctx.saved_tensors
-        relu, p_drop, shp, weight, bias, rows = ctx.cfg
-        dy2 = dy.reshape(-1, w.shape[0])
+        x2, wt, y = ctx.saved_tensors
+        relu, p_drop, shp, weight, bias, rows, n_out = ctx.cfg
+        dy2 = dy.reshape(-1, n_out)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
         if y is not None:
@@ -158,10 +162,10 @@ class LinearFn(torch.autograd.Function):
                 raise _lib.GtosHipError("dropout without relu is not fused in LinearFn")
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = gemm(dy2, weight_t(w), trans_b=True).view(shp)
+            dx = gemm(dy2, wt, trans_b=True).view(shp)
         if ctx.needs_input_grad[1]:
             tgt = _grad_target(weight)
-            M, N, K = w.shape[0], w.shape[1], dy2.shape[0]
+            M, N, K = n_out, x2.shape[1], dy2.shape[0]
             sk = _splitk(M, N, K)
             if tgt is None:
                 tgt = dw = torch.zeros(weight.shape, dtype=torch.float32, device=dy2.device)
