@@ -57,7 +57,9 @@ class RelationMultiheadAttention(nn.Module):
             offs = (0, 0, d)
         if isinstance(relation, FactoredRelation):
             fact = relation
-            rel = ops.linear(relation.bank.to(cd), self.relation_in_proj.weight)          # [R, 2d]
+            bank = relation.bank if relation.bank.dtype == cd else relation.bank.to(cd)
+            group = relation.grad_group if bank is relation.bank else None
+            rel = ops.linear(bank, self.relation_in_proj.weight, group=group)               # [R, 2d]
         else:
             fact = None
             rel = ops.linear(relation.to(cd), self.relation_in_proj.weight)               # [n, n, B, 2d]

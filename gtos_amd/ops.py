@@ -126,13 +126,37 @@ def _grad_target(p):
     return None
 
 
+class GradAccumGroup:
+    """Several LinearFn calls that share ONE input tensor (the relation bank feeds relation_in_proj of every layer): their
+    input gradients are accumulated by the GEMM epilogue into one buffer, and only the last backward call hands it to
+    autograd -- instead of L separate [R,d] tensors that autograd would add pairwise."""
+
+    def __init__(self):
+        self.pending = 0
+        self.buf = None
+
+    def register(self):
+        self.pending += 1
+
+    def add(self, dy2, wt, shape):
+        if self.buf is None:
+            self.buf = gemm(dy2, wt, trans_b=True)
+        else:
+            gemm(dy2, wt, trans_b=True, out=self.buf, accumulate=True)
+        self.pending -= 1
+        if self.pending > 0:
+            return None
+        out, self.buf = self.buf, None
+        return out.view(shape)
+
+
 class LinearFn(torch.autograd.Function):
     """y = dropout(relu(x W^T + b)) -- F.linear (+relu +dropout) of the reference's projections and FFN
     (generator/graph_transformer.py:61-63,106-122,166).  Weight/bias gradients are accumulated straight into the
     flat fp32 gradient bucket when one is attached (no per-parameter temporaries)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, relu, p_drop, rows):
+    def forward(ctx, x, weight, bias, relu, p_drop, rows, group=None):
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
         w = compute_weight(weight, x2.dtype)
@@ -144,13 +168,15 @@ class LinearFn(torch.autograd.Function):
         y = gemm(x2, w, trans_b=True, bias=b, relu=relu, p_drop=p_drop, seed=seed)
         wt = weight_t(weight, w, rows) if ctx.needs_input_grad[0] else None       # [in, out], for dX
         ctx.save_for_backward(x2, wt, y if (relu or p_drop > 0) else None)
-        ctx.cfg = (relu, p_drop, shp, weight, bias, rows, w.shape[0])
+        if group is not None and ctx.needs_input_grad[0]:
+            group.register()
+        ctx.cfg = (relu, p_drop, shp, weight, bias, rows, w.shape[0], group)
         return y.view(*shp[:-1], w.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
         x2, wt, y = ctx.saved_tensors
-        relu, p_drop, shp, weight, bias, rows, n_out = ctx.cfg
+        relu, p_drop, shp, weight, bias, rows, n_out, group = ctx.cfg
         dy2 = dy.reshape(-1, n_out)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
@@ -162,7 +188,7 @@ class LinearFn(torch.autograd.Function):
                 raise _lib.GtosHipError("dropout without relu is not fused in LinearFn")
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = gemm(dy2, wt, trans_b=True).view(shp)
+            dx = group.add(dy2, wt, shp) if group is not None else gemm(dy2, wt, trans_b=True).view(shp)
         if ctx.needs_input_grad[1]:
             tgt = _grad_target(weight)
             M, N, K = n_out, x2.shape[1], dy2.shape[0]
@@ -179,11 +205,11 @@ class LinearFn(torch.autograd.Function):
             if rows is not None:
                 tgt = tgt[rows[0]:rows[1]]
             call("gtos_colsum", dt(dy2), dy2.shape[0], dy2.shape[1], dy2.stride(0), ptr(dy2), ptr(tgt), stream())
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
-def linear(x, weight, bias=None, relu=False, p_drop=0.0, rows=None):
-    return LinearFn.apply(x, weight, bias, relu, float(p_drop), rows)
+def linear(x, weight, bias=None, relu=False, p_drop=0.0, rows=None, group=None):
+    return LinearFn.apply(x, weight, bias, relu, float(p_drop), rows, group)
 
 
 class LayerNormResidualFn(torch.autograd.Function):
@@ -246,6 +272,7 @@ class FactoredRelation:
     def __init__(self, bank, relation):
         require_cuda(bank, relation)
         self.bank = bank
+        self.grad_group = GradAccumGroup()
         n, n2, B = relation.shape
         assert n == n2
         self.n, self.B = n, B
