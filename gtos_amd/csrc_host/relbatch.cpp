@@ -1,0 +1,258 @@
+// Host-side graph -> relation tensors, C++17, one thread per graph.
+// See include/gtos_host.h for the contract and the reference lines this replaces.  Pure integer work.
+#include "../../include/gtos_host.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+struct Graph {
+    int n = 0, root = 0;
+    std::vector<int> adj_off, adj_dst, adj_lab;     // CSR in networkx adjacency (insertion) order
+    std::vector<int> order, pos, depth;             // BFS order from the root, position of each node, BFS depth
+};
+
+struct PairPaths {                                   // per graph: for every (i,j) in BFS-position space, its packed paths
+    std::vector<uint32_t> off;                       // [n*n+1]
+    std::vector<uint64_t> keys;
+};
+
+inline uint64_t splitmix(uint64_t& s) {
+    s += 0x9E3779B97F4A7C15ull;
+    uint64_t z = s;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// labels first..last packed one per byte, first label in the low byte (labels are >= 1, so the length is implicit)
+inline uint64_t pack(const int* labs, int k) {
+    uint64_t key = 0;
+    for (int i = 0; i < k; ++i) key |= (uint64_t)(labs[i] & 0xff) << (8 * i);
+    return key;
+}
+
+bool build_graph(Graph& g, int n, int root, int64_t e0, int64_t e1, const int* src, const int* dst, const int* lab) {
+    g.n = n; g.root = root;
+    if (n <= 0 || root < 0 || root >= n) return false;
+    // ordered adjacency with overwrite-in-place for repeated (u,v) (networkx DiGraph.add_edge)
+    std::vector<std::vector<std::pair<int, int>>> adj(n);
+    for (int64_t e = e0; e < e1; ++e) {
+        const int u = src[e], v = dst[e], l = lab[e];
+        if (u < 0 || u >= n || v < 0 || v >= n || l < 1 || l > 255) return false;
+        bool found = false;
+        for (auto& p : adj[u]) if (p.first == v) { p.second = l; found = true; break; }
+        if (!found) adj[u].emplace_back(v, l);
+    }
+    g.adj_off.assign(n + 1, 0);
+    for (int u = 0; u < n; ++u) g.adj_off[u + 1] = g.adj_off[u] + (int)adj[u].size();
+    g.adj_dst.resize(g.adj_off[n]); g.adj_lab.resize(g.adj_off[n]);
+    for (int u = 0; u < n; ++u)
+        for (size_t k = 0; k < adj[u].size(); ++k) { g.adj_dst[g.adj_off[u] + k] = adj[u][k].first; g.adj_lab[g.adj_off[u] + k] = adj[u][k].second; }
+    // BFS order / depth from the root (AMRGraph.py:82-98, dependencyGraph.py:36-52)
+    g.order.clear(); g.depth.clear(); g.pos.assign(n, -1);
+    g.order.push_back(root); g.depth.push_back(0); g.pos[root] = 0;
+    for (size_t step = 0; step < g.order.size(); ++step) {
+        const int u = g.order[step];
+        for (int k = g.adj_off[u]; k < g.adj_off[u + 1]; ++k) {
+            const int v = g.adj_dst[k];
+            if (g.pos[v] < 0) { g.pos[v] = (int)g.order.size(); g.order.push_back(v); g.depth.push_back(g.depth[step] + 1); }
+        }
+    }
+    return (int)g.order.size() == n;                 // "not connected" is an error in the reference too
+}
+
+// All-pairs label paths of one graph.
+void graph_paths(const Graph& g, int mode, uint64_t seed, int gid, int max_len, uint64_t self_key, uint64_t tl_key, PairPaths& out) {
+    const int n = g.n;
+    out.off.assign((size_t)n * n + 1, 0);
+    out.keys.clear();
+    std::vector<int> level(n), parent(n), plabel(n), frontier, next;
+    std::vector<double> count(n);
+    std::vector<std::vector<std::pair<int, int>>> pred(n);            // (predecessor, label of pred->node), discovery order
+    std::vector<std::vector<uint64_t>> row((size_t)n);                 // paths per target position for the current source
+    int labs[64];
+    for (int i = 0; i < n; ++i) {
+        const int s = g.order[i];
+        std::fill(level.begin(), level.end(), -1);
+        for (auto& p : pred) p.clear();
+        level[s] = 0; parent[s] = -1; count[s] = 1.0;
+        frontier.assign(1, s);
+        int lev = 0;
+        while (!frontier.empty()) {                                   // nx.predecessor / _single_shortest_path level loop
+            ++lev; next.clear();
+            for (int v : frontier)
+                for (int k = g.adj_off[v]; k < g.adj_off[v + 1]; ++k) {
+                    const int w = g.adj_dst[k];
+                    if (level[w] < 0) { level[w] = lev; parent[w] = v; plabel[w] = g.adj_lab[k]; count[w] = count[v];
+                                        pred[w].emplace_back(v, g.adj_lab[k]); next.push_back(w); }
+                    else if (level[w] == lev) { pred[w].emplace_back(v, g.adj_lab[k]); count[w] += count[v]; }
+                }
+            frontier.swap(next);
+        }
+        for (auto& r : row) r.clear();
+        for (int j = 0; j < n; ++j) {
+            const int t = g.order[j];
+            const int d = level[t];
+            std::vector<uint64_t>& dstv = row[j];
+            if (d == 0) { dstv.push_back(self_key); continue; }
+            if (d > max_len) { dstv.push_back(tl_key); continue; }   // every alternative collapses to <TL> (data.py:201-202)
+            if (mode == GTOS_PATH_FIRST) {
+                int v = t;
+                for (int k = d - 1; k >= 0; --k) { labs[k] = plabel[v]; v = parent[v]; }
+                dstv.push_back(pack(labs, d));
+            } else if (mode == GTOS_PATH_UNIFORM) {
+                uint64_t st = seed ^ (0x100000001B3ull * (uint64_t)(gid + 1)) ^ ((uint64_t)i << 40) ^ ((uint64_t)j << 20);
+                int v = t;
+                for (int k = d - 1; k >= 0; --k) {
+                    const double u01 = (double)(splitmix(st) >> 11) * (1.0 / 9007199254740992.0);
+                    double acc = 0.0, target = u01 * count[v];
+                    const auto& pv = pred[v];
+                    size_t pick = pv.size() - 1;
+                    for (size_t q = 0; q < pv.size(); ++q) { acc += count[pv[q].first]; if (target < acc) { pick = q; break; } }
+                    labs[k] = pv[pick].second; v = pv[pick].first;
+                }
+                dstv.push_back(pack(labs, d));
+            } else {                                                  // nx.all_shortest_paths enumeration order
+                // explicit stack of (node, next predecessor index), emitting when the source is reached
+                int st_node[64], st_idx[64], st_lab[64];
+                int top = 0;
+                st_node[0] = t; st_idx[0] = 0;
+                while (top >= 0) {
+                    const int node = st_node[top];
+                    if (node == s) {                                  // labels along the stack from the source side
+                        for (int k = 0; k < top; ++k) labs[k] = st_lab[top - k];
+                        dstv.push_back(pack(labs, top));
+                    }
+                    if ((int)pred[node].size() > st_idx[top]) {
+                        const auto pr = pred[node][st_idx[top]];
+                        st_idx[top]++;
+                        ++top;
+                        st_node[top] = pr.first; st_idx[top] = 0; st_lab[top] = pr.second;
+                    } else {
+                        --top;
+                    }
+                }
+            }
+        }
+        for (int j = 0; j < n; ++j) {
+            out.off[(size_t)i * n + j + 1] = (uint32_t)(out.keys.size() + row[j].size());
+            out.keys.insert(out.keys.end(), row[j].begin(), row[j].end());
+        }
+    }
+    // prefix form: off[k+1] currently holds the end of pair k (monotone by construction)
+}
+
+}  // namespace
+
+struct gtos_relbatch {
+    int B = 0, n = 0, R = 0, L = 0, K = 1;
+    std::vector<int64_t> relation, bank, length;
+    std::vector<int32_t> order, depth;
+};
+
+extern "C" gtos_relbatch* gtos_relbatch_build(int B, const int* n_nodes, const int* roots, const int64_t* edge_off,
+                                              const int* e_src, const int* e_dst, const int* e_label,
+                                              int path_mode, uint64_t seed, const int* ids, int max_len, int n_threads) {
+    if (B <= 0 || !n_nodes || !roots || !edge_off || !ids || max_len < 1 || max_len > 8) return nullptr;
+    if (path_mode < 0 || path_mode > 2) return nullptr;
+    const int pad_id = ids[0], cls_id = ids[1], rcls_id = ids[2], self_id = ids[3], tl_id = ids[4];
+    const uint64_t self_key = (uint64_t)self_id, tl_key = (uint64_t)tl_id;
+    std::vector<Graph> graphs(B);
+    std::vector<PairPaths> pp(B);
+    std::atomic<int> next(0), bad(0);
+    auto work = [&]() {
+        for (;;) {
+            const int g = next.fetch_add(1);
+            if (g >= B) return;
+            if (!build_graph(graphs[g], n_nodes[g], roots[g], edge_off[g], edge_off[g + 1], e_src, e_dst, e_label)) { bad = 1; continue; }
+            graph_paths(graphs[g], path_mode, seed, g, max_len, self_key, tl_key, pp[g]);
+        }
+    };
+    if (n_threads < 1) n_threads = (int)std::thread::hardware_concurrency();
+    n_threads = std::max(1, std::min(n_threads, B));
+    std::vector<std::thread> pool;
+    for (int t = 1; t < n_threads; ++t) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+    if (bad) return nullptr;
+
+    auto* h = new gtos_relbatch();
+    h->B = B;
+    int nmax = 0;
+    for (int g = 0; g < B; ++g) nmax = std::max(nmax, graphs[g].n);
+    const int n = nmax + 1;
+    h->n = n;
+    const bool all = path_mode == GTOS_PATH_ALL;
+    int K = 1;
+    if (all)
+        for (int g = 0; g < B; ++g)
+            for (size_t k = 0; k + 1 < pp[g].off.size(); ++k) {
+                const uint32_t b0 = k ? pp[g].off[k] : 0u;
+                K = std::max(K, (int)(pp[g].off[k + 1] - b0));
+            }
+    h->K = K;
+    // type ids in the reference's first-seen order: graphs in order, source i, target j (data.py:140-162 / :186-213)
+    std::unordered_map<uint64_t, int> types;
+    std::vector<uint64_t> type_key;
+    auto intern = [&](uint64_t key) { auto it = types.find(key); if (it != types.end()) return it->second;
+                                      const int id = (int)type_key.size(); types.emplace(key, id); type_key.push_back(key); return id; };
+    int t_cls, t_rcls, t_self;
+    if (all) { intern((uint64_t)pad_id); t_cls = intern((uint64_t)cls_id); t_rcls = intern((uint64_t)rcls_id); t_self = intern(self_key); }
+    else { t_cls = intern((uint64_t)cls_id); t_rcls = intern((uint64_t)rcls_id); t_self = intern(self_key); }
+    h->relation.assign((size_t)n * n * B * K, 0);
+    h->order.assign((size_t)B * (n - 1), -1);
+    h->depth.assign((size_t)B * (n - 1), 0);
+    auto rel_at = [&](int a, int c, int b, int k) -> int64_t& { return h->relation[(((size_t)a * n + c) * B + b) * K + k]; };
+    for (int b = 0; b < B; ++b) {
+        const Graph& g = graphs[b];
+        const int ng = g.n;
+        for (int p = 0; p < ng; ++p) { h->order[(size_t)b * (n - 1) + p] = g.order[p]; h->depth[(size_t)b * (n - 1) + p] = g.depth[p]; }
+        rel_at(0, 0, b, 0) = t_self;                                   // brs[0] = [<SELF>, <CLS>...], brs[c][0] = <rCLS>
+        for (int a = 1; a <= ng; ++a) { rel_at(a, 0, b, 0) = t_cls; rel_at(0, a, b, 0) = t_rcls; }
+        for (int i = 0; i < ng; ++i)
+            for (int j = 0; j < ng; ++j) {
+                const size_t k = (size_t)i * ng + j;
+                const uint32_t b0 = k ? pp[b].off[k] : 0u, b1 = pp[b].off[k + 1];
+                // eval keeps only the first alternative when it is <SELF>/<TL>; those pairs hold exactly one key already
+                for (uint32_t q = b0; q < b1; ++q) rel_at(j + 1, i + 1, b, (int)(q - b0)) = intern(pp[b].keys[q]);
+            }
+    }
+    const int R = (int)type_key.size();
+    h->R = R;
+    int L = 1;
+    std::vector<int> len(R);
+    for (int t = 0; t < R; ++t) { int l = 0; uint64_t k = type_key[t]; while (k) { ++l; k >>= 8; } len[t] = std::max(l, 1); L = std::max(L, len[t]); }
+    h->L = L;
+    h->bank.assign((size_t)L * R, 0);
+    h->length.resize(R);
+    for (int t = 0; t < R; ++t) {
+        h->length[t] = len[t];
+        for (int i = 0; i < len[t]; ++i) h->bank[(size_t)i * R + t] = (int64_t)((type_key[t] >> (8 * i)) & 0xff);
+    }
+    return h;
+}
+
+extern "C" int gtos_relbatch_dims(const gtos_relbatch* h, int* n, int* R, int* L, int* K) {
+    if (!h) return -1;
+    if (n) *n = h->n; if (R) *R = h->R; if (L) *L = h->L; if (K) *K = h->K;
+    return 0;
+}
+
+extern "C" int gtos_relbatch_export(const gtos_relbatch* h, int64_t* relation, int64_t* bank, int64_t* length,
+                                    int32_t* order, int32_t* depth) {
+    if (!h) return -1;
+    if (relation) std::memcpy(relation, h->relation.data(), h->relation.size() * sizeof(int64_t));
+    if (bank) std::memcpy(bank, h->bank.data(), h->bank.size() * sizeof(int64_t));
+    if (length) std::memcpy(length, h->length.data(), h->length.size() * sizeof(int64_t));
+    if (order) std::memcpy(order, h->order.data(), h->order.size() * sizeof(int32_t));
+    if (depth) std::memcpy(depth, h->depth.data(), h->depth.size() * sizeof(int32_t));
+    return 0;
+}
+
+extern "C" void gtos_relbatch_free(gtos_relbatch* h) { delete h; }

@@ -1,0 +1,53 @@
+/* gtos_host.h -- C ABI of libgtos_host.so: the host-side graph -> relation-tensor path.
+ *
+ * Native (C++17, multi-threaded) counterpart of the reference's Python/networkx preprocessing that feeds the hot path:
+ *   - bidirectional labelled graph + BFS node order/depth     generator/AMRGraph.py:76-98, translator/dependencyGraph.py:30-52
+ *   - all-pairs shortest label paths                          generator/AMRGraph.py:100-115 (nx.all_shortest_paths),
+ *                                                             translator/dependencyGraph.py:54-74 (nx.single_source_shortest_path)
+ *   - relation type ids, relation bank, <CLS> row/column      generator/data.py:134-176 (train), :178-232 (eval),
+ *                                                             translator/data.py:132-176
+ * Integer work only: results are bit-exact with the reference wherever the reference is deterministic (the translator
+ * flavour always; the generator flavour in eval mode); the generator's train-mode random.choice among alternative
+ * shortest paths is replaced by an exactly-uniform choice driven by a splitmix64 stream.
+ */
+#ifndef GTOS_HOST_H
+#define GTOS_HOST_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gtos_relbatch gtos_relbatch;
+
+#define GTOS_PATH_FIRST 0    /* one path per pair: BFS first discovery == nx.single_source_shortest_path (translator)        */
+#define GTOS_PATH_UNIFORM 1  /* one path per pair, uniform among all shortest paths (generator train, data.py:150)         */
+#define GTOS_PATH_ALL 2      /* every shortest path, networkx enumeration order (generator eval, data.py:199-213)          */
+
+/* Builds the relation tensors of one batch.
+ *   B graphs; graph g has n_nodes[g] nodes (ids 0..n-1), root roots[g] and the directed labelled edges
+ *   e in [edge_off[g], edge_off[g+1]) given in INSERTION order and already doubled with their reverse-labelled twins
+ *   (the reference inserts (src,des,rel) then (des,src,rel+'_reverse_'/'_r_')).  Labels are relation-vocabulary ids in
+ *   [1,255].  A repeated (src,dst) overwrites the earlier label in place (networkx DiGraph semantics).
+ *   ids: {pad, cls, rcls, self, tl} relation-vocabulary ids; max_len: paths longer than this collapse to <TL> (8).
+ * Returns NULL on invalid input (disconnected graph, label out of range, ...). */
+gtos_relbatch* gtos_relbatch_build(int B, const int* n_nodes, const int* roots, const int64_t* edge_off,
+                                   const int* e_src, const int* e_dst, const int* e_label,
+                                   int path_mode, uint64_t seed, const int* special_ids5, int max_len, int n_threads);
+
+/* n = 1 + max nodes (the <CLS> node is index 0), R = number of distinct paths (bank rows), L = longest bank path,
+ * K = alternatives per pair (1 unless GTOS_PATH_ALL). */
+int gtos_relbatch_dims(const gtos_relbatch* h, int* n, int* R, int* L, int* K);
+
+/* relation: int64 [n,n,B] (K==1) or [n,n,B,K]; relation[a][c][b] = type id of the path from node c to node a
+ * (generator/data.py:164-165), 0-padded.  bank: int64 [L,R] 0-padded label ids; length: int64 [R];
+ * order: int32 [B, n-1] node id at each BFS position (-1 padded); depth: int32 [B, n-1] BFS depth. */
+int gtos_relbatch_export(const gtos_relbatch* h, int64_t* relation, int64_t* bank, int64_t* length,
+                         int32_t* order, int32_t* depth);
+
+void gtos_relbatch_free(gtos_relbatch* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

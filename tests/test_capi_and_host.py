@@ -38,6 +38,17 @@ def test_library_exports_every_declared_symbol(lib_path):
     assert lib.gtos_abi_version() == 1
 
 
+def test_host_library_exports_every_declared_symbol():
+    from gtos_amd import build
+    lib = ctypes.CDLL(build.build_host(verbose=False))
+    src = open(os.path.join(ROOT, "include", "gtos_host.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b(gtos_relbatch_\w+)\s*\(", src)
+    assert set(names) == {"gtos_relbatch_build", "gtos_relbatch_dims", "gtos_relbatch_export", "gtos_relbatch_free"}
+    for n in names:
+        assert hasattr(lib, n)
+
+
 def test_ctypes_binding_mirrors_header(lib_path):
     from gtos_amd import _lib
     funcs = header_functions()

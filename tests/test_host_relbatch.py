@@ -1,0 +1,150 @@
+"""Host graph->relation-tensor path (libgtos_host.so) against golden vectors produced by the reference's own pipeline
+(tests/golden/make_golden_host.py) and against networkx on random multi-path graphs.  Integer work: bit-exact."""
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+
+@pytest.fixture(scope="module")
+def rb():
+    from gtos_amd import build, relbatch
+    build.build_host(verbose=False)
+    relbatch.load()
+    return relbatch
+
+
+@pytest.mark.parametrize("bi", [0, 1])
+def test_translator_flavour_matches_reference_on_real_dev_data(rb, bi):
+    g = load_golden("host_dep_dev")
+    p = "b%d/" % bi
+    off = g[p + "off"]
+    graphs = []
+    for k in range(len(off) - 1):
+        sl = slice(off[k], off[k + 1])
+        graphs.append(rb.dependency_edges(g[p + "heads"][sl].tolist(), g[p + "dep_ids"][sl].tolist(), g[p + "rev_ids"][sl].tolist()))
+    out = rb.build_relation_batch(graphs, g["special_ids"].tolist(), path_mode=rb.PATH_FIRST)
+    assert torch.equal(out["relation"], torch.from_numpy(g[p + "relation"]))
+    assert torch.equal(out["relation_bank"], torch.from_numpy(g[p + "relation_bank"]))
+    assert torch.equal(out["relation_length"], torch.from_numpy(g[p + "relation_length"]))
+    # translator: concept_depth = [0] + BFS node order (dependencyGraph.py:72-73), 0-padded
+    want = torch.from_numpy(g[p + "concept_depth"])[1:].t()
+    got = out["order"].clamp(min=0).long()
+    assert torch.equal(got, want)
+    # uniform choice among alternatives must agree too: shortest paths in a tree are unique
+    out2 = rb.build_relation_batch(graphs, g["special_ids"].tolist(), path_mode=rb.PATH_UNIFORM, seed=7)
+    assert torch.equal(out2["relation"], out["relation"]) and torch.equal(out2["relation_bank"], out["relation_bank"])
+
+
+def test_generator_flavour_eval_matches_reference_on_smatch_amrs(rb):
+    g = load_golden("host_amr_smatch")
+    eo = g["edge_off"]
+    graphs = [(int(g["n_nodes"][k]), int(g["roots"][k]), g["edges"][eo[k]:eo[k + 1]]) for k in range(len(g["n_nodes"]))]
+    out = rb.build_relation_batch(graphs, g["special_ids"].tolist(), path_mode=rb.PATH_ALL)
+    assert torch.equal(out["relation"], torch.from_numpy(g["relation"]))
+    assert torch.equal(out["relation_bank"], torch.from_numpy(g["relation_bank"]))
+    assert torch.equal(out["relation_length"], torch.from_numpy(g["relation_length"]))
+    want_depth = torch.from_numpy(g["concept_depth"])[1:].t()
+    assert torch.equal(out["depth"].long(), want_depth)
+
+
+def _random_graph(rng, n, extra):
+    """connected labelled graph with reverse twins, as (n, root, edges) plus the networkx DiGraph built the reference way"""
+    import networkx as nx
+    G = nx.DiGraph()
+    edges = []
+    for v in range(n):
+        G.add_node(v)
+
+    def add(u, v):
+        lab = int(rng.integers(6, 20))
+        for (a, b, l) in ((u, v, lab), (v, u, lab + 20)):
+            G.add_edge(a, b, label=l)
+            edges.append((a, b, l))
+    for v in range(1, n):
+        add(int(rng.integers(0, v)), v)
+    for _ in range(extra):
+        u, v = int(rng.integers(0, n)), int(rng.integers(0, n))
+        if u != v:
+            add(u, v)
+    return G, (n, 0, np.array(edges, dtype=np.int32))
+
+
+def test_all_paths_and_first_path_orders_match_networkx(rb):
+    nx = pytest.importorskip("networkx")
+    rng = np.random.default_rng(5)
+    special = [0, 2, 3, 4, 5]
+    for trial in range(6):
+        n = int(rng.integers(5, 14))
+        G, graph = _random_graph(rng, n, extra=int(rng.integers(2, 3 * n)))
+        out_all = rb.build_relation_batch([graph], special, path_mode=rb.PATH_ALL)
+        out_first = rb.build_relation_batch([graph], special, path_mode=rb.PATH_FIRST)
+        order = out_all["order"][0].tolist()
+        bank_all, len_all = out_all["relation_bank"], out_all["relation_length"]
+        bank_f, len_f = out_first["relation_bank"], out_first["relation_length"]
+
+        def labels(bank, length, t):
+            return bank[:int(length[t]), t].tolist()
+        for i, s in enumerate(order):
+            sp = nx.single_source_shortest_path(G, s)
+            for j, t in enumerate(order):
+                want = [[G[p[k]][p[k + 1]]["label"] for k in range(len(p) - 1)] for p in nx.all_shortest_paths(G, s, t)]
+                ids = [int(x) for x in out_all["relation"][j + 1, i + 1, 0] if int(x) != 0]
+                got = [labels(bank_all, len_all, x) for x in ids]
+                if len(want[0]) == 0:
+                    assert got == [[4]]
+                else:
+                    assert got == want, (trial, s, t)
+                first = [G[sp[t][k]][sp[t][k + 1]]["label"] for k in range(len(sp[t]) - 1)] or [4]
+                assert labels(bank_f, len_f, int(out_first["relation"][j + 1, i + 1, 0])) == first
+
+
+def test_uniform_choice_is_uniform_over_alternatives(rb):
+    # diamond s->{a,b,c}->t: three shortest paths 0->4; the choice must be ~uniform over seeds and always a shortest path
+    edges = []
+    for mid, lab in ((1, 6), (2, 7), (3, 8)):
+        edges += [(0, mid, lab), (mid, 0, lab + 20), (mid, 4, lab + 3), (4, mid, lab + 23)]
+    graph = (5, 0, np.array(edges, dtype=np.int32))
+    counts = {}
+    for seed in range(600):
+        out = rb.build_relation_batch([graph], [0, 2, 3, 4, 5], path_mode=rb.PATH_UNIFORM, seed=seed)
+        pos = out["order"][0].tolist().index(4)
+        t = int(out["relation"][pos + 1, 1, 0])                  # path from the root (position 0) to node 4
+        key = tuple(out["relation_bank"][:2, t].tolist())
+        counts[key] = counts.get(key, 0) + 1
+    assert set(counts) == {(6, 9), (7, 10), (8, 11)}
+    assert min(counts.values()) > 150 and max(counts.values()) < 250
+
+
+def test_synthetic_c2_batch_speed_and_invariants(rb):
+    """64 AMR-shaped graphs of 100 nodes (the C2 batch): the native path must be >10x the Python generator's 2.3 s and agree
+    with it on everything that does not depend on tie-breaking."""
+    from gtos_amd import synth
+    rng_graphs = []
+    cfg = synth.CONFIGS["C2"]
+    lab_cdf = synth._zipf_table(40)
+    for gidx in range(cfg["B"]):
+        r = synth.SplitMix64(2 * 10 ** 6 + gidx)
+        adj = synth._amr_graph(r, cfg["N"], cfg["extra_frac"], 40, lab_cdf)
+        edges = [(u, v, l) for u in range(len(adj)) for (v, l) in adj[u]]
+        rng_graphs.append((cfg["N"], 0, np.array(edges, dtype=np.int32)))
+    t0 = time.time()
+    out = rb.build_relation_batch(rng_graphs, [synth.PAD, synth.REL_CLS, synth.REL_RCLS, synth.REL_SELF, synth.REL_TL],
+                                  path_mode=rb.PATH_UNIFORM, seed=1)
+    dt = time.time() - t0
+    rel = out["relation"]
+    n = cfg["N"] + 1
+    assert rel.shape == (n, n, cfg["B"])
+    assert int(rel.max()) == out["relation_bank"].shape[1] - 1
+    assert bool((torch.diagonal(rel[1:, 1:, 0]) == 2).all()) and int(rel[0, 0, 0]) == 2
+    assert bool((rel[1:, 0, :] == 0).all()) and bool((rel[0, 1:, :] == 1).all())
+    assert int(out["relation_length"].max()) <= 8
+    # path lengths are tie-break independent: compare the length multiset of graph 0 with the Python BFS
+    order, depth = synth._bfs_order([[(int(v), int(l)) for (u2, v, l) in rng_graphs[0][2] if u2 == u] for u in range(cfg["N"])])
+    assert out["order"][0].tolist() == order and out["depth"][0].tolist() == depth
+    print("native relation batch for C2: %.3f s, R=%d" % (dt, out["relation_bank"].shape[1]))
+    assert dt < 1.0
