@@ -50,8 +50,12 @@ template <> struct Raw8<float> {
     }
 };
 
-template <typename T> struct Unroll { static constexpr int U = 4; };
-template <> struct Unroll<float> { static constexpr int U = 2; };
+// keys per register set; the streaming loops keep TWO sets in flight (software pipeline)
+#ifndef GTOS_ATTN_U
+#define GTOS_ATTN_U 2
+#endif
+template <typename T> struct Unroll { static constexpr int U = GTOS_ATTN_U; };
+template <> struct Unroll<float> { static constexpr int U = 1; };
 
 struct AttnArgs {
     const void *q, *k, *v; int64_t ldq, ldk, ldv;          // rows (t*B+b)*ld, element units
@@ -74,22 +78,30 @@ struct AttnArgs {
     float scale, p_drop; uint64_t seed;
 };
 
+// Sum over the LH lanes of a head.  DPP lane permutes (VALU speed) for the steps inside a 16-lane row: hipcc lowers
+// __shfl_xor to ds_bpermute (an LDS-pipe round trip of ~100 cycles) even for constant offsets, and three of those per key
+// sat on the critical path of the streaming loop.
+#define GTOS_DPP(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, true))
 template <int LH> __device__ __forceinline__ float head_sum(float v) {
-#pragma unroll
-    for (int o = 1; o < LH; o <<= 1) v += __shfl_xor(v, o);
+    if (LH >= 2) v += GTOS_DPP(v, 0xB1);       // quad_perm [1,0,3,2]  (xor 1)
+    if (LH >= 4) v += GTOS_DPP(v, 0x4E);       // quad_perm [2,3,0,1]  (xor 2)
+    if (LH >= 8) v += GTOS_DPP(v, 0x141);      // row_half_mirror: the other quad of the 8-lane half row
+    if (LH >= 16) v += GTOS_DPP(v, 0x140);     // row_mirror: the other half of the 16-lane row
+    if (LH >= 32) v += __shfl_xor(v, 16);
+    if (LH >= 64) v += __shfl_xor(v, 32);
     return v;
 }
 
-// block -> (row index, graph).  4 waves of a block take 4 consecutive graphs of one row; blocks are dealt to
-// XCDs round-robin by the dispatcher (block id % 8), so give each XCD a fixed subset of graphs.
+// block -> (row index, graph).  One 4-wave workgroup owns one (row, graph); its waves split the other axis (keys in the
+// forward / query-major kernels, queries in the key-major one) 4 ways, interleaved, and merge through LDS.  Work items
+// of 1/4 the size quadruple the number of workgroups (6464 at C2 instead of 1616 for ~768 resident), which removes the
+// 30 % tail loss of "2.1 rounds rounded up to 3".  Blocks are dealt to XCDs round-robin by the dispatcher (id % 8), so
+// each XCD gets a fixed subset of graphs and their K/V rows stay in its private L2.
 __device__ __forceinline__ bool map_block(int rows, int B, int& row, int& b) {
-    const int nbg = (B + 3) >> 2;
     const int blk = blockIdx.x;
-    int bg;
-    if ((nbg & 7) == 0) { const int x = blk & 7, w = blk >> 3, gpx = nbg >> 3; bg = x * gpx + (w % gpx); row = w / gpx; }
-    else { bg = blk % nbg; row = blk / nbg; }
-    b = bg * 4 + (threadIdx.x >> 6);
-    return b < B && row < rows;
+    if ((B & 7) == 0) { const int x = blk & 7, w = blk >> 3, gpx = B >> 3; b = x * gpx + (w % gpx); row = w / gpx; }
+    else { b = blk % B; row = blk / B; }
+    return row < rows;
 }
 
 __device__ __forceinline__ bool is_masked(const AttnArgs& a, int i, int j, int b) {
@@ -99,14 +111,13 @@ __device__ __forceinline__ bool is_masked(const AttnArgs& a, int i, int j, int b
     return m;
 }
 
-// Combined key-padding / attention mask of this wave's (i,b) row staged once in LDS (one byte per key): the per-key
+// Combined key-padding / attention mask of this block's (i,b) row staged once in LDS (one byte per key): the per-key
 // global byte loads in the streaming loop cost a VMEM issue each and showed up as ~25 % of the kernel time.
 constexpr int MAXS_LDS = 1024;
-__device__ __forceinline__ const unsigned char* stage_mask(const AttnArgs& a, bool ok, int i, int b, unsigned char (*smask)[MAXS_LDS]) {
+__device__ __forceinline__ const unsigned char* stage_mask(const AttnArgs& a, int i, int b, unsigned char* sm) {
     const bool use = (a.key_pad || a.attn_mask) && a.S <= MAXS_LDS;
-    unsigned char* sm = smask[threadIdx.x >> 6];
-    if (use && ok) for (int j = threadIdx.x & 63; j < a.S; j += 64) sm[j] = is_masked(a, i, j, b) ? 1 : 0;
-    __syncthreads();                 // every wave of the block reaches this (the out-of-range ones return after it)
+    if (use) for (int j = threadIdx.x; j < a.S; j += 256) sm[j] = is_masked(a, i, j, b) ? 1 : 0;
+    __syncthreads();
     return use ? sm : nullptr;
 }
 __device__ __forceinline__ bool key_dead(const AttnArgs& a, const unsigned char* sm, int i, int j, int b) {
@@ -118,55 +129,58 @@ __device__ __forceinline__ bool key_dead(const AttnArgs& a, const unsigned char*
 template <typename T, int LH>
 __global__ __launch_bounds__(256) void rel_attn_fwd_kernel(AttnArgs a) {
     constexpr int U = Unroll<T>::U;
-    __shared__ unsigned char smask[4][MAXS_LDS];
+    __shared__ unsigned char smask[MAXS_LDS];
+    __shared__ float red[4][64][10];             // per wave, per lane: m, l, o[8]
+    __shared__ float fin[64][2];                 // merged m and 1/l per lane (for the weights pass)
     int i, b;
-    const bool ok = map_block(a.T, a.B, i, b);
-    const unsigned char* sm = stage_mask(a, ok, i, b, smask);
-    if (!ok) return;
-    const int lane = threadIdx.x & 63;
+    if (!map_block(a.T, a.B, i, b)) return;      // whole block
+    const unsigned char* sm = stage_mask(a, i, b, smask);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int d = a.d, LR = d >> 3, G = 64 / LR, g = lane / LR, cl = lane % LR, c = cl * 8, h = cl / LH;
+    const int KS = 4 * G;                        // keys taken per unroll slot by the whole block
     const T* qp = static_cast<const T*>(a.q) + ((int64_t)i * a.B + b) * a.ldq + c;
     const T* kb = static_cast<const T*>(a.k) + (int64_t)b * a.ldk + c;
     const T* vb = static_cast<const T*>(a.v) + (int64_t)b * a.ldv + c;
     const T* rel = static_cast<const T*>(a.rel);
     const int* iq = a.mode == 2 ? a.idx_q + ((int64_t)i * a.B + b) * a.S : nullptr;
     const float keep_scale = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
+    const int joff = wv * G + g;                 // this lane group's key inside a slot
 
     float qf[8];
     { Raw8<T> r; r.load(qp); r.get(qf); }
     float m = -INFINITY, l = 0.f, o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
-    int tn[U];
+    // Software pipeline over two register sets: the loads of the NEXT U keys are issued before the current U keys are
+    // reduced, so every wave always has a set of loads in flight (the un-pipelined loop had none while it computed).
+    struct KeySet { Raw8<T> ra[U], rb[U], k[U], v[U]; int tn[U]; };
+    auto load_idx = [&](int jb, KeySet& ks) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) { const int j = u * G + g; tn[u] = (iq && j < a.S) ? iq[j] : 0; }
-
-    for (int jb = 0; jb < a.S; jb += G * U) {
-        Raw8<T> rra[U], rrb[U], rk[U], rv[U];
+        for (int u = 0; u < U; ++u) { const int j = jb + u * KS + joff; ks.tn[u] = (iq && j < a.S) ? iq[j] : 0; }
+    };
+    auto issue = [&](int jb, KeySet& ks) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int j = jb + u * G + g;
-            rra[u].zero(); rrb[u].zero(); rk[u].zero(); rv[u].zero();
+            const int j = jb + u * KS + joff;
+            ks.ra[u].zero(); ks.rb[u].zero(); ks.k[u].zero(); ks.v[u].zero();
             if (j < a.S) {
-                rk[u].load(kb + (int64_t)j * a.B * a.ldk);
-                rv[u].load(vb + (int64_t)j * a.B * a.ldv);
+                ks.k[u].load(kb + (int64_t)j * a.B * a.ldk);
+                ks.v[u].load(vb + (int64_t)j * a.B * a.ldv);
                 if (a.mode == 1) {
                     const T* p = rel + (((int64_t)j * a.T + i) * a.B + b) * (2 * d) + c;
-                    rra[u].load(p); rrb[u].load(p + d);
+                    ks.ra[u].load(p); ks.rb[u].load(p + d);
                 } else if (a.mode == 2) {
-                    const T* p = rel + (int64_t)tn[u] * (2 * d) + c;
-                    rra[u].load(p); rrb[u].load(p + d);
+                    const T* p = rel + (int64_t)ks.tn[u] * (2 * d) + c;
+                    ks.ra[u].load(p); ks.rb[u].load(p + d);
                 }
             }
         }
-        if (iq) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) { const int j = jb + G * U + u * G + g; tn[u] = j < a.S ? iq[j] : 0; }
-        }
+    };
+    auto consume = [&](int jb, const KeySet& ks) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int j = jb + u * G + g;
+            const int j = jb + u * KS + joff;
             float ra[8], rb[8], kf[8], vf[8];
-            rra[u].get(ra); rrb[u].get(rb); rk[u].get(kf); rv[u].get(vf);
+            ks.ra[u].get(ra); ks.rb[u].get(rb); ks.k[u].get(kf); ks.v[u].get(vf);
             float s = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) s = fmaf(qf[e] + ra[e], kf[e] + rb[e], s);
@@ -185,8 +199,19 @@ __global__ __launch_bounds__(256) void rel_attn_fwd_kernel(AttnArgs a) {
             for (int e = 0; e < 8; ++e) o[e] = fmaf(o[e], alpha, pv * vf[e]);
             m = mn;
         }
+    };
+    const int STEP = KS * U;
+    KeySet A, Bs;
+    load_idx(0, A); load_idx(STEP, Bs);
+    issue(0, A);
+    for (int jb = 0; jb < a.S; jb += 2 * STEP) {
+        issue(jb + STEP, Bs); load_idx(jb + 2 * STEP, A);
+        consume(jb, A);
+        if (jb + STEP >= a.S) break;
+        issue(jb + 2 * STEP, A); load_idx(jb + 3 * STEP, Bs);
+        consume(jb + STEP, Bs);
     }
-    // merge the G key-groups (lanes with equal cl, different g)
+    // merge the G key-groups of this wave (lanes with equal cl, different g)
     for (int off = LR; off < 64; off <<= 1) {
         const float m2 = __shfl_xor(m, off), l2 = __shfl_xor(l, off);
         const float mn = fmaxf(m, m2);
@@ -197,21 +222,44 @@ __global__ __launch_bounds__(256) void rel_attn_fwd_kernel(AttnArgs a) {
         for (int e = 0; e < 8; ++e) { const float o2 = __shfl_xor(o[e], off); o[e] = o[e] * a1 + o2 * a2; }
         m = mn;
     }
-    const float inv = l > 0.f ? 1.f / l : 0.f;
-    if (g == 0) {
-        float r[8];
+    // merge the 4 waves through LDS
+    red[wv][lane][0] = m; red[wv][lane][1] = l;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) r[e] = o[e] * inv;
-        Vec8<T>::store(static_cast<T*>(a.o) + ((int64_t)i * a.B + b) * a.ldo + c, r);
-        if ((cl % LH) == 0) a.lse[((int64_t)i * a.B + b) * a.H + h] = (l > 0.f) ? m + __logf(l) : -INFINITY;
+    for (int e = 0; e < 8; ++e) red[wv][lane][2 + e] = o[e];
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+        for (int w2 = 1; w2 < 4; ++w2) {
+            const float m2 = red[w2][lane][0], l2 = red[w2][lane][1];
+            const float mn = fmaxf(m, m2);
+            float a1 = 1.f, a2 = 1.f;
+            if (mn != -INFINITY) { a1 = __expf(m - mn); a2 = __expf(m2 - mn); }
+            l = l * a1 + l2 * a2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = o[e] * a1 + red[w2][lane][2 + e] * a2;
+            m = mn;
+        }
+        const float inv = l > 0.f ? 1.f / l : 0.f;
+        fin[lane][0] = m; fin[lane][1] = inv;
+        if (g == 0) {
+            float r[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r[e] = o[e] * inv;
+            Vec8<T>::store(static_cast<T*>(a.o) + ((int64_t)i * a.B + b) * a.ldo + c, r);
+            if ((cl % LH) == 0) a.lse[((int64_t)i * a.B + b) * a.H + h] = (l > 0.f) ? m + __logf(l) : -INFINITY;
+        }
     }
-    if (a.w && (cl % LH) == 0) {   // normalise the raw scores this same lane wrote above
-        for (int j = g; j < a.S; j += G) {
-            const int64_t off = (((int64_t)i * a.S + j) * a.B + b) * a.H + h;
-            const float s = a.w[off];
-            float p = (s == -INFINITY || l <= 0.f) ? 0.f : __expf(s - m) * inv;
-            if (a.p_drop > 0.f && p > 0.f) p = drop_keep(a.seed, (uint64_t)off, a.p_drop) ? p * keep_scale : 0.f;
-            a.w[off] = p;
+    if (a.w) {                                   // normalise the raw scores this same lane wrote above
+        __syncthreads();
+        if ((cl % LH) == 0) {
+            const float mf = fin[lane][0], inv = fin[lane][1];
+            for (int j = joff; j < a.S; j += KS) {
+                const int64_t off = (((int64_t)i * a.S + j) * a.B + b) * a.H + h;
+                const float s = a.w[off];
+                float p = (s == -INFINITY || inv <= 0.f) ? 0.f : __expf(s - mf) * inv;
+                if (a.p_drop > 0.f && p > 0.f) p = drop_keep(a.seed, (uint64_t)off, a.p_drop) ? p * keep_scale : 0.f;
+                a.w[off] = p;
+            }
         }
     }
 }
@@ -222,13 +270,15 @@ __global__ __launch_bounds__(256) void rel_attn_fwd_kernel(AttnArgs a) {
 template <typename T, int LH>
 __global__ __launch_bounds__(256) void rel_attn_bwd_q_kernel(AttnArgs a) {
     constexpr int U = Unroll<T>::U;
-    __shared__ unsigned char smask[4][MAXS_LDS];
+    __shared__ unsigned char smask[MAXS_LDS];
+    __shared__ float red[4][64][8];
+    __shared__ float redw[4][64];
     int i, b;
-    const bool ok = map_block(a.T, a.B, i, b);
-    const unsigned char* sm = stage_mask(a, ok, i, b, smask);
-    if (!ok) return;
-    const int lane = threadIdx.x & 63;
+    if (!map_block(a.T, a.B, i, b)) return;
+    const unsigned char* sm = stage_mask(a, i, b, smask);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int d = a.d, LR = d >> 3, G = 64 / LR, g = lane / LR, cl = lane % LR, c = cl * 8, h = cl / LH;
+    const int KS = 4 * G, joff = wv * G + g;
     const int64_t row = (int64_t)i * a.B + b;
     const T* kb = static_cast<const T*>(a.k) + (int64_t)b * a.ldk + c;
     const T* vb = static_cast<const T*>(a.v) + (int64_t)b * a.ldv + c;
@@ -244,50 +294,50 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_q_kernel(AttnArgs a) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) D = fmaf(dof[e], of[e], D);
     D = head_sum<LH>(D);
-    if (a.dw) {     // upstream gradient on the returned weights: D += sum_j w_ij * dw_ij
+    if (a.dw) {     // upstream gradient on the returned weights: D += sum_j w_ij * dw_ij (over ALL keys: 4 waves x G groups)
         float acc = 0.f;
-        for (int j = g; j < a.S; j += G) {
-            const int64_t off = ((row / a.B * a.S + j) * a.B + b) * a.H + h;   // [i,j,b,h]
+        for (int j = joff; j < a.S; j += KS) {
+            const int64_t off = (((int64_t)i * a.S + j) * a.B + b) * a.H + h;
             acc = fmaf(a.w[off], a.dw[off], acc);
         }
         for (int off = LR; off < 64; off <<= 1) acc += __shfl_xor(acc, off);
-        D += acc;
+        redw[wv][lane] = acc;
+        __syncthreads();
+        D += redw[0][lane] + redw[1][lane] + redw[2][lane] + redw[3][lane];
     }
     const float lse = a.lse[row * a.H + h];
     float dq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
-    int tn[U];
+    struct KeySet { Raw8<T> ra[U], rb[U], k[U], v[U]; int tn[U]; };
+    auto load_idx = [&](int jb, KeySet& ks) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) { const int j = u * G + g; tn[u] = (iq && j < a.S) ? iq[j] : 0; }
-
-    for (int jb = 0; jb < a.S; jb += G * U) {
-        Raw8<T> rra[U], rrb[U], rk[U], rv[U];
+        for (int u = 0; u < U; ++u) { const int j = jb + u * KS + joff; ks.tn[u] = (iq && j < a.S) ? iq[j] : 0; }
+    };
+    auto issue = [&](int jb, KeySet& ks) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int j = jb + u * G + g;
-            rra[u].zero(); rrb[u].zero(); rk[u].zero(); rv[u].zero();
+            const int j = jb + u * KS + joff;
+            ks.ra[u].zero(); ks.rb[u].zero(); ks.k[u].zero(); ks.v[u].zero();
             if (j < a.S) {
-                rk[u].load(kb + (int64_t)j * a.B * a.ldk);
-                rv[u].load(vb + (int64_t)j * a.B * a.ldv);
+                ks.k[u].load(kb + (int64_t)j * a.B * a.ldk);
+                ks.v[u].load(vb + (int64_t)j * a.B * a.ldv);
                 if (a.mode == 1) {
                     const T* p = rel + (((int64_t)j * a.T + i) * a.B + b) * (2 * d) + c;
-                    rra[u].load(p); rrb[u].load(p + d);
+                    ks.ra[u].load(p); ks.rb[u].load(p + d);
                 } else if (a.mode == 2) {
-                    const T* p = rel + (int64_t)tn[u] * (2 * d) + c;
-                    rra[u].load(p); rrb[u].load(p + d);
+                    const T* p = rel + (int64_t)ks.tn[u] * (2 * d) + c;
+                    ks.ra[u].load(p); ks.rb[u].load(p + d);
                 }
             }
         }
-        if (iq) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) { const int j = jb + G * U + u * G + g; tn[u] = j < a.S ? iq[j] : 0; }
-        }
+    };
+    auto consume = [&](int jb, const KeySet& ks) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int j = jb + u * G + g;
+            const int j = jb + u * KS + joff;
             if (j >= a.S) continue;
             float ra[8], rb[8], kf[8], vf[8];
-            rra[u].get(ra); rrb[u].get(rb); rk[u].get(kf); rv[u].get(vf);
+            ks.ra[u].get(ra); ks.rb[u].get(rb); ks.k[u].get(kf); ks.v[u].get(vf);
             float s = 0.f, dpv = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -315,23 +365,43 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_q_kernel(AttnArgs a) {
                 Vec8<T>::store(p2 + d, drb);
             }
         }
+    };
+    const int STEP = KS * U;
+    KeySet A, Bs;
+    load_idx(0, A); load_idx(STEP, Bs);
+    issue(0, A);
+    for (int jb = 0; jb < a.S; jb += 2 * STEP) {
+        issue(jb + STEP, Bs); load_idx(jb + 2 * STEP, A);
+        consume(jb, A);
+        if (jb + STEP >= a.S) break;
+        issue(jb + 2 * STEP, A); load_idx(jb + 3 * STEP, Bs);
+        consume(jb + STEP, Bs);
     }
     for (int off = LR; off < 64; off <<= 1) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) dq[e] += __shfl_xor(dq[e], off);
     }
-    if (g == 0) Vec8<T>::store(static_cast<T*>(a.dq) + row * a.lddq + c, dq);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[wv][lane][e] = dq[e];
+    __syncthreads();
+    if (wv == 0 && g == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dq[e] = red[0][lane][e] + red[1][lane][e] + red[2][lane][e] + red[3][lane][e];
+        Vec8<T>::store(static_cast<T*>(a.dq) + row * a.lddq + c, dq);
+    }
 }
 
 // ------------------------------------------------------------------------------------------- backward, key-major
-// per (j,b): dv_j = sum_i pd_ij do_i ; dk_j = sum_i gs_ij (q_i + ra_ji)
+// per (j,b): dv_j = sum_i pd_ij do_i ; dk_j = sum_i gs_ij (q_i + ra_ji); the 4 waves split the queries
 template <typename T, int LH>
 __global__ __launch_bounds__(256) void rel_attn_bwd_kv_kernel(AttnArgs a) {
     constexpr int U = Unroll<T>::U;
+    __shared__ float red[4][64][16];
     int j, b;
     if (!map_block(a.S, a.B, j, b)) return;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int d = a.d, LR = d >> 3, G = 64 / LR, g = lane / LR, cl = lane % LR, c = cl * 8, h = cl / LH;
+    const int KS = 4 * G, ioff = wv * G + g;
     const int64_t row = (int64_t)j * a.B + b;
     const T* qb = static_cast<const T*>(a.q) + (int64_t)b * a.ldq + c;
     const T* dob = static_cast<const T*>(a.d_o) + (int64_t)b * a.lddo + c;
@@ -339,12 +409,12 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_kv_kernel(AttnArgs a) {
     const int* ik = a.mode == 2 ? a.idx_k + row * a.T : nullptr;
     float dk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
-    for (int ib = 0; ib < a.T; ib += G * U) {
+    for (int ib = 0; ib < a.T; ib += KS * U) {
         Raw8<T> rq[U], rdo[U], rra[U];
         float pdv[U], gsv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int i = ib + u * G + g;
+            const int i = ib + u * KS + ioff;
             rq[u].zero(); rdo[u].zero(); rra[u].zero(); pdv[u] = 0.f; gsv[u] = 0.f;
             if (i < a.T) {
                 rq[u].load(qb + (int64_t)i * a.B * a.ldq);
@@ -367,7 +437,15 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_kv_kernel(AttnArgs a) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) { dk[e] += __shfl_xor(dk[e], off); dv[e] += __shfl_xor(dv[e], off); }
     }
-    if (g == 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[wv][lane][e] = dk[e]; red[wv][lane][8 + e] = dv[e]; }
+    __syncthreads();
+    if (wv == 0 && g == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            dk[e] = red[0][lane][e] + red[1][lane][e] + red[2][lane][e] + red[3][lane][e];
+            dv[e] = red[0][lane][8 + e] + red[1][lane][8 + e] + red[2][lane][8 + e] + red[3][lane][8 + e];
+        }
         Vec8<T>::store(static_cast<T*>(a.dk) + row * a.lddk + c, dk);
         Vec8<T>::store(static_cast<T*>(a.dv) + row * a.lddv + c, dv);
     }
@@ -474,7 +552,7 @@ int check_shape(int d, int H) {
     return 0;
 }
 
-int nblocks(int rows, int B) { return rows * ((B + 3) / 4); }
+int nblocks(int rows, int B) { return rows * B; }
 
 }  // namespace
 
