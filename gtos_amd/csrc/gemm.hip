@@ -124,6 +124,44 @@ __device__ __forceinline__ void glds_tile(const T* __restrict__ base, const U128
     }
 }
 
+// ---- M/N-contiguous bf16 operands ([K, rows] in memory: dY and X of dW = dY^T X, W of dX = dY W) also go global -> LDS
+//      directly, as a [BK k][128 rows] tile (256-byte k-rows), and the MFMA fragments (8 consecutive k of one row) are
+//      fetched with the hardware transpose read ds_read_b64_tr_b16: within a 16-lane group lane i supplies the address of
+//      4 contiguous bf16 (row i/4, cols (i%4)*4..) of a 4x16 block and lane l receives column l&15 -- measured on gfx950
+//      with tools/probes/tr_b16_probe.hip.  32-byte granules are XOR-swizzled with (k & 3) so the 4 k-rows of one read
+//      (256 B apart = same banks) land on different banks; the swizzle is applied on the DMA's source address.
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+template <typename T, int NTH>
+__device__ __forceinline__ void glds_tile_km(const T* __restrict__ base, const U128* __restrict__ zeros, int64_t ld, int rows_total,
+                                             int row0, int k0, int kend, char* lds_tile) {
+    static_assert(sizeof(T) == 2, "transpose-read path is bf16 only");
+    constexpr int NT = NTH, ITERS = TCfg<NTH>::ITERS;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int blk = it * (NT / 64) + wave;                    // 1 KB block = k-rows blk*4 .. blk*4+3
+        const int kr = lane >> 4, pp = lane & 15;                 // k-row inside the block, physical 16-byte piece
+        const int lp = ((((pp >> 1) ^ kr) & 7) << 1) | (pp & 1);  // logical piece (8 rows) stored at this physical slot
+        const int k = k0 + blk * 4 + kr, r = row0 + lp * 8;
+        const bool ok = k < kend && r + 8 <= rows_total;
+        const void* src = ok ? static_cast<const void*>(base + (int64_t)k * ld + r) : static_cast<const void*>(zeros);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds_tile + blk * 1024), 16, 0, 0);
+    }
+}
+
+// fragment (8 consecutive k = ks*32 + fq*8 .. +7) of row/column c0 + fr from a [k][128] tile
+__device__ __forceinline__ bf16x8_t tr_fragment(const char* tile, int c0, int ks, int fr, int fq) {
+    const int kq = fr >> 2;                                       // this lane addresses k-row kbase + kq (== k & 3)
+    const int col = (((c0 >> 4) ^ kq) << 5) + (fr & 3) * 8;       // swizzled 32-byte granule + 8-byte piece
+    const char* p0 = tile + (ks * 32 + fq * 8 + kq) * 256 + col;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p0));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p0 + 4 * 256));
+    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
 // ---- register -> LDS.  `lds` is the byte base of this operand's tile in the target stage.
 template <typename T, bool KC, int NTH>
 __device__ __forceinline__ void store_tile(char* __restrict__ lds, const U128 (&regs)[TCfg<NTH>::ITERS]) {
@@ -179,6 +217,9 @@ __global__ __launch_bounds__(NTH, 4) void gemm_kernel(GemmArgs a) {
     constexpr int BK = GemmCfg<T>::BK;
     constexpr int NT = NTH, WAVES_N = TCfg<NTH>::WAVES_N, WTN = TCfg<NTH>::WTN, NTW = TCfg<NTH>::NTW, ITERS = TCfg<NTH>::ITERS;
     constexpr int STAGE = (BM + BN) * ROWB;                       // 32 KB
+    constexpr bool BF = sizeof(T) == 2;
+    constexpr bool GA = FAST && (!TA || BF), GB = FAST && (TB || BF);   // operand goes global -> LDS by DMA
+    constexpr bool TRA = GA && TA, TRB = GB && !TB;                      // ... as a [k][rows] tile read with ds_read_b64_tr_b16
     __shared__ __attribute__((aligned(16))) char lds[STAGES * STAGE];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -224,17 +265,29 @@ __global__ __launch_bounds__(NTH, 4) void gemm_kernel(GemmArgs a) {
     // twice so the two register sets are named, never indexed.  Only the OLDER set is waited for at the end of a step
     // (s_waitcnt vmcnt(8) leaves the 8 newest loads in flight), so HBM latency has two steps of MFMAs to hide under.
     const int fr = lane & 15, fq = lane >> 4;
+    auto dma_a = [&](int k0x, char* dst) {
+        if constexpr (TRA) glds_tile_km<T, NTH>(A, Z, a.lda, a.M, m0, k0x, kend, dst);
+        else glds_tile<T, NTH>(A, Z, a.lda, a.M, m0, k0x, kend, dst);
+    };
+    auto dma_b = [&](int k0x, char* dst) {
+        if constexpr (TRB) glds_tile_km<T, NTH>(B, Z, a.ldb, a.N, n0, k0x, kend, dst);
+        else glds_tile<T, NTH>(B, Z, a.ldb, a.N, n0, k0x, kend, dst);
+    };
     auto mma_stage = [&](const char* As, const char* Bs) {
         if constexpr (sizeof(T) == 2) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {               // BK = 64 = 2 MFMA k-steps of 32; lane chunk = ks*4 + fq
                 bf16x8_t fa[4], fb[NTW];
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    fa[t] = *reinterpret_cast<const bf16x8_t*>(As + lds_off(wm + t * 16 + fr, ks * 4 + fq));
+                for (int t = 0; t < 4; ++t) {
+                    if constexpr (TRA) fa[t] = tr_fragment(As, wm + t * 16, ks, fr, fq);
+                    else fa[t] = *reinterpret_cast<const bf16x8_t*>(As + lds_off(wm + t * 16 + fr, ks * 4 + fq));
+                }
 #pragma unroll
-                for (int t = 0; t < NTW; ++t)
-                    fb[t] = *reinterpret_cast<const bf16x8_t*>(Bs + lds_off(wn + t * 16 + fr, ks * 4 + fq));
+                for (int t = 0; t < NTW; ++t) {
+                    if constexpr (TRB) fb[t] = tr_fragment(Bs, wn + t * 16, ks, fr, fq);
+                    else fb[t] = *reinterpret_cast<const bf16x8_t*>(Bs + lds_off(wn + t * 16 + fr, ks * 4 + fq));
+                }
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -260,10 +313,10 @@ __global__ __launch_bounds__(NTH, 4) void gemm_kernel(GemmArgs a) {
 
     if constexpr (STAGES == 1) {
         // both operands by global_load_lds into the single stage; the other resident workgroups cover the wait
-        static_assert(!(STAGES == 1) || (FAST && !TA && TB), "single-stage variant is the all-DMA forward kernel");
+        static_assert(!(STAGES == 1) || (GA && GB), "single-stage variant needs both operands by DMA");
         for (int k0 = kbeg; k0 < kend; k0 += BK) {
-            glds_tile<T, NTH>(A, Z, a.lda, a.M, m0, k0, kend, lds);
-            glds_tile<T, NTH>(B, Z, a.ldb, a.N, n0, k0, kend, lds + BM * ROWB);
+            dma_a(k0, lds);
+            dma_b(k0, lds + BM * ROWB);
             __syncthreads();                               // hipcc drains the DMA (vmcnt(0)) in front of the barrier
             mma_stage(lds, lds + BM * ROWB);
             __syncthreads();                               // every wave is done reading before the next tile lands
@@ -271,12 +324,11 @@ __global__ __launch_bounds__(NTH, 4) void gemm_kernel(GemmArgs a) {
     } else {
     // K-contiguous operands on the fast path go global -> LDS directly (prefetch distance 1: the barrier drains the
     // DMA); the others through the two register sets (distance 2).
-    constexpr bool GA = FAST && !TA, GB = FAST && TB;
     U128 ra0[ITERS], rb0[ITERS], ra1[ITERS], rb1[ITERS];
-    if constexpr (GA) glds_tile<T, NTH>(A, Z, a.lda, a.M, m0, kbeg, kend, lds);
+    if constexpr (GA) dma_a(kbeg, lds);
     else { load_tile<T, !TA, FAST, NTH>(A, Z, a.lda, a.M, m0, kbeg, kend, ra0); store_tile<T, !TA, NTH>(lds, ra0);
            load_tile<T, !TA, FAST, NTH>(A, Z, a.lda, a.M, m0, kbeg + BK, kend, ra0); }
-    if constexpr (GB) glds_tile<T, NTH>(B, Z, a.ldb, a.N, n0, kbeg, kend, lds + BM * ROWB);
+    if constexpr (GB) dma_b(kbeg, lds + BM * ROWB);
     else { load_tile<T, TB, FAST, NTH>(B, Z, a.ldb, a.N, n0, kbeg, kend, rb0); store_tile<T, TB, NTH>(lds + BM * ROWB, rb0);
            load_tile<T, TB, FAST, NTH>(B, Z, a.ldb, a.N, n0, kbeg + BK, kend, rb0); }
     __syncthreads();
@@ -286,9 +338,9 @@ __global__ __launch_bounds__(NTH, 4) void gemm_kernel(GemmArgs a) {
         {   // even step: tile k0 in stage cur, tile k0+BK in flight in set 0, issue tile k0+2BK into set 1
             const char* As = lds + cur * STAGE;
             char* An = lds + (cur ^ 1) * STAGE;
-            if constexpr (GA) glds_tile<T, NTH>(A, Z, a.lda, a.M, m0, k0 + BK, kend, An);
+            if constexpr (GA) dma_a(k0 + BK, An);
             else load_tile<T, !TA, FAST, NTH>(A, Z, a.lda, a.M, m0, k0 + 2 * BK, kend, ra1);
-            if constexpr (GB) glds_tile<T, NTH>(B, Z, a.ldb, a.N, n0, k0 + BK, kend, An + BM * ROWB);
+            if constexpr (GB) dma_b(k0 + BK, An + BM * ROWB);
             else load_tile<T, TB, FAST, NTH>(B, Z, a.ldb, a.N, n0, k0 + 2 * BK, kend, rb1);
             __builtin_amdgcn_sched_barrier(0);             // keep the loads ahead of the MFMA block (hipcc sinks them)
             mma_stage(As, As + BM * ROWB);
@@ -302,9 +354,9 @@ __global__ __launch_bounds__(NTH, 4) void gemm_kernel(GemmArgs a) {
         {   // odd step: roles of the register sets swapped
             const char* As = lds + cur * STAGE;
             char* An = lds + (cur ^ 1) * STAGE;
-            if constexpr (GA) glds_tile<T, NTH>(A, Z, a.lda, a.M, m0, k0 + 2 * BK, kend, An);
+            if constexpr (GA) dma_a(k0 + 2 * BK, An);
             else load_tile<T, !TA, FAST, NTH>(A, Z, a.lda, a.M, m0, k0 + 3 * BK, kend, ra0);
-            if constexpr (GB) glds_tile<T, NTH>(B, Z, a.ldb, a.N, n0, k0 + 2 * BK, kend, An + BM * ROWB);
+            if constexpr (GB) dma_b(k0 + 2 * BK, An + BM * ROWB);
             else load_tile<T, TB, FAST, NTH>(B, Z, a.ldb, a.N, n0, k0 + 3 * BK, kend, rb0);
             __builtin_amdgcn_sched_barrier(0);
             mma_stage(As, As + BM * ROWB);
@@ -426,15 +478,18 @@ int launch(const GemmArgs& a, int transA, int transB, hipStream_t s) {
     if (nblk > 0x7fffffffLL) return -6;
     dim3 grid((unsigned)nblk);
     const bool fast = a.vecA && a.vecB;          // both operands 16-byte aligned with whole vectors in range
+    constexpr bool BF = sizeof(T) == 2;          // bf16: every layout is all-DMA (transpose reads) -> single-stage kernel
     if (!transA && transB) {
         if (fast) hipLaunchKernelGGL((gemm_kernel<T, TO, false, true, true, 256, 1>), grid, dim3(256), 0, s, a);
         else      hipLaunchKernelGGL((gemm_kernel<T, TO, false, true, false, 512, 2>), grid, dim3(512), 0, s, a);
     } else if (!transA && !transB) {
-        if (fast) hipLaunchKernelGGL((gemm_kernel<T, TO, false, false, true, 512, 2>), grid, dim3(512), 0, s, a);
-        else      hipLaunchKernelGGL((gemm_kernel<T, TO, false, false, false, 512, 2>), grid, dim3(512), 0, s, a);
+        if (fast && BF) hipLaunchKernelGGL((gemm_kernel<T, TO, false, false, true, 256, BF ? 1 : 2>), grid, dim3(256), 0, s, a);
+        else if (fast)  hipLaunchKernelGGL((gemm_kernel<T, TO, false, false, true, 512, 2>), grid, dim3(512), 0, s, a);
+        else            hipLaunchKernelGGL((gemm_kernel<T, TO, false, false, false, 512, 2>), grid, dim3(512), 0, s, a);
     } else if (transA && !transB) {
-        if (fast) hipLaunchKernelGGL((gemm_kernel<T, TO, true, false, true, 512, 2>), grid, dim3(512), 0, s, a);
-        else      hipLaunchKernelGGL((gemm_kernel<T, TO, true, false, false, 512, 2>), grid, dim3(512), 0, s, a);
+        if (fast && BF) hipLaunchKernelGGL((gemm_kernel<T, TO, true, false, true, 256, BF ? 1 : 2>), grid, dim3(256), 0, s, a);
+        else if (fast)  hipLaunchKernelGGL((gemm_kernel<T, TO, true, false, true, 512, 2>), grid, dim3(512), 0, s, a);
+        else            hipLaunchKernelGGL((gemm_kernel<T, TO, true, false, false, 512, 2>), grid, dim3(512), 0, s, a);
     } else return -2;
     GTOS_CHECK_LAUNCH();
     return 0;
