@@ -260,7 +260,19 @@ __global__ void gru_fwd_kernel(int rows, int hs, const T* __restrict__ xg, const
 template <typename T>
 __global__ void gru_bwd_kernel(int rows, int hs, const T* __restrict__ gates, const T* __restrict__ hprev,
                                const T* __restrict__ dy, int64_t ldy, float* __restrict__ dh,
-                               T* __restrict__ dxg, T* __restrict__ dhg, float p_drop, uint64_t seed, int64_t drop_base) {
+                               T* __restrict__ dxg, T* __restrict__ dhg, float p_drop, uint64_t seed, int64_t drop_base,
+                               float* __restrict__ bias_part) {
+    // bias_part (optional, [gridDim.x, 4*hs] fp32, owned block-row-wise): running column sums of d(r), d(z), d(n_x),
+    // d(n_h) -- the bias gradients of the GRU -- accumulated here instead of re-reading dxg/dhg in 8 colsum passes.
+    // Needs 256 % (hs/8) == 0 so that a thread keeps the same 8 channels over its grid-stride rows.
+    extern __shared__ float btab[];
+    if (bias_part) { for (int i = threadIdx.x; i < 4 * hs; i += blockDim.x) btab[i] = 0.f; __syncthreads(); }
+    float bs[4][8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bs[q][e] = 0.f;
+    int my_c = -1;
     const int hv = hs / 8;
     const float ks = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < (int64_t)rows * hv; t += (int64_t)gridDim.x * blockDim.x) {
@@ -295,6 +307,25 @@ __global__ void gru_bwd_kernel(int rows, int hs, const T* __restrict__ gates, co
         T* hp2 = dhg + (int64_t)row * 3 * hs + c;
         Vec8<T>::store(xp, dr_); Vec8<T>::store(xp + hs, dz_); Vec8<T>::store(xp + 2 * hs, dn_);
         Vec8<T>::store(hp2, dr_); Vec8<T>::store(hp2 + hs, dz_); Vec8<T>::store(hp2 + 2 * hs, dhn);
+        if (bias_part) {
+            my_c = c;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {   // sums of the values as stored (rounded to T), like a colsum over dxg/dhg would see
+                bs[0][e] += to_f<T>(from_f<T>(dr_[e])); bs[1][e] += to_f<T>(from_f<T>(dz_[e]));
+                bs[2][e] += to_f<T>(from_f<T>(dn_[e])); bs[3][e] += to_f<T>(from_f<T>(dhn[e]));
+            }
+        }
+    }
+    if (bias_part) {
+        if (my_c >= 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) atomicAdd(&btab[q * hs + my_c + e], bs[q][e]);
+        }
+        __syncthreads();
+        float* dst = bias_part + (int64_t)blockIdx.x * 4 * hs;
+        for (int i = threadIdx.x; i < 4 * hs; i += blockDim.x) dst[i] += btab[i];
     }
 }
 
@@ -486,13 +517,18 @@ extern "C" int gtos_gru_cell_fwd(int dtype, int rows, int hs, const void* xg, co
 }
 
 extern "C" int gtos_gru_cell_bwd(int dtype, int rows, int hs, const void* gates, const void* hprev, const void* dy, int64_t ldy,
-                                 float* dh, void* dxg, void* dhg, float p_drop, uint64_t seed, int64_t drop_base, void* stream) {
+                                 float* dh, void* dxg, void* dhg, float p_drop, uint64_t seed, int64_t drop_base,
+                                 float* bias_partials, int n_partials, void* stream) {
     if (hs % 8) return -22;
     if (rows <= 0) return 0;
+    if (bias_partials && (256 % (hs / 8) != 0 || n_partials < 1)) return -26;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    dim3 grid(grid_for((int64_t)rows * hs / 8, 256)), block(256);
-    if (dtype == GTOS_BF16) hipLaunchKernelGGL(gru_bwd_kernel<bf16_t>, grid, block, 0, s, rows, hs, (const bf16_t*)gates, (const bf16_t*)hprev, (const bf16_t*)dy, ldy, dh, (bf16_t*)dxg, (bf16_t*)dhg, p_drop, seed, drop_base);
-    else hipLaunchKernelGGL(gru_bwd_kernel<float>, grid, block, 0, s, rows, hs, (const float*)gates, (const float*)hprev, (const float*)dy, ldy, dh, (float*)dxg, (float*)dhg, p_drop, seed, drop_base);
+    int nb = grid_for((int64_t)rows * hs / 8, 256);
+    if (bias_partials && nb > n_partials) nb = n_partials;
+    dim3 grid(nb), block(256);
+    const size_t sh = bias_partials ? (size_t)4 * hs * sizeof(float) : 0;
+    if (dtype == GTOS_BF16) hipLaunchKernelGGL(gru_bwd_kernel<bf16_t>, grid, block, sh, s, rows, hs, (const bf16_t*)gates, (const bf16_t*)hprev, (const bf16_t*)dy, ldy, dh, (bf16_t*)dxg, (bf16_t*)dhg, p_drop, seed, drop_base, bias_partials);
+    else hipLaunchKernelGGL(gru_bwd_kernel<float>, grid, block, sh, s, rows, hs, (const float*)gates, (const float*)hprev, (const float*)dy, ldy, dh, (float*)dxg, (float*)dhg, p_drop, seed, drop_base, bias_partials);
     GTOS_CHECK_LAUNCH();
     return 0;
 }
@@ -565,4 +601,4 @@ extern "C" int gtos_cast_f32_to_bf16(int64_t n, const float* src, void* dst, voi
     return 0;
 }
 
-extern "C" int gtos_abi_version(void) { return 1; }
+extern "C" int gtos_abi_version(void) { return 2; }

@@ -18,10 +18,13 @@ def _cell_fwd(A, hs, xg, hg, h, y, y_off_elems, ldy, hprev, gates, p, seed, drop
          float(p), seed, drop_base, stream())
 
 
-def _cell_bwd(A, hs, gates, hprev, dy, dy_off_elems, ldy, dh, dxg, dhg, p, seed, drop_base):
+N_BIAS_PARTIALS = 1024
+
+
+def _cell_bwd(A, hs, gates, hprev, dy, dy_off_elems, ldy, dh, dxg, dhg, p, seed, drop_base, bpart):
     dyp = None if dy is None else dy.data_ptr() + dy_off_elems * dy.element_size()
     call("gtos_gru_cell_bwd", dt(gates), A, hs, ptr(gates), ptr(hprev), dyp, ldy, ptr(dh), ptr(dxg), ptr(dhg),
-         float(p), seed, drop_base, stream())
+         float(p), seed, drop_base, ptr(bpart), 0 if bpart is None else bpart.shape[0], stream())
 
 
 class BiGRUFinalFn(torch.autograd.Function):
@@ -92,10 +95,13 @@ class BiGRUFinalFn(torch.autograd.Function):
                 dxg = torch.empty((N, 3 * hs), dtype=dtp, device=dev)
                 dhg = torch.empty((N, 3 * hs), dtype=dtp, device=dev)
                 steps = range(L - 1, -1, -1) if direction == 0 else range(L)
+                # bias gradients accumulate inside the cell kernel (per-block partial column sums) when the shape allows
+                fuse_bias = (256 % (hs // 8) == 0) and (b_ih.requires_grad or b_hh.requires_grad)
+                bpart = torch.zeros((N_BIAS_PARTIALS, 4 * hs), dtype=torch.float32, device=dev) if fuse_bias else None
                 for t in steps:
                     A, off = batch_sizes[t], offs[t]
                     _cell_bwd(A, hs, gates[off:off + A], hprev[off:off + A], dY, off * 2 * hs + direction * hs, 2 * hs,
-                              dh, dxg[off:off + A], dhg[off:off + A], pl, seed, off * 2 * hs + direction * hs)
+                              dh, dxg[off:off + A], dhg[off:off + A], pl, seed, off * 2 * hs + direction * hs, bpart)
                     gemm(dhg[off:off + A], wh_t, trans_b=True, out=dh[:A], accumulate=True)   # dh += d(hg) W_hh
                 # parameter gradients over all steps at once
                 for (wt, dyv, xin, slot) in ((w_hh, dhg, hprev, 1), (w_ih, dxg, inp, 0)):
@@ -104,12 +110,17 @@ class BiGRUFinalFn(torch.autograd.Function):
                         if tgt is None:
                             tgt = grads[base + slot] = torch.zeros(wt.shape, dtype=torch.float32, device=dev)
                         gemm(dyv, xin, trans_a=True, out=tgt, accumulate=True, splitk=_splitk(wt.shape[0], wt.shape[1], N))
+                bsum = bpart.sum(0) if fuse_bias else None            # [4*hs]: d(r), d(z), d(n_x), d(n_h)
                 for (bt, dyv, slot) in ((b_hh, dhg, 3), (b_ih, dxg, 2)):
                     if bt.requires_grad:
                         tgt = _grad_target(bt)
                         if tgt is None:
                             tgt = grads[base + slot] = torch.zeros(bt.shape, dtype=torch.float32, device=dev)
-                        call("gtos_colsum", dt(dyv), N, 3 * hs, 3 * hs, ptr(dyv), ptr(tgt), stream())
+                        if fuse_bias:
+                            tgt[:2 * hs] += bsum[:2 * hs]
+                            tgt[2 * hs:] += bsum[2 * hs:3 * hs] if slot == 2 else bsum[3 * hs:]
+                        else:
+                            call("gtos_colsum", dt(dyv), N, 3 * hs, 3 * hs, ptr(dyv), ptr(tgt), stream())
                 if l > 0 or ctx.needs_input_grad[0]:
                     if d_inp is None:
                         d_inp = gemm(dxg, wi_t, trans_b=True)

@@ -104,9 +104,13 @@ int gtos_colsum(int dtype, int rows, int N, int64_t ld, const void* dy, float* o
  * inter-layer dropout of nn.GRU(dropout=...) when p_drop>0), saves h_prev and the gates [rows,4*hs]. */
 int gtos_gru_cell_fwd(int dtype, int rows, int hs, const void* xg, const void* hg, void* h, void* y, int64_t ldy,
                       void* hprev_save, void* gates, float p_drop, uint64_t seed, int64_t drop_base, void* stream);
-/* Backward of one step: dh (fp32, in/out) carries the state gradient; writes d(xg), d(hg) [rows,3*hs]. */
+/* Backward of one step: dh (fp32, in/out) carries the state gradient; writes d(xg), d(hg) [rows,3*hs].
+ * bias_partials (optional, fp32 [n_partials, 4*hs], zeroed by the caller once per layer/direction): running column sums
+ * of d(r), d(z), d(n_x), d(n_h) per launch block -- summed over dim 0 they are the GRU bias gradients
+ * (b_ih: r,z,n_x; b_hh: r,z,n_h), so no extra pass over d(xg)/d(hg) is needed.  Requires 256 % (hs/8) == 0. */
 int gtos_gru_cell_bwd(int dtype, int rows, int hs, const void* gates, const void* hprev, const void* dy, int64_t ldy,
-                      float* dh, void* dxg, void* dhg, float p_drop, uint64_t seed, int64_t drop_base, void* stream);
+                      float* dh, void* dxg, void* dhg, float p_drop, uint64_t seed, int64_t drop_base,
+                      float* bias_partials, int n_partials, void* stream);
 
 /* Relation lookup/aggregation: out[P,d] = mean over the K path ids of bank rows, row 0 zeroed, divisor
  * clamp(#non-zero ids, 1) (generator/generator.py:83-88, :60-65); zero_row0=0,K=1 is the train lookup (:79). */

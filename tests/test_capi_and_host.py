@@ -35,7 +35,8 @@ def test_library_exports_every_declared_symbol(lib_path):
     for name in funcs:
         assert hasattr(lib, name), "libgtos_hip.so does not export %s" % name
     lib.gtos_abi_version.restype = ctypes.c_int
-    assert lib.gtos_abi_version() == 1
+    from gtos_amd import _lib
+    assert lib.gtos_abi_version() == _lib.ABI_VERSION
 
 
 def test_host_library_exports_every_declared_symbol():

@@ -30,6 +30,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--only", default="")
+    ap.add_argument("--torch", action="store_true", help="also time torch.matmul (hipBLASLt) on the same operands")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     for name, ta, tb, M, N, K, od in SHAPES:
@@ -53,6 +54,18 @@ def main():
         byts = (M * K + N * K) * 2 + M * N * out.element_size()
         print("%-16s M=%8d N=%5d K=%8d splitk=%2d  %8.3f ms  %7.1f TF/s  min-traffic %6.2f GB -> %5.2f TB/s" % (
             name, M, N, K, sk, ms, flops / ms / 1e9, byts / 1e9, byts / ms / 1e9), flush=True)
+        if a.torch:
+            At, Bt = (A.t() if ta else A), (B.t() if tb else B)
+            ref = torch.matmul(At, Bt)
+            torch.cuda.synchronize()
+            s.record()
+            for _ in range(a.reps):
+                ref = torch.matmul(At, Bt)
+            e.record()
+            torch.cuda.synchronize()
+            mt = s.elapsed_time(e) / a.reps
+            print("%-16s   torch.matmul (bf16 out)        %8.3f ms  %7.1f TF/s" % ("", mt, flops / mt / 1e9), flush=True)
+            del ref
         del A, B, out
 
 
