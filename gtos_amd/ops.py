@@ -12,6 +12,7 @@ _seed_state = [0x5DEECE66D]
 
 # Optional kernel timing with HIP events on the launch stream (bench.py's roofline leg): name -> [(start, end)]
 PROFILE = None
+GEMM_PROFILE = None        # tools/profile_step.py: (layout, N, K, out dtype) -> [(M, start, end)]
 
 
 class _Timed:
@@ -77,8 +78,17 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, bias=None, relu=False, p_
     ldc = out.stride(0) if M > 1 else max(N, out.stride(0))
     if bias is not None and bias.dtype != torch.float32:
         bias = bias.float()
+    if GEMM_PROFILE is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     call("gtos_gemm", dt(a), dt(out), int(trans_a), int(trans_b), M, N, K, ptr(a), lda, ptr(b), ldb, ptr(out), ldc,
          ptr(bias), int(relu), float(p_drop), seed, int(accumulate), splitk, stream())
+    if GEMM_PROFILE is not None:
+        ev[1].record()
+        big = "M" if trans_a else "K"       # weight-gradient GEMMs reduce over the long dimension
+        key = ("%s%s" % ("T" if trans_a else "N", "T" if trans_b else "N"), N, M if trans_a else K,
+               str(a.dtype)[6:] + ">" + str(out.dtype)[6:], splitk if trans_a else 1, big)
+        GEMM_PROFILE.setdefault(key, []).append((K if trans_a else M, ev[0], ev[1]))
     return out
 
 
