@@ -22,6 +22,17 @@
 //     LDS and leave as full 128-byte row segments.
 #include "common.h"
 
+// 256 bytes of zeros in GLOBAL memory (allocated once per process): target of out-of-range tile loads.  A __device__
+// constant would make the selected pointer generic and turn the tile loads into flat loads.  Shared with gru_step.hip.
+__attribute__((visibility("hidden"))) const void* gtos_zero_block() {
+    static void* z = nullptr;
+    if (!z) {
+        if (hipMalloc(&z, 256) != hipSuccess) return nullptr;
+        if (hipMemset(z, 0, 256) != hipSuccess) return nullptr;
+    }
+    return z;
+}
+
 namespace {
 
 constexpr int BM = 128, BN = 128;
@@ -37,16 +48,7 @@ template <int NTH> struct TCfg {
     static constexpr int ITERS = 1024 / NTH;    // 16-byte vectors per thread per operand tile (128 rows x 128 B / NTH / 16)
 };
 
-// 16 bytes of zeros in GLOBAL memory (allocated once per process): target of out-of-range tile loads.  A __device__
-// constant would make the selected pointer generic and turn the tile loads into flat loads.
-const void* zero_block() {
-    static void* z = nullptr;
-    if (!z) {
-        if (hipMalloc(&z, 256) != hipSuccess) return nullptr;
-        if (hipMemset(z, 0, 256) != hipSuccess) return nullptr;
-    }
-    return z;
-}
+inline const void* zero_block() { return gtos_zero_block(); }
 
 struct GemmArgs {
     const void* A; const void* B; void* C; const float* bias;

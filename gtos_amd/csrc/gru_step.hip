@@ -1,0 +1,238 @@
+// Fused forward GRU time step for gfx950 (bf16): gate products on MFMA with the cell in the epilogue.
+//
+// Replaces, for one time step of nn.GRU as RelationEncoder uses it (/root/reference/generator/encoder.py:93-111),
+//   xg = x W_ih^T + b_ih        (optional: HAS_X; otherwise xg is read)
+//   hg = h W_hh^T + b_hh
+//   r = s(xg_r + hg_r), z = s(xg_z + hg_z), n = tanh(xg_n + r * hg_n), h' = (1 - z) n + z h
+// without the [rows, 3*hs] round trips through HBM: a 256-thread workgroup owns 128 rows x 64 hidden channels, i.e. the
+// r, z and n columns of those channels (3 x 64 weight rows per operand tile), accumulates x- and h-products in four
+// fp32 accumulator groups (r, z, n_x, n_h) and applies the gates in registers.
+//
+// Layout tricks:
+//   * 4 waves stacked along the rows (32 rows x 192 columns each): a lane ends up with 16 CONSECUTIVE channels of a
+//     row (32 bytes) and the 4 lanes of a row with a full 128-byte segment, because the weight rows are loaded into
+//     the LDS tile in the order  lds_row = group*64 + nt*16 + q*4 + e  <->  channel = q*16 + nt*4 + e
+//     (nt = 16-column MFMA block, lane quad q holds rows q*4+e of the swapped-operand 16x16 result);
+//   * operands K-contiguous in LDS (128-byte rows, XOR chunk swizzle as in gemm.hip), filled by global_load_lds_dwordx4;
+//   * one 40 KB LDS stage; the resident workgroups of a CU cover each other's load latency;
+//   * XCD-aware tile order: the 4 channel tiles of a row panel run back to back on one XCD (h/x rows shared in its L2).
+// The new state of row m goes to h_out[m] when m < n_out (the packed "previous state" slot of the next time step, which
+// is the next launch's A operand) and to h_fin[m] otherwise (sequence finished) -- no separate h_prev copy.
+#include "common.h"
+
+__attribute__((visibility("hidden"))) const void* gtos_zero_block();      // gemm.hip: 256 zero bytes in global memory
+
+namespace {
+
+constexpr int ROWB = 128, BK = 64, TM = 128, TC = 64, WROWS = 3 * TC;
+constexpr int A_BYTES = TM * ROWB, B_BYTES = WROWS * ROWB;
+
+__device__ __forceinline__ int swz(int row) { return ((row >> 1) & 7) ^ ((row >> 4) & 3); }
+__device__ __forceinline__ int lds_off(int r, int c) { return r * ROWB + ((c ^ swz(r)) << 4); }
+
+struct StepArgs {
+    const bf16_t* x; int64_t ldx; int in_dim; const bf16_t* w_ih; const float* b_ih;
+    const bf16_t* xg;
+    const bf16_t* h_in; const bf16_t* w_hh; const float* b_hh;
+    bf16_t* h_out; int n_out; bf16_t* h_fin; bf16_t* gates; bf16_t* y; int64_t ldy;
+    float p_drop; uint64_t seed; int64_t drop_base;
+    int rows, hs; const void* zeros;
+};
+
+// 128 activation rows x 64 k
+__device__ __forceinline__ void dma_rows(const bf16_t* __restrict__ base, const U128* __restrict__ zeros, int64_t ld, int rows_total,
+                                         int row0, int k0, int kend, char* tile, int wave, int lane) {
+#pragma unroll
+    for (int it = 0; it < TM / 32; ++it) {
+        const int blk = it * 4 + wave, rl = blk * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ swz(rl);
+        const int r = row0 + rl, k = k0 + c * 8;
+        const bool ok = r < rows_total && k + 8 <= kend;
+        const void* src = ok ? static_cast<const void*>(base + (int64_t)r * ld + k) : static_cast<const void*>(zeros);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(tile + blk * 1024), 16, 0, 0);
+    }
+}
+
+// 3 x 64 weight rows (gates r, z, n of channels c0..c0+63) x 64 k, in the permuted row order described above
+__device__ __forceinline__ void dma_weights(const bf16_t* __restrict__ w, const U128* __restrict__ zeros, int64_t ld, int hs,
+                                            int c0, int k0, int kend, char* tile, int wave, int lane) {
+#pragma unroll
+    for (int it = 0; it < WROWS / 32; ++it) {
+        const int blk = it * 4 + wave, rl = blk * 8 + (lane >> 3);
+        const int g = rl >> 6, nt = (rl >> 4) & 3, q = (rl >> 2) & 3, e = rl & 3;
+        const int wrow = g * hs + c0 + q * 16 + nt * 4 + e;
+        const int c = (lane & 7) ^ swz(rl);
+        const int k = k0 + c * 8;
+        const bool ok = k + 8 <= kend;
+        const void* src = ok ? static_cast<const void*>(w + (int64_t)wrow * ld + k) : static_cast<const void*>(zeros);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(tile + blk * 1024), 16, 0, 0);
+    }
+}
+
+// one 64-deep k tile: weight group g (0 r, 1 z, 2 n) accumulates into accumulator group (g < 2 ? g : G2)
+template <int NG, int G2>
+__device__ __forceinline__ void mma_tile(const char* As, const char* Bs, int wrow0, int fr, int fq, f32x4_t (&acc)[2][NG * 4]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        bf16x8_t fa[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) fa[mt] = *reinterpret_cast<const bf16x8_t*>(As + lds_off(wrow0 + mt * 16 + fr, ks * 4 + fq));
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const int ag = g < 2 ? g : G2;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const bf16x8_t fb = *reinterpret_cast<const bf16x8_t*>(Bs + lds_off(g * 64 + nt * 16 + fr, ks * 4 + fq));
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)   // swapped operands: result rows <-> channels, columns <-> activation rows
+                    acc[mt][ag * 4 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa[mt], acc[mt][ag * 4 + nt], 0, 0, 0);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void ld16(const bf16_t* p, float (&v)[16]) {
+    const uint4 a = *reinterpret_cast<const uint4*>(p), b = *reinterpret_cast<const uint4*>(p + 8);
+    v[0] = lo_bf(a.x); v[1] = hi_bf(a.x); v[2] = lo_bf(a.y); v[3] = hi_bf(a.y);
+    v[4] = lo_bf(a.z); v[5] = hi_bf(a.z); v[6] = lo_bf(a.w); v[7] = hi_bf(a.w);
+    v[8] = lo_bf(b.x); v[9] = hi_bf(b.x); v[10] = lo_bf(b.y); v[11] = hi_bf(b.y);
+    v[12] = lo_bf(b.z); v[13] = hi_bf(b.z); v[14] = lo_bf(b.w); v[15] = hi_bf(b.w);
+}
+__device__ __forceinline__ void st16(bf16_t* p, const float (&v)[16]) {
+    *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf(v[0], v[1]), pack_bf(v[2], v[3]), pack_bf(v[4], v[5]), pack_bf(v[6], v[7]));
+    *reinterpret_cast<uint4*>(p + 8) = make_uint4(pack_bf(v[8], v[9]), pack_bf(v[10], v[11]), pack_bf(v[12], v[13]), pack_bf(v[14], v[15]));
+}
+__device__ __forceinline__ void ldf16(const float* p, float (&v)[16]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 a = *reinterpret_cast<const float4*>(p + i * 4);
+        v[i * 4] = a.x; v[i * 4 + 1] = a.y; v[i * 4 + 2] = a.z; v[i * 4 + 3] = a.w;
+    }
+}
+
+template <bool HAS_X>
+__global__ __launch_bounds__(256, 2) void gru_step_fwd_kernel(StepArgs a) {
+    constexpr int NG = HAS_X ? 4 : 3;           // accumulator groups: r, z, (n_x,) n_h
+    constexpr int GH = HAS_X ? 3 : 2;           // group of the h-part of n
+    __shared__ __attribute__((aligned(16))) char lds[A_BYTES + B_BYTES];
+    char* As = lds;
+    char* Bs = lds + A_BYTES;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int nC = a.hs / TC;
+    const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
+    const int m0 = ((sq / nC) * 8 + xcd) * TM, c0 = (sq % nC) * TC;
+    if (m0 >= a.rows) return;
+    const U128* Z = static_cast<const U128*>(a.zeros);
+
+    f32x4_t acc[2][NG * 4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NG * 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    if constexpr (HAS_X) {
+        for (int k0 = 0; k0 < a.in_dim; k0 += BK) {
+            dma_rows(a.x, Z, a.ldx, a.rows, m0, k0, a.in_dim, As, wave, lane);
+            dma_weights(a.w_ih, Z, a.in_dim, a.hs, c0, k0, a.in_dim, Bs, wave, lane);
+            __syncthreads();
+            mma_tile<NG, 2>(As, Bs, wave * 32, fr, fq, acc);
+            __syncthreads();
+        }
+    }
+    for (int k0 = 0; k0 < a.hs; k0 += BK) {
+        dma_rows(a.h_in, Z, a.hs, a.rows, m0, k0, a.hs, As, wave, lane);
+        dma_weights(a.w_hh, Z, a.hs, a.hs, c0, k0, a.hs, Bs, wave, lane);
+        __syncthreads();
+        mma_tile<NG, GH>(As, Bs, wave * 32, fr, fq, acc);
+        __syncthreads();
+    }
+
+    // ---- cell: lane (fr, fq) holds rows m0 + wave*32 + mt*16 + fr, channels cb .. cb+15 (index nt*4 + e)
+    const int cb = c0 + fq * 16, hs = a.hs;
+    float bhr[16], bhz[16], bhn[16];
+    ldf16(a.b_hh + cb, bhr); ldf16(a.b_hh + hs + cb, bhz); ldf16(a.b_hh + 2 * hs + cb, bhn);
+    if constexpr (HAS_X) {
+        float t[16];
+        ldf16(a.b_ih + cb, t);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bhr[i] += t[i];
+        ldf16(a.b_ih + hs + cb, t);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bhz[i] += t[i];
+    }
+    const float ks = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int m = m0 + wave * 32 + mt * 16 + fr;
+        if (m >= a.rows) continue;
+        float xr[16], xz[16], xn[16], hp[16];
+        if constexpr (HAS_X) {
+            ldf16(a.b_ih + 2 * hs + cb, xn);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { xr[i] = 0.f; xz[i] = 0.f; xn[i] += acc[mt][8 + (i >> 2)][i & 3]; }
+        } else {
+            const bf16_t* xp = a.xg + (int64_t)m * 3 * hs + cb;
+            ld16(xp, xr); ld16(xp + hs, xz); ld16(xp + 2 * hs, xn);
+        }
+        ld16(a.h_in + (int64_t)m * hs + cb, hp);
+        float gr[16], gz[16], gn[16], hn[16], o[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            gr[i] = 1.f / (1.f + __expf(-(xr[i] + acc[mt][(i >> 2)][i & 3] + bhr[i])));
+            gz[i] = 1.f / (1.f + __expf(-(xz[i] + acc[mt][4 + (i >> 2)][i & 3] + bhz[i])));
+            hn[i] = acc[mt][GH * 4 + (i >> 2)][i & 3] + bhn[i];
+            // the saved hn is what backward multiplies by: round it first so that forward and backward agree
+            hn[i] = bf2f(f2bf(hn[i]));
+            gn[i] = tanhf(xn[i] + gr[i] * hn[i]);
+            o[i] = (1.f - gz[i]) * gn[i] + gz[i] * hp[i];
+        }
+        bf16_t* gp = a.gates + (int64_t)m * 4 * hs + cb;
+        st16(gp, gr); st16(gp + hs, gz); st16(gp + 2 * hs, gn); st16(gp + 3 * hs, hn);
+        bf16_t* hdst = (m < a.n_out ? a.h_out : a.h_fin) + (int64_t)m * hs + cb;
+        st16(hdst, o);
+        if (a.y) {
+            if (a.p_drop > 0.f) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    o[i] = drop_keep(a.seed, (uint64_t)(a.drop_base + (int64_t)m * a.ldy + cb + i), a.p_drop) ? o[i] * ks : 0.f;
+            }
+            st16(a.y + (int64_t)m * a.ldy + cb, o);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, int in_dim, const void* w_ih, const float* b_ih,
+                                 const void* xg, const void* h_in, const void* w_hh, const float* b_hh,
+                                 void* h_out, int n_out, void* h_fin, void* gates, void* y, int64_t ldy,
+                                 float p_drop, uint64_t seed, int64_t drop_base, void* stream) {
+    if (rows <= 0) return 0;
+    if (hs <= 0 || hs % TC) return -22;
+    if (!h_in || !w_hh || !b_hh || !gates) return -23;
+    if ((n_out > 0 && !h_out) || (n_out < rows && !h_fin)) return -23;
+    if (x) {
+        if (!w_ih || !b_ih || in_dim <= 0 || in_dim % 8 || ldx % 8 || (uintptr_t)x % 16 || (uintptr_t)w_ih % 16) return -24;
+    } else if (!xg || (uintptr_t)xg % 16) return -24;
+    if ((uintptr_t)h_in % 16 || (uintptr_t)w_hh % 16 || (uintptr_t)gates % 16 || (uintptr_t)h_out % 16 || (uintptr_t)h_fin % 16 ||
+        (uintptr_t)b_hh % 16 || (uintptr_t)b_ih % 16) return -25;
+    if (y && ((uintptr_t)y % 16 || ldy % 8)) return -25;
+    StepArgs a;
+    a.x = (const bf16_t*)x; a.ldx = ldx; a.in_dim = in_dim; a.w_ih = (const bf16_t*)w_ih; a.b_ih = b_ih; a.xg = (const bf16_t*)xg;
+    a.h_in = (const bf16_t*)h_in; a.w_hh = (const bf16_t*)w_hh; a.b_hh = b_hh;
+    a.h_out = (bf16_t*)h_out; a.n_out = n_out; a.h_fin = (bf16_t*)h_fin; a.gates = (bf16_t*)gates; a.y = (bf16_t*)y; a.ldy = ldy;
+    a.p_drop = p_drop; a.seed = seed; a.drop_base = drop_base; a.rows = rows; a.hs = hs;
+    a.zeros = gtos_zero_block();
+    if (!a.zeros) return -5;
+    const long long nM = (rows + TM - 1) / TM, nC = hs / TC;
+    const long long nblk = ((nM + 7) / 8) * 8 * nC;
+    if (nblk > 0x7fffffffLL) return -6;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (x) hipLaunchKernelGGL(gru_step_fwd_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, s, a);
+    else   hipLaunchKernelGGL(gru_step_fwd_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, s, a);
+    GTOS_CHECK_LAUNCH();
+    return 0;
+}

@@ -5,6 +5,8 @@ MI355X counterpart of ``nn.utils.rnn.pack_padded_sequence`` + ``nn.GRU`` as Rela
 time step is one [active,h]x[h,3h] GEMM plus the fused gate kernel (gtos_gru_cell_fwd), and the backward pass
 is explicit BPTT with one weight-gradient GEMM per direction over all steps at once.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -19,6 +21,17 @@ def _cell_fwd(A, hs, xg, hg, h, y, y_off_elems, ldy, hprev, gates, p, seed, drop
 
 
 N_BIAS_PARTIALS = 1024
+
+# Forward time step on bf16: "x" = input AND recurrent gate products + cell in ONE kernel (gtos_gru_step_fwd),
+# "h" = recurrent product + cell fused, input gates by one big GEMM, "off" = GEMM + cell kernel per step (the fp32 path).
+FUSE = os.environ.get("GTOS_GRU_FUSE", "x")
+
+
+def _step_fwd(A, hs, x, xg, h_in, wi, b_ih, wh, b_hh, h_out, n_out, h_fin, gates, y, y_off_elems, ldy, p, seed, drop_base):
+    yp = None if y is None else y.data_ptr() + y_off_elems * y.element_size()
+    call("gtos_gru_step_fwd", A, hs, ptr(x), 0 if x is None else x.stride(0), 0 if x is None else x.shape[1],
+         ptr(wi) if x is not None else None, ptr(b_ih) if x is not None else None, ptr(xg), ptr(h_in), ptr(wh), ptr(b_hh),
+         ptr(h_out), n_out, ptr(h_fin), ptr(gates), yp, ldy, float(p), seed, drop_base, stream())
 
 
 def _cell_bwd(A, hs, gates, hprev, dy, dy_off_elems, ldy, dh, dxg, dhg, p, seed, drop_base, bpart):
@@ -54,17 +67,42 @@ class BiGRUFinalFn(torch.autograd.Function):
             for direction in (0, 1):
                 w_ih, w_hh, b_ih, b_hh = weights[l * 8 + direction * 4: l * 8 + direction * 4 + 4]
                 wi, wh = compute_weight(w_ih, dtp), compute_weight(w_hh, dtp)
-                xg = gemm(inp, wi, trans_b=True, bias=b_ih.detach())
-                h = torch.zeros((R, hs), dtype=dtp, device=dev)
-                hg = torch.empty((R, 3 * hs), dtype=dtp, device=dev)
                 gates = torch.empty((N, 4 * hs), dtype=dtp, device=dev)
                 hprev = torch.empty((N, hs), dtype=dtp, device=dev)
                 steps = range(L) if direction == 0 else range(L - 1, -1, -1)
-                for t in steps:
-                    A, off = batch_sizes[t], offs[t]
-                    gemm(h[:A], wh, trans_b=True, bias=b_hh.detach(), out=hg[:A])
-                    _cell_fwd(A, hs, xg[off:off + A], hg, h, Y, off * 2 * hs + direction * hs, 2 * hs,
-                              hprev[off:off + A], gates[off:off + A], pl, seed, off * 2 * hs + direction * hs)
+                fuse = FUSE if (dtp == torch.bfloat16 and hs % 64 == 0 and inp.shape[1] % 8 == 0) else "off"
+                if fuse != "off":
+                    # hprev[offs[t] + m] IS the state row m enters step t with: each step writes its result straight into
+                    # the next step's slot (or into `h` once the sequence is finished), nothing is copied
+                    h = torch.empty((R, hs), dtype=dtp, device=dev)
+                    xg = None if fuse == "x" else gemm(inp, wi, trans_b=True, bias=b_ih.detach())
+                    bi, bh = b_ih.detach(), b_hh.detach()
+                    if direction == 0:
+                        hprev[:R].zero_()
+                    else:                               # rows that become active at step t start from h = 0
+                        for t in range(L):
+                            lo = batch_sizes[t + 1] if t + 1 < L else 0
+                            if batch_sizes[t] > lo:
+                                hprev[offs[t] + lo: offs[t] + batch_sizes[t]].zero_()
+                    for t in steps:
+                        A, off = batch_sizes[t], offs[t]
+                        nxt = t + 1 if direction == 0 else t - 1
+                        if 0 <= nxt < L:
+                            h_out, n_out = hprev[offs[nxt]:], min(A, batch_sizes[nxt])
+                        else:
+                            h_out, n_out = h, A
+                        _step_fwd(A, hs, inp[off:off + A] if fuse == "x" else None, None if fuse == "x" else xg[off:off + A],
+                                  hprev[off:off + A], wi, bi, wh, bh, h_out, n_out, h, gates[off:off + A],
+                                  Y, off * 2 * hs + direction * hs, 2 * hs, pl, seed, off * 2 * hs + direction * hs)
+                else:
+                    xg = gemm(inp, wi, trans_b=True, bias=b_ih.detach())
+                    h = torch.zeros((R, hs), dtype=dtp, device=dev)
+                    hg = torch.empty((R, 3 * hs), dtype=dtp, device=dev)
+                    for t in steps:
+                        A, off = batch_sizes[t], offs[t]
+                        gemm(h[:A], wh, trans_b=True, bias=b_hh.detach(), out=hg[:A])
+                        _cell_fwd(A, hs, xg[off:off + A], hg, h, Y, off * 2 * hs + direction * hs, 2 * hs,
+                                  hprev[off:off + A], gates[off:off + A], pl, seed, off * 2 * hs + direction * hs)
                 finals.append(h)
                 layer_saved.append((weight_t(w_ih, wi), weight_t(w_hh, wh), gates, hprev))
             saved.append((inp, seed, pl, layer_saved))

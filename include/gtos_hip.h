@@ -104,6 +104,17 @@ int gtos_colsum(int dtype, int rows, int N, int64_t ld, const void* dy, float* o
  * inter-layer dropout of nn.GRU(dropout=...) when p_drop>0), saves h_prev and the gates [rows,4*hs]. */
 int gtos_gru_cell_fwd(int dtype, int rows, int hs, const void* xg, const void* hg, void* h, void* y, int64_t ldy,
                       void* hprev_save, void* gates, float p_drop, uint64_t seed, int64_t drop_base, void* stream);
+/* Fused forward GRU step, bf16 only, hs % 64 == 0 (gru_step.hip): the gate products run on MFMA and the cell is the
+ * epilogue, so no [rows,3*hs] gate tensor round-trips through HBM.  Either x [rows,in_dim] (row stride ldx, in_dim % 8
+ * == 0) with w_ih [3hs,in_dim], b_ih is given -- the input product is then fused too -- or x == NULL and xg [rows,3hs]
+ * already holds x W_ih^T + b_ih.  h_in [rows,hs] is read-only; the new state of row m is written to h_out[m] when
+ * m < n_out (the next step's h_in slot) and to h_fin[m] otherwise (both [*,hs]).  gates [rows,4hs] = r, z, n, hn as
+ * gtos_gru_cell_fwd saves them; y (optional, row stride ldy) receives dropout(h_new) with the same counter layout. */
+int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, int in_dim, const void* w_ih, const float* b_ih,
+                      const void* xg, const void* h_in, const void* w_hh, const float* b_hh,
+                      void* h_out, int n_out, void* h_fin, void* gates, void* y, int64_t ldy,
+                      float p_drop, uint64_t seed, int64_t drop_base, void* stream);
+
 /* Backward of one step: dh (fp32, in/out) carries the state gradient; writes d(xg), d(hg) [rows,3*hs].
  * bias_partials (optional, fp32 [n_partials, 4*hs], zeroed by the caller once per layer/direction): running column sums
  * of d(r), d(z), d(n_x), d(n_h) per launch block -- summed over dim 0 they are the GRU bias gradients

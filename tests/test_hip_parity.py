@@ -182,6 +182,101 @@ def test_relation_encoder_vs_golden(name):
     cmp_param_grads(m, g)
 
 
+def _rel_frob(a, b):
+    return float((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-12))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fuse", ["x", "h", "off"])
+def test_relation_encoder_bf16_fused_step_vs_golden(fuse, monkeypatch):
+    """bf16 GRU: the fused MFMA step kernel (gtos_gru_step_fwd, input product fused or not) and the GEMM + cell path
+    against the reference vectors; bf16 bar = 2e-2 abs on outputs, 3e-2 relative Frobenius on gradients."""
+    from gtos_amd import gru
+    from gtos_amd.encoder import RelationEncoder
+    from oracle.gtos_oracle import VocabSpec
+    monkeypatch.setattr(gru, "FUSE", fuse)
+    g = load_golden("relenc_wide")
+    V, rel_dim, d, hid, R, Lmax = [int(v) for v in g["cfg"]]
+    m = RelationEncoder(VocabSpec(V, 0), rel_dim, d, hid, 2, 0.0).to(dev())
+    m.load_state_dict(sub(g, "sd/"))
+    m.compute_dtype = torch.bfloat16
+    out = m(T(g["tokens"]).to(dev()), T(g["lengths"]).to(dev()))
+    torch.testing.assert_close(out.float().cpu(), T(g["out"]), rtol=2e-2, atol=2e-2)
+    (out.float() * T(g["wout"]).to(dev())).sum().backward()
+    want = sub(g, "grad/")
+    for k, p in m.named_parameters():
+        assert _rel_frob(p.grad.cpu(), want[k]) < 3e-2, k
+
+
+@pytest.mark.gpu
+def test_gru_fused_step_matches_unfused_many_tiles(monkeypatch):
+    """hs=256 (the C2 width), ragged lengths, >1 row panel with a partial last tile, layer dropout on: the fused step
+    kernels must reproduce the GEMM + cell path (same dropout counters) and the pinned oracle (p=0)."""
+    from gtos_amd import gru, ops
+    from oracle import gtos_oracle as O
+    torch.manual_seed(5)
+    R, L, hs, ind = 333, 6, 256, 104
+    lengths = torch.randint(1, L + 1, (R,))
+    lengths[0] = L
+    sl, _ = torch.sort(lengths, descending=True, stable=True)
+    bs = [int((sl > t).sum()) for t in range(L)]
+    N = sum(bs)
+    x32 = 0.5 * torch.randn(N, ind)
+    ws32 = []
+    for l in range(2):
+        for _ in range(2):
+            i = ind if l == 0 else 2 * hs
+            ws32 += [0.08 * torch.randn(3 * hs, i), 0.08 * torch.randn(3 * hs, hs), 0.1 * torch.randn(3 * hs), 0.1 * torch.randn(3 * hs)]
+    wout = torch.randn(R, 2 * hs)
+
+    def run(fuse, p):
+        monkeypatch.setattr(gru, "FUSE", fuse)
+        ops.set_seed(77)
+        x = x32.to(dev(), torch.bfloat16).requires_grad_()
+        ws = [w.to(dev()).requires_grad_() for w in ws32]
+        out = gru.bigru_final(x, bs, hs, 2, p, ws)
+        (out.float() * wout.to(dev())).sum().backward()
+        return out.float().cpu(), x.grad.float().cpu(), [w.grad.cpu() for w in ws]
+
+    ref = run("off", 0.3)
+    for fuse in ("h", "x"):
+        got = run(fuse, 0.3)
+        torch.testing.assert_close(got[0], ref[0], rtol=2e-2, atol=2e-2)
+        assert _rel_frob(got[1], ref[1]) < 3e-2
+        for a, b in zip(got[2], ref[2]):
+            assert _rel_frob(a, b) < 3e-2
+    # p = 0 against the oracle GRU (fp32, CPU)
+    xs = x32.clone().requires_grad_()
+    wo = [w.clone().requires_grad_() for w in ws32]
+    inp = xs
+    fin = None
+    offs = [0]
+    for a in bs:
+        offs.append(offs[-1] + a)
+    for l in range(2):
+        outs, fin = [], []
+        for d_ in range(2):
+            w_ih, w_hh, b_ih, b_hh = wo[l * 8 + d_ * 4: l * 8 + d_ * 4 + 4]
+            h = torch.zeros(R, hs)
+            ys = [None] * L
+            for t in (range(L) if d_ == 0 else range(L - 1, -1, -1)):
+                A = bs[t]
+                hn = O.gru_cell(torch.nn.functional.linear(inp[offs[t]:offs[t] + A], w_ih, b_ih), h[:A], w_hh, b_hh)
+                h = torch.cat([hn, h[A:]], 0)
+                ys[t] = hn
+            outs.append(torch.cat(ys, 0))
+            fin.append(h)
+        inp = torch.cat(outs, 1)
+    want = torch.cat(fin, 1)
+    (want * wout).sum().backward()
+    for fuse in ("x", "h"):
+        got = run(fuse, 0.0)
+        torch.testing.assert_close(got[0], want.detach(), rtol=3e-2, atol=3e-2)
+        assert _rel_frob(got[1], xs.grad) < 4e-2
+        for a, b in zip(got[2], wo):
+            assert _rel_frob(a, b.grad) < 4e-2
+
+
 # ------------------------------------------------------------------------------------------------ decoder blocks
 @pytest.mark.parametrize("name", ["tl_self", "tl_kv"])
 def test_transformer_layer_vs_golden(name):
