@@ -204,6 +204,155 @@ __global__ __launch_bounds__(256, 2) void gru_step_fwd_kernel(StepArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused BACKWARD time step.  With d4 = [d r | d z | d n_x | d n_h] ([rows, 4*hs], ONE buffer: d(xg) = columns 0..3hs,
+// d(hg) = columns {0..2hs, 3hs..4hs}) the gradient that reaches the state of step t through time is
+//     dh_t = dh_direct (kept in the fp32 dh buffer) + d(hg)_{later step} W_hh
+// so the kernel first multiplies the d4 rows of the step processed just before (A operand, K = 3*hs, skipping the n_x
+// block) with W_hh (B operand: rows c0..c0+63 of W_hh^T, K-contiguous), adds dh and the gradient arriving through the
+// layer output (dy, same dropout counters as forward), and then runs the cell backward in registers for its 128 rows x
+// 64 channels: writes d4, leaves dh = dh_total * z, and accumulates the four bias-gradient column sums
+// (wave DPP reduction over the 16 rows of a lane group -> LDS -> one fp32 atomic per (gate, channel) and workgroup).
+struct StepBwdArgs {
+    const bf16_t* d4_prev; int rows_prev; const bf16_t* wh_t;
+    const bf16_t* gates; const bf16_t* hprev; const bf16_t* dy; int64_t ldy;
+    float* dh; bf16_t* d4; float* bias_part; int n_partials;
+    float p_drop; uint64_t seed; int64_t drop_base;
+    int rows, hs; const void* zeros;
+};
+
+#define GTOS_DPP(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, true))
+__device__ __forceinline__ float row16_sum(float v) {   // sum over the 16 lanes of a DPP row (lane & 15)
+    v += GTOS_DPP(v, 0xB1); v += GTOS_DPP(v, 0x4E); v += GTOS_DPP(v, 0x141); v += GTOS_DPP(v, 0x140);
+    return v;
+}
+
+// 64 rows of W_hh^T (channels c0..c0+63, permuted like the forward weight tile) x 64 k
+__device__ __forceinline__ void dma_wt(const bf16_t* __restrict__ w, int64_t ld, int c0, int k0, char* tile, int wave, int lane) {
+#pragma unroll
+    for (int it = 0; it < TC / 32; ++it) {
+        const int blk = it * 4 + wave, rl = blk * 8 + (lane >> 3);
+        const int nt = (rl >> 4) & 3, q = (rl >> 2) & 3, e = rl & 3;
+        const int wrow = c0 + q * 16 + nt * 4 + e;
+        const int c = (lane & 7) ^ swz(rl);
+        const void* src = static_cast<const void*>(w + (int64_t)wrow * ld + k0 + c * 8);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(tile + blk * 1024), 16, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void gru_step_bwd_kernel(StepBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) char lds[A_BYTES + TC * ROWB];
+    __shared__ float btab[4 * TC];
+    char* As = lds;
+    char* Bs = lds + A_BYTES;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int hs = a.hs, nC = hs / TC;
+    const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
+    const int m0 = ((sq / nC) * 8 + xcd) * TM, c0 = (sq % nC) * TC;
+    if (m0 >= a.rows) return;
+    const U128* Z = static_cast<const U128*>(a.zeros);
+    if (a.bias_part) { btab[threadIdx.x] = 0.f; }
+
+    f32x4_t acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    if (a.d4_prev && m0 < a.rows_prev) {
+        for (int kk = 0; kk < 3 * hs; kk += BK) {
+            const int ak = kk < 2 * hs ? kk : kk + hs;                 // skip the d n_x block of d4
+            dma_rows(a.d4_prev, Z, 4 * (int64_t)hs, a.rows_prev, m0, ak, ak + BK, As, wave, lane);
+            dma_wt(a.wh_t, 3 * (int64_t)hs, c0, kk, Bs, wave, lane);
+            __syncthreads();
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8_t fa[2], fb[4];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) fa[mt] = *reinterpret_cast<const bf16x8_t*>(As + lds_off(wave * 32 + mt * 16 + fr, ks * 4 + fq));
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) fb[nt] = *reinterpret_cast<const bf16x8_t*>(Bs + lds_off(nt * 16 + fr, ks * 4 + fq));
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+    } else if (a.bias_part) {
+        __syncthreads();                                               // btab zeroed before anyone adds to it
+    }
+
+    const int cb = c0 + fq * 16;
+    const float ks = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
+    float bs[4][16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bs[q][i] = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int m = m0 + wave * 32 + mt * 16 + fr;
+        if (m >= a.rows) continue;
+        float gr[16], gz[16], gn[16], hn[16], hp[16], g[16];
+        const bf16_t* gp = a.gates + (int64_t)m * 4 * hs + cb;
+        ld16(gp, gr); ld16(gp + hs, gz); ld16(gp + 2 * hs, gn); ld16(gp + 3 * hs, hn);
+        ld16(a.hprev + (int64_t)m * hs + cb, hp);
+        float* dhp = a.dh + (int64_t)m * hs + cb;
+        ldf16(dhp, g);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) g[i] += acc[mt][i >> 2][i & 3];
+        if (a.dy) {
+            float dyv[16];
+            ld16(a.dy + (int64_t)m * a.ldy + cb, dyv);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float t2 = dyv[i];
+                if (a.p_drop > 0.f) t2 = drop_keep(a.seed, (uint64_t)(a.drop_base + (int64_t)m * a.ldy + cb + i), a.p_drop) ? t2 * ks : 0.f;
+                g[i] += t2;
+            }
+        }
+        float dr_[16], dz_[16], dn_[16], dhn[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float dn = g[i] * (1.f - gz[i]);
+            const float dz = g[i] * (hp[i] - gn[i]);
+            dn_[i] = dn * (1.f - gn[i] * gn[i]);
+            dhn[i] = dn_[i] * gr[i];
+            dr_[i] = dn_[i] * hn[i] * gr[i] * (1.f - gr[i]);
+            dz_[i] = dz * gz[i] * (1.f - gz[i]);
+            g[i] *= gz[i];                                             // the direct path h_prev -> h
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<float4*>(dhp + i * 4) = make_float4(g[i * 4], g[i * 4 + 1], g[i * 4 + 2], g[i * 4 + 3]);
+        bf16_t* dp = a.d4 + (int64_t)m * 4 * hs + cb;
+        st16(dp, dr_); st16(dp + hs, dz_); st16(dp + 2 * hs, dn_); st16(dp + 3 * hs, dhn);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {      // sums of the values as stored (rounded), what the weight-gradient GEMMs see
+            bs[0][i] += bf2f(f2bf(dr_[i])); bs[1][i] += bf2f(f2bf(dz_[i]));
+            bs[2][i] += bf2f(f2bf(dn_[i])); bs[3][i] += bf2f(f2bf(dhn[i]));
+        }
+    }
+    if (a.bias_part) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float t = row16_sum(bs[q][i]);
+                if (fr == 0) atomicAdd(&btab[q * TC + fq * 16 + i], t);
+            }
+        __syncthreads();
+        const int q = threadIdx.x >> 6, ch = threadIdx.x & 63;
+        float* dst = a.bias_part + (int64_t)(blockIdx.x % a.n_partials) * 4 * hs + q * hs + c0 + ch;
+        atomicAdd(dst, btab[threadIdx.x]);
+    }
+}
+
 }  // namespace
 
 extern "C" int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, int in_dim, const void* w_ih, const float* b_ih,
@@ -233,6 +382,31 @@ extern "C" int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, i
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (x) hipLaunchKernelGGL(gru_step_fwd_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, s, a);
     else   hipLaunchKernelGGL(gru_step_fwd_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, s, a);
+    GTOS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gtos_gru_step_bwd(int rows, int hs, const void* d4_prev, int rows_prev, const void* w_hh_t,
+                                 const void* gates, const void* hprev, const void* dy, int64_t ldy, float* dh, void* d4,
+                                 float p_drop, uint64_t seed, int64_t drop_base, float* bias_partials, int n_partials,
+                                 void* stream) {
+    if (rows <= 0) return 0;
+    if (hs <= 0 || hs % TC) return -22;
+    if (!gates || !hprev || !dh || !d4 || (d4_prev && !w_hh_t)) return -23;
+    if (bias_partials && n_partials < 1) return -26;
+    if ((uintptr_t)d4_prev % 16 || (uintptr_t)w_hh_t % 16 || (uintptr_t)gates % 16 || (uintptr_t)hprev % 16 || (uintptr_t)dh % 16 ||
+        (uintptr_t)d4 % 16 || (dy && ((uintptr_t)dy % 16 || ldy % 8))) return -25;
+    StepBwdArgs a;
+    a.d4_prev = (const bf16_t*)d4_prev; a.rows_prev = d4_prev ? rows_prev : 0; a.wh_t = (const bf16_t*)w_hh_t;
+    a.gates = (const bf16_t*)gates; a.hprev = (const bf16_t*)hprev; a.dy = (const bf16_t*)dy; a.ldy = ldy;
+    a.dh = dh; a.d4 = (bf16_t*)d4; a.bias_part = bias_partials; a.n_partials = n_partials;
+    a.p_drop = p_drop; a.seed = seed; a.drop_base = drop_base; a.rows = rows; a.hs = hs;
+    a.zeros = gtos_zero_block();
+    if (!a.zeros) return -5;
+    const long long nM = (rows + TM - 1) / TM, nC = hs / TC;
+    const long long nblk = ((nM + 7) / 8) * 8 * nC;
+    if (nblk > 0x7fffffffLL) return -6;
+    hipLaunchKernelGGL(gru_step_bwd_kernel, dim3((unsigned)nblk), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     GTOS_CHECK_LAUNCH();
     return 0;
 }

@@ -130,34 +130,58 @@ class BiGRUFinalFn(torch.autograd.Function):
                     dh = d_out[:, direction * hs:(direction + 1) * hs].float().contiguous()
                 else:
                     dh = torch.zeros((R, hs), dtype=torch.float32, device=dev)
-                dxg = torch.empty((N, 3 * hs), dtype=dtp, device=dev)
-                dhg = torch.empty((N, 3 * hs), dtype=dtp, device=dev)
                 steps = range(L - 1, -1, -1) if direction == 0 else range(L)
-                # bias gradients accumulate inside the cell kernel (per-block partial column sums) when the shape allows
-                fuse_bias = (256 % (hs // 8) == 0) and (b_ih.requires_grad or b_hh.requires_grad)
-                bpart = torch.zeros((N_BIAS_PARTIALS, 4 * hs), dtype=torch.float32, device=dev) if fuse_bias else None
-                for t in steps:
-                    A, off = batch_sizes[t], offs[t]
-                    _cell_bwd(A, hs, gates[off:off + A], hprev[off:off + A], dY, off * 2 * hs + direction * hs, 2 * hs,
-                              dh, dxg[off:off + A], dhg[off:off + A], pl, seed, off * 2 * hs + direction * hs, bpart)
-                    gemm(dhg[off:off + A], wh_t, trans_b=True, out=dh[:A], accumulate=True)   # dh += d(hg) W_hh
+                want_bias = b_ih.requires_grad or b_hh.requires_grad
+                fused = FUSE != "off" and dtp == torch.bfloat16 and hs % 64 == 0
+                if fused:
+                    # d4 = [d r | d z | d n_x | d n_h]: d(xg) and d(hg) share their first two blocks, so ONE buffer serves both
+                    d4 = torch.empty((N, 4 * hs), dtype=dtp, device=dev)
+                    bpart = torch.zeros((N_BIAS_PARTIALS, 4 * hs), dtype=torch.float32, device=dev) if want_bias else None
+                    prev = None
+                    for t in steps:
+                        A, off = batch_sizes[t], offs[t]
+                        dyp = None if dY is None else dY.data_ptr() + (off * 2 * hs + direction * hs) * dY.element_size()
+                        call("gtos_gru_step_bwd", A, hs, None if prev is None else ptr(d4[offs[prev]:]),
+                             0 if prev is None else batch_sizes[prev], ptr(wh_t), ptr(gates[off:off + A]), ptr(hprev[off:off + A]),
+                             dyp, 2 * hs, ptr(dh), ptr(d4[off:off + A]), float(pl), seed, off * 2 * hs + direction * hs,
+                             ptr(bpart), N_BIAS_PARTIALS, stream())
+                        prev = t
+                    dxg = d4[:, :3 * hs]
+                    w_jobs = ((w_hh, d4[:, :2 * hs], hprev, 1, slice(0, 2 * hs)), (w_hh, d4[:, 3 * hs:], hprev, 1, slice(2 * hs, 3 * hs)),
+                              (w_ih, dxg, inp, 0, slice(0, 3 * hs)))
+                else:
+                    dxg = torch.empty((N, 3 * hs), dtype=dtp, device=dev)
+                    dhg = torch.empty((N, 3 * hs), dtype=dtp, device=dev)
+                    # bias gradients accumulate inside the cell kernel (per-block partial column sums) when the shape allows
+                    fuse_bias = (256 % (hs // 8) == 0) and want_bias
+                    bpart = torch.zeros((N_BIAS_PARTIALS, 4 * hs), dtype=torch.float32, device=dev) if fuse_bias else None
+                    for t in steps:
+                        A, off = batch_sizes[t], offs[t]
+                        _cell_bwd(A, hs, gates[off:off + A], hprev[off:off + A], dY, off * 2 * hs + direction * hs, 2 * hs,
+                                  dh, dxg[off:off + A], dhg[off:off + A], pl, seed, off * 2 * hs + direction * hs, bpart)
+                        gemm(dhg[off:off + A], wh_t, trans_b=True, out=dh[:A], accumulate=True)   # dh += d(hg) W_hh
+                    w_jobs = ((w_hh, dhg, hprev, 1, slice(0, 3 * hs)), (w_ih, dxg, inp, 0, slice(0, 3 * hs)))
                 # parameter gradients over all steps at once
-                for (wt, dyv, xin, slot) in ((w_hh, dhg, hprev, 1), (w_ih, dxg, inp, 0)):
+                for (wt, dyv, xin, slot, rows) in w_jobs:
                     if wt.requires_grad:
                         tgt = _grad_target(wt)
                         if tgt is None:
-                            tgt = grads[base + slot] = torch.zeros(wt.shape, dtype=torch.float32, device=dev)
-                        gemm(dyv, xin, trans_a=True, out=tgt, accumulate=True, splitk=_splitk(wt.shape[0], wt.shape[1], N))
-                bsum = bpart.sum(0) if fuse_bias else None            # [4*hs]: d(r), d(z), d(n_x), d(n_h)
-                for (bt, dyv, slot) in ((b_hh, dhg, 3), (b_ih, dxg, 2)):
+                            if grads[base + slot] is None:
+                                grads[base + slot] = torch.zeros(wt.shape, dtype=torch.float32, device=dev)
+                            tgt = grads[base + slot]
+                        nrow = rows.stop - rows.start
+                        gemm(dyv, xin, trans_a=True, out=tgt[rows], accumulate=True, splitk=_splitk(nrow, wt.shape[1], N))
+                bsum = bpart.sum(0) if bpart is not None else None     # [4*hs]: d(r), d(z), d(n_x), d(n_h)
+                for (bt, slot) in ((b_hh, 3), (b_ih, 2)):
                     if bt.requires_grad:
                         tgt = _grad_target(bt)
                         if tgt is None:
                             tgt = grads[base + slot] = torch.zeros(bt.shape, dtype=torch.float32, device=dev)
-                        if fuse_bias:
+                        if bsum is not None:
                             tgt[:2 * hs] += bsum[:2 * hs]
                             tgt[2 * hs:] += bsum[2 * hs:3 * hs] if slot == 2 else bsum[3 * hs:]
                         else:
+                            dyv = dhg if slot == 3 else dxg
                             call("gtos_colsum", dt(dyv), N, 3 * hs, 3 * hs, ptr(dyv), ptr(tgt), stream())
                 if l > 0 or ctx.needs_input_grad[0]:
                     if d_inp is None:
