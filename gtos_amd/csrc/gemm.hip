@@ -57,6 +57,7 @@ struct GemmArgs {
     int relu, accumulate, splitk;
     float p_drop; uint64_t seed;
     const void* zeros;        // 16 zero bytes in global memory
+    float* ws;                // split-K partial tiles [splitk, M, N] (fp32), or null: fp32 atomics straight into C
 };
 
 // f(row) = ((row>>1)&7) ^ ((row>>4)&3).  ds_read_b128 is serviced in 16-lane groups that pair the rows {0-3,12-15} of one
@@ -445,8 +446,12 @@ __global__ __launch_bounds__(NTH, 4) void gemm_kernel(GemmArgs a) {
             TO* cp = C + (int64_t)m * a.ldc + n;
             if (a.splitk > 1) {
                 if constexpr (sizeof(TO) == 4) {
+                    if (a.ws) {     // N % 4 == 0 (host): plain 16-byte stores of this split's partial tile, reduced afterwards
+                        *reinterpret_cast<float4*>(a.ws + ((int64_t)bz * a.M + m) * a.N + n) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) if (n + i < a.N) atomicAdd(reinterpret_cast<float*>(cp) + i, v[i]);
+                        for (int i = 0; i < 4; ++i) if (n + i < a.N) atomicAdd(reinterpret_cast<float*>(cp) + i, v[i]);
+                    }
                 }
                 continue;
             }
@@ -470,6 +475,23 @@ __global__ __launch_bounds__(NTH, 4) void gemm_kernel(GemmArgs a) {
                 }
             }
         }
+    }
+}
+
+// C[m,n] += sum over the K splits of the partial tiles (deterministic alternative to the atomic epilogue: device-scope
+// fp32 atomics from 8 XCDs resolve at the memory side and cost more than the GEMM itself when K per split is short)
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int N, float* __restrict__ C, int64_t ldc) {
+    const int64_t n4 = N / 4, total = (int64_t)M * n4, plane = (int64_t)M * N;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(t / n4), n = (int)(t % n4) * 4;
+        const float* p = ws + (int64_t)m * N + n;
+        float4 acc = *reinterpret_cast<const float4*>(p);
+        for (int s = 1; s < splits; ++s) {
+            const float4 v = *reinterpret_cast<const float4*>(p + s * plane);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        float* cp = C + (int64_t)m * ldc + n;
+        cp[0] += acc.x; cp[1] += acc.y; cp[2] += acc.z; cp[3] += acc.w;
     }
 }
 
@@ -502,7 +524,7 @@ int launch(const GemmArgs& a, int transA, int transB, hipStream_t s) {
 extern "C" int gtos_gemm(int in_dtype, int out_dtype, int transA, int transB, int M, int N, int K,
                          const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                          const float* bias, int relu, float p_drop, uint64_t seed, int accumulate,
-                         int splitk, void* stream) {
+                         int splitk, void* workspace, int64_t workspace_bytes, void* stream) {
     if (M <= 0 || N <= 0) return 0;
     if (K <= 0) return -3;
     const int es = in_dtype == GTOS_BF16 ? 2 : 4, vec = 16 / es;
@@ -520,9 +542,22 @@ extern "C" int gtos_gemm(int in_dtype, int out_dtype, int transA, int transB, in
     const int BKc = in_dtype == GTOS_BF16 ? GemmCfg<bf16_t>::BK : GemmCfg<float>::BK;
     const int ktiles = (K + BKc - 1) / BKc;
     if (splitk > ktiles) splitk = ktiles;
+    if (splitk > 1) { const int tps = (ktiles + splitk - 1) / splitk; splitk = (ktiles + tps - 1) / tps; }   // no empty split
     a.splitk = splitk;
     if (splitk > 1 && (out_dtype != GTOS_F32 || bias || relu || p_drop > 0.f || !accumulate)) return -4;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    a.ws = nullptr;
+    if (splitk > 1 && workspace && N % 4 == 0 && (uintptr_t)workspace % 16 == 0 && (uintptr_t)C % 4 == 0 &&
+        (int64_t)splitk * M * N * 4 <= workspace_bytes) {
+        a.ws = static_cast<float*>(workspace);
+        int rc = in_dtype == GTOS_BF16 ? launch<bf16_t, float>(a, transA, transB, s) : launch<float, float>(a, transA, transB, s);
+        if (rc) return rc;
+        const int64_t total = (int64_t)M * (N / 4);
+        const int nb = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, s, a.ws, splitk, M, N, static_cast<float*>(C), ldc);
+        GTOS_CHECK_LAUNCH();
+        return 0;
+    }
     if (in_dtype == GTOS_BF16 && out_dtype == GTOS_BF16) return launch<bf16_t, bf16_t>(a, transA, transB, s);
     if (in_dtype == GTOS_BF16 && out_dtype == GTOS_F32)  return launch<bf16_t, float>(a, transA, transB, s);
     if (in_dtype == GTOS_F32 && out_dtype == GTOS_F32)   return launch<float, float>(a, transA, transB, s);

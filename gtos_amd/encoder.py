@@ -65,7 +65,7 @@ class RelationEncoder(nn.Module):
         p = self.dropout if (self.training and self.num_layers > 1) else 0.0
         fin = bigru_final(x, batch_sizes, self.hidden_size, self.num_layers, p, self._weights(pad))   # [R, 2h] sorted
         positions = torch.sort(indices)[1]
-        fin = fin.index_select(0, positions)
+        fin = ops.permute_rows(fin, positions, indices)                            # unsort (inverse of `indices`)
         return ops.linear(fin, self.out_proj.weight, self.out_proj.bias)
 
 

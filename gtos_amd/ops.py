@@ -52,10 +52,25 @@ def _row_major(t):
 
 
 def _splitk(M, N, K):
+    """K splits for weight-gradient shapes (few output tiles, long K): enough workgroups for 4 per CU, at least 512 of
+    K per split; the partial tiles go through the workspace (ops._workspace), so splitting is cheap."""
     blocks = ((M + 127) // 128) * ((N + 127) // 128)
     if blocks >= 512 or K < 1024:
         return 1
-    return max(1, min(1024 // blocks, K // 512, 64))
+    cap = max(1, WORKSPACE_BYTES // (4 * M * N))
+    return max(1, min((1024 + blocks - 1) // blocks, K // 512, 256, cap))
+
+
+_WS = {}
+WORKSPACE_BYTES = 256 << 20
+
+
+def _workspace(device):
+    """Split-K partial-tile workspace (one per device, stream-ordered reuse)."""
+    ws = _WS.get(device)
+    if ws is None:
+        ws = _WS[device] = torch.empty(WORKSPACE_BYTES // 4, dtype=torch.float32, device=device)
+    return ws
 
 
 def gemm(a, b, trans_a=False, trans_b=False, out=None, bias=None, relu=False, p_drop=0.0, seed=0,
@@ -82,7 +97,8 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, bias=None, relu=False, p_
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
     call("gtos_gemm", dt(a), dt(out), int(trans_a), int(trans_b), M, N, K, ptr(a), lda, ptr(b), ldb, ptr(out), ldc,
-         ptr(bias), int(relu), float(p_drop), seed, int(accumulate), splitk, stream())
+         ptr(bias), int(relu), float(p_drop), seed, int(accumulate), splitk,
+         ptr(_workspace(a.device)) if splitk > 1 else None, WORKSPACE_BYTES if splitk > 1 else 0, stream())
     if GEMM_PROFILE is not None:
         ev[1].record()
         big = "M" if trans_a else "K"       # weight-gradient GEMMs reduce over the long dimension
@@ -432,3 +448,22 @@ class EmbedRowsFn(torch.autograd.Function):
 
 def embed_rows(tokens, table, dim_pad, p_drop, dtype):
     return EmbedRowsFn.apply(tokens, table, dim_pad, float(p_drop), dtype)
+
+
+class PermuteRowsFn(torch.autograd.Function):
+    """y = x[perm] for a PERMUTATION perm with inverse inv: the backward is the gather g[inv] instead of the
+    atomics-based index_add_ that autograd derives for a general index_select."""
+
+    @staticmethod
+    def forward(ctx, x, perm, inv):
+        ctx.save_for_backward(inv)
+        return x.index_select(0, perm)
+
+    @staticmethod
+    def backward(ctx, g):
+        (inv,) = ctx.saved_tensors
+        return g.index_select(0, inv), None, None
+
+
+def permute_rows(x, perm, inv):
+    return PermuteRowsFn.apply(x, perm, inv)

@@ -30,13 +30,16 @@ int gtos_abi_version(void);
 /* C[M,N] (+)= act(opA(A)[M,K] . opB(B)[K,N] + bias[N]), row-major, MFMA (bf16: 16x16x32, fp32: 16x16x4).
  * Supported (transA,transB): (0,1) Linear forward Y = X W^T; (0,0) dX = dY W; (1,0) dW = dY^T X.
  * relu / p_drop>0 fuse ReLU and dropout(seed) into the epilogue; accumulate adds into C; splitk>1 splits K
- * over grid.z with fp32 atomic accumulation (needs out_dtype F32, accumulate=1, no bias/relu/dropout).
+ * (needs out_dtype F32, accumulate=1, no bias/relu/dropout): with a workspace of >= splitk*M*N*4 bytes (16-byte
+ * aligned, N % 4 == 0) the splits write partial tiles that a second kernel adds into C in a fixed order
+ * (deterministic); without one they accumulate into C with fp32 atomics.
  * Replaces F.linear / nn.Linear and their autograd mm's: generator/graph_transformer.py:61-63 (fc1, relu,
  * dropout, fc2), :106-122 (in_proj, relation_in_proj), :166 (out_proj), :176-197; generator/transformer.py:66-69,
  * :109-119,:162,:175-196; generator/encoder.py:117 and the nn.GRU gate products (:76-82). */
 int gtos_gemm(int in_dtype, int out_dtype, int transA, int transB, int M, int N, int K,
               const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
-              const float* bias, int relu, float p_drop, uint64_t seed, int accumulate, int splitk, void* stream);
+              const float* bias, int relu, float p_drop, uint64_t seed, int accumulate, int splitk,
+              void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Fused relation-aware attention forward: scores, both masks, softmax over keys, weight dropout, P.V.
  *   mode 0: no relation (MultiheadAttention, generator/transformer.py:120-162; q is NOT pre-scaled: scale is
