@@ -37,10 +37,15 @@ class TokenGenerator(nn.Module):
             nn.init.normal_(l.weight, std=0.02)
             nn.init.constant_(l.bias, 0.)
 
-    def forward(self, outs, graph_state, graph_padding_mask, copy_seq, target=None, work=False):
+    def forward(self, outs, graph_state, graph_padding_mask, copy_seq, target=None, work=False, align_kv=None,
+                tot_ext=None):
         p = self.dropout if self.training else 0.0
-        x, alignment_weight = self.alignment_layer(outs, graph_state, graph_state,
-                                                   key_padding_mask=graph_padding_mask, need_weights=True)
+        if align_kv is not None:       # incremental decoding: the graph states' K/V projection is cached
+            x, alignment_weight = self.alignment_layer.attend_cached(outs, align_kv, key_padding_mask=graph_padding_mask,
+                                                                     need_weights=True)
+        else:
+            x, alignment_weight = self.alignment_layer(outs, graph_state, graph_state,
+                                                       key_padding_mask=graph_padding_mask, need_weights=True)
         ln = self.alignment_layer_norm
         outs = ops.layer_norm_residual(outs.to(x.dtype), x, ln.weight, ln.bias, p, ln.eps)
         seq_len, bsz, _ = outs.size()
@@ -49,7 +54,8 @@ class TokenGenerator(nn.Module):
         gate = F.softmax(_padded_linear(outs_token, self.diverter).float(), -1)
         gen_gate, copy_gate = gate.chunk(2, dim=-1)
         probs = gen_gate * F.softmax(_padded_linear(outs_token, self.generator).float(), -1)
-        tot_ext = 1 + int(copy_seq.max().item())
+        if tot_ext is None:
+            tot_ext = 1 + int(copy_seq.max().item())
         vocab_size = probs.size(-1)
         if tot_ext - vocab_size > 0:
             probs = torch.cat([probs, probs.new_zeros((seq_len, bsz, tot_ext - vocab_size))], -1)
@@ -81,3 +87,17 @@ class DecodeLayer(nn.Module):
         token_loss = self.token_generator(outs, graph_state, graph_padding_mask, copy_seq, target=target, work=False)
         token_tot = snt_padding_mask.size(0) - snt_padding_mask.float().sum(0)
         return (token_loss / token_tot).mean()
+
+    def step(self, probe, token_row, caches, mem):
+        """Log-likelihoods of the next token, [1,N,V+ext] (decoder.py:85-87 with work=True), for N live hypotheses.
+        token_row [1,N,d]: the newest sentence-encoder state; caches: per inference layer [t,N,2d] or None;
+        mem: 'inf_ext_kv' (list), 'align_kv', 'graph_padding_mask', 'cp_seq', 'tot_ext' already gathered per hypothesis."""
+        outs = probe
+        new_caches = []
+        for li, layer in enumerate(self.inference_core.layers):
+            outs, c = layer.step(outs, token_row, None if caches is None else caches[li], mem['inf_ext_kv'][li],
+                                 mem['graph_padding_mask'])
+            new_caches.append(c)
+        ll = self.token_generator(outs, None, mem['graph_padding_mask'], mem['cp_seq'], work=True,
+                                  align_kv=mem['align_kv'], tot_ext=mem['tot_ext'])
+        return ll, new_caches

@@ -4,7 +4,8 @@ HIP-backed modules.  Same constructor arguments and state_dict keys, so referenc
 Train-mode ``encode_step`` hands the graph encoder the relation in FACTORED form (bank + type ids): it is the
 exact same function as the reference's ``relation.index_select(0, idx).view(n,n,B,d)`` (generator.py:79) but the
 [n,n,B,d] tensor is never built.  Eval mode aggregates alternative shortest paths with the gather-mean kernel
-(generator.py:83-88).  Beam search (work/decode_step) is outside the hot path.
+(generator.py:83-88).  Inference (work / decode_step, generator.py:96-167) runs the beam search of gtos_amd.search over
+projected K/V caches: the reference re-projects the whole prefix in every layer at every step.
 """
 import math
 
@@ -17,6 +18,8 @@ from .encoder import TokenEncoder, RelationEncoder
 from .decoder import DecodeLayer
 from .transformer import Transformer, SinusoidalPositionalEmbedding, SelfAttentionMask
 from .graph_transformer import GraphTransformer, set_compute_dtype
+from .search import Beam, beam_search
+from .vocab import lists_to_tensor, strings_to_char_tensor
 
 
 class Generator(nn.Module):
@@ -100,3 +103,61 @@ class Generator(nn.Module):
         probe = probe.expand_as(token_repr)
         return self.decoder(probe, concept_repr, token_repr, concept_mask, token_mask, attn_mask,
                             data['cp_seq'], target=data['token_out'])
+
+    # ------------------------------------------------------------------------------------------------ inference
+    def work(self, data, beam_size, max_time_step, min_time_step=1):
+        """Beam search for every graph of the batch (generator.py:96-110).  Returns the finished Beam objects
+        (``beam.get_k_best(k, alpha)``)."""
+        with torch.no_grad():
+            concept_repr, concept_mask, probe = self.encode_step(data, train=False)
+            concept_repr = concept_repr.contiguous()
+            dec = self.decoder
+            memory = {
+                'probe': probe,
+                'graph_padding_mask': concept_mask,
+                'cp_seq': data['cp_seq'],
+                'tot_ext': 1 + int(data['cp_seq'].max().item()),
+                'local_idx2token': data['local_idx2token'],
+                # K/V projections of the graph states for every cross-attention that reads them: computed once
+                'snt_ext_kv': [l.external_attn.project_kv(concept_repr) for l in self.snt_encoder.layers],
+                'inf_ext_kv': [l.external_attn.project_kv(concept_repr) for l in dec.inference_core.layers],
+                'align_kv': dec.token_generator.alignment_layer.project_kv(concept_repr),
+            }
+            beams = [Beam(beam_size, min_time_step, max_time_step) for _ in range(concept_repr.size(1))]
+            beam_search(self, beams, memory)
+        return beams
+
+    def prepare_incremental_input(self, step_seq):
+        token = lists_to_tensor(step_seq, self.vocabs['token'])
+        token_char = strings_to_char_tensor(step_seq, self.vocabs['token_char'])
+        return token.to(self.device), token_char.to(self.device)
+
+    def decode_step(self, tokens, state, memory, beam_of_hyp, offset, topk):
+        """One step for N live hypotheses (generator.py:119-167).  tokens: their last token strings; state: None or
+        {'snt': [cache per sentence-encoder layer], 'inf': [cache per inference layer]}, every cache [t,N,2d];
+        beam_of_hyp [N]: graph index of each hypothesis.  Returns (state grown by one row, per hypothesis the top-k
+        [(token string, log-likelihood)])."""
+        step_token, step_token_char = self.prepare_incremental_input([[t] for t in tokens])
+        sel = lambda v: v.index_select(1, beam_of_hyp)
+        mem = {'graph_padding_mask': sel(memory['graph_padding_mask']), 'cp_seq': sel(memory['cp_seq']),
+               'tot_ext': memory['tot_ext'], 'inf_ext_kv': [sel(v) for v in memory['inf_ext_kv']],
+               'align_kv': sel(memory['align_kv'])}
+        snt_ext = [sel(v) for v in memory['snt_ext_kv']]
+        probe = sel(memory['probe'])
+        pos = self.token_position(step_token, offset).to(self.compute_dtype)
+        x = self.embed_scale * self.token_encoder(step_token, step_token_char) + pos
+        ln = self.token_embed_layer_norm
+        x = ops.layer_norm_residual(x, None, ln.weight, ln.bias, 0.0, ln.eps)
+        snt_caches = []
+        for li, layer in enumerate(self.snt_encoder.layers):
+            x, c = layer.step(x, x, None if state is None else state['snt'][li], snt_ext[li], mem['graph_padding_mask'])
+            snt_caches.append(c)
+        ll, inf_caches = self.decoder.step(probe, x, None if state is None else state['inf'], mem)
+        topk_scores, topk_token = torch.topk(ll.squeeze(0).float(), topk, 1)
+        vocab = self.vocabs['predictable_token']
+        owners = beam_of_hyp.tolist()
+        results = []
+        for s, t, bi in zip(topk_scores.tolist(), topk_token.tolist(), owners):
+            local = memory['local_idx2token'][bi]
+            results.append([(local[i] if i in local else vocab.idx2token(i), sc) for sc, i in zip(s, t)])
+        return {'snt': snt_caches, 'inf': inf_caches}, results

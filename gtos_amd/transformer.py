@@ -62,6 +62,23 @@ class MultiheadAttention(nn.Module):
         return attn, w
 
 
+    # ---- incremental decoding (inference only): projected K/V rows are cached instead of re-projecting the prefix
+    def project_kv(self, key):
+        """[S,B,d] -> packed [S,B,2d] = (W_k key + b_k | W_v key + b_v): the K/V cache rows of `key`."""
+        d = self.embed_dim
+        return ops.linear(key.to(self.compute_dtype), self.in_proj_weight, self.in_proj_bias, rows=(d, 3 * d))
+
+    def attend_cached(self, query, kv, key_padding_mask=None, need_weights=False):
+        """Attention of `query` [T,B,d] over cached projected rows kv [S,B,2d] (eval mode: no dropout)."""
+        d, H = self.embed_dim, self.num_heads
+        q = ops.linear(query.to(self.compute_dtype), self.in_proj_weight, self.in_proj_bias, rows=(0, d))
+        o, w = ops.attention_core(q, kv, (0, 0, d), d, H, self.scaling, key_pad=key_padding_mask, need_weights=need_weights)
+        attn = ops.linear(o, self.out_proj.weight, self.out_proj.bias)
+        if need_weights:
+            w = w.max(dim=3)[0].transpose(1, 2)
+        return attn, w
+
+
 class TransformerLayer(nn.Module):
     def __init__(self, embed_dim, ff_embed_dim, num_heads, dropout, with_external=False, weights_dropout=True):
         super().__init__()
@@ -104,6 +121,28 @@ class TransformerLayer(nn.Module):
         ln = self.ff_layer_norm
         x = ops.layer_norm_residual(x, f, ln.weight, ln.bias, p, ln.eps)
         return x, self_attn, external_attn
+
+
+    def step(self, x, new_kv_src, self_cache, ext_kv, ext_mask):
+        """One decoding step in eval mode.  x [1,N,d]: the query rows; new_kv_src [1,N,d]: the row whose K/V projection
+        joins this layer's self-attention cache (x itself in the sentence encoder, the newest token state in the
+        inference core); self_cache [t,N,2d] or None; ext_kv [S,N,2d]: cached projection of the graph states.
+        Same arithmetic as forward(x, kv=whole prefix, ...) of generator/transformer.py:25-44, without re-projecting
+        the prefix.  Returns (x_out, grown cache)."""
+        x = x.to(self.self_attn.compute_dtype)
+        row = self.self_attn.project_kv(new_kv_src)
+        cache = row if self_cache is None else torch.cat([self_cache, row], 0)
+        a, _ = self.self_attn.attend_cached(x, cache)
+        ln = self.attn_layer_norm
+        x = ops.layer_norm_residual(x, a, ln.weight, ln.bias, 0.0, ln.eps)
+        if self.with_external:
+            a, _ = self.external_attn.attend_cached(x, ext_kv, key_padding_mask=ext_mask)
+            ln = self.external_layer_norm
+            x = ops.layer_norm_residual(x, a, ln.weight, ln.bias, 0.0, ln.eps)
+        h = ops.linear(x, self.fc1.weight, self.fc1.bias, relu=True)
+        f = ops.linear(h, self.fc2.weight, self.fc2.bias)
+        ln = self.ff_layer_norm
+        return ops.layer_norm_residual(x, f, ln.weight, ln.bias, 0.0, ln.eps), cache
 
 
 class Transformer(nn.Module):

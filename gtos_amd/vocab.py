@@ -1,0 +1,137 @@
+"""Vocabulary files and batch tensorisation (used by the inference path, rank 2).
+
+File format and semantics of /root/reference/generator/data.py:12-110 (the translator's copy is identical):
+``token<TAB>count`` per line; ids are [<PAD>, <UNK>] + specials + every token whose count reaches the threshold, in
+file order; ``priority`` keeps the raw count of every token; ``coverage`` is the kept fraction of the token mass.
+"""
+import torch
+
+PAD, UNK = '<PAD>', '<UNK>'
+CLS = '<CLS>'
+STR, END = '<STR>', '<END>'
+SEL, rCLS, TL = '<SELF>', '<rCLS>', '<TL>'
+
+# (file-name attribute of the checkpoint's args, min count, specials): generator/work.py:78-84, generator/train.py:95-101
+VOCAB_SPECS = {
+    'concept': ('concept_vocab', 5, [CLS]),
+    'token': ('token_vocab', 5, [STR, END]),
+    'predictable_token': ('predictable_token_vocab', 5, [END]),
+    'token_char': ('token_char_vocab', 100, [STR, END]),
+    'concept_char': ('concept_char_vocab', 100, [STR, END]),
+    'relation': ('relation_vocab', 5, [CLS, rCLS, SEL, TL]),
+}
+
+
+class Vocab(object):
+    """Same public surface as the reference class: size, padding_idx, unk_idx, token2idx, idx2token, priority, coverage."""
+
+    def __init__(self, filename, min_occur_cnt, specials=None):
+        tokens = [PAD, UNK] + list(specials or [])
+        self._priority = {}
+        total = kept = 0
+        token = cnt = None
+        with open(filename) as f:
+            for raw in f:
+                fields = raw.strip().split('\t')
+                try:
+                    if len(fields) != 2:
+                        raise ValueError(raw)
+                    token, cnt = fields[0], int(fields[1])
+                    total += cnt
+                except ValueError:
+                    # The reference prints a malformed line and then falls through with the PREVIOUS line's token and
+                    # count (data.py:19-28), i.e. that token is entered once more.  Vocabulary sizes fix the embedding
+                    # shapes of existing checkpoints, so the quirk is kept.
+                    if cnt is None:
+                        raise ValueError("%s: malformed first line %r" % (filename, raw))
+                if cnt >= min_occur_cnt:
+                    tokens.append(token)
+                    kept += cnt
+                self._priority[token] = cnt
+        self.coverage = kept / total if total else 0.0
+        self._idx2token = tokens
+        self._token2idx = {}
+        for i, t in enumerate(tokens):                        # a repeated token keeps its LAST id, like dict(zip(...))
+            self._token2idx[t] = i
+        self._padding_idx = self._token2idx[PAD]
+        self._unk_idx = self._token2idx[UNK]
+
+    def priority(self, x):
+        return self._priority.get(x, 0)
+
+    @property
+    def size(self):
+        return len(self._idx2token)
+
+    @property
+    def unk_idx(self):
+        return self._unk_idx
+
+    @property
+    def padding_idx(self):
+        return self._padding_idx
+
+    def idx2token(self, x):
+        if isinstance(x, list):
+            return [self.idx2token(i) for i in x]
+        return self._idx2token[x]
+
+    def token2idx(self, x):
+        if isinstance(x, list):
+            return [self.token2idx(i) for i in x]
+        return self._token2idx.get(x, self._unk_idx)
+
+
+def load_vocabs(args_or_dir):
+    """The six vocabularies of a run: from a checkpoint's ``args`` namespace (attributes ``concept_vocab`` ...) or from
+    a directory holding files with those names."""
+    import os
+    out = {}
+    for name, (attr, min_cnt, specials) in VOCAB_SPECS.items():
+        path = os.path.join(args_or_dir, attr) if isinstance(args_or_dir, str) else getattr(args_or_dir, attr)
+        out[name] = Vocab(path, min_cnt, specials)
+    return out
+
+
+def lists_to_tensor(xs, vocab=None, local_vocabs=None):
+    """Ragged token lists -> int64 [max_len, batch], padded (data.py:76-98 without the training-time UNK noise).
+    ``local_vocabs[i]`` (token -> id, the per-graph copy vocabulary) takes precedence over ``vocab``."""
+    pad = vocab.padding_idx if vocab is not None else 0
+    width = max(len(x) for x in xs)
+    rows = []
+    for i, x in enumerate(xs):
+        if vocab is None:
+            ids = list(x)
+        else:
+            local = local_vocabs[i] if local_vocabs is not None else None
+            ids = [local[w] if (local is not None and w in local) else vocab.token2idx(w) for w in x]
+        rows.append(ids + [pad] * (width - len(x)))
+    return torch.tensor(rows, dtype=torch.int64).t().contiguous()
+
+
+def strings_to_char_tensor(xs, vocab, max_string_len=20):
+    """Ragged lists of strings -> int64 [max_len, batch, max_string_len + 2] of <STR> chars <END> ids (data.py:100-112)."""
+    width = max(len(x) for x in xs)
+    out = []
+    for x in xs:
+        row = []
+        for z in list(x) + [PAD] * (width - len(x)):
+            chars = list(z[:max_string_len])
+            row.append(vocab.token2idx([STR] + chars + [END]) + [vocab.padding_idx] * (max_string_len - len(chars)))
+        out.append(row)
+    return torch.tensor(out, dtype=torch.int64).transpose(0, 1).contiguous()
+
+
+def copy_vocab(concepts, vocab):
+    """Per-graph copy vocabulary (extract.py:47-63): every concept that the predictable-token vocabulary does not know
+    gets a fresh id after its end.  Returns (cp_seq, token2idx, idx2token).  The reference iterates a ``set``; ids are
+    assigned here in first-occurrence order, which is deterministic (any assignment is valid: the ids only link
+    cp_seq, token_out and local_idx2token inside one batch)."""
+    token2idx, idx2token = {}, {}
+    nxt = vocab.size
+    for c in concepts:
+        if c not in token2idx and vocab.token2idx(c) == vocab.unk_idx:
+            token2idx[c] = nxt
+            idx2token[nxt] = c
+            nxt += 1
+    return list(concepts), token2idx, idx2token

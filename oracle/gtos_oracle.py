@@ -511,6 +511,74 @@ class Generator(nn.Module):
 
 
 # --------------------------------------------------------------------------------------
+# inference: beam search   (generator/generator.py:96-167, generator/search.py)
+# --------------------------------------------------------------------------------------
+# The reference decodes incrementally and interleaves all sentences of a batch in one loop.  Sentences never interact
+# and decoding is causal, so this restatement does the plainest equivalent thing: one sentence at a time, and at every
+# step the whole prefix of every live hypothesis is pushed through the decoder again (no state is carried).
+def next_token_ll(model, graph, gmask, probe, cp_seq, prefixes, vocabs, max_string_len=20):
+    """graph [S,1,d], gmask [S,1], probe [1,1,d], cp_seq [S,1] of ONE sentence; prefixes: n token-string lists of equal
+    length t (each starts with <STR>).  Returns log-likelihoods [n, V+ext] of the next token (decoder.py:85-87)."""
+    n, t = len(prefixes), len(prefixes[0])
+    tv, cv = vocabs['token'], vocabs['token_char']
+    ids = torch.tensor([[tv.token2idx(w) for w in p] for p in prefixes], dtype=torch.int64).t().contiguous()      # [t,n]
+    chars = torch.tensor([[cv.token2idx(['<STR>'] + list(w[:max_string_len]) + ['<END>'])
+                           + [cv.padding_idx] * (max_string_len - len(w[:max_string_len])) for w in p] for p in prefixes],
+                         dtype=torch.int64).transpose(0, 1).contiguous()                                           # [t,n,22]
+    g, gm, cs = graph.expand(-1, n, -1), gmask.expand(-1, n), cp_seq.expand(-1, n)
+    pos = sinusoid_table(max(t, 2), model.embed_dim)[:t].unsqueeze(1)
+    tok = model.token_embed_layer_norm(model.embed_scale * model.token_encoder(ids, chars) + pos)
+    tok = model.snt_encoder(tok, self_padding_mask=None, self_attn_mask=causal_mask(t),
+                            external_memories=g, external_padding_mask=gm)
+    # the query is the probe alone: one row that sees the whole (already causal) prefix (generator.py:149)
+    return model.decoder(probe.expand(-1, n, -1), g, tok, gm, None, None, cs, work=True)[0]
+
+
+def beam_search_sentence(model, graph, gmask, probe, cp_seq, local_idx2token, vocabs, beam_size, max_time_step,
+                         min_time_step=1):
+    """-> (finished, alive): lists of (token strings incl. <STR>/<END>, accumulated log-likelihood) in the order the
+    reference's Beam holds them (search.py:57-101)."""
+    pv = vocabs['predictable_token']
+    alive, finished, steps = [(['<STR>'], 0.0)], [], 0
+    while len(finished) < beam_size and steps < max_time_step and alive:
+        ll = next_token_ll(model, graph, gmask, probe, cp_seq, [seq for seq, _ in alive], vocabs)
+        top_s, top_i = torch.topk(ll, beam_size, 1)
+        pool = []
+        for h, (seq, score) in enumerate(alive):
+            for s, i in zip(top_s[h].tolist(), top_i[h].tolist()):
+                word = local_idx2token[i] if i in local_idx2token else pv.idx2token(i)
+                pool.append((seq + [word], float('-inf') if word == '<UNK>' else score + s))
+        pool = sorted(pool, key=lambda c: -c[1])[:beam_size - len(finished)]       # stable, like list.sort(reverse=True)
+        alive = []
+        for seq, score in pool:
+            if seq[-1] == '<END>':
+                if len(seq) - 2 >= min_time_step:
+                    finished.append((seq, score))
+            else:
+                alive.append((seq, score))
+        steps += 1
+    return finished, alive
+
+
+def k_best(finished, alive, k, alpha):
+    """Final ranking with length normalisation (search.py:97-101)."""
+    cands = finished if finished else alive
+    return sorted(cands, key=lambda c: -(c[1] / ((1 + len(c[0])) ** alpha)))[:k]
+
+
+def generator_work(model, data, vocabs, beam_size, max_time_step, min_time_step=1):
+    """All sentences of a batch (generator.py:96-110): list of (finished, alive)."""
+    with torch.no_grad():
+        graph, gmask, probe = model.encode_step(data, train=False)
+        out = []
+        for b in range(graph.shape[1]):
+            out.append(beam_search_sentence(model, graph[:, b:b + 1], gmask[:, b:b + 1], probe[:, b:b + 1],
+                                            data['cp_seq'][:, b:b + 1], data['local_idx2token'][b], vocabs, beam_size,
+                                            max_time_step, min_time_step))
+    return out
+
+
+# --------------------------------------------------------------------------------------
 # optimizer step   (generator/adam.py:28-87, generator/train.py:81-83,123-132,151)
 # --------------------------------------------------------------------------------------
 def inverse_sqrt_lr(embed_size, step, warmup_steps):

@@ -1,0 +1,244 @@
+"""vocabulary files, checkpoint format, beam search.
+
+Fixtures: tests/golden/beam_smatch.{npz,json}, produced by the reference itself (tests/golden/make_golden_beam.py):
+its Vocab on six small vocabulary files (thresholds, a malformed line), and Generator.work on the six AMRs of
+generator/smatch/test_input*.txt with three (beam size, max steps, min steps) settings."""
+import argparse
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN as GOLDEN_DIR, T
+
+SCORE_TOL = 2e-4          # accumulated fp32 log-likelihoods, CPU oracle / GPU kernels vs the reference's CPU run
+
+
+def load_case():
+    meta = json.load(open(os.path.join(GOLDEN_DIR, "beam_smatch.json")))
+    arrs = np.load(os.path.join(GOLDEN_DIR, "beam_smatch.npz"))
+    return meta, arrs
+
+
+def write_vocab_files(meta, tmp_path):
+    for name, text in meta["files"].items():
+        (tmp_path / name).write_text(text)
+    return str(tmp_path)
+
+
+def make_vocabs(meta, tmp_path):
+    from gtos_amd.vocab import load_vocabs
+    return load_vocabs(write_vocab_files(meta, tmp_path))
+
+
+def batch_of(meta, arrs, device=None):
+    b = {k[len("batch/"):]: T(arrs[k]) for k in arrs.files if k.startswith("batch/")}
+    if device is not None:
+        b = {k: v.to(device) for k, v in b.items()}
+    b["local_idx2token"] = [{int(k): v for k, v in d.items()} for d in meta["local_idx2token"]]
+    return b
+
+
+def state_dict_of(arrs):
+    return {k[len("sd/"):]: T(arrs[k]) for k in arrs.files if k.startswith("sd/")}
+
+
+def check_hyps(got, want, what):
+    assert [list(s) for s, _ in got] == [list(s) for s, _ in want], what
+    for (_, a), (_, b) in zip(got, want):
+        if b == float("-inf") or a == float("-inf"):
+            assert a == b, what
+        else:
+            assert abs(a - b) < SCORE_TOL, (what, a, b)
+
+
+# ------------------------------------------------------------------------------------------------ vocabulary files
+def test_vocab_matches_reference(tmp_path):
+    meta, _ = load_case()
+    vocabs = make_vocabs(meta, tmp_path)
+    for name, truth in meta["vocab_truth"].items():
+        v = vocabs[name]
+        assert v.size == truth["size"], name
+        assert abs(v.coverage - truth["coverage"]) < 1e-12
+        assert v.idx2token(list(range(v.size))) == truth["idx2token"]
+        for tok, idx in truth["token2idx"].items():
+            assert v.token2idx(tok) == idx, (name, tok)
+        for tok, pr in truth["priority"].items():
+            assert v.priority(tok) == pr
+        assert v.padding_idx == 0 and v.unk_idx == 1
+    # the malformed (blank) line re-enters the previous token, as the reference does: sizes decide embedding shapes
+    assert meta["vocab_truth"]["token"]["idx2token"].count("go") == 2
+
+
+def test_tensorisers_shapes_and_padding(tmp_path):
+    from gtos_amd.vocab import lists_to_tensor, strings_to_char_tensor, copy_vocab, STR, END
+    meta, _ = load_case()
+    vocabs = make_vocabs(meta, tmp_path)
+    tv, cv = vocabs["token"], vocabs["token_char"]
+    x = lists_to_tensor([["the", "boy"], ["girl"]], tv)
+    assert x.shape == (2, 2) and x[1, 1].item() == tv.padding_idx and x[0, 0].item() == tv.token2idx("the")
+    c = strings_to_char_tensor([["the", "boy"], ["girl"]], cv)
+    assert c.shape == (2, 2, 22)
+    assert c[0, 0, 0].item() == cv.token2idx(STR) and c[0, 0, 4].item() == cv.token2idx(END)
+    assert c[1, 1].tolist() == strings_to_char_tensor([["<PAD>"]], cv)[0, 0].tolist()       # padded slot = the string <PAD>
+    pv = vocabs["predictable_token"]
+    cp, t2i, i2t = copy_vocab(["zzz-01", "the", "zzz-01", "qqq"], pv)
+    assert cp == ["zzz-01", "the", "zzz-01", "qqq"] and t2i == {"zzz-01": pv.size, "qqq": pv.size + 1}
+    assert i2t == {pv.size: "zzz-01", pv.size + 1: "qqq"}
+    loc = lists_to_tensor([["zzz-01", "the"]], pv, [t2i])
+    assert loc[:, 0].tolist() == [pv.size, pv.token2idx("the")]
+
+
+# ------------------------------------------------------------------------------------------------ checkpoints
+def test_checkpoint_roundtrip_in_reference_format(tmp_path):
+    from gtos_amd.checkpoint import save_checkpoint, load_checkpoint, build_from_checkpoint
+    meta, arrs = load_case()
+    vdir = write_vocab_files(meta, tmp_path)
+    cfg = meta["cfg"]
+    ga = cfg["gen_args"]
+    args = argparse.Namespace(
+        token_char_dim=ga[0], token_dim=ga[1], concept_char_dim=ga[2], concept_dim=ga[3],
+        cnn_filters=[tuple(f) for f in ga[4]], char2word_dim=ga[5], char2concept_dim=ga[6], rel_dim=ga[7],
+        rnn_hidden_size=ga[8], rnn_num_layers=ga[9], embed_dim=cfg["d"], ff_embed_dim=cfg["ff"], num_heads=cfg["H"],
+        dropout=0.2, snt_layers=cfg["snt_layers"], graph_layers=cfg["graph_layers"],
+        inference_layers=cfg["inference_layers"], pretrained_file=None,
+        **{n: os.path.join(vdir, n) for n in meta["files"]})
+    sd = state_dict_of(arrs)
+    # exactly what generator/train.py:164 writes
+    path = str(tmp_path / "epoch1_batch2")
+    torch.save({"args": args, "model": sd}, path)
+    model, args2, vocabs = build_from_checkpoint(path, torch.device("cpu"))
+    assert vars(args2) == vars(args)
+    got = model.state_dict()
+    assert set(got) == set(sd)
+    for k in sd:
+        assert torch.equal(got[k], sd[k]), k
+    assert not model.training
+    # and back: a checkpoint written by this stack has the reference's layout
+    path2 = str(tmp_path / "resaved")
+    save_checkpoint(path2, args, model)
+    raw = torch.load(path2, map_location="cpu", weights_only=False)
+    assert set(raw) == {"args", "model"} and isinstance(raw["args"], argparse.Namespace)
+    a3, sd3 = load_checkpoint(path2)
+    assert all(torch.equal(sd3[k], sd[k]) for k in sd)
+
+
+# ------------------------------------------------------------------------------------------------ beam search
+def test_beam_bookkeeping_rules():
+    """Beam.advance on hand-made steps: <UNK> -> -inf, budget shrinks with finished hypotheses, min_time_step drops
+    early <END>, stable tie order."""
+    from gtos_amd.search import Beam
+    from gtos_amd.vocab import END, UNK
+    b = Beam(3, 2, 10)
+    parents = b.advance([[("a", -1.0), (END, -0.5), (UNK, -0.1)]])
+    # <END> after 0 tokens is dropped (min_time_step 2), <UNK> kept alive with -inf (the reference keeps it too)
+    assert parents == [0, 0] and [h.seq[-1] for h in b.hypotheses] == ["a", UNK] and b.completed_hypotheses == []
+    assert b.hypotheses[1].score == float("-inf")
+    parents = b.advance([[("b", -1.0), ("c", -1.0), (END, -3.0)], [("x", -0.1), ("y", -0.2), ("z", -0.3)]])
+    assert [h.seq[-1] for h in b.hypotheses] == ["b", "c"] and parents == [0, 0]      # tie keeps rank order; 3rd is <END>
+    assert b.completed_hypotheses == []                                                  # 1 token < min_time_step 2
+    parents = b.advance([[(END, -0.1), ("d", -5.0)], [("e", -0.2), (END, -9.0)]])
+    assert len(b.completed_hypotheses) == 1 and [h.seq[-1] for h in b.hypotheses] == ["e", "d"] and parents == [1, 0]
+    b.advance([[("f", -1.0), ("g", -2.0), ("h", -3.0)], [("i", -1.0), ("j", -2.0), ("k", -3.0)]])
+    assert len(b.hypotheses) == 2                                                        # budget = 3 - 1 finished
+    assert not b.completed()
+    best = b.get_k_best(1, 0.6)[0]
+    assert best.seq[-1] == END
+
+
+def test_oracle_beam_search_matches_reference(tmp_path):
+    from oracle import gtos_oracle as O
+    meta, arrs = load_case()
+    vocabs = make_vocabs(meta, tmp_path)
+    cfg = meta["cfg"]
+    ga = [[tuple(f) for f in a] if isinstance(a, list) else a for a in cfg["gen_args"]]
+    model = O.Generator(vocabs, *ga, cfg["d"], cfg["ff"], cfg["H"], 0.0, cfg["snt_layers"], cfg["graph_layers"],
+                        cfg["inference_layers"])
+    model.load_state_dict(state_dict_of(arrs))
+    model.eval()
+    batch = batch_of(meta, arrs)
+    for run in meta["runs"]:
+        out = O.generator_work(model, batch, vocabs, run["beam"], run["max_step"], run["min_step"])
+        for b, ((fin, alive), want) in enumerate(zip(out, run["expect"])):
+            tag = "run %s sentence %d" % ((run["beam"], run["max_step"], run["min_step"]), b)
+            check_hyps(fin, want["finished"], tag + " finished")
+            if len(fin) < run["beam"]:                 # the reference stops updating a full beam; its leftovers differ
+                check_hyps(alive, want["alive"], tag + " alive")
+            check_hyps(O.k_best(fin, alive, run["beam"], cfg["alpha"]), want["k_best"], tag + " k-best")
+
+
+@pytest.mark.gpu
+def test_hip_beam_search_matches_reference(tmp_path):
+    from gtos_amd.generator import Generator
+    meta, arrs = load_case()
+    dev = torch.device("cuda:0")
+    vocabs = make_vocabs(meta, tmp_path)
+    cfg = meta["cfg"]
+    ga = [[tuple(f) for f in a] if isinstance(a, list) else a for a in cfg["gen_args"]]
+    model = Generator(vocabs, *ga, cfg["d"], cfg["ff"], cfg["H"], 0.0, cfg["snt_layers"], cfg["graph_layers"],
+                      cfg["inference_layers"], None, dev).to(dev)
+    model.load_state_dict(state_dict_of(arrs))
+    model.eval()
+    batch = batch_of(meta, arrs, dev)
+    for run in meta["runs"]:
+        beams = model.work(batch, run["beam"], run["max_step"], run["min_step"])
+        for b, (beam, want) in enumerate(zip(beams, run["expect"])):
+            tag = "run %s sentence %d" % ((run["beam"], run["max_step"], run["min_step"]), b)
+            fin = [(h.seq, h.score) for h in beam.completed_hypotheses]
+            alive = [(h.seq, h.score) for h in beam.hypotheses]
+            assert beam.steps == want["steps"], tag
+            check_hyps(fin, want["finished"], tag + " finished")
+            check_hyps(alive, want["alive"], tag + " alive")
+            best = [(h.seq, h.score) for h in beam.get_k_best(run["beam"], cfg["alpha"])]
+            check_hyps(best, want["k_best"], tag + " k-best")
+
+
+@pytest.mark.gpu
+def test_hip_incremental_step_equals_full_prefix_recompute(tmp_path):
+    """The K/V-cache decode step against the pinned oracle recomputing whole prefixes (teacher-forced random prefixes,
+    several hypotheses per graph): next-token log-likelihoods agree to fp32 tolerance at every step."""
+    from gtos_amd.generator import Generator
+    from oracle import gtos_oracle as O
+    meta, arrs = load_case()
+    dev = torch.device("cuda:0")
+    vocabs = make_vocabs(meta, tmp_path)
+    cfg = meta["cfg"]
+    ga = [[tuple(f) for f in a] if isinstance(a, list) else a for a in cfg["gen_args"]]
+    args = (cfg["d"], cfg["ff"], cfg["H"], 0.0, cfg["snt_layers"], cfg["graph_layers"], cfg["inference_layers"])
+    model = Generator(vocabs, *ga, *args, None, dev).to(dev)
+    ref = O.Generator(vocabs, *ga, *args)
+    sd = state_dict_of(arrs)
+    model.load_state_dict(sd)
+    ref.load_state_dict(sd)
+    model.eval()
+    ref.eval()
+    batch_cpu, batch = batch_of(meta, arrs), batch_of(meta, arrs, dev)
+    words = [w for w in vocabs["token"].idx2token(list(range(4, vocabs["token"].size)))]
+    rng = np.random.RandomState(3)
+    owners = [0, 0, 1, 3, 3, 3, 5]                       # hypotheses per graph: ragged on purpose
+    prefixes = [["<STR>"] for _ in owners]
+    with torch.no_grad():
+        g, gm, pr = model.encode_step(batch, train=False)
+        g = g.contiguous()
+        dec = model.decoder
+        memory = {'probe': pr, 'graph_padding_mask': gm, 'cp_seq': batch['cp_seq'],
+                  'tot_ext': 1 + int(batch['cp_seq'].max().item()), 'local_idx2token': batch['local_idx2token'],
+                  'snt_ext_kv': [l.external_attn.project_kv(g) for l in model.snt_encoder.layers],
+                  'inf_ext_kv': [l.external_attn.project_kv(g) for l in dec.inference_core.layers],
+                  'align_kv': dec.token_generator.alignment_layer.project_kv(g)}
+        rg, rgm, rpr = ref.encode_step(batch_cpu, train=False)
+        state = None
+        own_t = torch.tensor(owners, device=dev)
+        V = vocabs["predictable_token"].size
+        for step in range(5):
+            state, results = model.decode_step([p[-1] for p in prefixes], state, memory, own_t, step, 6)
+            for h, b in enumerate(owners):
+                want = O.next_token_ll(ref, rg[:, b:b + 1], rgm[:, b:b + 1], rpr[:, b:b + 1],
+                                       batch_cpu['cp_seq'][:, b:b + 1], [prefixes[h]], vocabs)[0]
+                top_s, top_i = torch.topk(want, 6)
+                got_s = [s for _, s in results[h]]
+                assert np.allclose(got_s, top_s.tolist(), atol=2e-4), (step, h)
+            for p in prefixes:
+                p.append(words[rng.randint(len(words))])
