@@ -315,3 +315,40 @@ def make_config_batch(name, rank=0, train=True, padded=False, B=None):
     B = B or c["B"]
     return make_batch(c["id"], B, c["N"], c["T"], kind=c["kind"], extra_frac=c["extra_frac"],
                       train=train, padded=padded, first_graph=rank * B)
+
+
+class SynthVocab(object):
+    """String vocabulary of a given size for the inference benchmark / tests: ids 0,1 = <PAD>,<UNK>, then the specials,
+    then made-up words (``prefix`` + number) or, for character vocabularies, single characters.  Same surface as
+    gtos_amd.vocab.Vocab."""
+
+    def __init__(self, size, specials, prefix="w", chars=False):
+        toks = ['<PAD>', '<UNK>'] + list(specials)
+        if chars:
+            pool = list("abcdefghijklmnopqrstuvwxyz0123456789-_.") + [chr(0x100 + i) for i in range(size)]
+            toks += pool[:size - len(toks)]
+        else:
+            toks += ["%s%d" % (prefix, i) for i in range(size - len(toks))]
+        self._idx2token = toks
+        self._token2idx = {t: i for i, t in enumerate(toks)}
+
+    size = property(lambda self: len(self._idx2token))
+    padding_idx = property(lambda self: 0)
+    unk_idx = property(lambda self: 1)
+
+    def idx2token(self, x):
+        return [self.idx2token(i) for i in x] if isinstance(x, list) else self._idx2token[x]
+
+    def token2idx(self, x):
+        return [self.token2idx(i) for i in x] if isinstance(x, list) else self._token2idx.get(x, 1)
+
+
+def synth_vocabs(vocab=None):
+    """The six vocabularies at DEFAULT_VOCAB sizes with the reference's specials (generator/work.py:78-84).  Words of
+    the token and predictable-token vocabularies coincide, so a generated id maps to an in-vocabulary input token."""
+    v = dict(DEFAULT_VOCAB, **(vocab or {}))
+    return {'concept': SynthVocab(v['concept'], ['<CLS>'], "c"), 'token': SynthVocab(v['token'], ['<STR>', '<END>']),
+            'predictable_token': SynthVocab(v['predictable_token'], ['<END>']),
+            'token_char': SynthVocab(v['token_char'], ['<STR>', '<END>'], chars=True),
+            'concept_char': SynthVocab(v['concept_char'], ['<STR>', '<END>'], chars=True),
+            'relation': SynthVocab(v['relation'], ['<CLS>', '<rCLS>', '<SELF>', '<TL>'], "r")}
