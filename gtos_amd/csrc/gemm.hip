@@ -21,6 +21,7 @@
 //   * MFMA operands are swapped (D = B.A^T) so a lane holds 4 consecutive output columns; bf16 outputs go through
 //     LDS and leave as full 128-byte row segments.
 #include "common.h"
+#include <stdlib.h>
 
 // 256 bytes of zeros in GLOBAL memory (allocated once per process): target of out-of-range tile loads.  A __device__
 // constant would make the selected pointer generic and turn the tile loads into flat loads.  Shared with gru_step.hip.
@@ -495,6 +496,154 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splits, i
     }
 }
 
+
+// ---- 256x256 macro tile for big K-contiguous bf16 products with a DEEP reduction (K >= 1024).  Measured on MI355X
+//      (tools/bench_gemm.py): [434624,4096]x[1024,4096]^T 1001 TF/s vs 832 for the 128x128 kernel, 8192^3 1004 vs 705;
+//      at K = 512 both sit at ~690 TF/s because a tile's output write (not overlapped inside a 1-workgroup-per-CU
+//      kernel) costs as much as its 8 k tiles, so the dispatcher keeps short-K shapes on the 128x128 kernel.  8 waves (2 x 4), each 128 x 64 = 8 x 4 MFMA
+//      tiles (128 accumulator registers), two 64 KB LDS stages.  Per k tile: barrier (drains this stage's DMA), ALL
+//      fragments of the tile are read into registers, THEN the next tile's DMA is issued into the other stage, then the
+//      64 MFMAs run while it lands -- hipcc waits for every outstanding LDS-DMA in front of any ds_read, so the reads
+//      have to precede the prefetch for the two to overlap.  One barrier per k tile.
+constexpr int BM2 = 256, BN2 = 256, STAGE2 = (BM2 + BN2) * ROWB;
+const bool g_use256 = !(getenv("GTOS_GEMM256") && getenv("GTOS_GEMM256")[0] == '0');
+
+__global__ __launch_bounds__(512, 2) void gemm256_nt_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds2[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
+    const int nN = (a.N + BN2 - 1) / BN2;
+    const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
+    const int m0 = ((sq / nN) * 8 + xcd) * BM2, n0 = (sq % nN) * BN2;
+    if (m0 >= a.M) return;
+    const bf16_t* A = static_cast<const bf16_t*>(a.A);
+    const bf16_t* B = static_cast<const bf16_t*>(a.B);
+    const U128* Z = static_cast<const U128*>(a.zeros);
+
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    auto dma = [&](int k0, char* st) {
+#pragma unroll
+        for (int op = 0; op < 2; ++op) {
+            const bf16_t* base = op ? B : A;
+            const int64_t ld = op ? a.ldb : a.lda;
+            const int rows_total = op ? a.N : a.M, row0 = op ? n0 : m0;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int blk = it * 8 + wave, rl = blk * 8 + (lane >> 3);
+                const int c = (lane & 7) ^ swz(rl);
+                const int r = row0 + rl, k = k0 + c * 8;
+                const bool ok = r < rows_total && k + 8 <= a.K;
+                const void* src = ok ? static_cast<const void*>(base + (int64_t)r * ld + k) : static_cast<const void*>(Z);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(st + op * (BM2 * ROWB) + blk * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    const int nk = (a.K + 63) / 64;
+    dma(0, lds2);
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* As = lds2 + (kt & 1) * STAGE2;
+        const char* Bs = As + BM2 * ROWB;
+        __syncthreads();                                   // this stage has landed (hipcc drains vmcnt in front of it)
+        bf16x8_t fa[2][8], fb[2][4];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) fa[ks][t] = *reinterpret_cast<const bf16x8_t*>(As + lds_off(wm + t * 16 + fr, ks * 4 + fq));
+#pragma unroll
+            for (int t = 0; t < 4; ++t) fb[ks][t] = *reinterpret_cast<const bf16x8_t*>(Bs + lds_off(wn + t * 16 + fr, ks * 4 + fq));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) dma((kt + 1) * 64, lds2 + ((kt + 1) & 1) * STAGE2);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][nt], fa[ks][mt], acc[mt][nt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- epilogue (bf16 out): bias/act in registers, 32 rows x 64 columns of the wave tile at a time through LDS
+    __syncthreads();
+    bf16_t* C = static_cast<bf16_t*>(a.C);
+    const float keep_scale = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
+    constexpr int CP = 64 * 2 + 16;                        // bytes per staged row
+    char* cs = lds2 + wave * 32 * CP;                      // private to the wave
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int mt = q4 * 2 + mh;
+                const int m = m0 + wm + mt * 16 + fr, n = n0 + wn + nt * 16 + fq * 4;
+                float v[4] = {acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (a.bias && n + i < a.N) v[i] += a.bias[n + i];
+                    if (a.relu) v[i] = fmaxf(v[i], 0.f);
+                    if (a.p_drop > 0.f)
+                        v[i] = drop_keep(a.seed, (uint64_t)m * (uint64_t)a.N + (uint64_t)(n + i), a.p_drop) ? v[i] * keep_scale : 0.f;
+                }
+                *reinterpret_cast<uint2*>(cs + (mh * 16 + fr) * CP + (nt * 16 + fq * 4) * 2) = make_uint2(pack_bf(v[0], v[1]), pack_bf(v[2], v[3]));
+            }
+        // wave-private region: only this wave's own LDS writes have to be visible to its reads
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0)
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int row = pass * 8 + (lane >> 3), col = (lane & 7) * 8;
+            const int m = m0 + wm + q4 * 32 + row, n = n0 + wn + col;
+            if (m >= a.M || n >= a.N) continue;
+            uint4 val = *reinterpret_cast<const uint4*>(cs + row * CP + col * 2);
+            bf16_t* cp = C + (int64_t)m * a.ldc + n;
+            if (n + 8 <= a.N) {
+                if (a.accumulate) {
+                    const uint4 old = *reinterpret_cast<const uint4*>(cp);
+                    val = make_uint4(pack_bf(lo_bf(val.x) + lo_bf(old.x), hi_bf(val.x) + hi_bf(old.x)),
+                                     pack_bf(lo_bf(val.y) + lo_bf(old.y), hi_bf(val.y) + hi_bf(old.y)),
+                                     pack_bf(lo_bf(val.z) + lo_bf(old.z), hi_bf(val.z) + hi_bf(old.z)),
+                                     pack_bf(lo_bf(val.w) + lo_bf(old.w), hi_bf(val.w) + hi_bf(old.w)));
+                }
+                *reinterpret_cast<uint4*>(cp) = val;
+            } else {
+                const bf16_t* e = reinterpret_cast<const bf16_t*>(cs + row * CP + col * 2);
+                for (int i = 0; i < 8 && n + i < a.N; ++i) {
+                    float o = bf2f(e[i]);
+                    if (a.accumulate) o += bf2f(cp[i]);
+                    cp[i] = f2bf(o);
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                // the reads are done before the next quarter overwrites the rows
+    }
+}
+
+int launch256(const GemmArgs& a, hipStream_t s) {
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_nt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                2 * STAGE2) != hipSuccess) return -7;
+        configured = true;
+    }
+    const long long nMt = (a.M + BM2 - 1) / BM2, nNt = (a.N + BN2 - 1) / BN2;
+    const long long nblk = ((nMt + 7) / 8) * 8 * nNt;
+    if (nblk > 0x7fffffffLL) return -6;
+    hipLaunchKernelGGL(gemm256_nt_kernel, dim3((unsigned)nblk), dim3(512), 2 * STAGE2, s, a);
+    GTOS_CHECK_LAUNCH();
+    return 0;
+}
+
 template <typename T, typename TO>
 int launch(const GemmArgs& a, int transA, int transB, hipStream_t s) {
     const long long nMt = (a.M + BM - 1) / BM, nNt = (a.N + BN - 1) / BN;
@@ -558,7 +707,13 @@ extern "C" int gtos_gemm(int in_dtype, int out_dtype, int transA, int transB, in
         GTOS_CHECK_LAUNCH();
         return 0;
     }
-    if (in_dtype == GTOS_BF16 && out_dtype == GTOS_BF16) return launch<bf16_t, bf16_t>(a, transA, transB, s);
+    if (in_dtype == GTOS_BF16 && out_dtype == GTOS_BF16) {
+        // big forward-shaped products go to the 256x256 macro tile (enough tiles to give every CU several)
+        const long long t256 = ((long long)(M + BM2 - 1) / BM2) * ((N + BN2 - 1) / BN2);
+        if (g_use256 && !transA && transB && a.vecA && a.vecB && a.vecC && splitk == 1 && t256 >= 1024 && N >= 256 && K >= 1024)
+            return launch256(a, s);
+        return launch<bf16_t, bf16_t>(a, transA, transB, s);
+    }
     if (in_dtype == GTOS_BF16 && out_dtype == GTOS_F32)  return launch<bf16_t, float>(a, transA, transB, s);
     if (in_dtype == GTOS_F32 && out_dtype == GTOS_F32)   return launch<float, float>(a, transA, transB, s);
     return -1;

@@ -54,6 +54,27 @@ def test_gemm(dtype, ta, tb, M, N, K):
     torch.testing.assert_close(acc, ref + 1, **tol)
 
 
+@pytest.mark.parametrize("M,N,K", [(40003, 2056, 1096), (262144, 256, 1024), (70000, 1024, 2048)])
+def test_gemm_256_macro_tile(M, N, K):
+    """Shapes that take the 256x256 NT kernel (bf16 in/out, >= 1024 macro tiles): ragged M/N/K tails, fused bias+ReLU,
+    bf16 accumulate; against fp32 matmul of the same bf16 operands."""
+    from gtos_amd import ops
+    torch.manual_seed(M % 97)
+    a = (torch.randn(M, K, device=dev()) * 0.5).to(torch.bfloat16)
+    b = (torch.randn(N, K, device=dev()) * 0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device=dev())
+    want = a.float() @ b.float().t()
+    tol = dict(rtol=2e-2, atol=0.01 * K ** 0.5)
+    got = ops.gemm(a, b, trans_b=True)
+    torch.testing.assert_close(got.float(), want, **tol)
+    got = ops.gemm(a, b, trans_b=True, bias=bias, relu=True)
+    torch.testing.assert_close(got.float(), torch.relu(want + bias), **tol)
+    base = torch.randn(M, N, device=dev()).to(torch.bfloat16)
+    out = base.clone()
+    ops.gemm(a, b, trans_b=True, out=out, accumulate=True)
+    torch.testing.assert_close(out.float(), want + base.float(), rtol=3e-2, atol=0.02 * K ** 0.5)
+
+
 def test_gemm_strided_views_and_dropout():
     from gtos_amd import ops
     x = torch.randn(50, 96, device=dev())
