@@ -465,6 +465,7 @@ struct BankArgs {
     const int* chunk_start;      // [C]
     const int* chunk_count;      // [C]
     const int* chunk_slot;       // [C] -1 -> store d_bank[t] directly; >= 0 -> atomicAdd into heavy[slot]
+    const int* xcd_off;          // [9] or null: chunks [xcd_off[x], xcd_off[x+1]) belong to XCD x (their pairs' graphs live in its L2)
     void* d_bank;                // [R,2d] type T
     float* heavy;                // [n_heavy,2d] fp32, zero-initialised by the caller
     int nchunks, T, S, B, H, d;
@@ -474,61 +475,90 @@ template <typename T, int LH>
 __global__ __launch_bounds__(256) void rel_attn_bwd_bank_kernel(BankArgs a) {
     const int lane = threadIdx.x & 63;
     const int d = a.d, LR = d >> 3, G = 64 / LR, g = lane / LR, cl = lane % LR, c = cl * 8, h = cl / LH;
-    // most chunks hold one or two pairs: walk them grid-stride so a wave amortises its launch over many chunks
-    for (int ch = blockIdx.x * 4 + (threadIdx.x >> 6); ch < a.nchunks; ch += gridDim.x * 4) {
-    const int t = a.chunk_type[ch], start = a.chunk_start[ch], cnt = a.chunk_count[ch];
-    // the type's bank row does not depend on the pairs: issue its loads first so they overlap the pair walk
-    Raw8<T> rRA, rRB;
-    const T* bp = static_cast<const T*>(a.bank) + (int64_t)t * (2 * d) + c;
-    rRA.load(bp); rRB.load(bp + d);
-    // one coalesced load of the chunk's pair ids (<= 64 per chunk); pair p is then broadcast from lane p
-    const int my_pid = lane < cnt ? a.pair_sorted[start + lane] : 0;
-    float da[8] = {0, 0, 0, 0, 0, 0, 0, 0}, db[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gsum = 0.f;
-    for (int p0 = 0; p0 < cnt; p0 += 2 * G) {            // two pairs per group in flight
-        Raw8<T> rk[2], rq[2];
-        float gsc[2];
+    // Most chunks hold one or two pairs, so a chunk is a chain of three dependent global loads (chunk record -> pair ids
+    // and bank row -> q/k rows and gs) in front of a handful of FMAs.  Chunks are walked grid-stride and the chain is
+    // software-pipelined over three consecutive chunks of a wave: while chunk i is reduced, the pair ids / bank row of
+    // chunk i+1 and the record of chunk i+2 are already in flight, so an iteration costs one load latency, not three.
+    struct Meta { int t, start, cnt, slot; };
+    struct Lvl2 { Raw8<T> rRA, rRB; int my_pid; };
+    // With xcd_off the host has grouped the chunks by the XCD that owns their (first) pair's graph -- the same
+    // graph -> XCD map as the attention kernels -- so the q/k row gathers hit that XCD's private L2 instead of going out
+    // to the Infinity Cache: the 20 MB of q/k rows do not fit one 4 MB L2, an eighth of them does.
+    int lo = 0, hi = a.nchunks, stride = gridDim.x * 4, first = blockIdx.x * 4;
+    if (a.xcd_off) {
+        const int x = blockIdx.x & 7;
+        lo = a.xcd_off[x]; hi = a.xcd_off[x + 1];
+        stride = (gridDim.x >> 3) * 4; first = lo + (blockIdx.x >> 3) * 4;
+    }
+    const int last = hi - 1;
+    auto load_meta = [&](int ch) {
+        const int cc = ch < last ? ch : last;
+        Meta m;
+        m.t = a.chunk_type[cc]; m.start = a.chunk_start[cc]; m.cnt = a.chunk_count[cc]; m.slot = a.chunk_slot[cc];
+        return m;
+    };
+    auto load_lvl2 = [&](const Meta& m) {
+        Lvl2 l;
+        const T* bp = static_cast<const T*>(a.bank) + (int64_t)m.t * (2 * d) + c;
+        l.rRA.load(bp); l.rRB.load(bp + d);
+        l.my_pid = lane < m.cnt ? a.pair_sorted[m.start + lane] : 0;     // one coalesced load of the chunk's pair ids
+        return l;
+    };
+    int ch = first + (threadIdx.x >> 6);
+    if (ch >= hi) return;
+    Meta m1 = load_meta(ch), m2 = load_meta(ch + stride);
+    Lvl2 l1 = load_lvl2(m1);
+    for (; ch < hi; ch += stride) {
+        const Lvl2 l2 = load_lvl2(m2);
+        const Meta m3 = load_meta(ch + 2 * stride);
+        const int cnt = m1.cnt;
+        float da[8] = {0, 0, 0, 0, 0, 0, 0, 0}, db[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gsum = 0.f;
+        for (int p0 = 0; p0 < cnt; p0 += 2 * G) {            // two pairs per group in flight
+            Raw8<T> rk[2], rq[2];
+            float gsc[2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int p = p0 + u * G + g;
-            const int pid = __shfl(my_pid, p < cnt ? p : 0);
-            rk[u].zero(); rq[u].zero(); gsc[u] = 0.f;
-            if (p < cnt) {
-                const int b = pid % a.B, ji = pid / a.B, i = ji % a.T, j = ji / a.T;
-                gsc[u] = a.gs[(((int64_t)i * a.S + j) * a.B + b) * a.H + h];
-                rk[u].load(static_cast<const T*>(a.k) + ((int64_t)j * a.B + b) * a.ldk + c);
-                rq[u].load(static_cast<const T*>(a.q) + ((int64_t)i * a.B + b) * a.ldq + c);
+            for (int u = 0; u < 2; ++u) {
+                const int p = p0 + u * G + g;
+                const int pid = __shfl(l1.my_pid, p < cnt ? p : 0);
+                rk[u].zero(); rq[u].zero(); gsc[u] = 0.f;
+                if (p < cnt) {
+                    const int b = pid % a.B, ji = pid / a.B, i = ji % a.T, j = ji / a.T;
+                    gsc[u] = a.gs[(((int64_t)i * a.S + j) * a.B + b) * a.H + h];
+                    rk[u].load(static_cast<const T*>(a.k) + ((int64_t)j * a.B + b) * a.ldk + c);
+                    rq[u].load(static_cast<const T*>(a.q) + ((int64_t)i * a.B + b) * a.ldq + c);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float kf[8], qf[8];
+                rk[u].get(kf); rq[u].get(qf);
+                gsum += gsc[u];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { da[e] = fmaf(gsc[u], kf[e], da[e]); db[e] = fmaf(gsc[u], qf[e], db[e]); }
             }
         }
+        for (int off = LR; off < 64; off <<= 1) {
+            gsum += __shfl_xor(gsum, off);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            float kf[8], qf[8];
-            rk[u].get(kf); rq[u].get(qf);
-            gsum += gsc[u];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { da[e] = fmaf(gsc[u], kf[e], da[e]); db[e] = fmaf(gsc[u], qf[e], db[e]); }
+            for (int e = 0; e < 8; ++e) { da[e] += __shfl_xor(da[e], off); db[e] += __shfl_xor(db[e], off); }
         }
-    }
-    for (int off = LR; off < 64; off <<= 1) {
-        gsum += __shfl_xor(gsum, off);
+        if (g == 0) {
+            float RA[8], RB[8];
+            l1.rRA.get(RA); l1.rRB.get(RB);
+            if (m1.slot >= 0) {
+                float* out = a.heavy + (int64_t)m1.slot * (2 * d) + c;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { da[e] += __shfl_xor(da[e], off); db[e] += __shfl_xor(db[e], off); }
-    }
-    if (g != 0) continue;
-    float RA[8], RB[8];
-    rRA.get(RA); rRB.get(RB);
-    const int slot = a.chunk_slot[ch];
-    if (slot >= 0) {
-        float* out = a.heavy + (int64_t)slot * (2 * d) + c;
+                for (int e = 0; e < 8; ++e) { atomicAdd(out + e, fmaf(gsum, RB[e], da[e])); atomicAdd(out + d + e, fmaf(gsum, RA[e], db[e])); }
+            } else {
+                T* out = static_cast<T*>(a.d_bank) + (int64_t)m1.t * (2 * d) + c;
+                float r1[8], r2[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { atomicAdd(out + e, fmaf(gsum, RB[e], da[e])); atomicAdd(out + d + e, fmaf(gsum, RA[e], db[e])); }
-    } else {
-        T* out = static_cast<T*>(a.d_bank) + (int64_t)t * (2 * d) + c;
-        float r1[8], r2[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { r1[e] = fmaf(gsum, RB[e], da[e]); r2[e] = fmaf(gsum, RA[e], db[e]); }
-        Vec8<T>::store(out, r1);
-        Vec8<T>::store(out + d, r2);
-    }
+                for (int e = 0; e < 8; ++e) { r1[e] = fmaf(gsum, RB[e], da[e]); r2[e] = fmaf(gsum, RA[e], db[e]); }
+                Vec8<T>::store(out, r1);
+                Vec8<T>::store(out + d, r2);
+            }
+        }
+        m1 = m2; l1 = l2; m2 = m3;
     }
 }
 
@@ -619,7 +649,7 @@ extern "C" int gtos_rel_attn_bwd_bank(int dtype, int n, int B, int H, int d,
                                       const void* q, int64_t ldq, const void* k, int64_t ldk,
                                       const void* bank, const float* gs,
                                       const int* pair_sorted, const int* chunk_type, const int* chunk_start,
-                                      const int* chunk_count, const int* chunk_slot, int nchunks,
+                                      const int* chunk_count, const int* chunk_slot, const int* xcd_off, int nchunks,
                                       void* d_bank, float* heavy, void* stream) {
     int rc = check_shape(d, H);
     if (rc) return rc;
@@ -628,8 +658,10 @@ extern "C" int gtos_rel_attn_bwd_bank(int dtype, int n, int B, int H, int d,
     a.q = q; a.k = k; a.ldq = ldq; a.ldk = ldk; a.bank = bank; a.gs = gs; a.pair_sorted = pair_sorted;
     a.chunk_type = chunk_type; a.chunk_start = chunk_start; a.chunk_count = chunk_count; a.chunk_slot = chunk_slot;
     a.d_bank = d_bank; a.heavy = heavy; a.nchunks = nchunks; a.T = n; a.S = n; a.B = B; a.H = H; a.d = d;
+    a.xcd_off = xcd_off;
     hipStream_t s = static_cast<hipStream_t>(stream);
     int grid = (nchunks + 3) / 4; if (grid > 4096) grid = 4096;
+    if (xcd_off) grid = (grid + 7) / 8 * 8;
     return dispatch_lh(d / H / 8, [&](auto lh) {
         constexpr int LH = decltype(lh)::value;
         if (dtype == GTOS_BF16) hipLaunchKernelGGL((rel_attn_bwd_bank_kernel<bf16_t, LH>), dim3(grid), dim3(256), 0, s, a);

@@ -307,9 +307,12 @@ class FactoredRelation:
         self.idx_k = rel.permute(0, 2, 1).contiguous().to(torch.int32)    # [j,b,i]
         flat = rel.reshape(-1)
         R = bank.shape[0]
-        order = torch.sort(flat, stable=True)[1]
-        counts = torch.bincount(flat, minlength=R)
-        starts = torch.cumsum(counts, 0) - counts
+        # type ids fit 32 bits: a 32-bit key sort is about twice as fast as the int64 one; the per-type counts come from
+        # the sorted keys by binary search instead of an atomics histogram
+        skeys, order = torch.sort(flat.to(torch.int32), stable=True)
+        bounds = torch.searchsorted(skeys, torch.arange(R + 1, device=flat.device, dtype=torch.int32))
+        counts = bounds[1:] - bounds[:-1]
+        starts = bounds[:-1]
         nch = torch.clamp((counts + self.CHUNK - 1) // self.CHUNK, min=1)   # empty types get one empty chunk (writes zeros)
         ctype = torch.repeat_interleave(torch.arange(R, device=flat.device), nch)
         first = torch.cumsum(nch, 0) - nch
@@ -318,10 +321,19 @@ class FactoredRelation:
         slot_of_type = torch.full((R,), -1, dtype=torch.int64, device=flat.device)
         slot_of_type[heavy_types] = torch.arange(heavy_types.numel(), device=flat.device)
         self.pair_sorted = order.to(torch.int32)
-        self.chunk_type = ctype.to(torch.int32)
-        self.chunk_start = (starts[ctype] + local * self.CHUNK).to(torch.int32)
-        self.chunk_count = torch.clamp(counts[ctype] - local * self.CHUNK, min=0, max=self.CHUNK).to(torch.int32)
-        self.chunk_slot = slot_of_type[ctype].to(torch.int32)
+        c_type = ctype.to(torch.int32)
+        c_start = (starts[ctype] + local * self.CHUNK).to(torch.int32)
+        c_count = torch.clamp(counts[ctype] - local * self.CHUNK, min=0, max=self.CHUNK).to(torch.int32)
+        c_slot = slot_of_type[ctype].to(torch.int32)
+        # group the chunks by the XCD that owns the graph of their first pair (graph b -> XCD b // (B/8), the attention
+        # kernels' map), so the bank-gradient kernel gathers q/k rows from that XCD's private L2
+        first = self.pair_sorted[c_start.clamp(max=flat.numel() - 1).long()]
+        gb = first % B
+        xcd = (gb // (B // 8)) if B % 8 == 0 else (gb % 8)
+        xs, perm = torch.sort(xcd.to(torch.int32), stable=True)
+        self.xcd_off = torch.searchsorted(xs, torch.arange(9, device=flat.device, dtype=torch.int32)).to(torch.int32)
+        self.chunk_type, self.chunk_start = c_type[perm], c_start[perm]
+        self.chunk_count, self.chunk_slot = c_count[perm], c_slot[perm]
         self.heavy_types = heavy_types
         self.nchunks = int(ctype.numel())
 
@@ -388,7 +400,7 @@ class RelAttnFn(torch.autograd.Function):
             call("gtos_rel_attn_bwd_bank", dt(qsrc), T_, B, H, d,
                  qsrc.data_ptr() + q_off * es, Cq, kv.data_ptr() + k_off * es, Ckv,
                  ptr(rel), ptr(gs), ptr(fact.pair_sorted), ptr(fact.chunk_type), ptr(fact.chunk_start),
-                 ptr(fact.chunk_count), ptr(fact.chunk_slot), fact.nchunks, ptr(d_rel), ptr(heavy), stream())
+                 ptr(fact.chunk_count), ptr(fact.chunk_slot), ptr(fact.xcd_off), fact.nchunks, ptr(d_rel), ptr(heavy), stream())
             if nh:
                 d_rel[fact.heavy_types] = heavy[:nh].to(d_rel.dtype)
         return dqsrc, (dkv if kvsrc is not None else None), d_rel, None, None, None, None, None, None, None, None, None
