@@ -75,6 +75,26 @@ def test_gemm_256_macro_tile(M, N, K):
     torch.testing.assert_close(out.float(), want + base.float(), rtol=3e-2, atol=0.02 * K ** 0.5)
 
 
+@pytest.mark.parametrize("M,N,K,sk", [(768, 512, 300040, 43), (256, 256, 100000, 64), (1024, 512, 6464, 12), (512, 264, 70008, 16)])
+def test_gemm_weight_gradient_long_k_splitk(M, N, K, sk):
+    """dW = A^T B with K in the hundreds of thousands: transpose-read operand path + split-K partial tiles reduced
+    into the fp32 accumulator, contiguous and strided operands (the GRU backward passes column blocks of d4)."""
+    from gtos_amd import ops
+    torch.manual_seed(K % 89)
+    a = (torch.randn(K, M, device=dev()) * 0.5).to(torch.bfloat16)
+    b = (torch.randn(K, N, device=dev()) * 0.5).to(torch.bfloat16)
+    base = torch.randn(M, N, device=dev())
+    out = base.clone()
+    ops.gemm(a, b, trans_a=True, out=out, accumulate=True, splitk=sk)
+    want = base + a.float().t() @ b.float()
+    torch.testing.assert_close(out, want, rtol=2e-3, atol=2e-3 * K ** 0.5)
+    # strided operands (column blocks of a wider matrix, as the GRU backward passes them)
+    wide = (torch.randn(K, M + 256, device=dev()) * 0.5).to(torch.bfloat16)
+    out2 = torch.zeros(M, N, device=dev())
+    ops.gemm(wide[:, 256:], b, trans_a=True, out=out2, accumulate=True, splitk=sk)
+    torch.testing.assert_close(out2, wide[:, 256:].float().t() @ b.float(), rtol=2e-3, atol=2e-3 * K ** 0.5)
+
+
 def test_gemm_strided_views_and_dropout():
     from gtos_amd import ops
     x = torch.randn(50, 96, device=dev())
