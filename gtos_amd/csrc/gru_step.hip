@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void gru_step_fwd_kernel(StepArgs a) {
 struct StepBwdArgs {
     const bf16_t* d4_prev; int rows_prev; const bf16_t* wh_t;
     const bf16_t* gates; const bf16_t* hprev; const bf16_t* dy; int64_t ldy;
-    float* dh; bf16_t* d4; float* bias_part; int n_partials;
+    void* dh; int dh_bf16; bf16_t* d4; float* bias_part; int n_partials;
     float p_drop; uint64_t seed; int64_t drop_base;
     int rows, hs; const void* zeros;
 };
@@ -302,8 +302,9 @@ __global__ __launch_bounds__(256, 2) void gru_step_bwd_kernel(StepBwdArgs a) {
         const bf16_t* gp = a.gates + (int64_t)m * 4 * hs + cb;
         ld16(gp, gr); ld16(gp + hs, gz); ld16(gp + 2 * hs, gn); ld16(gp + 3 * hs, hn);
         ld16(a.hprev + (int64_t)m * hs + cb, hp);
-        float* dhp = a.dh + (int64_t)m * hs + cb;
-        ldf16(dhp, g);
+        float* dhp = static_cast<float*>(a.dh) + (int64_t)m * hs + cb;
+        bf16_t* dhb = static_cast<bf16_t*>(a.dh) + (int64_t)m * hs + cb;
+        if (a.dh_bf16) ld16(dhb, g); else ldf16(dhp, g);
 #pragma unroll
         for (int i = 0; i < 16; ++i) g[i] += acc[mt][i >> 2][i & 3];
         if (a.dy) {
@@ -327,9 +328,13 @@ __global__ __launch_bounds__(256, 2) void gru_step_bwd_kernel(StepBwdArgs a) {
             dz_[i] = dz * gz[i] * (1.f - gz[i]);
             g[i] *= gz[i];                                             // the direct path h_prev -> h
         }
+        if (a.dh_bf16) {
+            st16(dhb, g);
+        } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<float4*>(dhp + i * 4) = make_float4(g[i * 4], g[i * 4 + 1], g[i * 4 + 2], g[i * 4 + 3]);
+            for (int i = 0; i < 4; ++i)
+                *reinterpret_cast<float4*>(dhp + i * 4) = make_float4(g[i * 4], g[i * 4 + 1], g[i * 4 + 2], g[i * 4 + 3]);
+        }
         bf16_t* dp = a.d4 + (int64_t)m * 4 * hs + cb;
         st16(dp, dr_); st16(dp + hs, dz_); st16(dp + 2 * hs, dn_); st16(dp + 3 * hs, dhn);
 #pragma unroll
@@ -387,9 +392,9 @@ extern "C" int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, i
 }
 
 extern "C" int gtos_gru_step_bwd(int rows, int hs, const void* d4_prev, int rows_prev, const void* w_hh_t,
-                                 const void* gates, const void* hprev, const void* dy, int64_t ldy, float* dh, void* d4,
-                                 float p_drop, uint64_t seed, int64_t drop_base, float* bias_partials, int n_partials,
-                                 void* stream) {
+                                 const void* gates, const void* hprev, const void* dy, int64_t ldy, void* dh, int dh_dtype,
+                                 void* d4, float p_drop, uint64_t seed, int64_t drop_base, float* bias_partials,
+                                 int n_partials, void* stream) {
     if (rows <= 0) return 0;
     if (hs <= 0 || hs % TC) return -22;
     if (!gates || !hprev || !dh || !d4 || (d4_prev && !w_hh_t)) return -23;
@@ -399,7 +404,7 @@ extern "C" int gtos_gru_step_bwd(int rows, int hs, const void* d4_prev, int rows
     StepBwdArgs a;
     a.d4_prev = (const bf16_t*)d4_prev; a.rows_prev = d4_prev ? rows_prev : 0; a.wh_t = (const bf16_t*)w_hh_t;
     a.gates = (const bf16_t*)gates; a.hprev = (const bf16_t*)hprev; a.dy = (const bf16_t*)dy; a.ldy = ldy;
-    a.dh = dh; a.d4 = (bf16_t*)d4; a.bias_part = bias_partials; a.n_partials = n_partials;
+    a.dh = dh; a.dh_bf16 = dh_dtype == GTOS_BF16; a.d4 = (bf16_t*)d4; a.bias_part = bias_partials; a.n_partials = n_partials;
     a.p_drop = p_drop; a.seed = seed; a.drop_base = drop_base; a.rows = rows; a.hs = hs;
     a.zeros = gtos_zero_block();
     if (!a.zeros) return -5;

@@ -126,13 +126,14 @@ class BiGRUFinalFn(torch.autograd.Function):
                 wi_t, wh_t, gates, hprev = layer_saved[direction]
                 base = l * 8 + direction * 4
                 w_ih, w_hh, b_ih, b_hh = weights[base:base + 4]
-                if l == num_layers - 1:
-                    dh = d_out[:, direction * hs:(direction + 1) * hs].float().contiguous()
-                else:
-                    dh = torch.zeros((R, hs), dtype=torch.float32, device=dev)
                 steps = range(L - 1, -1, -1) if direction == 0 else range(L)
                 want_bias = b_ih.requires_grad or b_hh.requires_grad
                 fused = FUSE != "off" and dtp == torch.bfloat16 and hs % 64 == 0
+                dh_dt = dtp if fused else torch.float32     # the fused step keeps the running state gradient in bf16
+                if l == num_layers - 1:
+                    dh = d_out[:, direction * hs:(direction + 1) * hs].to(dh_dt).contiguous()
+                else:
+                    dh = torch.zeros((R, hs), dtype=dh_dt, device=dev)
                 if fused:
                     # d4 = [d r | d z | d n_x | d n_h]: d(xg) and d(hg) share their first two blocks, so ONE buffer serves both
                     d4 = torch.empty((N, 4 * hs), dtype=dtp, device=dev)
@@ -143,7 +144,7 @@ class BiGRUFinalFn(torch.autograd.Function):
                         dyp = None if dY is None else dY.data_ptr() + (off * 2 * hs + direction * hs) * dY.element_size()
                         call("gtos_gru_step_bwd", A, hs, None if prev is None else ptr(d4[offs[prev]:]),
                              0 if prev is None else batch_sizes[prev], ptr(wh_t), ptr(gates[off:off + A]), ptr(hprev[off:off + A]),
-                             dyp, 2 * hs, ptr(dh), ptr(d4[off:off + A]), float(pl), seed, off * 2 * hs + direction * hs,
+                             dyp, 2 * hs, ptr(dh), dt(dh), ptr(d4[off:off + A]), float(pl), seed, off * 2 * hs + direction * hs,
                              ptr(bpart), N_BIAS_PARTIALS, stream())
                         prev = t
                     dxg = d4[:, :3 * hs]

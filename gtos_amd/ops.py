@@ -58,7 +58,7 @@ def _splitk(M, N, K):
     if blocks >= 512 or K < 1024:
         return 1
     cap = max(1, WORKSPACE_BYTES // (4 * M * N))
-    return max(1, min((1024 + blocks - 1) // blocks, K // 512, 256, cap))
+    return max(1, min(1024 // blocks, K // 512, 256, cap))      # <= 1024 workgroups: one resident round (4 per CU)
 
 
 _WS = {}

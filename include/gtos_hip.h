@@ -123,11 +123,11 @@ int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, int in_dim, 
 /* Fused backward GRU step, bf16 only, hs % 64 == 0 (gru_step.hip).  d4 [rows,4hs] = d r | d z | d n_x | d n_h in ONE
  * buffer (d(xg) = columns 0..3hs, d(hg) = columns 0..2hs and 3hs..4hs).  First adds d(hg) W_hh of the step processed
  * just before (d4_prev [rows_prev,4hs], may be NULL; w_hh_t = W_hh^T [hs,3hs]) to the running state gradient dh
- * [rows,hs] fp32 -- this replaces the per-step GEMM -- then runs the cell backward: dh += dropout-masked dy, writes d4,
+ * [rows,hs] (dh_dtype: GTOS_F32 or GTOS_BF16) -- this replaces the per-step GEMM -- then runs the cell backward: dh += dropout-masked dy, writes d4,
  * leaves dh = dh_total * z.  bias_partials [n_partials,4hs] fp32 (optional, zeroed by the caller) accumulates the
  * column sums of d4 with atomics (sum over dim 0 = GRU bias gradients, as in gtos_gru_cell_bwd). */
 int gtos_gru_step_bwd(int rows, int hs, const void* d4_prev, int rows_prev, const void* w_hh_t,
-                      const void* gates, const void* hprev, const void* dy, int64_t ldy, float* dh, void* d4,
+                      const void* gates, const void* hprev, const void* dy, int64_t ldy, void* dh, int dh_dtype, void* d4,
                       float p_drop, uint64_t seed, int64_t drop_base, float* bias_partials, int n_partials, void* stream);
 
 /* Backward of one step: dh (fp32, in/out) carries the state gradient; writes d(xg), d(hg) [rows,3*hs].
