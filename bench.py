@@ -54,6 +54,10 @@ def parse():
     ap.add_argument("--dense", action="store_true", help="dense relation[n,n,B,d] signature instead of the factored form")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-graphs", type=int, default=2)
+    ap.add_argument("--decode", action="store_true",
+                    help="secondary benchmark (SURVEY 8f rank 2): beam search over the K/V-cached decoder instead of the train step")
+    ap.add_argument("--beam", type=int, default=8)
+    ap.add_argument("--max-steps", type=int, default=50)
     return ap.parse_args()
 
 
@@ -102,8 +106,71 @@ def cpu_baseline(cfg_name, graphs):
                 graphs, cfg_name, stats["n"], stats["R"], n_timed, dt_)}
 
 
+def decode_bench(a):
+    """Inference benchmark: beam search (generator/work.py flow) on synthetic graphs of the named config, eval-mode batch
+    (all shortest paths, K alternatives per pair), random-weight model.  Prints one JSON line: sentences/s, ms per decoder
+    step; cpu_baseline = the pinned oracle (full-prefix recompute, no state carried) on --cpu-graphs of the graphs."""
+    from gtos_amd import synth
+    from gtos_amd.config import generator_args
+    from gtos_amd.generator import Generator
+    dev = torch.device("cuda:0")
+    cfg = synth.CONFIGS[a.config]
+    vocabs = synth.synth_vocabs()
+    cd = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+
+    def local_vocabs(batch):        # cp_seq ids beyond the predictable vocabulary are per-graph copy ids: give them strings
+        pv, cp = vocabs['predictable_token'], batch['cp_seq']
+        return [{int(i): "copy%d" % int(i) for i in cp[:, b].tolist() if i >= pv.size} for b in range(cp.shape[1])]
+
+    torch.manual_seed(19940117)
+    model = Generator(vocabs, device=dev, depth_size=256 if cfg["kind"] == "dep" else 32, **generator_args(cfg)).to(dev)
+    model.set_compute_dtype(cd)
+    model.eval()
+    batch, stats = synth.make_config_batch(a.config, train=False)
+    B = stats["B"]
+    batch_dev = {k: v.to(dev) for k, v in batch.items()}
+    batch_dev['local_idx2token'] = local_vocabs(batch)
+    model.work(batch_dev, a.beam, 3)                       # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        model.encode_step(batch_dev, train=False)
+    torch.cuda.synchronize()
+    t_enc = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    beams = model.work(batch_dev, a.beam, a.max_steps)
+    torch.cuda.synchronize()
+    dt_ = time.perf_counter() - t0
+    steps = max(b.steps for b in beams)
+    out = {"metric": "sentences/sec beam search (100-node AMR, batch 64, beam %d, %d steps)" % (a.beam, a.max_steps),
+           "value": B / dt_, "unit": "sentences/s", "n_gpus": 1, "higher_is_better": True, "dtype": a.dtype, "data": "synthetic",
+           "config": {"workload": "%s eval batch: %d graphs, n=%d, beam %d, max %d decoder steps, random weights" % (
+               a.config, B, stats["n"], a.beam, a.max_steps)},
+           "seconds": dt_, "encode_seconds": t_enc, "decoder_steps": steps,
+           "ms_per_decoder_step": 1e3 * (dt_ - t_enc) / max(1, steps)}
+    if not a.no_cpu_baseline:
+        from oracle import gtos_oracle as O
+        cores = host_cores()
+        torch.set_num_threads(cores)
+        torch.manual_seed(19940117)
+        ref = O.Generator(vocabs, depth_size=256 if cfg["kind"] == "dep" else 32, **generator_args(cfg))
+        ref.eval()
+        small, _ = synth.make_config_batch(a.config, train=False, B=a.cpu_graphs)
+        small['local_idx2token'] = local_vocabs(small)
+        t0 = time.perf_counter()
+        O.generator_work(ref, small, vocabs, a.beam, a.max_steps)
+        ct = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": a.cpu_graphs / ct, "unit": "sentences/s", "cores": cores, "kind": "port",
+                               "sample": "%d graphs of %s, fp32, beam %d, %d steps, %.1f s" % (
+                                   a.cpu_graphs, a.config, a.beam, a.max_steps, ct)}
+    print(json.dumps(out))
+
+
 def main():
     a = parse()
+    if a.decode:
+        torch.cuda.set_device(0)
+        return decode_bench(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
