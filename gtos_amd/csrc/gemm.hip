@@ -8,18 +8,20 @@
 //   dX = dY W               -> TA=0, TB=0
 //   dW = dY^T X             -> TA=1, TB=0, split-K, fp32 atomic accumulate
 //
-// Structure (one 256-thread workgroup = 4 waves, 2x2, per 128x128 output tile; each wave 64x64 = 4x4 MFMA tiles;
-// bf16 inputs: v_mfma_f32_16x16x32_bf16, fp32 inputs: the exact-fp32 v_mfma_f32_16x16x4_f32):
-//   * both operands live K-contiguous in LDS, 128-byte rows of 8 16-byte chunks, chunk index XOR-swizzled with
-//     ((row>>1)&7) ^ ((row>>4)&3) so that fragment ds_read_b128s and row-wise tile writes are bank-conflict free and
-//     the transposed writes of M/N-contiguous operands at most 2-way, without padding;
-//   * two LDS stages; the next tile's global loads are issued BEFORE the MFMAs of the current tile and written to
-//     the other stage AFTER them, one barrier per K tile; the loads are branch-free (out-of-range vectors read a
-//     block of zeros) so they issue back to back;
-//   * M/N-contiguous operands (dY^T, X in dW; W in dX) are transposed in registers (4x8 bf16 blocks) and written
-//     with ds_write_b64 instead of 2-byte scatter writes;
+// Structure of the main kernel (one 256-thread workgroup = 4 waves, 2x2, per 128x128 output tile; each wave 64x64 =
+// 4x4 MFMA tiles; bf16 inputs: v_mfma_f32_16x16x32_bf16, fp32 inputs: the exact-fp32 v_mfma_f32_16x16x4_f32):
+//   * bf16 operands of EVERY layout go global -> LDS directly (global_load_lds_dwordx4), one 32 KB stage, up to 4
+//     workgroups per CU covering each other's load latency: K-contiguous operands as 128-byte rows of 8 16-byte chunks
+//     with the chunk index XOR-swizzled by ((row>>1)&7) ^ ((row>>4)&3) on the DMA's source address (conflict-free
+//     fragment ds_read_b128), M/N-contiguous operands as a [k][128] tile read with ds_read_b64_tr_b16;
+//   * fp32 operands that are not K-contiguous keep a register-staged path: 512 threads, two LDS stages, prefetch
+//     distance 2, branch-free loads (out-of-range vectors read a block of zeros), 4x8 in-register transposes and
+//     ds_write_b64 instead of 2-byte scatter writes;
 //   * MFMA operands are swapped (D = B.A^T) so a lane holds 4 consecutive output columns; bf16 outputs go through
-//     LDS and leave as full 128-byte row segments.
+//     LDS and leave as full 128-byte row segments; bias / ReLU / dropout are applied in the epilogue;
+//   * split-K (weight gradients) writes per-split partial tiles to a workspace, splitk_reduce_kernel adds them into C;
+//   * XCD-aware tile order (block id % 8 = XCD): an XCD walks the N tiles of an M panel / all tiles of one K split;
+//   * gemm256_nt_kernel: 256x256 macro tile with a two-stage DMA pipeline for deep-K products (see its comment).
 #include "common.h"
 #include <stdlib.h>
 

@@ -1,4 +1,5 @@
-// Fused relation-aware graph attention for gfx950 (forward + backward), wave-per-query streaming kernels.
+// Fused relation-aware graph attention for gfx950 (forward + backward): streaming kernels, one 4-wave workgroup per
+// (query, graph) row whose waves split the keys.
 //
 // Replaces the reference op sequence of RelationMultiheadAttention.forward
 // (/root/reference/generator/graph_transformer.py:122-165: q.unsqueeze(1)+ra, k.unsqueeze(0)+rb, scaling,
@@ -17,13 +18,14 @@
 //                      inside the kernel, which fuses away the reference's index_select
 //                      (/root/reference/generator/generator.py:79).
 //
-// Mapping: one 64-lane wave owns one (query i, graph b).  A row of d channels is spread over LR = d/8 lanes,
-// 8 channels (16 B bf16 / 32 B fp32) per lane, so one wave-instruction streams a whole 2d-wide relation row
-// with fully coalesced 16-byte loads; the per-head dot product is a shuffle reduction over the LH = hd/8 lanes
-// of a head and the softmax over keys is an online (running max / sum) update, i.e. the per-head softmax
-// reduction is wavefront shuffles only.  If d < 512 the wave processes G = 64/LR keys at once and merges the
-// G partial softmax states at the end.  K/V rows come through L2: the block->(i,b) map keeps every graph's
-// K/V on one XCD (8 XCDs, private L2s).
+// Mapping: one 256-thread workgroup owns one (query i, graph b); its 4 waves take the keys interleaved (wave w, key
+// group g: j = jb + w*G + g) and merge their online-softmax states (running max / sum / output) through LDS at the
+// end.  Inside a wave a row of d channels is spread over LR = d/8 lanes, 8 channels (16 B bf16 / 32 B fp32) per lane,
+// so one wave-instruction streams a whole 2d-wide relation row with fully coalesced 16-byte loads; the per-head dot
+// product is a DPP reduction (v_add with quad_perm / row_mirror modifiers, no LDS round trip) over the LH = hd/8
+// lanes of a head.  If d < 512 a wave processes G = 64/LR keys at once.  The key loop is double buffered: two named
+// register sets of U keys, the loads of one in flight while the other is consumed.  Masks are staged in LDS once per
+// workgroup.  K/V rows come through L2: the block->(i,b) map keeps every graph's K/V on one XCD (8 XCDs, private L2s).
 #include "common.h"
 #include <type_traits>
 
