@@ -194,6 +194,74 @@ def test_factored_relation_matches_oracle(n, B, d, H, R):
         torch.testing.assert_close(p.grad.cpu(), q.grad, msg=lambda s, k=k: "%s: %s" % (k, s), **GRAD)
 
 
+@pytest.mark.parametrize("n,B,d,H,R,npad", [(2, 1, 16, 1, 3, 0), (3, 1, 64, 8, 1, 1), (1100, 1, 32, 4, 50, 37), (5, 11, 32, 4, 7, 2)])
+def test_graph_transformer_edge_shapes(n, B, d, H, R, npad):
+    """Smallest graphs (<CLS> + one node), one relation type for every pair, head_dim 8 (one lane per head), B not a
+    multiple of 8 (no XCD graph map), and more keys than the LDS mask buffer holds (1100 > 1024: masks read from global
+    memory) -- factored and dense operands against the pinned oracle, forward and backward."""
+    from gtos_amd.graph_transformer import GraphTransformer
+    from gtos_amd.ops import FactoredRelation
+    from oracle import gtos_oracle as O
+    g = torch.Generator().manual_seed(n * 7 + d)
+    bank = 0.5 * torch.randn(R, d, generator=g)
+    idx = torch.randint(0, R, (n, n, B), generator=g)
+    x = torch.randn(n, B, d, generator=g)
+    pad = torch.zeros(n, B, dtype=torch.bool)
+    if npad:
+        pad[n - npad:, B - 1] = True
+    torch.manual_seed(11)
+    ref = O.GraphTransformer(1, d, 2 * d, H, 0.0)
+    m = GraphTransformer(1, d, 2 * d, H, 0.0).to(dev())
+    m.load_state_dict(ref.state_dict())
+    wout = torch.randn(n, B, d, generator=g)
+    bank_r, x_r = bank.clone().requires_grad_(), x.clone().requires_grad_()
+    out_r = ref(x_r, O.relation_lookup_train(bank_r, idx), self_padding_mask=pad)
+    (out_r * wout).sum().backward()
+    for factored in (True, False):
+        bank_d, x_d = bank.to(dev()).requires_grad_(), x.to(dev()).requires_grad_()
+        rel = FactoredRelation(bank_d, idx.to(dev())) if factored else bank_d.index_select(0, idx.to(dev()).reshape(-1)).view(n, n, B, d)
+        out_d = m(x_d, rel, self_padding_mask=pad.to(dev()))
+        (out_d * wout.to(dev())).sum().backward()
+        torch.testing.assert_close(out_d.cpu(), out_r, **FP32)
+        torch.testing.assert_close(x_d.grad.cpu(), x_r.grad, **GRAD)
+        torch.testing.assert_close(bank_d.grad.cpu(), bank_r.grad, rtol=2e-3, atol=2e-3 if n > 1000 else 1e-3)
+        m.zero_grad()
+
+
+def test_relation_encoder_edge_shapes():
+    """A single path of length 1; all paths of length 1; one long path among short ones -- against the pinned oracle."""
+    from gtos_amd.encoder import RelationEncoder
+    from oracle import gtos_oracle as O
+    from oracle.gtos_oracle import VocabSpec
+    cases = [torch.tensor([1]), torch.ones(17, dtype=torch.int64), torch.tensor([1, 8, 1, 2, 1, 1])]
+    for lengths in cases:
+        R, L = lengths.numel(), int(lengths.max())
+        torch.manual_seed(3 + R)
+        toks = torch.randint(1, 30, (L, R))
+        for r in range(R):
+            toks[int(lengths[r]):, r] = 0
+        ref = O.RelationEncoder(VocabSpec(30, 0), 12, 32, 16, 2, 0.0)
+        m = RelationEncoder(VocabSpec(30, 0), 12, 32, 16, 2, 0.0).to(dev())
+        m.load_state_dict(ref.state_dict())
+        out_r = ref(toks, lengths)
+        out_r.square().sum().backward()
+        out_d = m(toks.to(dev()), lengths.to(dev()))
+        out_d.square().sum().backward()
+        torch.testing.assert_close(out_d.cpu(), out_r, **FP32)
+        for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+            torch.testing.assert_close(p.grad.cpu(), q.grad, msg=lambda s_, k=k: "%s: %s" % (k, s_), **GRAD)
+
+
+def test_gemm_degenerate_sizes():
+    from gtos_amd import ops
+    a = torch.randn(0, 16, device=dev())
+    b = torch.randn(8, 16, device=dev())
+    assert ops.gemm(a, b, trans_b=True).shape == (0, 8)                 # no rows: nothing launched
+    a1 = torch.randn(1, 8, device=dev()).to(torch.bfloat16)
+    b1 = torch.randn(1, 8, device=dev()).to(torch.bfloat16)
+    torch.testing.assert_close(ops.gemm(a1, b1, trans_b=True).float(), a1.float() @ b1.float().t(), rtol=2e-2, atol=2e-2)
+
+
 def test_relation_gather_mean_eval_lookup():
     from gtos_amd import ops
     from oracle import gtos_oracle as O
