@@ -129,7 +129,7 @@ __device__ __forceinline__ bool key_dead(const AttnArgs& a, const unsigned char*
 
 // ------------------------------------------------------------------------------------------- forward
 template <typename T, int LH>
-__global__ __launch_bounds__(256) void rel_attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 4) void rel_attn_fwd_kernel(AttnArgs a) {
     constexpr int U = Unroll<T>::U;
     __shared__ unsigned char smask[MAXS_LDS];
     __shared__ float red[4][64][10];             // per wave, per lane: m, l, o[8]
