@@ -1,9 +1,12 @@
 """Bidirectional multi-layer GRU over packed, length-sorted relation label paths (final states only).
 
 MI355X counterpart of ``nn.utils.rnn.pack_padded_sequence`` + ``nn.GRU`` as RelationEncoder uses them
-(/root/reference/generator/encoder.py:93-111): the input-gate products of ALL steps are one MFMA GEMM, each
-time step is one [active,h]x[h,3h] GEMM plus the fused gate kernel (gtos_gru_cell_fwd), and the backward pass
-is explicit BPTT with one weight-gradient GEMM per direction over all steps at once.
+(/root/reference/generator/encoder.py:93-111), with explicit BPTT.  bf16 (hidden size a multiple of 64): one fused MFMA
+kernel per time step and direction, forward (gtos_gru_step_fwd: x W_ih^T and h W_hh^T gate products + cell; the state
+is written straight into the next step's operand slot) and backward (gtos_gru_step_bwd: recurrent gradient product +
+cell backward + bias sums, one d4 = [dr|dz|dn_x|dn_h] buffer).  fp32 / other sizes: the input-gate products of ALL
+steps are one GEMM, each step one [active,h]x[h,3h] GEMM plus gtos_gru_cell_fwd / gtos_gru_cell_bwd.  Weight and
+input gradients are GEMMs over all steps at once in both paths.
 """
 import os
 
