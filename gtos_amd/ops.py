@@ -52,13 +52,18 @@ def _row_major(t):
 
 
 def _splitk(M, N, K):
-    """K splits for weight-gradient shapes (few output tiles, long K): enough workgroups for 4 per CU, at least 512 of
-    K per split; the partial tiles go through the workspace (ops._workspace), so splitting is cheap."""
+    """K splits for weight-gradient shapes (few output tiles, long K).  The kernel runs all tiles of one split on one
+    XCD (32 CUs x 4 resident workgroups = 128 slots), so the split count is a multiple of 8 with tiles * splits / 8 <= 128:
+    one resident round on every XCD (42 splits of a 24-tile product left two XCDs with 6 x 24 = 144 workgroups, a second
+    round, and 565 instead of 800 TF/s).  At least 6 k tiles per split; partial tiles go through the workspace."""
     blocks = ((M + 127) // 128) * ((N + 127) // 128)
     if blocks >= 512 or K < 1024:
         return 1
-    cap = max(1, WORKSPACE_BYTES // (4 * M * N))
-    return max(1, min(1024 // blocks, K // 512, 256, cap))      # <= 1024 workgroups: one resident round (4 per CU)
+    sk = min(8 * max(1, 128 // blocks), 256, max(1, WORKSPACE_BYTES // (4 * M * N)))
+    kmax = K // 384
+    if kmax < sk:
+        sk = (kmax // 8) * 8 if kmax >= 8 else kmax
+    return max(1, sk)
 
 
 _WS = {}

@@ -23,6 +23,8 @@ SHAPES = [  # name, ta, tb, M, N, K, out dtype
     ("gru_dwih_l1 TN", True, False, 768, 512, 2497000, torch.float32),
     ("rel_dw      TN", True, False, 1024, 512, 434624, torch.float32),
     ("ffn_fc1     NT", False, True, 6464, 1024, 512, torch.bfloat16),
+    ("tn_m1024_Kbig TN", True, False, 1024, 512, 2497000, torch.float32),
+    ("tn_m768_Ksml  TN", True, False, 768, 512, 434624, torch.float32),
     ("deepK       NT", False, True, 434624, 1024, 4096, torch.bfloat16),     # same tile count as rel_proj, 8x the k tiles
     ("square8k    NT", False, True, 8192, 8192, 8192, torch.bfloat16),
 ]
