@@ -502,7 +502,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splits, i
 // ---- 256x256 macro tile for big K-contiguous bf16 products with a DEEP reduction (K >= 1024).  Measured on MI355X
 //      (tools/bench_gemm.py): [434624,4096]x[1024,4096]^T 1001 TF/s vs 832 for the 128x128 kernel, 8192^3 1004 vs 705;
 //      at K = 512 both sit at ~690 TF/s because a tile's output write (not overlapped inside a 1-workgroup-per-CU
-//      kernel) costs as much as its 8 k tiles, so the dispatcher keeps short-K shapes on the 128x128 kernel.  8 waves (2 x 4), each 128 x 64 = 8 x 4 MFMA
+//      kernel) costs as much as its 8 k tiles, so the dispatcher keeps K < 2048 on the 128x128 kernel (at K = 1024, N = 512 the macro tile measured 603 vs 653 TF/s in the training step).  8 waves (2 x 4), each 128 x 64 = 8 x 4 MFMA
 //      tiles (128 accumulator registers), two 64 KB LDS stages.  Per k tile: barrier (drains this stage's DMA), ALL
 //      fragments of the tile are read into registers, THEN the next tile's DMA is issued into the other stage, then the
 //      64 MFMAs run while it lands -- hipcc waits for every outstanding LDS-DMA in front of any ds_read, so the reads
@@ -712,7 +712,7 @@ extern "C" int gtos_gemm(int in_dtype, int out_dtype, int transA, int transB, in
     if (in_dtype == GTOS_BF16 && out_dtype == GTOS_BF16) {
         // big forward-shaped products go to the 256x256 macro tile (enough tiles to give every CU several)
         const long long t256 = ((long long)(M + BM2 - 1) / BM2) * ((N + BN2 - 1) / BN2);
-        if (g_use256 && !transA && transB && a.vecA && a.vecB && a.vecC && splitk == 1 && t256 >= 1024 && N >= 256 && K >= 1024)
+        if (g_use256 && !transA && transB && a.vecA && a.vecB && a.vecC && splitk == 1 && t256 >= 1024 && N >= 256 && K >= 2048)
             return launch256(a, s);
         return launch<bf16_t, bf16_t>(a, transA, transB, s);
     }
