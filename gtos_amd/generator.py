@@ -76,7 +76,9 @@ class Generator(nn.Module):
             else:
                 relation = bank.index_select(0, inp['relation'].reshape(-1)).view(*inp['relation'].size(), -1)
         else:
-            relation = ops.relation_gather_mean(bank.detach(), inp['relation'], zero_row0=True)
+            # generator flavour: [n,n,B,K] alternatives averaged (generator.py:83-88); translator flavour: one path per
+            # pair, the plain lookup (translator/generator.py:73), here without building an autograd graph
+            relation = ops.relation_gather_mean(bank.detach(), inp['relation'], zero_row0=inp['relation'].dim() == 4)
         concept_repr = self.graph_encoder(concept_repr, relation, self_padding_mask=concept_mask)
         probe = torch.tanh(ops.linear(concept_repr[:1], self.probe_generator.weight, self.probe_generator.bias))
         return concept_repr[1:], concept_mask[1:], probe

@@ -490,7 +490,9 @@ class Generator(nn.Module):
         c = self.concept_embed_layer_norm(c)
         cmask = inp['concept'].eq(self.vocabs['concept'].padding_idx)
         bank = self.relation_encoder(inp['relation_bank'], inp['relation_length'])
-        rel = relation_lookup_train(bank, inp['relation']) if train else \
+        # eval batches of the generator carry K alternative paths per pair; the translator's carry one (its encode_step
+        # has no train flag, translator/generator.py:67-80)
+        rel = relation_lookup_train(bank, inp['relation']) if (train or inp['relation'].dim() == 3) else \
             relation_lookup_eval(bank, inp['relation'])
         c = self.graph_encoder(c, rel, self_padding_mask=cmask)
         probe = torch.tanh(self.probe_generator(c[:1]))

@@ -16,9 +16,12 @@ from conftest import GOLDEN as GOLDEN_DIR, T
 SCORE_TOL = 2e-4          # accumulated fp32 log-likelihoods, CPU oracle / GPU kernels vs the reference's CPU run
 
 
-def load_case():
-    meta = json.load(open(os.path.join(GOLDEN_DIR, "beam_smatch.json")))
-    arrs = np.load(os.path.join(GOLDEN_DIR, "beam_smatch.npz"))
+CASES = ["beam_smatch", "beam_dep_dev"]     # generator flavour (AMR, K-path eval batch) / translator flavour (real dev.txt)
+
+
+def load_case(name="beam_smatch"):
+    meta = json.load(open(os.path.join(GOLDEN_DIR, name + ".json"), encoding="utf8"))
+    arrs = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
     return meta, arrs
 
 
@@ -55,21 +58,23 @@ def check_hyps(got, want, what):
 
 
 # ------------------------------------------------------------------------------------------------ vocabulary files
-def test_vocab_matches_reference(tmp_path):
-    meta, _ = load_case()
+@pytest.mark.parametrize("case", CASES)
+def test_vocab_matches_reference(case, tmp_path):
+    meta, _ = load_case(case)
     vocabs = make_vocabs(meta, tmp_path)
     for name, truth in meta["vocab_truth"].items():
         v = vocabs[name]
         assert v.size == truth["size"], name
         assert abs(v.coverage - truth["coverage"]) < 1e-12
         assert v.idx2token(list(range(v.size))) == truth["idx2token"]
-        for tok, idx in truth["token2idx"].items():
+        for tok, idx in truth.get("token2idx", {}).items():
             assert v.token2idx(tok) == idx, (name, tok)
-        for tok, pr in truth["priority"].items():
+        for tok, pr in truth.get("priority", {}).items():
             assert v.priority(tok) == pr
         assert v.padding_idx == 0 and v.unk_idx == 1
-    # the malformed (blank) line re-enters the previous token, as the reference does: sizes decide embedding shapes
-    assert meta["vocab_truth"]["token"]["idx2token"].count("go") == 2
+    if case == "beam_smatch":
+        # the malformed (blank) line re-enters the previous token, as the reference does: sizes decide embedding shapes
+        assert meta["vocab_truth"]["token"]["idx2token"].count("go") == 2
 
 
 def test_tensorisers_shapes_and_padding(tmp_path):
@@ -148,14 +153,15 @@ def test_beam_bookkeeping_rules():
     assert best.seq[-1] == END
 
 
-def test_oracle_beam_search_matches_reference(tmp_path):
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_beam_search_matches_reference(case, tmp_path):
     from oracle import gtos_oracle as O
-    meta, arrs = load_case()
+    meta, arrs = load_case(case)
     vocabs = make_vocabs(meta, tmp_path)
     cfg = meta["cfg"]
     ga = [[tuple(f) for f in a] if isinstance(a, list) else a for a in cfg["gen_args"]]
     model = O.Generator(vocabs, *ga, cfg["d"], cfg["ff"], cfg["H"], 0.0, cfg["snt_layers"], cfg["graph_layers"],
-                        cfg["inference_layers"])
+                        cfg["inference_layers"], depth_size=cfg.get("depth_size", 32))
     model.load_state_dict(state_dict_of(arrs))
     model.eval()
     batch = batch_of(meta, arrs)
@@ -170,15 +176,16 @@ def test_oracle_beam_search_matches_reference(tmp_path):
 
 
 @pytest.mark.gpu
-def test_hip_beam_search_matches_reference(tmp_path):
+@pytest.mark.parametrize("case", CASES)
+def test_hip_beam_search_matches_reference(case, tmp_path):
     from gtos_amd.generator import Generator
-    meta, arrs = load_case()
+    meta, arrs = load_case(case)
     dev = torch.device("cuda:0")
     vocabs = make_vocabs(meta, tmp_path)
     cfg = meta["cfg"]
     ga = [[tuple(f) for f in a] if isinstance(a, list) else a for a in cfg["gen_args"]]
     model = Generator(vocabs, *ga, cfg["d"], cfg["ff"], cfg["H"], 0.0, cfg["snt_layers"], cfg["graph_layers"],
-                      cfg["inference_layers"], None, dev).to(dev)
+                      cfg["inference_layers"], None, dev, depth_size=cfg.get("depth_size", 32)).to(dev)
     model.load_state_dict(state_dict_of(arrs))
     model.eval()
     batch = batch_of(meta, arrs, dev)
