@@ -6,7 +6,8 @@
       (single shortest path per pair, depth table of 256) decodes them with translator/search.py on a small
       random-weight model.  The .json holds the vocabulary files (only lines that matter: every token that reaches its
       threshold, plus the total count mass so that `coverage` can be checked), what the reference's Vocab makes of
-      them, the copy vocabularies and the beams.
+      them, the copy vocabularies and the beams.  The .npz also carries the TRAINING forward/backward of the same real
+      batch (loss + every parameter gradient, dropout 0).
 
 Run in the build container only:  python tests/golden/make_golden_beam_dep.py
 Harness shims (monkey-patches, the reference files are not edited): np.int; Tensor.cuda -> identity; bool causal mask.
@@ -33,6 +34,9 @@ from extract import IO, LexicalMap            # noqa: E402
 from dependencyGraph import dependencyGraph   # noqa: E402
 
 rtf.SelfAttentionMask.get_mask = staticmethod(lambda size: torch.ones((size, size), dtype=torch.bool).triu_(1))
+# q *= scaling on a chunk view trips autograd on current torch (training forward only) -> hand out clones
+_orig_qkv = rtf.MultiheadAttention.in_proj_qkv
+rtf.MultiheadAttention.in_proj_qkv = lambda self, q: tuple(t.clone() for t in _orig_qkv(self, q))
 
 GEN_ARGS = (8, 12, 8, 12, [(3, 16)], 10, 10, 6, 8, 2)      # tests/tests_support.py SMALL_GEN_ARGS
 D, FF, H, SNT_L, GRAPH_L, INF_L = 32, 64, 4, 1, 2, 3
@@ -127,8 +131,18 @@ def main():
             print(len(fin), len(alive), steps, " ".join(best[0][0]), "%.4f" % best[0][1])
         runs.append({"beam": beam_size, "max_step": max_step, "min_step": min_step, "expect": expect})
     arrs = {"sd/" + k: v.numpy() for k, v in model.state_dict().items()}
-    for k in ("concept", "concept_char", "concept_depth", "relation", "relation_bank", "relation_length", "cp_seq"):
+    for k in ("concept", "concept_char", "concept_depth", "relation", "relation_bank", "relation_length", "cp_seq",
+              "token_in", "token_char_in", "token_out"):
         arrs["batch/" + k] = np.asarray(batch[k])
+    # the same real batch through the TRAINING forward/backward (dropout 0): loss and every parameter gradient
+    model.train()
+    loss = model(batch)
+    loss.backward()
+    arrs["train/loss"] = loss.detach().numpy()
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            arrs["grad/" + k] = p.grad.numpy()
+    print("training loss on the real batch: %.6f" % float(loss))
     np.savez_compressed(os.path.join(HERE, "beam_dep_dev.npz"), **arrs)
     meta = {"files": files, "vocab_truth": vocab_truth,
             "local_idx2token": [{str(k): v for k, v in d.items()} for d in batch['local_idx2token']],

@@ -249,3 +249,49 @@ def test_hip_incremental_step_equals_full_prefix_recompute(tmp_path):
                 assert np.allclose(got_s, top_s.tolist(), atol=2e-4), (step, h)
             for p in prefixes:
                 p.append(words[rng.randint(len(words))])
+
+
+# ------------------------------------------------------------------------------------------------ real-data train step
+def test_oracle_training_step_on_real_translator_batch(tmp_path):
+    """Loss and every parameter gradient of translator/generator.py on a real dev.txt batch (ragged lengths, copy ids,
+    real vocabularies) -- pins the oracle on data the synthetic fixtures do not resemble."""
+    from oracle import gtos_oracle as O
+    meta, arrs = load_case("beam_dep_dev")
+    vocabs = make_vocabs(meta, tmp_path)
+    cfg = meta["cfg"]
+    ga = [[tuple(f) for f in a] if isinstance(a, list) else a for a in cfg["gen_args"]]
+    model = O.Generator(vocabs, *ga, cfg["d"], cfg["ff"], cfg["H"], 0.0, cfg["snt_layers"], cfg["graph_layers"],
+                        cfg["inference_layers"], depth_size=256)
+    model.load_state_dict(state_dict_of(arrs))
+    model.train()
+    loss = model(batch_of(meta, arrs))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(arrs["train/loss"])) < 1e-4
+    want = {k[len("grad/"):]: T(arrs[k]) for k in arrs.files if k.startswith("grad/")}
+    got = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+    assert set(got) == set(want)
+    for k in want:
+        torch.testing.assert_close(got[k], want[k], rtol=2e-3, atol=2e-5, msg=lambda m, k=k: "%s: %s" % (k, m))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("factored", [True, False])
+def test_hip_training_step_on_real_translator_batch(factored, tmp_path):
+    from gtos_amd.generator import Generator
+    meta, arrs = load_case("beam_dep_dev")
+    dev = torch.device("cuda:0")
+    vocabs = make_vocabs(meta, tmp_path)
+    cfg = meta["cfg"]
+    ga = [[tuple(f) for f in a] if isinstance(a, list) else a for a in cfg["gen_args"]]
+    model = Generator(vocabs, *ga, cfg["d"], cfg["ff"], cfg["H"], 0.0, cfg["snt_layers"], cfg["graph_layers"],
+                      cfg["inference_layers"], None, dev, depth_size=256, factored_relation=factored).to(dev)
+    model.load_state_dict(state_dict_of(arrs))
+    model.train()
+    loss = model(batch_of(meta, arrs, dev))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(arrs["train/loss"])) < 1e-3
+    want = {k[len("grad/"):]: T(arrs[k]) for k in arrs.files if k.startswith("grad/")}
+    got = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+    assert set(got) == set(want)
+    for k in want:
+        torch.testing.assert_close(got[k].cpu(), want[k], rtol=2e-3, atol=1e-3, msg=lambda m, k=k: "%s: %s" % (k, m))
