@@ -83,10 +83,11 @@ def main():
     vocab_truth = {k: {"size": v.size, "coverage": v.coverage, "idx2token": list(v._idx2token)} for k, v in vocabs.items()}
 
     lex = LexicalMap()
-    items = []
+    items, trees = [], []
     for k, (dep, head, tok, tgt) in enumerate(IO.read1(os.path.join(REF, "translator_data", "dev.txt"))):
         if k >= 6:
             break
+        trees.append([dep, head, tok, tgt])
         g = dependencyGraph(dep, head, tok, tgt)
         concept, depth, relation, ok = g.collect_concepts_and_relations()
         assert ok
@@ -144,7 +145,8 @@ def main():
             arrs["grad/" + k] = p.grad.numpy()
     print("training loss on the real batch: %.6f" % float(loss))
     np.savez_compressed(os.path.join(HERE, "beam_dep_dev.npz"), **arrs)
-    meta = {"files": files, "vocab_truth": vocab_truth,
+    meta = {"files": files, "vocab_truth": vocab_truth, "trees": trees,
+            "local_token2idx": batch['local_token2idx'],
             "local_idx2token": [{str(k): v for k, v in d.items()} for d in batch['local_idx2token']],
             "cfg": {"gen_args": [list(a) if isinstance(a, tuple) else a for a in GEN_ARGS], "d": D, "ff": FF, "H": H,
                     "snt_layers": SNT_L, "graph_layers": GRAPH_L, "inference_layers": INF_L, "alpha": ALPHA, "depth_size": 256},

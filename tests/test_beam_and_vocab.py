@@ -295,3 +295,26 @@ def test_hip_training_step_on_real_translator_batch(factored, tmp_path):
     assert set(got) == set(want)
     for k in want:
         torch.testing.assert_close(got[k].cpu(), want[k], rtol=2e-3, atol=1e-3, msg=lambda m, k=k: "%s: %s" % (k, m))
+
+
+# ------------------------------------------------------------------------------------------------ batch assembly
+def test_batchify_dependency_matches_reference_batch(tmp_path):
+    """Raw dev.txt trees -> gtos_amd.data.batchify_dependency (C++ relation path + vocab tensorisers) must reproduce
+    translator/data.py:batchify bit for bit: every tensor of the batch and the per-graph copy vocabularies."""
+    from gtos_amd.data import batchify_dependency, read_dependency_file
+    meta, arrs = load_case("beam_dep_dev")
+    vocabs = make_vocabs(meta, tmp_path)
+    trees = [(d, h, t, g) for d, h, t, g in meta["trees"]]
+    got = batchify_dependency(trees, vocabs, n_threads=2)
+    for k in ("concept", "concept_char", "concept_depth", "relation", "relation_bank", "relation_length", "cp_seq",
+              "token_in", "token_char_in", "token_out"):
+        want = T(arrs["batch/" + k])
+        assert got[k].dtype == torch.int64 and tuple(got[k].shape) == tuple(want.shape), k
+        assert torch.equal(got[k], want), k
+    assert got["local_idx2token"] == [{int(k): v for k, v in d.items()} for d in meta["local_idx2token"]]
+    assert got["local_token2idx"] == meta["local_token2idx"]
+    # the text reader: the reference's 4-line format
+    path = tmp_path / "mini.txt"
+    path.write_text("".join(" ".join(str(x) for x in part) + "\n" for tr in trees[:2] for part in tr), encoding="utf8")
+    back = read_dependency_file(str(path))
+    assert [list(map(list, tr)) for tr in back] == [[list(p) for p in tr] for tr in trees[:2]]
