@@ -65,3 +65,45 @@ def read_dependency_file(path):
         assert len(dep) == len(head) == len(tok)
         out.append((dep, head, tok, tgt))
     return out
+
+
+class DependencyLoader(object):
+    """Batching policy of translator/data.py:207-264 (``DataLoader``): examples are shuffled and (stably) sorted by size
+    ``n_source_tokens**2 + n_target_tokens`` when training, packed greedily until a batch holds ``batch_size`` size units
+    (or 257 examples), a trailing batch is kept if it is at least half full (always in evaluation), and the batch order is
+    shuffled.  Both shuffles draw from ``rng`` (default: the ``random`` module, like the reference) BEFORE the first batch is
+    assembled, so under the same seed the batches and their order are the reference's.  Yields batchify_dependency dicts."""
+
+    def __init__(self, vocabs, filename, batch_size, for_train, rng=None, n_threads=0):
+        import random
+        self.data = read_dependency_file(filename) if isinstance(filename, str) else list(filename)
+        self.vocabs, self.batch_size, self.train = vocabs, batch_size, for_train
+        self.rng = rng if rng is not None else random
+        self.n_threads = n_threads
+
+    @staticmethod
+    def size_of(tree):
+        dep, head, tok, tgt = tree
+        return len(tok) ** 2 + len(tgt)
+
+    def batch_indices(self):
+        idx = list(range(len(self.data)))
+        if self.train:
+            self.rng.shuffle(idx)
+            idx.sort(key=lambda i: self.size_of(self.data[i]))
+        batches, units, cur = [], 0, []
+        for i in idx:
+            units += self.size_of(self.data[i])
+            cur.append(i)
+            if units >= self.batch_size or len(cur) > 256:
+                batches.append(cur)
+                units, cur = 0, []
+        if not self.train or units > self.batch_size / 2:
+            batches.append(cur)
+        if self.train:
+            self.rng.shuffle(batches)
+        return batches
+
+    def __iter__(self):
+        for b in self.batch_indices():
+            yield batchify_dependency([self.data[i] for i in b], self.vocabs, n_threads=self.n_threads)

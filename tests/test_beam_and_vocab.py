@@ -318,3 +318,20 @@ def test_batchify_dependency_matches_reference_batch(tmp_path):
     path.write_text("".join(" ".join(str(x) for x in part) + "\n" for tr in trees[:2] for part in tr), encoding="utf8")
     back = read_dependency_file(str(path))
     assert [list(map(list, tr)) for tr in back] == [[list(p) for p in tr] for tr in trees[:2]]
+
+
+def test_dependency_loader_batches_like_the_reference():
+    """Batch composition and order of translator/data.py:DataLoader on the reference's dev.txt (2169 examples; the
+    fixture carries their sizes, which is all the policy looks at) for four (batch_size, train, seed) settings."""
+    import random
+    from gtos_amd.data import DependencyLoader
+    g = json.load(open(os.path.join(GOLDEN_DIR, "loader_dep_dev.json")))
+    trees = [(["d"] * n, [0] * n, ["w"] * n, ["t"] * m) for n, m in g["sizes"]]
+    for run in g["runs"]:
+        assert run["n_examples"] == len(trees)
+        random.seed(run["seed"])
+        dl = DependencyLoader(None, trees, run["batch_size"], run["train"])
+        assert dl.batch_indices() == run["batches"], (run["batch_size"], run["train"], run["seed"])
+        # an explicit generator gives the same result as the module-level one
+        dl2 = DependencyLoader(None, trees, run["batch_size"], run["train"], rng=random.Random(run["seed"]))
+        assert dl2.batch_indices() == run["batches"]
