@@ -55,7 +55,9 @@ def build_from_checkpoint(path, device, vocabs=None, compute_dtype=torch.float32
     filters = ga[4]
     if filters and not isinstance(filters[0], (tuple, list)):
         ga[4] = list(zip(filters[:-1:2], filters[1::2]))
-    model = Generator(vocabs, *ga, device)
+    ga[-1] = None                                             # pretrained vectors only seed training; the weights are in sd
+    # the two flavours differ in the depth-embedding table only: 32 rows (generator.py:38) or 256 (translator/generator.py:39)
+    model = Generator(vocabs, *ga, device, depth_size=sd['concept_depth.weight'].shape[0])
     model.load_state_dict(sd)
     model = model.to(device)
     model.set_compute_dtype(compute_dtype)

@@ -335,3 +335,53 @@ def test_dependency_loader_batches_like_the_reference():
         # an explicit generator gives the same result as the module-level one
         dl2 = DependencyLoader(None, trees, run["batch_size"], run["train"], rng=random.Random(run["seed"]))
         assert dl2.batch_indices() == run["batches"]
+
+
+@pytest.mark.gpu
+def test_end_to_end_translator_flow_on_gpu(tmp_path):
+    """The pieces compose like translator/train.py + work.py: raw trees -> DependencyLoader/batchify -> Trainer steps
+    (fp32, dropout on) -> checkpoint in the reference's format -> build_from_checkpoint -> beam search."""
+    import argparse
+    import random
+    from gtos_amd.checkpoint import save_checkpoint, build_from_checkpoint
+    from gtos_amd.data import DependencyLoader
+    from gtos_amd.generator import Generator
+    from gtos_amd.train import Trainer
+    meta, arrs = load_case("beam_dep_dev")
+    dev = torch.device("cuda:0")
+    vdir = write_vocab_files(meta, tmp_path)
+    from gtos_amd.vocab import load_vocabs
+    vocabs = load_vocabs(vdir)
+    cfg = meta["cfg"]
+    ga = [[tuple(f) for f in a] if isinstance(a, list) else a for a in cfg["gen_args"]]
+    torch.manual_seed(3)
+    model = Generator(vocabs, *ga, cfg["d"], cfg["ff"], cfg["H"], 0.1, cfg["snt_layers"], cfg["graph_layers"],
+                      cfg["inference_layers"], None, dev, depth_size=256).to(dev)
+    model.train()
+    trainer = Trainer(model, cfg["d"], warmup_steps=200, world_size=1)
+    trees = [tuple(t) for t in meta["trees"]]
+    random.seed(5)
+    loader = DependencyLoader(vocabs, trees, 1200, for_train=True, n_threads=2)   # size units: n_src**2 + n_tgt per tree
+    losses = []
+    for epoch in range(40):
+        for batch in loader:
+            batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+            losses.append(trainer.step(batch))
+    assert losses[-1] < 0.6 * losses[0], (losses[0], losses[-1])
+    args = argparse.Namespace(
+        token_char_dim=ga[0], token_dim=ga[1], concept_char_dim=ga[2], concept_dim=ga[3], cnn_filters=ga[4],
+        char2word_dim=ga[5], char2concept_dim=ga[6], rel_dim=ga[7], rnn_hidden_size=ga[8], rnn_num_layers=ga[9],
+        embed_dim=cfg["d"], ff_embed_dim=cfg["ff"], num_heads=cfg["H"], dropout=0.1, snt_layers=cfg["snt_layers"],
+        graph_layers=cfg["graph_layers"], inference_layers=cfg["inference_layers"], pretrained_file=None,
+        **{n: os.path.join(vdir, n) for n in meta["files"]})
+    path = str(tmp_path / "ckpt")
+    save_checkpoint(path, args, model)
+    served, _, _ = build_from_checkpoint(path, dev)            # depth table size (256) is read off the state_dict
+    assert served.concept_depth.weight.shape[0] == 256 and not served.training
+    batch = next(iter(DependencyLoader(vocabs, trees, 10 ** 9, for_train=False)))
+    batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    beams = served.work(batch, 3, 12)
+    assert len(beams) == len(trees)
+    for beam in beams:
+        best = beam.get_k_best(1, 0.6)[0]
+        assert best.seq[0] == "<STR>" and len(best.seq) >= 2 and best.score == best.score
