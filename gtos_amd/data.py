@@ -107,3 +107,57 @@ class DependencyLoader(object):
     def __iter__(self):
         for b in self.batch_indices():
             yield batchify_dependency([self.data[i] for i in b], self.vocabs, n_threads=self.n_threads)
+
+
+# ------------------------------------------------------------------------------------------------ generator flavour
+def _edges_from_paths(item, rel_vocab):
+    """The preprocessed AMR items store, per ordered pair of BFS positions, the list of shortest label paths
+    (generator/AMRGraph.py:100-115) but not the graph.  Its edges are exactly the pairs joined by a path of length 1, and
+    because positions are BFS discovery order, inserting them sorted by (source, target) position reproduces that order."""
+    n = len(item['concept'])
+    rel = item['relation']
+    edges = []
+    for i in range(n):
+        row = rel[str(i)] if str(i) in rel else rel[i]
+        for j in range(n):
+            for path in (row[str(j)] if str(j) in row else row[j]):
+                if len(path['edge']) == 1:
+                    edges.append((i, j, rel_vocab.token2idx(path['edge'][0])))
+                    break
+    import numpy as np
+    return n, 0, np.array(edges, dtype=np.int32).reshape(-1, 3)
+
+
+def batchify_amr(items, vocabs, train=True, seed=0, n_threads=0):
+    """Generator flavour (generator/data.py:126-267).  items: dicts with 'concept' (BFS order), 'depth', 'relation'
+    (path lists, only used to recover the edges), 'token', and optionally 'abstract'.  train=True draws ONE shortest path
+    per pair, uniformly among the alternatives like the reference's random.choice (from a splitmix64 stream seeded with
+    ``seed``); train=False keeps them all: relation is [n,n,B,K], type 0 = <PAD> (data.py:178-232).  The alternatives of a
+    pair are the reference's set; their order over K and the numbering of the types follow this module's enumeration
+    (the model averages over K, so neither is observable)."""
+    rv = vocabs['relation']
+    graphs = [_edges_from_paths(x, rv) for x in items]
+    rel = relbatch.build_relation_batch(graphs, relation_special_ids(rv),
+                                        path_mode=relbatch.PATH_UNIFORM if train else relbatch.PATH_ALL, seed=seed,
+                                        n_threads=n_threads)
+    for b, x in enumerate(items):
+        n = len(x['concept'])
+        assert rel['order'][b, :n].tolist() == list(range(n)), "items must list their concepts in BFS order"
+    cps, t2is, i2ts = [], [], []
+    for x in items:
+        cp_seq, t2i, i2t = copy_vocab(x['concept'], vocabs['predictable_token'])
+        cps.append(cp_seq); t2is.append(t2i); i2ts.append(i2t)
+    aug = [[STR] + list(x['token']) + [END] for x in items]
+    with_cls = [[CLS] + list(x['concept']) for x in items]
+    return {
+        'concept': lists_to_tensor(with_cls, vocabs['concept']),
+        'concept_char': strings_to_char_tensor(with_cls, vocabs['concept_char']),
+        'concept_depth': lists_to_tensor([[0] + list(x['depth']) for x in items]),
+        'relation': rel['relation'], 'relation_bank': rel['relation_bank'], 'relation_length': rel['relation_length'],
+        'local_idx2token': i2ts, 'local_token2idx': t2is,
+        'token_in': lists_to_tensor(aug, vocabs['token'])[:-1],
+        'token_char_in': strings_to_char_tensor(aug, vocabs['token_char'])[:-1],
+        'token_out': lists_to_tensor(aug, vocabs['predictable_token'], t2is)[1:],
+        'cp_seq': lists_to_tensor(cps, vocabs['predictable_token'], t2is),
+        'abstract': [x.get('abstract') for x in items],
+    }

@@ -3,7 +3,8 @@
   host_dep_dev.npz     translator flavour on the real data shipped with the reference (translator_data/dev.txt, first 48
                        trees): translator/extract.py builds the vocabularies, translator/dependencyGraph.py +
                        translator/data.py:batchify build relation / relation_bank / relation_length / concept_depth.
-  host_amr_smatch.npz  generator flavour, eval mode (all shortest paths), on the six AMRs of generator/smatch/test_input{1,2}.txt:
+  host_amr_smatch.npz  generator flavour, eval mode (all shortest paths), on the six AMRs of generator/smatch/test_input{1,2}.txt plus two
+                       hand-written re-entrant graphs (pairs with several shortest paths):
                        generator/AMRGraph.py + generator/data.py:batchify(train=False).
 
 Run in the build container only:  python tests/golden/make_golden_host.py
@@ -88,6 +89,10 @@ def amr_case():
                 if not line:
                     break
                 graphs.append(AMRGraph(AMR.parse_AMR_line(line)))
+    # two hand-written graphs with re-entrancies, so that pairs with SEVERAL shortest paths occur (K > 1 in eval batches)
+    for line in ("(a / alpha :ARG0 (b / beta :ARG0 (d / delta)) :ARG1 (c / gamma :ARG0 d))",
+                 "(r / root-01 :ARG0 (x / xx :mod (y / yy :ARG1 (z / zz))) :ARG1 (u / uu :mod y :ARG2 z) :ARG2 (v / vv :ARG0 x :ARG1 u))"):
+        graphs.append(AMRGraph(AMR.parse_AMR_line(line)))
     labels = sorted({d['label'] for g in graphs for _, _, d in g.graph.edges(data=True)})
     tdir = tempfile.mkdtemp()
 
@@ -132,6 +137,12 @@ def amr_case():
                                      rv.token2idx(rdata.TL)]))
     np.savez_compressed(os.path.join(HERE, "host_amr_smatch.npz"), **out)
     print("host_amr_smatch.npz", {k: v.shape for k, v in out.items()})
+    # the items exactly as the generator's DataLoader hands them to batchify (concept / depth / relation path lists, as the
+    # preprocessed JSON stores them) + the relation vocabulary file: input of gtos_amd.data.batchify_amr
+    with open(os.path.join(HERE, "host_amr_smatch_items.json"), "w") as fo:
+        json.dump({"items": [{k: it[k] for k in ("concept", "depth", "relation")} for it in items],
+                   "relation_vocab": open(os.path.join(tdir, "relation_vocab")).read()}, fo)
+    print("host_amr_smatch_items.json %.1f KB" % (os.path.getsize(os.path.join(HERE, "host_amr_smatch_items.json")) / 1024))
 
 
 if __name__ == "__main__":

@@ -148,3 +148,66 @@ def test_synthetic_c2_batch_speed_and_invariants(rb):
     assert out["order"][0].tolist() == order and out["depth"][0].tolist() == depth
     print("native relation batch for C2: %.3f s, R=%d" % (dt, out["relation_bank"].shape[1]))
     assert dt < 1.0
+
+
+def _amr_vocabs(tmp_path, text):
+    """Only the relation vocabulary matters for the relation tensors; the others get a minimal file."""
+    from gtos_amd.vocab import Vocab, CLS, rCLS, SEL, TL, STR, END
+    (tmp_path / "relation_vocab").write_text(text)
+    (tmp_path / "mini").write_text("a\t1000\nb\t1000\n")
+    m = str(tmp_path / "mini")
+    return {'relation': Vocab(str(tmp_path / "relation_vocab"), 5, [CLS, rCLS, SEL, TL]), 'concept': Vocab(m, 5, [CLS]),
+            'token': Vocab(m, 5, [STR, END]), 'predictable_token': Vocab(m, 5, [END]),
+            'token_char': Vocab(m, 100, [STR, END]), 'concept_char': Vocab(m, 100, [STR, END])}
+
+
+def _paths_of(rel, bank, length):
+    """{(a, c, b): sorted list of label-path tuples} from relation [n,n,B,K] / [n,n,B] + bank."""
+    rel = rel.numpy() if rel.dim() == 4 else rel.unsqueeze(-1).numpy()
+    bank, length = bank.numpy(), length.numpy()
+    out = {}
+    n, _, B, K = rel.shape
+    for a in range(n):
+        for c in range(n):
+            for b in range(B):
+                ids = [int(t) for t in rel[a, c, b] if t != 0]
+                out[(a, c, b)] = sorted(tuple(int(v) for v in bank[:length[t], t]) for t in ids)
+    return out
+
+
+def test_batchify_amr_from_preprocessed_items(tmp_path):
+    """gtos_amd.data.batchify_amr rebuilds each graph from the length-1 paths of the preprocessed item and must give every
+    pair the reference's SET of shortest label paths (eval: all of them, K=3 here; train: one of them)."""
+    import json
+    from conftest import GOLDEN
+    from gtos_amd.data import batchify_amr
+    g = np.load(os.path.join(GOLDEN, "host_amr_smatch.npz"))
+    meta = json.load(open(os.path.join(GOLDEN, "host_amr_smatch_items.json")))
+    vocabs = _amr_vocabs(tmp_path, meta["relation_vocab"])
+    items = [dict(it, token=["a"]) for it in meta["items"]]
+    want = _paths_of(torch.from_numpy(g["relation"]), torch.from_numpy(g["relation_bank"]), torch.from_numpy(g["relation_length"]))
+    ev = batchify_amr(items, vocabs, train=False)
+    assert tuple(ev["relation"].shape) == tuple(g["relation"].shape)
+    assert _paths_of(ev["relation"], ev["relation_bank"], ev["relation_length"]) == want
+    assert torch.equal(ev["concept_depth"], torch.from_numpy(g["concept_depth"]))
+    assert max(len(v) for v in want.values()) == 3                      # the re-entrant graphs have 3-way ties
+    # the eval bank starts with <PAD>, <CLS>, <rCLS>, <SELF> (data.py:186-189), the train bank with <CLS>, <rCLS>, <SELF>
+    rv = vocabs['relation']
+    assert ev["relation_bank"][0, :4].tolist() == [rv.padding_idx, rv.token2idx('<CLS>'), rv.token2idx('<rCLS>'), rv.token2idx('<SELF>')]
+    seen = {}
+    for seed in range(12):
+        tr = batchify_amr(items, vocabs, train=True, seed=seed)
+        assert tr["relation"].dim() == 3
+        assert tr["relation_bank"][0, :3].tolist() == [rv.token2idx('<CLS>'), rv.token2idx('<rCLS>'), rv.token2idx('<SELF>')]
+        got = _paths_of(tr["relation"], tr["relation_bank"], tr["relation_length"])
+        for key, alts in want.items():
+            a, c, b = key
+            if a == 0 or c == 0:
+                continue                                                 # <CLS> row / column: eval and train banks differ by <PAD>
+            if not alts:
+                assert got[key] == []                                    # padding beyond this graph's nodes
+                continue
+            assert len(got[key]) == 1 and got[key][0] in alts, key
+            seen.setdefault(key, set()).add(got[key][0])
+    multi = [k for k, v in want.items() if len(v) > 1 and k[0] and k[1]]
+    assert multi and all(len(seen[k]) > 1 for k in multi)                # over 12 seeds every tie is broken both ways
