@@ -139,7 +139,15 @@ class TokenEncoder(nn.Module):
     def forward(self, token_input, char_input):
         seq_len, bsz, _ = char_input.size()
         cd = self.compute_dtype
-        char_repr = self.char_embed(char_input.view(seq_len * bsz, -1)).to(cd)
+        ce = self.char_embed
+        cdim = ce.weight.shape[1]
+        if cdim % 8 == 0 and ce.weight.shape[0] * cdim * 4 <= 48 * 1024:
+            # small table: gather kernel forward, LDS-accumulated scatter backward (torch's sort-based embedding
+            # backward costs more than the whole character CNN here)
+            char_repr = ops.embed_rows(char_input.reshape(-1), ce.weight, cdim, 0.0, cd, pad_idx=ce.padding_idx)
+            char_repr = char_repr.view(seq_len * bsz, -1, cdim)
+        else:
+            char_repr = ce(char_input.view(seq_len * bsz, -1)).to(cd)
         char_repr = self.char2token(char_repr).view(seq_len, bsz, -1)
         token_repr = self.token_embed(token_input).to(cd)
         token = F.dropout(torch.cat([char_repr, token_repr], -1), p=self.dropout, training=self.training)

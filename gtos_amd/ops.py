@@ -437,7 +437,7 @@ class EmbedRowsFn(torch.autograd.Function):
     RelationEncoder (generator/encoder.py:99-100).  Backward scatters into the (small) table through LDS."""
 
     @staticmethod
-    def forward(ctx, tokens, table, dim_pad, p_drop, dtype):
+    def forward(ctx, tokens, table, dim_pad, p_drop, dtype, pad_idx=None):
         require_cuda(tokens, table)
         tokens = tokens.contiguous()
         n, (V, dim) = tokens.numel(), table.shape
@@ -445,13 +445,13 @@ class EmbedRowsFn(torch.autograd.Function):
         seed = next_seed() if p_drop > 0 else 0
         call("gtos_embed_rows_fwd", dt(out), n, dim, dim_pad, ptr(tokens), ptr(table), ptr(out), float(p_drop), seed, stream())
         ctx.save_for_backward(tokens)
-        ctx.cfg = (table, dim_pad, p_drop, seed)
+        ctx.cfg = (table, dim_pad, p_drop, seed, pad_idx)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         tokens, = ctx.saved_tensors
-        table, dim_pad, p_drop, seed = ctx.cfg
+        table, dim_pad, p_drop, seed, pad_idx = ctx.cfg
         dout = dout.contiguous()
         V, dim = table.shape
         tgt = _grad_target(table)
@@ -460,11 +460,13 @@ class EmbedRowsFn(torch.autograd.Function):
             tgt = dtab = torch.zeros(table.shape, dtype=torch.float32, device=table.device)
         call("gtos_embed_rows_bwd", dt(dout), tokens.numel(), V, dim, dim_pad, ptr(tokens), ptr(dout), ptr(tgt),
              float(p_drop), seed, stream())
-        return None, dtab, None, None, None
+        if pad_idx is not None:
+            tgt[pad_idx].zero_()          # nn.Embedding(padding_idx=...): the padding row takes no gradient
+        return None, dtab, None, None, None, None
 
 
-def embed_rows(tokens, table, dim_pad, p_drop, dtype):
-    return EmbedRowsFn.apply(tokens, table, dim_pad, float(p_drop), dtype)
+def embed_rows(tokens, table, dim_pad, p_drop, dtype, pad_idx=None):
+    return EmbedRowsFn.apply(tokens, table, dim_pad, float(p_drop), dtype, pad_idx)
 
 
 class PermuteRowsFn(torch.autograd.Function):
