@@ -28,6 +28,18 @@ N_BIAS_PARTIALS = 1024
 # Forward time step on bf16: "x" = input AND recurrent gate products + cell in ONE kernel (gtos_gru_step_fwd),
 # "h" = recurrent product + cell fused, input gates by one big GEMM, "off" = GEMM + cell kernel per step (the fp32 path).
 FUSE = os.environ.get("GTOS_GRU_FUSE", "x")
+# Backward: run the weight-gradient GEMMs of one direction on a second HIP stream while the (memory-bound) BPTT steps of
+# the next direction occupy the main stream: the step kernels are limited to 2 waves per SIMD by registers, an MFMA GEMM
+# wave fits beside them.
+SIDE_STREAM = os.environ.get("GTOS_GRU_SIDE", "1") != "0"
+_SIDE = {}
+
+
+def _side_stream(dev):
+    s = _SIDE.get(dev)
+    if s is None:
+        s = _SIDE[dev] = torch.cuda.Stream(device=dev)
+    return s
 
 
 def _step_fwd(A, hs, x, xg, h_in, wi, b_ih, wh, b_hh, h_out, n_out, h_fin, gates, y, y_off_elems, ldy, p, seed, drop_base):
@@ -120,6 +132,7 @@ class BiGRUFinalFn(torch.autograd.Function):
         d_out = d_out.contiguous()
         dev = d_out.device
         grads = [None] * len(weights)
+        used_side = False
         dY = None                                   # gradient w.r.t. this layer's (dropped) output [N, 2hs]
         for l in range(num_layers - 1, -1, -1):
             inp, seed, pl, layer_saved = saved[l]
@@ -165,34 +178,52 @@ class BiGRUFinalFn(torch.autograd.Function):
                                   dh, dxg[off:off + A], dhg[off:off + A], pl, seed, off * 2 * hs + direction * hs, bpart)
                         gemm(dhg[off:off + A], wh_t, trans_b=True, out=dh[:A], accumulate=True)   # dh += d(hg) W_hh
                     w_jobs = ((w_hh, dhg, hprev, 1, slice(0, 3 * hs)), (w_ih, dxg, inp, 0, slice(0, 3 * hs)))
-                # parameter gradients over all steps at once
-                for (wt, dyv, xin, slot, rows) in w_jobs:
-                    if wt.requires_grad:
-                        tgt = _grad_target(wt)
-                        if tgt is None:
-                            if grads[base + slot] is None:
-                                grads[base + slot] = torch.zeros(wt.shape, dtype=torch.float32, device=dev)
-                            tgt = grads[base + slot]
-                        nrow = rows.stop - rows.start
-                        gemm(dyv, xin, trans_a=True, out=tgt[rows], accumulate=True, splitk=_splitk(nrow, wt.shape[1], N))
-                bsum = bpart.sum(0) if bpart is not None else None     # [4*hs]: d(r), d(z), d(n_x), d(n_h)
+                # parameter gradients over all steps at once -- on the side stream (see SIDE_STREAM), after this
+                # direction's steps; gradient tensors that are not views of the flat bucket are allocated on the main
+                # stream first so that the caching allocator ties them to the stream that will consume them
+                for (wt, _, _, slot, _) in w_jobs:
+                    if wt.requires_grad and _grad_target(wt) is None and grads[base + slot] is None:
+                        grads[base + slot] = torch.zeros(wt.shape, dtype=torch.float32, device=dev)
                 for (bt, slot) in ((b_hh, 3), (b_ih, 2)):
-                    if bt.requires_grad:
-                        tgt = _grad_target(bt)
-                        if tgt is None:
-                            tgt = grads[base + slot] = torch.zeros(bt.shape, dtype=torch.float32, device=dev)
-                        if bsum is not None:
-                            tgt[:2 * hs] += bsum[:2 * hs]
-                            tgt[2 * hs:] += bsum[2 * hs:3 * hs] if slot == 2 else bsum[3 * hs:]
-                        else:
-                            dyv = dhg if slot == 3 else dxg
-                            call("gtos_colsum", dt(dyv), N, 3 * hs, 3 * hs, ptr(dyv), ptr(tgt), stream())
+                    if bt.requires_grad and _grad_target(bt) is None:
+                        grads[base + slot] = torch.zeros(bt.shape, dtype=torch.float32, device=dev)
+                main = torch.cuda.current_stream(dev)
+                side = _side_stream(dev) if (SIDE_STREAM and fused) else main
+                if side is not main:
+                    side.wait_stream(main)
+                    # locals that die (or are rebound) before the side stream is done with them: tell the allocator
+                    for t_ in (d4, bpart):
+                        if t_ is not None:
+                            t_.record_stream(side)
+                with torch.cuda.stream(side):
+                    for (wt, dyv, xin, slot, rows) in w_jobs:
+                        if wt.requires_grad:
+                            tgt = _grad_target(wt)
+                            if tgt is None:
+                                tgt = grads[base + slot]
+                            nrow = rows.stop - rows.start
+                            gemm(dyv, xin, trans_a=True, out=tgt[rows], accumulate=True, splitk=_splitk(nrow, wt.shape[1], N))
+                    bsum = bpart.sum(0) if bpart is not None else None     # [4*hs]: d(r), d(z), d(n_x), d(n_h)
+                    for (bt, slot) in ((b_hh, 3), (b_ih, 2)):
+                        if bt.requires_grad:
+                            tgt = _grad_target(bt)
+                            if tgt is None:
+                                tgt = grads[base + slot]
+                            if bsum is not None:
+                                tgt[:2 * hs] += bsum[:2 * hs]
+                                tgt[2 * hs:] += bsum[2 * hs:3 * hs] if slot == 2 else bsum[3 * hs:]
+                            else:
+                                dyv = dhg if slot == 3 else dxg
+                                call("gtos_colsum", dt(dyv), N, 3 * hs, 3 * hs, ptr(dyv), ptr(tgt), stream())
+                used_side = used_side or side is not main
                 if l > 0 or ctx.needs_input_grad[0]:
                     if d_inp is None:
                         d_inp = gemm(dxg, wi_t, trans_b=True)
                     else:
                         gemm(dxg, wi_t, trans_b=True, out=d_inp, accumulate=True)
             dY = d_inp
+        if used_side:       # everything the side stream produced (and read) is complete before the caller goes on
+            torch.cuda.current_stream(dev).wait_stream(_side_stream(dev))
         return (dY if ctx.needs_input_grad[0] else None, None, None, None, None) + tuple(grads)
 
 

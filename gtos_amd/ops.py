@@ -71,10 +71,12 @@ WORKSPACE_BYTES = 256 << 20
 
 
 def _workspace(device):
-    """Split-K partial-tile workspace (one per device, stream-ordered reuse)."""
-    ws = _WS.get(device)
+    """Split-K partial-tile workspace: one per (device, stream) -- launches on one stream reuse it in order, launches on
+    different streams (the GRU weight gradients run beside the BPTT steps) must not share it."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WS.get(key)
     if ws is None:
-        ws = _WS[device] = torch.empty(WORKSPACE_BYTES // 4, dtype=torch.float32, device=device)
+        ws = _WS[key] = torch.empty(WORKSPACE_BYTES // 4, dtype=torch.float32, device=device)
     return ws
 
 
