@@ -59,7 +59,9 @@ class RelationMultiheadAttention(nn.Module):
             fact = relation
             bank = relation.bank if relation.bank.dtype == cd else relation.bank.to(cd)
             group = relation.grad_group if bank is relation.bank else None
-            rel = ops.linear(bank, self.relation_in_proj.weight, group=group)               # [R, 2d]
+            rel = relation.take_projection(self)                                           # prefetched on the side stream?
+            if rel is None:
+                rel = ops.linear(bank, self.relation_in_proj.weight, group=group)           # [R, 2d]
         else:
             fact = None
             rel = ops.linear(relation.to(cd), self.relation_in_proj.weight)               # [n, n, B, 2d]
@@ -111,6 +113,8 @@ class GraphTransformer(nn.Module):
             self.layers.append(GraphTransformerLayer(embed_dim, ff_embed_dim, num_heads, dropout, weights_dropout))
 
     def forward(self, x, relation, kv=None, self_padding_mask=None, self_attn_mask=None):
+        if isinstance(relation, FactoredRelation):
+            relation.prefetch_projections([layer.self_attn for layer in self.layers])
         for layer in self.layers:
             x, _ = layer(x, relation, kv, self_padding_mask, self_attn_mask)
         return x

@@ -14,7 +14,7 @@ import torch
 
 from . import _lib
 from ._lib import call, dt, ptr, stream
-from .ops import gemm, compute_weight, next_seed, weight_t, _grad_target, _splitk
+from .ops import gemm, compute_weight, next_seed, weight_t, _grad_target, _splitk, side_stream as _side_stream
 
 
 def _cell_fwd(A, hs, xg, hg, h, y, y_off_elems, ldy, hprev, gates, p, seed, drop_base):
@@ -32,14 +32,6 @@ FUSE = os.environ.get("GTOS_GRU_FUSE", "x")
 # the next direction occupy the main stream: the step kernels are limited to 2 waves per SIMD by registers, an MFMA GEMM
 # wave fits beside them.
 SIDE_STREAM = os.environ.get("GTOS_GRU_SIDE", "1") != "0"
-_SIDE = {}
-
-
-def _side_stream(dev):
-    s = _SIDE.get(dev)
-    if s is None:
-        s = _SIDE[dev] = torch.cuda.Stream(device=dev)
-    return s
 
 
 def _step_fwd(A, hs, x, xg, h_in, wi, b_ih, wh, b_hh, h_out, n_out, h_fin, gates, y, y_off_elems, ldy, p, seed, drop_base):

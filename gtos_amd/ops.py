@@ -80,6 +80,21 @@ def _workspace(device):
     return ws
 
 
+_SIDE = {}
+# Opt-in (GTOS_PROJ_SIDE=1): prefetch every layer's relation projection on the side stream.  Measured at C2: 104.8 ->
+# 102.7 ms/step, but the attention kernels then share the chip with a GEMM and their own launches stretch from 259 to
+# 595 us, which would make the in-step roofline figure of bench.py meaningless -- so it is off by default.
+PROJ_SIDE = __import__("os").environ.get("GTOS_PROJ_SIDE", "0") == "1"
+
+
+def side_stream(device):
+    """One auxiliary HIP stream per device for work that is independent of the main chain (see gru.py, FactoredRelation)."""
+    s = _SIDE.get(device)
+    if s is None:
+        s = _SIDE[device] = torch.cuda.Stream(device=device)
+    return s
+
+
 def gemm(a, b, trans_a=False, trans_b=False, out=None, bias=None, relu=False, p_drop=0.0, seed=0,
          accumulate=False, out_dtype=None, splitk=1):
     """out[M,N] (+)= act(op(a) @ op(b) + bias).  a,b share a dtype (fp32 or bf16)."""
@@ -343,6 +358,39 @@ class FactoredRelation:
         self.chunk_count, self.chunk_slot = c_count[perm], c_slot[perm]
         self.heavy_types = heavy_types
         self.nchunks = int(ctype.numel())
+        self._proj = {}
+
+    def prefetch_projections(self, attns):
+        """relation_in_proj(bank) of EVERY layer depends only on the bank, not on the layer chain: compute them on the side
+        stream, ahead of the layers, so the MFMA GEMMs run beside the (HBM-bound) attention kernels and the small
+        per-layer kernels of the main stream.  autograd runs a node's backward on the stream of its forward, so the
+        projection's dX / dW GEMMs overlap the main chain in backward as well."""
+        self._proj = {}
+        if not (PROJ_SIDE and self.bank.is_cuda and torch.is_grad_enabled()):
+            return
+        dev = self.bank.device
+        main, side = torch.cuda.current_stream(dev), side_stream(dev)
+        if any(m.compute_dtype != self.bank.dtype for m in attns):
+            return
+        side.wait_stream(main)
+        self.bank.record_stream(side)
+        with torch.cuda.stream(side):
+            for m in attns:
+                y = linear(self.bank, m.relation_in_proj.weight, group=self.grad_group)
+                ev = torch.cuda.Event()
+                ev.record(side)
+                self._proj[id(m)] = (y, ev)
+
+    def take_projection(self, attn):
+        """The prefetched [R,2d] projection for this attention module (the main stream is made to wait for it), or None."""
+        hit = self._proj.pop(id(attn), None)
+        if hit is None:
+            return None
+        y, ev = hit
+        main = torch.cuda.current_stream(y.device)
+        main.wait_event(ev)
+        y.record_stream(main)
+        return y
 
 
 class RelAttnFn(torch.autograd.Function):
