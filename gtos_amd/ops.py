@@ -85,6 +85,8 @@ _SIDE = {}
 # 102.7 ms/step, but the attention kernels then share the chip with a GEMM and their own launches stretch from 259 to
 # 595 us, which would make the in-step roofline figure of bench.py meaningless -- so it is off by default.
 PROJ_SIDE = __import__("os").environ.get("GTOS_PROJ_SIDE", "0") == "1"
+# Backward of the relation projections on the side stream (see LinearFn.backward): overlaps only backward kernels.
+BWD_SIDE = __import__("os").environ.get("GTOS_BWD_SIDE", "1") != "0"
 
 
 def side_stream(device):
@@ -235,6 +237,26 @@ class LinearFn(torch.autograd.Function):
             else:
                 raise _lib.GtosHipError("dropout without relu is not fused in LinearFn")
         dx = dw = db = None
+        # A grouped projection (relation_in_proj of one layer) whose weight gradient lands in the flat bucket hands
+        # nothing to autograd until the LAST member of its group: its two GEMMs can run on the side stream, beside the
+        # attention-backward kernels of the main chain.  The last member makes the main stream wait for all of them.
+        offload = (BWD_SIDE and group is not None and bias is None and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
+                   and _grad_target(weight) is not None)
+        if offload:
+            dev = dy2.device
+            main, side = torch.cuda.current_stream(dev), side_stream(dev)
+            side.wait_stream(main)
+            dy2.record_stream(side)
+            with torch.cuda.stream(side):
+                dx = group.add(dy2, wt, shp)
+                tgt = _grad_target(weight)
+                if rows is not None:
+                    tgt = tgt[rows[0]:rows[1]]
+                gemm(dy2, x2, trans_a=True, out=tgt, accumulate=True, splitk=_splitk(n_out, x2.shape[1], dy2.shape[0]))
+            if dx is not None:
+                main.wait_stream(side)
+                dx.record_stream(main)
+            return dx, None, None, None, None, None, None
         if ctx.needs_input_grad[0]:
             dx = group.add(dy2, wt, shp) if group is not None else gemm(dy2, wt, trans_b=True).view(shp)
         if ctx.needs_input_grad[1]:

@@ -631,3 +631,48 @@ def test_trainer_two_steps_reduce_loss_and_keep_mirror_in_sync():
     assert float((tr.flat.param - before).abs().max()) > 0
     torch.testing.assert_close(tr.flat.mirror.float(), tr.flat.param, rtol=1e-2, atol=1e-3)
     assert float(tr.flat.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_side_stream_paths_give_the_same_gradients(dtype, monkeypatch):
+    """The flat gradient bucket after one backward with the auxiliary-stream paths on (GRU weight gradients and the
+    relation projections' backward GEMMs beside the main chain) equals the single-stream result: same kernels, same
+    reduction order, only the stream differs -- and against the per-parameter oracle gradients in fp32."""
+    from gtos_amd import synth, ops, gru
+    from gtos_amd.config import build_generator
+    from gtos_amd.flat import FlatParams
+    from gtos_amd.generator import Generator
+    batch, _ = synth.make_config_batch("C1")
+    batch = {k: v.to(dev()) for k, v in batch.items()}
+
+    def run(side):
+        monkeypatch.setattr(ops, "BWD_SIDE", side)
+        monkeypatch.setattr(gru, "SIDE_STREAM", side)
+        m = build_generator(Generator, "C1", dev(), dropout=0.0).to(dev())
+        m.set_compute_dtype(dtype)
+        m.train()
+        flat = FlatParams(m, mirror_dtype=dtype)
+        loss = m(batch)
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss.detach()), flat.grad.clone(), m, flat
+
+    l1, g1, m1, f1 = run(True)
+    l0, g0, _, _ = run(False)
+    assert abs(l1 - l0) < 1e-6
+    assert float(g1.abs().max()) > 0
+    # not bitwise: a few reductions use fp32 atomics (embedding scatter, bias partial sums, multi-chunk relation types)
+    torch.testing.assert_close(g1, g0, rtol=1e-4, atol=1e-6 if dtype == torch.float32 else 1e-4)
+    if dtype == torch.float32:
+        from oracle import gtos_oracle as O
+        from gtos_amd.config import generator_args
+        cfg = synth.CONFIGS["C1"]
+        torch.manual_seed(19940117)
+        ref = O.Generator({k: O.VocabSpec(v, 0) for k, v in synth.DEFAULT_VOCAB.items()}, depth_size=32,
+                          **dict(generator_args(cfg), dropout=0.0))
+        ref.load_state_dict({k: v.detach().cpu() for k, v in m1.state_dict().items()})
+        ref.train()
+        cpu_batch = {k: v.cpu() for k, v in batch.items()}
+        ref(cpu_batch).backward()
+        for (k, p), (_, q) in zip(m1.named_parameters(), ref.named_parameters()):
+            torch.testing.assert_close(p.grad.cpu(), q.grad, msg=lambda s_, k=k: "%s: %s" % (k, s_), **GRAD)
