@@ -11,6 +11,7 @@ except for ``bias`` / ``layer_norm`` parameters (train.py:123-132), lr = d^-0.5 
 import torch
 
 from ._lib import call, ptr, stream
+from . import ops as _ops
 
 ALIGN = 8   # elements; keeps every view 32-byte (fp32) / 16-byte (bf16 mirror) aligned for vector loads
 
@@ -58,6 +59,7 @@ class FlatParams:
         self.steps = 0
 
     def zero_grad(self):
+        _ops.join_side()
         self.grad.zero_()
 
     def grad_norm(self, gscale=1.0):
@@ -66,6 +68,7 @@ class FlatParams:
         return self.sqnorm.sqrt() * gscale
 
     def step(self, lr, gscale=1.0, max_norm=1.0):
+        _ops.join_side()                   # deferred side-stream gradient work must have landed in self.grad
         """gscale = 1/world_size after a SUM all-reduce.  Clips by global norm then applies Adam."""
         self.sqnorm.zero_()
         call("gtos_sqnorm", self.total, ptr(self.grad), ptr(self.sqnorm), stream())

@@ -14,7 +14,7 @@ import torch
 
 from . import _lib
 from ._lib import call, dt, ptr, stream
-from .ops import gemm, compute_weight, next_seed, weight_t, _grad_target, _splitk, side_stream as _side_stream
+from .ops import gemm, compute_weight, next_seed, weight_t, _grad_target, _splitk, side_stream as _side_stream, defer_side_join
 
 
 def _cell_fwd(A, hs, xg, hg, h, y, y_off_elems, ldy, hprev, gates, p, seed, drop_base):
@@ -184,7 +184,7 @@ class BiGRUFinalFn(torch.autograd.Function):
                 if side is not main:
                     side.wait_stream(main)
                     # locals that die (or are rebound) before the side stream is done with them: tell the allocator
-                    for t_ in (d4, bpart):
+                    for t_ in (d4, bpart, hprev, inp):
                         if t_ is not None:
                             t_.record_stream(side)
                 with torch.cuda.stream(side):
@@ -214,8 +214,13 @@ class BiGRUFinalFn(torch.autograd.Function):
                     else:
                         gemm(dxg, wi_t, trans_b=True, out=d_inp, accumulate=True)
             dY = d_inp
-        if used_side:       # everything the side stream produced (and read) is complete before the caller goes on
-            torch.cuda.current_stream(dev).wait_stream(_side_stream(dev))
+        if used_side:
+            if all(gr is None for gr in grads):
+                # every gradient of this function went into the flat bucket: nobody reads the side stream's results before
+                # the optimizer / all-reduce, which join it (ops.join_side) -- the remaining GEMMs overlap what follows
+                defer_side_join(dev)
+            else:
+                torch.cuda.current_stream(dev).wait_stream(_side_stream(dev))
         return (dY if ctx.needs_input_grad[0] else None, None, None, None, None) + tuple(grads)
 
 

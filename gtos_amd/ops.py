@@ -97,6 +97,23 @@ def side_stream(device):
     return s
 
 
+_PENDING_SIDE = set()
+
+
+def defer_side_join(device):
+    """The side stream still holds work whose only consumers are the flat gradient bucket's readers: join_side() must run
+    before the bucket is read (Trainer.step / FlatParams.step do it)."""
+    _PENDING_SIDE.add(device)
+
+
+def join_side(device=None):
+    """Make the current stream wait for deferred side-stream work (no-op when there is none)."""
+    for dev in list(_PENDING_SIDE):
+        if device is None or dev == device:
+            torch.cuda.current_stream(dev).wait_stream(side_stream(dev))
+            _PENDING_SIDE.discard(dev)
+
+
 def gemm(a, b, trans_a=False, trans_b=False, out=None, bias=None, relu=False, p_drop=0.0, seed=0,
          accumulate=False, out_dtype=None, splitk=1):
     """out[M,N] (+)= act(op(a) @ op(b) + bias).  a,b share a dtype (fp32 or bf16)."""

@@ -9,6 +9,7 @@ Counterpart of the hot loop of /root/reference/generator/train.py:136-154: forwa
 import torch
 import torch.distributed as dist
 
+from . import ops
 from .flat import FlatParams, inverse_sqrt_lr
 
 
@@ -21,6 +22,7 @@ class Trainer:
         self.batches_acm, self.loss_acm, self.discarded = 0, 0.0, 0
 
     def all_reduce_grads(self):
+        ops.join_side()                    # deferred side-stream gradient GEMMs (gru.py) land before the bucket is read
         if self.world_size > 1:
             dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM)
 
