@@ -1,4 +1,7 @@
-// Host-side graph -> relation tensors, C++17, one thread per graph.
+// Host-side graph -> relation tensors, C++17.  Three phases: (a) per graph, in parallel: BFS
+// order, all-pairs shortest label paths, and the graph's distinct paths in first-seen order; (b) serial: merge the
+// per-graph lists, in graph order, into the batch-wide type table (this is what fixes the reference's type numbering);
+// (c) in parallel over the rows of relation[a][c][b][k]: translate and write contiguous memory.
 // See include/gtos_host.h for the contract and the reference lines this replaces.  Pure integer work.
 #include "../../include/gtos_host.h"
 
@@ -6,7 +9,6 @@
 #include <atomic>
 #include <cstring>
 #include <thread>
-#include <unordered_map>
 #include <vector>
 
 namespace {
@@ -20,6 +22,26 @@ struct Graph {
 struct PairPaths {                                   // per graph: for every (i,j) in BFS-position space, its packed paths
     std::vector<uint32_t> off;                       // [n*n+1]
     std::vector<uint64_t> keys;
+    std::vector<uint32_t> lid;                       // per key: index into uniq
+    std::vector<uint64_t> uniq;                      // this graph's distinct keys in first-seen (i, j, alternative) order
+    std::vector<int32_t> gid;                        // per uniq entry: batch-wide type id (phase b)
+};
+
+// open-addressing map uint64 -> int (linear probing, 2x capacity); value 0 marks an empty slot
+struct FlatMap {
+    std::vector<uint64_t> key;
+    std::vector<int32_t> val;
+    size_t mask = 0;
+    void init(size_t n) { size_t cap = 16; while (cap < 2 * n + 2) cap <<= 1; key.assign(cap, 0); val.assign(cap, 0); mask = cap - 1; }
+    static inline size_t hash(uint64_t k) { k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33; return (size_t)k; }
+    inline int find(uint64_t k) const {
+        for (size_t p = hash(k) & mask;; p = (p + 1) & mask) { if (!val[p]) return -1; if (key[p] == k) return val[p] - 1; }
+    }
+    inline void insert(uint64_t k, int id) {                          // k must be absent
+        size_t p = hash(k) & mask;
+        while (val[p]) p = (p + 1) & mask;
+        key[p] = k; val[p] = id + 1;
+    }
 };
 
 inline uint64_t splitmix(uint64_t& s) {
@@ -172,14 +194,28 @@ extern "C" gtos_relbatch* gtos_relbatch_build(int B, const int* n_nodes, const i
             if (g >= B) return;
             if (!build_graph(graphs[g], n_nodes[g], roots[g], edge_off[g], edge_off[g + 1], e_src, e_dst, e_label)) { bad = 1; continue; }
             graph_paths(graphs[g], path_mode, seed, g, max_len, self_key, tl_key, pp[g]);
+            // phase (a), second half: this graph's distinct keys, in the order the reference would first meet them
+            PairPaths& P = pp[g];
+            FlatMap local;
+            local.init(P.keys.size());
+            P.lid.resize(P.keys.size());
+            P.uniq.clear();
+            for (size_t q = 0; q < P.keys.size(); ++q) {
+                int id = local.find(P.keys[q]);
+                if (id < 0) { id = (int)P.uniq.size(); local.insert(P.keys[q], id); P.uniq.push_back(P.keys[q]); }
+                P.lid[q] = (uint32_t)id;
+            }
         }
     };
     if (n_threads < 1) n_threads = (int)std::thread::hardware_concurrency();
     n_threads = std::max(1, std::min(n_threads, B));
-    std::vector<std::thread> pool;
-    for (int t = 1; t < n_threads; ++t) pool.emplace_back(work);
-    work();
-    for (auto& t : pool) t.join();
+    auto run_parallel = [&](auto&& fn) {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < n_threads; ++t) pool.emplace_back(fn);
+        fn();
+        for (auto& t : pool) t.join();
+    };
+    run_parallel(work);
     if (bad) return nullptr;
 
     auto* h = new gtos_relbatch();
@@ -197,14 +233,24 @@ extern "C" gtos_relbatch* gtos_relbatch_build(int B, const int* n_nodes, const i
                 K = std::max(K, (int)(pp[g].off[k + 1] - b0));
             }
     h->K = K;
-    // type ids in the reference's first-seen order: graphs in order, source i, target j (data.py:140-162 / :186-213)
-    std::unordered_map<uint64_t, int> types;
+    // phase (b): type ids in the reference's first-seen order -- graphs in order, source i, target j, alternative
+    // (data.py:140-162 / :186-213); the per-graph lists are already in that order, so merging them in graph order is enough
+    size_t tot_uniq = 8;
+    for (int g = 0; g < B; ++g) tot_uniq += pp[g].uniq.size();
+    FlatMap types;
+    types.init(tot_uniq);
     std::vector<uint64_t> type_key;
-    auto intern = [&](uint64_t key) { auto it = types.find(key); if (it != types.end()) return it->second;
-                                      const int id = (int)type_key.size(); types.emplace(key, id); type_key.push_back(key); return id; };
+    type_key.reserve(tot_uniq);
+    auto intern = [&](uint64_t key) { int id = types.find(key); if (id >= 0) return id;
+                                      id = (int)type_key.size(); types.insert(key, id); type_key.push_back(key); return id; };
     int t_cls, t_rcls, t_self;
     if (all) { intern((uint64_t)pad_id); t_cls = intern((uint64_t)cls_id); t_rcls = intern((uint64_t)rcls_id); t_self = intern(self_key); }
     else { t_cls = intern((uint64_t)cls_id); t_rcls = intern((uint64_t)rcls_id); t_self = intern(self_key); }
+    for (int g = 0; g < B; ++g) {
+        PairPaths& P = pp[g];
+        P.gid.resize(P.uniq.size());
+        for (size_t u = 0; u < P.uniq.size(); ++u) P.gid[u] = intern(P.uniq[u]);
+    }
     h->relation.assign((size_t)n * n * B * K, 0);
     h->order.assign((size_t)B * (n - 1), -1);
     h->depth.assign((size_t)B * (n - 1), 0);
@@ -215,14 +261,31 @@ extern "C" gtos_relbatch* gtos_relbatch_build(int B, const int* n_nodes, const i
         for (int p = 0; p < ng; ++p) { h->order[(size_t)b * (n - 1) + p] = g.order[p]; h->depth[(size_t)b * (n - 1) + p] = g.depth[p]; }
         rel_at(0, 0, b, 0) = t_self;                                   // brs[0] = [<SELF>, <CLS>...], brs[c][0] = <rCLS>
         for (int a = 1; a <= ng; ++a) { rel_at(a, 0, b, 0) = t_cls; rel_at(0, a, b, 0) = t_rcls; }
-        for (int i = 0; i < ng; ++i)
-            for (int j = 0; j < ng; ++j) {
-                const size_t k = (size_t)i * ng + j;
-                const uint32_t b0 = k ? pp[b].off[k] : 0u, b1 = pp[b].off[k + 1];
-                // eval keeps only the first alternative when it is <SELF>/<TL>; those pairs hold exactly one key already
-                for (uint32_t q = b0; q < b1; ++q) rel_at(j + 1, i + 1, b, (int)(q - b0)) = intern(pp[b].keys[q]);
-            }
     }
+    // phase (c): relation[a = j+1][c = i+1][b][k] = type of the k-th path from BFS position i to j of graph b.  A thread owns
+    // whole rows a, i.e. contiguous memory (no false sharing); eval keeps only the first alternative when it is
+    // <SELF>/<TL>, and those pairs hold exactly one key already.
+    std::atomic<int> next_row(1);
+    auto fill = [&]() {
+        for (;;) {
+            const int a = next_row.fetch_add(1);
+            if (a >= n) return;
+            const int j = a - 1;
+            for (int c = 1; c < n; ++c) {
+                const int i = c - 1;
+                int64_t* dst = &h->relation[(((size_t)a * n + c) * B) * K];
+                for (int b = 0; b < B; ++b) {
+                    const int ng = graphs[b].n;
+                    if (i >= ng || j >= ng) continue;
+                    const PairPaths& P = pp[b];
+                    const size_t k = (size_t)i * ng + j;
+                    const uint32_t b0 = k ? P.off[k] : 0u, b1 = P.off[k + 1];
+                    for (uint32_t q = b0; q < b1; ++q) dst[(size_t)b * K + (q - b0)] = P.gid[P.lid[q]];
+                }
+            }
+        }
+    };
+    run_parallel(fill);
     const int R = (int)type_key.size();
     h->R = R;
     int L = 1;
