@@ -32,6 +32,7 @@ FUSE = os.environ.get("GTOS_GRU_FUSE", "x")
 # the next direction occupy the main stream: the step kernels are limited to 2 waves per SIMD by registers, an MFMA GEMM
 # wave fits beside them.
 SIDE_STREAM = os.environ.get("GTOS_GRU_SIDE", "1") != "0"
+SIDE_MIN_ROWS = 200000          # below this the GEMMs are launch-bound and the stream hand-over costs more than it hides
 
 
 def _step_fwd(A, hs, x, xg, h_in, wi, b_ih, wh, b_hh, h_out, n_out, h_fin, gates, y, y_off_elems, ldy, p, seed, drop_base):
@@ -180,7 +181,7 @@ class BiGRUFinalFn(torch.autograd.Function):
                     if bt.requires_grad and _grad_target(bt) is None:
                         grads[base + slot] = torch.zeros(bt.shape, dtype=torch.float32, device=dev)
                 main = torch.cuda.current_stream(dev)
-                side = _side_stream(dev) if (SIDE_STREAM and fused) else main
+                side = _side_stream(dev) if (SIDE_STREAM and fused and N >= SIDE_MIN_ROWS) else main
                 if side is not main:
                     side.wait_stream(main)
                     # locals that die (or are rebound) before the side stream is done with them: tell the allocator

@@ -87,6 +87,7 @@ _SIDE = {}
 PROJ_SIDE = __import__("os").environ.get("GTOS_PROJ_SIDE", "0") == "1"
 # Backward of the relation projections on the side stream (see LinearFn.backward): overlaps only backward kernels.
 BWD_SIDE = __import__("os").environ.get("GTOS_BWD_SIDE", "1") != "0"
+BWD_SIDE_MIN_ROWS = 100000
 
 
 def side_stream(device):
@@ -258,7 +259,7 @@ class LinearFn(torch.autograd.Function):
         # nothing to autograd until the LAST member of its group: its two GEMMs can run on the side stream, beside the
         # attention-backward kernels of the main chain.  The last member makes the main stream wait for all of them.
         offload = (BWD_SIDE and group is not None and bias is None and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
-                   and _grad_target(weight) is not None)
+                   and _grad_target(weight) is not None and dy2.shape[0] >= BWD_SIDE_MIN_ROWS)   # small problems are launch-bound
         if offload:
             dev = dy2.device
             main, side = torch.cuda.current_stream(dev), side_stream(dev)
