@@ -130,8 +130,23 @@ class Generator(nn.Module):
         return beams
 
     def prepare_incremental_input(self, step_seq):
-        token = lists_to_tensor(step_seq, self.vocabs['token'])
-        token_char = strings_to_char_tensor(step_seq, self.vocabs['token_char'])
+        """step_seq: one single-token list per live hypothesis (generator.py:112-117).  Token id and character row of a
+        string are cached: beam search feeds the same few thousand strings over and over."""
+        if any(len(x) != 1 for x in step_seq):
+            token = lists_to_tensor(step_seq, self.vocabs['token'])
+            token_char = strings_to_char_tensor(step_seq, self.vocabs['token_char'])
+            return token.to(self.device), token_char.to(self.device)
+        cache = self.__dict__.setdefault('_step_input_cache', {})
+        ids, rows = [], []
+        for (w,) in step_seq:
+            hit = cache.get(w)
+            if hit is None:
+                hit = (self.vocabs['token'].token2idx(w), strings_to_char_tensor([[w]], self.vocabs['token_char'])[0, 0].tolist())
+                cache[w] = hit
+            ids.append(hit[0])
+            rows.append(hit[1])
+        token = torch.tensor([ids], dtype=torch.int64)
+        token_char = torch.tensor([rows], dtype=torch.int64)
         return token.to(self.device), token_char.to(self.device)
 
     def decode_step(self, tokens, state, memory, beam_of_hyp, offset, topk):

@@ -385,3 +385,19 @@ def test_end_to_end_translator_flow_on_gpu(tmp_path):
     for beam in beams:
         best = beam.get_k_best(1, 0.6)[0]
         assert best.seq[0] == "<STR>" and len(best.seq) >= 2 and best.score == best.score
+
+
+def test_cached_step_inputs_equal_the_tensorisers(tmp_path):
+    """Generator.prepare_incremental_input caches (token id, character row) per string: same tensors as the generic path."""
+    from gtos_amd.generator import Generator
+    from gtos_amd.vocab import lists_to_tensor, strings_to_char_tensor
+    meta, _ = load_case()
+    vocabs = make_vocabs(meta, tmp_path)
+    cfg = meta["cfg"]
+    ga = [[tuple(f) for f in a] if isinstance(a, list) else a for a in cfg["gen_args"]]
+    m = Generator(vocabs, *ga, cfg["d"], cfg["ff"], cfg["H"], 0.0, 1, 2, 3, None, torch.device("cpu"))
+    seq = [["the"], ["boy"], ["never-seen-token"], ["the"], ["a-token-longer-than-twenty-characters"], ["<STR>"]]
+    for _ in range(2):                                     # second pass is served from the cache
+        t, c = m.prepare_incremental_input(seq)
+        assert torch.equal(t, lists_to_tensor(seq, vocabs['token']))
+        assert torch.equal(c, strings_to_char_tensor(seq, vocabs['token_char']))
