@@ -242,7 +242,7 @@ __device__ __forceinline__ void dma_wt(const bf16_t* __restrict__ w, int64_t ld,
     }
 }
 
-__global__ __launch_bounds__(256, 2) void gru_step_bwd_kernel(StepBwdArgs a) {
+__global__ __launch_bounds__(256, 3) void gru_step_bwd_kernel(StepBwdArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[A_BYTES + TC * ROWB];
     __shared__ float btab[4 * TC];
     char* As = lds;
@@ -289,15 +289,13 @@ __global__ __launch_bounds__(256, 2) void gru_step_bwd_kernel(StepBwdArgs a) {
 
     const int cb = c0 + fq * 16;
     const float ks = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
-    float bs[4][16];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) bs[q][i] = 0.f;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-        const int m = m0 + wave * 32 + mt * 16 + fr;
-        if (m >= a.rows) continue;
+        // rows past the end read the last valid row and contribute zeros: every lane stays active, because the bias sums
+        // below are cross-lane (DPP) reductions
+        const int m_raw = m0 + wave * 32 + mt * 16 + fr;
+        const bool valid = m_raw < a.rows;
+        const int m = valid ? m_raw : a.rows - 1;
         float gr[16], gz[16], gn[16], hn[16], hp[16], g[16];
         const bf16_t* gp = a.gates + (int64_t)m * 4 * hs + cb;
         ld16(gp, gr); ld16(gp + hs, gz); ld16(gp + 2 * hs, gn); ld16(gp + 3 * hs, hn);
@@ -327,30 +325,34 @@ __global__ __launch_bounds__(256, 2) void gru_step_bwd_kernel(StepBwdArgs a) {
             dr_[i] = dn_[i] * hn[i] * gr[i] * (1.f - gr[i]);
             dz_[i] = dz * gz[i] * (1.f - gz[i]);
             g[i] *= gz[i];                                             // the direct path h_prev -> h
+            if (!valid) { dn_[i] = 0.f; dhn[i] = 0.f; dr_[i] = 0.f; dz_[i] = 0.f; }
         }
-        if (a.dh_bf16) {
-            st16(dhb, g);
-        } else {
+        if (valid) {
+            if (a.dh_bf16) {
+                st16(dhb, g);
+            } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                *reinterpret_cast<float4*>(dhp + i * 4) = make_float4(g[i * 4], g[i * 4 + 1], g[i * 4 + 2], g[i * 4 + 3]);
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<float4*>(dhp + i * 4) = make_float4(g[i * 4], g[i * 4 + 1], g[i * 4 + 2], g[i * 4 + 3]);
+            }
+            bf16_t* dp = a.d4 + (int64_t)m * 4 * hs + cb;
+            st16(dp, dr_); st16(dp + hs, dz_); st16(dp + 2 * hs, dn_); st16(dp + 3 * hs, dhn);
         }
-        bf16_t* dp = a.d4 + (int64_t)m * 4 * hs + cb;
-        st16(dp, dr_); st16(dp + hs, dz_); st16(dp + 2 * hs, dn_); st16(dp + 3 * hs, dhn);
+        if (a.bias_part) {
+            // bias gradients: column sums of the values as stored (rounded), reduced over the 16 rows of this lane group
+            // right away (keeping 64 running sums per lane across both row blocks costs a third workgroup per CU)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {      // sums of the values as stored (rounded), what the weight-gradient GEMMs see
-            bs[0][i] += bf2f(f2bf(dr_[i])); bs[1][i] += bf2f(f2bf(dz_[i]));
-            bs[2][i] += bf2f(f2bf(dn_[i])); bs[3][i] += bf2f(f2bf(dhn[i]));
+            for (int i = 0; i < 16; ++i) {
+                const float t0 = row16_sum(bf2f(f2bf(dr_[i]))), t1 = row16_sum(bf2f(f2bf(dz_[i])));
+                const float t2 = row16_sum(bf2f(f2bf(dn_[i]))), t3 = row16_sum(bf2f(f2bf(dhn[i])));
+                if (fr == 0) {
+                    atomicAdd(&btab[0 * TC + fq * 16 + i], t0); atomicAdd(&btab[1 * TC + fq * 16 + i], t1);
+                    atomicAdd(&btab[2 * TC + fq * 16 + i], t2); atomicAdd(&btab[3 * TC + fq * 16 + i], t3);
+                }
+            }
         }
     }
     if (a.bias_part) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float t = row16_sum(bs[q][i]);
-                if (fr == 0) atomicAdd(&btab[q * TC + fq * 16 + i], t);
-            }
         __syncthreads();
         const int q = threadIdx.x >> 6, ch = threadIdx.x & 63;
         float* dst = a.bias_part + (int64_t)(blockIdx.x % a.n_partials) * 4 * hs + q * hs + c0 + ch;
