@@ -94,6 +94,7 @@ void graph_paths(const Graph& g, int mode, uint64_t seed, int gid, int max_len, 
     const int n = g.n;
     out.off.assign((size_t)n * n + 1, 0);
     out.keys.clear();
+    out.keys.reserve((size_t)n * n + 64);
     std::vector<int> level(n), parent(n), plabel(n), frontier, next;
     std::vector<double> count(n);
     std::vector<std::vector<std::pair<int, int>>> pred(n);            // (predecessor, label of pred->node), discovery order
