@@ -3,6 +3,8 @@
 Each ``torch.autograd.Function`` here is the MI355X counterpart of one ATen op sequence of the reference
 (cited per function).  Tensors provide device memory; kernels are enqueued on torch's current HIP stream.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -84,9 +86,9 @@ _SIDE = {}
 # Opt-in (GTOS_PROJ_SIDE=1): prefetch every layer's relation projection on the side stream.  Measured at C2: 104.8 ->
 # 102.7 ms/step, but the attention kernels then share the chip with a GEMM and their own launches stretch from 259 to
 # 595 us, which would make the in-step roofline figure of bench.py meaningless -- so it is off by default.
-PROJ_SIDE = __import__("os").environ.get("GTOS_PROJ_SIDE", "0") == "1"
+PROJ_SIDE = os.environ.get("GTOS_PROJ_SIDE", "0") == "1"
 # Backward of the relation projections on the side stream (see LinearFn.backward): overlaps only backward kernels.
-BWD_SIDE = __import__("os").environ.get("GTOS_BWD_SIDE", "1") != "0"
+BWD_SIDE = os.environ.get("GTOS_BWD_SIDE", "1") != "0"
 BWD_SIDE_MIN_ROWS = 100000
 
 
