@@ -52,9 +52,11 @@ template <> struct Raw8<float> {
     }
 };
 
-// keys per register set; the streaming loops keep TWO sets in flight (software pipeline)
+// keys per register set; the streaming loops keep TWO sets in flight (software pipeline).  One key per set: 90 VGPRs in
+// the forward kernel (5 waves per SIMD), 106 in the query-major backward (4); two keys per set measured 4-9 % slower on
+// the same box (fewer resident waves outweigh the deeper per-wave pipeline)
 #ifndef GTOS_ATTN_U
-#define GTOS_ATTN_U 2
+#define GTOS_ATTN_U 1
 #endif
 template <typename T> struct Unroll { static constexpr int U = GTOS_ATTN_U; };
 template <> struct Unroll<float> { static constexpr int U = 1; };
