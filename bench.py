@@ -2,7 +2,7 @@
 """Headline benchmark: graphs/s of one full training step (fwd + bwd + gradient all-reduce + clip + Adam) of the gtos
 Generator on synthetic 100-node AMR graphs, batch 64 per GPU, bf16 activations (BASELINE.json configs[1] = "C2").
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W        (N>1: one rank per GPU; launched by torch.distributed.run, or self-launching)
 
 Prints ONE JSON line (rank 0).  Also reports
   roofline      relation-attention forward kernel: algorithmic bytes per launch (P*2d*s + 4*n*B*d*s + n*B,
@@ -58,6 +58,8 @@ def parse():
                     help="secondary benchmark (SURVEY 8f rank 2): beam search over the K/V-cached decoder instead of the train step")
     ap.add_argument("--beam", type=int, default=8)
     ap.add_argument("--max-steps", type=int, default=50)
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="only check the rank launch / rendezvous (gloo, no GPU): every rank prints its rank and exits")
     return ap.parse_args()
 
 
@@ -171,10 +173,30 @@ def main():
     if a.decode:
         torch.cuda.set_device(0)
         return decode_bench(a)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher, one rank per GPU (the reference spawns its own ranks too,
+        # generator/train.py:173-190)
+        import socket
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+    if world != a.gpus:
+        raise SystemExit("bench.py --gpus %d was launched with WORLD_SIZE=%d" % (a.gpus, world))
+    if a.dry_launch:
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            t = torch.ones(1)
+            dist.all_reduce(t)
+            assert int(t.item()) == world
+            dist.destroy_process_group()
+        print("dry-launch rank %d of %d ok" % (rank, world), flush=True)
+        return
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -191,7 +213,7 @@ def main():
     model = build_generator(Generator, a.config, dev, factored_relation=not a.dense).to(dev)
     model.set_compute_dtype(cd)
     model.train()
-    trainer = Trainer(model, cfg["d"], warmup_steps=2000, compute_dtype=cd, world_size=world)
+    trainer = Trainer(model, cfg["d"], warmup_steps=2000, compute_dtype=cd, world_size=world, rank=rank)
     log("model on device; generating batch")
     batch, stats = synth.make_config_batch(a.config, rank=rank)        # weak scaling: B graphs per GPU
     log("batch", stats)

@@ -383,13 +383,17 @@ __global__ void embed_rows_fwd_kernel(int64_t n, int dim, int dim_pad, const int
 
 // dtable[tok[n], :] += dropmask * dout[n, 0:dim].  The table is small (relation vocabulary ~ 90 x 100): each block
 // accumulates a private copy in LDS (ds_add_f32) over its slice of rows and flushes it with global atomics.
-template <typename T>
+template <typename T, bool use_lds>
 __global__ __launch_bounds__(256) void embed_rows_bwd_kernel(int64_t n, int V, int dim, int dim_pad, const int64_t* __restrict__ tok,
                                                              const T* __restrict__ dout, float* __restrict__ dtable, float p_drop,
                                                              uint64_t seed, int64_t rows_per_block) {
+    // small tables (the relation / character vocabularies) are accumulated in a private LDS copy first; large ones take
+    // fp32 atomics in global memory directly (many rows: little contention)
     extern __shared__ float tab[];
-    for (int i = threadIdx.x; i < V * dim; i += 256) tab[i] = 0.f;
-    __syncthreads();
+    if (use_lds) {
+        for (int i = threadIdx.x; i < V * dim; i += 256) tab[i] = 0.f;
+        __syncthreads();
+    }
     const float ks = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
     const int vpr = dim_pad / 8;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(n, r0 + rows_per_block);
@@ -397,18 +401,20 @@ __global__ __launch_bounds__(256) void embed_rows_bwd_kernel(int64_t n, int V, i
         const int64_t row = t / vpr; const int c = (int)(t % vpr) * 8;
         float v[8];
         Vec8<T>::load(dout + row * dim_pad + c, v);
-        float* dst = tab + tok[row] * dim;
+        float* dst = (use_lds ? tab : dtable) + tok[row] * dim;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             if (c + e < dim) {
                 float x = v[e];
                 if (p_drop > 0.f) x = drop_keep(seed, (uint64_t)row * dim_pad + c + e, p_drop) ? x * ks : 0.f;
-                atomicAdd(dst + c + e, x);
+                if (use_lds || x != 0.f) atomicAdd(dst + c + e, x);
             }
         }
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < V * dim; i += 256) { const float x = tab[i]; if (x != 0.f) atomicAdd(dtable + i, x); }
+    if (use_lds) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < V * dim; i += 256) { const float x = tab[i]; if (x != 0.f) atomicAdd(dtable + i, x); }
+    }
 }
 
 // =========================================================================== optimizer (flat buffers)
@@ -561,15 +567,17 @@ extern "C" int gtos_embed_rows_fwd(int dtype, int64_t n, int dim, int dim_pad, c
 extern "C" int gtos_embed_rows_bwd(int dtype, int64_t n, int V, int dim, int dim_pad, const int64_t* tok, const void* dout,
                                    float* dtable, float p_drop, uint64_t seed, void* stream) {
     if (dim_pad % 8 || dim_pad < dim) return -24;
-    if ((size_t)V * dim * 4 > 60 * 1024) return -25;          // private LDS table; larger vocabularies are not on this path
+    const int use_lds = (size_t)V * dim * 4 <= 60 * 1024;     // private LDS table, else global atomics
     if (n <= 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     int64_t nb = (n + 2047) / 2048; if (nb > 1024) nb = 1024; if (nb < 1) nb = 1;
     const int64_t rpb = (n + nb - 1) / nb;
     dim3 grid((unsigned)((n + rpb - 1) / rpb)), block(256);
-    const size_t sh = (size_t)V * dim * 4;
-    if (dtype == GTOS_BF16) hipLaunchKernelGGL(embed_rows_bwd_kernel<bf16_t>, grid, block, sh, s, n, V, dim, dim_pad, tok, (const bf16_t*)dout, dtable, p_drop, seed, rpb);
-    else hipLaunchKernelGGL(embed_rows_bwd_kernel<float>, grid, block, sh, s, n, V, dim, dim_pad, tok, (const float*)dout, dtable, p_drop, seed, rpb);
+    const size_t sh = use_lds ? (size_t)V * dim * 4 : 0;
+#define GTOS_EMB_BWD(T, L) hipLaunchKernelGGL((embed_rows_bwd_kernel<T, L>), grid, block, sh, s, n, V, dim, dim_pad, tok, (const T*)dout, dtable, p_drop, seed, rpb)
+    if (dtype == GTOS_BF16) { if (use_lds) GTOS_EMB_BWD(bf16_t, true); else GTOS_EMB_BWD(bf16_t, false); }
+    else { if (use_lds) GTOS_EMB_BWD(float, true); else GTOS_EMB_BWD(float, false); }
+#undef GTOS_EMB_BWD
     GTOS_CHECK_LAUNCH();
     return 0;
 }

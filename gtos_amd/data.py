@@ -18,8 +18,12 @@ def relation_special_ids(rel_vocab):
             rel_vocab.token2idx(TL))
 
 
-def batchify_dependency(trees, vocabs, n_threads=0):
-    """trees: list of (dep labels, heads (1-based, 0 = root), source tokens, target tokens) as translator/extract.py's
+def batchify_dependency(trees, vocabs, n_threads=0, unk_rate=0., rng=None, replay_reference_draws=False):
+    """``unk_rate`` / ``rng``: the training-time <UNK> noise on ``concept`` and ``token_in`` only (translator/data.py:129,185),
+    see vocab.lists_to_tensor.  Between those two tensors the reference's batchify calls ``random.choice`` once per node
+    pair on a one-element path list (data.py:149); ``replay_reference_draws`` consumes ``rng`` the same way so that the
+    ``token_in`` noise is bit-identical to the reference's under the same generator state (a Python loop over n^2 pairs:
+    for tests, off by default).  trees: list of (dep labels, heads (1-based, 0 = root), source tokens, target tokens) as translator/extract.py's
     IO.read1 yields them.  Returns the dict of translator/data.py:185-201 (int64 tensors, time-major) including
     ``local_idx2token`` / ``local_token2idx``; ``concept_depth`` is the node's position in the source sentence
     (dependencyGraph.py:72-73), concepts are in BFS order from the root."""
@@ -40,13 +44,20 @@ def batchify_dependency(trees, vocabs, n_threads=0):
         cps.append(cp_seq); t2is.append(t2i); i2ts.append(i2t)
     aug = [[STR] + list(tgt) + [END] for _, _, _, tgt in trees]
     with_cls = [[CLS] + c for c in concepts]
+    concept = lists_to_tensor(with_cls, vocabs['concept'], unk_rate=unk_rate, rng=rng)
+    if replay_reference_draws and unk_rate > 0.:
+        import random
+        gen, one = (rng if rng is not None else random), [0]
+        for c in concepts:
+            for _ in range(len(c) * len(c)):
+                gen.choice(one)
     return {
-        'concept': lists_to_tensor(with_cls, vocabs['concept']),
+        'concept': concept,
         'concept_char': strings_to_char_tensor(with_cls, vocabs['concept_char']),
         'concept_depth': lists_to_tensor([[0] + d for d in depths]),
         'relation': rel['relation'], 'relation_bank': rel['relation_bank'], 'relation_length': rel['relation_length'],
         'local_idx2token': i2ts, 'local_token2idx': t2is,
-        'token_in': lists_to_tensor(aug, vocabs['token'])[:-1],
+        'token_in': lists_to_tensor(aug, vocabs['token'], unk_rate=unk_rate, rng=rng)[:-1],
         'token_char_in': strings_to_char_tensor(aug, vocabs['token_char'])[:-1],
         'token_out': lists_to_tensor(aug, vocabs['predictable_token'], t2is)[1:],
         'cp_seq': lists_to_tensor(cps, vocabs['predictable_token'], t2is),
@@ -80,6 +91,11 @@ class DependencyLoader(object):
         self.vocabs, self.batch_size, self.train = vocabs, batch_size, for_train
         self.rng = rng if rng is not None else random
         self.n_threads = n_threads
+        self.unk_rate = 0.
+
+    def set_unk_rate(self, x):
+        """translator/data.py:218-219; train.py:128 calls it with --unk_rate (0.33 in train.sh)."""
+        self.unk_rate = x
 
     @staticmethod
     def size_of(tree):
@@ -106,7 +122,8 @@ class DependencyLoader(object):
 
     def __iter__(self):
         for b in self.batch_indices():
-            yield batchify_dependency([self.data[i] for i in b], self.vocabs, n_threads=self.n_threads)
+            yield batchify_dependency([self.data[i] for i in b], self.vocabs, n_threads=self.n_threads,
+                                      unk_rate=self.unk_rate, rng=self.rng)
 
 
 # ------------------------------------------------------------------------------------------------ generator flavour
@@ -128,8 +145,9 @@ def _edges_from_paths(item, rel_vocab):
     return n, 0, np.array(edges, dtype=np.int32).reshape(-1, 3)
 
 
-def batchify_amr(items, vocabs, train=True, seed=0, n_threads=0):
-    """Generator flavour (generator/data.py:126-267).  items: dicts with 'concept' (BFS order), 'depth', 'relation'
+def batchify_amr(items, vocabs, train=True, seed=0, n_threads=0, unk_rate=0., rng=None):
+    """``unk_rate`` / ``rng``: <UNK> noise on ``concept`` and ``token_in`` (generator/data.py:127,244).
+    Generator flavour (generator/data.py:126-267).  items: dicts with 'concept' (BFS order), 'depth', 'relation'
     (path lists, only used to recover the edges), 'token', and optionally 'abstract'.  train=True draws ONE shortest path
     per pair, uniformly among the alternatives like the reference's random.choice (from a splitmix64 stream seeded with
     ``seed``); train=False keeps them all: relation is [n,n,B,K], type 0 = <PAD> (data.py:178-232).  The alternatives of a
@@ -150,12 +168,12 @@ def batchify_amr(items, vocabs, train=True, seed=0, n_threads=0):
     aug = [[STR] + list(x['token']) + [END] for x in items]
     with_cls = [[CLS] + list(x['concept']) for x in items]
     return {
-        'concept': lists_to_tensor(with_cls, vocabs['concept']),
+        'concept': lists_to_tensor(with_cls, vocabs['concept'], unk_rate=unk_rate, rng=rng),
         'concept_char': strings_to_char_tensor(with_cls, vocabs['concept_char']),
         'concept_depth': lists_to_tensor([[0] + list(x['depth']) for x in items]),
         'relation': rel['relation'], 'relation_bank': rel['relation_bank'], 'relation_length': rel['relation_length'],
         'local_idx2token': i2ts, 'local_token2idx': t2is,
-        'token_in': lists_to_tensor(aug, vocabs['token'])[:-1],
+        'token_in': lists_to_tensor(aug, vocabs['token'], unk_rate=unk_rate, rng=rng)[:-1],
         'token_char_in': strings_to_char_tensor(aug, vocabs['token_char'])[:-1],
         'token_out': lists_to_tensor(aug, vocabs['predictable_token'], t2is)[1:],
         'cp_seq': lists_to_tensor(cps, vocabs['predictable_token'], t2is),

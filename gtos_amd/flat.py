@@ -3,10 +3,11 @@
 MI355X-first replacement for the reference's per-parameter machinery (/root/reference/generator/train.py:74-79
 ``average_gradients`` = 182 blocking all-reduces, :151 ``clip_grad_norm_``, generator/adam.py:28-87 = 5 small kernels
 per parameter): every parameter is a view into ONE fp32 buffer, every gradient a view into ONE fp32 bucket, so
-data parallelism is a single RCCL all-reduce and the optimizer is three kernel launches (square-norm, Adam on
-the weight-decay segment, Adam on the no-decay segment).  Semantics are the reference's: grads averaged over
-ranks, global-norm clip to 1.0, Adam(0.9, 0.999, eps 1e-6) without bias correction, decoupled weight decay 1e-4
-except for ``bias`` / ``layer_norm`` parameters (train.py:123-132), lr = d^-0.5 min(s^-0.5, s w^-1.5) (train.py:81-83).
+data parallelism is a handful of large RCCL all-reduces over CONTIGUOUS segments of the bucket (train.Trainer launches
+each as soon as backward has produced it) and the optimizer is a square-norm launch plus one Adam launch per
+(segment, weight-decay class).  Semantics are the reference's: grads averaged over ranks, global-norm clip to 1.0,
+Adam(0.9, 0.999, eps 1e-6) without bias correction, decoupled weight decay 1e-4 except for ``bias`` / ``layer_norm``
+parameters (train.py:123-132), lr = d^-0.5 min(s^-0.5, s w^-1.5) (train.py:81-83).
 """
 import torch
 
@@ -25,19 +26,29 @@ def inverse_sqrt_lr(embed_size, step, warmup_steps):
 
 
 class FlatParams:
-    def __init__(self, model, mirror_dtype=None, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-6):
+    """``segment_of(name) -> int`` groups the parameters into contiguous segments of the flat buffers (segment 0 first);
+    inside a segment the weight-decay parameters precede the no-decay ones.  Default: one segment."""
+
+    def __init__(self, model, mirror_dtype=None, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-6, segment_of=None):
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
-        decay = [(n, p) for n, p in named if not is_no_decay(n)]
-        nodecay = [(n, p) for n, p in named if is_no_decay(n)]
+        seg_id = (lambda n: 0) if segment_of is None else segment_of
+        nseg = 1 + max(seg_id(n) for n, _ in named)
         self.entries = []
+        self.segments = []          # (lo, hi) element ranges, one per segment
+        self.adam_ranges = []       # (lo, hi, weight decay)
         off = 0
-        for n, p in decay + nodecay:
-            if len(self.entries) == len(decay):
-                self.decay_end = off
-            self.entries.append((n, p, off))
-            off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
-        if len(nodecay) == 0:
-            self.decay_end = off
+        for s in range(nseg):
+            seg_lo = off
+            for nodecay in (False, True):
+                lo = off
+                for n, p in named:
+                    if seg_id(n) == s and is_no_decay(n) == nodecay:
+                        self.entries.append((n, p, off))
+                        off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+                if off > lo:
+                    self.adam_ranges.append((lo, off, 0.0 if nodecay else weight_decay))
+            self.segments.append((seg_lo, off))
+        assert len(self.entries) == len(named)
         self.total = off
         dev = named[0][1].device
         self.param = torch.zeros(off, dtype=torch.float32, device=dev)
@@ -53,34 +64,52 @@ class FlatParams:
             p.grad = self.grad[o:o + k].view(p.shape)
             if self.mirror is not None:
                 p._gtos_mirror = self.mirror[o:o + k].view(p.shape)
-        if self.mirror is not None:
-            call("gtos_cast_f32_to_bf16", self.total, ptr(self.param), ptr(self.mirror), stream())
         self.weight_decay, self.betas, self.eps = weight_decay, betas, eps
         self.steps = 0
+        self.sync_mirror()
+        # a checkpoint loaded after construction writes the fp32 masters in place: refresh everything derived from them
+        if hasattr(model, "register_load_state_dict_post_hook"):
+            model.register_load_state_dict_post_hook(lambda module, incompatible: self.sync_mirror())
+
+    def sync_mirror(self):
+        """Re-derive the bf16 mirror and invalidate cached weight transposes after the fp32 masters were written by
+        anything other than step() (load_state_dict, manual edits)."""
+        self.check_views()
+        if self.mirror is not None:
+            call("gtos_cast_f32_to_bf16", self.total, ptr(self.param), ptr(self.mirror), stream())
+        _ops.PARAM_EPOCH[0] += 1
+
+    def check_views(self):
+        """model.to()/.float() after construction would silently detach parameters from the flat buffers."""
+        base, es = self.param.data_ptr(), 4
+        for n, p, o in self.entries:
+            if p.data_ptr() != base + o * es:
+                raise RuntimeError("parameter %s no longer lives in the flat buffer (was the model moved or cast after "
+                                   "FlatParams/Trainer construction?)" % n)
 
     def zero_grad(self):
         _ops.join_side()
         self.grad.zero_()
 
     def grad_norm(self, gscale=1.0):
+        _ops.join_side()                   # deferred side-stream gradient GEMMs (gru.py) must have landed
         self.sqnorm.zero_()
         call("gtos_sqnorm", self.total, ptr(self.grad), ptr(self.sqnorm), stream())
         return self.sqnorm.sqrt() * gscale
 
     def step(self, lr, gscale=1.0, max_norm=1.0):
-        _ops.join_side()                   # deferred side-stream gradient work must have landed in self.grad
         """gscale = 1/world_size after a SUM all-reduce.  Clips by global norm then applies Adam."""
+        _ops.join_side()                   # deferred side-stream gradient work must have landed in self.grad
+        if self.steps == 0:
+            self.check_views()
         self.sqnorm.zero_()
         call("gtos_sqnorm", self.total, ptr(self.grad), ptr(self.sqnorm), stream())
         b1, b2 = self.betas
         es = 4
-        for lo, hi, wd in ((0, self.decay_end, self.weight_decay), (self.decay_end, self.total, 0.0)):
-            if hi <= lo:
-                continue
+        for lo, hi, wd in self.adam_ranges:
             mir = None if self.mirror is None else self.mirror.data_ptr() + lo * self.mirror.element_size()
             call("gtos_adam_step", hi - lo, self.param.data_ptr() + lo * es, self.grad.data_ptr() + lo * es,
                  self.m.data_ptr() + lo * es, self.v.data_ptr() + lo * es, float(lr), b1, b2, self.eps, wd,
                  float(gscale), ptr(self.sqnorm), float(max_norm), mir, stream())
         self.steps += 1
-        from . import ops
-        ops.PARAM_EPOCH[0] += 1
+        _ops.PARAM_EPOCH[0] += 1

@@ -50,6 +50,7 @@ class Generator(nn.Module):
         self.device = device
         self.factored_relation = factored_relation
         self.compute_dtype = torch.float32
+        self.grad_sync = None           # train.Trainer (data parallel): places the gradient-segment boundary markers
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -70,6 +71,9 @@ class Generator(nn.Module):
     def encode_step(self, inp, train=True):
         concept_repr, concept_mask = self._concepts(inp)
         bank = self.relation_encoder(inp['relation_bank'], inp['relation_length'])           # [R, d]
+        if train and self.grad_sync is not None:
+            # everything downstream of these two belongs to gradient segments <= 2 (graph encoder, probe, decoders)
+            concept_repr, bank = self.grad_sync.boundary(2, concept_repr, bank)
         if train:
             if self.factored_relation:
                 relation = ops.FactoredRelation(bank, inp['relation'])
@@ -100,9 +104,14 @@ class Generator(nn.Module):
         token_mask = torch.eq(data['token_in'], self.vocabs['token'].padding_idx)
         attn_mask = self.self_attn_mask(data['token_in'].size(0))
         concept_repr = concept_repr.contiguous()
+        gs = self.grad_sync
+        if gs is not None:          # downstream: sentence encoder (segment 1) and decoder (segment 0)
+            token_repr, concept_repr, probe = gs.boundary(1, token_repr, concept_repr, probe)
         token_repr = self.snt_encoder(token_repr, self_padding_mask=token_mask, self_attn_mask=attn_mask,
                                       external_memories=concept_repr, external_padding_mask=concept_mask)
         probe = probe.expand_as(token_repr)
+        if gs is not None:          # downstream: the decoder only
+            probe, concept_repr, token_repr = gs.boundary(0, probe, concept_repr, token_repr)
         return self.decoder(probe, concept_repr, token_repr, concept_mask, token_mask, attn_mask,
                             data['cp_seq'], target=data['token_out'])
 

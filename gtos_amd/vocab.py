@@ -93,18 +93,32 @@ def load_vocabs(args_or_dir):
     return out
 
 
-def lists_to_tensor(xs, vocab=None, local_vocabs=None):
-    """Ragged token lists -> int64 [max_len, batch], padded (data.py:76-98 without the training-time UNK noise).
-    ``local_vocabs[i]`` (token -> id, the per-graph copy vocabulary) takes precedence over ``vocab``."""
+def lists_to_tensor(xs, vocab=None, local_vocabs=None, unk_rate=0., rng=None):
+    """Ragged token lists -> int64 [max_len, batch], padded (data.py:76-98).  ``local_vocabs[i]`` (token -> id, the
+    per-graph copy vocabulary) takes precedence over ``vocab``.  ``unk_rate`` > 0 is the reference's training-time noise
+    (data.py:84-85; train.sh --unk_rate 0.33): every token, in sequence-major order, becomes <UNK> when
+    ``rng.random() < unk_rate`` -- drawn BEFORE the local-vocabulary lookup, from ``rng`` (default: the ``random`` module,
+    like the reference), so under the same generator state the noise pattern is the reference's.  (The reference draws a
+    number per token even at rate 0; this function only draws when the rate is positive.)"""
     pad = vocab.padding_idx if vocab is not None else 0
     width = max(len(x) for x in xs)
+    noisy = vocab is not None and unk_rate > 0.
+    if noisy and rng is None:
+        import random as rng
     rows = []
     for i, x in enumerate(xs):
         if vocab is None:
             ids = list(x)
         else:
             local = local_vocabs[i] if local_vocabs is not None else None
-            ids = [local[w] if (local is not None and w in local) else vocab.token2idx(w) for w in x]
+            ids = []
+            for w in x:
+                if noisy and rng.random() < unk_rate:
+                    ids.append(vocab.unk_idx)
+                elif local is not None and w in local:
+                    ids.append(local[w])
+                else:
+                    ids.append(vocab.token2idx(w))
         rows.append(ids + [pad] * (width - len(x)))
     return torch.tensor(rows, dtype=torch.int64).t().contiguous()
 

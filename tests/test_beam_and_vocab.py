@@ -401,3 +401,35 @@ def test_cached_step_inputs_equal_the_tensorisers(tmp_path):
         t, c = m.prepare_incremental_input(seq)
         assert torch.equal(t, lists_to_tensor(seq, vocabs['token']))
         assert torch.equal(c, strings_to_char_tensor(seq, vocabs['token_char']))
+
+
+# ------------------------------------------------------------------------------------------------ training-time UNK noise
+def test_unk_rate_noise_matches_the_reference_loader(tmp_path):
+    """translator/data.py:77-99 under --unk_rate: with the same `random` state, batchify_dependency replaces exactly the
+    concept / token_in entries the reference replaces, and never touches token_out / cp_seq (tests/golden/make_golden_unk.py)."""
+    import random
+    from gtos_amd.data import batchify_dependency, DependencyLoader
+    meta = json.load(open(os.path.join(GOLDEN_DIR, "beam_dep_dev.json")))
+    vocabs = make_vocabs(meta, tmp_path)
+    g = np.load(os.path.join(GOLDEN_DIR, "unk_dep_dev.npz"))
+    trees = [tuple(t) for t in meta["trees"]]
+    clean = batchify_dependency(trees, vocabs)
+    for k, (rate, seed) in enumerate(g["settings"]):
+        rng = random.Random(int(seed))
+        b = batchify_dependency(trees, vocabs, unk_rate=float(rate), rng=rng, replay_reference_draws=True)
+        for key in ("concept", "token_in"):
+            assert torch.equal(b[key], T(g["%d/%s" % (k, key)])), (rate, seed, key)
+        for key in ("token_out", "cp_seq"):
+            assert torch.equal(b[key], clean[key]) and torch.equal(b[key], T(g["%d/%s" % (k, key)]))
+        if rate > 0:
+            assert not torch.equal(b["concept"], clean["concept"])
+    # the module-level default generator is `random`, like the reference
+    random.seed(int(g["settings"][0][1]))
+    b = batchify_dependency(trees, vocabs, unk_rate=float(g["settings"][0][0]))
+    assert torch.equal(b["concept"], T(g["0/concept"]))
+    # the loader threads its rate and generator through (translator/data.py:218-219,265)
+    dl = DependencyLoader(vocabs, trees, 10 ** 9, for_train=False, rng=random.Random(int(g["settings"][1][1])))
+    dl.set_unk_rate(float(g["settings"][1][0]))
+    b = next(iter(dl))
+    assert torch.equal(b["concept"], T(g["1/concept"]))
+    assert abs(float((b["token_in"] == vocabs['token'].unk_idx).float().mean()) - float((T(g["1/token_in"]) == vocabs['token'].unk_idx).float().mean())) < 0.1

@@ -1,0 +1,24 @@
+"""`python bench.py --gpus N` must launch its own ranks (one per GPU) when it is not already under torch.distributed.run
+-- the reference spawns its ranks itself (generator/train.py:173-190).  Checked on CPU with the --dry-launch leg (gloo)."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env=None):
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=e, capture_output=True, text=True, timeout=300)
+
+
+def test_bench_self_launches_two_ranks():
+    r = _run(["--gpus", "2", "--dry-launch"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "dry-launch rank 0 of 2 ok" in r.stdout and "dry-launch rank 1 of 2 ok" in r.stdout
+
+
+def test_bench_rejects_mismatched_world_size():
+    r = _run(["--gpus", "2", "--dry-launch"], env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)

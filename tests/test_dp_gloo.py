@@ -63,3 +63,168 @@ def test_flat_bucket_allreduce_matches_per_parameter():
         assert ok, "flat all-reduce differs from per-parameter all-reduce on rank %d" % rank
         assert sigs[0] != sigs[1], "ranks drew identical synthetic graphs"
         assert flag == 1.0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Trainer.step itself with world_size 2 (SURVEY section 7 test vi): the HIP optimizer kernels are replaced by the oracle's
+# CPU Adam / clip (same arithmetic), everything else -- segment layout, boundary markers, async all-reduce launch order,
+# join_side, the 1/W fold, the collective abnormal-loss flag -- is the product code.
+def _cpu_flat_step(self, lr, gscale=1.0, max_norm=1.0):
+    from oracle import gtos_oracle as O
+    from gtos_amd import ops
+    ops.join_side()
+    g = self.grad * gscale
+    coef, _ = O.clip_coef([g], max_norm)
+    for lo, hi, wd in self.adam_ranges:
+        p, m, v = O.adam_step(self.param[lo:hi], g[lo:hi] * coef, self.m[lo:hi], self.v[lo:hi], lr, wd)
+        self.param[lo:hi].copy_(p)
+        self.m[lo:hi].copy_(m)
+        self.v[lo:hi].copy_(v)
+    self.steps += 1
+
+
+class _SegModel(torch.nn.Module):
+    """Four sub-modules named like the Generator's gradient segments, wired with the same boundary markers."""
+
+    def __init__(self):
+        super().__init__()
+        lin = lambda: torch.nn.Sequential(torch.nn.Linear(12, 12), torch.nn.Tanh())
+        self.concept_encoder, self.graph_encoder, self.snt_encoder, self.decoder = lin(), lin(), lin(), lin()
+        self.probe_generator = torch.nn.Linear(12, 12)
+        self.grad_sync = None
+
+    def forward(self, x):                     # x [B, 12]; loss = mean over the batch rows
+        gs = self.grad_sync
+        h = self.concept_encoder(x)
+        side = h * 0.5
+        if gs is not None:
+            h, side = gs.boundary(2, h, side)
+        h = self.graph_encoder(h) + side
+        probe = self.probe_generator(h)
+        if gs is not None:
+            h, probe = gs.boundary(1, h, probe)
+        t = self.snt_encoder(h)
+        if gs is not None:
+            t, h, probe = gs.boundary(0, t, h, probe)
+        return (self.decoder(t + h) * probe).pow(2).sum(1).mean()
+
+
+def _trainer_worker(rank, world, port, q, kind, steps):
+    import gtos_amd.flat as flat_mod
+    import gtos_amd.train as train_mod
+    from gtos_amd import ops
+    flat_mod.FlatParams.step = _cpu_flat_step
+    log = []
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        real_ar = dist.all_reduce
+
+        def logged_all_reduce(t, op=dist.ReduceOp.SUM, async_op=False, **kw):
+            log.append(("all_reduce", t.numel(), "max" if op == dist.ReduceOp.MAX else "sum", bool(async_op)))
+            return real_ar(t, op=op, async_op=async_op, **kw)
+        train_mod.dist.all_reduce = logged_all_reduce
+    real_join = ops.join_side
+    ops.join_side = lambda *a: (log.append(("join_side",)), real_join(*a))[1]
+    torch.manual_seed(19940117)
+    if kind == "seg":
+        model = _SegModel()
+        g = torch.Generator().manual_seed(5)
+        data = torch.randn(8, 12, generator=g)
+        per = 8 // world
+        batch = data[rank * per:(rank + 1) * per]
+        trainer = train_mod.Trainer(model, 10000, warmup_steps=1, world_size=world, rank=rank,
+                                    segment_of=train_mod.generator_segment_of)
+        model.grad_sync = trainer if trainer.overlap else None
+    else:                                     # the pinned oracle Generator: the real model math, no markers
+        from oracle import gtos_oracle as O
+        from gtos_amd import synth
+        from tests_support import SMALL_VOCAB, SMALL_GEN_ARGS
+        vocabs = {k: O.VocabSpec(v, 0) for k, v in SMALL_VOCAB.items()}
+        model = O.Generator(vocabs, *SMALL_GEN_ARGS, 32, 64, 4, 0.0, 1, 2, 2)
+        model.train()
+        per = 4 // world
+        batch, _ = synth.make_batch(77, per, 7, 6, vocab=SMALL_VOCAB, first_graph=rank * per)
+        trainer = train_mod.Trainer(model, 250000, warmup_steps=1, world_size=world, rank=rank)    # lr = 2e-3 / sqrt(step)
+    nseg = len(trainer.flat.segments)
+    seg_sizes = [hi - lo for lo, hi in trainer.flat.segments]
+    losses, marks = [], []
+    real_backward = torch.Tensor.backward
+
+    def marked_backward(self_, *a, **kw):
+        r = real_backward(self_, *a, **kw)
+        log.append(("backward_end",))         # everything logged so far happened before backward() returned
+        return r
+    torch.Tensor.backward = marked_backward
+    for _ in range(steps):
+        log.append(("step_begin",))
+        losses.append(trainer.step(batch))
+    q.put((rank, losses, trainer.flat.param.detach().numpy().copy(), [n for n, _, _ in trainer.flat.entries], log, marks, nseg, seg_sizes,
+           trainer.flat.grad.abs().max().item()))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _run_trainer(world, kind, steps):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_trainer_worker, args=(r, world, port, q, kind, steps)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return [(r[0], r[1], torch.from_numpy(r[2])) + tuple(r[3:]) for r in res]
+
+
+def test_trainer_step_two_ranks_segments_overlap_and_equal_one_rank():
+    steps = 4
+    two = _run_trainer(2, "seg", steps)
+    one = _run_trainer(1, "seg", steps)[0]
+    for r in two:
+        rank, losses, param, names, log, marks, nseg, seg_sizes, gmax = r
+        assert nseg == 4 and all(s > 0 for s in seg_sizes)
+        assert names == one[3]
+        assert gmax == 0.0                                           # zero_grad ran after the optimizer
+        # two ranks on half the batch each == one rank on the whole batch (gradient of the global mean)
+        torch.testing.assert_close(param, one[2], rtol=1e-4, atol=2e-5)     # Adam's m/sqrt(v) amplifies fp32 summation-order noise
+        # event order inside every step
+        per_step, cur = [], None
+        for e in log:
+            if e == ("step_begin",):
+                cur = []
+                per_step.append(cur)
+            else:
+                cur.append(e)
+        assert len(per_step) == steps
+        for s, ev in enumerate(per_step):
+            if s >= 2:                                               # batches_acm > warmup_steps: the collective skip flag
+                assert ev[0] == ("all_reduce", 1, "max", False)
+                ev = ev[1:]
+            k = ev.index(("backward_end",))
+            # segments 0,1,2 go out from inside backward, async, in order
+            assert ev[:k] == [("all_reduce", seg_sizes[i], "sum", True) for i in range(3)], (s, ev)
+            after = ev[k + 1:]
+            # after backward: join the side stream FIRST, then the last segment; the optimizer joins again (no-op)
+            assert after[0] == ("join_side",) and after[1] == ("all_reduce", seg_sizes[3], "sum", True), after
+            assert all(e == ("join_side",) for e in after[2:]), after
+    mean_two = [(a + b) / 2 for a, b in zip(two[0][1], two[1][1])]
+    for a, b in zip(mean_two, one[1]):
+        assert abs(a - b) < 1e-5 * max(1.0, abs(b))
+
+
+def test_trainer_step_real_model_two_ranks_equal_one_rank():
+    """The oracle Generator (the real model math on CPU) through Trainer.step: 2 ranks x 2 graphs == 1 rank x 4 graphs
+    after 3 optimizer steps -- loss-curve equality at equal global batch."""
+    steps = 3
+    two = _run_trainer(2, "gen", steps)
+    one = _run_trainer(1, "gen", steps)[0]
+    assert two[0][3] == one[3]
+    for r in two:
+        torch.testing.assert_close(r[2], one[2], rtol=2e-4, atol=2e-6)
+    assert torch.equal(two[0][2], two[1][2])                          # replicas stay bit-identical
+    for a, b, c in zip(two[0][1], two[1][1], one[1]):
+        assert abs((a + b) / 2 - c) < 1e-4 * max(1.0, abs(c))

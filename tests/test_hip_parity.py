@@ -678,3 +678,185 @@ def test_side_stream_paths_give_the_same_gradients(dtype, monkeypatch):
         ref(cpu_batch).backward()
         for (k, p), (_, q) in zip(m1.named_parameters(), ref.named_parameters()):
             torch.testing.assert_close(p.grad.cpu(), q.grad, msg=lambda s_, k=k: "%s: %s" % (k, s_), **GRAD)
+
+
+# ------------------------------------------------------------------------------------------------ round 2: C2 / C5 slices
+_SLICE_CACHE = {}
+
+
+def _oracle_slice(cfg_name, B):
+    """Oracle loss + gradients of a full-depth slice of a BASELINE config (computed once per session: C5 takes ~1 min)."""
+    key = (cfg_name, B)
+    if key not in _SLICE_CACHE:
+        ref, m, batch, stats = _full_model_pair(cfg_name, B)
+        ref.train()
+        loss_r = ref(batch)
+        loss_r.backward()
+        grads = {k: p.grad.clone() for k, p in ref.named_parameters()}
+        _SLICE_CACHE[key] = (ref.state_dict(), batch, stats, float(loss_r), grads)
+        del m
+    return _SLICE_CACHE[key]
+
+
+# bf16 bound on a full-depth (8-layer, d=512) model: loss 1e-2 relative (north_star); every parameter gradient within
+# BF16_GRAD_REL relative Frobenius error of the fp32 oracle gradient -- activations, saved tensors and the gradient
+# signal are rounded to bf16 (2^-9 relative) at ~100 points of an 8-layer post-LN chain, so errors add up to percent level
+BF16_GRAD_REL = 6e-2
+
+
+def _product_on(cfg_name, sd, dtype):
+    from gtos_amd import synth
+    from gtos_amd.config import default_vocabs, generator_args
+    from gtos_amd.generator import Generator
+    cfg = dict(synth.CONFIGS[cfg_name])
+    args = generator_args(cfg)
+    args["dropout"] = 0.0
+    m = Generator(default_vocabs(), device=dev(), depth_size=256 if cfg["kind"] == "dep" else 32, **args).to(dev())
+    m.load_state_dict(sd)
+    m.set_compute_dtype(dtype)
+    m.train()
+    return m
+
+
+def _check_slice(cfg_name, B, dtype):
+    sd, batch, stats, loss_r, grads = _oracle_slice(cfg_name, B)
+    m = _product_on(cfg_name, sd, dtype)
+    loss = m({k: v.to(dev()) for k, v in batch.items()})
+    loss.backward()
+    torch.cuda.synchronize()
+    table = []
+    for k, p in m.named_parameters():
+        q = grads[k]
+        table.append((k, _rel_frob(p.grad.cpu(), q), float(q.norm())))
+    worst = sorted(table, key=lambda r: -r[1])[:8]
+    print("%s B=%d %s: loss %.6f vs %.6f; worst relative gradient errors: %s" % (
+        cfg_name, B, dtype, loss.item(), loss_r, ", ".join("%s %.3g" % (k, e) for k, e, _ in worst)))
+    if dtype == torch.float32:
+        assert abs(loss.item() - loss_r) < 1e-3 * max(1.0, abs(loss_r)), (loss.item(), loss_r)
+        for k, p in m.named_parameters():
+            q = grads[k]
+            err = (p.grad.cpu() - q).abs().max().item()
+            assert err < 1e-3 + 2e-3 * q.abs().max().item(), (k, err, q.abs().max().item())
+    else:
+        assert abs(loss.item() - loss_r) < 1e-2 * max(1.0, abs(loss_r)), (loss.item(), loss_r)
+        gmax = max(nrm for _, _, nrm in table)
+        for k, e, nrm in table:
+            if nrm > 1e-4 * gmax:                     # gradients that are numerically zero carry no relative information
+                assert e < BF16_GRAD_REL, (k, e, nrm)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_c2_slice_full_depth_vs_oracle(dtype):
+    """BASELINE config C2 at full depth and width (n~100, L=8, d=512, H=8), 3 graphs: loss and EVERY parameter gradient
+    against the pinned oracle, fp32 and bf16."""
+    _check_slice("C2", 3, dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_c5_slice_full_depth_vs_oracle(dtype):
+    """BASELINE config C5 (300-node dense graphs, n~300: the long-key case) at full depth, one graph."""
+    _check_slice("C5", 1, dtype)
+
+
+def test_c3_slice_bf16_translator_flavour():
+    """Translator flavour (dependency trees, depth table 256, single path per pair) in bf16, full depth."""
+    _check_slice("C3", 3, torch.bfloat16)
+
+
+def _attention_fact_vs_dense(qkv, bankp, idx, pad, H, wout, p_drop=0.0):
+    """One relation-attention forward + backward on the factored and on the dense operand; returns both result sets."""
+    from gtos_amd import ops
+    n, B, d3 = qkv.shape
+    d = d3 // 3
+    res = []
+    for factored in (True, False):
+        q = qkv.clone().requires_grad_()
+        bp = bankp.clone().requires_grad_()
+        if factored:
+            fact = ops.FactoredRelation(torch.zeros(bankp.shape[0], 8, device=qkv.device), idx)
+            rel = bp
+        else:
+            fact = None
+            rel = bp.index_select(0, idx.reshape(-1)).view(n, n, B, 2 * d)
+        ops.set_seed(99)
+        o, _ = ops.attention_core(q, None, (0, d, 2 * d), d, H, (d // H) ** -0.5, rel=rel, fact=fact, key_pad=pad, p_drop=p_drop)
+        (o.float() * wout).sum().backward()
+        res.append((o.detach(), q.grad, bp.grad))
+    return res
+
+
+def test_c5_shape_attention_factored_equals_dense_fwd_bwd():
+    """n=301 keys per query (C5), d=512, H=8, bf16, with key padding and weight dropout: the factored operand must give
+    the dense operand's output and gradients (q/k/v bitwise-identical math; the bank gradient is the index_add of the
+    dense per-pair gradient, accumulated in fp32 instead of through bf16 pair rows)."""
+    n, B, d, H, R = 301, 4, 512, 8, 60000
+    g = torch.Generator().manual_seed(301)
+    qkv = torch.randn(n, B, 3 * d, generator=g).to(dev(), torch.bfloat16)
+    bankp = (0.3 * torch.randn(R, 2 * d, generator=g)).to(dev(), torch.bfloat16)
+    idx = torch.randint(0, R, (n, n, B), generator=g)
+    idx[0, :, :] = 1
+    idx[:, 0, :] = 0
+    idx = idx.to(dev())
+    pad = torch.zeros(n, B, dtype=torch.bool)
+    pad[250:, 1] = True
+    pad = pad.to(dev())
+    wout = torch.randn(n, B, d, generator=g).to(dev())
+    for p_drop in (0.0, 0.2):
+        (o_f, dq_f, db_f), (o_d, dq_d, db_d) = _attention_fact_vs_dense(qkv, bankp, idx, pad, H, wout, p_drop)
+        assert torch.equal(o_f, o_d)
+        torch.testing.assert_close(dq_f.float(), dq_d.float(), rtol=2e-2, atol=2e-3)
+        assert _rel_frob(db_f, db_d) < 1e-2
+        assert float(o_f[:, 1].float().abs().max()) > 0
+
+
+def test_c2_full_size_backward_properties_with_the_real_bank():
+    """The full C2 batch (n=101, B=64, d=512, H=8, bf16) with the type ids of the REAL synthetic batch (R = 434,624 types,
+    a handful of which -- <CLS>, <rCLS>, <SELF>, <TL> -- span thousands of chunks, the rest 1-2 pairs): the bank-gradient
+    kernel's heavy/light split at scale.  Properties: factored == dense for the output and dq/dk/dv; d_bank equals the
+    fp32 index_add of the dense operand's per-pair gradient; rows of types that never occur are exactly zero; the
+    gradient is linear in the upstream gradient."""
+    from gtos_amd import synth
+    batch, stats = synth.make_config_batch("C2")
+    idx = batch["relation"].to(dev())
+    n, _, B = idx.shape
+    d, H, R = 512, 8, stats["R"]
+    assert (n, B, R) == (101, 64, 434624)
+    g = torch.Generator().manual_seed(2)
+    qkv = torch.randn(n, B, 3 * d, generator=g).to(dev(), torch.bfloat16)
+    bankp = (0.3 * torch.randn(R + 7, 2 * d, generator=g)).to(dev(), torch.bfloat16)     # 7 trailing types never occur
+    wout = torch.randn(n, B, d, generator=g).to(dev())
+    (o_f, dq_f, db_f), (o_d, dq_d, db_d) = _attention_fact_vs_dense(qkv, bankp, idx, None, H, wout)
+    assert torch.equal(o_f, o_d)
+    torch.testing.assert_close(dq_f.float(), dq_d.float(), rtol=2e-2, atol=2e-3)
+    assert _rel_frob(db_f, db_d) < 1e-2
+    counts = torch.bincount(idx.reshape(-1), minlength=R + 7)
+    assert float(db_f[counts == 0].float().abs().max()) == 0.0
+    heavy = torch.nonzero(counts > 1000).flatten()
+    assert heavy.numel() >= 3                                   # <CLS>, <rCLS>, <SELF> (and <TL>)
+    assert _rel_frob(db_f[heavy], db_d[heavy]) < 1e-2
+    _, dq2, db2 = _attention_fact_vs_dense(qkv, bankp, idx, None, H, 2 * wout)[0]
+    torch.testing.assert_close(db2.float(), 2 * db_f.float(), rtol=2e-2, atol=1e-3)
+
+
+def test_relation_encoder_large_vocabulary_backward():
+    """A relation vocabulary whose embedding table does not fit the LDS scatter buffer (V*dim*4 > 60 KB): real AMR role
+    inventories with their `_reverse_` twins exceed the synthetic V=86.  Forward + every gradient against the oracle."""
+    from gtos_amd.encoder import RelationEncoder
+    from oracle import gtos_oracle as O
+    V, rel_dim = 260, 100
+    torch.manual_seed(8)
+    R, L = 300, 5
+    lengths = torch.randint(1, L + 1, (R,))
+    toks = torch.randint(1, V, (L, R))
+    for r in range(R):
+        toks[int(lengths[r]):, r] = 0
+    ref = O.RelationEncoder(O.VocabSpec(V, 0), rel_dim, 64, 32, 2, 0.0)
+    m = RelationEncoder(O.VocabSpec(V, 0), rel_dim, 64, 32, 2, 0.0).to(dev())
+    m.load_state_dict(ref.state_dict())
+    out_r = ref(toks, lengths)
+    out_r.square().sum().backward()
+    out_d = m(toks.to(dev()), lengths.to(dev()))
+    out_d.square().sum().backward()
+    torch.testing.assert_close(out_d.cpu(), out_r, **FP32)
+    for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        torch.testing.assert_close(p.grad.cpu(), q.grad, msg=lambda s_, k=k: "%s: %s" % (k, s_), **GRAD)
