@@ -130,7 +130,8 @@ def decode_bench(a):
     model.eval()
     batch, stats = synth.make_config_batch(a.config, train=False)
     B = stats["B"]
-    batch_dev = {k: v.to(dev) for k, v in batch.items()}
+    from gtos_amd.pathtrie import attach_path_trie
+    batch_dev = {k: v.to(dev) for k, v in attach_path_trie(batch).items()}
     batch_dev['local_idx2token'] = local_vocabs(batch)
     model.work(batch_dev, a.beam, 3)                       # warm-up
     torch.cuda.synchronize()
@@ -217,6 +218,8 @@ def main():
     log("model on device; generating batch")
     batch, stats = synth.make_config_batch(a.config, rank=rank)        # weak scaling: B graphs per GPU
     log("batch", stats)
+    from gtos_amd.pathtrie import attach_path_trie
+    attach_path_trie(batch)            # host-side index preparation, part of batch assembly like the relation bank itself
     batch = {k: v.to(dev) for k, v in batch.items()}
     ops.set_seed(19940117 + rank)
 

@@ -17,7 +17,7 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-HOST_SRC = os.path.join(os.path.dirname(CSRC), "csrc_host", "relbatch.cpp")
+HOST_SRCS = [os.path.join(os.path.dirname(CSRC), "csrc_host", f) for f in ("relbatch.cpp", "pathtrie.cpp")]
 HOST_LIB = os.path.join(os.path.dirname(CSRC), "csrc_host", "libgtos_host.so")
 CXX = os.environ.get("CXX", "g++")
 
@@ -25,8 +25,8 @@ CXX = os.environ.get("CXX", "g++")
 def build_host(force=False, verbose=True):
     """libgtos_host.so: the C++ graph -> relation-tensor path (include/gtos_host.h); plain g++, no GPU code."""
     hdr = os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "gtos_host.h")
-    if force or _stale(HOST_LIB, [HOST_SRC, hdr]):
-        cmd = [CXX, "-O3", "-std=c++17", "-shared", "-fPIC", "-pthread", HOST_SRC, "-o", HOST_LIB]
+    if force or _stale(HOST_LIB, HOST_SRCS + [hdr]):
+        cmd = [CXX, "-O3", "-std=c++17", "-shared", "-fPIC", "-pthread"] + HOST_SRCS + ["-o", HOST_LIB]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -33,7 +33,8 @@ __device__ __forceinline__ int lds_off(int r, int c) { return r * ROWB + ((c ^ s
 struct StepArgs {
     const bf16_t* x; int64_t ldx; int in_dim; const bf16_t* w_ih; const float* b_ih;
     const bf16_t* xg;
-    const bf16_t* h_in; const bf16_t* w_hh; const float* b_hh;
+    const bf16_t* gf; const int* gf_idx; const bf16_t* gb; const int* gb_idx;     // MODE 2: xg = gf[gf_idx[m]] + gb[gb_idx[m]] + b_ih
+    const bf16_t* h_in; const int* h_idx; const bf16_t* w_hh; const float* b_hh;   // h_idx: row m enters with h_in[h_idx[m]]
     bf16_t* h_out; int n_out; bf16_t* h_fin; bf16_t* gates; bf16_t* y; int64_t ldy;
     float p_drop; uint64_t seed; int64_t drop_base;
     int rows, hs; const void* zeros;
@@ -41,14 +42,16 @@ struct StepArgs {
 
 // 128 activation rows x 64 k
 __device__ __forceinline__ void dma_rows(const bf16_t* __restrict__ base, const U128* __restrict__ zeros, int64_t ld, int rows_total,
-                                         int row0, int k0, int kend, char* tile, int wave, int lane) {
+                                         int row0, int k0, int kend, char* tile, int wave, int lane,
+                                         const int* __restrict__ gather = nullptr) {
 #pragma unroll
     for (int it = 0; it < TM / 32; ++it) {
         const int blk = it * 4 + wave, rl = blk * 8 + (lane >> 3);
         const int c = (lane & 7) ^ swz(rl);
         const int r = row0 + rl, k = k0 + c * 8;
         const bool ok = r < rows_total && k + 8 <= kend;
-        const void* src = ok ? static_cast<const void*>(base + (int64_t)r * ld + k) : static_cast<const void*>(zeros);
+        const int64_t sr = (gather && ok) ? gather[r] : r;             // optional row gather (trie parent / state row)
+        const void* src = ok ? static_cast<const void*>(base + sr * ld + k) : static_cast<const void*>(zeros);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(tile + blk * 1024), 16, 0, 0);
     }
@@ -112,8 +115,10 @@ __device__ __forceinline__ void ldf16(const float* p, float (&v)[16]) {
     }
 }
 
-template <bool HAS_X>
+// MODE 0: input gates read from xg; 1: x W_ih^T computed here (HAS_X); 2: input gates gathered from two bf16 tables
+template <int MODE>
 __global__ __launch_bounds__(256, 2) void gru_step_fwd_kernel(StepArgs a) {
+    constexpr bool HAS_X = MODE == 1;
     constexpr int NG = HAS_X ? 4 : 3;           // accumulator groups: r, z, (n_x,) n_h
     constexpr int GH = HAS_X ? 3 : 2;           // group of the h-part of n
     __shared__ __attribute__((aligned(16))) char lds[A_BYTES + B_BYTES];
@@ -143,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void gru_step_fwd_kernel(StepArgs a) {
         }
     }
     for (int k0 = 0; k0 < a.hs; k0 += BK) {
-        dma_rows(a.h_in, Z, a.hs, a.rows, m0, k0, a.hs, As, wave, lane);
+        dma_rows(a.h_in, Z, a.hs, a.rows, m0, k0, a.hs, As, wave, lane, a.h_idx);
         dma_weights(a.w_hh, Z, a.hs, a.hs, c0, k0, a.hs, Bs, wave, lane);
         __syncthreads();
         mma_tile<NG, GH>(As, Bs, wave * 32, fr, fq, acc);
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void gru_step_fwd_kernel(StepArgs a) {
     const int cb = c0 + fq * 16, hs = a.hs;
     float bhr[16], bhz[16], bhn[16];
     ldf16(a.b_hh + cb, bhr); ldf16(a.b_hh + hs + cb, bhz); ldf16(a.b_hh + 2 * hs + cb, bhn);
-    if constexpr (HAS_X) {
+    if constexpr (MODE != 0) {                   // b_ih of r and z joins b_hh; the n part is added to the input-side term below
         float t[16];
         ldf16(a.b_ih + cb, t);
 #pragma unroll
@@ -173,11 +178,27 @@ __global__ __launch_bounds__(256, 2) void gru_step_fwd_kernel(StepArgs a) {
             ldf16(a.b_ih + 2 * hs + cb, xn);
 #pragma unroll
             for (int i = 0; i < 16; ++i) { xr[i] = 0.f; xz[i] = 0.f; xn[i] += acc[mt][8 + (i >> 2)][i & 3]; }
+        } else if constexpr (MODE == 2) {
+            const bf16_t* fp = a.gf + (int64_t)a.gf_idx[m] * 3 * hs + cb;
+            const bf16_t* bp = a.gb + (int64_t)a.gb_idx[m] * 3 * hs + cb;
+            float t[16];
+            ld16(fp, xr); ld16(bp, t);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) xr[i] += t[i];
+            ld16(fp + hs, xz); ld16(bp + hs, t);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) xz[i] += t[i];
+            ld16(fp + 2 * hs, xn); ld16(bp + 2 * hs, t);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) xn[i] += t[i];
+            ldf16(a.b_ih + 2 * hs + cb, t);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) xn[i] += t[i];
         } else {
             const bf16_t* xp = a.xg + (int64_t)m * 3 * hs + cb;
             ld16(xp, xr); ld16(xp + hs, xz); ld16(xp + 2 * hs, xn);
         }
-        ld16(a.h_in + (int64_t)m * hs + cb, hp);
+        ld16(a.h_in + (int64_t)(a.h_idx ? a.h_idx[m] : m) * hs + cb, hp);
         float gr[16], gz[16], gn[16], hn[16], o[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -216,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void gru_step_fwd_kernel(StepArgs a) {
 // (wave DPP reduction over the 16 rows of a lane group -> LDS -> one fp32 atomic per (gate, channel) and workgroup).
 struct StepBwdArgs {
     const bf16_t* d4_prev; int rows_prev; const bf16_t* wh_t;
-    const bf16_t* gates; const bf16_t* hprev; const bf16_t* dy; int64_t ldy;
+    const bf16_t* gates; const bf16_t* hprev; const int* hprev_idx; const bf16_t* dy; int64_t ldy;
     void* dh; int dh_bf16; bf16_t* d4; float* bias_part; int n_partials;
     float p_drop; uint64_t seed; int64_t drop_base;
     int rows, hs; const void* zeros;
@@ -299,7 +320,7 @@ __global__ __launch_bounds__(256, 3) void gru_step_bwd_kernel(StepBwdArgs a) {
         float gr[16], gz[16], gn[16], hn[16], hp[16], g[16];
         const bf16_t* gp = a.gates + (int64_t)m * 4 * hs + cb;
         ld16(gp, gr); ld16(gp + hs, gz); ld16(gp + 2 * hs, gn); ld16(gp + 3 * hs, hn);
-        ld16(a.hprev + (int64_t)m * hs + cb, hp);
+        ld16(a.hprev + (int64_t)(a.hprev_idx ? a.hprev_idx[m] : m) * hs + cb, hp);
         float* dhp = static_cast<float*>(a.dh) + (int64_t)m * hs + cb;
         bf16_t* dhb = static_cast<bf16_t*>(a.dh) + (int64_t)m * hs + cb;
         if (a.dh_bf16) ld16(dhb, g); else ldf16(dhp, g);
@@ -363,22 +384,27 @@ __global__ __launch_bounds__(256, 3) void gru_step_bwd_kernel(StepBwdArgs a) {
 }  // namespace
 
 extern "C" int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, int in_dim, const void* w_ih, const float* b_ih,
-                                 const void* xg, const void* h_in, const void* w_hh, const float* b_hh,
+                                 const void* xg, const void* gf, const int* gf_idx, const void* gb, const int* gb_idx,
+                                 const void* h_in, const int* h_idx, const void* w_hh, const float* b_hh,
                                  void* h_out, int n_out, void* h_fin, void* gates, void* y, int64_t ldy,
                                  float p_drop, uint64_t seed, int64_t drop_base, void* stream) {
     if (rows <= 0) return 0;
     if (hs <= 0 || hs % TC) return -22;
     if (!h_in || !w_hh || !b_hh || !gates) return -23;
     if ((n_out > 0 && !h_out) || (n_out < rows && !h_fin)) return -23;
-    if (x) {
+    const int mode = x ? 1 : (gf ? 2 : 0);
+    if (mode == 1) {
         if (!w_ih || !b_ih || in_dim <= 0 || in_dim % 8 || ldx % 8 || (uintptr_t)x % 16 || (uintptr_t)w_ih % 16) return -24;
+    } else if (mode == 2) {
+        if (!gb || !gf_idx || !gb_idx || !b_ih || (uintptr_t)gf % 16 || (uintptr_t)gb % 16) return -24;
     } else if (!xg || (uintptr_t)xg % 16) return -24;
     if ((uintptr_t)h_in % 16 || (uintptr_t)w_hh % 16 || (uintptr_t)gates % 16 || (uintptr_t)h_out % 16 || (uintptr_t)h_fin % 16 ||
         (uintptr_t)b_hh % 16 || (uintptr_t)b_ih % 16) return -25;
     if (y && ((uintptr_t)y % 16 || ldy % 8)) return -25;
     StepArgs a;
     a.x = (const bf16_t*)x; a.ldx = ldx; a.in_dim = in_dim; a.w_ih = (const bf16_t*)w_ih; a.b_ih = b_ih; a.xg = (const bf16_t*)xg;
-    a.h_in = (const bf16_t*)h_in; a.w_hh = (const bf16_t*)w_hh; a.b_hh = b_hh;
+    a.gf = (const bf16_t*)gf; a.gf_idx = gf_idx; a.gb = (const bf16_t*)gb; a.gb_idx = gb_idx;
+    a.h_in = (const bf16_t*)h_in; a.h_idx = h_idx; a.w_hh = (const bf16_t*)w_hh; a.b_hh = b_hh;
     a.h_out = (bf16_t*)h_out; a.n_out = n_out; a.h_fin = (bf16_t*)h_fin; a.gates = (bf16_t*)gates; a.y = (bf16_t*)y; a.ldy = ldy;
     a.p_drop = p_drop; a.seed = seed; a.drop_base = drop_base; a.rows = rows; a.hs = hs;
     a.zeros = gtos_zero_block();
@@ -387,14 +413,15 @@ extern "C" int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, i
     const long long nblk = ((nM + 7) / 8) * 8 * nC;
     if (nblk > 0x7fffffffLL) return -6;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (x) hipLaunchKernelGGL(gru_step_fwd_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, s, a);
-    else   hipLaunchKernelGGL(gru_step_fwd_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, s, a);
+    if (mode == 1) hipLaunchKernelGGL(gru_step_fwd_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, s, a);
+    else if (mode == 2) hipLaunchKernelGGL(gru_step_fwd_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(gru_step_fwd_kernel<0>, dim3((unsigned)nblk), dim3(256), 0, s, a);
     GTOS_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int gtos_gru_step_bwd(int rows, int hs, const void* d4_prev, int rows_prev, const void* w_hh_t,
-                                 const void* gates, const void* hprev, const void* dy, int64_t ldy, void* dh, int dh_dtype,
+                                 const void* gates, const void* hprev, const int* hprev_idx, const void* dy, int64_t ldy, void* dh, int dh_dtype,
                                  void* d4, float p_drop, uint64_t seed, int64_t drop_base, float* bias_partials,
                                  int n_partials, void* stream) {
     if (rows <= 0) return 0;
@@ -405,7 +432,7 @@ extern "C" int gtos_gru_step_bwd(int rows, int hs, const void* d4_prev, int rows
         (uintptr_t)d4 % 16 || (dy && ((uintptr_t)dy % 16 || ldy % 8))) return -25;
     StepBwdArgs a;
     a.d4_prev = (const bf16_t*)d4_prev; a.rows_prev = d4_prev ? rows_prev : 0; a.wh_t = (const bf16_t*)w_hh_t;
-    a.gates = (const bf16_t*)gates; a.hprev = (const bf16_t*)hprev; a.dy = (const bf16_t*)dy; a.ldy = ldy;
+    a.gates = (const bf16_t*)gates; a.hprev = (const bf16_t*)hprev; a.hprev_idx = hprev_idx; a.dy = (const bf16_t*)dy; a.ldy = ldy;
     a.dh = dh; a.dh_bf16 = dh_dtype == GTOS_BF16; a.d4 = (bf16_t*)d4; a.bias_part = bias_partials; a.n_partials = n_partials;
     a.p_drop = p_drop; a.seed = seed; a.drop_base = drop_base; a.rows = rows; a.hs = hs;
     a.zeros = gtos_zero_block();

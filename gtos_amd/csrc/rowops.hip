@@ -417,6 +417,108 @@ __global__ __launch_bounds__(256) void embed_rows_bwd_kernel(int64_t n, int V, i
     }
 }
 
+// =========================================================================== segmented row sums (trie GRU backward)
+// dst[node, 0:W] = sum over the node's rows of src[row, 0:W]  (bf16 rows, fp32 accumulation, one rounding).  The rows of a
+// node are entries [start, start+cnt) of `rows` (or the consecutive rows start.. when rows == NULL); a node with several
+// chunks ("heavy": a trie node near the root is the prefix of thousands of paths) accumulates its chunks with fp32 atomics
+// in heavy[slot, 0:W] and is written by seg_finish_kernel.  One WAVE per chunk: a lane owns 8 channels of each 512-channel
+// slab, so a row is read with 1 KB coalesced wave loads; four row loads are in flight per lane.
+template <int SLABS>
+__global__ __launch_bounds__(256) void seg_sum_kernel(int n_chunks, const int* __restrict__ rows, const int* __restrict__ chunk_node,
+                                                      const int* __restrict__ chunk_start, const int* __restrict__ chunk_cnt,
+                                                      const int* __restrict__ chunk_slot, const bf16_t* __restrict__ src, int64_t ld_src,
+                                                      int W, bf16_t* __restrict__ dst, int64_t ld_dst, float* __restrict__ heavy) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= n_chunks) return;
+    const int node = chunk_node[c], start = chunk_start[c], cnt = chunk_cnt[c];
+    float acc[SLABS][8];
+#pragma unroll
+    for (int sl = 0; sl < SLABS; ++sl)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[sl][e] = 0.f;
+    for (int i0 = 0; i0 < cnt; i0 += 4) {
+        int64_t r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = min(i0 + u, cnt - 1);
+            r[u] = rows ? rows[start + i] : start + i;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + u < cnt) {
+#pragma unroll
+                for (int sl = 0; sl < SLABS; ++sl) {
+                    const int ch = sl * 512 + lane * 8;
+                    if (ch < W) {
+                        float v[8];
+                        Vec8<bf16_t>::load(src + r[u] * ld_src + ch, v);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[sl][e] += v[e];
+                    }
+                }
+            }
+        }
+    }
+    const int slot = chunk_slot ? chunk_slot[c] : -1;
+#pragma unroll
+    for (int sl = 0; sl < SLABS; ++sl) {
+        const int ch = sl * 512 + lane * 8;
+        if (ch < W) {
+            if (slot < 0) {
+                Vec8<bf16_t>::store(dst + (int64_t)node * ld_dst + ch, acc[sl]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) atomicAdd(heavy + (int64_t)slot * W + ch + e, acc[sl][e]);
+            }
+        }
+    }
+}
+
+// contiguous variant: segment s sums the consecutive rows ranges[2s] .. ranges[2s+1]-1 (the children of a trie node) into
+// dst row s; an empty range writes zeros
+template <int SLABS>
+__global__ __launch_bounds__(256) void seg_sum_range_kernel(int n_seg, const int* __restrict__ ranges, const bf16_t* __restrict__ src,
+                                                            int64_t ld_src, int W, bf16_t* __restrict__ dst, int64_t ld_dst) {
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= n_seg) return;
+    const int lo = ranges[2 * s], hi = ranges[2 * s + 1];
+    float acc[SLABS][8];
+#pragma unroll
+    for (int sl = 0; sl < SLABS; ++sl)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[sl][e] = 0.f;
+    for (int64_t r = lo; r < hi; ++r) {
+#pragma unroll
+        for (int sl = 0; sl < SLABS; ++sl) {
+            const int ch = sl * 512 + lane * 8;
+            if (ch < W) {
+                float v[8];
+                Vec8<bf16_t>::load(src + r * ld_src + ch, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[sl][e] += v[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int sl = 0; sl < SLABS; ++sl) {
+        const int ch = sl * 512 + lane * 8;
+        if (ch < W) Vec8<bf16_t>::store(dst + (int64_t)s * ld_dst + ch, acc[sl]);
+    }
+}
+
+__global__ void seg_finish_kernel(int n_heavy, const int* __restrict__ heavy_node, const float* __restrict__ heavy, int W,
+                                  bf16_t* __restrict__ dst, int64_t ld_dst) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int vpr = W / 8;
+    if (t >= (int64_t)n_heavy * vpr) return;
+    const int s = (int)(t / vpr), ch = (int)(t % vpr) * 8;
+    float v[8];
+    Vec8<float>::load(heavy + (int64_t)s * W + ch, v);
+    Vec8<bf16_t>::store(dst + (int64_t)heavy_node[s] * ld_dst + ch, v);
+}
+
 // =========================================================================== optimizer (flat buffers)
 // sum of squares of g (for clip_grad_norm_, /root/reference/generator/train.py:151)
 __global__ __launch_bounds__(256) void sqnorm_kernel(int64_t n, const float* __restrict__ g, float* __restrict__ out) {
@@ -582,6 +684,48 @@ extern "C" int gtos_embed_rows_bwd(int dtype, int64_t n, int V, int dim, int dim
     return 0;
 }
 
+extern "C" int gtos_segment_sum_rows(int n_chunks, const int* rows, const int* chunk_node, const int* chunk_start, const int* chunk_cnt,
+                                     const int* chunk_slot, const void* src, int64_t ld_src, int width, void* dst, int64_t ld_dst,
+                                     float* heavy, void* stream) {
+    if (n_chunks <= 0) return 0;
+    if (width <= 0 || width % 8 || width > 1536 || ld_src % 8 || ld_dst % 8 || (uintptr_t)src % 16 || (uintptr_t)dst % 16) return -24;
+    if (!chunk_node || !chunk_start || !chunk_cnt || !src || !dst || (chunk_slot && !heavy)) return -23;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)((n_chunks + 3) / 4)), block(256);
+#define GTOS_SEG(S) hipLaunchKernelGGL(seg_sum_kernel<S>, grid, block, 0, s, n_chunks, rows, chunk_node, chunk_start, chunk_cnt, chunk_slot, \
+                                       (const bf16_t*)src, ld_src, width, (bf16_t*)dst, ld_dst, heavy)
+    if (width <= 512) GTOS_SEG(1); else if (width <= 1024) GTOS_SEG(2); else GTOS_SEG(3);
+#undef GTOS_SEG
+    GTOS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gtos_segment_sum_finish(int n_heavy, const int* heavy_node, const float* heavy, int width, void* dst, int64_t ld_dst,
+                                       void* stream) {
+    if (n_heavy <= 0) return 0;
+    if (width <= 0 || width % 8 || ld_dst % 8 || !heavy_node || !heavy || !dst) return -24;
+    const int64_t n = (int64_t)n_heavy * (width / 8);
+    hipLaunchKernelGGL(seg_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), n_heavy,
+                       heavy_node, heavy, width, (bf16_t*)dst, ld_dst);
+    GTOS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gtos_segment_sum_ranges(int n_seg, const int* ranges, const void* src, int64_t ld_src, int width, void* dst, int64_t ld_dst,
+                                       void* stream) {
+    if (n_seg <= 0) return 0;
+    if (width <= 0 || width % 8 || width > 1536 || ld_src % 8 || ld_dst % 8 || (uintptr_t)src % 16 || (uintptr_t)dst % 16) return -24;
+    if (!ranges || !src || !dst) return -23;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)((n_seg + 3) / 4)), block(256);
+#define GTOS_SEG(S) hipLaunchKernelGGL(seg_sum_range_kernel<S>, grid, block, 0, s, n_seg, ranges, (const bf16_t*)src, ld_src, width, \
+                                       (bf16_t*)dst, ld_dst)
+    if (width <= 512) GTOS_SEG(1); else if (width <= 1024) GTOS_SEG(2); else GTOS_SEG(3);
+#undef GTOS_SEG
+    GTOS_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int gtos_sqnorm(int64_t n, const float* g, float* out, void* stream) {
     if (n <= 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -609,4 +753,4 @@ extern "C" int gtos_cast_f32_to_bf16(int64_t n, const float* src, void* dst, voi
     return 0;
 }
 
-extern "C" int gtos_abi_version(void) { return 5; }
+extern "C" int gtos_abi_version(void) { return 6; }

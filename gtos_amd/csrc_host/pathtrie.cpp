@@ -1,0 +1,268 @@
+// libgtos_host.so, second half: the prefix / suffix tries of a batch's relation bank (include/gtos_host.h).
+//
+// The relation bank of a batch (generator/data.py:166-176: relation_bank[L,R], relation_length[R]) is a set of label
+// paths out of BFS trees, so it is (almost) prefix- and suffix-closed: R paths with sum(len) = 5.7 R tokens have only ~R
+// distinct prefixes and ~1.05 R distinct suffixes.  The first GRU layer of RelationEncoder (generator/encoder.py:93-111)
+// in the forward direction depends only on the prefix read so far, in the reverse direction only on the suffix, so it
+// is evaluated once per TRIE NODE; and the second layer's input-gate product splits into a prefix-node term plus a
+// suffix-node term (gtos_amd/gru.py).  This file builds, in O(sum(len)) after one sort per trie:
+//   * the packed sequence order of the second layer (length descending, then lexicographic),
+//   * both tries, level-major (level k = prefixes / suffixes of k+1 tokens), nodes of a level in lexicographic order, so
+//     the children of a node are a contiguous range of the next level,
+//   * the node of every packed row (sequence s, position t) in both tries,
+//   * the rows of every node (CSR), cut into chunks of <= `chunk` rows for the segmented gradient reduction.
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <numeric>
+#include <thread>
+#include <vector>
+
+#include "../../include/gtos_host.h"
+
+namespace {
+
+struct Trie {
+    int64_t n_nodes = 0;
+    std::vector<int64_t> level_off;          // [L+1]
+    std::vector<int32_t> tok, par;           // per node; par = n_nodes for level-0 nodes (the all-zero state row)
+    std::vector<int32_t> child_off;          // [2*n_nodes]: children of node u are nodes child_off[2u] .. child_off[2u+1]-1
+    std::vector<int32_t> node_of;            // [R*L]: node of sequence s at level k (or -1)
+    // rows of every node, chunked
+    std::vector<int32_t> rows;               // [N] packed rows sorted by node
+    std::vector<int32_t> chunk_node, chunk_start, chunk_cnt, chunk_slot, heavy_node;
+};
+
+struct Seqs {
+    int L = 0;
+    int64_t R = 0;
+    std::vector<int32_t> tok;                // [R*L] row-major per sequence, 0-padded
+    std::vector<int32_t> len;                // [R]
+};
+
+// lexicographic order of the sequences (a proper prefix sorts first); stable in the sequence id
+std::vector<int32_t> lex_order(const Seqs& q) {
+    std::vector<int32_t> idx(q.R);
+    std::iota(idx.begin(), idx.end(), 0);
+    const int L = q.L;
+    bool small = L <= 8;
+    if (small)
+        for (int64_t i = 0; i < q.R * L && small; ++i) small = q.tok[i] >= 0 && q.tok[i] < 255;
+    if (small) {
+        // pack (token + 1) bytes, most significant first: integer order == lexicographic order with "shorter first"
+        std::vector<uint64_t> key(q.R);
+        for (int64_t s = 0; s < q.R; ++s) {
+            uint64_t k = 0;
+            for (int t = 0; t < 8; ++t) k = (k << 8) | (uint64_t)((t < L && t < q.len[s]) ? q.tok[s * L + t] + 1 : 0);
+            key[s] = k;
+        }
+        std::stable_sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b) { return key[a] < key[b]; });
+    } else {
+        std::stable_sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b) {
+            const int la = q.len[a], lb = q.len[b], m = la < lb ? la : lb;
+            for (int t = 0; t < m; ++t) {
+                const int32_t x = q.tok[(int64_t)a * L + t], y = q.tok[(int64_t)b * L + t];
+                if (x != y) return x < y;
+            }
+            return la < lb;
+        });
+    }
+    return idx;
+}
+
+void build_trie(const Seqs& q, const std::vector<int32_t>& order, Trie& tr) {
+    const int L = q.L;
+    const int64_t R = q.R;
+    tr.node_of.assign(R * L, -1);
+    tr.level_off.assign(L + 1, 0);
+    tr.tok.clear();
+    tr.par.clear();
+    int64_t next = 0;
+    for (int k = 0; k < L; ++k) {
+        tr.level_off[k] = next;
+        int32_t prev_seq = -1;
+        for (int64_t i = 0; i < R; ++i) {
+            const int32_t s = order[i];
+            if (q.len[s] <= k) continue;
+            bool fresh = prev_seq < 0;
+            if (!fresh) {
+                // same node as the previous sequence of this level iff same parent node and same token
+                const int32_t pa = k ? tr.node_of[(int64_t)prev_seq * L + k - 1] : -1, pb = k ? tr.node_of[(int64_t)s * L + k - 1] : -1;
+                fresh = pa != pb || q.tok[(int64_t)prev_seq * L + k] != q.tok[(int64_t)s * L + k];
+            }
+            if (fresh) {
+                tr.tok.push_back(q.tok[(int64_t)s * L + k]);
+                tr.par.push_back(k ? tr.node_of[(int64_t)s * L + k - 1] : -1);
+                ++next;
+            }
+            tr.node_of[(int64_t)s * L + k] = (int32_t)(next - 1);
+            prev_seq = s;
+        }
+    }
+    tr.level_off[L] = next;
+    tr.n_nodes = next;
+    for (auto& p : tr.par)
+        if (p < 0) p = (int32_t)next;                      // level 0: the extra all-zero row behind the last node
+    // children of a node: a contiguous range of the next level (nodes of a level are sorted by parent, then token);
+    // stored as [start, end) pairs, start == end for leaves
+    tr.child_off.assign(2 * next, 0);
+    for (int64_t v = 0; v < next; ++v) {
+        const int64_t p = tr.par[v];
+        if (p >= next) continue;
+        if (tr.child_off[2 * p + 1] == 0) tr.child_off[2 * p] = (int32_t)v;
+        tr.child_off[2 * p + 1] = (int32_t)(v + 1);
+    }
+}
+
+// rows of every node (counting sort by node), cut into chunks
+void build_rows(const std::vector<int32_t>& row_node, int64_t n_nodes, int chunk, Trie& tr) {
+    const int64_t N = (int64_t)row_node.size();
+    std::vector<int64_t> off(n_nodes + 1, 0);
+    for (int64_t p = 0; p < N; ++p) off[row_node[p] + 1]++;
+    for (int64_t u = 0; u < n_nodes; ++u) off[u + 1] += off[u];
+    tr.rows.resize(N);
+    {
+        std::vector<int64_t> cur(off.begin(), off.end() - 1);
+        for (int64_t p = 0; p < N; ++p) tr.rows[cur[row_node[p]]++] = (int32_t)p;
+    }
+    tr.chunk_node.clear(); tr.chunk_start.clear(); tr.chunk_cnt.clear(); tr.chunk_slot.clear(); tr.heavy_node.clear();
+    for (int64_t u = 0; u < n_nodes; ++u) {
+        const int64_t lo = off[u], hi = off[u + 1];
+        const int64_t nch = hi > lo ? (hi - lo + chunk - 1) / chunk : 1;      // a node without rows still gets a (zero) result
+        int32_t slot = -1;
+        if (nch > 1) {
+            slot = (int32_t)tr.heavy_node.size();
+            tr.heavy_node.push_back((int32_t)u);
+        }
+        for (int64_t c = 0; c < nch; ++c) {
+            const int64_t s = lo + c * chunk;
+            tr.chunk_node.push_back((int32_t)u);
+            tr.chunk_start.push_back((int32_t)s);
+            tr.chunk_cnt.push_back((int32_t)std::max<int64_t>(0, std::min<int64_t>(chunk, hi - s)));
+            tr.chunk_slot.push_back(slot);
+        }
+    }
+}
+
+}  // namespace
+
+struct gtos_pathtrie {
+    int L = 0;
+    int64_t R = 0, N = 0;
+    std::vector<int32_t> batch_sizes;        // [L]
+    std::vector<int32_t> seq_order, seq_pos; // sorted position -> sequence id, sequence id -> sorted position
+    std::vector<int32_t> row_pf, row_sf;     // [N]
+    Trie pf, sf;
+};
+
+extern "C" gtos_pathtrie* gtos_pathtrie_build(int L, int64_t R, const int64_t* bank, const int64_t* length, int chunk) {
+    if (L <= 0 || R <= 0 || !bank || !length || chunk <= 0 || R > 0x7fffffffLL / (L > 0 ? L : 1)) return nullptr;
+    Seqs fw, bw;
+    fw.L = bw.L = L;
+    fw.R = bw.R = R;
+    fw.tok.assign(R * L, 0);
+    bw.tok.assign(R * L, 0);
+    fw.len.resize(R);
+    bw.len.resize(R);
+    int64_t N = 0;
+    int maxlen = 0;
+    for (int64_t s = 0; s < R; ++s) {
+        const int64_t l = length[s];
+        if (l < 1 || l > L) return nullptr;
+        fw.len[s] = bw.len[s] = (int32_t)l;
+        N += l;
+        maxlen = std::max<int>(maxlen, (int)l);
+        for (int t = 0; t < l; ++t) {
+            const int64_t v = bank[(int64_t)t * R + s];
+            if (v < 0 || v > 0x7fffffff) return nullptr;
+            fw.tok[s * L + t] = (int32_t)v;
+            bw.tok[s * L + (l - 1 - t)] = (int32_t)v;
+        }
+    }
+    if (N > 0x7fffffffLL) return nullptr;
+    auto* h = new gtos_pathtrie();
+    h->L = maxlen;
+    h->R = R;
+    h->N = N;
+    std::vector<int32_t> ord_f, ord_b;
+    std::thread tb([&] { ord_b = lex_order(bw); build_trie(bw, ord_b, h->sf); });
+    ord_f = lex_order(fw);
+    build_trie(fw, ord_f, h->pf);
+    tb.join();
+    // packed order: length descending, then lexicographic
+    std::vector<int32_t> rank(R);
+    for (int64_t i = 0; i < R; ++i) rank[ord_f[i]] = (int32_t)i;
+    h->seq_order.resize(R);
+    std::iota(h->seq_order.begin(), h->seq_order.end(), 0);
+    std::stable_sort(h->seq_order.begin(), h->seq_order.end(), [&](int32_t a, int32_t b) {
+        if (fw.len[a] != fw.len[b]) return fw.len[a] > fw.len[b];
+        return rank[a] < rank[b];
+    });
+    h->seq_pos.resize(R);
+    for (int64_t i = 0; i < R; ++i) h->seq_pos[h->seq_order[i]] = (int32_t)i;
+    h->batch_sizes.assign(maxlen, 0);
+    for (int64_t s = 0; s < R; ++s)
+        for (int t = 0; t < fw.len[s]; ++t) h->batch_sizes[t]++;
+    std::vector<int64_t> offs(maxlen + 1, 0);
+    for (int t = 0; t < maxlen; ++t) offs[t + 1] = offs[t] + h->batch_sizes[t];
+    h->row_pf.resize(N);
+    h->row_sf.resize(N);
+    for (int64_t m = 0; m < R; ++m) {
+        const int32_t s = h->seq_order[m];
+        const int l = fw.len[s];
+        for (int t = 0; t < l; ++t) {
+            const int64_t p = offs[t] + m;               // rows of step t are the first batch_sizes[t] sequences of the order
+            h->row_pf[p] = h->pf.node_of[(int64_t)s * L + t];
+            h->row_sf[p] = h->sf.node_of[(int64_t)s * L + (l - 1 - t)];
+        }
+    }
+    std::thread tr([&] { build_rows(h->row_sf, h->sf.n_nodes, chunk, h->sf); });
+    build_rows(h->row_pf, h->pf.n_nodes, chunk, h->pf);
+    tr.join();
+    // level offsets beyond the longest sequence collapse
+    h->pf.level_off.resize(maxlen + 1);
+    h->sf.level_off.resize(maxlen + 1);
+    h->pf.level_off[maxlen] = h->pf.n_nodes;
+    h->sf.level_off[maxlen] = h->sf.n_nodes;
+    return h;
+}
+
+// sizes[0..]: L, R, N, nPF, nSF, pf chunks, pf heavy, sf chunks, sf heavy
+extern "C" int gtos_pathtrie_sizes(const gtos_pathtrie* h, int64_t* sizes) {
+    if (!h || !sizes) return -1;
+    sizes[0] = h->L; sizes[1] = h->R; sizes[2] = h->N; sizes[3] = h->pf.n_nodes; sizes[4] = h->sf.n_nodes;
+    sizes[5] = (int64_t)h->pf.chunk_node.size(); sizes[6] = (int64_t)h->pf.heavy_node.size();
+    sizes[7] = (int64_t)h->sf.chunk_node.size(); sizes[8] = (int64_t)h->sf.heavy_node.size();
+    return 0;
+}
+
+namespace {
+template <typename V>
+void put(int32_t* dst, const V& v) { if (dst && !v.empty()) std::memcpy(dst, v.data(), v.size() * sizeof(int32_t)); }
+}
+
+extern "C" int gtos_pathtrie_export(const gtos_pathtrie* h, int32_t** out) {
+    if (!h || !out) return -1;
+    int k = 0;
+    put(out[k++], h->batch_sizes);
+    put(out[k++], h->seq_order);
+    put(out[k++], h->seq_pos);
+    put(out[k++], h->row_pf);
+    put(out[k++], h->row_sf);
+    for (const Trie* t : {&h->pf, &h->sf}) {
+        std::vector<int32_t> lo(t->level_off.begin(), t->level_off.end());
+        put(out[k++], lo);
+        put(out[k++], t->tok);
+        put(out[k++], t->par);
+        put(out[k++], t->child_off);
+        put(out[k++], t->rows);
+        put(out[k++], t->chunk_node);
+        put(out[k++], t->chunk_start);
+        put(out[k++], t->chunk_cnt);
+        put(out[k++], t->chunk_slot);
+        put(out[k++], t->heavy_node);
+    }
+    return k;
+}
+
+extern "C" void gtos_pathtrie_free(gtos_pathtrie* h) { delete h; }

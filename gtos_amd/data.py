@@ -10,6 +10,7 @@ in first-occurrence order.
 import torch
 
 from . import relbatch
+from .pathtrie import build_path_trie
 from .vocab import CLS, rCLS, SEL, TL, STR, END, lists_to_tensor, strings_to_char_tensor, copy_vocab
 
 
@@ -56,6 +57,7 @@ def batchify_dependency(trees, vocabs, n_threads=0, unk_rate=0., rng=None, repla
         'concept_char': strings_to_char_tensor(with_cls, vocabs['concept_char']),
         'concept_depth': lists_to_tensor([[0] + d for d in depths]),
         'relation': rel['relation'], 'relation_bank': rel['relation_bank'], 'relation_length': rel['relation_length'],
+        'relation_trie': build_path_trie(rel['relation_bank'], rel['relation_length']),   # index prep of the trie-evaluated GRU
         'local_idx2token': i2ts, 'local_token2idx': t2is,
         'token_in': lists_to_tensor(aug, vocabs['token'], unk_rate=unk_rate, rng=rng)[:-1],
         'token_char_in': strings_to_char_tensor(aug, vocabs['token_char'])[:-1],
@@ -172,6 +174,7 @@ def batchify_amr(items, vocabs, train=True, seed=0, n_threads=0, unk_rate=0., rn
         'concept_char': strings_to_char_tensor(with_cls, vocabs['concept_char']),
         'concept_depth': lists_to_tensor([[0] + list(x['depth']) for x in items]),
         'relation': rel['relation'], 'relation_bank': rel['relation_bank'], 'relation_length': rel['relation_length'],
+        'relation_trie': build_path_trie(rel['relation_bank'], rel['relation_length']),   # index prep of the trie-evaluated GRU
         'local_idx2token': i2ts, 'local_token2idx': t2is,
         'token_in': lists_to_tensor(aug, vocabs['token'], unk_rate=unk_rate, rng=rng)[:-1],
         'token_char_in': strings_to_char_tensor(aug, vocabs['token_char'])[:-1],

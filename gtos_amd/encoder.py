@@ -8,7 +8,9 @@ from torch import nn
 import torch.nn.functional as F
 
 from . import ops
-from .gru import bigru_final
+from . import gru as _gru
+from .gru import bigru_final, trie_bigru_final
+from .pathtrie import build_path_trie
 from .transformer import Embedding
 
 
@@ -49,7 +51,19 @@ class RelationEncoder(nn.Module):
                        getattr(self.rnn, "bias_ih_l%d%s" % (l, suf)), getattr(self.rnn, "bias_hh_l%d%s" % (l, suf))]
         return ws
 
-    def forward(self, src_tokens, src_lengths):
+    def forward(self, src_tokens, src_lengths, trie=None):
+        """``trie``: the batch's gtos_amd.pathtrie.PathTrie (``batch['relation_trie']``, built by the loader on the host
+        with the bank); when the trie path applies and none is given it is built here (a host round trip)."""
+        rel_dim = self.rel_embed.weight.shape[1]
+        pad = (-rel_dim) % 8                                                       # 16-byte rows for the GEMM
+        if (_gru.TRIE and self.compute_dtype == torch.bfloat16 and self.num_layers == 2 and self.hidden_size % 64 == 0
+                and src_tokens.is_cuda):
+            if trie is None or not trie.matches(src_tokens, src_lengths):
+                trie = build_path_trie(src_tokens, src_lengths).to(src_tokens.device)
+            p_e = self.dropout if self.training else 0.0
+            fin = trie_bigru_final(trie, self.rel_embed.weight, rel_dim + pad, p_e, self.hidden_size, p_e, self._weights(pad))
+            fin = ops.permute_rows(fin, trie.seq_pos, trie.seq_order)              # packed order -> bank order
+            return ops.linear(fin, self.out_proj.weight, self.out_proj.bias)
         seq_len, bsz = src_tokens.size()
         sorted_len, indices = torch.sort(src_lengths, descending=True, stable=True)
         toks = src_tokens.index_select(1, indices)                                  # [L, R] sorted
@@ -58,8 +72,6 @@ class RelationEncoder(nn.Module):
         while batch_sizes and batch_sizes[-1] == 0:
             batch_sizes.pop()
         packed = torch.cat([toks[t, :a] for t, a in enumerate(batch_sizes)])       # [N]
-        rel_dim = self.rel_embed.weight.shape[1]
-        pad = (-rel_dim) % 8                                                       # 16-byte rows for the GEMM
         x = ops.embed_rows(packed, self.rel_embed.weight, rel_dim + pad, self.dropout if self.training else 0.0,
                            self.compute_dtype)
         p = self.dropout if (self.training and self.num_layers > 1) else 0.0

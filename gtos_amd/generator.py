@@ -70,7 +70,7 @@ class Generator(nn.Module):
 
     def encode_step(self, inp, train=True):
         concept_repr, concept_mask = self._concepts(inp)
-        bank = self.relation_encoder(inp['relation_bank'], inp['relation_length'])           # [R, d]
+        bank = self.relation_encoder(inp['relation_bank'], inp['relation_length'], trie=inp.get('relation_trie'))   # [R, d]
         if train and self.grad_sync is not None:
             # everything downstream of these two belongs to gradient segments <= 2 (graph encoder, probe, decoders)
             concept_repr, bank = self.grad_sync.boundary(2, concept_repr, bank)
@@ -90,7 +90,7 @@ class Generator(nn.Module):
     def encoder_attn(self, inp):
         with torch.no_grad():
             concept_repr, concept_mask = self._concepts(inp)
-            bank = self.relation_encoder(inp['relation_bank'], inp['relation_length'])
+            bank = self.relation_encoder(inp['relation_bank'], inp['relation_length'], trie=inp.get('relation_trie'))
             relation = ops.relation_gather_mean(bank, inp['relation'], zero_row0=True)
             return self.graph_encoder.get_attn_weights(concept_repr, relation, self_padding_mask=concept_mask)
 

@@ -35,11 +35,20 @@ SIDE_STREAM = os.environ.get("GTOS_GRU_SIDE", "1") != "0"
 SIDE_MIN_ROWS = 200000          # below this the GEMMs are launch-bound and the stream hand-over costs more than it hides
 
 
-def _step_fwd(A, hs, x, xg, h_in, wi, b_ih, wh, b_hh, h_out, n_out, h_fin, gates, y, y_off_elems, ldy, p, seed, drop_base):
+def _step_fwd(A, hs, x, xg, h_in, wi, b_ih, wh, b_hh, h_out, n_out, h_fin, gates, y, y_off_elems, ldy, p, seed, drop_base,
+              h_idx=None, gf=None, gf_idx=None, gb=None, gb_idx=None):
     yp = None if y is None else y.data_ptr() + y_off_elems * y.element_size()
+    need_bi = x is not None or gf is not None
     call("gtos_gru_step_fwd", A, hs, ptr(x), 0 if x is None else x.stride(0), 0 if x is None else x.shape[1],
-         ptr(wi) if x is not None else None, ptr(b_ih) if x is not None else None, ptr(xg), ptr(h_in), ptr(wh), ptr(b_hh),
+         ptr(wi) if x is not None else None, ptr(b_ih) if need_bi else None, ptr(xg),
+         ptr(gf), ptr(gf_idx), ptr(gb), ptr(gb_idx), ptr(h_in), ptr(h_idx), ptr(wh), ptr(b_hh),
          ptr(h_out), n_out, ptr(h_fin), ptr(gates), yp, ldy, float(p), seed, drop_base, stream())
+
+
+def _step_bwd(A, hs, d4_prev, rows_prev, wh_t, gates, hprev, dy_ptr, ldy, dh, d4, p, seed, drop_base, bpart, hprev_idx=None):
+    call("gtos_gru_step_bwd", A, hs, ptr(d4_prev), rows_prev if d4_prev is not None else 0, ptr(wh_t), ptr(gates), ptr(hprev),
+         ptr(hprev_idx), dy_ptr, ldy, ptr(dh), dt(dh), ptr(d4), float(p), seed, drop_base,
+         ptr(bpart), N_BIAS_PARTIALS if bpart is not None else 0, stream())
 
 
 def _cell_bwd(A, hs, gates, hprev, dy, dy_off_elems, ldy, dh, dxg, dhg, p, seed, drop_base, bpart):
@@ -151,10 +160,9 @@ class BiGRUFinalFn(torch.autograd.Function):
                     for t in steps:
                         A, off = batch_sizes[t], offs[t]
                         dyp = None if dY is None else dY.data_ptr() + (off * 2 * hs + direction * hs) * dY.element_size()
-                        call("gtos_gru_step_bwd", A, hs, None if prev is None else ptr(d4[offs[prev]:]),
-                             0 if prev is None else batch_sizes[prev], ptr(wh_t), ptr(gates[off:off + A]), ptr(hprev[off:off + A]),
-                             dyp, 2 * hs, ptr(dh), dt(dh), ptr(d4[off:off + A]), float(pl), seed, off * 2 * hs + direction * hs,
-                             ptr(bpart), N_BIAS_PARTIALS, stream())
+                        _step_bwd(A, hs, None if prev is None else d4[offs[prev]:], 0 if prev is None else batch_sizes[prev], wh_t,
+                                  gates[off:off + A], hprev[off:off + A], dyp, 2 * hs, dh, d4[off:off + A], pl, seed,
+                                  off * 2 * hs + direction * hs, bpart)
                         prev = t
                     dxg = d4[:, :3 * hs]
                     w_jobs = ((w_hh, d4[:, :2 * hs], hprev, 1, slice(0, 2 * hs)), (w_hh, d4[:, 3 * hs:], hprev, 1, slice(2 * hs, 3 * hs)),
@@ -227,3 +235,221 @@ class BiGRUFinalFn(torch.autograd.Function):
 
 def bigru_final(x_packed, batch_sizes, hs, num_layers, p_drop, weights):
     return BiGRUFinalFn.apply(x_packed, tuple(batch_sizes), hs, num_layers, float(p_drop), *weights)
+
+
+# =====================================================================================================================
+# Trie-evaluated 2-layer bi-GRU (bf16).  Same function of its inputs as BiGRUFinalFn at dropout 0 / in eval mode:
+#   * layer 0, forward direction: the state after tokens 0..t of a path depends only on that PREFIX, so it is computed once
+#     per node of the prefix trie (level k = all distinct prefixes of k+1 tokens, one fused step launch per level, the parent
+#     state gathered by index); reverse direction: once per node of the SUFFIX trie.  The relation bank of a batch is
+#     (almost) prefix/suffix closed -- ~R nodes per trie instead of sum(len) = 5.7 R rows (csrc_host/pathtrie.cpp);
+#   * layer 1 (needs every (path, position) row: its input mixes a prefix state and a suffix state): the input-gate product
+#     x W_ih^T with x = [y0f(prefix node) ; y0b(suffix node)] splits into Gf[prefix node] + Gb[suffix node] with
+#     Gf = Y0f W_ih[:, :h]^T, Gb = Y0b W_ih[:, h:]^T computed once per trie node; the step kernel gathers the two rows.
+#   * backward mirrors it: the gradient of a shared node is the segmented sum over the rows / children that share it
+#     (gtos_segment_sum_*), then ordinary GEMMs on ~R rows.
+# With dropout > 0 (training) the embedding dropout and the inter-layer dropout masks are drawn per TRIE NODE and channel:
+# every path still sees independent Bernoulli(1-p) masks at each of its positions, exactly the reference's per-path
+# distribution; what changes is that two paths sharing a prefix (suffix) share the mask on the shared part, and that the two
+# directions draw separate embedding masks.  GTOS_GRU_TRIE=0 selects the per-row path above.
+TRIE = os.environ.get("GTOS_GRU_TRIE", "1") != "0"
+
+
+def _seg_rows(side, src, width, dst):
+    """dst[node] = sum of src rows of the node (row lists of the trie side), fp32 accumulation."""
+    heavy = torch.zeros((max(1, side.n_heavy), width), dtype=torch.float32, device=src.device)
+    call("gtos_segment_sum_rows", side.n_chunks, ptr(side.rows), ptr(side.chunk_node), ptr(side.chunk_start), ptr(side.chunk_cnt),
+         ptr(side.chunk_slot), ptr(src), src.stride(0), width, ptr(dst), dst.stride(0), ptr(heavy), stream())
+    call("gtos_segment_sum_finish", side.n_heavy, ptr(side.heavy_node), ptr(heavy), width, ptr(dst), dst.stride(0), stream())
+
+
+def _seg_ranges(n_seg, ranges, src, width, dst):
+    call("gtos_segment_sum_ranges", n_seg, ptr(ranges), ptr(src), src.stride(0), width, ptr(dst), dst.stride(0), stream())
+
+
+def _acc_weight_grad(grads, slot, wt, dy, x, rows=None, cols=None):
+    """(flat bucket view or grads[slot])[rows, cols] += dy^T x"""
+    if not wt.requires_grad:
+        return
+    tgt = _grad_target(wt)
+    if tgt is None:
+        if grads[slot] is None:
+            grads[slot] = torch.zeros(wt.shape, dtype=torch.float32, device=dy.device)
+        tgt = grads[slot]
+    if rows is not None:
+        tgt = tgt[rows]
+    if cols is not None:
+        tgt = tgt[:, cols]
+    gemm(dy, x, trans_a=True, out=tgt, accumulate=True, splitk=_splitk(dy.shape[1], x.shape[1], dy.shape[0]))
+
+
+def _acc_bias_grads(grads, base, b_ih, b_hh, bsum, hs):
+    for bt, slot in ((b_hh, 3), (b_ih, 2)):
+        if not bt.requires_grad:
+            continue
+        tgt = _grad_target(bt)
+        if tgt is None:
+            if grads[base + slot] is None:
+                grads[base + slot] = torch.zeros(bt.shape, dtype=torch.float32, device=bsum.device)
+            tgt = grads[base + slot]
+        tgt[:2 * hs] += bsum[:2 * hs]
+        tgt[2 * hs:] += bsum[2 * hs:3 * hs] if slot == 2 else bsum[3 * hs:]
+
+
+class TrieBiGRUFn(torch.autograd.Function):
+    """(trie, embedding table [V,dim], weights of a 2-layer bidirectional GRU) -> [R, 2*hs] final states of the top layer
+    in PACKED order (trie.seq_order).  weights as in BiGRUFinalFn; layer 0's w_ih zero-padded to dim_pad columns."""
+
+    @staticmethod
+    def forward(ctx, trie, table, dim_pad, p_embed, hs, p_layer, *weights):
+        dev, dtp = table.device, torch.bfloat16
+        L, R, N = trie.L, trie.R, trie.N
+        bs = trie.batch_sizes
+        offs = [0]
+        for a in bs:
+            offs.append(offs[-1] + a)
+        sides = (trie.pf, trie.sf)
+        dim = table.shape[1]
+        tab = table.detach()
+        # ---- layer 0 on the tries
+        l0 = []
+        for d, side in enumerate(sides):
+            n = side.n_nodes
+            w_ih, w_hh, b_ih, b_hh = weights[d * 4: d * 4 + 4]
+            wi, wh = compute_weight(w_ih, dtp), compute_weight(w_hh, dtp)
+            seed_e = next_seed() if p_embed > 0 else 0
+            seed_y = next_seed() if p_layer > 0 else 0
+            X = torch.empty((n, dim_pad), dtype=dtp, device=dev)
+            call("gtos_embed_rows_fwd", dt(X), n, dim, dim_pad, ptr(side.tok), ptr(tab), ptr(X), float(p_embed), seed_e, stream())
+            H = torch.empty((n + 1, hs), dtype=dtp, device=dev)
+            H[n].zero_()                                        # the state every level-0 node starts from
+            gates = torch.empty((n, 4 * hs), dtype=dtp, device=dev)
+            Y = torch.empty((n, hs), dtype=dtp, device=dev) if p_layer > 0 else None
+            bi, bh = b_ih.detach(), b_hh.detach()
+            for k in range(L):
+                lo, hi = side.level_off[k], side.level_off[k + 1]
+                if hi > lo:
+                    _step_fwd(hi - lo, hs, X[lo:hi], None, H, wi, bi, wh, bh, H[lo:hi], hi - lo, None, gates[lo:hi],
+                              Y, lo * hs, hs, p_layer, seed_y, lo * hs, h_idx=side.par[lo:hi])
+            l0.append((X, H, gates, Y, seed_e, seed_y, weight_t(w_ih, wi), weight_t(w_hh, wh)))
+        src = [l0[d][3] if p_layer > 0 else l0[d][1][:sides[d].n_nodes] for d in (0, 1)]
+        # ---- layer 1: per-node input-gate tables, then the recurrent steps over the packed rows
+        finals, l1 = [], []
+        for d in (0, 1):
+            w_ih, w_hh, b_ih, b_hh = weights[8 + d * 4: 8 + d * 4 + 4]
+            wi, wh = compute_weight(w_ih, dtp), compute_weight(w_hh, dtp)
+            Gf = gemm(src[0], wi[:, :hs], trans_b=True)         # [nodes of the prefix trie, 3hs]
+            Gb = gemm(src[1], wi[:, hs:], trans_b=True)         # [nodes of the suffix trie, 3hs]
+            gates = torch.empty((N, 4 * hs), dtype=dtp, device=dev)
+            hprev = torch.empty((N, hs), dtype=dtp, device=dev)
+            h = torch.empty((R, hs), dtype=dtp, device=dev)
+            bi, bh = b_ih.detach(), b_hh.detach()
+            if d == 0:
+                hprev[:R].zero_()
+            else:                                               # rows that become active at step t start from h = 0
+                for t in range(L):
+                    lo = bs[t + 1] if t + 1 < L else 0
+                    if bs[t] > lo:
+                        hprev[offs[t] + lo: offs[t] + bs[t]].zero_()
+            for t in (range(L) if d == 0 else range(L - 1, -1, -1)):
+                A, off = bs[t], offs[t]
+                nxt = t + 1 if d == 0 else t - 1
+                if 0 <= nxt < L:
+                    h_out, n_out = hprev[offs[nxt]:], min(A, bs[nxt])
+                else:
+                    h_out, n_out = h, A
+                _step_fwd(A, hs, None, None, hprev[off:off + A], None, bi, wh, bh, h_out, n_out, h, gates[off:off + A],
+                          None, 0, hs, 0.0, 0, 0, gf=Gf, gf_idx=trie.row_pf[off:off + A], gb=Gb, gb_idx=trie.row_sf[off:off + A])
+            finals.append(h)
+            l1.append((gates, hprev, wi, weight_t(w_hh, wh)))
+        ctx.cfg = (trie, table, dim_pad, p_embed, hs, p_layer, weights, l0, l1, offs)
+        return torch.cat(finals, 1)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        trie, table, dim_pad, p_embed, hs, p_layer, weights, l0, l1, offs = ctx.cfg
+        dev, dtp = d_out.device, torch.bfloat16
+        L, R, N = trie.L, trie.R, trie.N
+        bs = trie.batch_sizes
+        sides = (trie.pf, trie.sf)
+        d_out = d_out.contiguous()
+        grads = [None] * len(weights)
+        src = [l0[d][3] if p_layer > 0 else l0[d][1][:sides[d].n_nodes] for d in (0, 1)]
+        dsrc = [None, None]
+        # ---- layer 1
+        for d in (0, 1):
+            gates, hprev, wi, wh_t = l1[d]
+            base = 8 + d * 4
+            w_ih, w_hh, b_ih, b_hh = weights[base:base + 4]
+            want_bias = b_ih.requires_grad or b_hh.requires_grad
+            dh = d_out[:, d * hs:(d + 1) * hs].to(dtp).contiguous()
+            d4 = torch.empty((N, 4 * hs), dtype=dtp, device=dev)
+            bpart = torch.zeros((N_BIAS_PARTIALS, 4 * hs), dtype=torch.float32, device=dev) if want_bias else None
+            prev = None
+            for t in (range(L - 1, -1, -1) if d == 0 else range(L)):
+                A, off = bs[t], offs[t]
+                _step_bwd(A, hs, None if prev is None else d4[offs[prev]:], 0 if prev is None else bs[prev], wh_t,
+                          gates[off:off + A], hprev[off:off + A], None, hs, dh, d4[off:off + A], 0.0, 0, 0, bpart)
+                prev = t
+            _acc_weight_grad(grads, base + 1, w_hh, d4[:, :2 * hs], hprev, rows=slice(0, 2 * hs))
+            _acc_weight_grad(grads, base + 1, w_hh, d4[:, 3 * hs:], hprev, rows=slice(2 * hs, 3 * hs))
+            if want_bias:
+                _acc_bias_grads(grads, base, b_ih, b_hh, bpart.sum(0), hs)
+            # gradient of the per-node input-gate tables: sum of d(xg) = d4[:, :3hs] over the rows of each node
+            for s_, side in enumerate(sides):
+                dG = torch.empty((side.n_nodes, 3 * hs), dtype=dtp, device=dev)
+                _seg_rows(side, d4, 3 * hs, dG)
+                cols = slice(0, hs) if s_ == 0 else slice(hs, 2 * hs)
+                _acc_weight_grad(grads, base, w_ih, dG, src[s_], cols=cols)
+                wt = weight_t(w_ih, wi[:, cols], rows=("cols", s_))                     # [hs, 3hs]
+                if dsrc[s_] is None:
+                    dsrc[s_] = gemm(dG, wt, trans_b=True)
+                else:
+                    gemm(dG, wt, trans_b=True, out=dsrc[s_], accumulate=True)
+            del d4
+        # ---- layer 0 on the tries, deepest level first
+        dtab = None
+        for d, side in enumerate(sides):
+            X, H, gates, Y, seed_e, seed_y, wi_t, wh_t = l0[d]
+            n = side.n_nodes
+            base = d * 4
+            w_ih, w_hh, b_ih, b_hh = weights[base:base + 4]
+            want_bias = b_ih.requires_grad or b_hh.requires_grad
+            d4 = torch.empty((n, 4 * hs), dtype=dtp, device=dev)
+            dhz = torch.zeros((n, hs), dtype=dtp, device=dev)        # per node: (state gradient) * z, what its parent receives directly
+            widest = max(side.level_off[k + 1] - side.level_off[k] for k in range(L))
+            S = torch.empty((widest, 4 * hs), dtype=dtp, device=dev)  # per parent of the current level: sum of its children's d4
+            bpart = torch.zeros((N_BIAS_PARTIALS, 4 * hs), dtype=torch.float32, device=dev) if want_bias else None
+            dy = dsrc[d]
+            for k in range(L - 1, -1, -1):
+                lo, hi = side.level_off[k], side.level_off[k + 1]
+                A = hi - lo
+                if A == 0:
+                    continue
+                has_kids = k + 1 < L and side.level_off[k + 2] > side.level_off[k + 1]
+                if has_kids:
+                    rng_ = side.child_off[2 * lo:2 * hi]
+                    _seg_ranges(A, rng_, d4, 4 * hs, S)
+                    _seg_ranges(A, rng_, dhz, hs, dhz[lo:hi])
+                _step_bwd(A, hs, S if has_kids else None, A, wh_t, gates[lo:hi], H, dy.data_ptr() + lo * hs * dy.element_size(), hs,
+                          dhz[lo:hi], d4[lo:hi], p_layer, seed_y, lo * hs, bpart, hprev_idx=side.par[lo:hi])
+            hp = H.index_select(0, side.par_long)                    # the state each node started from, aligned with d4's rows
+            _acc_weight_grad(grads, base + 1, w_hh, d4[:, :2 * hs], hp, rows=slice(0, 2 * hs))
+            _acc_weight_grad(grads, base + 1, w_hh, d4[:, 3 * hs:], hp, rows=slice(2 * hs, 3 * hs))
+            _acc_weight_grad(grads, base, w_ih, d4[:, :3 * hs], X)
+            if want_bias:
+                _acc_bias_grads(grads, base, b_ih, b_hh, bpart.sum(0), hs)
+            if table.requires_grad:
+                dX = gemm(d4[:, :3 * hs], wi_t, trans_b=True)        # [n, dim_pad]
+                tgt = _grad_target(table)
+                if tgt is None:
+                    if dtab is None:
+                        dtab = torch.zeros(table.shape, dtype=torch.float32, device=dev)
+                    tgt = dtab
+                call("gtos_embed_rows_bwd", dt(dX), n, table.shape[0], table.shape[1], dim_pad, ptr(side.tok), ptr(dX), ptr(tgt),
+                     float(p_embed), seed_e, stream())
+        return (None, dtab, None, None, None, None) + tuple(grads)
+
+
+def trie_bigru_final(trie, table, dim_pad, p_embed, hs, p_layer, weights):
+    return TrieBiGRUFn.apply(trie, table, dim_pad, float(p_embed), hs, float(p_layer), *weights)

@@ -1,0 +1,120 @@
+"""Prefix / suffix tries of a batch's relation bank (include/gtos_host.h, csrc_host/pathtrie.cpp).
+
+Index preparation for the trie-evaluated RelationEncoder (gtos_amd/gru.py): built on the HOST from the integer
+``relation_bank`` / ``relation_length`` of a batch -- like the bank itself, which the reference's ``batchify`` builds on the
+host (generator/data.py:134-176) -- and shipped with the batch as ``batch['relation_trie']``.  A ``PathTrie`` behaves like
+a tensor for ``{k: v.to(device) for k, v in batch.items()}``.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import relbatch
+
+CHUNK = 64
+_COMMON = ("batch_sizes", "seq_order", "seq_pos", "row_pf", "row_sf")
+_PER_TRIE = ("level_off", "tok", "par", "child_off", "rows", "chunk_node", "chunk_start", "chunk_cnt", "chunk_slot", "heavy_node")
+_signed = False
+
+
+def _lib():
+    global _signed
+    lib = relbatch.load()
+    if not _signed:
+        P = ctypes.c_void_p
+        lib.gtos_pathtrie_build.restype = P
+        lib.gtos_pathtrie_build.argtypes = [ctypes.c_int, ctypes.c_int64, P, P, ctypes.c_int]
+        lib.gtos_pathtrie_sizes.restype = ctypes.c_int
+        lib.gtos_pathtrie_sizes.argtypes = [P, P]
+        lib.gtos_pathtrie_export.restype = ctypes.c_int
+        lib.gtos_pathtrie_export.argtypes = [P, P]
+        lib.gtos_pathtrie_free.restype = None
+        lib.gtos_pathtrie_free.argtypes = [P]
+        _signed = True
+    return lib
+
+
+class TrieSide(object):
+    """One trie: int32 index tensors + the level offsets as Python ints (launch geometry, never read from the device)."""
+
+    def __init__(self, arrays, level_off):
+        self.__dict__.update(arrays)
+        if self.tok.dtype != torch.int64:
+            self.tok = self.tok.to(torch.int64)        # the embedding kernels take int64 token ids
+        if "par_long" not in arrays:
+            self.par_long = self.par.to(torch.int64)   # index_select operand (the parent-state gather of the weight gradient)
+        self.level_off = list(level_off)
+        self.n_nodes = self.level_off[-1]
+        self.n_chunks = int(self.chunk_node.numel())
+        self.n_heavy = int(self.heavy_node.numel())
+
+    def to(self, device):
+        arrays = {k: v.to(device) for k, v in self.__dict__.items() if isinstance(v, torch.Tensor)}
+        return TrieSide(arrays, self.level_off)
+
+
+class PathTrie(object):
+    def __init__(self, L, R, N, batch_sizes, common, pf, sf):
+        self.L, self.R, self.N = L, R, N
+        self.batch_sizes = list(batch_sizes)
+        self.seq_order, self.seq_pos, self.row_pf, self.row_sf = common
+        self.pf, self.sf = pf, sf
+
+    def to(self, device, *a, **k):
+        common = tuple(t.to(device) for t in (self.seq_order, self.seq_pos, self.row_pf, self.row_sf))
+        return PathTrie(self.L, self.R, self.N, self.batch_sizes, common, self.pf.to(device), self.sf.to(device))
+
+    def cpu(self):
+        return self.to("cpu")
+
+    def cuda(self, device=None):
+        return self.to("cuda" if device is None else device)
+
+    @property
+    def device(self):
+        return self.row_pf.device
+
+    def matches(self, src_tokens, src_lengths):
+        return src_tokens.shape[1] == self.R and self.device == src_tokens.device
+
+
+def build_path_trie(bank, length, chunk=CHUNK):
+    """bank: int64 [L,R] (relation_bank), length: int64 [R]; CPU tensors (device tensors are copied to the host)."""
+    bank = np.ascontiguousarray(bank.detach().cpu().numpy().astype(np.int64, copy=False))
+    length = np.ascontiguousarray(length.detach().cpu().numpy().astype(np.int64, copy=False))
+    L, R = bank.shape
+    lib = _lib()
+    h = lib.gtos_pathtrie_build(L, R, bank.ctypes.data, length.ctypes.data, chunk)
+    if not h:
+        raise ValueError("gtos_pathtrie_build rejected the bank (lengths must be in 1..L, label ids non-negative)")
+    try:
+        sizes = np.zeros(9, dtype=np.int64)
+        lib.gtos_pathtrie_sizes(h, sizes.ctypes.data)
+        Lm, R_, N, nPF, nSF, cPF, hPF, cSF, hSF = [int(v) for v in sizes]
+        shapes = [Lm, R, R, N, N]
+        for n, c, hv in ((nPF, cPF, hPF), (nSF, cSF, hSF)):
+            shapes += [Lm + 1, n, n, 2 * n, N, c, c, c, c, hv]
+        arrs = [np.zeros(max(1, s), dtype=np.int32) for s in shapes]
+        ptrs = (ctypes.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        got = lib.gtos_pathtrie_export(h, ptrs)
+        assert got == len(arrs)
+    finally:
+        lib.gtos_pathtrie_free(h)
+    ts = [torch.from_numpy(a[:s]) for a, s in zip(arrs, shapes)]
+    common = dict(zip(_COMMON, ts[:5]))
+    sides = []
+    for k in (0, 1):
+        d = dict(zip(_PER_TRIE, ts[5 + 10 * k: 15 + 10 * k]))
+        level_off = d.pop("level_off").tolist()
+        sides.append(TrieSide(d, level_off))
+    # seq_order / seq_pos feed index_select (int64); the row -> node maps stay int32 for the kernels
+    return PathTrie(Lm, R, N, common["batch_sizes"].tolist(),
+                    (common["seq_order"].to(torch.int64), common["seq_pos"].to(torch.int64), common["row_pf"], common["row_sf"]),
+                    sides[0], sides[1])
+
+
+def attach_path_trie(batch):
+    """Adds ``batch['relation_trie']`` (host side, before the batch moves to the device) and returns the batch."""
+    batch['relation_trie'] = build_path_trie(batch['relation_bank'], batch['relation_length'])
+    return batch

@@ -110,13 +110,18 @@ int gtos_colsum(int dtype, int rows, int N, int64_t ld, const void* dy, float* o
 int gtos_gru_cell_fwd(int dtype, int rows, int hs, const void* xg, const void* hg, void* h, void* y, int64_t ldy,
                       void* hprev_save, void* gates, float p_drop, uint64_t seed, int64_t drop_base, void* stream);
 /* Fused forward GRU step, bf16 only, hs % 64 == 0 (gru_step.hip): the gate products run on MFMA and the cell is the
- * epilogue, so no [rows,3*hs] gate tensor round-trips through HBM.  Either x [rows,in_dim] (row stride ldx, in_dim % 8
- * == 0) with w_ih [3hs,in_dim], b_ih is given -- the input product is then fused too -- or x == NULL and xg [rows,3hs]
- * already holds x W_ih^T + b_ih.  h_in [rows,hs] is read-only; the new state of row m is written to h_out[m] when
- * m < n_out (the next step's h_in slot) and to h_fin[m] otherwise (both [*,hs]).  gates [rows,4hs] = r, z, n, hn as
- * gtos_gru_cell_fwd saves them; y (optional, row stride ldy) receives dropout(h_new) with the same counter layout. */
+ * epilogue, so no [rows,3*hs] gate tensor round-trips through HBM.  The input gates come from ONE of
+ *   x [rows,in_dim] (row stride ldx, in_dim % 8 == 0) with w_ih [3hs,in_dim], b_ih -- the input product is fused too;
+ *   xg [rows,3hs] already holding x W_ih^T + b_ih (x == NULL, gf == NULL);
+ *   gf / gb: two bf16 tables [*,3hs] gathered per row, xg[m] = gf[gf_idx[m]] + gb[gb_idx[m]] + b_ih -- the second GRU layer
+ *   on the path tries, whose input product splits into a prefix-node and a suffix-node term (gtos_amd/gru.py).
+ * h_in [*,hs] is read-only; row m enters with h_in[h_idx[m]] (h_idx == NULL: h_in[m]; the trie's parent state).  The new
+ * state of row m is written to h_out[m] when m < n_out (the next step's h_in slot) and to h_fin[m] otherwise (both
+ * [*,hs]).  gates [rows,4hs] = r, z, n, hn as gtos_gru_cell_fwd saves them; y (optional, row stride ldy) receives
+ * dropout(h_new) with the same counter layout. */
 int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, int in_dim, const void* w_ih, const float* b_ih,
-                      const void* xg, const void* h_in, const void* w_hh, const float* b_hh,
+                      const void* xg, const void* gf, const int* gf_idx, const void* gb, const int* gb_idx,
+                      const void* h_in, const int* h_idx, const void* w_hh, const float* b_hh,
                       void* h_out, int n_out, void* h_fin, void* gates, void* y, int64_t ldy,
                       float p_drop, uint64_t seed, int64_t drop_base, void* stream);
 
@@ -124,11 +129,26 @@ int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, int in_dim, 
  * buffer (d(xg) = columns 0..3hs, d(hg) = columns 0..2hs and 3hs..4hs).  First adds d(hg) W_hh of the step processed
  * just before (d4_prev [rows_prev,4hs], may be NULL; w_hh_t = W_hh^T [hs,3hs]) to the running state gradient dh
  * [rows,hs] (dh_dtype: GTOS_F32 or GTOS_BF16) -- this replaces the per-step GEMM -- then runs the cell backward: dh += dropout-masked dy, writes d4,
- * leaves dh = dh_total * z.  bias_partials [n_partials,4hs] fp32 (optional, zeroed by the caller) accumulates the
+ * leaves dh = dh_total * z.  The state row m entered the step with is hprev[hprev_idx[m]] (hprev_idx == NULL: hprev[m]).
+ * bias_partials [n_partials,4hs] fp32 (optional, zeroed by the caller) accumulates the
  * column sums of d4 with atomics (sum over dim 0 = GRU bias gradients, as in gtos_gru_cell_bwd). */
 int gtos_gru_step_bwd(int rows, int hs, const void* d4_prev, int rows_prev, const void* w_hh_t,
-                      const void* gates, const void* hprev, const void* dy, int64_t ldy, void* dh, int dh_dtype, void* d4,
+                      const void* gates, const void* hprev, const int* hprev_idx, const void* dy, int64_t ldy, void* dh, int dh_dtype, void* d4,
                       float p_drop, uint64_t seed, int64_t drop_base, float* bias_partials, int n_partials, void* stream);
+
+/* Segmented row sums for the trie-evaluated RelationEncoder's backward (generator/encoder.py:93-111 runs every path
+ * separately; here the gradient of a shared trie node is the sum over the rows that share it).  bf16 rows, fp32
+ * accumulation, bf16 result.  _rows: chunk c adds the rows rows[chunk_start[c] .. +chunk_cnt[c]) of src into node
+ * chunk_node[c]: straight into dst[node] when chunk_slot[c] < 0 (the node's only chunk), else with fp32 atomics into
+ * heavy[chunk_slot[c], 0:width] (zeroed by the caller), which _finish rounds into dst[heavy_node[s]].  _ranges: dst[s] =
+ * sum of the consecutive src rows ranges[2s] .. ranges[2s+1]-1 (zeros for an empty range).  width % 8 == 0, <= 1536. */
+int gtos_segment_sum_rows(int n_chunks, const int* rows, const int* chunk_node, const int* chunk_start, const int* chunk_cnt,
+                          const int* chunk_slot, const void* src, int64_t ld_src, int width, void* dst, int64_t ld_dst,
+                          float* heavy, void* stream);
+int gtos_segment_sum_finish(int n_heavy, const int* heavy_node, const float* heavy, int width, void* dst, int64_t ld_dst,
+                            void* stream);
+int gtos_segment_sum_ranges(int n_seg, const int* ranges, const void* src, int64_t ld_src, int width, void* dst, int64_t ld_dst,
+                            void* stream);
 
 /* Backward of one step: dh (fp32, in/out) carries the state gradient; writes d(xg), d(hg) [rows,3*hs].
  * bias_partials (optional, fp32 [n_partials, 4*hs], zeroed by the caller once per layer/direction): running column sums

@@ -47,6 +47,37 @@ int gtos_relbatch_export(const gtos_relbatch* h, int64_t* relation, int64_t* ban
 
 void gtos_relbatch_free(gtos_relbatch* h);
 
+/* ---- Prefix / suffix tries of a relation bank (gtos_amd/csrc_host/pathtrie.cpp).
+ * Index preparation for the RelationEncoder of generator/encoder.py:66-119 on MI355X: the first bi-GRU layer runs once
+ * per trie node instead of once per (sequence, position), the second layer's input-gate product splits into a
+ * prefix-node and a suffix-node term.  bank: int64 [L,R] 0-padded label ids (relation_bank of generator/data.py:166-176,
+ * time-major), length: int64 [R] (1..L).  chunk: rows per reduction chunk (64).  NULL on invalid input. */
+typedef struct gtos_pathtrie gtos_pathtrie;
+gtos_pathtrie* gtos_pathtrie_build(int L, int64_t R, const int64_t* bank, const int64_t* length, int chunk);
+
+/* sizes[9] = {L (longest sequence), R, N = sum(length), nodes of the prefix trie, of the suffix trie,
+ *             prefix-trie row chunks, prefix-trie multi-chunk ("heavy") nodes, suffix-trie row chunks, heavy nodes}. */
+int gtos_pathtrie_sizes(const gtos_pathtrie* h, int64_t* sizes);
+
+/* Fills 25 caller-allocated int32 arrays (a NULL entry is skipped), in this order:
+ *   batch_sizes[L]      sequences longer than t (rows of packed step t)
+ *   seq_order[R]        packed position -> sequence id (length descending, then lexicographic)
+ *   seq_pos[R]          sequence id -> packed position
+ *   row_pf[N], row_sf[N] packed row (step t of the sequence at packed position m = offs[t] + m) -> prefix-trie node of
+ *                       tokens 0..t / suffix-trie node of tokens t..len-1
+ * then for the prefix trie and again for the suffix trie (10 arrays each):
+ *   level_off[L+1]      nodes of level k (k+1 tokens) are level_off[k] .. level_off[k+1]-1, lexicographic within a level
+ *   tok[n]              label id the node appends (prefix trie: last token; suffix trie: first token of the suffix)
+ *   par[n]              parent node, n (one past the last node: the all-zero state row) at level 0
+ *   child_off[2n]       [start, end) of the node's children, a contiguous node range
+ *   rows[N]             packed rows sorted by node
+ *   chunk_node/start/cnt/slot[chunks]  reduction chunks over `rows`: node, first entry, entries (<= chunk), and the heavy
+ *                       slot of a node with several chunks (-1: single chunk)
+ *   heavy_node[heavy]   node of every heavy slot.
+ * Returns the number of arrays (25). */
+int gtos_pathtrie_export(const gtos_pathtrie* h, int32_t** out);
+void gtos_pathtrie_free(gtos_pathtrie* h);
+
 #ifdef __cplusplus
 }
 #endif

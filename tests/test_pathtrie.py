@@ -1,0 +1,102 @@
+"""Host trie builder (libgtos_host.so, include/gtos_host.h) against a direct Python construction of the same tries."""
+import numpy as np
+import pytest
+import torch
+
+from gtos_amd.pathtrie import build_path_trie, CHUNK
+
+
+def _random_bank(seed, R, L, V, closed=True):
+    """Label paths with heavy prefix sharing: paths out of a random tree (prefix-closed) plus a few random ones."""
+    rng = np.random.RandomState(seed)
+    seqs = {(int(rng.randint(1, V)),)}
+    while len(seqs) < R:
+        base = list(seqs)[rng.randint(len(seqs))]
+        if len(base) < L and rng.rand() < 0.8:
+            seqs.add(base + (int(rng.randint(1, V)),))
+        else:
+            seqs.add(tuple(int(v) for v in rng.randint(1, V, size=rng.randint(1, L + 1))))
+    seqs = list(seqs)
+    rng.shuffle(seqs)
+    Lm = max(len(s) for s in seqs)
+    bank = np.zeros((Lm, R), np.int64)
+    for r, s in enumerate(seqs):
+        bank[:len(s), r] = s
+    return seqs, torch.from_numpy(bank), torch.tensor([len(s) for s in seqs])
+
+
+def _check(seqs, trie, chunk=CHUNK):
+    R = len(seqs)
+    N = sum(len(s) for s in seqs)
+    assert (trie.R, trie.N, trie.L) == (R, N, max(len(s) for s in seqs))
+    assert trie.batch_sizes == [sum(len(s) > t for s in seqs) for t in range(trie.L)]
+    order = trie.seq_order.tolist()
+    assert sorted(order) == list(range(R))
+    # packed order: length descending, then lexicographic
+    keys = [(-len(seqs[s]), seqs[s]) for s in order]
+    assert keys == sorted(keys)
+    assert [order[p] for p in trie.seq_pos.tolist()] == list(range(R))
+    offs = np.concatenate([[0], np.cumsum(trie.batch_sizes)])
+    for side, rows_node, rev in ((trie.pf, trie.row_pf.tolist(), False), (trie.sf, trie.row_sf.tolist(), True)):
+        strings = [tuple(reversed(s)) for s in seqs] if rev else seqs
+        want_nodes = sorted({s[:k + 1] for s in strings for k in range(len(s))}, key=lambda p: (len(p), p))
+        assert side.n_nodes == len(want_nodes)
+        node_id = {p: i for i, p in enumerate(want_nodes)}
+        lo = side.level_off
+        assert lo == [sum(len(p) <= k for p in want_nodes) for k in range(trie.L + 1)]
+        assert side.tok.tolist() == [p[-1] for p in want_nodes]
+        assert side.par.tolist() == [node_id[p[:-1]] if len(p) > 1 else side.n_nodes for p in want_nodes]
+        co = side.child_off.view(-1, 2).tolist()
+        par = side.par.tolist()
+        for u, (a, b) in enumerate(co):
+            kids = [v for v in range(side.n_nodes) if par[v] == u] if side.n_nodes < 3000 else None
+            if kids is not None:
+                assert kids == list(range(a, b)), (u, a, b, kids)
+        # node of every packed row
+        for m, s in enumerate(order):
+            st = strings[s]
+            for t in range(len(st)):
+                p = offs[t] + m
+                key = st[:len(st) - t] if rev else st[:t + 1]      # suffix trie: tokens t..len-1 reversed = first len-t reversed tokens
+                assert rows_node[p] == node_id[key]
+        # CSR rows + chunks
+        rows = side.rows.tolist()
+        cn, cs, cc, sl = side.chunk_node.tolist(), side.chunk_start.tolist(), side.chunk_cnt.tolist(), side.chunk_slot.tolist()
+        seen = [[] for _ in range(side.n_nodes)]
+        nch = [0] * side.n_nodes
+        for c in range(len(cn)):
+            assert 0 < cc[c] <= chunk
+            seen[cn[c]] += rows[cs[c]:cs[c] + cc[c]]
+            nch[cn[c]] += 1
+        heavy = side.heavy_node.tolist()
+        for u in range(side.n_nodes):
+            assert sorted(seen[u]) == [p for p in range(N) if rows_node[p] == u] if N < 4000 else len(seen[u]) > 0
+        for c in range(len(cn)):
+            assert (sl[c] >= 0) == (nch[cn[c]] > 1)
+            if sl[c] >= 0:
+                assert heavy[sl[c]] == cn[c]
+        assert sorted(r for u in seen for r in u) == list(range(N))
+
+
+@pytest.mark.parametrize("seed,R,L,V", [(1, 1, 1, 5), (2, 40, 4, 6), (3, 300, 8, 5), (4, 500, 8, 300), (5, 700, 11, 9)])
+def test_pathtrie_matches_python_construction(seed, R, L, V):
+    seqs, bank, length = _random_bank(seed, R, L, V)
+    _check(seqs, build_path_trie(bank, length, chunk=8), chunk=8)
+
+
+def test_pathtrie_on_synthetic_amr_bank_is_prefix_closed():
+    from gtos_amd import synth
+    batch, stats = synth.make_batch(2, 6, 30, 8)
+    trie = build_path_trie(batch["relation_bank"], batch["relation_length"])
+    assert trie.pf.n_nodes == stats["R"]                      # paths out of BFS trees: every prefix is itself a path
+    assert stats["R"] <= trie.sf.n_nodes <= 1.2 * stats["R"]
+    assert trie.N == int(batch["relation_length"].sum())
+    moved = trie.to("cpu")
+    assert moved.pf.level_off == trie.pf.level_off and torch.equal(moved.row_sf, trie.row_sf)
+
+
+def test_pathtrie_rejects_bad_lengths():
+    with pytest.raises(ValueError):
+        build_path_trie(torch.ones(3, 4, dtype=torch.int64), torch.tensor([1, 0, 2, 3]))
+    with pytest.raises(ValueError):
+        build_path_trie(torch.ones(3, 4, dtype=torch.int64), torch.tensor([1, 4, 2, 3]))
