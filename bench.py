@@ -266,6 +266,13 @@ def main():
                 "kernel": "rel_attn_fwd_kernel (%s relation operand)" % ("dense" if a.dense else "factored"),
                 "launches": len(evs), "avg_us": round(avg_ms * 1e3, 1), "algorithmic_bytes": alg_bytes}
 
+    def avg_ms(name):
+        ev_ = prof.get(name, [])
+        return round(sum(s_.elapsed_time(e_) for s_, e_ in ev_) / max(1, len(ev_)), 3) if ev_ else None
+    components = {"relation_encoder_fwd_ms": avg_ms("relation_encoder_fwd"), "relation_gru_bwd_ms": avg_ms("relation_gru_bwd"),
+                  "graph_encoder_fwd_ms": avg_ms("graph_encoder_fwd"),
+                  "note": "HIP-event spans on the main stream inside the timed region, per step"}
+
     if rank == 0 and not a.dense and a.config in ("C1", "C2", "C3"):
         # the same kernel on the reference's dense relation signature (rarb[S,T,B,2d] materialised), outside the timed region
         del trainer
@@ -294,7 +301,7 @@ def main():
                           "mean_path_len": round(stats["mean_path_len"], 2), "T": stats["T"],
                           "relation_operand": "dense" if a.dense else "factored", "parallelism": "dp%d" % world,
                           "loss_first": losses[0], "loss_last": losses[-1]},
-               "roofline": roofline}
+               "roofline": roofline, "components": components}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.config, a.cpu_graphs)
         print(json.dumps(out))

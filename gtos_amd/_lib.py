@@ -37,6 +37,9 @@ SIGNATURES = {
     "gtos_relation_gather_mean": [c_i, c_l, c_i, c_i, c_p, c_p, c_i, c_p, c_p],
     "gtos_embed_rows_fwd": [c_i, c_l, c_i, c_i, c_p, c_p, c_p, c_f, c_u64, c_p],
     "gtos_embed_rows_bwd": [c_i, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_f, c_u64, c_p],
+    "gtos_copy_nll_fwd": [c_i, c_i, c_i, c_i, c_i, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_p, c_p, c_p, c_p],
+    "gtos_copy_nll_bwd": [c_i, c_i, c_i, c_i, c_i, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "gtos_copy_ll_fwd": [c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_l, c_p, c_p, c_p, c_p, c_p],
     "gtos_sqnorm": [c_l, c_p, c_p, c_p],
     "gtos_adam_step": [c_l, c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_f, c_p, c_p],
     "gtos_cast_f32_to_bf16": [c_l, c_p, c_p, c_p],

@@ -1,8 +1,8 @@
 """DecodeLayer / TokenGenerator (/root/reference/generator/decoder.py) on the gfx950 kernels.
 
-The decoder's self- and cross-attention, LayerNorms, FFN and vocabulary projections run on the HIP kernels;
-the copy/generate mixture (softmax over the vocabulary, scatter_add_, log, NLL gather) stays on PyTorch-ROCm
-device ops in fp32 -- adjacent to the hot path, not a roofline target.
+The decoder's self- and cross-attention, LayerNorms, FFN and vocabulary projections run on the HIP kernels, and so does
+the copy/generate mixture: one fused kernel evaluates the NLL of the target without materialising the [T,B,V+copies]
+distribution (csrc/copy_nll.hip); inference gets the full log-likelihood row from a second kernel.
 """
 import torch
 from torch import nn
@@ -48,26 +48,18 @@ class TokenGenerator(nn.Module):
                                                        key_padding_mask=graph_padding_mask, need_weights=True)
         ln = self.alignment_layer_norm
         outs = ops.layer_norm_residual(outs.to(x.dtype), x, ln.weight, ln.bias, p, ln.eps)
-        seq_len, bsz, _ = outs.size()
-        outs_token = torch.tanh(ops.linear(outs, self.transfer.weight, self.transfer.bias))
-        outs_token = F.dropout(outs_token, p=self.dropout, training=self.training)
-        gate = F.softmax(_padded_linear(outs_token, self.diverter).float(), -1)
-        gen_gate, copy_gate = gate.chunk(2, dim=-1)
-        probs = gen_gate * F.softmax(_padded_linear(outs_token, self.generator).float(), -1)
-        if tot_ext is None:
-            tot_ext = 1 + int(copy_seq.max().item())
-        vocab_size = probs.size(-1)
-        if tot_ext - vocab_size > 0:
-            probs = torch.cat([probs, probs.new_zeros((seq_len, bsz, tot_ext - vocab_size))], -1)
-        index = copy_seq.transpose(0, 1).contiguous().view(1, bsz, -1).expand(seq_len, -1, -1)
-        copy_probs = (copy_gate * alignment_weight.float()).view(seq_len, bsz, -1)
-        probs = probs.scatter_add(-1, index, copy_probs)
-        ll = torch.log(probs + 1e-12)
+        hidden = torch.tanh(ops.linear(outs, self.transfer.weight, self.transfer.bias))
+        hidden = F.dropout(hidden, p=self.dropout, training=self.training)
+        logits = _padded_linear(hidden, self.generator)              # [T,B,V] vocabulary scores
+        div = _padded_linear(hidden, self.diverter)                  # [T,B,2] generate-vs-copy scores
+        # decoder.py:40-63 (softmaxes, gate * probabilities, scatter_add of the copy mass at the concepts' copy ids,
+        # log(p + 1e-12), NLL gather) is ONE kernel: gtos_copy_nll_* for the loss, gtos_copy_ll_fwd for the full row
         if work:
-            return ll
-        token_loss = -ll.gather(dim=-1, index=target.unsqueeze(-1)).squeeze(-1)
-        token_mask = torch.eq(target, self.vocabs['predictable_token'].padding_idx)
-        return token_loss.masked_fill(token_mask, 0.).sum(0)
+            if tot_ext is None:
+                tot_ext = 1 + int(copy_seq.max().item())
+            return ops.copy_log_likelihood(logits, div, alignment_weight, copy_seq, tot_ext)
+        pad = self.vocabs['predictable_token'].padding_idx
+        return ops.copy_nll(logits, div, alignment_weight, copy_seq, target, pad).sum(0)
 
 
 class DecodeLayer(nn.Module):

@@ -70,7 +70,8 @@ class Generator(nn.Module):
 
     def encode_step(self, inp, train=True):
         concept_repr, concept_mask = self._concepts(inp)
-        bank = self.relation_encoder(inp['relation_bank'], inp['relation_length'], trie=inp.get('relation_trie'))   # [R, d]
+        with ops._Timed("relation_encoder_fwd"):
+            bank = self.relation_encoder(inp['relation_bank'], inp['relation_length'], trie=inp.get('relation_trie'))   # [R, d]
         if train and self.grad_sync is not None:
             # everything downstream of these two belongs to gradient segments <= 2 (graph encoder, probe, decoders)
             concept_repr, bank = self.grad_sync.boundary(2, concept_repr, bank)
@@ -83,7 +84,8 @@ class Generator(nn.Module):
             # generator flavour: [n,n,B,K] alternatives averaged (generator.py:83-88); translator flavour: one path per
             # pair, the plain lookup (translator/generator.py:73), here without building an autograd graph
             relation = ops.relation_gather_mean(bank.detach(), inp['relation'], zero_row0=inp['relation'].dim() == 4)
-        concept_repr = self.graph_encoder(concept_repr, relation, self_padding_mask=concept_mask)
+        with ops._Timed("graph_encoder_fwd"):
+            concept_repr = self.graph_encoder(concept_repr, relation, self_padding_mask=concept_mask)
         probe = torch.tanh(ops.linear(concept_repr[:1], self.probe_generator.weight, self.probe_generator.bias))
         return concept_repr[1:], concept_mask[1:], probe
 

@@ -14,7 +14,7 @@ import torch
 
 from . import _lib
 from ._lib import call, dt, ptr, stream
-from .ops import gemm, compute_weight, next_seed, weight_t, _grad_target, _splitk, side_stream as _side_stream, defer_side_join
+from .ops import gemm, compute_weight, next_seed, weight_t, _grad_target, _splitk, side_stream as _side_stream, defer_side_join, _Timed
 
 
 def _cell_fwd(A, hs, xg, hg, h, y, y_off_elems, ldy, hprev, gates, p, seed, drop_base):
@@ -129,6 +129,11 @@ class BiGRUFinalFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_out):
+        with _Timed("relation_gru_bwd"):
+            return BiGRUFinalFn._backward(ctx, d_out)
+
+    @staticmethod
+    def _backward(ctx, d_out):
         batch_sizes, offs, hs, num_layers, weights, saved = ctx.cfg
         L, R, N = len(batch_sizes), batch_sizes[0], offs[-1]
         d_out = d_out.contiguous()
@@ -367,6 +372,11 @@ class TrieBiGRUFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_out):
+        with _Timed("relation_gru_bwd"):
+            return TrieBiGRUFn._backward(ctx, d_out)
+
+    @staticmethod
+    def _backward(ctx, d_out):
         trie, table, dim_pad, p_embed, hs, p_layer, weights, l0, l1, offs = ctx.cfg
         dev, dtp = d_out.device, torch.bfloat16
         L, R, N = trie.L, trie.R, trie.N

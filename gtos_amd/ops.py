@@ -578,3 +578,54 @@ class PermuteRowsFn(torch.autograd.Function):
 
 def permute_rows(x, perm, inv):
     return PermuteRowsFn.apply(x, perm, inv)
+
+
+class CopyNllFn(torch.autograd.Function):
+    """nll[t,b] = -log(gen_gate * softmax(logits)[target] + copy_gate * sum_{s: cp_seq[s,b] == target} align[t,b,s] + 1e-12),
+    0 at padded targets: the generate/copy mixture of TokenGenerator evaluated only where the loss looks
+    (generator/decoder.py:40-63), one kernel forward, one backward."""
+
+    @staticmethod
+    def forward(ctx, logits, div, align, cp_seq, target, pad_idx):
+        require_cuda(logits, div, align, cp_seq, target)
+        T_, B, V = logits.shape
+        S = cp_seq.shape[0]
+        logits, div = logits.contiguous(), div.contiguous()
+        align = align.float().contiguous()
+        cp_seq, target = cp_seq.contiguous(), target.contiguous()
+        nll = torch.empty((T_, B), dtype=torch.float32, device=logits.device)
+        lse, p = torch.empty_like(nll), torch.empty_like(nll)
+        call("gtos_copy_nll_fwd", dt(logits), T_, B, V, S, ptr(logits), V, ptr(div), ptr(align), ptr(cp_seq), ptr(target),
+             int(pad_idx), ptr(nll), ptr(lse), ptr(p), stream())
+        ctx.save_for_backward(logits, div, align, cp_seq, target, lse, p)
+        ctx.pad_idx = int(pad_idx)
+        return nll
+
+    @staticmethod
+    def backward(ctx, d_nll):
+        logits, div, align, cp_seq, target, lse, p = ctx.saved_tensors
+        T_, B, V = logits.shape
+        S = cp_seq.shape[0]
+        d_logits, d_div = torch.empty_like(logits), torch.empty_like(div)
+        d_align = torch.empty_like(align)
+        call("gtos_copy_nll_bwd", dt(logits), T_, B, V, S, ptr(logits), V, ptr(div), ptr(align), ptr(cp_seq), ptr(target),
+             ctx.pad_idx, ptr(lse), ptr(p), ptr(d_nll.float().contiguous()), ptr(d_logits), ptr(d_div), ptr(d_align), stream())
+        return d_logits, d_div, d_align, None, None, None
+
+
+def copy_nll(logits, div, align, cp_seq, target, pad_idx):
+    return CopyNllFn.apply(logits, div, align, cp_seq, target, pad_idx)
+
+
+def copy_log_likelihood(logits, div, align, cp_seq, tot_ext):
+    """Inference form: ll [T,B,tot_ext] fp32 = log(mixture + 1e-12) over the vocabulary and the batch's copy ids."""
+    require_cuda(logits, div, align, cp_seq)
+    T_, B, V = logits.shape
+    logits, div = logits.contiguous(), div.contiguous()
+    align = align.float().contiguous()
+    cp_seq = cp_seq.contiguous()
+    tot = max(int(tot_ext), V)
+    ll = torch.empty((T_, B, tot), dtype=torch.float32, device=logits.device)
+    call("gtos_copy_ll_fwd", dt(logits), T_, B, V, cp_seq.shape[0], tot, ptr(logits), V, ptr(div), ptr(align), ptr(cp_seq),
+         ptr(ll), stream())
+    return ll

@@ -181,6 +181,23 @@ int gtos_adam_step(int64_t n, float* p, const float* g, float* m, float* v, floa
                    void* bf16_mirror, void* stream);
 int gtos_cast_f32_to_bf16(int64_t n, const float* src, void* dst, void* stream);
 
+/* Fused generate/copy mixture of TokenGenerator (generator/decoder.py:40-63): vocabulary softmax, 2-way diverter softmax,
+ * gen_gate * p_vocab extended by the per-graph copy ids, scatter_add of copy_gate * alignment weights at cp_seq, log(p + 1e-12).
+ * logits [T,B,V] (row stride ld_logits) and div [T,B,2] share `dtype`; align fp32 [T,B,S] (head-max alignment weights),
+ * cp_seq int64 [S,B], target int64 [T,B].
+ * _nll_fwd (training): nll[t,b] = -log p(target) (0 where target == pad_idx) without materialising the distribution; saves
+ * lse and p(target).  _nll_bwd: d_logits [T,B,V] (dtype), d_div [T,B,2] (dtype), d_align fp32 [T,B,S] from d_nll [T,B].
+ * _ll_fwd (inference, work=True): the whole row ll[t,b, 0:tot_ext] fp32, tot_ext = 1 + max(cp_seq) >= V. */
+int gtos_copy_nll_fwd(int dtype, int T, int B, int V, int S, const void* logits, int64_t ld_logits, const void* div,
+                      const float* align, const int64_t* cp_seq, const int64_t* target, int64_t pad_idx,
+                      float* nll, float* lse, float* p_tgt, void* stream);
+int gtos_copy_nll_bwd(int dtype, int T, int B, int V, int S, const void* logits, int64_t ld_logits, const void* div,
+                      const float* align, const int64_t* cp_seq, const int64_t* target, int64_t pad_idx,
+                      const float* lse, const float* p_tgt, const float* d_nll, void* d_logits, void* d_div,
+                      float* d_align, void* stream);
+int gtos_copy_ll_fwd(int dtype, int T, int B, int V, int S, int tot_ext, const void* logits, int64_t ld_logits,
+                     const void* div, const float* align, const int64_t* cp_seq, float* ll, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1013,3 +1013,51 @@ def test_segment_sum_kernels():
         _seg_rows(side, d4, 768, out)
         want = torch.zeros(side.n_nodes, 768, device=dev()).index_add_(0, row_node.long(), d4[:, :768].float())
         torch.testing.assert_close(out.float(), want, rtol=1e-2, atol=1e-2 * want.abs().max().item())
+
+
+# ------------------------------------------------------------------------------------------------ fused copy/generate mixture
+def _mixture_reference(logits, div, align, cp_seq, tot):
+    """The op sequence of the oracle's TokenGenerator (pinned to generator/decoder.py:40-63 by the golden vectors)."""
+    T_, B, V = logits.shape
+    gate = torch.softmax(div, -1)
+    probs = gate[..., :1] * torch.softmax(logits, -1)
+    if tot > V:
+        probs = torch.cat([probs, probs.new_zeros(T_, B, tot - V)], -1)
+    index = cp_seq.transpose(0, 1).reshape(1, B, -1).expand(T_, -1, -1)
+    probs = probs.scatter_add(-1, index, (gate[..., 1:] * align).reshape(T_, B, -1))
+    return torch.log(probs + 1e-12)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("T_,B,V,S", [(5, 3, 64, 7), (9, 4, 203, 12), (50, 8, 10000, 100)])
+def test_fused_copy_mixture_nll_and_loglikelihood(T_, B, V, S, dtype):
+    from gtos_amd import ops
+    g = torch.Generator().manual_seed(T_ * 31 + V)
+    logits = (2.0 * torch.randn(T_, B, V, generator=g)).to(dtype).float()       # both sides see the rounded values
+    div = torch.randn(T_, B, 2, generator=g).to(dtype).float()
+    align = torch.softmax(torch.randn(T_, B, S, generator=g), -1)
+    cp_seq = torch.randint(3, V + 6, (S, B), generator=g)                        # some ids beyond the vocabulary (copy-only)
+    cp_seq[1] = cp_seq[0]                                                        # several concepts sharing a copy id
+    cp_seq[S - 1] = 0                                                            # padded source position
+    tot = 1 + int(cp_seq.max())
+    target = torch.randint(1, V, (T_, B), generator=g)
+    target[0] = cp_seq[0]                                                        # targets reachable by copying
+    target[1, 0] = int(cp_seq.max())
+    target[T_ - 1] = 0                                                           # padding
+    lr, dr, ar = logits.clone().requires_grad_(), div.clone().requires_grad_(), align.clone().requires_grad_()
+    ll_r = _mixture_reference(lr, dr, ar, cp_seq, tot)
+    nll_r = (-ll_r.gather(-1, target.unsqueeze(-1)).squeeze(-1)).masked_fill(target.eq(0), 0.)
+    wt = torch.rand(T_, B, generator=g)
+    (nll_r * wt).sum().backward()
+    ld = logits.to(dev(), dtype).requires_grad_()
+    dd = div.to(dev(), dtype).requires_grad_()
+    ad = align.to(dev()).requires_grad_()
+    nll = ops.copy_nll(ld, dd, ad, cp_seq.to(dev()), target.to(dev()), 0)
+    (nll * wt.to(dev())).sum().backward()
+    tol = dict(rtol=1e-4, atol=1e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-3)
+    torch.testing.assert_close(nll.cpu(), nll_r.detach(), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(ld.grad.float().cpu(), lr.grad, **tol)
+    torch.testing.assert_close(dd.grad.float().cpu(), dr.grad, **tol)
+    torch.testing.assert_close(ad.grad.cpu(), ar.grad, rtol=1e-4, atol=1e-5)
+    ll = ops.copy_log_likelihood(ld.detach(), dd.detach(), ad.detach(), cp_seq.to(dev()), tot)
+    torch.testing.assert_close(ll.cpu(), ll_r.detach(), rtol=1e-4, atol=1e-4)

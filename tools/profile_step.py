@@ -28,7 +28,8 @@ def main():
     model.train()
     trainer = Trainer(model, cfg["d"], warmup_steps=2000, compute_dtype=torch.bfloat16, world_size=1)
     batch, stats = synth.make_config_batch(a.config)
-    batch = {k: v.to(dev) for k, v in batch.items()}
+    from gtos_amd.pathtrie import attach_path_trie
+    batch = {k: v.to(dev) for k, v in attach_path_trie(batch).items()}
     for _ in range(2):
         trainer.step(batch)
     torch.cuda.synchronize()
@@ -36,6 +37,24 @@ def main():
     trainer.step(batch)
     torch.cuda.synchronize()
     plain = time.perf_counter() - t0
+    # RelationEncoder alone (generator/encoder.py:66-119): forward and backward, HIP events, dropout as in training
+    enc = model.relation_encoder
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    tf, tb = [], []
+    for it in range(4):
+        ev[0].record()
+        out = enc(batch['relation_bank'], batch['relation_length'], trie=batch.get('relation_trie'))
+        ev[1].record()
+        out.backward(torch.ones_like(out))
+        ops.join_side()
+        ev[2].record()
+        torch.cuda.synchronize()
+        if it:
+            tf.append(ev[0].elapsed_time(ev[1]))
+            tb.append(ev[1].elapsed_time(ev[2]))
+    trainer.flat.zero_grad()
+    print("RelationEncoder alone (R=%d, sum(len)=%d): forward %.2f ms, backward %.2f ms" % (
+        stats["R"], int(batch['relation_length'].sum()), sum(tf) / len(tf), sum(tb) / len(tb)))
     ops.GEMM_PROFILE = {}
     t0 = time.perf_counter()
     trainer.step(batch)
