@@ -53,7 +53,8 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--dense", action="store_true", help="dense relation[n,n,B,d] signature instead of the factored form")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-graphs", type=int, default=2)
+    ap.add_argument("--cpu-graphs", type=int, default=8, help="micro-batch of the CPU baseline (SURVEY 8d: 8 graphs)")
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU steps per leg (after 1 warm-up; time-capped)")
     ap.add_argument("--decode", action="store_true",
                     help="secondary benchmark (SURVEY 8f rank 2): beam search over the K/V-cached decoder instead of the train step")
     ap.add_argument("--beam", type=int, default=8)
@@ -63,8 +64,21 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(cfg_name, graphs):
-    """Oracle (kind 'port') full training step on the host cores, fp32, on `graphs` graphs of the same config."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg_name, graphs, steps, budget_s=75.0):
+    """Oracle (kind 'port': the CPU restatement pinned to the reference's golden vectors) on the host cores, fp32, on a
+    micro-batch of `graphs` graphs of the same config: (i) the full training step, (ii) the graph encoder
+    alone (RelationEncoder + GraphTransformer forward + backward).  1 warm-up + up to `steps` timed steps per leg, capped by
+    a wall-clock budget so the default run stays bounded."""
     from oracle import gtos_oracle as O
     from gtos_amd import synth
     from gtos_amd.config import generator_args
@@ -83,7 +97,7 @@ def cpu_baseline(cfg_name, graphs):
     v = [torch.zeros_like(p) for p in params]
     names = [n for n, _ in model.named_parameters()]
 
-    def step(i):
+    def full_step(i):
         loss = model(batch)
         loss.backward()
         grads = [p.grad for p in params]
@@ -95,17 +109,151 @@ def cpu_baseline(cfg_name, graphs):
                 p.copy_(np_)
                 p.grad = None
         return loss.item()
-    step(1)
-    log("cpu_baseline: warm-up step done")
-    t0 = time.time()
-    n_timed = 0
-    while n_timed < 2 and (n_timed == 0 or time.time() - t0 < 15.0):
-        step(2 + n_timed)
-        n_timed += 1
-    dt_ = (time.time() - t0) / n_timed
-    return {"value": graphs / dt_, "unit": "graphs/s", "cores": cores, "kind": "port",
-            "sample": "%d graphs of %s (n=%d, R=%d), fp32, full train step, %d timed steps, %.1f s/step" % (
-                graphs, cfg_name, stats["n"], stats["R"], n_timed, dt_)}
+
+    def encoder_step(i):
+        graph, _, probe = model.encode_step(batch)
+        (graph.float().sum() + probe.float().sum()).backward()
+        for p in params:
+            p.grad = None
+
+    def timed(fn, budget):
+        fn(1)                                      # warm-up
+        t0, k = time.time(), 0
+        while k < steps and (k == 0 or time.time() - t0 < budget):
+            fn(2 + k)
+            k += 1
+        return (time.time() - t0) / k, k
+    t_all = time.time()
+    dt_full, k_full = timed(full_step, budget_s * 0.6)
+    log("cpu_baseline: full step %.1f s x %d" % (dt_full, k_full))
+    dt_enc, k_enc = timed(encoder_step, budget_s * 0.4)
+    return {"value": graphs / dt_full, "unit": "graphs/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+            "encoder_only": {"value": graphs / dt_enc, "unit": "graphs/s", "timed_steps": k_enc, "s_per_step": round(dt_enc, 2)},
+            "sample": "micro-batch of %d graphs of %s (n=%d, R=%d), fp32, full train step (fwd+bwd+clip+Adam), 1 warm-up + %d timed "
+                      "steps, %.1f s/step; encoder-only leg (RelationEncoder + GraphTransformer fwd+bwd) %.1f s/step; %.0f s total" % (
+                          graphs, cfg_name, stats["n"], stats["R"], k_full, dt_full, dt_enc, time.time() - t_all)}
+
+
+MFMA_PEAK_TFS = 2500.0
+
+
+def build_roofline(a, cfg, stats, model, trainer, batch, prof, dev, cd):
+    """roofline object of the JSON line.  Headline (SURVEY 8d "Stage A"): the relation-attention forward kernel on the
+    reference's DENSE relation signature (rarb[n,n,B,2d] = relation_in_proj(relation) materialised), measured live here with
+    HIP events on the real batch -- layer-0 q/k/v of the real concept embeddings, the real projected bank rows gathered by the
+    real type ids, the key-padding mask the model passes.  The training step itself runs the FACTORED operand; its launches
+    inside the timed region are reported next to it against ITS algorithmic bytes (every bank row once), not Stage A's.
+    `kernels`: one row per other dominant kernel from a detail pass (2 extra steps with per-launch events)."""
+    from gtos_amd import ops
+    n, B, d, H = stats["n"], stats["B"], cfg["d"], cfg["H"]
+    s_el = 2 if cd == torch.bfloat16 else 4
+    P, R = n * n * B, stats["R"]
+    N_rows = int(batch["relation_length"].sum())
+    hs = 256
+
+    def span(pr, name):
+        ev_ = pr.get(name, [])
+        ms = [s_.elapsed_time(e_) for s_, e_, _u in ev_]
+        return (sum(ms) / len(ms), len(ms), sum(u for _, _, u in ev_), sum(ms)) if ms else (None, 0, 0, 0.0)
+
+    stage_a = P * 2 * d * s_el + 4 * n * B * d * s_el + n * B
+    fact_bytes = R * 2 * d * s_el + P * 4 + 4 * n * B * d * s_el + n * B
+    pmc = {}
+    pmc_file = os.path.join(ROOT, "profiles", "r2_rel_attn_pmc.json")
+    if a.config == "C2" and a.dtype == "bf16" and os.path.exists(pmc_file):
+        pmc = json.load(open(pmc_file))
+    key = "rel_attn_fwd_mode1" if a.dense else "rel_attn_fwd_mode2"
+    ms_in, n_in, _, _ = span(prof, key)
+    in_step = None
+    if ms_in:
+        alg = stage_a if a.dense else fact_bytes
+        in_step = {"kernel": "rel_attn_fwd_kernel, %s operand (what the timed training steps launch)" % ("dense" if a.dense else "factored"),
+                   "launches": n_in, "avg_us": round(ms_in * 1e3, 1), "algorithmic_bytes": alg,
+                   "algorithmic_bytes_formula": "P*2d*s + 4nBd*s + nB" if a.dense else "R*2d*s (each bank row once) + P*4 (type ids) + 4nBd*s + nB",
+                   "achieved": round(alg / ms_in / 1e6, 1), "frac": round(alg / ms_in / 1e6 / HBM_PEAK_GBS, 4),
+                   "traffic": pmc.get("dense" if a.dense else "factored", {}).get("rel_attn_fwd_kernel", {}).get("traffic_bytes_per_launch")}
+
+    # ---- dense-signature leg on the real batch (outside the timed region)
+    model.eval()
+    with torch.no_grad():
+        x, mask = model._concepts(batch)
+        bank = model.relation_encoder(batch['relation_bank'], batch['relation_length'], trie=batch.get('relation_trie'))
+        layer = model.graph_encoder.layers[0].self_attn
+        qkv = ops.linear(x, layer.in_proj_weight, layer.in_proj_bias)
+        proj = ops.linear(bank, layer.relation_in_proj.weight)                          # [R, 2d]
+        rarb = proj.index_select(0, batch['relation'].reshape(-1)).view(n, n, B, 2 * d)  # the dense operand, [j][i] order
+        ops.PROFILE = {}
+        for _ in range(8):
+            ops.attention_core(qkv, None, (0, d, 2 * d), d, H, (d // H) ** -0.5, rel=rarb, key_pad=mask)
+        torch.cuda.synchronize()
+        ev = ops.PROFILE["rel_attn_fwd_mode1"][2:]
+        ops.PROFILE = None
+    dms = sum(s_.elapsed_time(e_) for s_, e_, _ in ev) / len(ev)
+    del rarb, proj, qkv
+    model.train()
+    roof = {"bound": "hbm", "achieved": round(stage_a / dms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(stage_a / dms / 1e6 / HBM_PEAK_GBS, 4),
+            "traffic": pmc.get("dense", {}).get("rel_attn_fwd_kernel", {}).get("traffic_bytes_per_launch"),
+            "traffic_source": ("profiles/r2_rel_attn_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes per operand "
+                               "mode (tools/pmc_rel_attn.sh), gfx950 corrections of MI355X_MICROARCH.md") if pmc else None,
+            "kernel": "rel_attn_fwd_kernel<bf16,8>, DENSE relation signature rarb[n,n,B,2d] (SURVEY 8d Stage A), real batch: layer-0 "
+                      "q/k/v, real projected bank rows, key-padding mask",
+            "launches": len(ev), "avg_us": round(dms * 1e3, 1), "algorithmic_bytes": stage_a,
+            "measured": "HIP events on the launch stream, live in this run, after the timed region",
+            "in_step": in_step}
+
+    # ---- detail pass: per-launch events on the other dominant kernels (they would perturb the timed region)
+    rows = []
+    if not a.dense and cd == torch.bfloat16:
+        ops.PROFILE, ops.PROFILE_DETAIL, ops.GEMM_PROFILE = {}, True, {}
+        for _ in range(2):
+            trainer.step(batch)
+        torch.cuda.synchronize()
+        dp, gp = ops.PROFILE, ops.GEMM_PROFILE
+        ops.PROFILE, ops.PROFILE_DETAIL, ops.GEMM_PROFILE = None, False, None
+
+        def hbm_row(name, label, bytes_per_launch=None, bytes_per_unit=None, note=""):
+            ms, cnt, units, tot = span(dp, name)
+            if not ms:
+                return
+            byt = bytes_per_launch if bytes_per_launch is not None else bytes_per_unit * units / cnt
+            rows.append({"kernel": label, "bound": "hbm", "launches_per_step": cnt // 2, "avg_us": round(ms * 1e3, 1),
+                         "algorithmic_bytes_per_launch": int(byt), "achieved": round(byt / ms / 1e6, 1), "unit": "GB/s",
+                         "peak": HBM_PEAK_GBS, "frac": round(byt / ms / 1e6 / HBM_PEAK_GBS, 4), "ms_per_step": round(tot / 2, 2),
+                         "bytes": note})
+        hbm_row("rel_attn_bwd_q+kv_mode2", "rel_attn_bwd_q_kernel + rel_attn_bwd_kv_kernel (factored, one C call)",
+                bytes_per_launch=2 * R * 2 * d * s_el + 10 * n * B * d * s_el + 4 * P * H * 4 + 2 * P * 4,
+                note="2 passes x R*2d*s bank rows + 10nBd*s (q,k,v,o,do read; dq,dk,dv written) + pd,gs [P,H] fp32 written+read + ids")
+        hbm_row("rel_attn_bwd_bank", "rel_attn_bwd_bank_kernel",
+                bytes_per_launch=2 * R * 2 * d * s_el + P * H * 4 + P * 4 + 2 * n * B * d * s_el,
+                note="R*2d*s bank read + R*2d*s d_bank written + gs [P,H] fp32 + pair ids + q,k rows once (they are served by L2)")
+        hbm_row("gru_step_fwd_tables", "gru_step_fwd_kernel<2> (GRU layer 1, gate tables gathered)",
+                bytes_per_unit=(4 + 1 + 1 + 6) * hs * 2 + 8,
+                note="per active row: gates 4h + new state h written, state h read, two 3h table rows gathered, 2 node ids")
+        hbm_row("gru_step_fwd_x", "gru_step_fwd_kernel<1> (GRU layer 0 on the tries, input product fused)",
+                bytes_per_unit=(4 + 1 + 1 + 1) * hs * 2 + 104 * 2 + 4,
+                note="per trie node: gates 4h + state h + dropped copy h written, parent state h gathered, embedding row read")
+        hbm_row("gru_step_bwd_rows", "gru_step_bwd_kernel (GRU layer 1)", bytes_per_unit=(4 + 1 + 3 + 2 + 4) * hs * 2,
+                note="per active row: gates 4h + h_prev h read, later step's d(hg) 3h read (MFMA operand), dh read+written, d4 4h written")
+        hbm_row("segment_sum_rows", "seg_sum_kernel (gate-table gradients: rows -> trie nodes)",
+                bytes_per_unit=3 * hs * 2 + 4, note="per row: d(xg) 3h read + row id; + nodes x 3h written (not counted)")
+        grows = []
+        for key_, evs in gp.items():
+            lay, nn, kk, dts, sk, big = key_
+            ms = sum(s_.elapsed_time(e_) for _, s_, e_ in evs)
+            long_sum = sum(m_ for m_, _, _ in evs)
+            grows.append((ms, lay, nn, kk, dts, sk, len(evs), long_sum))
+        for ms, lay, nn, kk, dts, sk, calls, long_sum in sorted(grows, reverse=True)[:4]:
+            fl = 2.0 * long_sum * nn * kk
+            rows.append({"kernel": "gemm_kernel %s N=%d %s=%d %s splitk=%d" % (lay, nn, "M" if lay[0] == "T" else "K", kk, dts, sk),
+                         "bound": "mfma", "launches_per_step": calls // 2, "avg_us": round(ms * 1e3 / calls, 1),
+                         "flops_per_launch": int(fl / calls), "achieved": round(fl / ms / 1e9, 1), "unit": "TFLOP/s",
+                         "peak": MFMA_PEAK_TFS, "frac": round(fl / ms / 1e9 / MFMA_PEAK_TFS, 4), "ms_per_step": round(ms / 2, 2)})
+    roof["kernels"] = rows
+    roof["kernels_note"] = ("detail pass: 2 extra training steps with a HIP-event pair around every launch of these kernels "
+                            "(the events slow the step, so they are not taken inside the timed region); bytes are algorithmic, "
+                            "per launch; GEMM rows: the four shapes with the largest time share")
+    return roof
 
 
 def decode_bench(a):
@@ -204,6 +352,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world)   # RCCL on ROCm
 
     from gtos_amd import ops, synth
+    from gtos_amd import gru as gru_mod
     from gtos_amd.config import build_generator
     from gtos_amd.generator import Generator
     from gtos_amd.train import Trainer
@@ -219,7 +368,8 @@ def main():
     batch, stats = synth.make_config_batch(a.config, rank=rank)        # weak scaling: B graphs per GPU
     log("batch", stats)
     from gtos_amd.pathtrie import attach_path_trie
-    attach_path_trie(batch)            # host-side index preparation, part of batch assembly like the relation bank itself
+    from gtos_amd.relindex import attach_relation_index
+    attach_relation_index(attach_path_trie(batch))   # host-side index preparation: batch assembly, like the relation bank itself
     batch = {k: v.to(dev) for k, v in batch.items()}
     ops.set_seed(19940117 + rank)
 
@@ -235,12 +385,14 @@ def main():
     sync()
     log("warmup done")
     ops.PROFILE = {}
+    trainer.comm_exposed_s = 0.0
     t0 = time.perf_counter()
     losses = []
     for _ in range(a.steps):
         losses.append(trainer.step(batch))
     sync()
     elapsed = time.perf_counter() - t0
+    comm_exposed = trainer.comm_exposed_s
     log("timed region done", elapsed)
     prof, ops.PROFILE = ops.PROFILE, None
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -248,47 +400,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-    # ---- roofline of the relation-attention forward kernel (launches inside the timed region)
-    n, B, d = stats["n"], stats["B"], cfg["d"]
+    n, B, d, H = stats["n"], stats["B"], cfg["d"], cfg["H"]
     s_el = 2 if cd == torch.bfloat16 else 4
-    P = n * n * B
-    alg_bytes = P * 2 * d * s_el + 4 * n * B * d * s_el + n * B
-    key = "rel_attn_fwd_mode1" if a.dense else "rel_attn_fwd_mode2"
-    evs = prof.get(key, [])
-    avg_ms = sum(s.elapsed_time(e) for s, e in evs) / max(1, len(evs))
-    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if evs else 0.0
-    traffic = None          # HBM bytes per launch from the PMC passes (separate rocprofv3 runs, see the json's "method")
-    pmc_file = os.path.join(ROOT, "profiles", "r1_rel_attn_pmc.json")
-    if a.config == "C2" and a.dtype == "bf16" and os.path.exists(pmc_file):
-        traffic = json.load(open(pmc_file))["traffic_bytes_per_launch"]
-    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": "rel_attn_fwd_kernel (%s relation operand)" % ("dense" if a.dense else "factored"),
-                "launches": len(evs), "avg_us": round(avg_ms * 1e3, 1), "algorithmic_bytes": alg_bytes}
+    P, R = n * n * B, stats["R"]
 
-    def avg_ms(name):
-        ev_ = prof.get(name, [])
-        return round(sum(s_.elapsed_time(e_) for s_, e_ in ev_) / max(1, len(ev_)), 3) if ev_ else None
-    components = {"relation_encoder_fwd_ms": avg_ms("relation_encoder_fwd"), "relation_gru_bwd_ms": avg_ms("relation_gru_bwd"),
-                  "graph_encoder_fwd_ms": avg_ms("graph_encoder_fwd"),
+    def span(pr, name):
+        ev_ = pr.get(name, [])
+        ms = [s_.elapsed_time(e_) for s_, e_, _u in ev_]
+        return (sum(ms) / len(ms), len(ms), sum(u for _, _, u in ev_)) if ms else (None, 0, 0)
+
+    components = {"relation_encoder_fwd_ms": span(prof, "relation_encoder_fwd")[0], "relation_gru_bwd_ms": span(prof, "relation_gru_bwd")[0],
+                  "graph_encoder_fwd_ms": span(prof, "graph_encoder_fwd")[0],
                   "note": "HIP-event spans on the main stream inside the timed region, per step"}
-
-    if rank == 0 and not a.dense and a.config in ("C1", "C2", "C3"):
-        # the same kernel on the reference's dense relation signature (rarb[S,T,B,2d] materialised), outside the timed region
-        del trainer
-        torch.cuda.empty_cache()
-        g = torch.Generator().manual_seed(1)
-        qkv = torch.randn(n, B, 3 * d, generator=g).to(dev, cd)
-        rarb = (0.3 * torch.randn(n * n * B, 2 * d, generator=g)).to(dev, cd).view(n, n, B, 2 * d)
-        ops.PROFILE = {}
-        for _ in range(6):
-            ops.attention_core(qkv, None, (0, d, 2 * d), d, cfg["H"], (d // cfg["H"]) ** -0.5, rel=rarb)
-        torch.cuda.synchronize()
-        ev = ops.PROFILE["rel_attn_fwd_mode1"][1:]
-        ops.PROFILE = None
-        dms = sum(s_.elapsed_time(e_) for s_, e_ in ev) / len(ev)
-        roofline["dense_signature"] = {"avg_us": round(dms * 1e3, 1), "achieved": round(alg_bytes / dms / 1e6, 1),
-                                       "frac": round(alg_bytes / dms / 1e6 / HBM_PEAK_GBS, 4)}
+    roofline = None
+    if rank == 0:
+        roofline = build_roofline(a, cfg, stats, model, trainer, batch, prof, dev, cd)
     if rank == 0:
         out = {"metric": "graphs/sec training step (100-node AMR, batch 64)", "value": world * B * a.steps / elapsed,
                "unit": "graphs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -296,14 +422,16 @@ def main():
                "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                "config": {"workload": "%s: generator/ %dx%d-node synthetic AMR graphs per GPU, %d-layer d=%d %d-head, "
                                       "full train step (fwd+bwd+allreduce+clip+Adam), dropout 0.2" % (
-                                          a.config, B, cfg["N"], cfg["layers"], d, cfg["H"]),
-                          "n": n, "B_per_gpu": B, "global_batch": world * B, "P": P, "R": stats["R"],
+                                          a.config, B, cfg["N"], cfg["layers"], d, H),
+                          "n": n, "B_per_gpu": B, "global_batch": world * B, "P": P, "R": R,
                           "mean_path_len": round(stats["mean_path_len"], 2), "T": stats["T"],
                           "relation_operand": "dense" if a.dense else "factored", "parallelism": "dp%d" % world,
+                          "relation_gru": "trie (dropout masks per trie node)" if gru_mod.TRIE else "per row",
+                          "allreduce_exposed_ms_per_step": round(1e3 * comm_exposed / a.steps, 3),
                           "loss_first": losses[0], "loss_last": losses[-1]},
                "roofline": roofline, "components": components}
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.config, a.cpu_graphs)
+            out["cpu_baseline"] = cpu_baseline(a.config, a.cpu_graphs, a.cpu_steps)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -17,7 +17,7 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-HOST_SRCS = [os.path.join(os.path.dirname(CSRC), "csrc_host", f) for f in ("relbatch.cpp", "pathtrie.cpp")]
+HOST_SRCS = [os.path.join(os.path.dirname(CSRC), "csrc_host", f) for f in ("relbatch.cpp", "pathtrie.cpp", "relindex.cpp")]
 HOST_LIB = os.path.join(os.path.dirname(CSRC), "csrc_host", "libgtos_host.so")
 CXX = os.environ.get("CXX", "g++")
 

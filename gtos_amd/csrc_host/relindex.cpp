@@ -1,0 +1,107 @@
+// libgtos_host.so, third part: index preparation of the FACTORED relation operand (include/gtos_host.h).
+//
+// generator/generator.py:79 expands relation[n,n,B] (type ids) into a dense [n,n,B,d] tensor; the MI355X attention kernels
+// read the type ids instead (gtos_amd/ops.py FactoredRelation) and need, once per batch:
+//   * the ids in query-major and key-major order as int32 (the kernels stream them beside q / k),
+//   * for the bank gradient (the index_add of autograd's index_select backward): the pairs grouped by type, cut into chunks
+//     of <= `chunk` pairs; types with several chunks ("heavy": <CLS>, <rCLS>, <SELF>, <TL>) get an fp32 accumulation slot,
+//   * the chunks ordered by (XCD that owns the graph of the chunk's first pair, graph, key row) so that consecutive
+//     workgroups of the gradient kernel gather q / k rows of one graph from that XCD's L2.
+// All of it is integer work on the batch's relation tensor, so it belongs to batch assembly on the host, next to the bank.
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#include "../../include/gtos_host.h"
+
+struct gtos_relindex {
+    int n = 0, B = 0;
+    int64_t R = 0, P = 0;
+    std::vector<int32_t> idx_q, idx_k, pair_sorted, chunk_type, chunk_start, chunk_count, chunk_slot, xcd_off, heavy_types;
+};
+
+extern "C" gtos_relindex* gtos_relindex_build(int n, int B, int64_t R, const int64_t* relation, int chunk) {
+    if (n <= 0 || B <= 0 || R <= 0 || !relation || chunk <= 0) return nullptr;
+    const int64_t P = (int64_t)n * n * B;
+    if (P > 0x7fffffffLL || R > 0x7fffffffLL) return nullptr;
+    auto* h = new gtos_relindex();
+    h->n = n; h->B = B; h->R = R; h->P = P;
+    h->idx_q.resize(P);
+    h->idx_k.resize(P);
+    std::vector<int64_t> count(R + 1, 0);
+    // relation[j][i][b] at flat index (j*n + i)*B + b
+    for (int64_t j = 0; j < n; ++j)
+        for (int64_t i = 0; i < n; ++i)
+            for (int64_t b = 0; b < B; ++b) {
+                const int64_t t = relation[(j * n + i) * B + b];
+                if (t < 0 || t >= R) { delete h; return nullptr; }
+                h->idx_q[(i * B + b) * n + j] = (int32_t)t;       // [i,b,j]
+                h->idx_k[(j * B + b) * n + i] = (int32_t)t;       // [j,b,i]
+                count[t + 1]++;
+            }
+    for (int64_t t = 0; t < R; ++t) count[t + 1] += count[t];
+    // pairs grouped by type; inside a type graph-major (b, j, i): the pairs of one graph are neighbours
+    h->pair_sorted.resize(P);
+    {
+        std::vector<int64_t> cur(count.begin(), count.end() - 1);
+        for (int64_t b = 0; b < B; ++b)
+            for (int64_t j = 0; j < n; ++j)
+                for (int64_t i = 0; i < n; ++i) {
+                    const int64_t p = (j * n + i) * B + b;
+                    h->pair_sorted[cur[relation[p]]++] = (int32_t)p;
+                }
+    }
+    struct Chunk { int32_t type, start, cnt, slot; int64_t key; };
+    std::vector<Chunk> chunks;
+    chunks.reserve(R + P / chunk);
+    for (int64_t t = 0; t < R; ++t) {
+        const int64_t lo = count[t], hi = count[t + 1];
+        const int64_t nch = hi > lo ? (hi - lo + chunk - 1) / chunk : 1;      // a type without pairs still writes its zero row
+        int32_t slot = -1;
+        if (nch > 1) {
+            slot = (int32_t)h->heavy_types.size();
+            h->heavy_types.push_back((int32_t)t);
+        }
+        for (int64_t c = 0; c < nch; ++c) {
+            const int64_t s = lo + c * chunk;
+            const int64_t cnt = std::max<int64_t>(0, std::min<int64_t>(chunk, hi - s));
+            const int64_t first = h->pair_sorted[std::min<int64_t>(s, P - 1)];
+            const int64_t gb = first % B, j = first / ((int64_t)n * B);
+            const int64_t xcd = (B % 8 == 0) ? gb / (B / 8) : gb % 8;       // the attention kernels' graph -> XCD map
+            chunks.push_back({(int32_t)t, (int32_t)s, (int32_t)cnt, slot, (xcd << 40) | (gb << 20) | j});
+        }
+    }
+    std::stable_sort(chunks.begin(), chunks.end(), [](const Chunk& a, const Chunk& b) { return a.key < b.key; });
+    const size_t nc = chunks.size();
+    h->chunk_type.resize(nc); h->chunk_start.resize(nc); h->chunk_count.resize(nc); h->chunk_slot.resize(nc);
+    h->xcd_off.assign(9, 0);
+    for (size_t c = 0; c < nc; ++c) {
+        h->chunk_type[c] = chunks[c].type; h->chunk_start[c] = chunks[c].start;
+        h->chunk_count[c] = chunks[c].cnt; h->chunk_slot[c] = chunks[c].slot;
+        h->xcd_off[(chunks[c].key >> 40) + 1]++;
+    }
+    for (int x = 0; x < 8; ++x) h->xcd_off[x + 1] += h->xcd_off[x];
+    return h;
+}
+
+extern "C" int gtos_relindex_sizes(const gtos_relindex* h, int64_t* sizes) {
+    if (!h || !sizes) return -1;
+    sizes[0] = h->P; sizes[1] = (int64_t)h->chunk_type.size(); sizes[2] = (int64_t)h->heavy_types.size();
+    return 0;
+}
+
+extern "C" int gtos_relindex_export(const gtos_relindex* h, int32_t** out) {
+    if (!h || !out) return -1;
+    const std::vector<int32_t>* v[] = {&h->idx_q, &h->idx_k, &h->pair_sorted, &h->chunk_type, &h->chunk_start, &h->chunk_count,
+                                       &h->chunk_slot, &h->xcd_off, &h->heavy_types};
+    int k = 0;
+    for (auto* a : v) {
+        if (out[k] && !a->empty()) std::memcpy(out[k], a->data(), a->size() * sizeof(int32_t));
+        ++k;
+    }
+    return k;
+}
+
+extern "C" void gtos_relindex_free(gtos_relindex* h) { delete h; }

@@ -11,6 +11,7 @@ import torch
 
 from . import relbatch
 from .pathtrie import build_path_trie
+from .relindex import attach_relation_index
 from .vocab import CLS, rCLS, SEL, TL, STR, END, lists_to_tensor, strings_to_char_tensor, copy_vocab
 
 
@@ -52,7 +53,7 @@ def batchify_dependency(trees, vocabs, n_threads=0, unk_rate=0., rng=None, repla
         for c in concepts:
             for _ in range(len(c) * len(c)):
                 gen.choice(one)
-    return {
+    return attach_relation_index({
         'concept': concept,
         'concept_char': strings_to_char_tensor(with_cls, vocabs['concept_char']),
         'concept_depth': lists_to_tensor([[0] + d for d in depths]),
@@ -63,7 +64,7 @@ def batchify_dependency(trees, vocabs, n_threads=0, unk_rate=0., rng=None, repla
         'token_char_in': strings_to_char_tensor(aug, vocabs['token_char'])[:-1],
         'token_out': lists_to_tensor(aug, vocabs['predictable_token'], t2is)[1:],
         'cp_seq': lists_to_tensor(cps, vocabs['predictable_token'], t2is),
-    }
+    })
 
 
 def read_dependency_file(path):
@@ -169,7 +170,7 @@ def batchify_amr(items, vocabs, train=True, seed=0, n_threads=0, unk_rate=0., rn
         cps.append(cp_seq); t2is.append(t2i); i2ts.append(i2t)
     aug = [[STR] + list(x['token']) + [END] for x in items]
     with_cls = [[CLS] + list(x['concept']) for x in items]
-    return {
+    return attach_relation_index({
         'concept': lists_to_tensor(with_cls, vocabs['concept'], unk_rate=unk_rate, rng=rng),
         'concept_char': strings_to_char_tensor(with_cls, vocabs['concept_char']),
         'concept_depth': lists_to_tensor([[0] + list(x['depth']) for x in items]),
@@ -181,4 +182,4 @@ def batchify_amr(items, vocabs, train=True, seed=0, n_threads=0, unk_rate=0., rn
         'token_out': lists_to_tensor(aug, vocabs['predictable_token'], t2is)[1:],
         'cp_seq': lists_to_tensor(cps, vocabs['predictable_token'], t2is),
         'abstract': [x.get('abstract') for x in items],
-    }
+    })   # train batches also carry 'relation_index' (eval batches are [n,n,B,K]: not factored)

@@ -77,12 +77,17 @@ class Generator(nn.Module):
             concept_repr, bank = self.grad_sync.boundary(2, concept_repr, bank)
         if train:
             if self.factored_relation:
-                relation = ops.FactoredRelation(bank, inp['relation'])
+                relation = ops.FactoredRelation(bank, inp['relation'], index=inp.get('relation_index'))
             else:
                 relation = bank.index_select(0, inp['relation'].reshape(-1)).view(*inp['relation'].size(), -1)
+        elif inp['relation'].dim() == 4 and self.factored_relation:
+            # generator flavour, eval: [n,n,B,K] alternative paths averaged (generator.py:83-88) -- as a derived bank of the
+            # distinct K-tuples + per-pair ids, so the [n,n,B,d] tensor and its projection are never built
+            relation = ops.factored_eval_relation(bank.detach(), inp['relation'])
+        elif inp['relation'].dim() == 3 and self.factored_relation:
+            # translator flavour: one path per pair, the plain lookup (translator/generator.py:73), no autograd graph
+            relation = ops.FactoredRelation(bank.detach(), inp['relation'], index=inp.get('relation_index'))
         else:
-            # generator flavour: [n,n,B,K] alternatives averaged (generator.py:83-88); translator flavour: one path per
-            # pair, the plain lookup (translator/generator.py:73), here without building an autograd graph
             relation = ops.relation_gather_mean(bank.detach(), inp['relation'], zero_row0=inp['relation'].dim() == 4)
         with ops._Timed("graph_encoder_fwd"):
             concept_repr = self.graph_encoder(concept_repr, relation, self_padding_mask=concept_mask)
@@ -93,7 +98,8 @@ class Generator(nn.Module):
         with torch.no_grad():
             concept_repr, concept_mask = self._concepts(inp)
             bank = self.relation_encoder(inp['relation_bank'], inp['relation_length'], trie=inp.get('relation_trie'))
-            relation = ops.relation_gather_mean(bank, inp['relation'], zero_row0=True)
+            relation = (ops.factored_eval_relation(bank, inp['relation']) if self.factored_relation
+                        else ops.relation_gather_mean(bank, inp['relation'], zero_row0=True))
             return self.graph_encoder.get_attn_weights(concept_repr, relation, self_padding_mask=concept_mask)
 
     def forward(self, data):

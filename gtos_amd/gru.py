@@ -39,6 +39,13 @@ def _step_fwd(A, hs, x, xg, h_in, wi, b_ih, wh, b_hh, h_out, n_out, h_fin, gates
               h_idx=None, gf=None, gf_idx=None, gb=None, gb_idx=None):
     yp = None if y is None else y.data_ptr() + y_off_elems * y.element_size()
     need_bi = x is not None or gf is not None
+    with _Timed("gru_step_fwd_%s" % ("x" if x is not None else ("tables" if gf is not None else "xg")), detail=True, units=A):
+        _step_fwd_call(A, hs, x, xg, h_in, wi, b_ih, wh, b_hh, h_out, n_out, h_fin, gates, yp, ldy, p, seed, drop_base,
+                       h_idx, gf, gf_idx, gb, gb_idx, need_bi)
+
+
+def _step_fwd_call(A, hs, x, xg, h_in, wi, b_ih, wh, b_hh, h_out, n_out, h_fin, gates, yp, ldy, p, seed, drop_base,
+                   h_idx, gf, gf_idx, gb, gb_idx, need_bi):
     call("gtos_gru_step_fwd", A, hs, ptr(x), 0 if x is None else x.stride(0), 0 if x is None else x.shape[1],
          ptr(wi) if x is not None else None, ptr(b_ih) if need_bi else None, ptr(xg),
          ptr(gf), ptr(gf_idx), ptr(gb), ptr(gb_idx), ptr(h_in), ptr(h_idx), ptr(wh), ptr(b_hh),
@@ -46,9 +53,10 @@ def _step_fwd(A, hs, x, xg, h_in, wi, b_ih, wh, b_hh, h_out, n_out, h_fin, gates
 
 
 def _step_bwd(A, hs, d4_prev, rows_prev, wh_t, gates, hprev, dy_ptr, ldy, dh, d4, p, seed, drop_base, bpart, hprev_idx=None):
-    call("gtos_gru_step_bwd", A, hs, ptr(d4_prev), rows_prev if d4_prev is not None else 0, ptr(wh_t), ptr(gates), ptr(hprev),
-         ptr(hprev_idx), dy_ptr, ldy, ptr(dh), dt(dh), ptr(d4), float(p), seed, drop_base,
-         ptr(bpart), N_BIAS_PARTIALS if bpart is not None else 0, stream())
+    with _Timed("gru_step_bwd_%s" % ("trie" if hprev_idx is not None else "rows"), detail=True, units=A):
+        call("gtos_gru_step_bwd", A, hs, ptr(d4_prev), rows_prev if d4_prev is not None else 0, ptr(wh_t), ptr(gates), ptr(hprev),
+             ptr(hprev_idx), dy_ptr, ldy, ptr(dh), dt(dh), ptr(d4), float(p), seed, drop_base,
+             ptr(bpart), N_BIAS_PARTIALS if bpart is not None else 0, stream())
 
 
 def _cell_bwd(A, hs, gates, hprev, dy, dy_off_elems, ldy, dh, dxg, dhg, p, seed, drop_base, bpart):
@@ -263,6 +271,11 @@ TRIE = os.environ.get("GTOS_GRU_TRIE", "1") != "0"
 def _seg_rows(side, src, width, dst):
     """dst[node] = sum of src rows of the node (row lists of the trie side), fp32 accumulation."""
     heavy = torch.zeros((max(1, side.n_heavy), width), dtype=torch.float32, device=src.device)
+    with _Timed("segment_sum_rows", detail=True, units=int(side.rows.numel())):
+        _seg_rows_call(side, src, width, dst, heavy)
+
+
+def _seg_rows_call(side, src, width, dst, heavy):
     call("gtos_segment_sum_rows", side.n_chunks, ptr(side.rows), ptr(side.chunk_node), ptr(side.chunk_start), ptr(side.chunk_cnt),
          ptr(side.chunk_slot), ptr(src), src.stride(0), width, ptr(dst), dst.stride(0), ptr(heavy), stream())
     call("gtos_segment_sum_finish", side.n_heavy, ptr(side.heavy_node), ptr(heavy), width, ptr(dst), dst.stride(0), stream())

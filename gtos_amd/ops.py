@@ -14,23 +14,28 @@ _seed_state = [0x5DEECE66D]
 
 # Optional kernel timing with HIP events on the launch stream (bench.py's roofline leg): name -> [(start, end)]
 PROFILE = None
+PROFILE_DETAIL = False     # also time the per-launch kernels (GRU steps, attention backward, segment sums): bench.py's detail pass
 GEMM_PROFILE = None        # tools/profile_step.py: (layout, N, K, out dtype) -> [(M, start, end)]
 
 
 class _Timed:
-    def __init__(self, name):
-        self.name = name
+    """HIP-event span on the current stream, recorded into PROFILE[name] as (start, end, units); ``detail`` spans are only
+    taken in bench.py's detail pass (an event pair costs more than a small kernel)."""
+
+    def __init__(self, name, detail=False, units=0):
+        self.name, self.units = name, units
+        self.on = PROFILE is not None and (PROFILE_DETAIL or not detail)
 
     def __enter__(self):
-        if PROFILE is not None:
+        if self.on:
             self.s = torch.cuda.Event(enable_timing=True)
             self.e = torch.cuda.Event(enable_timing=True)
             self.s.record()
 
     def __exit__(self, *a):
-        if PROFILE is not None:
+        if self.on:
             self.e.record()
-            PROFILE.setdefault(self.name, []).append((self.s, self.e))
+            PROFILE.setdefault(self.name, []).append((self.s, self.e, self.units))
 
 
 def next_seed():
@@ -345,6 +350,17 @@ def layer_norm_residual(x, r, gamma, beta, p_drop=0.0, eps=1e-5):
     return LayerNormResidualFn.apply(x, r, gamma, beta, float(p_drop), eps)
 
 
+def check_attention_shape(embed_dim, num_heads):
+    """The attention kernels' hard shape boundary (include/gtos_hip.h, gtos_rel_attn_fwd): refuse at construction, loudly,
+    instead of failing at the first forward."""
+    hd = embed_dim // max(1, num_heads)
+    ok = (num_heads > 0 and embed_dim % num_heads == 0 and embed_dim <= 512 and embed_dim & (embed_dim - 1) == 0
+          and hd >= 8 and hd & (hd - 1) == 0)
+    if not ok:
+        raise _lib.GtosHipError("attention shape embed_dim=%d, heads=%d is outside the gfx950 kernels' boundary: embed_dim and "
+                                "embed_dim/heads must be powers of two, head size >= 8, embed_dim <= 512" % (embed_dim, num_heads))
+
+
 def _u8(mask):
     if mask is None:
         return None
@@ -359,13 +375,30 @@ class FactoredRelation:
 
     CHUNK = 32
 
-    def __init__(self, bank, relation):
+    def __init__(self, bank, relation, index=None):
+        """``index``: the batch's host-built gtos_amd.relindex.RelationIndex (``batch['relation_index']``); without one the
+        same arrays are derived here with device sort / search ops."""
         require_cuda(bank, relation)
         self.bank = bank
         self.grad_group = GradAccumGroup()
         n, n2, B = relation.shape
         assert n == n2
         self.n, self.B = n, B
+        self._proj = {}
+        if not (torch.is_grad_enabled() and bank.requires_grad):
+            # forward only (inference): the kernels read the query-major ids, nothing else
+            self.idx_q = (index.idx_q if index is not None and index.matches(bank, relation)
+                          else relation.permute(1, 2, 0).contiguous().to(torch.int32))
+            self.idx_k = self.pair_sorted = self.chunk_type = self.chunk_start = self.chunk_count = self.chunk_slot = None
+            self.xcd_off = self.heavy_types = None
+            self.nchunks = 0
+            return
+        if index is not None and index.matches(bank, relation):
+            self.idx_q, self.idx_k, self.pair_sorted = index.idx_q, index.idx_k, index.pair_sorted
+            self.chunk_type, self.chunk_start = index.chunk_type, index.chunk_start
+            self.chunk_count, self.chunk_slot = index.chunk_count, index.chunk_slot
+            self.xcd_off, self.heavy_types, self.nchunks = index.xcd_off, index.heavy_types, index.nchunks
+            return
         rel = relation.contiguous()
         self.idx_q = rel.permute(1, 2, 0).contiguous().to(torch.int32)    # [i,b,j] = relation[j,i,b]
         self.idx_k = rel.permute(0, 2, 1).contiguous().to(torch.int32)    # [j,b,i]
@@ -398,9 +431,8 @@ class FactoredRelation:
         self.xcd_off = torch.searchsorted(xs, torch.arange(9, device=flat.device, dtype=torch.int32)).to(torch.int32)
         self.chunk_type, self.chunk_start = c_type[perm], c_start[perm]
         self.chunk_count, self.chunk_slot = c_count[perm], c_slot[perm]
-        self.heavy_types = heavy_types
+        self.heavy_types = heavy_types.to(torch.int32)
         self.nchunks = int(ctype.numel())
-        self._proj = {}
 
     def prefetch_projections(self, attns):
         """relation_in_proj(bank) of EVERY layer depends only on the bank, not on the layer chain: compute them on the side
@@ -483,23 +515,27 @@ class RelAttnFn(torch.autograd.Function):
         pd = torch.empty((T_, S, B, H), dtype=torch.float32, device=qsrc.device)
         gs = torch.empty_like(pd)
         es = qsrc.element_size()
-        call("gtos_rel_attn_bwd", dt(qsrc), mode, T_, S, B, H, d,
-             qsrc.data_ptr() + q_off * es, Cq, kv.data_ptr() + k_off * es, Ckv, kv.data_ptr() + v_off * es, Ckv,
-             ptr(rel), ptr(fact.idx_q) if fact is not None else None, ptr(fact.idx_k) if fact is not None else None,
-             ptr(key_pad), ptr(attn_mask), float(scale), float(p_drop), seed,
-             ptr(o), d, ptr(lse), ptr(w), ptr(d_o), d, ptr(d_w),
-             dqsrc.data_ptr() + q_off * es, Cq, dkv.data_ptr() + k_off * es, Ckv, dkv.data_ptr() + v_off * es, Ckv,
-             ptr(d_rel), ptr(pd), ptr(gs), stream())
+        with _Timed("rel_attn_bwd_q+kv_mode%d" % mode, detail=True):
+            call("gtos_rel_attn_bwd", dt(qsrc), mode, T_, S, B, H, d,
+                 qsrc.data_ptr() + q_off * es, Cq, kv.data_ptr() + k_off * es, Ckv, kv.data_ptr() + v_off * es, Ckv,
+                 ptr(rel), ptr(fact.idx_q) if fact is not None else None, ptr(fact.idx_k) if fact is not None else None,
+                 ptr(key_pad), ptr(attn_mask), float(scale), float(p_drop), seed,
+                 ptr(o), d, ptr(lse), ptr(w), ptr(d_o), d, ptr(d_w),
+                 dqsrc.data_ptr() + q_off * es, Cq, dkv.data_ptr() + k_off * es, Ckv, dkv.data_ptr() + v_off * es, Ckv,
+                 ptr(d_rel), ptr(pd), ptr(gs), stream())
         if mode == 2:
             d_rel = torch.empty_like(rel)
             nh = int(fact.heavy_types.numel())
             heavy = torch.zeros((max(nh, 1), 2 * d), dtype=torch.float32, device=rel.device)
-            call("gtos_rel_attn_bwd_bank", dt(qsrc), T_, B, H, d,
-                 qsrc.data_ptr() + q_off * es, Cq, kv.data_ptr() + k_off * es, Ckv,
-                 ptr(rel), ptr(gs), ptr(fact.pair_sorted), ptr(fact.chunk_type), ptr(fact.chunk_start),
-                 ptr(fact.chunk_count), ptr(fact.chunk_slot), ptr(fact.xcd_off), fact.nchunks, ptr(d_rel), ptr(heavy), stream())
-            if nh:
-                d_rel[fact.heavy_types] = heavy[:nh].to(d_rel.dtype)
+            with _Timed("rel_attn_bwd_bank", detail=True):
+                call("gtos_rel_attn_bwd_bank", dt(qsrc), T_, B, H, d,
+                     qsrc.data_ptr() + q_off * es, Cq, kv.data_ptr() + k_off * es, Ckv,
+                     ptr(rel), ptr(gs), ptr(fact.pair_sorted), ptr(fact.chunk_type), ptr(fact.chunk_start),
+                     ptr(fact.chunk_count), ptr(fact.chunk_slot), ptr(fact.xcd_off), fact.nchunks, ptr(d_rel), ptr(heavy), stream())
+            if nh and d_rel.dtype == torch.bfloat16:         # heavy types: fp32 slots rounded straight into their bank rows
+                call("gtos_segment_sum_finish", nh, ptr(fact.heavy_types), ptr(heavy), 2 * d, ptr(d_rel), 2 * d, stream())
+            elif nh:
+                d_rel[fact.heavy_types.long()] = heavy[:nh].to(d_rel.dtype)
         return dqsrc, (dkv if kvsrc is not None else None), d_rel, None, None, None, None, None, None, None, None, None
 
 
@@ -507,6 +543,18 @@ def attention_core(qsrc, kvsrc, offs, d, H, scale, rel=None, fact=None, key_pad=
                    p_drop=0.0, need_weights=False):
     return RelAttnFn.apply(qsrc, kvsrc, rel, fact, offs, d, H, scale, _u8(key_pad), _u8(attn_mask),
                            float(p_drop), need_weights)
+
+
+def factored_eval_relation(bank, relation):
+    """Eval-mode relation operand WITHOUT the dense [n,n,B,d] tensor: relation [n,n,B,K] lists up to K alternative
+    shortest paths per pair (0 = <PAD>), and the reference feeds the graph encoder the mean of their bank rows
+    (generator/generator.py:83-88).  Many pairs share their K-tuple of types, so the distinct tuples become a derived bank
+    (mean of the tuple's rows, same arithmetic as the reference: bank row 0 zeroed, sum, divide by the clamped count) and
+    every pair an id into it: the encoder then runs on the factored operand exactly as in training."""
+    n, n2, B, K = relation.shape
+    tuples, inv = torch.unique(relation.reshape(-1, K), dim=0, return_inverse=True)
+    bank_c = relation_gather_mean(bank, tuples, zero_row0=True)                 # [C, d]
+    return FactoredRelation(bank_c, inv.view(n, n2, B))
 
 
 def relation_gather_mean(bank, idx, zero_row0):

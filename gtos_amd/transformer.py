@@ -19,6 +19,7 @@ class MultiheadAttention(nn.Module):
         self.embed_dim, self.num_heads, self.dropout = embed_dim, num_heads, dropout
         self.head_dim = embed_dim // num_heads
         assert self.head_dim * num_heads == self.embed_dim, "embed_dim must be divisible by num_heads"
+        ops.check_attention_shape(embed_dim, num_heads)
         self.scaling = self.head_dim ** -0.5
         self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
         self.in_proj_bias = nn.Parameter(torch.empty(3 * embed_dim))

@@ -78,6 +78,23 @@ int gtos_pathtrie_sizes(const gtos_pathtrie* h, int64_t* sizes);
 int gtos_pathtrie_export(const gtos_pathtrie* h, int32_t** out);
 void gtos_pathtrie_free(gtos_pathtrie* h);
 
+/* ---- Index preparation of the factored relation operand (gtos_amd/csrc_host/relindex.cpp): what the attention kernels
+ * read instead of the dense relation.index_select(...).view(n,n,B,d) of generator/generator.py:79.
+ * relation: int64 [n,n,B] type ids in [0,R) (relation[j][i][b] pairs query i with key j).  chunk: pairs per bank-gradient
+ * chunk (32).  NULL on invalid input. */
+typedef struct gtos_relindex gtos_relindex;
+gtos_relindex* gtos_relindex_build(int n, int B, int64_t R, const int64_t* relation, int chunk);
+/* sizes[3] = {P = n*n*B, chunks, heavy types} */
+int gtos_relindex_sizes(const gtos_relindex* h, int64_t* sizes);
+/* Fills 9 caller-allocated int32 arrays (NULL entries are skipped):
+ *   idx_q[P]  ids in [i,b,j] order      idx_k[P]  ids in [j,b,i] order
+ *   pair_sorted[P]  flat pair indices (j*n+i)*B+b grouped by type, graph-major inside a type
+ *   chunk_type/start/count/slot[chunks]  gradient chunks over pair_sorted (slot = heavy slot, -1 for single-chunk types),
+ *                   ordered by (XCD of the first pair's graph, graph, key row)
+ *   xcd_off[9]      chunk ranges per XCD      heavy_types[heavy]  type id of every heavy slot.  Returns 9. */
+int gtos_relindex_export(const gtos_relindex* h, int32_t** out);
+void gtos_relindex_free(gtos_relindex* h);
+
 #ifdef __cplusplus
 }
 #endif

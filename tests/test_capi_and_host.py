@@ -174,3 +174,18 @@ def test_lr_schedule_and_decay_rule():
     assert inverse_sqrt_lr(512, 8000, 2000) < inverse_sqrt_lr(512, 2000, 2000)
     assert is_no_decay("graph_encoder.layers.0.fc1.bias") and is_no_decay("token_embed_layer_norm.weight")
     assert not is_no_decay("graph_encoder.layers.0.self_attn.in_proj_weight")
+
+
+def test_attention_shape_boundary_is_refused_at_construction():
+    """include/gtos_hip.h documents the kernels' hard shape boundary (d, d/H powers of two, d/H >= 8, d <= 512); the
+    modules must raise at construction for anything else (the reference only needs d % H == 0)."""
+    import pytest
+    from gtos_amd._lib import GtosHipError
+    from gtos_amd.graph_transformer import RelationMultiheadAttention
+    from gtos_amd.transformer import MultiheadAttention
+    for cls in (RelationMultiheadAttention, MultiheadAttention):
+        cls(512, 8)
+        cls(64, 1)
+        for d, H in ((768, 8), (1024, 8), (96, 4), (32, 8)):
+            with pytest.raises(GtosHipError):
+                cls(d, H)

@@ -1061,3 +1061,40 @@ def test_fused_copy_mixture_nll_and_loglikelihood(T_, B, V, S, dtype):
     torch.testing.assert_close(ad.grad.cpu(), ar.grad, rtol=1e-4, atol=1e-5)
     ll = ops.copy_log_likelihood(ld.detach(), dd.detach(), ad.detach(), cp_seq.to(dev()), tot)
     torch.testing.assert_close(ll.cpu(), ll_r.detach(), rtol=1e-4, atol=1e-4)
+
+
+def test_factored_relation_host_index_equals_device_index():
+    """ops.FactoredRelation with the loader's host-built RelationIndex must give the results of the device-built index:
+    same output, same dq/dk/dv, same bank gradient (chunk order and pair order inside a type differ, sums do not)."""
+    from gtos_amd import ops, synth
+    from gtos_amd.relindex import build_relation_index
+    batch, st = synth.make_batch(4, 8, 40, 8)
+    idx = batch["relation"].to(dev())
+    n, _, B = idx.shape
+    d, H, R = 256, 4, st["R"]
+    g = torch.Generator().manual_seed(8)
+    qkv = torch.randn(n, B, 3 * d, generator=g).to(dev(), torch.bfloat16)
+    bankp = (0.3 * torch.randn(R, 2 * d, generator=g)).to(dev(), torch.bfloat16)
+    wout = torch.randn(n, B, d, generator=g).to(dev())
+    index = build_relation_index(batch["relation"], R).to(dev())
+    assert index.n_heavy >= 3
+    res = []
+    for ix in (index, None):
+        q = qkv.clone().requires_grad_()
+        rel = bankp.clone().requires_grad_()
+        fact = ops.FactoredRelation(torch.zeros(R, 8, device=dev()), idx, index=ix)
+        o, _ = ops.attention_core(q, None, (0, d, 2 * d), d, H, (d // H) ** -0.5, rel=rel, fact=fact)
+        (o.float() * wout).sum().backward()
+        res.append((o.detach(), q.grad, rel.grad))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    torch.testing.assert_close(res[0][2].float(), res[1][2].float(), rtol=2e-2, atol=1e-3)
+
+
+def test_attention_kernel_rejects_shapes_outside_the_boundary():
+    """The C ABI returns an error code (no launch, no fallback) for shapes outside the documented boundary."""
+    from gtos_amd import ops
+    from gtos_amd._lib import GtosHipError
+    for d, H in ((768, 8), (96, 4)):
+        qkv = torch.randn(5, 2, 3 * d, device=dev())
+        with pytest.raises(GtosHipError):
+            ops.attention_core(qkv, None, (0, d, 2 * d), d, H, 1.0)

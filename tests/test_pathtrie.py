@@ -100,3 +100,37 @@ def test_pathtrie_rejects_bad_lengths():
         build_path_trie(torch.ones(3, 4, dtype=torch.int64), torch.tensor([1, 0, 2, 3]))
     with pytest.raises(ValueError):
         build_path_trie(torch.ones(3, 4, dtype=torch.int64), torch.tensor([1, 4, 2, 3]))
+
+
+# ------------------------------------------------------------------------------------------------ relation index (host)
+@pytest.mark.parametrize("B", [5, 8])
+def test_relation_index_groups_pairs_by_type(B):
+    from gtos_amd import synth
+    from gtos_amd.relindex import build_relation_index
+    batch, st = synth.make_batch(3, B, 12, 6)
+    rel, R = batch['relation'], batch['relation_bank'].shape[1]
+    ix = build_relation_index(rel, R, chunk=4)
+    n = rel.shape[0]
+    assert torch.equal(ix.idx_q.long(), rel.permute(1, 2, 0)) and torch.equal(ix.idx_k.long(), rel.permute(0, 2, 1))
+    flat = rel.reshape(-1)
+    ps = ix.pair_sorted.long()
+    assert sorted(ps.tolist()) == list(range(flat.numel()))
+    seen, keys = {}, []
+    for c in range(ix.nchunks):
+        t, s, k, sl = int(ix.chunk_type[c]), int(ix.chunk_start[c]), int(ix.chunk_count[c]), int(ix.chunk_slot[c])
+        assert 0 <= k <= 4 and all(int(flat[p]) == t for p in ps[s:s + k])
+        seen.setdefault(t, []).extend(ps[s:s + k].tolist())
+        assert (sl >= 0) == (int((flat == t).sum()) > 4)
+        if sl >= 0:
+            assert int(ix.heavy_types[sl]) == t
+        first = int(ps[min(s, flat.numel() - 1)])
+        gb = first % B
+        keys.append(((gb // (B // 8)) if B % 8 == 0 else gb % 8, gb, first // (n * B)))
+    assert set(seen) == set(range(R))                                   # every type has a chunk, even one without pairs
+    for t, got in seen.items():
+        assert sorted(got) == torch.nonzero(flat == t).flatten().tolist()
+    assert keys == sorted(keys)                                          # (XCD, graph, key row) order
+    xo = ix.xcd_off.tolist()
+    assert xo[0] == 0 and xo[-1] == ix.nchunks and [sum(1 for k_ in keys if k_[0] == x) for x in range(8)] == [xo[x + 1] - xo[x] for x in range(8)]
+    with pytest.raises(ValueError):
+        build_relation_index(rel, R - 1)

@@ -29,7 +29,8 @@ def main():
     trainer = Trainer(model, cfg["d"], warmup_steps=2000, compute_dtype=torch.bfloat16, world_size=1)
     batch, stats = synth.make_config_batch(a.config)
     from gtos_amd.pathtrie import attach_path_trie
-    batch = {k: v.to(dev) for k, v in attach_path_trie(batch).items()}
+    from gtos_amd.relindex import attach_relation_index
+    batch = {k: v.to(dev) for k, v in attach_relation_index(attach_path_trie(batch)).items()}
     for _ in range(2):
         trainer.step(batch)
     torch.cuda.synchronize()
