@@ -385,8 +385,8 @@ class FactoredRelation:
         assert n == n2
         self.n, self.B = n, B
         self._proj = {}
-        if not (torch.is_grad_enabled() and bank.requires_grad):
-            # forward only (inference): the kernels read the query-major ids, nothing else
+        if not torch.is_grad_enabled():
+            # forward only (inference, under no_grad): the kernels read the query-major ids, nothing else
             self.idx_q = (index.idx_q if index is not None and index.matches(bank, relation)
                           else relation.permute(1, 2, 0).contiguous().to(torch.int32))
             self.idx_k = self.pair_sorted = self.chunk_type = self.chunk_start = self.chunk_count = self.chunk_slot = None
