@@ -470,7 +470,7 @@ struct BankArgs {
     const int* chunk_count;      // [C]
     const int* chunk_slot;       // [C] -1 -> store d_bank[t] directly; >= 0 -> atomicAdd into heavy[slot]
     const int* xcd_off;          // [9] or null: chunks [xcd_off[x], xcd_off[x+1]) belong to XCD x (their pairs' graphs live in its L2)
-    void* d_bank;                // [R,2d] type T
+    void* d_bank; int64_t ld_dbank;   // [R,2d] type T, row stride ld_dbank (a column block of a wider gradient slab)
     float* heavy;                // [n_heavy,2d] fp32, zero-initialised by the caller
     int nchunks, T, S, B, H, d;
 };
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_bank_kernel(BankArgs a) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { atomicAdd(out + e, fmaf(gsum, RB[e], da[e])); atomicAdd(out + d + e, fmaf(gsum, RA[e], db[e])); }
             } else {
-                T* out = static_cast<T*>(a.d_bank) + (int64_t)m1.t * (2 * d) + c;
+                T* out = static_cast<T*>(a.d_bank) + (int64_t)m1.t * a.ld_dbank + c;
                 float r1[8], r2[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { r1[e] = fmaf(gsum, RB[e], da[e]); r2[e] = fmaf(gsum, RA[e], db[e]); }
@@ -654,14 +654,15 @@ extern "C" int gtos_rel_attn_bwd_bank(int dtype, int n, int B, int H, int d,
                                       const void* bank, const float* gs,
                                       const int* pair_sorted, const int* chunk_type, const int* chunk_start,
                                       const int* chunk_count, const int* chunk_slot, const int* xcd_off, int nchunks,
-                                      void* d_bank, float* heavy, void* stream) {
+                                      void* d_bank, int64_t ld_dbank, float* heavy, void* stream) {
     int rc = check_shape(d, H);
     if (rc) return rc;
+    if (ld_dbank < 2 * d || ld_dbank % 8) return -14;
     if (nchunks <= 0) return 0;
     BankArgs a;
     a.q = q; a.k = k; a.ldq = ldq; a.ldk = ldk; a.bank = bank; a.gs = gs; a.pair_sorted = pair_sorted;
     a.chunk_type = chunk_type; a.chunk_start = chunk_start; a.chunk_count = chunk_count; a.chunk_slot = chunk_slot;
-    a.d_bank = d_bank; a.heavy = heavy; a.nchunks = nchunks; a.T = n; a.S = n; a.B = B; a.H = H; a.d = d;
+    a.d_bank = d_bank; a.ld_dbank = ld_dbank; a.heavy = heavy; a.nchunks = nchunks; a.T = n; a.S = n; a.B = B; a.H = H; a.d = d;
     a.xcd_off = xcd_off;
     hipStream_t s = static_cast<hipStream_t>(stream);
     int grid = (nchunks + 3) / 4; if (grid > 4096) grid = 4096;

@@ -201,27 +201,76 @@ def _grad_target(p):
     return None
 
 
+# The relation bank feeds relation_in_proj of every graph-encoder layer.  Instead of L input-gradient products
+# [R,2d] x [2d,d] accumulated one after the other (K = 2d = 1024: the 128x128-tile kernel, a read-modify-write of the [R,d]
+# accumulator per layer, bf16 rounding L times), the layers' d(rel) are written side by side into ONE [R, L*2d] slab (the
+# bank-gradient kernel takes a row stride) and the bank's gradient is ONE product with K = L*2d = 8192 on the 256x256
+# deep-K kernel, accumulated in fp32 across all layers.  GTOS_BATCH_DX=0 restores the per-layer products.
+BATCH_DX = os.environ.get("GTOS_BATCH_DX", "1") != "0"
+
+
 class GradAccumGroup:
-    """Several LinearFn calls that share ONE input tensor (the relation bank feeds relation_in_proj of every layer): their
-    input gradients are accumulated by the GEMM epilogue into one buffer, and only the last backward call hands it to
-    autograd -- instead of L separate [R,d] tensors that autograd would add pairwise."""
+    """Several LinearFn calls that share ONE input tensor (the relation bank): only the last backward call hands the summed
+    input gradient to autograd -- instead of L separate [R,d] tensors that autograd would add pairwise."""
 
     def __init__(self):
-        self.pending = 0
-        self.buf = None
+        self.pending = 0          # members whose backward has not run yet
+        self.members = 0          # registered in forward
+        self.buf = None           # per-member accumulation (fallback path)
+        self.slab = None          # [R, members*w]: the members' output gradients side by side
+        self.width = 0
+        self.handed = 0           # column blocks handed out
+        self.pieces = []          # (column block, W^T [in, w]) of members whose backward has run
 
     def register(self):
         self.pending += 1
+        self.members += 1
+
+    def grad_slice(self, like):
+        """Column block of the slab for the next member's output gradient ([R,w], row stride members*w), or None."""
+        R, w = like.shape
+        if not BATCH_DX or self.members < 2 or like.dtype != torch.bfloat16:
+            return None
+        if self.slab is None:
+            self.slab = torch.empty((R, self.members * w), dtype=like.dtype, device=like.device)
+            self.width, self.handed = w, 0
+        if self.handed >= self.members or w != self.width or self.slab.shape[0] != R:
+            return None
+        j = self.handed
+        self.handed += 1
+        return self.slab[:, j * w:(j + 1) * w]
+
+    def _block_of(self, dy2):
+        if self.slab is None or dy2.stride(0) != self.slab.stride(0) or dy2.shape != (self.slab.shape[0], self.width):
+            return None
+        off = dy2.data_ptr() - self.slab.data_ptr()
+        step = self.width * dy2.element_size()
+        return off // step if (0 <= off < self.slab.stride(0) * dy2.element_size() and off % step == 0) else None
 
     def add(self, dy2, wt, shape):
-        if self.buf is None:
+        j = self._block_of(dy2)
+        if j is not None:
+            self.pieces.append((j, wt))
+        elif self.buf is None:
             self.buf = gemm(dy2, wt, trans_b=True)
         else:
             gemm(dy2, wt, trans_b=True, out=self.buf, accumulate=True)
         self.pending -= 1
         if self.pending > 0:
             return None
-        out, self.buf = self.buf, None
+        if self.pieces:
+            pieces = sorted(self.pieces, key=lambda t: t[0])
+            if self.buf is None and [jj for jj, _ in pieces] == list(range(self.members)):
+                wcat = torch.cat([w_ for _, w_ in pieces], dim=1)              # [in, members*w]
+                self.buf = gemm(self.slab, wcat, trans_b=True)                 # one deep-K product, fp32 accumulation over all layers
+            else:                                                              # mixed: fold the slab blocks in one by one
+                for jj, w_ in pieces:
+                    blk = self.slab[:, jj * self.width:(jj + 1) * self.width]
+                    if self.buf is None:
+                        self.buf = gemm(blk, w_, trans_b=True)
+                    else:
+                        gemm(blk, w_, trans_b=True, out=self.buf, accumulate=True)
+        out, self.buf, self.slab, self.pieces = self.buf, None, None, []
         return out.view(shape)
 
 
@@ -253,8 +302,8 @@ class LinearFn(torch.autograd.Function):
         x2, wt, y = ctx.saved_tensors
         relu, p_drop, shp, weight, bias, rows, n_out, group = ctx.cfg
         dy2 = dy.reshape(-1, n_out)
-        if not dy2.is_contiguous():
-            dy2 = dy2.contiguous()
+        if not (dy2.stride(1) == 1 and dy2.stride(0) >= n_out and y is None) and not dy2.is_contiguous():
+            dy2 = dy2.contiguous()           # row-strided views (column blocks of a gradient slab) go to the GEMMs as they are
         if y is not None:
             if relu:
                 dy2 = dy2.clone()
@@ -524,16 +573,19 @@ class RelAttnFn(torch.autograd.Function):
                  dqsrc.data_ptr() + q_off * es, Cq, dkv.data_ptr() + k_off * es, Ckv, dkv.data_ptr() + v_off * es, Ckv,
                  ptr(d_rel), ptr(pd), ptr(gs), stream())
         if mode == 2:
-            d_rel = torch.empty_like(rel)
+            d_rel = fact.grad_group.grad_slice(rel) if ctx.needs_input_grad[2] else None   # a block of the layers' shared slab
+            if d_rel is None:
+                d_rel = torch.empty_like(rel)
+            ldr = d_rel.stride(0)
             nh = int(fact.heavy_types.numel())
             heavy = torch.zeros((max(nh, 1), 2 * d), dtype=torch.float32, device=rel.device)
             with _Timed("rel_attn_bwd_bank", detail=True):
                 call("gtos_rel_attn_bwd_bank", dt(qsrc), T_, B, H, d,
                      qsrc.data_ptr() + q_off * es, Cq, kv.data_ptr() + k_off * es, Ckv,
                      ptr(rel), ptr(gs), ptr(fact.pair_sorted), ptr(fact.chunk_type), ptr(fact.chunk_start),
-                     ptr(fact.chunk_count), ptr(fact.chunk_slot), ptr(fact.xcd_off), fact.nchunks, ptr(d_rel), ptr(heavy), stream())
+                     ptr(fact.chunk_count), ptr(fact.chunk_slot), ptr(fact.xcd_off), fact.nchunks, ptr(d_rel), ldr, ptr(heavy), stream())
             if nh and d_rel.dtype == torch.bfloat16:         # heavy types: fp32 slots rounded straight into their bank rows
-                call("gtos_segment_sum_finish", nh, ptr(fact.heavy_types), ptr(heavy), 2 * d, ptr(d_rel), 2 * d, stream())
+                call("gtos_segment_sum_finish", nh, ptr(fact.heavy_types), ptr(heavy), 2 * d, ptr(d_rel), ldr, stream())
             elif nh:
                 d_rel[fact.heavy_types.long()] = heavy[:nh].to(d_rel.dtype)
         return dqsrc, (dkv if kvsrc is not None else None), d_rel, None, None, None, None, None, None, None, None, None

@@ -83,13 +83,15 @@ int gtos_rel_attn_bwd(int dtype, int mode, int T, int S, int B, int H, int d,
  * fits one chunk (chunk_slot = -1) stores its row directly, a type spanning several chunks accumulates with fp32
  * atomics into heavy[chunk_slot] ([n_heavy,2d], zeroed by the caller, who folds it back into d_bank).
  * xcd_off (optional, int[9]): the chunk list is grouped so that chunks [xcd_off[x], xcd_off[x+1]) gather q/k rows of
- * the graphs XCD x owns (graph b -> XCD b / (B/8), as in the attention kernels); workgroup ids == x (mod 8) walk them. */
+ * the graphs XCD x owns (graph b -> XCD b / (B/8), as in the attention kernels); workgroup ids == x (mod 8) walk them.
+ * ld_dbank (>= 2d): row stride of d_bank -- the layers' gradients are written side by side into one [R, L*2d] slab so
+ * that the bank's input gradient is ONE deep-K product over all layers (gtos_amd/ops.py GradAccumGroup). */
 int gtos_rel_attn_bwd_bank(int dtype, int n, int B, int H, int d,
                            const void* q, int64_t ldq, const void* k, int64_t ldk,
                            const void* bank, const float* gs,
                            const int* pair_sorted, const int* chunk_type, const int* chunk_start,
                            const int* chunk_count, const int* chunk_slot, const int* xcd_off, int nchunks,
-                           void* d_bank, float* heavy, void* stream);
+                           void* d_bank, int64_t ld_dbank, float* heavy, void* stream);
 
 /* y = LayerNorm(x + dropout(r)) * gamma + beta (r may be NULL), saving mean/rstd per row.
  * Replaces F.dropout + nn.LayerNorm(residual + x): generator/graph_transformer.py:57-58,64-65;

@@ -1098,3 +1098,35 @@ def test_attention_kernel_rejects_shapes_outside_the_boundary():
         qkv = torch.randn(5, 2, 3 * d, device=dev())
         with pytest.raises(GtosHipError):
             ops.attention_core(qkv, None, (0, d, 2 * d), d, H, 1.0)
+
+
+def test_batched_bank_gradient_equals_per_layer_products(monkeypatch):
+    """The layers' d(rel) written side by side into one slab + ONE deep-K product for the bank gradient (ops.GradAccumGroup)
+    against the per-layer products: same flat gradient bucket (bf16: the batched form rounds once instead of L times)."""
+    from gtos_amd import synth, ops
+    from gtos_amd.config import build_generator
+    from gtos_amd.flat import FlatParams
+    from gtos_amd.generator import Generator
+    batch, _ = synth.make_config_batch("C1")
+    batch = {k: v.to(dev()) for k, v in batch.items()}
+    res = []
+    for on in (True, False):
+        monkeypatch.setattr(ops, "BATCH_DX", on)
+        m = build_generator(Generator, "C1", dev(), dropout=0.0).to(dev())
+        m.set_compute_dtype(torch.bfloat16)
+        m.train()
+        flat = FlatParams(m, mirror_dtype=torch.bfloat16)
+        loss = m(batch)
+        loss.backward()
+        ops.join_side()
+        torch.cuda.synchronize()
+        res.append((float(loss.detach()), flat.grad.clone(), [n for n, _, _ in flat.entries], flat))
+    assert res[0][0] == res[1][0]
+    g1, g0 = res[0][1], res[1][1]
+    assert float((g1 - g0).norm() / g0.norm()) < 5e-3
+    # the relation encoder's parameters are the ones downstream of the bank gradient
+    for n_, p_, off in res[0][3].entries:
+        if n_.startswith("relation_encoder."):
+            k = p_.numel()
+            a_, b_ = g1[off:off + k], g0[off:off + k]
+            assert float((a_ - b_).norm() / b_.norm().clamp_min(1e-12)) < 3e-2, n_
