@@ -423,56 +423,70 @@ __global__ __launch_bounds__(256) void embed_rows_bwd_kernel(int64_t n, int V, i
 // chunks ("heavy": a trie node near the root is the prefix of thousands of paths) accumulates its chunks with fp32 atomics
 // in heavy[slot, 0:W] and is written by seg_finish_kernel.  One WAVE per chunk: a lane owns 8 channels of each 512-channel
 // slab, so a row is read with 1 KB coalesced wave loads; four row loads are in flight per lane.
-template <int SLABS>
+template <int SLABS, int NSRC>
 __global__ __launch_bounds__(256) void seg_sum_kernel(int n_chunks, const int* __restrict__ rows, const int* __restrict__ chunk_node,
                                                       const int* __restrict__ chunk_start, const int* __restrict__ chunk_cnt,
-                                                      const int* __restrict__ chunk_slot, const bf16_t* __restrict__ src, int64_t ld_src,
-                                                      int W, bf16_t* __restrict__ dst, int64_t ld_dst, float* __restrict__ heavy) {
+                                                      const int* __restrict__ chunk_slot, const bf16_t* __restrict__ src0,
+                                                      const bf16_t* __restrict__ src1, int64_t ld_src,
+                                                      int W, bf16_t* __restrict__ dst0, bf16_t* __restrict__ dst1, int64_t ld_dst,
+                                                      float* __restrict__ heavy0, float* __restrict__ heavy1) {
+    // NSRC = 2: the same row lists reduce two source matrices (the two GRU directions' gradients) in one pass -- one
+    // index fetch and twice the bytes per gathered row
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= n_chunks) return;
     const int node = chunk_node[c], start = chunk_start[c], cnt = chunk_cnt[c];
-    float acc[SLABS][8];
+    const bf16_t* srcs[2] = {src0, src1};
+    float acc[NSRC][SLABS][8];
 #pragma unroll
-    for (int sl = 0; sl < SLABS; ++sl)
+    for (int q = 0; q < NSRC; ++q)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[sl][e] = 0.f;
-    for (int i0 = 0; i0 < cnt; i0 += 4) {
-        int64_t r[4];
+        for (int sl = 0; sl < SLABS; ++sl)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+            for (int e = 0; e < 8; ++e) acc[q][sl][e] = 0.f;
+    constexpr int UN = NSRC == 2 ? 2 : 4;
+    for (int i0 = 0; i0 < cnt; i0 += UN) {
+        int64_t r[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
             const int i = min(i0 + u, cnt - 1);
             r[u] = rows ? rows[start + i] : start + i;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < UN; ++u) {
             if (i0 + u < cnt) {
 #pragma unroll
-                for (int sl = 0; sl < SLABS; ++sl) {
-                    const int ch = sl * 512 + lane * 8;
-                    if (ch < W) {
-                        float v[8];
-                        Vec8<bf16_t>::load(src + r[u] * ld_src + ch, v);
+                for (int q = 0; q < NSRC; ++q)
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) acc[sl][e] += v[e];
+                    for (int sl = 0; sl < SLABS; ++sl) {
+                        const int ch = sl * 512 + lane * 8;
+                        if (ch < W) {
+                            float v[8];
+                            Vec8<bf16_t>::load(srcs[q] + r[u] * ld_src + ch, v);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) acc[q][sl][e] += v[e];
+                        }
                     }
-                }
             }
         }
     }
     const int slot = chunk_slot ? chunk_slot[c] : -1;
+    bf16_t* dsts[2] = {dst0, dst1};
+    float* heavies[2] = {heavy0, heavy1};
 #pragma unroll
-    for (int sl = 0; sl < SLABS; ++sl) {
-        const int ch = sl * 512 + lane * 8;
-        if (ch < W) {
-            if (slot < 0) {
-                Vec8<bf16_t>::store(dst + (int64_t)node * ld_dst + ch, acc[sl]);
-            } else {
+    for (int q = 0; q < NSRC; ++q)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) atomicAdd(heavy + (int64_t)slot * W + ch + e, acc[sl][e]);
+        for (int sl = 0; sl < SLABS; ++sl) {
+            const int ch = sl * 512 + lane * 8;
+            if (ch < W) {
+                if (slot < 0) {
+                    Vec8<bf16_t>::store(dsts[q] + (int64_t)node * ld_dst + ch, acc[q][sl]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) atomicAdd(heavies[q] + (int64_t)slot * W + ch + e, acc[q][sl][e]);
+                }
             }
         }
-    }
 }
 
 // contiguous variant: segment s sums the consecutive rows ranges[2s] .. ranges[2s+1]-1 (the children of a trie node) into
@@ -685,16 +699,20 @@ extern "C" int gtos_embed_rows_bwd(int dtype, int64_t n, int V, int dim, int dim
 }
 
 extern "C" int gtos_segment_sum_rows(int n_chunks, const int* rows, const int* chunk_node, const int* chunk_start, const int* chunk_cnt,
-                                     const int* chunk_slot, const void* src, int64_t ld_src, int width, void* dst, int64_t ld_dst,
-                                     float* heavy, void* stream) {
+                                     const int* chunk_slot, const void* src, const void* src2, int64_t ld_src, int width,
+                                     void* dst, void* dst2, int64_t ld_dst, float* heavy, float* heavy2, void* stream) {
     if (n_chunks <= 0) return 0;
-    if (width <= 0 || width % 8 || width > 1536 || ld_src % 8 || ld_dst % 8 || (uintptr_t)src % 16 || (uintptr_t)dst % 16) return -24;
+    if (width <= 0 || width % 8 || width > 1536 || ld_src % 8 || ld_dst % 8 || (uintptr_t)src % 16 || (uintptr_t)dst % 16 ||
+        (uintptr_t)src2 % 16 || (uintptr_t)dst2 % 16) return -24;
     if (!chunk_node || !chunk_start || !chunk_cnt || !src || !dst || (chunk_slot && !heavy)) return -23;
+    if (src2 && (!dst2 || (chunk_slot && !heavy2))) return -23;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)((n_chunks + 3) / 4)), block(256);
-#define GTOS_SEG(S) hipLaunchKernelGGL(seg_sum_kernel<S>, grid, block, 0, s, n_chunks, rows, chunk_node, chunk_start, chunk_cnt, chunk_slot, \
-                                       (const bf16_t*)src, ld_src, width, (bf16_t*)dst, ld_dst, heavy)
-    if (width <= 512) GTOS_SEG(1); else if (width <= 1024) GTOS_SEG(2); else GTOS_SEG(3);
+#define GTOS_SEG(S, Q) hipLaunchKernelGGL((seg_sum_kernel<S, Q>), grid, block, 0, s, n_chunks, rows, chunk_node, chunk_start, chunk_cnt, \
+                                          chunk_slot, (const bf16_t*)src, (const bf16_t*)src2, ld_src, width, (bf16_t*)dst, (bf16_t*)dst2, \
+                                          ld_dst, heavy, heavy2)
+    if (src2) { if (width <= 512) GTOS_SEG(1, 2); else if (width <= 1024) GTOS_SEG(2, 2); else GTOS_SEG(3, 2); }
+    else { if (width <= 512) GTOS_SEG(1, 1); else if (width <= 1024) GTOS_SEG(2, 1); else GTOS_SEG(3, 1); }
 #undef GTOS_SEG
     GTOS_CHECK_LAUNCH();
     return 0;
@@ -753,4 +771,4 @@ extern "C" int gtos_cast_f32_to_bf16(int64_t n, const float* src, void* dst, voi
     return 0;
 }
 
-extern "C" int gtos_abi_version(void) { return 7; }
+extern "C" int gtos_abi_version(void) { return 8; }

@@ -268,17 +268,17 @@ def bigru_final(x_packed, batch_sizes, hs, num_layers, p_drop, weights):
 TRIE = os.environ.get("GTOS_GRU_TRIE", "1") != "0"
 
 
-def _seg_rows(side, src, width, dst):
-    """dst[node] = sum of src rows of the node (row lists of the trie side), fp32 accumulation."""
-    heavy = torch.zeros((max(1, side.n_heavy), width), dtype=torch.float32, device=src.device)
-    with _Timed("segment_sum_rows", detail=True, units=int(side.rows.numel())):
-        _seg_rows_call(side, src, width, dst, heavy)
-
-
-def _seg_rows_call(side, src, width, dst, heavy):
-    call("gtos_segment_sum_rows", side.n_chunks, ptr(side.rows), ptr(side.chunk_node), ptr(side.chunk_start), ptr(side.chunk_cnt),
-         ptr(side.chunk_slot), ptr(src), src.stride(0), width, ptr(dst), dst.stride(0), ptr(heavy), stream())
-    call("gtos_segment_sum_finish", side.n_heavy, ptr(side.heavy_node), ptr(heavy), width, ptr(dst), dst.stride(0), stream())
+def _seg_rows(side, src, width, dst, src2=None, dst2=None):
+    """dst[node] = sum of src rows of the node (row lists of the trie side), fp32 accumulation; (src2, dst2): a second
+    matrix reduced over the same row lists in the same pass."""
+    heavy = torch.zeros((2 if src2 is not None else 1, max(1, side.n_heavy), width), dtype=torch.float32, device=src.device)
+    with _Timed("segment_sum_rows", detail=True, units=int(side.rows.numel()) * (2 if src2 is not None else 1)):
+        call("gtos_segment_sum_rows", side.n_chunks, ptr(side.rows), ptr(side.chunk_node), ptr(side.chunk_start), ptr(side.chunk_cnt),
+             ptr(side.chunk_slot), ptr(src), ptr(src2), src.stride(0), width, ptr(dst), ptr(dst2), dst.stride(0),
+             ptr(heavy[0]), ptr(heavy[1]) if src2 is not None else None, stream())
+        call("gtos_segment_sum_finish", side.n_heavy, ptr(side.heavy_node), ptr(heavy[0]), width, ptr(dst), dst.stride(0), stream())
+        if src2 is not None:
+            call("gtos_segment_sum_finish", side.n_heavy, ptr(side.heavy_node), ptr(heavy[1]), width, ptr(dst2), dst2.stride(0), stream())
 
 
 def _seg_ranges(n_seg, ranges, src, width, dst):
@@ -399,7 +399,28 @@ class TrieBiGRUFn(torch.autograd.Function):
         grads = [None] * len(weights)
         src = [l0[d][3] if p_layer > 0 else l0[d][1][:sides[d].n_nodes] for d in (0, 1)]
         dsrc = [None, None]
-        # ---- layer 1
+        # ---- layer 1.  The BPTT steps (memory-bound, 2-3 workgroups per CU) stay on the main stream; every GEMM of this
+        # function (weight gradients, gate-table input gradients) goes to the auxiliary stream and runs beside the steps /
+        # segment sums that follow it.
+        main = torch.cuda.current_stream(dev)
+        aux = _side_stream(dev) if (SIDE_STREAM and N >= SIDE_MIN_ROWS) else main
+        use_side = aux is not main
+
+        def on_side(*tensors):
+            """Context for work that may run on the auxiliary stream once everything queued on main so far is done."""
+            if use_side:
+                aux.wait_stream(main)
+                for t_ in tensors:
+                    if t_ is not None:
+                        t_.record_stream(aux)
+            return torch.cuda.stream(aux)
+        # gradient tensors that are not views of the flat bucket are created on the main stream first
+        for base in (8, 12, 0, 4):
+            for slot in range(4):
+                wt_ = weights[base + slot]
+                if wt_.requires_grad and _grad_target(wt_) is None and grads[base + slot] is None:
+                    grads[base + slot] = torch.zeros(wt_.shape, dtype=torch.float32, device=dev)
+        d4s = []
         for d in (0, 1):
             gates, hprev, wi, wh_t = l1[d]
             base = 8 + d * 4
@@ -414,24 +435,36 @@ class TrieBiGRUFn(torch.autograd.Function):
                 _step_bwd(A, hs, None if prev is None else d4[offs[prev]:], 0 if prev is None else bs[prev], wh_t,
                           gates[off:off + A], hprev[off:off + A], None, hs, dh, d4[off:off + A], 0.0, 0, 0, bpart)
                 prev = t
-            _acc_weight_grad(grads, base + 1, w_hh, d4[:, :2 * hs], hprev, rows=slice(0, 2 * hs))
-            _acc_weight_grad(grads, base + 1, w_hh, d4[:, 3 * hs:], hprev, rows=slice(2 * hs, 3 * hs))
-            if want_bias:
-                _acc_bias_grads(grads, base, b_ih, b_hh, bpart.sum(0), hs)
-            # gradient of the per-node input-gate tables: sum of d(xg) = d4[:, :3hs] over the rows of each node
-            for s_, side in enumerate(sides):
-                dG = torch.empty((side.n_nodes, 3 * hs), dtype=dtp, device=dev)
-                _seg_rows(side, d4, 3 * hs, dG)
-                cols = slice(0, hs) if s_ == 0 else slice(hs, 2 * hs)
-                _acc_weight_grad(grads, base, w_ih, dG, src[s_], cols=cols)
-                wt = weight_t(w_ih, wi[:, cols], rows=("cols", s_))                     # [hs, 3hs]
-                if dsrc[s_] is None:
-                    dsrc[s_] = gemm(dG, wt, trans_b=True)
-                else:
-                    gemm(dG, wt, trans_b=True, out=dsrc[s_], accumulate=True)
-            del d4
+            with on_side(d4, hprev, bpart):
+                _acc_weight_grad(grads, base + 1, w_hh, d4[:, :2 * hs], hprev, rows=slice(0, 2 * hs))
+                _acc_weight_grad(grads, base + 1, w_hh, d4[:, 3 * hs:], hprev, rows=slice(2 * hs, 3 * hs))
+                if want_bias:
+                    _acc_bias_grads(grads, base, b_ih, b_hh, bpart.sum(0), hs)
+            d4s.append(d4)
+        # gradient of the per-node input-gate tables: sum of d(xg) = d4[:, :3hs] over the rows of each node, both directions
+        # in one pass per trie
+        for s_, side_t in enumerate(sides):
+            dG = [torch.empty((side_t.n_nodes, 3 * hs), dtype=dtp, device=dev) for _ in (0, 1)]
+            _seg_rows(side_t, d4s[0], 3 * hs, dG[0], d4s[1], dG[1])
+            cols = slice(0, hs) if s_ == 0 else slice(hs, 2 * hs)
+            with on_side(dG[0], dG[1], src[s_]):
+                for d in (0, 1):
+                    w_ih, wi = weights[8 + d * 4], l1[d][2]
+                    _acc_weight_grad(grads, 8 + d * 4, w_ih, dG[d], src[s_], cols=cols)
+                    wt = weight_t(w_ih, wi[:, cols], rows=("cols", s_))                 # [hs, 3hs]
+                    if dsrc[s_] is None:
+                        dsrc[s_] = gemm(dG[d], wt, trans_b=True)
+                    else:
+                        gemm(dG[d], wt, trans_b=True, out=dsrc[s_], accumulate=True)
+        del d4s
+        if use_side:
+            main.wait_stream(aux)                  # layer 0 consumes dsrc
+            for t_ in dsrc:
+                t_.record_stream(main)
         # ---- layer 0 on the tries, deepest level first
         dtab = None
+        if table.requires_grad and _grad_target(table) is None:
+            dtab = torch.zeros(table.shape, dtype=torch.float32, device=dev)
         for d, side in enumerate(sides):
             X, H, gates, Y, seed_e, seed_y, wi_t, wh_t = l0[d]
             n = side.n_nodes
@@ -457,20 +490,24 @@ class TrieBiGRUFn(torch.autograd.Function):
                 _step_bwd(A, hs, S if has_kids else None, A, wh_t, gates[lo:hi], H, dy.data_ptr() + lo * hs * dy.element_size(), hs,
                           dhz[lo:hi], d4[lo:hi], p_layer, seed_y, lo * hs, bpart, hprev_idx=side.par[lo:hi])
             hp = H.index_select(0, side.par_long)                    # the state each node started from, aligned with d4's rows
-            _acc_weight_grad(grads, base + 1, w_hh, d4[:, :2 * hs], hp, rows=slice(0, 2 * hs))
-            _acc_weight_grad(grads, base + 1, w_hh, d4[:, 3 * hs:], hp, rows=slice(2 * hs, 3 * hs))
-            _acc_weight_grad(grads, base, w_ih, d4[:, :3 * hs], X)
-            if want_bias:
-                _acc_bias_grads(grads, base, b_ih, b_hh, bpart.sum(0), hs)
-            if table.requires_grad:
-                dX = gemm(d4[:, :3 * hs], wi_t, trans_b=True)        # [n, dim_pad]
-                tgt = _grad_target(table)
-                if tgt is None:
-                    if dtab is None:
-                        dtab = torch.zeros(table.shape, dtype=torch.float32, device=dev)
-                    tgt = dtab
-                call("gtos_embed_rows_bwd", dt(dX), n, table.shape[0], table.shape[1], dim_pad, ptr(side.tok), ptr(dX), ptr(tgt),
-                     float(p_embed), seed_e, stream())
+            with on_side(d4, hp, X, bpart):
+                _acc_weight_grad(grads, base + 1, w_hh, d4[:, :2 * hs], hp, rows=slice(0, 2 * hs))
+                _acc_weight_grad(grads, base + 1, w_hh, d4[:, 3 * hs:], hp, rows=slice(2 * hs, 3 * hs))
+                _acc_weight_grad(grads, base, w_ih, d4[:, :3 * hs], X)
+                if want_bias:
+                    _acc_bias_grads(grads, base, b_ih, b_hh, bpart.sum(0), hs)
+                if table.requires_grad:
+                    dX = gemm(d4[:, :3 * hs], wi_t, trans_b=True)        # [n, dim_pad]
+                    tgt = _grad_target(table)
+                    if tgt is None:
+                        tgt = dtab
+                    call("gtos_embed_rows_bwd", dt(dX), n, table.shape[0], table.shape[1], dim_pad, ptr(side.tok), ptr(dX), ptr(tgt),
+                         float(p_embed), seed_e, stream())
+        if use_side:
+            if dtab is None and all(gr is None for gr in grads):
+                defer_side_join(dev)       # every gradient went into the flat bucket: its readers join the side stream
+            else:
+                main.wait_stream(aux)
         return (None, dtab, None, None, None, None) + tuple(grads)
 
 

@@ -147,10 +147,12 @@ int gtos_gru_step_bwd(int rows, int hs, const void* d4_prev, int rows_prev, cons
  * accumulation, bf16 result.  _rows: chunk c adds the rows rows[chunk_start[c] .. +chunk_cnt[c]) of src into node
  * chunk_node[c]: straight into dst[node] when chunk_slot[c] < 0 (the node's only chunk), else with fp32 atomics into
  * heavy[chunk_slot[c], 0:width] (zeroed by the caller), which _finish rounds into dst[heavy_node[s]].  _ranges: dst[s] =
- * sum of the consecutive src rows ranges[2s] .. ranges[2s+1]-1 (zeros for an empty range).  width % 8 == 0, <= 1536. */
+ * sum of the consecutive src rows ranges[2s] .. ranges[2s+1]-1 (zeros for an empty range).  width % 8 == 0, <= 1536.
+ * _rows takes an optional second source / destination / heavy triple (src2, dst2, heavy2; NULL = none) reduced over the
+ * same row lists in the same pass: the two GRU directions' gradients share them. */
 int gtos_segment_sum_rows(int n_chunks, const int* rows, const int* chunk_node, const int* chunk_start, const int* chunk_cnt,
-                          const int* chunk_slot, const void* src, int64_t ld_src, int width, void* dst, int64_t ld_dst,
-                          float* heavy, void* stream);
+                          const int* chunk_slot, const void* src, const void* src2, int64_t ld_src, int width,
+                          void* dst, void* dst2, int64_t ld_dst, float* heavy, float* heavy2, void* stream);
 int gtos_segment_sum_finish(int n_heavy, const int* heavy_node, const float* heavy, int width, void* dst, int64_t ld_dst,
                             void* stream);
 int gtos_segment_sum_ranges(int n_seg, const int* ranges, const void* src, int64_t ld_src, int width, void* dst, int64_t ld_dst,
