@@ -106,12 +106,16 @@ def side_stream(device):
 
 
 _PENDING_SIDE = set()
+_HELD = {}
 
 
-def defer_side_join(device):
+def defer_side_join(device, keep_alive=None):
     """The side stream still holds work whose only consumers are the flat gradient bucket's readers: join_side() must run
-    before the bucket is read (Trainer.step / FlatParams.step do it)."""
+    before the bucket is read (Trainer.step / FlatParams.step do it).  ``keep_alive``: tensors that work reads; they are
+    released at the join."""
     _PENDING_SIDE.add(device)
+    if keep_alive:
+        _HELD.setdefault(device, []).extend(keep_alive)
 
 
 def join_side(device=None):
@@ -120,6 +124,7 @@ def join_side(device=None):
         if device is None or dev == device:
             torch.cuda.current_stream(dev).wait_stream(side_stream(dev))
             _PENDING_SIDE.discard(dev)
+            _HELD.pop(dev, None)
 
 
 def gemm(a, b, trans_a=False, trans_b=False, out=None, bias=None, relu=False, p_drop=0.0, seed=0,
