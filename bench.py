@@ -142,7 +142,7 @@ def cpu_baseline(cfg_name, graphs, steps, budget_s=75.0):
 MFMA_PEAK_TFS = 2500.0
 
 
-def build_roofline(a, cfg, stats, model, trainer, batch, prof, dev, cd):
+def build_roofline(a, cfg, stats, model, trainer, batch, prof, dev, cd, detail=True):
     """roofline object of the JSON line.  Headline (SURVEY 8d "Stage A"): the relation-attention forward kernel on the
     reference's DENSE relation signature (rarb[n,n,B,2d] = relation_in_proj(relation) materialised), measured live here with
     HIP events on the real batch -- layer-0 q/k/v of the real concept embeddings, the real projected bank rows gathered by the
@@ -209,7 +209,7 @@ def build_roofline(a, cfg, stats, model, trainer, batch, prof, dev, cd):
 
     # ---- detail pass: per-launch events on the other dominant kernels (they would perturb the timed region)
     rows = []
-    if not a.dense and cd == torch.bfloat16:
+    if detail and not a.dense and cd == torch.bfloat16:
         ops.PROFILE, ops.PROFILE_DETAIL, ops.GEMM_PROFILE = {}, True, {}
         for _ in range(2):
             trainer.step(batch)
@@ -351,10 +351,12 @@ def main():
             dist.destroy_process_group()
         print("dry-launch rank %d of %d ok" % (rank, world), flush=True)
         return
+    if os.environ.get("GTOS_ONE_DEVICE"):      # functional check of the N>1 path on a 1-GPU box: every rank on cuda:0, gloo
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world)   # RCCL on ROCm
+        dist.init_process_group(os.environ.get("GTOS_DIST_BACKEND", "nccl"), rank=rank, world_size=world)   # nccl = RCCL on ROCm
 
     from gtos_amd import ops, synth
     from gtos_amd import gru as gru_mod
@@ -419,7 +421,8 @@ def main():
                   "note": "HIP-event spans on the main stream inside the timed region, per step"}
     roofline = None
     if rank == 0:
-        roofline = build_roofline(a, cfg, stats, model, trainer, batch, prof, dev, cd)
+        # N > 1: no detail pass (its extra training steps would issue collectives the other ranks do not join)
+        roofline = build_roofline(a, cfg, stats, model, trainer, batch, prof, dev, cd, detail=(world == 1))
     if rank == 0:
         out = {"metric": "graphs/sec training step (100-node AMR, batch 64)", "value": world * B * a.steps / elapsed,
                "unit": "graphs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -439,6 +442,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(a.config, a.cpu_graphs, a.cpu_steps, a.cpu_budget)
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()                     # rank 0 may still be measuring its dense-signature leg
         dist.destroy_process_group()
 
 

@@ -1130,3 +1130,23 @@ def test_batched_bank_gradient_equals_per_layer_products(monkeypatch):
             k = p_.numel()
             a_, b_ = g1[off:off + k], g0[off:off + k]
             assert float((a_ - b_).norm() / b_.norm().clamp_min(1e-12)) < 3e-2, n_
+
+
+def test_bench_two_ranks_on_one_gpu_functional():
+    """The N>1 path of bench.py end to end on the 1-GPU box: `python bench.py --gpus 2` self-launches two ranks, both on
+    cuda:0, process group gloo (RCCL refuses two ranks on one device): sharded synthetic batches, the segment-wise async
+    all-reduce launched from the backward boundary markers, the 1/W fold, max-over-ranks timing, one JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(GTOS_ONE_DEVICE="1", GTOS_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "C1", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 * d["config"]["B_per_gpu"] and d["scaling"] == "weak"
+    assert d["value"] > 0 and np.isfinite(d["config"]["loss_last"])
+    assert "allreduce_exposed_ms_per_step" in d["config"]
