@@ -266,6 +266,10 @@ def bigru_final(x_packed, batch_sizes, hs, num_layers, p_drop, weights):
 # distribution; what changes is that two paths sharing a prefix (suffix) share the mask on the shared part, and that the two
 # directions draw separate embedding masks.  GTOS_GRU_TRIE=0 selects the per-row path above.
 TRIE = os.environ.get("GTOS_GRU_TRIE", "1") != "0"
+# Trie backward: its GEMMs on the auxiliary stream beside the BPTT steps.  Measured at C2: no gain (73.6 vs 73.7 ms/step -- the
+# step kernels slow down by what the GEMMs gain once the per-row work is gone), so it is off by default and the profile stays
+# one kernel at a time.
+TRIE_SIDE = os.environ.get("GTOS_GRU_TRIE_SIDE", "0") == "1"
 
 
 def _seg_rows(side, src, width, dst, src2=None, dst2=None):
@@ -403,7 +407,7 @@ class TrieBiGRUFn(torch.autograd.Function):
         # function (weight gradients, gate-table input gradients) goes to the auxiliary stream and runs beside the steps /
         # segment sums that follow it.
         main = torch.cuda.current_stream(dev)
-        aux = _side_stream(dev) if (SIDE_STREAM and N >= SIDE_MIN_ROWS) else main
+        aux = _side_stream(dev) if (TRIE_SIDE and SIDE_STREAM and N >= SIDE_MIN_ROWS) else main
         use_side = aux is not main
 
         keep = []      # tensors the auxiliary stream reads: kept alive until main has waited for it (no record_stream: blocks

@@ -649,6 +649,7 @@ def test_side_stream_paths_give_the_same_gradients(dtype, monkeypatch):
     def run(side):
         monkeypatch.setattr(ops, "BWD_SIDE", side)
         monkeypatch.setattr(gru, "SIDE_STREAM", side)
+        monkeypatch.setattr(gru, "TRIE_SIDE", side)
         monkeypatch.setattr(ops, "BWD_SIDE_MIN_ROWS", 0)          # C1 is below the size thresholds: force the side paths
         monkeypatch.setattr(gru, "SIDE_MIN_ROWS", 0)
         m = build_generator(Generator, "C1", dev(), dropout=0.0).to(dev())
