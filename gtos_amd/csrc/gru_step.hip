@@ -18,6 +18,7 @@
 //   * XCD-aware tile order: the 4 channel tiles of a row panel run back to back on one XCD (h/x rows shared in its L2).
 // The new state of row m goes to h_out[m] when m < n_out (the packed "previous state" slot of the next time step, which
 // is the next launch's A operand) and to h_fin[m] otherwise (sequence finished) -- no separate h_prev copy.
+#include <cstdlib>
 #include "common.h"
 
 __attribute__((visibility("hidden"))) const void* gtos_zero_block();      // gemm.hip: 256 zero bytes in global memory
@@ -227,6 +228,161 @@ __global__ __launch_bounds__(256, 2) void gru_step_fwd_kernel(StepArgs a) {
 
 
 // ---------------------------------------------------------------------------------------------------------------------
+// PERSISTENT forward step for the second GRU layer on the path tries (input gates gathered from the two per-node tables,
+// MODE 2 above), hs <= 256.  The step is memory-latency bound in the tile-per-workgroup kernel: every workgroup re-streams
+// its 96 KB W_hh slice and walks load -> barrier -> MFMA four times before it even starts the gathers of its epilogue,
+// with two workgroups per CU to hide all of that.  Here ONE 4-wave workgroup per CU keeps its channel tile's W_hh slice
+// (3 x 64 rows x hs, 96 KB at hs = 256) in LDS for the whole launch and walks the row tiles; the waves are decoupled (each
+// owns 32 rows and its own 16 KB state-row buffer, no workgroup barrier in the loop) and software-pipelined: while a wave
+// runs the cell of tile i, the LDS-DMA of its state rows for tile i+1 is in flight, and the table / state gathers of
+// tile i+1 are issued as soon as the registers of tile i are consumed, so they fly during the next MFMA phase's drain.
+// Workgroup -> (XCD, channel tile, worker): the hs/64 channel tiles of a worker sit on ONE XCD and walk the same row
+// tiles, so the state rows and node ids are fetched from HBM once and shared through that XCD's L2.
+struct Raw16 { uint4 a, b; };
+__device__ __forceinline__ void unpack16(const Raw16& r, float (&v)[16]) {
+    v[0] = lo_bf(r.a.x); v[1] = hi_bf(r.a.x); v[2] = lo_bf(r.a.y); v[3] = hi_bf(r.a.y);
+    v[4] = lo_bf(r.a.z); v[5] = hi_bf(r.a.z); v[6] = lo_bf(r.a.w); v[7] = hi_bf(r.a.w);
+    v[8] = lo_bf(r.b.x); v[9] = hi_bf(r.b.x); v[10] = lo_bf(r.b.y); v[11] = hi_bf(r.b.y);
+    v[12] = lo_bf(r.b.z); v[13] = hi_bf(r.b.z); v[14] = lo_bf(r.b.w); v[15] = hi_bf(r.b.w);
+}
+__device__ __forceinline__ Raw16 ldraw16(const bf16_t* p) {
+    Raw16 r;
+    r.a = *reinterpret_cast<const uint4*>(p);
+    r.b = *reinterpret_cast<const uint4*>(p + 8);
+    return r;
+}
+
+constexpr int P_ROWS = 32;                       // rows per wave tile (2 MFMA row blocks)
+constexpr int P_TM = 4 * P_ROWS;                 // rows per workgroup tile
+
+template <int KT>                                // k tiles of 64: hs = 64 * KT
+__global__ __launch_bounds__(256, 1) void gru_l1_fwd_persistent_kernel(StepArgs a, int n_workers) {
+    extern __shared__ __attribute__((aligned(16))) char plds[];
+    constexpr int HS = 64 * KT;
+    constexpr int A_TILE = P_ROWS * ROWB;        // one k tile of a wave's 32 rows: 4 KB
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    char* Ws = plds;                                               // KT x [192 x 128 B]
+    char* Aw = plds + KT * B_BYTES + wave * (KT * A_TILE);         // this wave's state rows: KT x [32 x 128 B]
+    const int nC = KT;
+    const int xcd = blockIdx.x & 7, sub = blockIdx.x >> 3;
+    const int ct = sub % nC, worker = (sub / nC) * 8 + xcd, c0 = ct * TC;
+    const U128* Z = static_cast<const U128*>(a.zeros);
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) dma_weights(a.w_hh, Z, HS, HS, c0, kt * BK, HS, Ws + kt * B_BYTES, wave, lane);
+    __syncthreads();
+
+    const int cb = c0 + fq * 16;
+    float bhr[16], bhz[16], bhn[16], bin[16];
+    {
+        float t[16];
+        ldf16(a.b_hh + cb, bhr); ldf16(a.b_ih + cb, t);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bhr[i] += t[i];
+        ldf16(a.b_hh + HS + cb, bhz); ldf16(a.b_ih + HS + cb, t);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bhz[i] += t[i];
+        ldf16(a.b_hh + 2 * HS + cb, bhn); ldf16(a.b_ih + 2 * HS + cb, bin);
+    }
+    const int n_tiles = (a.rows + P_TM - 1) / P_TM;
+
+    auto dma_A = [&](int tile) {
+        const int r0 = tile * P_TM + wave * P_ROWS;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int it = 0; it < P_ROWS / 8; ++it) {
+                const int rl = it * 8 + (lane >> 3);
+                const int c = (lane & 7) ^ swz(rl);
+                const int r = r0 + rl;
+                const void* src = r < a.rows ? static_cast<const void*>(a.h_in + (int64_t)r * HS + kt * BK + c * 8)
+                                             : static_cast<const void*>(Z);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(Aw + kt * A_TILE + it * 1024), 16, 0, 0);
+            }
+    };
+    struct Pre { Raw16 f[3], b[3], h; };
+    auto gather = [&](int tile, Pre (&P)[2]) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            int m = tile * P_TM + wave * P_ROWS + mt * 16 + fr;
+            m = m < a.rows ? m : a.rows - 1;
+            const bf16_t* fp = a.gf + (int64_t)a.gf_idx[m] * 3 * HS + cb;
+            const bf16_t* bp = a.gb + (int64_t)a.gb_idx[m] * 3 * HS + cb;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) { P[mt].f[g] = ldraw16(fp + g * HS); P[mt].b[g] = ldraw16(bp + g * HS); }
+            P[mt].h = ldraw16(a.h_in + (int64_t)m * HS + cb);
+        }
+    };
+
+    int tile = worker;
+    Pre P[2];
+    if (tile < n_tiles) { dma_A(tile); gather(tile, P); }
+    for (; tile < n_tiles; tile += n_workers) {
+        f32x4_t acc[2][12];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 12; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            const char* As = Aw + kt * A_TILE;
+            const char* Bs = Ws + kt * B_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8_t fa[2];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) fa[mt] = *reinterpret_cast<const bf16x8_t*>(As + lds_off(mt * 16 + fr, ks * 4 + fq));
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const bf16x8_t fb = *reinterpret_cast<const bf16x8_t*>(Bs + lds_off(g * 64 + nt * 16 + fr, ks * 4 + fq));
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt)
+                            acc[mt][g * 4 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa[mt], acc[mt][g * 4 + nt], 0, 0, 0);
+                    }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);        // every LDS read of this tile's state rows has returned
+        const int next = tile + n_workers;
+        if (next < n_tiles) dma_A(next);           // flies during the cell below
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int m = tile * P_TM + wave * P_ROWS + mt * 16 + fr;
+            float xr[16], xz[16], xn[16], hp[16], t[16];
+            unpack16(P[mt].f[0], xr); unpack16(P[mt].b[0], t);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) xr[i] += t[i];
+            unpack16(P[mt].f[1], xz); unpack16(P[mt].b[1], t);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) xz[i] += t[i];
+            unpack16(P[mt].f[2], xn); unpack16(P[mt].b[2], t);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) xn[i] += t[i] + bin[i];
+            unpack16(P[mt].h, hp);
+            float gr[16], gz[16], gn[16], hn[16], o[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                gr[i] = 1.f / (1.f + __expf(-(xr[i] + acc[mt][(i >> 2)][i & 3] + bhr[i])));
+                gz[i] = 1.f / (1.f + __expf(-(xz[i] + acc[mt][4 + (i >> 2)][i & 3] + bhz[i])));
+                hn[i] = bf2f(f2bf(acc[mt][8 + (i >> 2)][i & 3] + bhn[i]));   // rounded like the saved value backward uses
+                gn[i] = tanhf(xn[i] + gr[i] * hn[i]);
+                o[i] = (1.f - gz[i]) * gn[i] + gz[i] * hp[i];
+            }
+            if (m < a.rows) {
+                bf16_t* gp = a.gates + (int64_t)m * 4 * HS + cb;
+                st16(gp, gr); st16(gp + HS, gz); st16(gp + 2 * HS, gn); st16(gp + 3 * HS, hn);
+                bf16_t* hdst = (m < a.n_out ? a.h_out : a.h_fin) + (int64_t)m * HS + cb;
+                st16(hdst, o);
+            }
+        }
+        if (next < n_tiles) gather(next, P);
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Fused BACKWARD time step.  With d4 = [d r | d z | d n_x | d n_h] ([rows, 4*hs], ONE buffer: d(xg) = columns 0..3hs,
 // d(hg) = columns {0..2hs, 3hs..4hs}) the gradient that reaches the state of step t through time is
 //     dh_t = dh_direct (kept in the fp32 dh buffer) + d(hg)_{later step} W_hh
@@ -413,6 +569,21 @@ extern "C" int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, i
     const long long nblk = ((nM + 7) / 8) * 8 * nC;
     if (nblk > 0x7fffffffLL) return -6;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    static const bool use_persistent = !(getenv("GTOS_GRU_PERSISTENT") && getenv("GTOS_GRU_PERSISTENT")[0] == '0');
+    if (mode == 2 && use_persistent && hs == 256 && !h_idx && !y && rows >= 16384) {
+        constexpr int KT = 4;
+        const size_t lds_bytes = (size_t)KT * B_BYTES + 4 * KT * P_ROWS * ROWB;        // 96 KB + 64 KB
+        static bool configured = false;
+        if (!configured) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_l1_fwd_persistent_kernel<KT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return -7;
+            configured = true;
+        }
+        const int n_cu = 256, n_workers = n_cu / KT;                                   // one workgroup per CU
+        hipLaunchKernelGGL(gru_l1_fwd_persistent_kernel<KT>, dim3(n_cu), dim3(256), lds_bytes, s, a, n_workers);
+        GTOS_CHECK_LAUNCH();
+        return 0;
+    }
     if (mode == 1) hipLaunchKernelGGL(gru_step_fwd_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, s, a);
     else if (mode == 2) hipLaunchKernelGGL(gru_step_fwd_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(gru_step_fwd_kernel<0>, dim3((unsigned)nblk), dim3(256), 0, s, a);

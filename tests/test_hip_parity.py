@@ -1151,3 +1151,40 @@ def test_bench_two_ranks_on_one_gpu_functional():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 * d["config"]["B_per_gpu"] and d["scaling"] == "weak"
     assert d["value"] > 0 and np.isfinite(d["config"]["loss_last"])
     assert "allreduce_exposed_ms_per_step" in d["config"]
+
+
+@pytest.mark.parametrize("rows", [300, 40000 + 77])
+def test_gru_layer1_step_kernel_vs_torch(rows):
+    """One forward step of the second GRU layer (gate tables gathered by node id) against plain torch fp32 on the same bf16
+    operands: small `rows` runs the tile-per-workgroup kernel, large `rows` the persistent one (W_hh slice resident in LDS,
+    decoupled software-pipelined waves); ragged tail, rows that finish (n_out < rows) and rows that continue."""
+    from gtos_amd.gru import _step_fwd
+    hs, nf, nb = 256, 5000, 7000
+    g = torch.Generator().manual_seed(rows)
+    bf = torch.bfloat16
+    gf = (0.5 * torch.randn(nf, 3 * hs, generator=g)).to(dev(), bf)
+    gb = (0.5 * torch.randn(nb, 3 * hs, generator=g)).to(dev(), bf)
+    fi = torch.randint(0, nf, (rows,), generator=g).to(dev(), torch.int32)
+    bi = torch.randint(0, nb, (rows,), generator=g).to(dev(), torch.int32)
+    h = torch.randn(rows, hs, generator=g).to(dev(), bf)
+    wh = (0.1 * torch.randn(3 * hs, hs, generator=g)).to(dev(), bf)
+    b_ih = (0.1 * torch.randn(3 * hs, generator=g)).to(dev())
+    b_hh = (0.1 * torch.randn(3 * hs, generator=g)).to(dev())
+    n_out = rows - rows // 3
+    h_out = torch.zeros(rows, hs, device=dev(), dtype=bf)
+    h_fin = torch.zeros(rows, hs, device=dev(), dtype=bf)
+    gates = torch.zeros(rows, 4 * hs, device=dev(), dtype=bf)
+    _step_fwd(rows, hs, None, None, h, None, b_ih, wh, b_hh, h_out, n_out, h_fin, gates, None, 0, hs, 0.0, 0, 0,
+              gf=gf, gf_idx=fi, gb=gb, gb_idx=bi)
+    xg = gf.float()[fi.long()] + gb.float()[bi.long()] + b_ih
+    hg = h.float() @ wh.float().t() + b_hh
+    r = torch.sigmoid(xg[:, :hs] + hg[:, :hs])
+    z = torch.sigmoid(xg[:, hs:2 * hs] + hg[:, hs:2 * hs])
+    hn = hg[:, 2 * hs:]
+    n = torch.tanh(xg[:, 2 * hs:] + r * hn)
+    o = (1 - z) * n + z * h.float()
+    want = torch.cat([r, z, n, hn], 1)
+    torch.testing.assert_close(gates.float(), want, rtol=2e-2, atol=2e-2)
+    got_h = torch.cat([h_out[:n_out], h_fin[n_out:]]).float()
+    torch.testing.assert_close(got_h, o, rtol=2e-2, atol=2e-2)
+    assert float(h_fin[:n_out].float().abs().max()) == 0.0 and float(h_out[n_out:].float().abs().max()) == 0.0
