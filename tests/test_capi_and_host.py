@@ -44,8 +44,10 @@ def test_host_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(build.build_host(verbose=False))
     src = open(os.path.join(ROOT, "include", "gtos_host.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    names = re.findall(r"\b(gtos_relbatch_\w+)\s*\(", src)
-    assert set(names) == {"gtos_relbatch_build", "gtos_relbatch_dims", "gtos_relbatch_export", "gtos_relbatch_free"}
+    names = re.findall(r"\b(gtos_(?:relbatch|pathtrie|relindex)_\w+)\s*\(", src)
+    assert set(names) == {"gtos_relbatch_build", "gtos_relbatch_dims", "gtos_relbatch_export", "gtos_relbatch_free",
+                          "gtos_pathtrie_build", "gtos_pathtrie_sizes", "gtos_pathtrie_export", "gtos_pathtrie_free",
+                          "gtos_relindex_build", "gtos_relindex_sizes", "gtos_relindex_export", "gtos_relindex_free"}
     for n in names:
         assert hasattr(lib, n)
 
