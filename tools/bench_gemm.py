@@ -22,6 +22,8 @@ SHAPES = [  # name, ta, tb, M, N, K, out dtype
     ("gru_dh      NNf", False, False, 400000, 256, 768, torch.float32),
     ("gru_dwih_l1 TN", True, False, 768, 512, 2497000, torch.float32),
     ("rel_dw      TN", True, False, 1024, 512, 434624, torch.float32),
+    ("gru_tables  NT", False, True, 434624, 768, 256, torch.bfloat16),
+    ("relenc_out  NT", False, True, 434624, 512, 512, torch.bfloat16),
     ("ffn_fc1     NT", False, True, 6464, 1024, 512, torch.bfloat16),
     ("tn_m1024_Kbig TN", True, False, 1024, 512, 2497000, torch.float32),
     ("tn_m768_Ksml  TN", True, False, 768, 512, 434624, torch.float32),
