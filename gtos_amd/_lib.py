@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgtos_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 c_p, c_i, c_l, c_f, c_u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_uint64
 
@@ -20,7 +20,7 @@ SIGNATURES = {
     "gtos_gemm": [c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_i, c_f, c_u64, c_i, c_i, c_p, c_l, c_p],
     "gtos_rel_attn_fwd": [c_i] * 7 + [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_f, c_f, c_u64, c_p, c_l, c_p, c_p, c_p],
     "gtos_rel_attn_bwd": [c_i] * 7 + [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_u64,
-                                      c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p],
+                                      c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p],
     "gtos_rel_attn_bwd_bank": [c_i] * 5 + [c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_p, c_p],  # ... nchunks, d_bank, ld, heavy, stream
     "gtos_ln_residual_fwd": [c_i, c_i, c_i, c_p, c_p, c_f, c_u64, c_p, c_p, c_f, c_p, c_p, c_p, c_p],
     "gtos_ln_residual_bwd": [c_i, c_i, c_i, c_p, c_p, c_p, c_f, c_u64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],

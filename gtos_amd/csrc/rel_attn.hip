@@ -75,6 +75,7 @@ struct AttnArgs {
     const void* d_o; int64_t lddo;
     const float* dw;            // optional upstream grad on w, [T,S,B,H]
     void *dq, *dk, *dv; int64_t lddq, lddk, lddv;
+    int64_t ld_drel;            // mode 2: row stride of d_rel = d(bank) for the singleton types' direct rows
     void* d_rel;                // mode 1: d_rarb [S,T,B,2d] (type T)
     float* pd;                  // scratch [T,S,B,H]: post-dropout probabilities
     float* gs;                  // scratch [T,S,B,H]: scale * dS
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(256, 4) void rel_attn_fwd_kernel(AttnArgs a) {
     struct KeySet { Raw8<T> ra[U], rb[U], k[U], v[U]; int tn[U]; };
     auto load_idx = [&](int jb, KeySet& ks) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) { const int j = jb + u * KS + joff; ks.tn[u] = (iq && j < a.S) ? iq[j] : 0; }
+        for (int u = 0; u < U; ++u) { const int j = jb + u * KS + joff; ks.tn[u] = (iq && j < a.S) ? iq[j] : 0; }   // bit 31: singleton type
     };
     auto issue = [&](int jb, KeySet& ks) {
 #pragma unroll
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256, 4) void rel_attn_fwd_kernel(AttnArgs a) {
                     const T* p = rel + (((int64_t)j * a.T + i) * a.B + b) * (2 * d) + c;
                     ks.ra[u].load(p); ks.rb[u].load(p + d);
                 } else if (a.mode == 2) {
-                    const T* p = rel + (int64_t)ks.tn[u] * (2 * d) + c;
+                    const T* p = rel + (int64_t)(ks.tn[u] & 0x7fffffff) * (2 * d) + c;
                     ks.ra[u].load(p); ks.rb[u].load(p + d);
                 }
             }
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_q_kernel(AttnArgs a) {
     struct KeySet { Raw8<T> ra[U], rb[U], k[U], v[U]; int tn[U]; };
     auto load_idx = [&](int jb, KeySet& ks) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) { const int j = jb + u * KS + joff; ks.tn[u] = (iq && j < a.S) ? iq[j] : 0; }
+        for (int u = 0; u < U; ++u) { const int j = jb + u * KS + joff; ks.tn[u] = (iq && j < a.S) ? iq[j] : 0; }   // bit 31: singleton type
     };
     auto issue = [&](int jb, KeySet& ks) {
 #pragma unroll
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_q_kernel(AttnArgs a) {
                     const T* p = rel + (((int64_t)j * a.T + i) * a.B + b) * (2 * d) + c;
                     ks.ra[u].load(p); ks.rb[u].load(p + d);
                 } else if (a.mode == 2) {
-                    const T* p = rel + (int64_t)ks.tn[u] * (2 * d) + c;
+                    const T* p = rel + (int64_t)(ks.tn[u] & 0x7fffffff) * (2 * d) + c;
                     ks.ra[u].load(p); ks.rb[u].load(p + d);
                 }
             }
@@ -365,6 +366,12 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_q_kernel(AttnArgs a) {
             for (int e = 0; e < 8; ++e) { dra[e] = gsc * rb[e]; drb[e] = gsc * ra[e]; dq[e] += dra[e]; }
             if (a.mode == 1) {
                 T* p2 = static_cast<T*>(a.d_rel) + (((int64_t)j * a.T + i) * a.B + b) * (2 * d) + c;
+                Vec8<T>::store(p2, dra);
+                Vec8<T>::store(p2 + d, drb);
+            } else if (a.mode == 2 && ks.tn[u] < 0 && a.d_rel) {
+                // a type that occurs ONCE in the batch (bit 31 of its id, set by the host index): this pair's term IS the
+                // type's bank gradient row -- written here, where both halves sit in registers; the type-major pass skips it
+                T* p2 = static_cast<T*>(a.d_rel) + (int64_t)(ks.tn[u] & 0x7fffffff) * a.ld_drel + c;
                 Vec8<T>::store(p2, dra);
                 Vec8<T>::store(p2 + d, drb);
             }
@@ -426,7 +433,7 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_kv_kernel(AttnArgs a) {
                 const int64_t off = (((int64_t)i * a.S + j) * a.B + b) * a.H + h;
                 pdv[u] = a.pd[off]; gsv[u] = a.gs[off];
                 if (a.mode == 1) rra[u].load(rel + (((int64_t)j * a.T + i) * a.B + b) * (2 * d) + c);
-                else if (a.mode == 2) rra[u].load(rel + (int64_t)ik[i] * (2 * d) + c);
+                else if (a.mode == 2) rra[u].load(rel + (int64_t)(ik[i] & 0x7fffffff) * (2 * d) + c);
             }
         }
 #pragma unroll
@@ -625,14 +632,15 @@ extern "C" int gtos_rel_attn_bwd(int dtype, int mode, int T_, int S, int B, int 
                                  const void* o, int64_t ldo, const float* lse, const float* w,
                                  const void* d_o, int64_t lddo, const float* dw,
                                  void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv,
-                                 void* d_rel, float* pd, float* gs, void* stream) {
+                                 void* d_rel, int64_t ld_drel, float* pd, float* gs, void* stream) {
     AttnArgs a = {};
     int rc = fill_args(a, T_, S, B, H, d, mode, scale, p_drop, seed);
     if (rc) return rc;
     a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.rel = rel; a.idx_q = idx_q; a.idx_k = idx_k;
     a.key_pad = key_pad; a.attn_mask = attn_mask; a.o = const_cast<void*>(o); a.ldo = ldo;
     a.lse = const_cast<float*>(lse); a.w = const_cast<float*>(w); a.d_o = d_o; a.lddo = lddo; a.dw = dw;
-    a.dq = dq; a.dk = dk; a.dv = dv; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv; a.d_rel = d_rel; a.pd = pd; a.gs = gs;
+    a.dq = dq; a.dk = dk; a.dv = dv; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv; a.d_rel = d_rel; a.ld_drel = ld_drel; a.pd = pd; a.gs = gs;
+    if (mode == 2 && d_rel && (ld_drel < 2 * d || ld_drel % 8)) return -14;
     if (dw && !w) return -13;
     hipStream_t s = static_cast<hipStream_t>(stream);
     return dispatch_lh(d / H / 8, [&](auto lh) {

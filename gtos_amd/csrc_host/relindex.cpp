@@ -4,7 +4,9 @@
 // read the type ids instead (gtos_amd/ops.py FactoredRelation) and need, once per batch:
 //   * the ids in query-major and key-major order as int32 (the kernels stream them beside q / k),
 //   * for the bank gradient (the index_add of autograd's index_select backward): the pairs grouped by type, cut into chunks
-//     of <= `chunk` pairs; types with several chunks ("heavy": <CLS>, <rCLS>, <SELF>, <TL>) get an fp32 accumulation slot,
+//     of <= `chunk` pairs; types with several chunks ("heavy": <CLS>, <rCLS>, <SELF>, <TL>) get an fp32 accumulation slot;
+//     types with ONE pair (86 % of the types of a synthetic AMR batch) get no chunk at all: their ids carry bit 31 and
+//     the query-major attention backward writes their gradient row directly,
 //   * the chunks ordered by (XCD that owns the graph of the chunk's first pair, graph, key row) so that consecutive
 //     workgroups of the gradient kernel gather q / k rows of one graph from that XCD's L2.
 // All of it is integer work on the batch's relation tensor, so it belongs to batch assembly on the host, next to the bank.
@@ -41,6 +43,13 @@ extern "C" gtos_relindex* gtos_relindex_build(int n, int B, int64_t R, const int
                 h->idx_k[(j * B + b) * n + i] = (int32_t)t;       // [j,b,i]
                 count[t + 1]++;
             }
+    // a type that occurs exactly once: its bank-gradient row is its single pair's term, which the query-major attention
+    // backward writes itself -- flagged with bit 31 of the id, and left out of the type-major chunk list below
+    for (int64_t p = 0; p < P; ++p) {
+        const int32_t tq = h->idx_q[p], tk = h->idx_k[p];
+        if (count[tq + 1] == 1) h->idx_q[p] = tq | (int32_t)0x80000000;
+        if (count[tk + 1] == 1) h->idx_k[p] = tk | (int32_t)0x80000000;
+    }
     for (int64_t t = 0; t < R; ++t) count[t + 1] += count[t];
     // pairs grouped by type; inside a type graph-major (b, j, i): the pairs of one graph are neighbours
     h->pair_sorted.resize(P);
@@ -58,6 +67,7 @@ extern "C" gtos_relindex* gtos_relindex_build(int n, int B, int64_t R, const int
     chunks.reserve(R + P / chunk);
     for (int64_t t = 0; t < R; ++t) {
         const int64_t lo = count[t], hi = count[t + 1];
+        if (hi - lo == 1) continue;                                          // singleton: written by the attention backward
         const int64_t nch = hi > lo ? (hi - lo + chunk - 1) / chunk : 1;      // a type without pairs still writes its zero row
         int32_t slot = -1;
         if (nch > 1) {

@@ -565,7 +565,17 @@ class RelAttnFn(torch.autograd.Function):
         full_q = (Cq == d) if kvsrc is not None else (Cq == 3 * d)
         dqsrc = (torch.empty_like if full_q else torch.zeros_like)(qsrc)
         dkv = dqsrc if kvsrc is None else (torch.empty_like if Ckv == 2 * d else torch.zeros_like)(kvsrc)
-        d_rel = torch.empty_like(rel) if mode == 1 else None
+        if mode == 1:
+            d_rel = torch.empty_like(rel)
+        elif mode == 2:
+            # a block of the layers' shared gradient slab; the attention backward writes the rows of the singleton types
+            # (flagged ids of the host index), the type-major pass below the rest
+            d_rel = fact.grad_group.grad_slice(rel) if ctx.needs_input_grad[2] else None
+            if d_rel is None:
+                d_rel = torch.empty_like(rel)
+        else:
+            d_rel = None
+        ldr = d_rel.stride(0) if mode == 2 else 0
         pd = torch.empty((T_, S, B, H), dtype=torch.float32, device=qsrc.device)
         gs = torch.empty_like(pd)
         es = qsrc.element_size()
@@ -576,12 +586,8 @@ class RelAttnFn(torch.autograd.Function):
                  ptr(key_pad), ptr(attn_mask), float(scale), float(p_drop), seed,
                  ptr(o), d, ptr(lse), ptr(w), ptr(d_o), d, ptr(d_w),
                  dqsrc.data_ptr() + q_off * es, Cq, dkv.data_ptr() + k_off * es, Ckv, dkv.data_ptr() + v_off * es, Ckv,
-                 ptr(d_rel), ptr(pd), ptr(gs), stream())
+                 ptr(d_rel), ldr, ptr(pd), ptr(gs), stream())
         if mode == 2:
-            d_rel = fact.grad_group.grad_slice(rel) if ctx.needs_input_grad[2] else None   # a block of the layers' shared slab
-            if d_rel is None:
-                d_rel = torch.empty_like(rel)
-            ldr = d_rel.stride(0)
             nh = int(fact.heavy_types.numel())
             heavy = torch.zeros((max(nh, 1), 2 * d), dtype=torch.float32, device=rel.device)
             with _Timed("rel_attn_bwd_bank", detail=True):

@@ -65,8 +65,10 @@ int gtos_rel_attn_fwd(int dtype, int mode, int T, int S, int B, int H, int d,
 /* Backward of the above (two launches: query-major then key-major).  Recomputes the probabilities from lse.
  * dw (optional) is an upstream gradient on the returned weights w (TokenGenerator's copy attention,
  * generator/decoder.py:32-34,55); then w must be the forward's output.  Mode 1 writes d_rel = d(rarb) [S,T,B,2d];
- * mode 2 leaves the bank gradient to gtos_rel_attn_bwd_bank.  pd/gs are caller-provided fp32 scratch [T,S,B,H]
- * (post-dropout probabilities, scale*dS). */
+ * mode 2 leaves the bank gradient to gtos_rel_attn_bwd_bank -- except for types whose id carries bit 31 in idx_q / idx_k
+ * (set by the host index for types that occur exactly once in the batch): their single pair's term IS their bank gradient
+ * row and is written straight into d_rel[type] (row stride ld_drel; d_rel may be NULL when no id is flagged).
+ * pd/gs are caller-provided fp32 scratch [T,S,B,H] (post-dropout probabilities, scale*dS). */
 int gtos_rel_attn_bwd(int dtype, int mode, int T, int S, int B, int H, int d,
                       const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                       const void* rel, const int* idx_q, const int* idx_k,
@@ -75,7 +77,7 @@ int gtos_rel_attn_bwd(int dtype, int mode, int T, int S, int B, int H, int d,
                       const void* o, int64_t ldo, const float* lse, const float* w,
                       const void* d_o, int64_t lddo, const float* dw,
                       void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv,
-                      void* d_rel, float* pd, float* gs, void* stream);
+                      void* d_rel, int64_t ld_drel, float* pd, float* gs, void* stream);
 
 /* Mode-2 bank gradient: d_bank[R,2d] (dtype) = scatter-add over pairs of [gs*(k_j + RB[t]) | gs*(q_i + RA[t])],
  * i.e. the backward of generator/generator.py:79's index_select composed with the relation term of

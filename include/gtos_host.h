@@ -87,7 +87,8 @@ gtos_relindex* gtos_relindex_build(int n, int B, int64_t R, const int64_t* relat
 /* sizes[3] = {P = n*n*B, chunks, heavy types} */
 int gtos_relindex_sizes(const gtos_relindex* h, int64_t* sizes);
 /* Fills 9 caller-allocated int32 arrays (NULL entries are skipped):
- *   idx_q[P]  ids in [i,b,j] order      idx_k[P]  ids in [j,b,i] order
+ *   idx_q[P]  ids in [i,b,j] order      idx_k[P]  ids in [j,b,i] order; bit 31 set on the ids of types that occur once in
+ *             the batch (no chunk below: gtos_rel_attn_bwd writes their bank-gradient row itself)
  *   pair_sorted[P]  flat pair indices (j*n+i)*B+b grouped by type, graph-major inside a type
  *   chunk_type/start/count/slot[chunks]  gradient chunks over pair_sorted (slot = heavy slot, -1 for single-chunk types),
  *                   ordered by (XCD of the first pair's graph, graph, key row)

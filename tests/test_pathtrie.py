@@ -111,8 +111,11 @@ def test_relation_index_groups_pairs_by_type(B):
     rel, R = batch['relation'], batch['relation_bank'].shape[1]
     ix = build_relation_index(rel, R, chunk=4)
     n = rel.shape[0]
-    assert torch.equal(ix.idx_q.long(), rel.permute(1, 2, 0)) and torch.equal(ix.idx_k.long(), rel.permute(0, 2, 1))
     flat = rel.reshape(-1)
+    occ = torch.bincount(flat, minlength=R)
+    single = occ[rel] == 1                                               # bit 31 flags the ids of types that occur once
+    for got, want, flag in ((ix.idx_q, rel.permute(1, 2, 0), single.permute(1, 2, 0)), (ix.idx_k, rel.permute(0, 2, 1), single.permute(0, 2, 1))):
+        assert torch.equal(got.long() & 0x7fffffff, want) and torch.equal(got < 0, flag)
     ps = ix.pair_sorted.long()
     assert sorted(ps.tolist()) == list(range(flat.numel()))
     seen, keys = {}, []
@@ -120,13 +123,14 @@ def test_relation_index_groups_pairs_by_type(B):
         t, s, k, sl = int(ix.chunk_type[c]), int(ix.chunk_start[c]), int(ix.chunk_count[c]), int(ix.chunk_slot[c])
         assert 0 <= k <= 4 and all(int(flat[p]) == t for p in ps[s:s + k])
         seen.setdefault(t, []).extend(ps[s:s + k].tolist())
+        assert int(occ[t]) != 1                                          # singleton types have no chunk
         assert (sl >= 0) == (int((flat == t).sum()) > 4)
         if sl >= 0:
             assert int(ix.heavy_types[sl]) == t
         first = int(ps[min(s, flat.numel() - 1)])
         gb = first % B
         keys.append(((gb // (B // 8)) if B % 8 == 0 else gb % 8, gb, first // (n * B)))
-    assert set(seen) == set(range(R))                                   # every type has a chunk, even one without pairs
+    assert set(seen) == {t for t in range(R) if int(occ[t]) != 1}       # every other type has a chunk, even one without pairs
     for t, got in seen.items():
         assert sorted(got) == torch.nonzero(flat == t).flatten().tolist()
     assert keys == sorted(keys)                                          # (XCD, graph, key row) order
