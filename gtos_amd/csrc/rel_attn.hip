@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_bank_kernel(BankArgs a) {
         Lvl2 l;
         const T* bp = static_cast<const T*>(a.bank) + (int64_t)m.t * (2 * d) + c;
         l.rRA.load(bp); l.rRB.load(bp + d);
-        l.my_pid = lane < m.cnt ? a.pair_sorted[m.start + lane] : 0;     // one coalesced load of the chunk's pair ids
+        l.my_pid = lane < min(m.cnt, 64) ? a.pair_sorted[m.start + lane] : 0;     // one coalesced load of the chunk's (first 64) pair ids
         return l;
     };
     int ch = first + (threadIdx.x >> 6);
@@ -524,28 +524,35 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_bank_kernel(BankArgs a) {
         const Meta m3 = load_meta(ch + 2 * stride);
         const int cnt = m1.cnt;
         float da[8] = {0, 0, 0, 0, 0, 0, 0, 0}, db[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gsum = 0.f;
-        for (int p0 = 0; p0 < cnt; p0 += 2 * G) {            // two pairs per group in flight
-            Raw8<T> rk[2], rq[2];
-            float gsc[2];
+        // a chunk of a heavy type may hold several 64-pair blocks (the host cuts <CLS>, <TL>, ... into long chunks so that a
+        // type with 65 k pairs costs ~130 fp32-atomic flushes per channel instead of ~2000); the first block's ids were
+        // prefetched with the chunk record, further blocks are loaded here
+        for (int sb = 0; sb < cnt; sb += 64) {
+            const int nb = min(64, cnt - sb);
+            const int my_pid = sb == 0 ? l1.my_pid : (lane < nb ? a.pair_sorted[m1.start + sb + lane] : 0);
+            for (int p0 = 0; p0 < nb; p0 += 2 * G) {            // two pairs per group in flight
+                Raw8<T> rk[2], rq[2];
+                float gsc[2];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int p = p0 + u * G + g;
-                const int pid = __shfl(l1.my_pid, p < cnt ? p : 0);
-                rk[u].zero(); rq[u].zero(); gsc[u] = 0.f;
-                if (p < cnt) {
-                    const int b = pid % a.B, ji = pid / a.B, i = ji % a.T, j = ji / a.T;
-                    gsc[u] = a.gs[(((int64_t)i * a.S + j) * a.B + b) * a.H + h];
-                    rk[u].load(static_cast<const T*>(a.k) + ((int64_t)j * a.B + b) * a.ldk + c);
-                    rq[u].load(static_cast<const T*>(a.q) + ((int64_t)i * a.B + b) * a.ldq + c);
+                for (int u = 0; u < 2; ++u) {
+                    const int p = p0 + u * G + g;
+                    const int pid = __shfl(my_pid, p < nb ? p : 0);
+                    rk[u].zero(); rq[u].zero(); gsc[u] = 0.f;
+                    if (p < nb) {
+                        const int b = pid % a.B, ji = pid / a.B, i = ji % a.T, j = ji / a.T;
+                        gsc[u] = a.gs[(((int64_t)i * a.S + j) * a.B + b) * a.H + h];
+                        rk[u].load(static_cast<const T*>(a.k) + ((int64_t)j * a.B + b) * a.ldk + c);
+                        rq[u].load(static_cast<const T*>(a.q) + ((int64_t)i * a.B + b) * a.ldq + c);
+                    }
                 }
-            }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                float kf[8], qf[8];
-                rk[u].get(kf); rq[u].get(qf);
-                gsum += gsc[u];
+                for (int u = 0; u < 2; ++u) {
+                    float kf[8], qf[8];
+                    rk[u].get(kf); rq[u].get(qf);
+                    gsum += gsc[u];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { da[e] = fmaf(gsc[u], kf[e], da[e]); db[e] = fmaf(gsc[u], qf[e], db[e]); }
+                    for (int e = 0; e < 8; ++e) { da[e] = fmaf(gsc[u], kf[e], da[e]); db[e] = fmaf(gsc[u], qf[e], db[e]); }
+                }
             }
         }
         for (int off = LR; off < 64; off <<= 1) {

@@ -68,15 +68,18 @@ extern "C" gtos_relindex* gtos_relindex_build(int n, int B, int64_t R, const int
     for (int64_t t = 0; t < R; ++t) {
         const int64_t lo = count[t], hi = count[t + 1];
         if (hi - lo == 1) continue;                                          // singleton: written by the attention backward
-        const int64_t nch = hi > lo ? (hi - lo + chunk - 1) / chunk : 1;      // a type without pairs still writes its zero row
+        // light types: one chunk of <= `chunk` pairs; heavy types (more than `chunk` pairs): long chunks of 16 * chunk pairs, so
+        // that their fp32-atomic flushes into the shared slot stay rare (65 k pairs of <TL>: 128 flushes, not 2048)
+        const int64_t csz = hi - lo > chunk ? 16 * (int64_t)chunk : chunk;
+        const int64_t nch = hi > lo ? (hi - lo + csz - 1) / csz : 1;          // a type without pairs still writes its zero row
         int32_t slot = -1;
-        if (nch > 1) {
+        if (hi - lo > chunk) {
             slot = (int32_t)h->heavy_types.size();
             h->heavy_types.push_back((int32_t)t);
         }
         for (int64_t c = 0; c < nch; ++c) {
-            const int64_t s = lo + c * chunk;
-            const int64_t cnt = std::max<int64_t>(0, std::min<int64_t>(chunk, hi - s));
+            const int64_t s = lo + c * csz;
+            const int64_t cnt = std::max<int64_t>(0, std::min<int64_t>(csz, hi - s));
             const int64_t first = h->pair_sorted[std::min<int64_t>(s, P - 1)];
             const int64_t gb = first % B, j = first / ((int64_t)n * B);
             const int64_t xcd = (B % 8 == 0) ? gb / (B / 8) : gb % 8;       // the attention kernels' graph -> XCD map
