@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_q_kernel(AttnArgs a) {
     const float lse = a.lse[row * a.H + h];
     float dq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
-    struct KeySet { Raw8<T> ra[U], rb[U], k[U], v[U]; int tn[U]; };
+    struct KeySet { Raw8<T> ra[U], rb[U], k[U], v[U]; int tn[U], tw[U]; };   // tn: ids prefetched for the NEXT issue; tw: ids of the rows in flight
     auto load_idx = [&](int jb, KeySet& ks) {
 #pragma unroll
         for (int u = 0; u < U; ++u) { const int j = jb + u * KS + joff; ks.tn[u] = (iq && j < a.S) ? iq[j] : 0; }   // bit 31: singleton type
@@ -332,6 +332,7 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_q_kernel(AttnArgs a) {
                 } else if (a.mode == 2) {
                     const T* p = rel + (int64_t)(ks.tn[u] & 0x7fffffff) * (2 * d) + c;
                     ks.ra[u].load(p); ks.rb[u].load(p + d);
+                    ks.tw[u] = ks.tn[u];
                 }
             }
         }
@@ -368,10 +369,10 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_q_kernel(AttnArgs a) {
                 T* p2 = static_cast<T*>(a.d_rel) + (((int64_t)j * a.T + i) * a.B + b) * (2 * d) + c;
                 Vec8<T>::store(p2, dra);
                 Vec8<T>::store(p2 + d, drb);
-            } else if (a.mode == 2 && ks.tn[u] < 0 && a.d_rel) {
+            } else if (a.mode == 2 && ks.tw[u] < 0 && a.d_rel) {
                 // a type that occurs ONCE in the batch (bit 31 of its id, set by the host index): this pair's term IS the
                 // type's bank gradient row -- written here, where both halves sit in registers; the type-major pass skips it
-                T* p2 = static_cast<T*>(a.d_rel) + (int64_t)(ks.tn[u] & 0x7fffffff) * a.ld_drel + c;
+                T* p2 = static_cast<T*>(a.d_rel) + (int64_t)(ks.tw[u] & 0x7fffffff) * a.ld_drel + c;
                 Vec8<T>::store(p2, dra);
                 Vec8<T>::store(p2 + d, drb);
             }
