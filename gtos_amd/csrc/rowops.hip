@@ -430,63 +430,81 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(int n_chunks, const int* _
                                                       const bf16_t* __restrict__ src1, int64_t ld_src,
                                                       int W, bf16_t* __restrict__ dst0, bf16_t* __restrict__ dst1, int64_t ld_dst,
                                                       float* __restrict__ heavy0, float* __restrict__ heavy1) {
-    // NSRC = 2: the same row lists reduce two source matrices (the two GRU directions' gradients) in one pass -- one
-    // index fetch and twice the bytes per gathered row
+    // NSRC = 2: the same row lists reduce two source matrices in one pass (one index fetch, twice the bytes per gathered row).
+    // Most chunks hold a handful of rows, so a chunk is a chain of three dependent loads (chunk record -> row ids -> rows).
+    // The waves walk the chunk list grid-stride and software-pipeline the chain: while chunk i is summed, the row ids of
+    // chunk i+1 (one coalesced load, a lane per row, broadcast with shuffles) and the record of chunk i+2 are in flight.
     const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c >= n_chunks) return;
-    const int node = chunk_node[c], start = chunk_start[c], cnt = chunk_cnt[c];
+    const int stride = gridDim.x * 4;
+    int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ch >= n_chunks) return;
+    struct Meta { int node, start, cnt, slot; };
+    const int last = n_chunks - 1;
+    auto load_meta = [&](int c) {
+        const int cc = c < last ? c : last;
+        Meta m;
+        m.node = chunk_node[cc]; m.start = chunk_start[cc]; m.cnt = chunk_cnt[cc]; m.slot = chunk_slot ? chunk_slot[cc] : -1;
+        return m;
+    };
+    auto load_ids = [&](const Meta& m) { return rows ? (lane < m.cnt ? rows[m.start + lane] : 0) : m.start + lane; };
     const bf16_t* srcs[2] = {src0, src1};
-    float acc[NSRC][SLABS][8];
+    bf16_t* dsts[2] = {dst0, dst1};
+    float* heavies[2] = {heavy0, heavy1};
+    Meta m1 = load_meta(ch), m2 = load_meta(ch + stride);
+    int ids1 = load_ids(m1);
+    for (; ch < n_chunks; ch += stride) {
+        const int ids2 = load_ids(m2);
+        const Meta m3 = load_meta(ch + 2 * stride);
+        const int cnt = m1.cnt;
+        float acc[NSRC][SLABS][8];
 #pragma unroll
-    for (int q = 0; q < NSRC; ++q)
+        for (int q = 0; q < NSRC; ++q)
 #pragma unroll
-        for (int sl = 0; sl < SLABS; ++sl)
+            for (int sl = 0; sl < SLABS; ++sl)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[q][sl][e] = 0.f;
-    constexpr int UN = NSRC == 2 ? 2 : 4;
-    for (int i0 = 0; i0 < cnt; i0 += UN) {
-        int64_t r[UN];
+                for (int e = 0; e < 8; ++e) acc[q][sl][e] = 0.f;
+        constexpr int UN = NSRC == 2 ? 2 : 4;
+        for (int i0 = 0; i0 < cnt; i0 += UN) {
+            uint4 raw[UN][NSRC][SLABS];
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int i = min(i0 + u, cnt - 1);
-            r[u] = rows ? rows[start + i] : start + i;
-        }
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            if (i0 + u < cnt) {
+            for (int u = 0; u < UN; ++u) {
+                const int64_t r = __shfl(ids1, i0 + u < cnt ? i0 + u : 0);
 #pragma unroll
                 for (int q = 0; q < NSRC; ++q)
 #pragma unroll
                     for (int sl = 0; sl < SLABS; ++sl) {
-                        const int ch = sl * 512 + lane * 8;
-                        if (ch < W) {
-                            float v[8];
-                            Vec8<bf16_t>::load(srcs[q] + r[u] * ld_src + ch, v);
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) acc[q][sl][e] += v[e];
-                        }
+                        const int chn = sl * 512 + lane * 8;
+                        raw[u][q][sl] = (chn < W && i0 + u < cnt) ? *reinterpret_cast<const uint4*>(srcs[q] + r * ld_src + chn)
+                                                                  : make_uint4(0, 0, 0, 0);
                     }
             }
+#pragma unroll
+            for (int u = 0; u < UN; ++u)
+#pragma unroll
+                for (int q = 0; q < NSRC; ++q)
+#pragma unroll
+                    for (int sl = 0; sl < SLABS; ++sl) {
+                        const uint4 v = raw[u][q][sl];
+                        acc[q][sl][0] += lo_bf(v.x); acc[q][sl][1] += hi_bf(v.x); acc[q][sl][2] += lo_bf(v.y); acc[q][sl][3] += hi_bf(v.y);
+                        acc[q][sl][4] += lo_bf(v.z); acc[q][sl][5] += hi_bf(v.z); acc[q][sl][6] += lo_bf(v.w); acc[q][sl][7] += hi_bf(v.w);
+                    }
         }
-    }
-    const int slot = chunk_slot ? chunk_slot[c] : -1;
-    bf16_t* dsts[2] = {dst0, dst1};
-    float* heavies[2] = {heavy0, heavy1};
 #pragma unroll
-    for (int q = 0; q < NSRC; ++q)
+        for (int q = 0; q < NSRC; ++q)
 #pragma unroll
-        for (int sl = 0; sl < SLABS; ++sl) {
-            const int ch = sl * 512 + lane * 8;
-            if (ch < W) {
-                if (slot < 0) {
-                    Vec8<bf16_t>::store(dsts[q] + (int64_t)node * ld_dst + ch, acc[q][sl]);
-                } else {
+            for (int sl = 0; sl < SLABS; ++sl) {
+                const int chn = sl * 512 + lane * 8;
+                if (chn < W) {
+                    if (m1.slot < 0) {
+                        Vec8<bf16_t>::store(dsts[q] + (int64_t)m1.node * ld_dst + chn, acc[q][sl]);
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) atomicAdd(heavies[q] + (int64_t)slot * W + ch + e, acc[q][sl][e]);
+                        for (int e = 0; e < 8; ++e) atomicAdd(heavies[q] + (int64_t)m1.slot * W + chn + e, acc[q][sl][e]);
+                    }
                 }
             }
-        }
+        m1 = m2; ids1 = ids2; m2 = m3;
+    }
 }
 
 // contiguous variant: segment s sums the consecutive rows ranges[2s] .. ranges[2s+1]-1 (the children of a trie node) into
@@ -707,7 +725,8 @@ extern "C" int gtos_segment_sum_rows(int n_chunks, const int* rows, const int* c
     if (!chunk_node || !chunk_start || !chunk_cnt || !src || !dst || (chunk_slot && !heavy)) return -23;
     if (src2 && (!dst2 || (chunk_slot && !heavy2))) return -23;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const dim3 grid((unsigned)((n_chunks + 3) / 4)), block(256);
+    const int nblk = (n_chunks + 3) / 4;
+    const dim3 grid((unsigned)(nblk < 4096 ? nblk : 4096)), block(256);      // grid-stride: 16 resident blocks per CU
 #define GTOS_SEG(S, Q) hipLaunchKernelGGL((seg_sum_kernel<S, Q>), grid, block, 0, s, n_chunks, rows, chunk_node, chunk_start, chunk_cnt, \
                                           chunk_slot, (const bf16_t*)src, (const bf16_t*)src2, ld_src, width, (bf16_t*)dst, (bf16_t*)dst2, \
                                           ld_dst, heavy, heavy2)
