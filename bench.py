@@ -161,6 +161,9 @@ def build_roofline(a, cfg, stats, model, trainer, batch, prof, dev, cd, detail=T
         ms = [s_.elapsed_time(e_) for s_, e_, _u in ev_]
         return (sum(ms) / len(ms), len(ms), sum(u for _, _, u in ev_), sum(ms)) if ms else (None, 0, 0, 0.0)
 
+    occ = torch.bincount(batch['relation'].reshape(-1), minlength=R)
+    R_single = int((occ == 1).sum())              # types with ONE pair: their bank-gradient row is written by the query-major pass
+    R_multi, P_multi = R - R_single, P - R_single
     stage_a = P * 2 * d * s_el + 4 * n * B * d * s_el + n * B
     fact_bytes = R * 2 * d * s_el + P * 4 + 4 * n * B * d * s_el + n * B
     pmc = {}
@@ -227,11 +230,13 @@ def build_roofline(a, cfg, stats, model, trainer, batch, prof, dev, cd, detail=T
                          "peak": HBM_PEAK_GBS, "frac": round(byt / ms / 1e6 / HBM_PEAK_GBS, 4), "ms_per_step": round(tot / 2, 2),
                          "bytes": note})
         hbm_row("rel_attn_bwd_q+kv_mode2", "rel_attn_bwd_q_kernel + rel_attn_bwd_kv_kernel (factored, one C call)",
-                bytes_per_launch=2 * R * 2 * d * s_el + 10 * n * B * d * s_el + 4 * P * H * 4 + 2 * P * 4,
-                note="2 passes x R*2d*s bank rows + 10nBd*s (q,k,v,o,do read; dq,dk,dv written) + pd,gs [P,H] fp32 written+read + ids")
-        hbm_row("rel_attn_bwd_bank", "rel_attn_bwd_bank_kernel",
-                bytes_per_launch=2 * R * 2 * d * s_el + P * H * 4 + P * 4 + 2 * n * B * d * s_el,
-                note="R*2d*s bank read + R*2d*s d_bank written + gs [P,H] fp32 + pair ids + q,k rows once (they are served by L2)")
+                bytes_per_launch=2 * R * 2 * d * s_el + R_single * 2 * d * s_el + 10 * n * B * d * s_el + 4 * P * H * 4 + 2 * P * 4,
+                note="2 passes x R*2d*s bank rows + R_single*2d*s bank-gradient rows of the %d single-pair types written + 10nBd*s (q,k,v,o,do "
+                     "read; dq,dk,dv written) + pd,gs [P,H] fp32 written+read + ids" % R_single)
+        hbm_row("rel_attn_bwd_bank", "rel_attn_bwd_bank_kernel (types with >= 2 pairs)",
+                bytes_per_launch=2 * R_multi * 2 * d * s_el + P_multi * H * 4 + P_multi * 4 + 2 * n * B * d * s_el,
+                note="%d multi-pair types: 2d*s bank row read + gradient row written each; their %d pairs: gs [H] fp32 + pair id; q,k rows "
+                     "once (they are served by L2)" % (R_multi, P_multi))
         hbm_row("gru_step_fwd_tables", "gru_step_fwd_kernel<2> (GRU layer 1, gate tables gathered)",
                 bytes_per_unit=(4 + 1 + 1 + 6) * hs * 2 + 8,
                 note="per active row: gates 4h + new state h written, state h read, two 3h table rows gathered, 2 node ids")

@@ -1188,3 +1188,48 @@ def test_gru_layer1_step_kernel_vs_torch(rows):
     got_h = torch.cat([h_out[:n_out], h_fin[n_out:]]).float()
     torch.testing.assert_close(got_h, o, rtol=2e-2, atol=2e-2)
     assert float(h_fin[:n_out].float().abs().max()) == 0.0 and float(h_out[n_out:].float().abs().max()) == 0.0
+
+
+def test_graph_layer_dropout_backward_matches_forward_bf16_d512():
+    """Training mode at the C2 width (d=512, H=8, ff=1024) in bf16 with all four dropout sites of a graph-encoder layer on
+    (graph_transformer.py:57,62,64,155): the analytic input gradient is the gradient of THAT seeded forward -- its
+    directional derivative along the normalised gradient, by central differences of the seeded forward, equals its norm."""
+    from gtos_amd.graph_transformer import GraphTransformerLayer, set_compute_dtype
+    from gtos_amd import ops
+    torch.manual_seed(0)
+    n, B, d = 24, 4, 512
+    m = GraphTransformerLayer(d, 1024, 8, 0.3).to(dev())
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.dim() == 2:
+                p.mul_(2.5)                       # N(0, 0.05): attention and FFN actually bend the output
+    set_compute_dtype(m, torch.bfloat16)
+    m.train()
+    x = torch.randn(n, B, d, device=dev())
+    R = 300
+    bank = (0.5 * torch.randn(R, d, device=dev())).requires_grad_()
+    idx = torch.randint(0, R, (n, n, B), device=dev())
+    wout = torch.randn(n, B, d, device=dev())
+
+    def f(xx, seed=4321):
+        ops.set_seed(seed)
+        return (m(xx, ops.FactoredRelation(bank, idx))[0].float() * wout).sum()
+    assert float(f(x).detach()) == float(f(x).detach()) and float(f(x).detach()) != float(f(x, 7).detach())
+    xg = x.clone().requires_grad_()
+    f(xg).backward()
+    g = xg.grad.float()
+    dirn = g / g.norm()
+    eps = 0.05 * float(x.norm()) / 10
+    num = (float(f(x + eps * dirn).detach()) - float(f(x - eps * dirn).detach())) / (2 * eps)
+    assert abs(num - float(g.norm())) < 0.15 * float(g.norm()), (num, float(g.norm()))
+    gb = bank.grad.float()
+    dirb = gb / gb.norm()
+    epsb = 0.05 * float(bank.detach().norm()) / 10
+    with torch.no_grad():
+        bank.add_(epsb * dirb)
+        up = float(f(x).detach())
+        bank.sub_(2 * epsb * dirb)
+        dn = float(f(x).detach())
+        bank.add_(epsb * dirb)
+    numb = (up - dn) / (2 * epsb)
+    assert abs(numb - float(gb.norm())) < 0.2 * float(gb.norm()), (numb, float(gb.norm()))
