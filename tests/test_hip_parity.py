@@ -965,7 +965,7 @@ def test_trie_gru_dropout_is_deterministic_and_backward_matches_forward():
         ops.set_seed(seed)
         return (m(bank_d, len_d, trie=trie).float() * wout).sum()
     a, b, c = f(), f(), f(99)
-    assert float(a) == float(b) and float(a) != float(c)
+    assert float(a.detach()) == float(b.detach()) and float(a.detach()) != float(c.detach())
     m.zero_grad()
     f().backward()
     for name in ("rnn.weight_hh_l0", "rnn.weight_ih_l1_reverse", "rel_embed.weight"):
