@@ -14,6 +14,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gtos_amd import ops, synth  # noqa: E402
+from gtos_amd.relindex import build_relation_index  # noqa: E402
 
 HBM = 8000.0
 
@@ -50,7 +51,8 @@ def main():
     qkv = torch.randn(n, B, 3 * d, generator=g).to(dev, dt)
     bankp = (0.3 * torch.randn(R, 2 * d, generator=g)).to(dev, dt)
     pad = torch.zeros(n, B, dtype=torch.bool, device=dev)
-    fact = ops.FactoredRelation(torch.zeros(R, d, device=dev, dtype=dt), idx)
+    index = build_relation_index(batch["relation"], R).to(dev)      # the loader's host-built index, as in the training step
+    fact = ops.FactoredRelation(torch.zeros(R, d, device=dev, dtype=dt), idx, index=index)
     out = []
     fwd_bytes = P * 2 * d * s_el + 4 * n * B * d * s_el + n * B
     bwd_dense_bytes = 2 * P * 2 * d * s_el + P * d * s_el + 10 * n * B * d * s_el     # re-read rarb, write d_rarb, re-read ra
