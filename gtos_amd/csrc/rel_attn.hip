@@ -526,16 +526,16 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_bank_kernel(BankArgs a) {
         const int cnt = m1.cnt;
         float da[8] = {0, 0, 0, 0, 0, 0, 0, 0}, db[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gsum = 0.f;
         // a chunk of a heavy type may hold several 64-pair blocks (the host cuts <CLS>, <TL>, ... into long chunks so that a
-        // type with 65 k pairs costs ~130 fp32-atomic flushes per channel instead of ~2000); the first block's ids were
+        // type with 65 k pairs costs ~500 fp32-atomic flushes per channel instead of ~2000); the first block's ids were
         // prefetched with the chunk record, further blocks are loaded here
         for (int sb = 0; sb < cnt; sb += 64) {
             const int nb = min(64, cnt - sb);
             const int my_pid = sb == 0 ? l1.my_pid : (lane < nb ? a.pair_sorted[m1.start + sb + lane] : 0);
-            for (int p0 = 0; p0 < nb; p0 += 2 * G) {            // two pairs per group in flight
-                Raw8<T> rk[2], rq[2];
-                float gsc[2];
+            for (int p0 = 0; p0 < nb; p0 += 4 * G) {            // four pairs per group in flight
+                Raw8<T> rk[4], rq[4];
+                float gsc[4];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < 4; ++u) {
                     const int p = p0 + u * G + g;
                     const int pid = __shfl(my_pid, p < nb ? p : 0);
                     rk[u].zero(); rq[u].zero(); gsc[u] = 0.f;
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_bank_kernel(BankArgs a) {
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < 4; ++u) {
                     float kf[8], qf[8];
                     rk[u].get(kf); rq[u].get(qf);
                     gsum += gsc[u];

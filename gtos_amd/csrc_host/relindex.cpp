@@ -12,6 +12,7 @@
 // All of it is integer work on the batch's relation tensor, so it belongs to batch assembly on the host, next to the bank.
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <vector>
@@ -68,9 +69,11 @@ extern "C" gtos_relindex* gtos_relindex_build(int n, int B, int64_t R, const int
     for (int64_t t = 0; t < R; ++t) {
         const int64_t lo = count[t], hi = count[t + 1];
         if (hi - lo == 1) continue;                                          // singleton: written by the attention backward
-        // light types: one chunk of <= `chunk` pairs; heavy types (more than `chunk` pairs): long chunks of 16 * chunk pairs, so
-        // that their fp32-atomic flushes into the shared slot stay rare (65 k pairs of <TL>: 128 flushes, not 2048)
-        const int64_t csz = hi - lo > chunk ? 16 * (int64_t)chunk : chunk;
+        // light types: one chunk of <= `chunk` pairs; heavy types (more than `chunk` pairs): chunks of 4 * chunk pairs -- fewer
+        // fp32-atomic flushes into the shared slot (65 k pairs of <TL>: 512, not 2048) without turning one wave's serial walk
+        // over its chunk into the kernel's critical path (16 * chunk measured 390 us per launch for 0.44 GB of traffic)
+        static const int64_t mult = getenv("GTOS_HEAVY_CHUNK_MULT") ? atoi(getenv("GTOS_HEAVY_CHUNK_MULT")) : 4;
+        const int64_t csz = hi - lo > chunk ? mult * (int64_t)chunk : chunk;
         const int64_t nch = hi > lo ? (hi - lo + csz - 1) / csz : 1;          // a type without pairs still writes its zero row
         int32_t slot = -1;
         if (hi - lo > chunk) {

@@ -121,7 +121,7 @@ def test_relation_index_groups_pairs_by_type(B):
     seen, keys = {}, []
     for c in range(ix.nchunks):
         t, s, k, sl = int(ix.chunk_type[c]), int(ix.chunk_start[c]), int(ix.chunk_count[c]), int(ix.chunk_slot[c])
-        assert 0 <= k <= (64 if int(occ[t]) > 4 else 4) and all(int(flat[p]) == t for p in ps[s:s + k])   # heavy: chunks of 16 x 4
+        assert 0 <= k <= (16 if int(occ[t]) > 4 else 4) and all(int(flat[p]) == t for p in ps[s:s + k])   # heavy: chunks of 4 x 4
         seen.setdefault(t, []).extend(ps[s:s + k].tolist())
         assert int(occ[t]) != 1                                          # singleton types have no chunk
         assert (sl >= 0) == (int((flat == t).sum()) > 4)
