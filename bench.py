@@ -214,11 +214,13 @@ def build_roofline(a, cfg, stats, model, trainer, batch, prof, dev, cd, detail=T
     rows = []
     if detail and not a.dense and cd == torch.bfloat16:
         ops.PROFILE, ops.PROFILE_DETAIL, ops.GEMM_PROFILE = {}, True, {}
+        side_was, ops.BWD_SIDE = ops.BWD_SIDE, False        # one kernel at a time: no auxiliary-stream GEMM beside the timed launches
         for _ in range(2):
             trainer.step(batch)
         torch.cuda.synchronize()
         dp, gp = ops.PROFILE, ops.GEMM_PROFILE
         ops.PROFILE, ops.PROFILE_DETAIL, ops.GEMM_PROFILE = None, False, None
+        ops.BWD_SIDE = side_was
 
         def hbm_row(name, label, bytes_per_launch=None, bytes_per_unit=None, note=""):
             ms, cnt, units, tot = span(dp, name)
@@ -237,7 +239,7 @@ def build_roofline(a, cfg, stats, model, trainer, batch, prof, dev, cd, detail=T
                 bytes_per_launch=2 * R_multi * 2 * d * s_el + P_multi * H * 4 + P_multi * 4 + 2 * n * B * d * s_el,
                 note="%d multi-pair types: 2d*s bank row read + gradient row written each; their %d pairs: gs [H] fp32 + pair id; q,k rows "
                      "once (they are served by L2)" % (R_multi, P_multi))
-        hbm_row("gru_step_fwd_tables", "gru_step_fwd_kernel<2> (GRU layer 1, gate tables gathered)",
+        hbm_row("gru_step_fwd_tables", "gru_l1_fwd_persistent_kernel (GRU layer 1 step, gate tables gathered, W_hh slice resident in LDS)",
                 bytes_per_unit=(4 + 1 + 1 + 6) * hs * 2 + 8,
                 note="per active row: gates 4h + new state h written, state h read, two 3h table rows gathered, 2 node ids")
         hbm_row("gru_step_fwd_x", "gru_step_fwd_kernel<1> (GRU layer 0 on the tries, input product fused)",
@@ -260,9 +262,10 @@ def build_roofline(a, cfg, stats, model, trainer, batch, prof, dev, cd, detail=T
                          "flops_per_launch": int(fl / calls), "achieved": round(fl / ms / 1e9, 1), "unit": "TFLOP/s",
                          "peak": MFMA_PEAK_TFS, "frac": round(fl / ms / 1e9 / MFMA_PEAK_TFS, 4), "ms_per_step": round(ms / 2, 2)})
     roof["kernels"] = rows
-    roof["kernels_note"] = ("detail pass: 2 extra training steps with a HIP-event pair around every launch of these kernels "
-                            "(the events slow the step, so they are not taken inside the timed region); bytes are algorithmic, "
-                            "per launch; GEMM rows: the four shapes with the largest time share")
+    roof["kernels_note"] = ("detail pass: 2 extra training steps with a HIP-event pair around every launch of these kernels, the "
+                            "auxiliary-stream overlap of the projection-gradient GEMMs switched off so that every launch is timed alone "
+                            "(events and serialisation slow the step, so none of this happens inside the timed region); bytes are "
+                            "algorithmic, per launch; GEMM rows: the four shapes with the largest time share")
     return roof
 
 
