@@ -1014,6 +1014,13 @@ def test_segment_sum_kernels():
         _seg_rows(side, d4, 768, out)
         want = torch.zeros(side.n_nodes, 768, device=dev()).index_add_(0, row_node.long(), d4[:, :768].float())
         torch.testing.assert_close(out.float(), want, rtol=1e-2, atol=1e-2 * want.abs().max().item())
+        # two sources over the same row lists in one pass
+        d4b = torch.randn(trie.N, 1024, generator=g).to(dev(), torch.bfloat16)
+        out_a, out_b = torch.empty_like(out), torch.empty_like(out)
+        _seg_rows(side, d4, 768, out_a, d4b, out_b)
+        want_b = torch.zeros(side.n_nodes, 768, device=dev()).index_add_(0, row_node.long(), d4b[:, :768].float())
+        torch.testing.assert_close(out_a.float(), want, rtol=1e-2, atol=1e-2 * want.abs().max().item())
+        torch.testing.assert_close(out_b.float(), want_b, rtol=1e-2, atol=1e-2 * want_b.abs().max().item())
 
 
 # ------------------------------------------------------------------------------------------------ fused copy/generate mixture
