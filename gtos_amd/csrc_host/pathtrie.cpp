@@ -71,38 +71,54 @@ std::vector<int32_t> lex_order(const Seqs& q) {
 }
 
 void build_trie(const Seqs& q, const std::vector<int32_t>& order, Trie& tr) {
+    // One pass over the lexicographically sorted sequences: sequence i shares its first lcp(i-1, i) nodes with its
+    // predecessor and opens a new node at every later position.  Nodes are first numbered per level in creation order
+    // (= lexicographic order inside the level), then shifted by the level offsets, so the walk is sequential in memory.
     const int L = q.L;
     const int64_t R = q.R;
     tr.node_of.assign(R * L, -1);
+    std::vector<int64_t> per_level(L + 1, 0);
+    std::vector<int32_t> cur(L, -1);                        // node (per-level rank) of the previous sequence at each position
+    std::vector<int32_t> lvl_tok[64], lvl_par[64];          // L <= 64 (relation paths have <= 8 labels)
+    const int32_t* prev = nullptr;
+    int prev_len = 0;
+    for (int64_t i = 0; i < R; ++i) {
+        const int32_t s = order[i];
+        const int32_t* t = &q.tok[(int64_t)s * L];
+        const int len = q.len[s];
+        int lcp = 0;
+        if (prev) {
+            const int m = len < prev_len ? len : prev_len;
+            while (lcp < m && t[lcp] == prev[lcp]) ++lcp;
+        }
+        int32_t* out = &tr.node_of[(int64_t)s * L];
+        for (int k = 0; k < lcp; ++k) out[k] = cur[k];
+        for (int k = lcp; k < len; ++k) {
+            cur[k] = (int32_t)per_level[k]++;
+            lvl_tok[k].push_back(t[k]);
+            lvl_par[k].push_back(k ? cur[k - 1] : -1);
+            out[k] = cur[k];
+        }
+        prev = t;
+        prev_len = len;
+    }
     tr.level_off.assign(L + 1, 0);
-    tr.tok.clear();
-    tr.par.clear();
-    int64_t next = 0;
+    for (int k = 0; k < L; ++k) tr.level_off[k + 1] = tr.level_off[k] + per_level[k];
+    const int64_t next = tr.level_off[L];
+    tr.n_nodes = next;
+    tr.tok.resize(next);
+    tr.par.resize(next);
     for (int k = 0; k < L; ++k) {
-        tr.level_off[k] = next;
-        int32_t prev_seq = -1;
-        for (int64_t i = 0; i < R; ++i) {
-            const int32_t s = order[i];
-            if (q.len[s] <= k) continue;
-            bool fresh = prev_seq < 0;
-            if (!fresh) {
-                // same node as the previous sequence of this level iff same parent node and same token
-                const int32_t pa = k ? tr.node_of[(int64_t)prev_seq * L + k - 1] : -1, pb = k ? tr.node_of[(int64_t)s * L + k - 1] : -1;
-                fresh = pa != pb || q.tok[(int64_t)prev_seq * L + k] != q.tok[(int64_t)s * L + k];
-            }
-            if (fresh) {
-                tr.tok.push_back(q.tok[(int64_t)s * L + k]);
-                tr.par.push_back(k ? tr.node_of[(int64_t)s * L + k - 1] : -1);
-                ++next;
-            }
-            tr.node_of[(int64_t)s * L + k] = (int32_t)(next - 1);
-            prev_seq = s;
+        const int64_t off = tr.level_off[k], poff = k ? tr.level_off[k - 1] : 0;
+        for (int64_t j = 0; j < per_level[k]; ++j) {
+            tr.tok[off + j] = lvl_tok[k][j];
+            tr.par[off + j] = k ? (int32_t)(poff + lvl_par[k][j]) : (int32_t)next;   // level 0: the all-zero row behind the last node
         }
     }
-    tr.level_off[L] = next;
-    tr.n_nodes = next;
-    for (auto& p : tr.par)
-        if (p < 0) p = (int32_t)next;                      // level 0: the extra all-zero row behind the last node
+    for (int64_t s = 0; s < R; ++s) {                         // per-level ranks -> global node ids
+        int32_t* out = &tr.node_of[s * L];
+        for (int k = 0; k < q.len[s]; ++k) out[k] += (int32_t)tr.level_off[k];
+    }
     // children of a node: a contiguous range of the next level (nodes of a level are sorted by parent, then token);
     // stored as [start, end) pairs, start == end for leaves
     tr.child_off.assign(2 * next, 0);
@@ -156,7 +172,7 @@ struct gtos_pathtrie {
 };
 
 extern "C" gtos_pathtrie* gtos_pathtrie_build(int L, int64_t R, const int64_t* bank, const int64_t* length, int chunk) {
-    if (L <= 0 || R <= 0 || !bank || !length || chunk <= 0 || R > 0x7fffffffLL / (L > 0 ? L : 1)) return nullptr;
+    if (L <= 0 || L > 64 || R <= 0 || !bank || !length || chunk <= 0 || R > 0x7fffffffLL / L) return nullptr;
     Seqs fw, bw;
     fw.L = bw.L = L;
     fw.R = bw.R = R;
