@@ -211,3 +211,48 @@ def test_batchify_amr_from_preprocessed_items(tmp_path):
             seen.setdefault(key, set()).add(got[key][0])
     multi = [k for k, v in want.items() if len(v) > 1 and k[0] and k[1]]
     assert multi and all(len(seen[k]) > 1 for k in multi)                # over 12 seeds every tie is broken both ways
+
+
+# ------------------------------------------------------------------------------------------------ loader overlap
+def test_prefetcher_keeps_order_defers_assembly_and_propagates_errors():
+    import threading
+    import time
+    from gtos_amd.data import Prefetcher
+    built = []
+
+    def make(i):
+        def f():
+            time.sleep(0.01 * ((7 - i) % 3))          # uneven assembly times: order must still be the source order
+            built.append((i, threading.current_thread().name))
+            return {"i": torch.tensor([i])}
+        return f
+    got = [int(b["i"]) for b in Prefetcher((make(i) for i in range(9)), depth=3, workers=3)]
+    assert got == list(range(9))
+    assert all(name != threading.current_thread().name for _, name in built)      # assembled off the consumer thread
+    # stays at most `depth` ahead
+    built.clear()
+    pf = Prefetcher((make(i) for i in range(9)), depth=2, workers=2)
+    first = next(pf)
+    time.sleep(0.2)
+    assert int(first["i"]) == 0 and len(built) <= 1 + 2 + 2
+    assert [int(b["i"]) for b in pf] == list(range(1, 9))
+
+    def boom():
+        raise ValueError("bad batch")
+    with pytest.raises(ValueError):
+        list(Prefetcher([make(0), boom, make(2)], depth=2))
+
+
+def test_prefetcher_over_the_real_loader_matches_direct_iteration():
+    from gtos_amd import synth
+    from gtos_amd.data import Prefetcher
+    from gtos_amd.pathtrie import attach_path_trie
+    from gtos_amd.relindex import attach_relation_index
+
+    def job(k):
+        return lambda: attach_relation_index(attach_path_trie(synth.make_batch(9, 3, 10, 5, first_graph=3 * k)[0]))
+    direct = [job(k)() for k in range(4)]
+    via = list(Prefetcher((job(k) for k in range(4)), depth=2, workers=2))
+    for a, b in zip(direct, via):
+        assert torch.equal(a["relation"], b["relation"]) and torch.equal(a["relation_trie"].row_sf, b["relation_trie"].row_sf)
+        assert torch.equal(a["relation_index"].pair_sorted, b["relation_index"].pair_sorted)
