@@ -1240,3 +1240,25 @@ def test_graph_layer_dropout_backward_matches_forward_bf16_d512():
         bank.add_(epsb * dirb)
     numb = (up - dn) / (2 * epsb)
     assert abs(numb - float(gb.norm())) < 0.2 * float(gb.norm()), (numb, float(gb.norm()))
+
+
+def test_prefetcher_uploads_batches_on_a_copy_stream():
+    """data.Prefetcher(device=...): batches assembled on a loader thread arrive on the GPU (tensors, path tries, relation
+    index) and a bf16 model step runs on them."""
+    from gtos_amd import synth
+    from gtos_amd.config import build_generator
+    from gtos_amd.data import Prefetcher
+    from gtos_amd.generator import Generator
+    from gtos_amd.pathtrie import attach_path_trie
+    from gtos_amd.relindex import attach_relation_index
+    m = build_generator(Generator, "C1", dev(), dropout=0.0).to(dev())
+    m.set_compute_dtype(torch.bfloat16)
+    m.train()
+
+    def job(k):
+        return lambda: attach_relation_index(attach_path_trie(synth.make_config_batch("C1", rank=k)[0]))
+    losses = []
+    for batch in Prefetcher((job(k) for k in range(3)), depth=2, workers=2, device=dev()):
+        assert batch["concept"].is_cuda and batch["relation_trie"].device.type == "cuda" and batch["relation_index"].device.type == "cuda"
+        losses.append(float(m(batch).detach()))
+    assert len(losses) == 3 and all(np.isfinite(l) for l in losses) and len(set(losses)) == 3
