@@ -430,9 +430,12 @@ def main():
     roofline = None
     if rank == 0:
         # N > 1: no detail pass (its extra training steps would issue collectives the other ranks do not join)
-        roofline = build_roofline(a, cfg, stats, model, trainer, batch, prof, dev, cd, detail=(world == 1))
+        roofline = build_roofline(a, cfg, stats, model, trainer, batch, prof, dev, cd,
+                                  detail=(world == 1 and not os.environ.get("GTOS_BENCH_NO_DETAIL")))
     if rank == 0:
-        out = {"metric": "graphs/sec training step (100-node AMR, batch 64)", "value": world * B * a.steps / elapsed,
+        metric = ("graphs/sec training step (100-node AMR, batch 64)" if a.config in ("C2", "C4") else
+                  "graphs/sec training step (%s: %d-node %s graphs, batch %d)" % (a.config, cfg["N"], cfg["kind"], B))
+        out = {"metric": metric, "value": world * B * a.steps / elapsed,
                "unit": "graphs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
