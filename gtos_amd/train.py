@@ -61,7 +61,8 @@ class Trainer:
         self.overlap = overlap and world_size > 1 and len(self.flat.segments) > 1
         self._launched = 0              # segments [0, _launched) have their all-reduce in flight
         self._works = []
-        self.comm_exposed_s = 0.0       # host time spent waiting for collectives after backward (bench.py reports it)
+        self.comm_exposed_s = 0.0       # host time spent waiting for collectives after backward (gloo blocks here)
+        self._comm_events = []          # (start, end) HIP events around the waits on the compute stream: the GPU-side exposed time
         if self.overlap and hasattr(model, "grad_sync"):
             model.grad_sync = self      # Generator.forward places the SegmentBoundaryFn markers
         if world_size > 1:
@@ -87,11 +88,26 @@ class Trainer:
         """After backward(): launch what backward did not (at least the last segment) and wait for everything."""
         ops.join_side()                    # deferred side-stream gradient GEMMs (gru.py) land before the bucket is read
         self.segment_ready(len(self.flat.segments) - 1)
+        timed = bool(self._works) and self.flat.grad.is_cuda
+        if timed:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         t0 = time.perf_counter()
         for w in self._works:
             w.wait()                       # nccl: the current stream waits for the collective; gloo: blocks the host
         self.comm_exposed_s += time.perf_counter() - t0
+        if timed:
+            ev[1].record()
+            self._comm_events.append(ev)
         self._works, self._launched = [], 0
+
+    def comm_exposed_ms(self, reset=True):
+        """Milliseconds the compute stream spent stalled on gradient collectives since the last call (HIP events around the
+        waits; needs the stream to be idle, i.e. call it after a synchronize)."""
+        ms = sum(s.elapsed_time(e) for s, e in self._comm_events)
+        if reset:
+            self._comm_events = []
+        return ms
 
     def step(self, batch):
         """Returns the loss value (float) of this step, or None when the batch was discarded."""
