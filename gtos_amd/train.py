@@ -99,6 +99,8 @@ class Trainer:
         if timed:
             ev[1].record()
             self._comm_events.append(ev)
+            if len(self._comm_events) > 512:       # nobody is reading them: keep the list bounded
+                del self._comm_events[:256]
         self._works, self._launched = [], 0
 
     def comm_exposed_ms(self, reset=True):
