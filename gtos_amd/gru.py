@@ -270,6 +270,9 @@ TRIE = os.environ.get("GTOS_GRU_TRIE", "1") != "0"
 # step kernels slow down by what the GEMMs gain once the per-row work is gone), so it is off by default and the profile stays
 # one kernel at a time.
 TRIE_SIDE = os.environ.get("GTOS_GRU_TRIE_SIDE", "0") == "1"
+# Layer 0 walks each trie level by level (<= 8 small launches per trie, the first levels far too small to fill the chip); the
+# prefix and the suffix trie are independent, so the suffix side runs on the auxiliary stream beside the prefix side.
+TRIE_L0_OVERLAP = os.environ.get("GTOS_GRU_L0_OVERLAP", "1") != "0"
 
 
 def _seg_rows(side, src, width, dst, src2=None, dst2=None):
@@ -333,27 +336,35 @@ class TrieBiGRUFn(torch.autograd.Function):
         sides = (trie.pf, trie.sf)
         dim = table.shape[1]
         tab = table.detach()
-        # ---- layer 0 on the tries
+        # ---- layer 0 on the tries (suffix side on the auxiliary stream, see TRIE_L0_OVERLAP)
         l0 = []
+        main = torch.cuda.current_stream(dev)
+        aux = _side_stream(dev) if (TRIE_L0_OVERLAP and table.is_cuda and N >= 4096) else main
+        seeds = [(next_seed() if p_embed > 0 else 0, next_seed() if p_layer > 0 else 0) for _ in sides]
+        if aux is not main:
+            aux.wait_stream(main)
         for d, side in enumerate(sides):
-            n = side.n_nodes
-            w_ih, w_hh, b_ih, b_hh = weights[d * 4: d * 4 + 4]
-            wi, wh = compute_weight(w_ih, dtp), compute_weight(w_hh, dtp)
-            seed_e = next_seed() if p_embed > 0 else 0
-            seed_y = next_seed() if p_layer > 0 else 0
-            X = torch.empty((n, dim_pad), dtype=dtp, device=dev)
-            call("gtos_embed_rows_fwd", dt(X), n, dim, dim_pad, ptr(side.tok), ptr(tab), ptr(X), float(p_embed), seed_e, stream())
-            H = torch.empty((n + 1, hs), dtype=dtp, device=dev)
-            H[n].zero_()                                        # the state every level-0 node starts from
-            gates = torch.empty((n, 4 * hs), dtype=dtp, device=dev)
-            Y = torch.empty((n, hs), dtype=dtp, device=dev) if p_layer > 0 else None
-            bi, bh = b_ih.detach(), b_hh.detach()
-            for k in range(L):
-                lo, hi = side.level_off[k], side.level_off[k + 1]
-                if hi > lo:
-                    _step_fwd(hi - lo, hs, X[lo:hi], None, H, wi, bi, wh, bh, H[lo:hi], hi - lo, None, gates[lo:hi],
-                              Y, lo * hs, hs, p_layer, seed_y, lo * hs, h_idx=side.par[lo:hi])
-            l0.append((X, H, gates, Y, seed_e, seed_y, weight_t(w_ih, wi), weight_t(w_hh, wh)))
+            with torch.cuda.stream(aux if d == 1 else main):
+                n = side.n_nodes
+                w_ih, w_hh, b_ih, b_hh = weights[d * 4: d * 4 + 4]
+                wi, wh = compute_weight(w_ih, dtp), compute_weight(w_hh, dtp)
+                seed_e, seed_y = seeds[d]
+                X = torch.empty((n, dim_pad), dtype=dtp, device=dev)
+                call("gtos_embed_rows_fwd", dt(X), n, dim, dim_pad, ptr(side.tok), ptr(tab), ptr(X), float(p_embed), seed_e, stream())
+                H = torch.empty((n + 1, hs), dtype=dtp, device=dev)
+                H[n].zero_()                                        # the state every level-0 node starts from
+                gates = torch.empty((n, 4 * hs), dtype=dtp, device=dev)
+                Y = torch.empty((n, hs), dtype=dtp, device=dev) if p_layer > 0 else None
+                bi, bh = b_ih.detach(), b_hh.detach()
+                for k in range(L):
+                    lo, hi = side.level_off[k], side.level_off[k + 1]
+                    if hi > lo:
+                        _step_fwd(hi - lo, hs, X[lo:hi], None, H, wi, bi, wh, bh, H[lo:hi], hi - lo, None, gates[lo:hi],
+                                  Y, lo * hs, hs, p_layer, seed_y, lo * hs, h_idx=side.par[lo:hi])
+                l0.append((X, H, gates, Y, seed_e, seed_y, weight_t(w_ih, wi), weight_t(w_hh, wh)))
+        if aux is not main:
+            main.wait_stream(aux)      # layer 1 reads both sides; the suffix side's buffers live in the auxiliary stream's pool and
+            #                            are only handed back after backward, when main has long passed this point
         src = [l0[d][3] if p_layer > 0 else l0[d][1][:sides[d].n_nodes] for d in (0, 1)]
         # ---- layer 1: per-node input-gate tables, then the recurrent steps over the packed rows
         finals, l1 = [], []
