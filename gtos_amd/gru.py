@@ -481,7 +481,15 @@ class TrieBiGRUFn(torch.autograd.Function):
         dtab = None
         if table.requires_grad and _grad_target(table) is None:
             dtab = torch.zeros(table.shape, dtype=torch.float32, device=dev)
+        # the two tries are independent: the suffix side runs on the auxiliary stream beside the prefix side (small launches per
+        # level on both); with TRIE_SIDE the GEMMs go to the auxiliary stream instead and both sides stay on main
+        l0_overlap = TRIE_L0_OVERLAP and not use_side and N >= 4096
+        aux0 = _side_stream(dev) if l0_overlap else main
+        if l0_overlap:
+            aux0.wait_stream(main)
+        import contextlib
         for d, side in enumerate(sides):
+          with torch.cuda.stream(aux0 if d == 1 else main):
             X, H, gates, Y, seed_e, seed_y, wi_t, wh_t = l0[d]
             n = side.n_nodes
             base = d * 4
@@ -506,7 +514,7 @@ class TrieBiGRUFn(torch.autograd.Function):
                 _step_bwd(A, hs, S if has_kids else None, A, wh_t, gates[lo:hi], H, dy.data_ptr() + lo * hs * dy.element_size(), hs,
                           dhz[lo:hi], d4[lo:hi], p_layer, seed_y, lo * hs, bpart, hprev_idx=side.par[lo:hi])
             hp = H.index_select(0, side.par_long)                    # the state each node started from, aligned with d4's rows
-            with on_side(d4, hp, X, bpart):
+            with (on_side(d4, hp, X, bpart) if use_side else contextlib.nullcontext()):
                 _acc_weight_grad(grads, base + 1, w_hh, d4[:, :2 * hs], hp, rows=slice(0, 2 * hs))
                 _acc_weight_grad(grads, base + 1, w_hh, d4[:, 3 * hs:], hp, rows=slice(2 * hs, 3 * hs))
                 _acc_weight_grad(grads, base, w_ih, d4[:, :3 * hs], X)
@@ -519,6 +527,11 @@ class TrieBiGRUFn(torch.autograd.Function):
                         tgt = dtab
                     call("gtos_embed_rows_bwd", dt(dX), n, table.shape[0], table.shape[1], dim_pad, ptr(side.tok), ptr(dX), ptr(tgt),
                          float(p_embed), seed_e, stream())
+            if l0_overlap and d == 1:
+                keep.extend((d4, dhz, S, bpart, hp))   # allocated in the auxiliary stream's pool: released after the join below
+        if l0_overlap:
+            main.wait_stream(aux0)
+            keep.clear()
         if use_side:
             if dtab is None and all(gr is None for gr in grads):
                 defer_side_join(dev, keep)     # every gradient went into the flat bucket: its readers join the side stream
