@@ -8,6 +8,7 @@ cell backward + bias sums, one d4 = [dr|dz|dn_x|dn_h] buffer).  fp32 / other siz
 steps are one GEMM, each step one [active,h]x[h,3h] GEMM plus gtos_gru_cell_fwd / gtos_gru_cell_bwd.  Weight and
 input gradients are GEMMs over all steps at once in both paths.
 """
+import contextlib
 import os
 
 import torch
@@ -487,7 +488,6 @@ class TrieBiGRUFn(torch.autograd.Function):
         aux0 = _side_stream(dev) if l0_overlap else main
         if l0_overlap:
             aux0.wait_stream(main)
-        import contextlib
         for d, side in enumerate(sides):
           with torch.cuda.stream(aux0 if d == 1 else main):
             X, H, gates, Y, seed_e, seed_y, wi_t, wh_t = l0[d]
