@@ -7,6 +7,11 @@ is written straight into the next step's operand slot) and backward (gtos_gru_st
 cell backward + bias sums, one d4 = [dr|dz|dn_x|dn_h] buffer).  fp32 / other sizes: the input-gate products of ALL
 steps are one GEMM, each step one [active,h]x[h,3h] GEMM plus gtos_gru_cell_fwd / gtos_gru_cell_bwd.  Weight and
 input gradients are GEMMs over all steps at once in both paths.
+
+The production path (bf16, two layers) is TrieBiGRUFn at the end of this file: the same function evaluated on the prefix /
+suffix tries of the relation bank (gtos_amd/pathtrie.py) -- layer 0 once per trie node, layer 1 with per-node input-gate tables
+and a persistent step kernel, segmented-sum backward; BiGRUFinalFn (one row per path and position, like the reference's packed
+sequence) remains the fp32 parity path and the GTOS_GRU_TRIE=0 fallback.
 """
 import contextlib
 import os
