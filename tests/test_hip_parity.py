@@ -906,7 +906,7 @@ def _grads_of(m):
     return {k: p.grad.detach().float().cpu().clone() for k, p in m.named_parameters()}
 
 
-@pytest.mark.parametrize("case", ["amr", "random", "single"])
+@pytest.mark.parametrize("case", ["amr", "random", "single", "all_len1", "duplicates"])
 def test_trie_gru_equals_flat_gru_and_oracle(case, monkeypatch):
     """RelationEncoder in bf16: the trie evaluation (layer 0 per prefix / suffix node, layer-1 input gates from per-node
     tables, segmented-sum backward) against the per-row evaluation of the same module (GTOS_GRU_TRIE=0) and against the
@@ -922,6 +922,11 @@ def test_trie_gru_equals_flat_gru_and_oracle(case, monkeypatch):
         bank = torch.randint(1, 90, (8, 700), generator=g)
         for r in range(700):
             bank[int(length[r]):, r] = 0
+    elif case == "all_len1":    # one trie level only: no parents, no children
+        bank, length = torch.arange(1, 18).view(1, 17), torch.ones(17, dtype=torch.int64)
+    elif case == "duplicates":  # the module API does not forbid repeated paths: they share every node, rows stay distinct
+        base = torch.tensor([[5, 5, 9, 9, 9, 3], [6, 6, 2, 2, 2, 0], [7, 7, 0, 0, 0, 0]])
+        bank, length = base, torch.tensor([3, 3, 2, 2, 2, 1])
     else:
         bank, length = torch.tensor([[7]]), torch.tensor([1])
     ref, m = _relenc_pair(bank, length)
