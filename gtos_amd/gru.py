@@ -345,7 +345,7 @@ class TrieBiGRUFn(torch.autograd.Function):
         # ---- layer 0 on the tries (suffix side on the auxiliary stream, see TRIE_L0_OVERLAP)
         l0 = []
         main = torch.cuda.current_stream(dev)
-        aux = _side_stream(dev) if (TRIE_L0_OVERLAP and table.is_cuda and N >= 4096) else main
+        aux = _side_stream(dev) if (TRIE_L0_OVERLAP and table.is_cuda and N >= SIDE_MIN_ROWS) else main
         seeds = [(next_seed() if p_embed > 0 else 0, next_seed() if p_layer > 0 else 0) for _ in sides]
         if aux is not main:
             aux.wait_stream(main)
@@ -489,7 +489,7 @@ class TrieBiGRUFn(torch.autograd.Function):
             dtab = torch.zeros(table.shape, dtype=torch.float32, device=dev)
         # the two tries are independent: the suffix side runs on the auxiliary stream beside the prefix side (small launches per
         # level on both); with TRIE_SIDE the GEMMs go to the auxiliary stream instead and both sides stay on main
-        l0_overlap = TRIE_L0_OVERLAP and not use_side and N >= 4096
+        l0_overlap = TRIE_L0_OVERLAP and not use_side and N >= SIDE_MIN_ROWS     # small banks are launch-bound: no stream hand-overs
         aux0 = _side_stream(dev) if l0_overlap else main
         if l0_overlap:
             aux0.wait_stream(main)
