@@ -49,7 +49,9 @@ class SegmentBoundaryFn(torch.autograd.Function):
 
 class Trainer:
     def __init__(self, model, embed_dim, warmup_steps=2000, compute_dtype=torch.float32, world_size=1, rank=0,
-                 segment_of="auto", base_seed=19940117, overlap=True):
+                 segment_of="auto", base_seed=19940117, overlap=True, force_collectives=False):
+        """``force_collectives``: issue the gradient collectives even with world_size == 1 (an initialised process group of one
+        rank): the RCCL code path -- async all-reduce of bucket views from inside backward -- on a single GPU."""
         self.model = model
         self.embed_dim, self.warmup_steps = embed_dim, warmup_steps
         self.world_size, self.rank = world_size, rank
@@ -58,7 +60,8 @@ class Trainer:
             segment_of = generator_segment_of if any(n.startswith("graph_encoder.") for n in names) else None
         self.flat = FlatParams(model, mirror_dtype=compute_dtype, segment_of=segment_of)
         self.batches_acm, self.loss_acm, self.discarded = 0, 0.0, 0
-        self.overlap = overlap and world_size > 1 and len(self.flat.segments) > 1
+        self.collective = world_size > 1 or force_collectives
+        self.overlap = overlap and self.collective and len(self.flat.segments) > 1
         self._launched = 0              # segments [0, _launched) have their all-reduce in flight
         self._works = []
         self.comm_exposed_s = 0.0       # host time spent waiting for collectives after backward (gloo blocks here)
@@ -80,7 +83,7 @@ class Trainer:
         while self._launched <= seg and self._launched < len(self.flat.segments):
             lo, hi = self.flat.segments[self._launched]
             self._launched += 1
-            if hi > lo and self.world_size > 1:
+            if hi > lo and self.collective:
                 # async: enqueued on the process group's own stream after the work already on the current stream
                 self._works.append(dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
 
@@ -116,7 +119,7 @@ class Trainer:
         loss = self.model(batch)
         loss_value = loss.item()
         abnormal = self.batches_acm > self.warmup_steps and loss_value > 5. * (self.loss_acm / self.batches_acm)
-        if self.world_size > 1 and self.batches_acm > self.warmup_steps:
+        if self.collective and self.batches_acm > self.warmup_steps:
             flag = torch.tensor([1.0 if abnormal else 0.0], device=loss.device)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             abnormal = bool(flag.item() > 0)

@@ -1267,3 +1267,13 @@ def test_prefetcher_uploads_batches_on_a_copy_stream():
         assert batch["concept"].is_cuda and batch["relation_trie"].device.type == "cuda" and batch["relation_index"].device.type == "cuda"
         losses.append(float(m(batch).detach()))
     assert len(losses) == 3 and all(np.isfinite(l) for l in losses) and len(set(losses)) == 3
+
+
+def test_trainer_step_on_rccl_single_rank():
+    """tools/rccl_step_check.py in a subprocess: Trainer.step with its collectives forced on over a 1-rank "nccl" (RCCL) group."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_step_check.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl step check ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
