@@ -58,6 +58,7 @@ def parse():
                          "--cpu-steps 5 --cpu-budget 600, committed once per round under profiles/)")
     ap.add_argument("--cpu-steps", type=int, default=2, help="timed CPU steps of the full-step leg (after 1 warm-up; time-capped)")
     ap.add_argument("--cpu-budget", type=float, default=45.0, help="wall-clock cap of the CPU baseline in seconds")
+    ap.add_argument("--cpu-warmup", type=int, default=1, help="untimed CPU warm-up steps (SURVEY 8d: 2)")
     ap.add_argument("--decode", action="store_true",
                     help="secondary benchmark (SURVEY 8f rank 2): beam search over the K/V-cached decoder instead of the train step")
     ap.add_argument("--beam", type=int, default=8)
@@ -77,7 +78,7 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(cfg_name, graphs, steps, budget_s=75.0):
+def cpu_baseline(cfg_name, graphs, steps, budget_s=75.0, warmup=1):
     """Oracle (kind 'port': the CPU restatement pinned to the reference's golden vectors) on the host cores, fp32, on a
     micro-batch of `graphs` graphs of the same config: (i) the full training step, (ii) the graph encoder
     alone (RelationEncoder + GraphTransformer forward + backward).  1 warm-up + up to `steps` timed steps per leg, capped by
@@ -120,7 +121,7 @@ def cpu_baseline(cfg_name, graphs, steps, budget_s=75.0):
             p.grad = None
 
     def timed(fn, n_steps, budget, warm):
-        if warm:
+        for _ in range(warmup if warm else 0):
             fn(1)
         t0, k = time.time(), 0
         while k < n_steps and (k == 0 or time.time() - t0 < budget):
@@ -134,7 +135,7 @@ def cpu_baseline(cfg_name, graphs, steps, budget_s=75.0):
     dt_enc, k_enc = timed(encoder_step, max(1, steps // 2), budget_s * 0.2, False)
     return {"value": graphs / dt_full, "unit": "graphs/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
             "encoder_only": {"value": graphs / dt_enc, "unit": "graphs/s", "timed_steps": k_enc, "s_per_step": round(dt_enc, 2)},
-            "sample": "micro-batch of %d graphs of %s (n=%d, R=%d), fp32, all host cores, full train step (fwd+bwd+clip+Adam), 1 warm-up + %d timed "
+            "sample": "micro-batch of %d graphs of %s (n=%d, R=%d), fp32, all host cores, full train step (fwd+bwd+clip+Adam), " + str(warmup) + " warm-up + %d timed "
                       "steps, %.1f s/step; encoder-only leg (RelationEncoder + GraphTransformer fwd+bwd) %.1f s/step; %.0f s total" % (
                           graphs, cfg_name, stats["n"], stats["R"], k_full, dt_full, dt_enc, time.time() - t_all)}
 
@@ -451,7 +452,7 @@ def main():
                           "loss_first": losses[0], "loss_last": losses[-1]},
                "roofline": roofline, "components": components}
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.config, a.cpu_graphs, a.cpu_steps, a.cpu_budget)
+            out["cpu_baseline"] = cpu_baseline(a.config, a.cpu_graphs, a.cpu_steps, a.cpu_budget, a.cpu_warmup)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()                     # rank 0 may still be measuring its dense-signature leg
