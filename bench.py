@@ -135,9 +135,10 @@ def cpu_baseline(cfg_name, graphs, steps, budget_s=75.0, warmup=1):
     dt_enc, k_enc = timed(encoder_step, max(1, steps // 2), budget_s * 0.2, False)
     return {"value": graphs / dt_full, "unit": "graphs/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
             "encoder_only": {"value": graphs / dt_enc, "unit": "graphs/s", "timed_steps": k_enc, "s_per_step": round(dt_enc, 2)},
-            "sample": "micro-batch of %d graphs of %s (n=%d, R=%d), fp32, all host cores, full train step (fwd+bwd+clip+Adam), " + str(warmup) + " warm-up + %d timed "
-                      "steps, %.1f s/step; encoder-only leg (RelationEncoder + GraphTransformer fwd+bwd) %.1f s/step; %.0f s total" % (
-                          graphs, cfg_name, stats["n"], stats["R"], k_full, dt_full, dt_enc, time.time() - t_all)}
+            "sample": ("micro-batch of %d graphs of %s (n=%d, R=%d), fp32, all host cores, full train step (fwd+bwd+clip+Adam), "
+                       "%d warm-up + %d timed steps, %.1f s/step; encoder-only leg (RelationEncoder + GraphTransformer fwd+bwd) "
+                       "%.1f s/step; %.0f s total") % (
+                           graphs, cfg_name, stats["n"], stats["R"], warmup, k_full, dt_full, dt_enc, time.time() - t_all)}
 
 
 MFMA_PEAK_TFS = 2500.0

@@ -22,3 +22,15 @@ def test_bench_self_launches_two_ranks():
 def test_bench_rejects_mismatched_world_size():
     r = _run(["--gpus", "2", "--dry-launch"], env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_cpu_baseline_leg_runs_on_a_tiny_config(monkeypatch):
+    """bench.py's cpu_baseline leg end to end on the CPU (the oracle on a 2-graph C1 sample): the record carries every field
+    the bench line promises -- a formatting slip here would only show up on the GPU box otherwise."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rec = bench.cpu_baseline("C1", 2, 1, budget_s=5.0, warmup=1)
+    assert rec["kind"] == "port" and rec["unit"] == "graphs/s" and rec["value"] > 0 and rec["cores"] >= 1
+    assert rec["encoder_only"]["value"] > 0 and "1 warm-up + 1 timed steps" in rec["sample"] and isinstance(rec["cpu"], str)
