@@ -138,3 +138,74 @@ def test_relation_index_groups_pairs_by_type(B):
     assert xo[0] == 0 and xo[-1] == ix.nchunks and [sum(1 for k_ in keys if k_[0] == x) for x in range(8)] == [xo[x + 1] - xo[x] for x in range(8)]
     with pytest.raises(ValueError):
         build_relation_index(rel, R - 1)
+
+
+# ------------------------------------------------------------------------------------------------ the trie algebra, on the CPU
+def _trie_relation_encoder(ref, trie, double=True):
+    """The evaluation order of gtos_amd.gru.TrieBiGRUFn restated with plain torch ops on the oracle's parameters: layer 0 once
+    per prefix / suffix trie node, layer-1 input gates as Gf[prefix node] + Gb[suffix node], recurrences over the packed
+    rows, final states un-permuted, out_proj.  Independent of the HIP kernels: this is the identity the kernels implement."""
+    from oracle.gtos_oracle import gru_cell
+    import torch.nn.functional as F
+    P = lambda n, l, s="": getattr(ref.rnn, "%s_l%d%s" % (n, l, s))
+    hs = ref.hidden_size
+    sides = (trie.pf, trie.sf)
+    Y0 = []
+    for d, side in enumerate(sides):
+        suf = "_reverse" if d else ""
+        x = ref.rel_embed(side.tok)                                        # [nodes, rel_dim]
+        xg = F.linear(x, P("weight_ih", 0, suf), P("bias_ih", 0, suf))
+        H = torch.zeros(side.n_nodes + 1, hs, dtype=x.dtype)
+        for k in range(trie.L):
+            lo, hi = side.level_off[k], side.level_off[k + 1]
+            if hi > lo:
+                hnew = gru_cell(xg[lo:hi], H[side.par_long[lo:hi]], P("weight_hh", 0, suf), P("bias_hh", 0, suf))
+                H = torch.cat([H[:lo], hnew, H[hi:]])                      # functional update (autograd-friendly)
+        Y0.append(H[:side.n_nodes])
+    bs, offs = trie.batch_sizes, [0]
+    for a in bs:
+        offs.append(offs[-1] + a)
+    R = trie.R
+    fin = []
+    for d in (0, 1):
+        suf = "_reverse" if d else ""
+        w_ih = P("weight_ih", 1, suf)
+        Gf = F.linear(Y0[0], w_ih[:, :hs])                                  # per prefix node
+        Gb = F.linear(Y0[1], w_ih[:, hs:])                                  # per suffix node
+        xg = Gf[trie.row_pf.long()] + Gb[trie.row_sf.long()] + P("bias_ih", 1, suf)     # [N, 3h] packed rows
+        h = torch.zeros(R, hs, dtype=xg.dtype)
+        for t in (range(trie.L) if d == 0 else range(trie.L - 1, -1, -1)):
+            A, off = bs[t], offs[t]
+            hn = gru_cell(xg[off:off + A], h[:A], P("weight_hh", 1, suf), P("bias_hh", 1, suf))
+            h = torch.cat([hn, h[A:]])
+        fin.append(h)
+    fin = torch.cat(fin, 1)[trie.seq_pos]                                   # packed order -> bank order
+    return ref.out_proj(fin)
+
+
+@pytest.mark.parametrize("kind", ["amr", "random"])
+def test_trie_evaluation_is_the_same_function_as_the_reference_gru(kind):
+    """RelationEncoder (generator/encoder.py:66-119, via the pinned oracle) == the trie evaluation, outputs and every
+    parameter gradient, in fp64 on the CPU (dropout 0)."""
+    from oracle import gtos_oracle as O
+    if kind == "amr":
+        from gtos_amd import synth
+        batch, _ = synth.make_batch(5, 4, 14, 6)
+        bank, length = batch["relation_bank"], batch["relation_length"]
+        V = 90
+    else:
+        seqs, bank, length = _random_bank(11, 120, 7, 9)
+        V = 12
+    torch.manual_seed(3)
+    ref = O.RelationEncoder(O.VocabSpec(V, 0), 10, 24, 16, 2, 0.0).double()
+    trie = build_path_trie(bank, length, chunk=8)
+    want = ref(bank, length)
+    wout = torch.randn_like(want)
+    (want * wout).sum().backward()
+    g_want = {k: p.grad.clone() for k, p in ref.named_parameters()}
+    ref.zero_grad()
+    got = _trie_relation_encoder(ref, trie)
+    torch.testing.assert_close(got, want, rtol=1e-10, atol=1e-12)
+    (got * wout).sum().backward()
+    for k, p in ref.named_parameters():
+        torch.testing.assert_close(p.grad, g_want[k], rtol=1e-8, atol=1e-11, msg=lambda m, k=k: "%s: %s" % (k, m))
