@@ -197,7 +197,6 @@ class Prefetcher(object):
     to wait for that copy when it takes the batch.  Order of the batches is the iterable's order."""
 
     def __init__(self, batches, depth=2, workers=1, device=None):
-        import queue
         import threading
         self._it = iter(batches)
         self._lock = threading.Lock()
