@@ -209,3 +209,44 @@ def test_trie_evaluation_is_the_same_function_as_the_reference_gru(kind):
     (got * wout).sum().backward()
     for k, p in ref.named_parameters():
         torch.testing.assert_close(p.grad, g_want[k], rtol=1e-8, atol=1e-11, msg=lambda m, k=k: "%s: %s" % (k, m))
+
+
+# ------------------------------------------------------------------------------------------------ property-based (hypothesis)
+def test_pathtrie_and_relation_index_invariants_property_based():
+    from hypothesis import given, settings, strategies as st
+    from gtos_amd.relindex import build_relation_index
+
+    seqs_st = st.lists(st.lists(st.integers(1, 6), min_size=1, max_size=5).map(tuple), min_size=1, max_size=40, unique=True)
+
+    @settings(max_examples=40, deadline=None)
+    @given(seqs_st, st.integers(1, 5))
+    def check_trie(seqs, chunk):
+        Lm = max(len(s) for s in seqs)
+        bank = torch.zeros(Lm, len(seqs), dtype=torch.int64)
+        for r, s in enumerate(seqs):
+            bank[:len(s), r] = torch.tensor(s)
+        _check(list(seqs), build_path_trie(bank, torch.tensor([len(s) for s in seqs]), chunk=chunk), chunk=chunk)
+
+    @settings(max_examples=40, deadline=None)
+    @given(st.integers(1, 5), st.integers(1, 9), st.integers(1, 12), st.integers(0, 10 ** 6), st.integers(1, 4))
+    def check_index(n, B, R, seed, chunk):
+        g = torch.Generator().manual_seed(seed)
+        rel = torch.randint(0, R, (n, n, B), generator=g)
+        ix = build_relation_index(rel, R, chunk=chunk)
+        flat = rel.reshape(-1)
+        occ = torch.bincount(flat, minlength=R)
+        assert torch.equal(ix.idx_q.long() & 0x7fffffff, rel.permute(1, 2, 0)) and torch.equal(ix.idx_q < 0, (occ[rel] == 1).permute(1, 2, 0))
+        ps = ix.pair_sorted.long()
+        got = {}
+        for c in range(ix.nchunks):
+            t, s, k = int(ix.chunk_type[c]), int(ix.chunk_start[c]), int(ix.chunk_count[c])
+            assert k <= (4 * chunk if int(occ[t]) > chunk else chunk)
+            got.setdefault(t, []).extend(ps[s:s + k].tolist())
+            assert (int(ix.chunk_slot[c]) >= 0) == (int(occ[t]) > chunk)
+        assert set(got) == {t for t in range(R) if int(occ[t]) != 1}
+        for t, pairs in got.items():
+            assert sorted(pairs) == torch.nonzero(flat == t).flatten().tolist()
+        assert int(ix.xcd_off[-1]) == ix.nchunks
+
+    check_trie()
+    check_index()
