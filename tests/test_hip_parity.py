@@ -55,7 +55,7 @@ def test_gemm(dtype, ta, tb, M, N, K):
     torch.testing.assert_close(acc, ref + 1, **tol)
 
 
-@pytest.mark.parametrize("M,N,K", [(40003, 2056, 1096), (262144, 256, 1024), (70000, 1024, 2048)])
+@pytest.mark.parametrize("M,N,K", [(40003, 2056, 1096), (262144, 256, 1024), (70000, 1024, 2048), (70000, 1024, 2056)])
 def test_gemm_256_macro_tile(M, N, K):
     """Shapes that take the 256x256 NT kernel (bf16 in/out, >= 1024 macro tiles): ragged M/N/K tails, fused bias+ReLU,
     bf16 accumulate; against fp32 matmul of the same bf16 operands."""
@@ -74,6 +74,34 @@ def test_gemm_256_macro_tile(M, N, K):
     out = base.clone()
     ops.gemm(a, b, trans_b=True, out=out, accumulate=True)
     torch.testing.assert_close(out.float(), want + base.float(), rtol=3e-2, atol=0.02 * K ** 0.5)
+
+
+@pytest.mark.parametrize("M,N,K", [(140037, 1000, 1056), (66000, 520, 1024), (70003, 264, 1088), (66000, 512, 1120), (70000, 1024, 4096)])
+def test_gemm_pipelined_256_tile(M, N, K):
+    """Forward-shaped products with K % 32 == 0, K >= 1024, N <= 2048 and >= 512 macro tiles take the ping-pong 256x256 NT
+    kernel (four 32-k LDS stages, explicit wait counts): every remainder of the 4-step unrolled loop (K/32 = 32, 33, 34,
+    35, 128), ragged M / N tails (rows past the end are re-read, never stored), strided A, fused bias + ReLU, bf16
+    accumulate; against fp32 matmul of the same bf16 operands."""
+    from gtos_amd import ops
+    torch.manual_seed(M % 89)
+    wide = (torch.randn(M, K + 64, device=dev()) * 0.5).to(torch.bfloat16)
+    a = wide[:, 64:]                                        # row stride K + 64
+    b = (torch.randn(N, K, device=dev()) * 0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device=dev())
+    want = a.float() @ b.float().t()
+    tol = dict(rtol=2e-2, atol=0.01 * K ** 0.5)
+    got = ops.gemm(a, b, trans_b=True)
+    torch.testing.assert_close(got.float(), want, **tol)
+    got = ops.gemm(a.contiguous(), b, trans_b=True, bias=bias, relu=True)
+    torch.testing.assert_close(got.float(), torch.relu(want + bias), **tol)
+    base = torch.randn(M, N, device=dev()).to(torch.bfloat16)
+    out = base.clone()
+    ops.gemm(a, b, trans_b=True, out=out, accumulate=True)
+    torch.testing.assert_close(out.float(), want + base.float(), rtol=3e-2, atol=0.02 * K ** 0.5)
+    # deterministic dropout epilogue: the same mask as the 128x128 kernel's (a function of seed and element index)
+    small = ops.gemm(a[:300], b, trans_b=True, p_drop=0.3, seed=77)
+    big = ops.gemm(a, b, trans_b=True, p_drop=0.3, seed=77)
+    assert torch.equal(small == 0, big[:300] == 0)
 
 
 @pytest.mark.parametrize("M,N,K,sk", [(768, 512, 300040, 43), (256, 256, 100000, 64), (1024, 512, 6464, 12), (512, 264, 70008, 16)])

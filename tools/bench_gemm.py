@@ -29,6 +29,16 @@ SHAPES = [  # name, ta, tb, M, N, K, out dtype
     ("tn_m768_Ksml  TN", True, False, 768, 512, 434624, torch.float32),
     ("deepK       NT", False, True, 434624, 1024, 4096, torch.bfloat16),     # same tile count as rel_proj, 8x the k tiles
     ("square8k    NT", False, True, 8192, 8192, 8192, torch.bfloat16),
+    # t(K) at the relation-projection shape: intercept = output write + launch, slope = k-loop rate
+    ("ksweep32    NT", False, True, 434624, 1024, 32, torch.bfloat16),
+    ("ksweep128   NT", False, True, 434624, 1024, 128, torch.bfloat16),
+    ("ksweep256   NT", False, True, 434624, 1024, 256, torch.bfloat16),
+    ("ksweep1024  NT", False, True, 434624, 1024, 1024, torch.bfloat16),
+    ("ksweep2016  NT", False, True, 434624, 1024, 2016, torch.bfloat16),
+    # the same 0.89 GB of output with narrower rows: a 128-wide tile writes whole rows at N = 128
+    ("ksweep32n128 NT", False, True, 434624 * 8, 128, 32, torch.bfloat16),
+    ("ksweep32n256 NT", False, True, 434624 * 4, 256, 32, torch.bfloat16),
+    ("ksweep32n4096 NT", False, True, 434624 // 4, 4096, 32, torch.bfloat16),
 ]
 
 
