@@ -654,6 +654,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_nt_kernel(GemmArgs a) {
 constexpr int ROW3 = 64, A3 = BM2 * ROW3, ST3 = (BM2 + BN2) * ROW3;
 const int g_min_k256 = getenv("GTOS_GEMM256_MINK") ? atoi(getenv("GTOS_GEMM256_MINK")) : 2048;   // A/B switch (tools/bench_gemm.py)
 const bool g_use_pipe = !(getenv("GTOS_GEMM_PIPE") && getenv("GTOS_GEMM_PIPE")[0] == '0');
+const bool g_use_pipe_tn = !(getenv("GTOS_GEMM_PIPE_TN") && getenv("GTOS_GEMM_PIPE_TN")[0] == '0');
 const int g_max_npipe = getenv("GTOS_GEMM_PIPE_MAXN") ? atoi(getenv("GTOS_GEMM_PIPE_MAXN")) : 2048;
 const int g_min_kpipe = getenv("GTOS_GEMM_PIPE_MINK") ? atoi(getenv("GTOS_GEMM_PIPE_MINK")) : 1024;
 
@@ -816,6 +817,141 @@ int launch256p(const GemmArgs& a, hipStream_t s) {
     return 0;
 }
 
+// ---- gemm256p_tn_kernel: the weight-gradient shape dW = A^T B (A [K, M], B [K, N] row-major, K in the hundreds of
+//      thousands, split-K into the fp32 partial-tile workspace) on the same 256x256 tile, four 32-k stages and ping-pong
+//      schedule as gemm256p_nt_kernel.  A 256x256 tile re-reads each operand row from L2 half as often as the 128x128
+//      tile (these products stream both operands from HBM once and are bound by the L2 -> LDS amplification).
+//      A stage holds [32 k][256 m] + [32 k][256 n] (512-byte k-rows); MFMA fragments (8 consecutive k of one column) come
+//      from ds_read_b64_tr_b16 as in gemm_kernel's transpose path: 32-byte granules XOR-swizzled with (k & 3), applied
+//      on the DMA's source address.  Rows k >= kend read a block of zeros; columns past M / N re-read the last 8 valid
+//      ones (never stored); stages past the end of the split re-read its last stage (never multiplied).
+__global__ __launch_bounds__(512) void gemm256p_tn_kernel(GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) char st0[ST3];
+    __shared__ __attribute__((aligned(16))) char st1[ST3];
+    __shared__ __attribute__((aligned(16))) char st2[ST3];
+    __shared__ __attribute__((aligned(16))) char st3[ST3];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
+    const int nN = (a.N + BN2 - 1) / BN2, nM = (a.M + BM2 - 1) / BM2, tiles = nM * nN;
+    const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
+    const int bz = (sq / tiles) * 8 + xcd, t_ = sq % tiles;        // all tiles of one K split on one XCD
+    if (bz >= a.splitk) return;
+    const int m0 = (t_ / nN) * BM2, n0 = (t_ % nN) * BN2;
+    const int ktiles = (a.K + 63) / 64, tps = (ktiles + a.splitk - 1) / a.splitk;   // the split boundaries of gemm_kernel
+    const int kbeg = bz * tps * 64, kend = min(a.K, kbeg + tps * 64);
+    if (kbeg >= kend) return;
+    const int nk = (kend - kbeg + 31) / 32;
+    const char* Z = static_cast<const char*>(a.zeros);
+    // DMA: a wave instruction fills 1 KB = 2 k-rows x 512 B; lane l -> k-row l >> 5, physical 16-byte piece l & 31.
+    // Wave w owns blocks w and w + 8 of each operand: k-rows 2w, 2w+1 and 2w+16, 2w+17 (k & 3 the same for both).
+    const int kr = lane >> 5, pp = lane & 31;
+    const int kl0 = 2 * wave + kr, kq_d = kl0 & 3;
+    const int lp = ((((pp >> 1) ^ kq_d)) << 1) | (pp & 1);        // logical piece (8 columns) stored at this physical slot
+    const int acol = min(m0 + lp * 8, a.M - 8), bcol = min(n0 + lp * 8, a.N - 8);
+    // running per-lane source pointers of the NEXT stage to fetch (k-row kcur and kcur + 16 of each operand); rows at or
+    // past kend -- also every row of the dummy stages after the split's last one -- read the block of zeros instead
+    const char* pa = reinterpret_cast<const char*>(static_cast<const bf16_t*>(a.A) + (int64_t)(kbeg + kl0) * a.lda + acol);
+    const char* pb = reinterpret_cast<const char*>(static_cast<const bf16_t*>(a.B) + (int64_t)(kbeg + kl0) * a.ldb + bcol);
+    const int64_t a16 = 32 * a.lda, b16 = 32 * a.ldb;      // bytes: 16 k-rows
+    int kcur = kbeg + kl0;
+    // fragment reads (tr_fragment of gemm_kernel with 512-byte k-rows): lane addresses k-row fq*8 + (fr >> 2) (+4), the
+    // 32-byte granule (column / 16) ^ (fr >> 2), piece fr & 3; column offsets are multiples of 64 elements + t*16
+    const int kq = fr >> 2;
+    const int fbase = (fq * 8 + kq) * 512 + (fr & 3) * 8;
+
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    bf16x8_t fa[8], fb[4];
+
+#define GTOS_DMA1(src, dst)                                                                                                   \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),                                    \
+                                     (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+#define GTOS_DMA4(stage)                                                                                                      \
+    {                                                                                                                         \
+        const bool ok0 = kcur < kend, ok1 = kcur + 16 < kend;                                                                 \
+        GTOS_DMA1(ok0 ? pa : Z, (stage) + wave * 1024);                                                                       \
+        GTOS_DMA1(ok1 ? pa + a16 : Z, (stage) + (8 + wave) * 1024);                                                           \
+        GTOS_DMA1(ok0 ? pb : Z, (stage) + A3 + wave * 1024);                                                                  \
+        GTOS_DMA1(ok1 ? pb + b16 : Z, (stage) + A3 + (8 + wave) * 1024);                                                      \
+        kcur += 32; pa += 2 * a16; pb += 2 * b16;                                                                             \
+    }
+#define GTOS_TRF(tile, c0)                                                                                                    \
+    ([&]() -> bf16x8_t {                                                                                                      \
+        const char* p0 = (tile) + fbase + ((((c0) >> 4) ^ kq) << 5);                                                          \
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p0));         \
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p0 + 4 * 512)); \
+        const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};                                           \
+        return __builtin_bit_cast(bf16x8_t, v);                                                                               \
+    }())
+#define GTOS_STEP(slot_s, slot_d, s_)                                                                                         \
+    {                                                                                                                         \
+        GTOS_DMA4(slot_d);                                                                                                  \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) fb[t] = GTOS_TRF((slot_s) + A3, wn + t * 16);                           \
+        _Pragma("unroll") for (int t = 0; t < 8; ++t) fa[t] = GTOS_TRF((slot_s), wm + t * 16);                                \
+        __builtin_amdgcn_s_waitcnt(0x0078);                /* vmcnt(8) lgkmcnt(0): fragments here, own pieces of s_+1 landed */ \
+        __builtin_amdgcn_s_barrier();                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                                    \
+        _Pragma("unroll") for (int mt = 0; mt < 8; ++mt)                                                                      \
+            _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                                  \
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                                    \
+        __builtin_amdgcn_s_barrier();                                                                                         \
+    }
+
+    GTOS_DMA4(st0);
+    GTOS_DMA4(st1);
+    GTOS_DMA4(st2);
+    GTOS_VMCNT(8);
+    __builtin_amdgcn_s_barrier();
+    if (wave >= 4) __builtin_amdgcn_s_barrier();           // the second wave of every SIMD starts one segment late
+    int s = 0;
+    for (; s + 4 <= nk; s += 4) {
+        GTOS_STEP(st0, st3, s);
+        GTOS_STEP(st1, st0, s + 1);
+        GTOS_STEP(st2, st1, s + 2);
+        GTOS_STEP(st3, st2, s + 3);
+    }
+    if (s < nk) {
+        GTOS_STEP(st0, st3, s);
+        if (s + 1 < nk) {
+            GTOS_STEP(st1, st0, s + 1);
+            if (s + 2 < nk) GTOS_STEP(st2, st1, s + 2);
+        }
+    }
+    if (wave < 4) __builtin_amdgcn_s_barrier();            // same number of barriers for both halves
+#undef GTOS_STEP
+#undef GTOS_TRF
+#undef GTOS_DMA4
+#undef GTOS_DMA1
+
+    // ---- this split's partial tile -> workspace (N % 4 == 0: plain 16-byte stores), reduced by splitk_reduce_kernel
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+        const int m = m0 + wm + mt * 16 + fr;
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n = n0 + wn + nt * 16 + fq * 4;
+            if (n >= a.N) continue;
+            *reinterpret_cast<float4*>(a.ws + ((int64_t)bz * a.M + m) * a.N + n) =
+                make_float4(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]);
+        }
+    }
+}
+
+int launch256p_tn(const GemmArgs& a, hipStream_t s) {
+    const long long tiles = ((long long)(a.M + BM2 - 1) / BM2) * ((a.N + BN2 - 1) / BN2);
+    const long long nblk = tiles * 8 * ((a.splitk + 7) / 8);
+    if (nblk > 0x7fffffffLL) return -6;
+    hipLaunchKernelGGL(gemm256p_tn_kernel, dim3((unsigned)nblk), dim3(512), 0, s, a);
+    GTOS_CHECK_LAUNCH();
+    return 0;
+}
+
 int launch256(const GemmArgs& a, hipStream_t s) {
     static bool configured = false;
     if (!configured) {
@@ -886,7 +1022,12 @@ extern "C" int gtos_gemm(int in_dtype, int out_dtype, int transA, int transB, in
     if (splitk > 1 && workspace && N % 4 == 0 && (uintptr_t)workspace % 16 == 0 && (uintptr_t)C % 4 == 0 &&
         (int64_t)splitk * M * N * 4 <= workspace_bytes) {
         a.ws = static_cast<float*>(workspace);
-        int rc = in_dtype == GTOS_BF16 ? launch<bf16_t, float>(a, transA, transB, s) : launch<float, float>(a, transA, transB, s);
+        // long-K weight gradients with at least one full 256x256 tile: the four-stage ping-pong kernel
+        const int kps = ((ktiles + splitk - 1) / splitk) * BKc;            // k per split
+        const bool tn256 = g_use_pipe_tn && in_dtype == GTOS_BF16 && transA && !transB && a.vecA && a.vecB && M >= 256 && N >= 256 &&
+                           M % 8 == 0 && N % 8 == 0 && kps >= 256;
+        int rc = tn256 ? launch256p_tn(a, s)
+                       : (in_dtype == GTOS_BF16 ? launch<bf16_t, float>(a, transA, transB, s) : launch<float, float>(a, transA, transB, s));
         if (rc) return rc;
         const int64_t total = (int64_t)M * (N / 4);
         const int nb = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
