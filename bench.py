@@ -259,7 +259,8 @@ def build_roofline(a, cfg, stats, model, trainer, batch, prof, dev, cd, detail=T
             grows.append((ms, lay, nn, kk, dts, sk, len(evs), long_sum))
         for ms, lay, nn, kk, dts, sk, calls, long_sum in sorted(grows, reverse=True)[:4]:
             fl = 2.0 * long_sum * nn * kk
-            rows.append({"kernel": "gemm_kernel %s N=%d %s=%d %s splitk=%d" % (lay, nn, "M" if lay[0] == "T" else "K", kk, dts, sk),
+            rows.append({"kernel": "%s %s N=%d %s=%d %s splitk=%d" % (_gemm_kernel_name(lay, nn, kk, sk, long_sum // calls), lay, nn,
+                                                                   "M" if lay[0] == "T" else "K", kk, dts, sk),
                          "bound": "mfma", "launches_per_step": calls // 2, "avg_us": round(ms * 1e3 / calls, 1),
                          "flops_per_launch": int(fl / calls), "achieved": round(fl / ms / 1e9, 1), "unit": "TFLOP/s",
                          "peak": MFMA_PEAK_TFS, "frac": round(fl / ms / 1e9 / MFMA_PEAK_TFS, 4), "ms_per_step": round(ms / 2, 2)})
@@ -269,6 +270,20 @@ def build_roofline(a, cfg, stats, model, trainer, batch, prof, dev, cd, detail=T
                             "(events and serialisation slow the step, so none of this happens inside the timed region); bytes are "
                             "algorithmic, per launch; GEMM rows: the four shapes with the largest time share")
     return roof
+
+
+def _gemm_kernel_name(lay, nn, kk, sk, long_dim):
+    """Which kernel gtos_gemm's dispatcher (csrc/gemm.hip) picks for a bf16 product of this shape; for NT `long_dim` is M
+    and kk is K, for TN kk is M and `long_dim` is K."""
+    if lay == "NT":
+        tiles256 = -(-long_dim // 256) * -(-nn // 256)
+        if tiles256 >= 512 and 256 <= nn <= 2048 and kk >= 1024 and kk % 32 == 0:
+            return "gemm256p_nt_kernel"
+        if tiles256 >= 1024 and nn >= 256 and kk >= 2048:
+            return "gemm256_nt_kernel"
+    if lay == "TN" and sk > 1 and nn >= 256 and kk >= 256 and long_dim // sk >= 256:
+        return "gemm256p_tn_kernel"
+    return "gemm_kernel"
 
 
 def decode_bench(a):

@@ -33,6 +33,7 @@ SHAPES = [  # name, ta, tb, M, N, K, out dtype
     ("ksweep32    NT", False, True, 434624, 1024, 32, torch.bfloat16),
     ("ksweep128   NT", False, True, 434624, 1024, 128, torch.bfloat16),
     ("ksweep256   NT", False, True, 434624, 1024, 256, torch.bfloat16),
+    ("ksweep512   NT", False, True, 434624, 1024, 512, torch.bfloat16),
     ("ksweep1024  NT", False, True, 434624, 1024, 1024, torch.bfloat16),
     ("ksweep2016  NT", False, True, 434624, 1024, 2016, torch.bfloat16),
     # the same 0.89 GB of output with narrower rows: a 128-wide tile writes whole rows at N = 128
