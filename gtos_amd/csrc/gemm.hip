@@ -320,12 +320,64 @@ __global__ __launch_bounds__(NTH, 4) void gemm_kernel(GemmArgs a) {
     if constexpr (STAGES == 1) {
         // both operands by global_load_lds into the single stage; the other resident workgroups cover the wait
         static_assert(!(STAGES == 1) || (GA && GB), "single-stage variant needs both operands by DMA");
+        if constexpr (!TRA && !TRB) {
+            // Forward shape (both operands K-contiguous): the per-lane part of every DMA source address is computed ONCE
+            // (counters: the generic helpers spend ~180 VALU instructions per k tile and wave on it, more issue cycles than
+            // the tile's 32 MFMAs).  Source = uniform tile base + k0 + 32-bit lane offset; rows past the end re-read the
+            // last valid row (their products land in rows / columns that are never stored); only a partial last k tile
+            // selects the block of zeros per lane.
+            const char* Ab = reinterpret_cast<const char*>(A + (int64_t)m0 * a.lda);
+            const char* Bb = reinterpret_cast<const char*>(B + (int64_t)n0 * a.ldb);
+            const int amax = a.M - 1 - m0, bmax = a.N - 1 - n0;
+            const uint32_t lda2 = (uint32_t)a.lda * (uint32_t)sizeof(T), ldb2 = (uint32_t)a.ldb * (uint32_t)sizeof(T);
+            const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+            uint32_t offA[ITERS], offB[ITERS];
+            int cc[ITERS];
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int rl = (it * (NT / 64) + wv) * 8 + (lane >> 3);
+                cc[it] = (lane & 7) ^ swz(rl);
+                offA[it] = (uint32_t)min(rl, amax) * lda2 + (uint32_t)(cc[it] << 4);
+                offB[it] = (uint32_t)min(rl, bmax) * ldb2 + (uint32_t)(cc[it] << 4);
+            }
+            constexpr int VEC = GemmCfg<T>::VEC;
+            for (int k0 = kbeg; k0 < kend; k0 += BK) {
+                const char* ak = Ab + (int64_t)k0 * (int)sizeof(T);
+                const char* bk = Bb + (int64_t)k0 * (int)sizeof(T);
+                if (k0 + BK <= kend) {
+#pragma unroll
+                    for (int it = 0; it < ITERS; ++it) {
+                        const int blk = it * (NT / 64) + wv;
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ak + offA[it]),
+                                                         (__attribute__((address_space(3))) void*)(lds + blk * 1024), 16, 0, 0);
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bk + offB[it]),
+                                                         (__attribute__((address_space(3))) void*)(lds + BM * ROWB + blk * 1024), 16, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int it = 0; it < ITERS; ++it) {
+                        const int blk = it * (NT / 64) + wv;
+                        const bool ok = k0 + cc[it] * VEC + VEC <= kend;
+                        const void* sa = ok ? static_cast<const void*>(ak + offA[it]) : static_cast<const void*>(Z);
+                        const void* sb = ok ? static_cast<const void*>(bk + offB[it]) : static_cast<const void*>(Z);
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sa,
+                                                         (__attribute__((address_space(3))) void*)(lds + blk * 1024), 16, 0, 0);
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sb,
+                                                         (__attribute__((address_space(3))) void*)(lds + BM * ROWB + blk * 1024), 16, 0, 0);
+                    }
+                }
+                __syncthreads();                           // hipcc drains the DMA (vmcnt(0)) in front of the barrier
+                mma_stage(lds, lds + BM * ROWB);
+                __syncthreads();                           // every wave is done reading before the next tile lands
+            }
+        } else {
         for (int k0 = kbeg; k0 < kend; k0 += BK) {
             dma_a(k0, lds);
             dma_b(k0, lds + BM * ROWB);
             __syncthreads();                               // hipcc drains the DMA (vmcnt(0)) in front of the barrier
             mma_stage(lds, lds + BM * ROWB);
             __syncthreads();                               // every wave is done reading before the next tile lands
+        }
         }
     } else {
     // K-contiguous operands on the fast path go global -> LDS directly (prefetch distance 1: the barrier drains the
@@ -386,7 +438,35 @@ __global__ __launch_bounds__(NTH, 4) void gemm_kernel(GemmArgs a) {
             constexpr int CP = WTN * 2 + 16;                           // bytes per staged row (WTN bf16 + pad)
             constexpr int LPR = WTN / 8, RPP = 64 / LPR;               // lanes per row, rows per pass
             char* cs = lds + wave * 32 * CP;                           // private to the wave; 32 rows at a time so that
-#pragma unroll                                                         // 4 waves x 32 x 144 B fit the one-stage 32 KB
+            //                                                            4 waves x 32 x 144 B fit the one-stage 32 KB
+            if (!a.bias && !a.relu && !(a.p_drop > 0.f) && !a.accumulate && m0 + BM <= a.M && n0 + BN <= a.N) {
+                // interior tile of a plain product (the relation projections): no per-element conditions, addresses
+                // computed once, wave-level ordering only (the staging rows are private to the wave)
+                const int rrow = lane / LPR, rcol = (lane % LPR) * 8;
+                char* wr = cs + fr * CP + fq * 8;
+                const char* rd = cs + rrow * CP + rcol * 2;
+                bf16_t* cp0 = reinterpret_cast<bf16_t*>(C) + (int64_t)(m0 + wm + rrow) * a.ldc + n0 + wn + rcol;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                        for (int nt = 0; nt < NTW; ++nt) {
+                            const f32x4_t v = acc[half * 2 + mh][nt];
+                            *reinterpret_cast<uint2*>(wr + mh * 16 * CP + nt * 32) = make_uint2(pack_bf(v[0], v[1]), pack_bf(v[2], v[3]));
+                        }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0)
+#pragma unroll
+                    for (int pass = 0; pass < 32 / RPP; ++pass) {
+                        const uint4 val = *reinterpret_cast<const uint4*>(rd + pass * RPP * CP);
+                        *reinterpret_cast<uint4*>(cp0 + (int64_t)(half * 32 + pass * RPP) * a.ldc) = val;
+                    }
+                    __builtin_amdgcn_s_waitcnt(0xc07f);                // read back before the next half overwrites the rows
+                }
+                return;
+            }
+#pragma unroll
             for (int half = 0; half < 2; ++half) {
                 if (half) __syncthreads();                             // the first half has been read back
 #pragma unroll
