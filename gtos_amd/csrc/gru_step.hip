@@ -75,6 +75,58 @@ __device__ __forceinline__ void dma_weights(const bf16_t* __restrict__ w, const 
     }
 }
 
+// The same two loaders with the per-lane part of the source addresses computed ONCE per operand instead of once per k
+// tile (row index -- through the gather table when there is one: that was a dependent global load in front of every
+// DMA --, swizzled chunk, bounds): per k tile only the k bound of a partial last tile is left.
+struct RowSrc { const char* p[TM / 32]; int c[TM / 32]; };
+__device__ __forceinline__ RowSrc row_src(const bf16_t* __restrict__ base, int64_t ld, int rows_total, int row0, int wave, int lane,
+                                          const int* __restrict__ gather = nullptr) {
+    RowSrc s;
+#pragma unroll
+    for (int it = 0; it < TM / 32; ++it) {
+        const int rl = (it * 4 + wave) * 8 + (lane >> 3);
+        const int r = row0 + rl;
+        s.c[it] = (lane & 7) ^ swz(rl);
+        const bool ok = r < rows_total;
+        const int64_t sr = (gather && ok) ? gather[r] : r;
+        s.p[it] = ok ? reinterpret_cast<const char*>(base + sr * ld + s.c[it] * 8) : nullptr;      // null: rows past the end
+    }
+    return s;
+}
+__device__ __forceinline__ void dma_rows_at(const RowSrc& s, const U128* __restrict__ zeros, int k0, int kend, char* tile, int wave) {
+#pragma unroll
+    for (int it = 0; it < TM / 32; ++it) {
+        const bool ok = s.p[it] != nullptr && k0 + s.c[it] * 8 + 8 <= kend;
+        const void* src = ok ? static_cast<const void*>(s.p[it] + (int64_t)k0 * 2) : static_cast<const void*>(zeros);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(tile + (it * 4 + wave) * 1024), 16, 0, 0);
+    }
+}
+struct WSrc { uint32_t off[WROWS / 32]; int c[WROWS / 32]; };
+__device__ __forceinline__ WSrc w_src(int64_t ld, int hs, int c0, int wave, int lane) {
+    WSrc s;
+#pragma unroll
+    for (int it = 0; it < WROWS / 32; ++it) {
+        const int rl = (it * 4 + wave) * 8 + (lane >> 3);
+        const int g = rl >> 6, nt = (rl >> 4) & 3, q = (rl >> 2) & 3, e = rl & 3;
+        const int wrow = g * hs + c0 + q * 16 + nt * 4 + e;
+        s.c[it] = (lane & 7) ^ swz(rl);
+        s.off[it] = (uint32_t)(wrow * (int)ld + s.c[it] * 8) * 2u;        // weights are a few hundred KB: 32-bit byte offsets
+    }
+    return s;
+}
+__device__ __forceinline__ void dma_weights_at(const WSrc& s, const bf16_t* __restrict__ w, const U128* __restrict__ zeros, int k0, int kend,
+                                               char* tile, int wave) {
+    const char* wk = reinterpret_cast<const char*>(w) + (int64_t)k0 * 2;
+#pragma unroll
+    for (int it = 0; it < WROWS / 32; ++it) {
+        const bool ok = k0 + s.c[it] * 8 + 8 <= kend;
+        const void* src = ok ? static_cast<const void*>(wk + s.off[it]) : static_cast<const void*>(zeros);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(tile + (it * 4 + wave) * 1024), 16, 0, 0);
+    }
+}
+
 // one 64-deep k tile: weight group g (0 r, 1 z, 2 n) accumulates into accumulator group (g < 2 ? g : G2)
 template <int NG, int G2>
 __device__ __forceinline__ void mma_tile(const char* As, const char* Bs, int wrow0, int fr, int fq, f32x4_t (&acc)[2][NG * 4]) {
@@ -140,20 +192,26 @@ __global__ __launch_bounds__(256, 2) void gru_step_fwd_kernel(StepArgs a) {
         for (int j = 0; j < NG * 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     if constexpr (HAS_X) {
+        const RowSrc xs = row_src(a.x, a.ldx, a.rows, m0, wave, lane);
+        const WSrc ws = w_src(a.in_dim, a.hs, c0, wave, lane);
         for (int k0 = 0; k0 < a.in_dim; k0 += BK) {
-            dma_rows(a.x, Z, a.ldx, a.rows, m0, k0, a.in_dim, As, wave, lane);
-            dma_weights(a.w_ih, Z, a.in_dim, a.hs, c0, k0, a.in_dim, Bs, wave, lane);
+            dma_rows_at(xs, Z, k0, a.in_dim, As, wave);
+            dma_weights_at(ws, a.w_ih, Z, k0, a.in_dim, Bs, wave);
             __syncthreads();
             mma_tile<NG, 2>(As, Bs, wave * 32, fr, fq, acc);
             __syncthreads();
         }
     }
-    for (int k0 = 0; k0 < a.hs; k0 += BK) {
-        dma_rows(a.h_in, Z, a.hs, a.rows, m0, k0, a.hs, As, wave, lane, a.h_idx);
-        dma_weights(a.w_hh, Z, a.hs, a.hs, c0, k0, a.hs, Bs, wave, lane);
-        __syncthreads();
-        mma_tile<NG, GH>(As, Bs, wave * 32, fr, fq, acc);
-        __syncthreads();
+    {
+        const RowSrc hsrc = row_src(a.h_in, a.hs, a.rows, m0, wave, lane, a.h_idx);
+        const WSrc ws = w_src(a.hs, a.hs, c0, wave, lane);
+        for (int k0 = 0; k0 < a.hs; k0 += BK) {
+            dma_rows_at(hsrc, Z, k0, a.hs, As, wave);
+            dma_weights_at(ws, a.w_hh, Z, k0, a.hs, Bs, wave);
+            __syncthreads();
+            mma_tile<NG, GH>(As, Bs, wave * 32, fr, fq, acc);
+            __syncthreads();
+        }
     }
 
     // ---- cell: lane (fr, fq) holds rows m0 + wave*32 + mt*16 + fr, channels cb .. cb+15 (index nt*4 + e)
