@@ -33,6 +33,9 @@ int gtos_abi_version(void);
  * (needs out_dtype F32, accumulate=1, no bias/relu/dropout): with a workspace of >= splitk*M*N*4 bytes (16-byte
  * aligned, N % 4 == 0) the splits write partial tiles that a second kernel adds into C in a fixed order
  * (deterministic); without one they accumulate into C with fp32 atomics.
+ * The shape picks the kernel (csrc/gemm.hip): 128x128 tiles by default; bf16 (0,1) with >= 512 macro tiles, K >= 1024,
+ * K % 32 == 0, 256 <= N <= 2048 and bf16 (1,0) split-K with M, N >= 256 run on 256x256 tiles with four LDS stages.
+ * Rows of A / B past M / N may be re-read (never stored): the operands must be readable up to their last valid row only.
  * Replaces F.linear / nn.Linear and their autograd mm's: generator/graph_transformer.py:61-63 (fc1, relu,
  * dropout, fc2), :106-122 (in_proj, relation_in_proj), :166 (out_proj), :176-197; generator/transformer.py:66-69,
  * :109-119,:162,:175-196; generator/encoder.py:117 and the nn.GRU gate products (:76-82). */
