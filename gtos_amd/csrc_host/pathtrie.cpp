@@ -49,14 +49,32 @@ std::vector<int32_t> lex_order(const Seqs& q) {
     if (small)
         for (int64_t i = 0; i < q.R * L && small; ++i) small = q.tok[i] >= 0 && q.tok[i] < 255;
     if (small) {
-        // pack (token + 1) bytes, most significant first: integer order == lexicographic order with "shorter first"
-        std::vector<uint64_t> key(q.R);
+        // pack (token + 1) bytes, most significant first: integer order == lexicographic order with "shorter first";
+        // LSD radix sort of (key, id) pairs, one pass per byte position that is not constant (stable: ties keep id order)
+        std::vector<uint64_t> key(q.R), key2(q.R);
+        std::vector<int32_t> idx2(q.R);
+        uint64_t all_or = 0, all_and = ~0ull;
         for (int64_t s = 0; s < q.R; ++s) {
             uint64_t k = 0;
             for (int t = 0; t < 8; ++t) k = (k << 8) | (uint64_t)((t < L && t < q.len[s]) ? q.tok[s * L + t] + 1 : 0);
             key[s] = k;
+            all_or |= k;
+            all_and &= k;
         }
-        std::stable_sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b) { return key[a] < key[b]; });
+        for (int byte = 0; byte < 8; ++byte) {
+            const int sh = byte * 8;
+            if ((((all_or ^ all_and) >> sh) & 0xff) == 0) continue;       // the same digit everywhere
+            int64_t cnt[257] = {0};
+            for (int64_t i = 0; i < q.R; ++i) cnt[((key[i] >> sh) & 0xff) + 1]++;
+            for (int d = 0; d < 256; ++d) cnt[d + 1] += cnt[d];
+            for (int64_t i = 0; i < q.R; ++i) {
+                const int64_t o = cnt[(key[i] >> sh) & 0xff]++;
+                key2[o] = key[i];
+                idx2[o] = idx[i];
+            }
+            key.swap(key2);
+            idx.swap(idx2);
+        }
     } else {
         std::stable_sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b) {
             const int la = q.len[a], lb = q.len[b], m = la < lb ? la : lb;
@@ -80,6 +98,7 @@ void build_trie(const Seqs& q, const std::vector<int32_t>& order, Trie& tr) {
     std::vector<int64_t> per_level(L + 1, 0);
     std::vector<int32_t> cur(L, -1);                        // node (per-level rank) of the previous sequence at each position
     std::vector<int32_t> lvl_tok[64], lvl_par[64];          // L <= 64 (relation paths have <= 8 labels)
+    for (int k = 0; k < L && k < 64; ++k) { lvl_tok[k].reserve((size_t)R / 4 + 16); lvl_par[k].reserve((size_t)R / 4 + 16); }
     const int32_t* prev = nullptr;
     int prev_len = 0;
     for (int64_t i = 0; i < R; ++i) {
@@ -142,6 +161,10 @@ void build_rows(const std::vector<int32_t>& row_node, int64_t n_nodes, int chunk
         for (int64_t p = 0; p < N; ++p) tr.rows[cur[row_node[p]]++] = (int32_t)p;
     }
     tr.chunk_node.clear(); tr.chunk_start.clear(); tr.chunk_cnt.clear(); tr.chunk_slot.clear(); tr.heavy_node.clear();
+    {
+        const size_t cap = (size_t)(n_nodes + N / chunk + 1);
+        tr.chunk_node.reserve(cap); tr.chunk_start.reserve(cap); tr.chunk_cnt.reserve(cap); tr.chunk_slot.reserve(cap);
+    }
     for (int64_t u = 0; u < n_nodes; ++u) {
         const int64_t lo = off[u], hi = off[u + 1];
         const int64_t nch = hi > lo ? (hi - lo + chunk - 1) / chunk : 1;      // a node without rows still gets a (zero) result
@@ -206,14 +229,17 @@ extern "C" gtos_pathtrie* gtos_pathtrie_build(int L, int64_t R, const int64_t* b
     build_trie(fw, ord_f, h->pf);
     tb.join();
     // packed order: length descending, then lexicographic
-    std::vector<int32_t> rank(R);
-    for (int64_t i = 0; i < R; ++i) rank[ord_f[i]] = (int32_t)i;
+    // counting sort by length (descending) over the sequences in lexicographic order
     h->seq_order.resize(R);
-    std::iota(h->seq_order.begin(), h->seq_order.end(), 0);
-    std::stable_sort(h->seq_order.begin(), h->seq_order.end(), [&](int32_t a, int32_t b) {
-        if (fw.len[a] != fw.len[b]) return fw.len[a] > fw.len[b];
-        return rank[a] < rank[b];
-    });
+    {
+        std::vector<int64_t> start(L + 2, 0);
+        for (int64_t s = 0; s < R; ++s) start[L - fw.len[s] + 1]++;               // bucket L - len: longest first
+        for (int b = 0; b <= L; ++b) start[b + 1] += start[b];
+        for (int64_t i = 0; i < R; ++i) {
+            const int32_t s = ord_f[i];
+            h->seq_order[start[L - fw.len[s]]++] = s;
+        }
+    }
     h->seq_pos.resize(R);
     for (int64_t i = 0; i < R; ++i) h->seq_pos[h->seq_order[i]] = (int32_t)i;
     h->batch_sizes.assign(maxlen, 0);

@@ -101,17 +101,22 @@ def build_path_trie(bank, length, chunk=CHUNK):
         assert got == len(arrs)
     finally:
         lib.gtos_pathtrie_free(h)
-    ts = [torch.from_numpy(a[:s]) for a, s in zip(arrs, shapes)]
+    nps = [a[:s] for a, s in zip(arrs, shapes)]
+    ts = [torch.from_numpy(a) for a in nps]
+
+    def wide(i):                                   # int64 copy made by numpy (torch's CPU int32 -> int64 cast is ~50x slower here)
+        return torch.from_numpy(nps[i].astype(np.int64))
     common = dict(zip(_COMMON, ts[:5]))
     sides = []
     for k in (0, 1):
-        d = dict(zip(_PER_TRIE, ts[5 + 10 * k: 15 + 10 * k]))
+        names = dict(zip(_PER_TRIE, range(5 + 10 * k, 15 + 10 * k)))
+        d = {n: ts[i] for n, i in names.items()}
+        d["tok"] = wide(names["tok"])              # the embedding kernels take int64 token ids
+        d["par_long"] = wide(names["par"])         # index_select operand (the parent-state gather of the weight gradient)
         level_off = d.pop("level_off").tolist()
         sides.append(TrieSide(d, level_off))
     # seq_order / seq_pos feed index_select (int64); the row -> node maps stay int32 for the kernels
-    return PathTrie(Lm, R, N, common["batch_sizes"].tolist(),
-                    (common["seq_order"].to(torch.int64), common["seq_pos"].to(torch.int64), common["row_pf"], common["row_sf"]),
-                    sides[0], sides[1])
+    return PathTrie(Lm, R, N, common["batch_sizes"].tolist(), (wide(1), wide(2), common["row_pf"], common["row_sf"]), sides[0], sides[1])
 
 
 def attach_path_trie(batch):
