@@ -27,7 +27,6 @@ struct Trie {
     std::vector<int64_t> level_off;          // [L+1]
     std::vector<int32_t> tok, par;           // per node; par = n_nodes for level-0 nodes (the all-zero state row)
     std::vector<int32_t> child_off;          // [2*n_nodes]: children of node u are nodes child_off[2u] .. child_off[2u+1]-1
-    std::vector<int32_t> node_of;            // [R*L]: node of sequence s at level k (or -1)
     // rows of every node, chunked
     std::vector<int32_t> rows;               // [N] packed rows sorted by node
     std::vector<int32_t> chunk_node, chunk_start, chunk_cnt, chunk_slot, heavy_node;
@@ -88,38 +87,34 @@ std::vector<int32_t> lex_order(const Seqs& q) {
     return idx;
 }
 
-void build_trie(const Seqs& q, const std::vector<int32_t>& order, Trie& tr) {
-    // One pass over the lexicographically sorted sequences: sequence i shares its first lcp(i-1, i) nodes with its
-    // predecessor and opens a new node at every later position.  Nodes are first numbered per level in creation order
-    // (= lexicographic order inside the level), then shifted by the level offsets, so the walk is sequential in memory.
+// One pass over the lexicographically sorted sequences: sequence i shares its first lcp(i-1, i) nodes with its
+// predecessor and opens a new node at every later position.  A first pass over the sorted order takes the lcp's and
+// counts the nodes per level, so the second pass numbers the nodes with their final ids (level-major, lexicographic inside a
+// level) and writes the node of every packed row straight into `row_node`: row of (sequence s, level k) =
+// offs[pos(k, len)] + seq_pos[s] with pos = k for the prefix trie and len - 1 - k for the suffix trie (`reversed`).
+void build_trie(const Seqs& q, const std::vector<int32_t>& order, const std::vector<int32_t>& seq_pos, const std::vector<int64_t>& offs,
+                bool reversed, Trie& tr, std::vector<int32_t>& row_node) {
     const int L = q.L;
     const int64_t R = q.R;
-    tr.node_of.assign(R * L, -1);
+    std::vector<uint8_t> lcps(R);
     std::vector<int64_t> per_level(L + 1, 0);
-    std::vector<int32_t> cur(L, -1);                        // node (per-level rank) of the previous sequence at each position
-    std::vector<int32_t> lvl_tok[64], lvl_par[64];          // L <= 64 (relation paths have <= 8 labels)
-    for (int k = 0; k < L && k < 64; ++k) { lvl_tok[k].reserve((size_t)R / 4 + 16); lvl_par[k].reserve((size_t)R / 4 + 16); }
-    const int32_t* prev = nullptr;
-    int prev_len = 0;
-    for (int64_t i = 0; i < R; ++i) {
-        const int32_t s = order[i];
-        const int32_t* t = &q.tok[(int64_t)s * L];
-        const int len = q.len[s];
-        int lcp = 0;
-        if (prev) {
-            const int m = len < prev_len ? len : prev_len;
-            while (lcp < m && t[lcp] == prev[lcp]) ++lcp;
+    {
+        const int32_t* prev = nullptr;
+        int prev_len = 0;
+        for (int64_t i = 0; i < R; ++i) {
+            const int32_t s = order[i];
+            const int32_t* t = &q.tok[(int64_t)s * L];
+            const int len = q.len[s];
+            int lcp = 0;
+            if (prev) {
+                const int m = len < prev_len ? len : prev_len;
+                while (lcp < m && t[lcp] == prev[lcp]) ++lcp;
+            }
+            lcps[i] = (uint8_t)lcp;
+            for (int k = lcp; k < len; ++k) per_level[k]++;
+            prev = t;
+            prev_len = len;
         }
-        int32_t* out = &tr.node_of[(int64_t)s * L];
-        for (int k = 0; k < lcp; ++k) out[k] = cur[k];
-        for (int k = lcp; k < len; ++k) {
-            cur[k] = (int32_t)per_level[k]++;
-            lvl_tok[k].push_back(t[k]);
-            lvl_par[k].push_back(k ? cur[k - 1] : -1);
-            out[k] = cur[k];
-        }
-        prev = t;
-        prev_len = len;
     }
     tr.level_off.assign(L + 1, 0);
     for (int k = 0; k < L; ++k) tr.level_off[k + 1] = tr.level_off[k] + per_level[k];
@@ -127,16 +122,21 @@ void build_trie(const Seqs& q, const std::vector<int32_t>& order, Trie& tr) {
     tr.n_nodes = next;
     tr.tok.resize(next);
     tr.par.resize(next);
-    for (int k = 0; k < L; ++k) {
-        const int64_t off = tr.level_off[k], poff = k ? tr.level_off[k - 1] : 0;
-        for (int64_t j = 0; j < per_level[k]; ++j) {
-            tr.tok[off + j] = lvl_tok[k][j];
-            tr.par[off + j] = k ? (int32_t)(poff + lvl_par[k][j]) : (int32_t)next;   // level 0: the all-zero row behind the last node
+    std::vector<int64_t> fill(tr.level_off.begin(), tr.level_off.end() - 1);   // next free node id per level
+    std::vector<int32_t> cur(L, -1);                                          // node of the previous sequence at each level
+    for (int64_t i = 0; i < R; ++i) {
+        const int32_t s = order[i];
+        const int32_t* t = &q.tok[(int64_t)s * L];
+        const int len = q.len[s], lcp = lcps[i];
+        for (int k = lcp; k < len; ++k) {
+            const int32_t v = (int32_t)fill[k]++;
+            cur[k] = v;
+            tr.tok[v] = t[k];
+            tr.par[v] = k ? cur[k - 1] : (int32_t)next;       // level 0: the all-zero row behind the last node
         }
-    }
-    for (int64_t s = 0; s < R; ++s) {                         // per-level ranks -> global node ids
-        int32_t* out = &tr.node_of[s * L];
-        for (int k = 0; k < q.len[s]; ++k) out[k] += (int32_t)tr.level_off[k];
+        const int64_t m = seq_pos[s];
+        if (!reversed) for (int k = 0; k < len; ++k) row_node[offs[k] + m] = cur[k];
+        else           for (int k = 0; k < len; ++k) row_node[offs[len - 1 - k] + m] = cur[k];
     }
     // children of a node: a contiguous range of the next level (nodes of a level are sorted by parent, then token);
     // stored as [start, end) pairs, start == end for leaves
@@ -224,12 +224,12 @@ extern "C" gtos_pathtrie* gtos_pathtrie_build(int L, int64_t R, const int64_t* b
     h->R = R;
     h->N = N;
     std::vector<int32_t> ord_f, ord_b;
-    std::thread tb([&] { ord_b = lex_order(bw); build_trie(bw, ord_b, h->sf); });
-    ord_f = lex_order(fw);
-    build_trie(fw, ord_f, h->pf);
-    tb.join();
-    // packed order: length descending, then lexicographic
-    // counting sort by length (descending) over the sequences in lexicographic order
+    {
+        std::thread tb([&] { ord_b = lex_order(bw); });
+        ord_f = lex_order(fw);
+        tb.join();
+    }
+    // packed order: length descending, then lexicographic = counting sort by length over the sequences in lexicographic order
     h->seq_order.resize(R);
     {
         std::vector<int64_t> start(L + 2, 0);
@@ -243,20 +243,16 @@ extern "C" gtos_pathtrie* gtos_pathtrie_build(int L, int64_t R, const int64_t* b
     h->seq_pos.resize(R);
     for (int64_t i = 0; i < R; ++i) h->seq_pos[h->seq_order[i]] = (int32_t)i;
     h->batch_sizes.assign(maxlen, 0);
-    for (int64_t s = 0; s < R; ++s)
-        for (int t = 0; t < fw.len[s]; ++t) h->batch_sizes[t]++;
-    std::vector<int64_t> offs(maxlen + 1, 0);
+    for (int64_t s = 0; s < R; ++s) h->batch_sizes[fw.len[s] - 1]++;                 // sequences of exactly this length ...
+    for (int t = maxlen - 2; t >= 0; --t) h->batch_sizes[t] += h->batch_sizes[t + 1]; // ... -> sequences longer than t
+    std::vector<int64_t> offs(L + 1, 0);                  // rows of step t are the first batch_sizes[t] sequences of the order
     for (int t = 0; t < maxlen; ++t) offs[t + 1] = offs[t] + h->batch_sizes[t];
     h->row_pf.resize(N);
     h->row_sf.resize(N);
-    for (int64_t m = 0; m < R; ++m) {
-        const int32_t s = h->seq_order[m];
-        const int l = fw.len[s];
-        for (int t = 0; t < l; ++t) {
-            const int64_t p = offs[t] + m;               // rows of step t are the first batch_sizes[t] sequences of the order
-            h->row_pf[p] = h->pf.node_of[(int64_t)s * L + t];
-            h->row_sf[p] = h->sf.node_of[(int64_t)s * L + (l - 1 - t)];
-        }
+    {
+        std::thread tb([&] { build_trie(bw, ord_b, h->seq_pos, offs, true, h->sf, h->row_sf); });
+        build_trie(fw, ord_f, h->seq_pos, offs, false, h->pf, h->row_pf);
+        tb.join();
     }
     std::thread tr([&] { build_rows(h->row_sf, h->sf.n_nodes, chunk, h->sf); });
     build_rows(h->row_pf, h->pf.n_nodes, chunk, h->pf);

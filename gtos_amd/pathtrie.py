@@ -95,7 +95,7 @@ def build_path_trie(bank, length, chunk=CHUNK):
         shapes = [Lm, R, R, N, N]
         for n, c, hv in ((nPF, cPF, hPF), (nSF, cSF, hSF)):
             shapes += [Lm + 1, n, n, 2 * n, N, c, c, c, c, hv]
-        arrs = [np.zeros(max(1, s), dtype=np.int32) for s in shapes]
+        arrs = [np.empty(max(1, s), dtype=np.int32) for s in shapes]       # the export fills every array completely
         ptrs = (ctypes.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
         got = lib.gtos_pathtrie_export(h, ptrs)
         assert got == len(arrs)
