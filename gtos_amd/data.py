@@ -148,6 +148,16 @@ def _edges_from_paths(item, rel_vocab):
     return n, 0, np.array(edges, dtype=np.int32).reshape(-1, 3)
 
 
+def _item_graph(item, rel_vocab):
+    """(n, root, edges) of an item, recovered once and kept on the item: the recovery is a Python loop over all n^2 pairs
+    (0.5 s for a 64 x 100-node batch), the result does not depend on the batch."""
+    g = item.get('_graph')
+    if g is None or g[0] is not rel_vocab:
+        g = (rel_vocab, _edges_from_paths(item, rel_vocab))
+        item['_graph'] = g
+    return g[1]
+
+
 def batchify_amr(items, vocabs, train=True, seed=0, n_threads=0, unk_rate=0., rng=None):
     """``unk_rate`` / ``rng``: <UNK> noise on ``concept`` and ``token_in`` (generator/data.py:127,244).
     Generator flavour (generator/data.py:126-267).  items: dicts with 'concept' (BFS order), 'depth', 'relation'
@@ -157,7 +167,7 @@ def batchify_amr(items, vocabs, train=True, seed=0, n_threads=0, unk_rate=0., rn
     pair are the reference's set; their order over K and the numbering of the types follow this module's enumeration
     (the model averages over K, so neither is observable)."""
     rv = vocabs['relation']
-    graphs = [_edges_from_paths(x, rv) for x in items]
+    graphs = [_item_graph(x, rv) for x in items]
     rel = relbatch.build_relation_batch(graphs, relation_special_ids(rv),
                                         path_mode=relbatch.PATH_UNIFORM if train else relbatch.PATH_ALL, seed=seed,
                                         n_threads=n_threads)
@@ -183,6 +193,69 @@ def batchify_amr(items, vocabs, train=True, seed=0, n_threads=0, unk_rate=0., rn
         'cp_seq': lists_to_tensor(cps, vocabs['predictable_token'], t2is),
         'abstract': [x.get('abstract') for x in items],
     })   # train batches also carry 'relation_index' (eval batches are [n,n,B,K]: not factored)
+
+
+class AMRLoader(object):
+    """Batching policy of generator/data.py:269-316 (``DataLoader``): the preprocessed JSON items are shuffled and (stably)
+    sorted by size ``n_tokens + n_concepts**2`` when training, packed greedily until a batch holds ``batch_size`` size units
+    (or 257 items), a trailing batch is kept if it is more than half full (always in evaluation), and the batch order is
+    shuffled.  Both shuffles draw from ``rng`` (default: the ``random`` module, like the reference) BEFORE the first batch is
+    assembled, so under the same seed the batches and their order are the reference's.  Yields batchify_amr dicts (with
+    ``record()``: (batch, items) pairs, data.py:287-288,313-316); the path sampling of a training batch is seeded from
+    ``rng`` per batch.  The graph of every item is recovered from its path lists once, at load time."""
+
+    def __init__(self, vocabs, filename, batch_size, for_train, rng=None, n_threads=0):
+        import json
+        import random
+        if isinstance(filename, str):
+            with open(filename, encoding='utf8') as fi:
+                self.data = json.load(fi)
+        else:
+            self.data = list(filename)
+        self.vocabs, self.batch_size, self.train = vocabs, batch_size, for_train
+        self.rng = rng if rng is not None else random
+        self.n_threads = n_threads
+        self.unk_rate = 0.
+        self.record_flag = False
+        if vocabs is not None:
+            for d in self.data:
+                _item_graph(d, vocabs['relation'])
+
+    def set_unk_rate(self, x):
+        """generator/data.py:284-285; train.py calls it with --unk_rate."""
+        self.unk_rate = x
+
+    def record(self):
+        self.record_flag = True
+
+    @staticmethod
+    def size_of(item):
+        return len(item['token']) + len(item['concept']) ** 2
+
+    def batch_indices(self):
+        idx = list(range(len(self.data)))
+        if self.train:
+            self.rng.shuffle(idx)
+            idx.sort(key=lambda i: self.size_of(self.data[i]))
+        batches, units, cur = [], 0, []
+        for i in idx:
+            units += self.size_of(self.data[i])
+            cur.append(i)
+            if units >= self.batch_size or len(cur) > 256:
+                batches.append(cur)
+                units, cur = 0, []
+        if not self.train or units > self.batch_size / 2:
+            batches.append(cur)
+        if self.train:
+            self.rng.shuffle(batches)
+        return batches
+
+    def __iter__(self):
+        for b in self.batch_indices():
+            items = [self.data[i] for i in b]
+            batch = batchify_amr(items, self.vocabs, train=self.train, seed=self.rng.getrandbits(63), n_threads=self.n_threads,
+                                 unk_rate=self.unk_rate, rng=self.rng)
+            yield (batch, items) if self.record_flag else batch
 
 
 # ------------------------------------------------------------------------------------------------ host / device overlap

@@ -213,6 +213,64 @@ def test_batchify_amr_from_preprocessed_items(tmp_path):
     assert multi and all(len(seen[k]) > 1 for k in multi)                # over 12 seeds every tie is broken both ways
 
 
+def test_amr_loader_batches_like_the_reference():
+    """Batch composition and order of generator/data.py:DataLoader for four (batch_size, train, seed) settings over 1500
+    synthetic items (the fixture carries their sizes, which is all the policy looks at; tests/golden/make_golden_loader_amr.py
+    ran the reference's loader on them)."""
+    import json
+    import random
+    from conftest import GOLDEN
+    from gtos_amd.data import AMRLoader
+    g = json.load(open(os.path.join(GOLDEN, "loader_amr_synth.json")))
+    items = [{"concept": ["c"] * n, "token": ["t"] * m} for n, m in g["sizes"]]
+    for run in g["runs"]:
+        assert run["n_examples"] == len(items)
+        random.seed(run["seed"])
+        dl = AMRLoader(None, items, run["batch_size"], run["train"])
+        assert dl.batch_indices() == run["batches"], (run["batch_size"], run["train"], run["seed"])
+        dl2 = AMRLoader(None, items, run["batch_size"], run["train"], rng=random.Random(run["seed"]))
+        assert dl2.batch_indices() == run["batches"]
+
+
+def test_amr_loader_yields_training_batches_from_a_json_file(tmp_path):
+    """File -> AMRLoader -> batchify_amr: every item lands in exactly one batch, the graph of an item is recovered once (the
+    cached edges are reused by later epochs), training batches carry the trie and the relation index, record() adds the items."""
+    import json
+    import random
+    from conftest import GOLDEN
+    from gtos_amd import data
+    meta = json.load(open(os.path.join(GOLDEN, "host_amr_smatch_items.json")))
+    vocabs = _amr_vocabs(tmp_path, meta["relation_vocab"])
+    items = [dict(it, token=["a"] * (1 + k % 3)) for k, it in enumerate(meta["items"] * 3)]
+    path = os.path.join(str(tmp_path), "items.json")
+    with open(path, "w", encoding="utf8") as fo:
+        json.dump(items, fo)
+    calls = []
+    orig = data._edges_from_paths
+    data._edges_from_paths = lambda item, rv: (calls.append(1), orig(item, rv))[1]
+    try:
+        dl = data.AMRLoader(vocabs, path, batch_size=60, for_train=True, rng=random.Random(5))
+        assert len(calls) == len(items)                                  # recovered at load time ...
+        dl.set_unk_rate(0.1)
+        dl.record()
+        seen = 0
+        for epoch in range(2):
+            for batch, its in dl:
+                B = len(its)
+                seen += B
+                assert batch["relation"].dim() == 3 and batch["relation"].shape[2] == B
+                assert batch["relation_trie"].R == batch["relation_bank"].shape[1]
+                assert "relation_index" in batch
+                assert batch["concept"].shape[1] == B and batch["token_in"].shape[1] == B
+        assert seen == 2 * len(items)
+        assert len(calls) == len(items)                                  # ... and never again
+        ev = data.AMRLoader(vocabs, items, batch_size=10 ** 9, for_train=False)
+        (b,) = list(ev)
+        assert b["relation"].dim() == 4 and b["relation"].shape[2] == len(items)
+    finally:
+        data._edges_from_paths = orig
+
+
 # ------------------------------------------------------------------------------------------------ loader overlap
 def test_prefetcher_keeps_order_defers_assembly_and_propagates_errors():
     import threading
