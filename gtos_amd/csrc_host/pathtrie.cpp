@@ -195,7 +195,7 @@ struct gtos_pathtrie {
 };
 
 extern "C" gtos_pathtrie* gtos_pathtrie_build(int L, int64_t R, const int64_t* bank, const int64_t* length, int chunk) {
-    if (L <= 0 || L > 64 || R <= 0 || !bank || !length || chunk <= 0 || R > 0x7fffffffLL / L) return nullptr;
+    if (L <= 0 || L > 64 || R <= 0 || !bank || !length || chunk <= 0 || chunk > 64 || R > 0x7fffffffLL / L) return nullptr;
     Seqs fw, bw;
     fw.L = bw.L = L;
     fw.R = bw.R = R;

@@ -20,7 +20,21 @@ def relation_special_ids(rel_vocab):
             rel_vocab.token2idx(TL))
 
 
-def batchify_dependency(trees, vocabs, n_threads=0, unk_rate=0., rng=None, replay_reference_draws=False):
+def _index_prep(batch, on):
+    """Host-side index preparation of the bf16 training path (gtos_amd.pathtrie, gtos_amd.relindex): the path tries of the
+    trie-evaluated RelationEncoder and the relation index of the factored attention operand.  ``on=False`` (fp32 / CPU use,
+    ``GTOS_GRU_TRIE=0``) skips it; a bank the trie builder rejects (a path longer than 64 labels -- the translator flavour
+    puts no cap on path length --, an empty path) leaves the batch without ``relation_trie`` and RelationEncoder takes its per-row path."""
+    if not on:
+        return batch
+    try:
+        batch['relation_trie'] = build_path_trie(batch['relation_bank'], batch['relation_length'])
+    except ValueError:
+        pass                  # no 'relation_trie' key: RelationEncoder.forward falls back to one row per (path, position)
+    return attach_relation_index(batch)
+
+
+def batchify_dependency(trees, vocabs, n_threads=0, unk_rate=0., rng=None, replay_reference_draws=False, index_prep=True):
     """``unk_rate`` / ``rng``: the training-time <UNK> noise on ``concept`` and ``token_in`` only (translator/data.py:129,185),
     see vocab.lists_to_tensor.  Between those two tensors the reference's batchify calls ``random.choice`` once per node
     pair on a one-element path list (data.py:149); ``replay_reference_draws`` consumes ``rng`` the same way so that the
@@ -53,18 +67,17 @@ def batchify_dependency(trees, vocabs, n_threads=0, unk_rate=0., rng=None, repla
         for c in concepts:
             for _ in range(len(c) * len(c)):
                 gen.choice(one)
-    return attach_relation_index({
+    return _index_prep({
         'concept': concept,
         'concept_char': strings_to_char_tensor(with_cls, vocabs['concept_char']),
         'concept_depth': lists_to_tensor([[0] + d for d in depths]),
         'relation': rel['relation'], 'relation_bank': rel['relation_bank'], 'relation_length': rel['relation_length'],
-        'relation_trie': build_path_trie(rel['relation_bank'], rel['relation_length']),   # index prep of the trie-evaluated GRU
         'local_idx2token': i2ts, 'local_token2idx': t2is,
         'token_in': lists_to_tensor(aug, vocabs['token'], unk_rate=unk_rate, rng=rng)[:-1],
         'token_char_in': strings_to_char_tensor(aug, vocabs['token_char'])[:-1],
         'token_out': lists_to_tensor(aug, vocabs['predictable_token'], t2is)[1:],
         'cp_seq': lists_to_tensor(cps, vocabs['predictable_token'], t2is),
-    })
+    }, index_prep)
 
 
 def read_dependency_file(path):
@@ -88,13 +101,14 @@ class DependencyLoader(object):
     shuffled.  Both shuffles draw from ``rng`` (default: the ``random`` module, like the reference) BEFORE the first batch is
     assembled, so under the same seed the batches and their order are the reference's.  Yields batchify_dependency dicts."""
 
-    def __init__(self, vocabs, filename, batch_size, for_train, rng=None, n_threads=0):
+    def __init__(self, vocabs, filename, batch_size, for_train, rng=None, n_threads=0, index_prep=True):
         import random
         self.data = read_dependency_file(filename) if isinstance(filename, str) else list(filename)
         self.vocabs, self.batch_size, self.train = vocabs, batch_size, for_train
         self.rng = rng if rng is not None else random
         self.n_threads = n_threads
         self.unk_rate = 0.
+        self.index_prep = index_prep          # path tries + relation index of the bf16 training path (see _index_prep)
 
     def set_unk_rate(self, x):
         """translator/data.py:218-219; train.py:128 calls it with --unk_rate (0.33 in train.sh)."""
@@ -117,7 +131,7 @@ class DependencyLoader(object):
             if units >= self.batch_size or len(cur) > 256:
                 batches.append(cur)
                 units, cur = 0, []
-        if not self.train or units > self.batch_size / 2:
+        if cur and (not self.train or units > self.batch_size / 2):     # (an empty trailing batch is dropped, see AMRLoader)
             batches.append(cur)
         if self.train:
             self.rng.shuffle(batches)
@@ -126,7 +140,18 @@ class DependencyLoader(object):
     def __iter__(self):
         for b in self.batch_indices():
             yield batchify_dependency([self.data[i] for i in b], self.vocabs, n_threads=self.n_threads,
-                                      unk_rate=self.unk_rate, rng=self.rng)
+                                      unk_rate=self.unk_rate, rng=self.rng, index_prep=self.index_prep)
+
+    def thunks(self):
+        """The same batches as callables (``Prefetcher`` runs a callable on its worker thread, so several workers assemble
+        batches in parallel; plain iteration assembles under the prefetcher's source lock, one at a time).  The <UNK> noise
+        of a batch then draws from a private ``random.Random`` seeded from ``rng`` when the thunk is CREATED, so the batches do
+        not depend on which worker runs first (they differ from plain iteration's draws, which share ``rng``)."""
+        import random
+        for b in self.batch_indices():
+            trees, sub = [self.data[i] for i in b], random.Random(self.rng.getrandbits(63))
+            yield lambda trees=trees, sub=sub: batchify_dependency(trees, self.vocabs, n_threads=self.n_threads, unk_rate=self.unk_rate,
+                                                                   rng=sub, index_prep=self.index_prep)
 
 
 # ------------------------------------------------------------------------------------------------ generator flavour
@@ -148,17 +173,20 @@ def _edges_from_paths(item, rel_vocab):
     return n, 0, np.array(edges, dtype=np.int32).reshape(-1, 3)
 
 
-def _item_graph(item, rel_vocab):
-    """(n, root, edges) of an item, recovered once and kept on the item: the recovery is a Python loop over all n^2 pairs
-    (0.5 s for a 64 x 100-node batch), the result does not depend on the batch."""
-    g = item.get('_graph')
-    if g is None or g[0] is not rel_vocab:
-        g = (rel_vocab, _edges_from_paths(item, rel_vocab))
-        item['_graph'] = g
-    return g[1]
+def _item_graph(item, rel_vocab, cache=None):
+    """(n, root, edges) of an item.  The recovery is a Python loop over all n^2 pairs (0.5 s for a 64 x 100-node batch) and
+    does not depend on the batch, so a loader passes a ``cache`` dict (keyed by the item object's id; the loader keeps the
+    items alive) and recovers every graph once; the items themselves are never written to (they stay JSON-serialisable for
+    ``record()`` consumers)."""
+    if cache is None:
+        return _edges_from_paths(item, rel_vocab)
+    g = cache.get(id(item))
+    if g is None or g[0] is not rel_vocab or g[1] is not item:
+        g = cache[id(item)] = (rel_vocab, item, _edges_from_paths(item, rel_vocab))
+    return g[2]
 
 
-def batchify_amr(items, vocabs, train=True, seed=0, n_threads=0, unk_rate=0., rng=None):
+def batchify_amr(items, vocabs, train=True, seed=0, n_threads=0, unk_rate=0., rng=None, index_prep=True, graph_cache=None):
     """``unk_rate`` / ``rng``: <UNK> noise on ``concept`` and ``token_in`` (generator/data.py:127,244).
     Generator flavour (generator/data.py:126-267).  items: dicts with 'concept' (BFS order), 'depth', 'relation'
     (path lists, only used to recover the edges), 'token', and optionally 'abstract'.  train=True draws ONE shortest path
@@ -167,7 +195,7 @@ def batchify_amr(items, vocabs, train=True, seed=0, n_threads=0, unk_rate=0., rn
     pair are the reference's set; their order over K and the numbering of the types follow this module's enumeration
     (the model averages over K, so neither is observable)."""
     rv = vocabs['relation']
-    graphs = [_item_graph(x, rv) for x in items]
+    graphs = [_item_graph(x, rv, graph_cache) for x in items]
     rel = relbatch.build_relation_batch(graphs, relation_special_ids(rv),
                                         path_mode=relbatch.PATH_UNIFORM if train else relbatch.PATH_ALL, seed=seed,
                                         n_threads=n_threads)
@@ -180,19 +208,18 @@ def batchify_amr(items, vocabs, train=True, seed=0, n_threads=0, unk_rate=0., rn
         cps.append(cp_seq); t2is.append(t2i); i2ts.append(i2t)
     aug = [[STR] + list(x['token']) + [END] for x in items]
     with_cls = [[CLS] + list(x['concept']) for x in items]
-    return attach_relation_index({
+    return _index_prep({
         'concept': lists_to_tensor(with_cls, vocabs['concept'], unk_rate=unk_rate, rng=rng),
         'concept_char': strings_to_char_tensor(with_cls, vocabs['concept_char']),
         'concept_depth': lists_to_tensor([[0] + list(x['depth']) for x in items]),
         'relation': rel['relation'], 'relation_bank': rel['relation_bank'], 'relation_length': rel['relation_length'],
-        'relation_trie': build_path_trie(rel['relation_bank'], rel['relation_length']),   # index prep of the trie-evaluated GRU
         'local_idx2token': i2ts, 'local_token2idx': t2is,
         'token_in': lists_to_tensor(aug, vocabs['token'], unk_rate=unk_rate, rng=rng)[:-1],
         'token_char_in': strings_to_char_tensor(aug, vocabs['token_char'])[:-1],
         'token_out': lists_to_tensor(aug, vocabs['predictable_token'], t2is)[1:],
         'cp_seq': lists_to_tensor(cps, vocabs['predictable_token'], t2is),
         'abstract': [x.get('abstract') for x in items],
-    })   # train batches also carry 'relation_index' (eval batches are [n,n,B,K]: not factored)
+    }, index_prep)   # train batches also carry 'relation_index' (eval batches are [n,n,B,K]: not factored)
 
 
 class AMRLoader(object):
@@ -204,7 +231,7 @@ class AMRLoader(object):
     ``record()``: (batch, items) pairs, data.py:287-288,313-316); the path sampling of a training batch is seeded from
     ``rng`` per batch.  The graph of every item is recovered from its path lists once, at load time."""
 
-    def __init__(self, vocabs, filename, batch_size, for_train, rng=None, n_threads=0):
+    def __init__(self, vocabs, filename, batch_size, for_train, rng=None, n_threads=0, index_prep=True):
         import json
         import random
         if isinstance(filename, str):
@@ -217,9 +244,11 @@ class AMRLoader(object):
         self.n_threads = n_threads
         self.unk_rate = 0.
         self.record_flag = False
+        self.index_prep = index_prep
+        self._graphs = {}
         if vocabs is not None:
             for d in self.data:
-                _item_graph(d, vocabs['relation'])
+                _item_graph(d, vocabs['relation'], self._graphs)
 
     def set_unk_rate(self, x):
         """generator/data.py:284-285; train.py calls it with --unk_rate."""
@@ -244,77 +273,133 @@ class AMRLoader(object):
             if units >= self.batch_size or len(cur) > 256:
                 batches.append(cur)
                 units, cur = 0, []
-        if not self.train or units > self.batch_size / 2:
+        # the reference appends the trailing batch in evaluation even when the last item closed a batch exactly and nothing is
+        # left (generator/data.py:306-307: batchify then fails on the empty list at the end of a dev pass); an empty batch is
+        # dropped here -- the non-empty compositions are the reference's
+        if cur and (not self.train or units > self.batch_size / 2):
             batches.append(cur)
         if self.train:
             self.rng.shuffle(batches)
         return batches
 
+    def _assemble(self, items, seed, rng):
+        batch = batchify_amr(items, self.vocabs, train=self.train, seed=seed, n_threads=self.n_threads, unk_rate=self.unk_rate,
+                             rng=rng, index_prep=self.index_prep, graph_cache=self._graphs)
+        return (batch, items) if self.record_flag else batch
+
     def __iter__(self):
         for b in self.batch_indices():
-            items = [self.data[i] for i in b]
-            batch = batchify_amr(items, self.vocabs, train=self.train, seed=self.rng.getrandbits(63), n_threads=self.n_threads,
-                                 unk_rate=self.unk_rate, rng=self.rng)
-            yield (batch, items) if self.record_flag else batch
+            yield self._assemble([self.data[i] for i in b], self.rng.getrandbits(63), self.rng)
+
+    def thunks(self):
+        """The same batches as callables for ``Prefetcher(workers > 1)`` (see DependencyLoader.thunks): path-sampling seed and
+        a private <UNK>-noise generator are drawn from ``rng`` when the thunk is created, in batch order."""
+        import random
+        for b in self.batch_indices():
+            items, seed, sub = [self.data[i] for i in b], self.rng.getrandbits(63), random.Random(self.rng.getrandbits(63))
+            yield lambda items=items, seed=seed, sub=sub: self._assemble(items, seed, sub)
 
 
 # ------------------------------------------------------------------------------------------------ host / device overlap
-class Prefetcher(object):
-    """Keeps ``depth`` batches assembled ahead of the consumer on a background thread.
+def _device_tensors(obj, seen=None):
+    """Every tensor reachable from a batch value: tensors, the index objects (PathTrie / TrieSide / RelationIndex keep theirs
+    as attributes), lists / tuples / dicts of those."""
+    seen = set() if seen is None else seen
+    if id(obj) in seen:
+        return
+    seen.add(id(obj))
+    if isinstance(obj, torch.Tensor):
+        yield obj
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            yield from _device_tensors(v, seen)
+    elif isinstance(obj, (list, tuple)):
+        if obj and not isinstance(obj[0], (str, int, float)):      # token / id lists: nothing to find
+            for v in obj:
+                yield from _device_tensors(v, seen)
+    elif hasattr(obj, "__dict__") and not isinstance(obj, type):
+        for v in vars(obj).values():
+            yield from _device_tensors(v, seen)
 
-    Batch assembly is host work -- graph paths + relation bank (0.08 s for a C2 batch), path tries (0.2 s), relation index
-    (0.03 s) -- and all of it runs inside libgtos_host.so, which ctypes calls with the GIL released, so it overlaps the GPU
-    step (0.07 s at C2) driven by the main thread: several loader threads (``workers``) keep up with the device.  The
-    reference assembles every batch synchronously in the training loop (generator/data.py:290-316).  With ``device`` the
-    finished batch is also copied to the GPU on a dedicated copy stream (pinned staging), and the consumer's stream is made
-    to wait for that copy when it takes the batch.  Order of the batches is the iterable's order."""
+
+class Prefetcher(object):
+    """Keeps ``depth`` batches assembled ahead of the consumer on background threads.
+
+    Batch assembly is host work -- graph paths + relation bank, path tries, relation index (csrc_host) -- and all of it runs
+    inside libgtos_host.so, which ctypes calls with the GIL released, so it overlaps the GPU step driven by the main thread.
+    The reference assembles every batch synchronously in the training loop (generator/data.py:290-316).
+
+    * ``batches`` yields batch dicts or CALLABLES returning one.  The source iterable is advanced under a lock, so a loader
+      that assembles inside ``__next__`` (``iter(AMRLoader)``) is serialised no matter how many ``workers`` there are;
+      ``workers > 1`` only pays off for sources that yield callables (``AMRLoader.thunks()``, ``DependencyLoader.thunks()``,
+      or ``(lambda i=i: make(i)) for i in ...``), which run on the worker that took them.
+    * With ``device`` the finished batch is copied to the GPU on a dedicated copy stream (pinned staging).  When the consumer
+      takes a batch, its current stream is made to wait for that copy AND every device tensor of the batch (including those
+      inside PathTrie / RelationIndex) is ``record_stream``-ed on the consumer's stream: the blocks live in the copy stream's
+      pool, and without the record the caching allocator could hand them to a later upload while the consumer's kernels
+      (backward, optimizer) still read them.
+    * Order of the batches is the iterable's order.  ``close()`` (also on garbage collection / context exit) stops the
+      workers; batches already assembled are dropped."""
 
     def __init__(self, batches, depth=2, workers=1, device=None):
         import threading
         self._it = iter(batches)
-        self._lock = threading.Lock()
         self._out = {}
-        self._cv = threading.Condition()
-        self._next_in, self._next_out, self._done, self._err = 0, 0, False, None
+        self._cv = threading.Condition()          # ONE lock: depth reservation, source advance and hand-over are atomic
+        self._next_in, self._next_out, self._done, self._err, self._stop = 0, 0, False, None, False
         self._depth = max(1, depth)
         self._device = torch.device(device) if device is not None else None
         self._copy_stream = torch.cuda.Stream(self._device) if self._device is not None and self._device.type == "cuda" else None
-        self._threads = [threading.Thread(target=self._work, daemon=True) for _ in range(max(1, workers))]
+        self.workers = max(1, workers)
+        self._threads = [threading.Thread(target=self._work, daemon=True) for _ in range(self.workers)]
         for t in self._threads:
             t.start()
 
     def _take(self):
-        with self._lock:                      # the source iterable is advanced by one thread at a time, in order
-            if self._done:
+        """Reserve a slot within ``depth`` of the consumer and take the next source item -- under one lock, so N workers can
+        never run more than ``depth`` batches ahead."""
+        with self._cv:
+            self._cv.wait_for(lambda: self._stop or self._done or self._err is not None or
+                              self._next_in - self._next_out < self._depth)
+            if self._stop or self._done or self._err is not None:
                 return None, None
             try:
                 item = next(self._it)
             except StopIteration:
                 self._done = True
+                self._cv.notify_all()
                 return None, None
             k = self._next_in
             self._next_in += 1
             return k, item
 
+    def _upload(self, batch):
+        with torch.cuda.stream(self._copy_stream):
+            def up(v):
+                if isinstance(v, torch.Tensor):
+                    return v.pin_memory().to(self._device, non_blocking=True)
+                return v.to(self._device) if hasattr(v, "to") else v
+            if isinstance(batch, tuple):           # (batch, items) of a recording loader
+                out = (dict((n, up(v)) for n, v in batch[0].items()),) + tuple(batch[1:])
+            else:
+                out = {n: up(v) for n, v in batch.items()}
+            ev = torch.cuda.Event()
+            ev.record(self._copy_stream)
+        return out, ev
+
     def _work(self):
         try:
             while True:
-                with self._cv:                # stay at most `depth` batches ahead of the consumer
-                    self._cv.wait_for(lambda: self._next_in - self._next_out < self._depth or self._done or self._err)
-                    if self._err:
-                        return
                 k, item = self._take()
                 if k is None:
                     break
                 batch = item() if callable(item) else item        # a callable defers the assembly to this thread
                 ev = None
                 if self._copy_stream is not None:
-                    with torch.cuda.stream(self._copy_stream):
-                        batch = {n: (v.pin_memory().to(self._device, non_blocking=True) if isinstance(v, torch.Tensor)
-                                     else (v.to(self._device) if hasattr(v, "to") else v)) for n, v in batch.items()}
-                        ev = torch.cuda.Event()
-                        ev.record(self._copy_stream)
+                    batch, ev = self._upload(batch)
                 with self._cv:
+                    if self._stop:
+                        break
                     self._out[k] = (batch, ev)
                     self._cv.notify_all()
         except BaseException as e:            # surfaced in the consumer
@@ -325,20 +410,42 @@ class Prefetcher(object):
             with self._cv:
                 self._cv.notify_all()
 
+    def close(self):
+        with self._cv:
+            self._stop = True
+            self._out.clear()
+            self._cv.notify_all()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
     def __iter__(self):
         return self
 
     def __next__(self):
         with self._cv:
-            self._cv.wait_for(lambda: self._next_out in self._out or self._err is not None or
+            self._cv.wait_for(lambda: self._next_out in self._out or self._err is not None or self._stop or
                               (self._done and self._next_out >= self._next_in))
             if self._err is not None:
                 raise self._err
-            if self._next_out not in self._out:       # source exhausted and everything taken from it has been handed out
+            if self._next_out not in self._out:       # source exhausted (or closed) and everything taken from it handed out
                 raise StopIteration
             batch, ev = self._out.pop(self._next_out)
             self._next_out += 1
             self._cv.notify_all()
         if ev is not None:
-            torch.cuda.current_stream(self._device).wait_event(ev)
+            cur = torch.cuda.current_stream(self._device)
+            cur.wait_event(ev)
+            for t in _device_tensors(batch):
+                if t.is_cuda:
+                    t.record_stream(cur)
         return batch

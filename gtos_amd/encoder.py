@@ -51,15 +51,22 @@ class RelationEncoder(nn.Module):
                        getattr(self.rnn, "bias_ih_l%d%s" % (l, suf)), getattr(self.rnn, "bias_hh_l%d%s" % (l, suf))]
         return ws
 
+    def _trie_ok(self, src_tokens):
+        return (_gru.TRIE and self.compute_dtype == torch.bfloat16 and self.num_layers == 2 and self.hidden_size % 64 == 0
+                and src_tokens.is_cuda)
+
     def forward(self, src_tokens, src_lengths, trie=None):
         """``trie``: the batch's gtos_amd.pathtrie.PathTrie (``batch['relation_trie']``, built by the loader on the host
         with the bank); when the trie path applies and none is given it is built here (a host round trip)."""
         rel_dim = self.rel_embed.weight.shape[1]
         pad = (-rel_dim) % 8                                                       # 16-byte rows for the GEMM
-        if (_gru.TRIE and self.compute_dtype == torch.bfloat16 and self.num_layers == 2 and self.hidden_size % 64 == 0
-                and src_tokens.is_cuda):
+        if self._trie_ok(src_tokens):
             if trie is None or not trie.matches(src_tokens, src_lengths):
-                trie = build_path_trie(src_tokens, src_lengths).to(src_tokens.device)
+                try:
+                    trie = build_path_trie(src_tokens, src_lengths).to(src_tokens.device)
+                except ValueError:            # a bank the trie builder rejects (paths longer than 64 labels): one row per
+                    trie = None               # (path, position) below, like the reference's packed sequence
+        if trie is not None and trie.matches(src_tokens, src_lengths) and self._trie_ok(src_tokens):
             p_e = self.dropout if self.training else 0.0
             fin = trie_bigru_final(trie, self.rel_embed.weight, rel_dim + pad, p_e, self.hidden_size, p_e, self._weights(pad))
             fin = ops.permute_rows(fin, trie.seq_pos, trie.seq_order)              # packed order -> bank order

@@ -719,8 +719,10 @@ class CopyNllFn(torch.autograd.Function):
         S = cp_seq.shape[0]
         d_logits, d_div = torch.empty_like(logits), torch.empty_like(div)
         d_align = torch.empty_like(align)
+        g = d_nll.float().contiguous()          # (an expanded view after .sum(0)): a named local that outlives the launch below
         call("gtos_copy_nll_bwd", dt(logits), T_, B, V, S, ptr(logits), V, ptr(div), ptr(align), ptr(cp_seq), ptr(target),
-             ctx.pad_idx, ptr(lse), ptr(p), ptr(d_nll.float().contiguous()), ptr(d_logits), ptr(d_div), ptr(d_align), stream())
+             ctx.pad_idx, ptr(lse), ptr(p), ptr(g), ptr(d_logits), ptr(d_div), ptr(d_align), stream())
+        del g
         return d_logits, d_div, d_align, None, None, None
 
 

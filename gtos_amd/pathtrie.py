@@ -84,10 +84,12 @@ def build_path_trie(bank, length, chunk=CHUNK):
     bank = np.ascontiguousarray(bank.detach().cpu().numpy().astype(np.int64, copy=False))
     length = np.ascontiguousarray(length.detach().cpu().numpy().astype(np.int64, copy=False))
     L, R = bank.shape
+    if not 1 <= chunk <= 64:
+        raise ValueError("chunk must be in 1..64: gtos_segment_sum_rows reads one row id per lane of a 64-lane wave")
     lib = _lib()
     h = lib.gtos_pathtrie_build(L, R, bank.ctypes.data, length.ctypes.data, chunk)
     if not h:
-        raise ValueError("gtos_pathtrie_build rejected the bank (lengths must be in 1..L, label ids non-negative)")
+        raise ValueError("gtos_pathtrie_build rejected the bank (at most 64 labels per path, lengths in 1..L, label ids non-negative)")
     try:
         sizes = np.zeros(9, dtype=np.int64)
         lib.gtos_pathtrie_sizes(h, sizes.ctypes.data)

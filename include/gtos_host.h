@@ -51,7 +51,8 @@ void gtos_relbatch_free(gtos_relbatch* h);
  * Index preparation for the RelationEncoder of generator/encoder.py:66-119 on MI355X: the first bi-GRU layer runs once
  * per trie node instead of once per (sequence, position), the second layer's input-gate product splits into a
  * prefix-node and a suffix-node term.  bank: int64 [L,R] 0-padded label ids (relation_bank of generator/data.py:166-176,
- * time-major), length: int64 [R] (1..L).  chunk: rows per reduction chunk (64).  NULL on invalid input. */
+ * time-major), length: int64 [R] (1..L).  chunk: rows per reduction chunk, 1..64 (gtos_segment_sum_rows
+ * reads one row id per lane of a 64-lane wave).  NULL on invalid input (L > 64, a length outside 1..L, chunk outside 1..64). */
 typedef struct gtos_pathtrie gtos_pathtrie;
 gtos_pathtrie* gtos_pathtrie_build(int L, int64_t R, const int64_t* bank, const int64_t* length, int chunk);
 

@@ -314,3 +314,92 @@ def test_prefetcher_over_the_real_loader_matches_direct_iteration():
     for a, b in zip(direct, via):
         assert torch.equal(a["relation"], b["relation"]) and torch.equal(a["relation_trie"].row_sf, b["relation_trie"].row_sf)
         assert torch.equal(a["relation_index"].pair_sorted, b["relation_index"].pair_sorted)
+
+
+def test_prefetcher_never_runs_more_than_depth_ahead_and_close_releases_the_workers():
+    import threading
+    import time
+    from gtos_amd.data import Prefetcher
+    started = []
+
+    def make(i):
+        def f():
+            started.append(i)
+            return {"i": torch.tensor([i])}
+        return f
+    pf = Prefetcher((make(i) for i in range(50)), depth=3, workers=6)
+    time.sleep(0.3)
+    assert len(started) == 3                      # reservation and take are one critical section: exactly `depth` ahead
+    assert int(next(pf)["i"]) == 0
+    time.sleep(0.2)
+    assert len(started) == 4
+    pf.close()
+    for t in pf._threads:
+        t.join(2.0)
+    assert not any(t.is_alive() for t in pf._threads)
+    with pytest.raises(StopIteration):
+        next(pf)
+    with Prefetcher((make(i) for i in range(5)), depth=2) as pf2:
+        assert int(next(pf2)["i"]) == 0
+    for t in pf2._threads:
+        t.join(2.0)
+    assert not any(t.is_alive() for t in pf2._threads)
+
+
+def test_device_tensor_walk_reaches_the_index_objects():
+    from gtos_amd import synth
+    from gtos_amd.data import _device_tensors
+    from gtos_amd.pathtrie import attach_path_trie
+    from gtos_amd.relindex import attach_relation_index
+    b = attach_relation_index(attach_path_trie(synth.make_batch(9, 3, 10, 5)[0]))
+    b["local_idx2token"] = [{5: "x"}]
+    got = {id(t) for t in _device_tensors(b)}
+    tr, ix = b["relation_trie"], b["relation_index"]
+    for t in (b["relation"], tr.row_pf, tr.seq_order, tr.pf.rows, tr.sf.par_long, tr.sf.tok, ix.idx_q, ix.chunk_slot, ix.heavy_types):
+        assert id(t) in got
+    assert all(isinstance(t, torch.Tensor) for t in _device_tensors((b, ["a", "b"])))
+
+
+def test_loaders_drop_an_empty_trailing_batch_keep_items_clean_and_offer_thunks(tmp_path):
+    import json
+    import random
+    from conftest import GOLDEN
+    from gtos_amd import data
+    meta = json.load(open(os.path.join(GOLDEN, "host_amr_smatch_items.json")))
+    vocabs = _amr_vocabs(tmp_path, meta["relation_vocab"])
+    items = [dict(it, token=["a"] * (1 + k % 3)) for k, it in enumerate(meta["items"] * 2)]
+    before = json.dumps(items, sort_keys=True)
+    unit = data.AMRLoader.size_of(items[0])
+    ev = data.AMRLoader(vocabs, items[:1], batch_size=unit, for_train=False)        # the only item closes a batch exactly
+    assert ev.batch_indices() == [[0]]
+    assert len(list(ev)) == 1
+    dep = data.DependencyLoader(None, [(["a"], [0], ["x"], ["y"])], batch_size=2, for_train=False)
+    assert dep.batch_indices() == [[0]]
+
+    def loader():
+        return data.AMRLoader(vocabs, items, batch_size=2 * unit, for_train=True, rng=random.Random(3))
+    first = [f() for f in loader().thunks()]
+    again = [f() for f in reversed(list(loader().thunks()))][::-1]                    # run order does not matter
+    assert len(first) == len(again) >= 2
+    for a, b in zip(first, again):
+        assert torch.equal(a["relation"], b["relation"]) and torch.equal(a["concept"], b["concept"])
+    via = list(data.Prefetcher(loader().thunks(), depth=2, workers=3))
+    assert len(via) == len(first)
+    for a, b in zip(first, via):
+        assert torch.equal(a["relation"], b["relation"]) and torch.equal(a["token_in"], b["token_in"])
+    assert json.dumps(items, sort_keys=True) == before                               # graphs cached beside the items, not on them
+    plain = data.batchify_amr(items[:2], vocabs, index_prep=False)
+    assert "relation_trie" not in plain and "relation_index" not in plain
+
+
+def test_trie_builder_rejection_falls_back_to_the_per_row_encoder(monkeypatch):
+    from gtos_amd import data
+    from gtos_amd.pathtrie import build_path_trie
+    with pytest.raises(ValueError):
+        build_path_trie(torch.ones(3, 4, dtype=torch.int64), torch.tensor([1, 2, 2, 3]), chunk=65)
+    with pytest.raises(ValueError):
+        build_path_trie(torch.ones(65, 2, dtype=torch.int64), torch.tensor([65, 1]))      # a 65-label path (translator flavour)
+    batch = {"relation": torch.zeros(2, 2, 1, dtype=torch.int64), "relation_bank": torch.ones(65, 2, dtype=torch.int64),
+             "relation_length": torch.tensor([65, 1])}
+    out = data._index_prep(dict(batch), True)
+    assert "relation_trie" not in out and "relation_index" in out
