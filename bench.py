@@ -63,6 +63,17 @@ def parse():
                     help="secondary benchmark (SURVEY 8f rank 2): beam search over the K/V-cached decoder instead of the train step")
     ap.add_argument("--beam", type=int, default=8)
     ap.add_argument("--max-steps", type=int, default=50)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: B graphs per GPU (the translator's policy, translator/train.py:201); strong: B graphs in TOTAL, "
+                         "B/N per GPU (the generator divides its batch budget by the world size, generator/train.py:183)")
+    ap.add_argument("--fresh-batches", action="store_true",
+                    help="loader in the loop: a NEW batch every step, assembled by gtos_amd.data.AMRLoader (C++ relation batch, path "
+                         "tries, relation index) on Prefetcher worker threads and uploaded on a copy stream, like the reference's "
+                         "training loop (generator/train.py:136-140, generator/data.py:290-316); default: one pre-built device batch")
+    ap.add_argument("--workers", type=int, default=4, help="--fresh-batches: loader threads per rank")
+    ap.add_argument("--depth", type=int, default=3, help="--fresh-batches: batches assembled ahead")
+    ap.add_argument("--relbatch-threads", type=int, default=2, help="--fresh-batches: threads inside one relation-batch build")
+    ap.add_argument("--pool", type=int, default=0, help="--fresh-batches: graphs in the per-rank item pool (default 4 batches)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="only check the rank launch / rendezvous (gloo, no GPU): every rank prints its rank and exits")
     return ap.parse_args()
@@ -396,14 +407,62 @@ def main():
     model.set_compute_dtype(cd)
     model.train()
     trainer = Trainer(model, cfg["d"], warmup_steps=2000, compute_dtype=cd, world_size=world, rank=rank)
+    B_cfg = cfg["B"]
+    if a.scaling == "strong":
+        if B_cfg % world:
+            raise SystemExit("--scaling strong needs the batch (%d graphs) to divide by --gpus %d" % (B_cfg, world))
+        B_rank = B_cfg // world            # the reference generator's policy: batch budget / world_size (generator/train.py:183)
+    else:
+        B_rank = B_cfg
     log("model on device; generating batch")
-    batch, stats = synth.make_config_batch(a.config, rank=rank)        # weak scaling: B graphs per GPU
-    log("batch", stats)
     from gtos_amd.pathtrie import attach_path_trie
     from gtos_amd.relindex import attach_relation_index
-    attach_relation_index(attach_path_trie(batch))   # host-side index preparation: batch assembly, like the relation bank itself
-    batch = {k: v.to(dev) for k, v in batch.items()}
+    loader_info, feed = None, None
+    if a.fresh_batches:
+        import random
+        from gtos_amd import data as data_mod
+        if cfg["kind"] != "amr":
+            raise SystemExit("--fresh-batches drives the generator-flavour loader (AMR configs)")
+        vocabs_s = synth.synth_vocabs()
+        pool_n = a.pool or 4 * B_rank
+        pool_n -= pool_n % B_rank
+        items, graphs = synth.make_amr_items(a.config, pool_n, first_graph=rank * pool_n, vocabs=vocabs_s)
+        unit = data_mod.AMRLoader.size_of(items[0])                       # every item of a config has the same size
+        loader = data_mod.AMRLoader(vocabs_s, items, batch_size=B_rank * unit - unit // 2, for_train=True,
+                                    rng=random.Random(19940117 + rank), n_threads=a.relbatch_threads, graphs=graphs)
+        asm_times = []
+
+        def timed_thunks():
+            while True:                                                   # epochs over the pool: reshuffled, paths re-drawn
+                for f in loader.thunks():
+                    def g(f=f):
+                        t_ = time.perf_counter()
+                        out_ = f()
+                        asm_times.append(time.perf_counter() - t_)
+                        return out_
+                    yield g
+        feed = data_mod.Prefetcher(timed_thunks(), depth=a.depth, workers=a.workers, device=dev)
+        batch = next(feed)
+        stats = {"n": int(batch["concept"].shape[0]), "B": int(batch["concept"].shape[1]), "T": int(batch["token_in"].shape[0]),
+                 "R": int(batch["relation_bank"].shape[1]),
+                 "mean_path_len": float(batch["relation_length"].float().mean())}
+        assert stats["B"] == B_rank, stats
+        loader_info = {"workers": a.workers, "depth": a.depth, "relbatch_threads": a.relbatch_threads, "pool_graphs_per_rank": pool_n}
+    else:
+        batch, stats = synth.make_config_batch(a.config, rank=rank, B=B_rank)   # rank r holds graphs [r*B_rank, (r+1)*B_rank)
+        attach_relation_index(attach_path_trie(batch))   # host-side index preparation: batch assembly, like the relation bank itself
+        batch = {k: v.to(dev) for k, v in batch.items()}
+    log("batch", stats)
     ops.set_seed(19940117 + rank)
+    wait_s = [0.0]
+
+    def next_batch():
+        if feed is None:
+            return batch
+        t_ = time.perf_counter()
+        b_ = next(feed)
+        wait_s[0] += time.perf_counter() - t_
+        return b_
 
     def sync():
         torch.cuda.synchronize()
@@ -412,26 +471,37 @@ def main():
             torch.cuda.synchronize()
 
     for i in range(a.warmup):
-        v = trainer.step(batch)
+        v = trainer.step(next_batch())
         log("warmup step", i, "loss", v)
     sync()
     log("warmup done")
     ops.PROFILE = {}
     trainer.comm_exposed_s = 0.0
     trainer.comm_exposed_ms()
+    wait_s[0] = 0.0
+    n_asm0 = len(asm_times) if feed is not None else 0
     t0 = time.perf_counter()
     losses = []
     for _ in range(a.steps):
-        losses.append(trainer.step(batch))
+        losses.append(trainer.step(next_batch()))
     sync()
     elapsed = time.perf_counter() - t0
+    my_elapsed = elapsed
+    if feed is not None:
+        done = asm_times[n_asm0:] or asm_times
+        loader_info.update({"host_assembly_s_per_batch": round(sum(done) / max(1, len(done)), 4),
+                            "consumer_wait_ms_per_step": round(1e3 * wait_s[0] / a.steps, 3)})
+        feed.close()                                   # the roofline legs below reuse the first batch the feed handed out
     comm_exposed = max(trainer.comm_exposed_s, 1e-3 * trainer.comm_exposed_ms())   # host wait (gloo) / compute-stream stall (RCCL)
     log("timed region done", elapsed)
     prof, ops.PROFILE = ops.PROFILE, None
-    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    # per-rank view: wall time of the timed region and the compute-stream stall on gradient collectives, gathered on rank 0
+    table = torch.zeros((world, 2), device=dev, dtype=torch.float64)
+    table[rank, 0], table[rank, 1] = my_elapsed, comm_exposed
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+        dist.all_reduce(table)                         # every rank fills its own row (a gather that gloo does on device tensors too)
+    per_rank = table.tolist()
+    elapsed = max(r[0] for r in per_rank)              # MAX over ranks: the job is as slow as its slowest rank
 
     n, B, d, H = stats["n"], stats["B"], cfg["d"], cfg["H"]
     s_el = 2 if cd == torch.bfloat16 else 4
@@ -455,16 +525,23 @@ def main():
                   "graphs/sec training step (%s: %d-node %s graphs, batch %d)" % (a.config, cfg["N"], cfg["kind"], B))
         out = {"metric": metric, "value": world * B * a.steps / elapsed,
                "unit": "graphs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-               "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
+               "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": a.scaling,
                "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-               "config": {"workload": "%s: generator/ %dx%d-node synthetic AMR graphs per GPU, %d-layer d=%d %d-head, "
-                                      "full train step (fwd+bwd+allreduce+clip+Adam), dropout 0.2" % (
-                                          a.config, B, cfg["N"], cfg["layers"], d, H),
+               "config": {"workload": "%s: generator/ %dx%d-node synthetic AMR graphs %s, %d-layer d=%d %d-head, "
+                                      "full train step (fwd+bwd+allreduce+clip+Adam), dropout 0.2%s" % (
+                                          a.config, B, cfg["N"], "per GPU" if a.scaling == "weak" else
+                                          "per GPU = %d in total over %d GPUs (generator/train.py:183)" % (world * B, world),
+                                          cfg["layers"], d, H,
+                                          ", a NEW loader-built batch every step" if a.fresh_batches else ", one pre-built device batch"),
                           "n": n, "B_per_gpu": B, "global_batch": world * B, "P": P, "R": R,
                           "mean_path_len": round(stats["mean_path_len"], 2), "T": stats["T"],
                           "relation_operand": "dense" if a.dense else "factored", "parallelism": "dp%d" % world,
                           "relation_gru": "trie (dropout masks per trie node)" if gru_mod.TRIE else "per row",
-                          "allreduce_exposed_ms_per_step": round(1e3 * comm_exposed / a.steps, 3),
+                          "allreduce_exposed_ms_per_step": round(1e3 * max(r[1] for r in per_rank) / a.steps, 3),
+                          "per_rank_ms_per_step": [round(1e3 * r[0] / a.steps, 3) for r in per_rank],
+                          "per_rank_allreduce_exposed_ms_per_step": [round(1e3 * r[1] / a.steps, 3) for r in per_rank],
+                          "rank_spread_ms_per_step": round(1e3 * (max(r[0] for r in per_rank) - min(r[0] for r in per_rank)) / a.steps, 3),
+                          "loader": loader_info,
                           "loss_first": losses[0], "loss_last": losses[-1]},
                "roofline": roofline, "components": components}
         if world == 1 and not a.no_cpu_baseline:

@@ -231,7 +231,9 @@ class AMRLoader(object):
     ``record()``: (batch, items) pairs, data.py:287-288,313-316); the path sampling of a training batch is seeded from
     ``rng`` per batch.  The graph of every item is recovered from its path lists once, at load time."""
 
-    def __init__(self, vocabs, filename, batch_size, for_train, rng=None, n_threads=0, index_prep=True):
+    def __init__(self, vocabs, filename, batch_size, for_train, rng=None, n_threads=0, index_prep=True, graphs=None):
+        """``graphs``: (n, root, edges) per item when the caller already holds them (gtos_amd.synth.make_amr_items): the items
+        then need no 'relation' path lists."""
         import json
         import random
         if isinstance(filename, str):
@@ -246,7 +248,11 @@ class AMRLoader(object):
         self.record_flag = False
         self.index_prep = index_prep
         self._graphs = {}
-        if vocabs is not None:
+        if graphs is not None:
+            assert len(graphs) == len(self.data)
+            for d, g in zip(self.data, graphs):
+                self._graphs[id(d)] = (vocabs['relation'], d, g)
+        elif vocabs is not None:
             for d in self.data:
                 _item_graph(d, vocabs['relation'], self._graphs)
 

@@ -352,3 +352,35 @@ def synth_vocabs(vocab=None):
             'token_char': SynthVocab(v['token_char'], ['<STR>', '<END>'], chars=True),
             'concept_char': SynthVocab(v['concept_char'], ['<STR>', '<END>'], chars=True),
             'relation': SynthVocab(v['relation'], ['<CLS>', '<rCLS>', '<SELF>', '<TL>'], "r")}
+
+
+def make_amr_items(name, count, first_graph=0, vocabs=None):
+    """A pool of ``count`` synthetic AMR items of a BASELINE config for the LOADER path (gtos_amd.data.AMRLoader ->
+    batchify_amr -> C++ relation batch / tries / index): the same graph family as make_batch (same seeds, same generator),
+    but as what the reference's preprocessing leaves in memory -- concept strings in BFS order, depths, token strings -- plus
+    the graph itself as (n, root, edges[E,3]) in BFS positions, edges sorted by (source, target), which is what
+    data._edges_from_paths recovers from a preprocessed item's length-1 paths.  Returns (items, graphs)."""
+    c = CONFIGS[name]
+    vocabs = vocabs or synth_vocabs()
+    sizes = {k: v.size for k, v in vocabs.items()}
+    n_labels = (sizes["relation"] - REL_FIRST_LABEL) // 2
+    lab_cdf = _zipf_table(n_labels)
+    c_cdf, t_cdf = _zipf_table(sizes["concept"] - 3), _zipf_table(sizes["token"] - 4)
+    items, graphs = [], []
+    for g in range(count):
+        rng = SplitMix64(c["id"] * 10 ** 6 + first_graph + g)
+        N, T = c["N"], c["T"]
+        if c["kind"] == "amr":
+            adj = _amr_graph(rng, N, c["extra_frac"], n_labels, lab_cdf)
+            order, depth = _bfs_order(adj)
+            depth = [min(d, 31) for d in depth]
+        else:
+            adj = _dep_tree(rng, N, n_labels, lab_cdf)
+            order, depth = _bfs_order(adj)
+        pos = {v: i for i, v in enumerate(order)}
+        edges = sorted((pos[u], pos[v], lab) for u in range(N) for v, lab in adj[u])
+        concept = vocabs["concept"].idx2token((3 + _zipf(rng, c_cdf, N)).tolist())
+        token = vocabs["token"].idx2token((4 + _zipf(rng, t_cdf, T - 1)).tolist())
+        items.append({"concept": concept, "depth": depth, "token": token})
+        graphs.append((N, 0, np.array(edges, dtype=np.int32).reshape(-1, 3)))
+    return items, graphs

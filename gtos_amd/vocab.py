@@ -123,16 +123,30 @@ def lists_to_tensor(xs, vocab=None, local_vocabs=None, unk_rate=0., rng=None):
     return torch.tensor(rows, dtype=torch.int64).t().contiguous()
 
 
+_CHAR_ROWS = {}       # (id(vocab), max_string_len) -> {string: id row}; strings repeat heavily (Zipf), the lookup is what costs
+
+
 def strings_to_char_tensor(xs, vocab, max_string_len=20):
-    """Ragged lists of strings -> int64 [max_len, batch, max_string_len + 2] of <STR> chars <END> ids (data.py:100-112)."""
+    """Ragged lists of strings -> int64 [max_len, batch, max_string_len + 2] of <STR> chars <END> ids (data.py:100-112).
+    The id row of a string is computed once per (vocabulary, width) and kept (bounded): batch assembly runs on loader threads
+    beside the training loop, and every Python-level loop it avoids is GIL time the launch thread gets back."""
     width = max(len(x) for x in xs)
-    out = []
-    for x in xs:
-        row = []
-        for z in list(x) + [PAD] * (width - len(x)):
+    key = (id(vocab), max_string_len)
+    ent = _CHAR_ROWS.get(key)
+    if ent is None or ent[0] is not vocab:
+        ent = _CHAR_ROWS[key] = (vocab, {})
+    rows = ent[1]
+    if len(rows) > 2000000:
+        rows.clear()
+
+    def row_of(z):
+        r = rows.get(z)
+        if r is None:
             chars = list(z[:max_string_len])
-            row.append(vocab.token2idx([STR] + chars + [END]) + [vocab.padding_idx] * (max_string_len - len(chars)))
-        out.append(row)
+            r = rows[z] = vocab.token2idx([STR] + chars + [END]) + [vocab.padding_idx] * (max_string_len - len(chars))
+        return r
+    pad_row = row_of(PAD)
+    out = [[row_of(z) for z in x] + [pad_row] * (width - len(x)) for x in xs]
     return torch.tensor(out, dtype=torch.int64).transpose(0, 1).contiguous()
 
 

@@ -1,0 +1,143 @@
+"""BASELINE config C2 at FULL size on the GPU (B = 64 graphs of 100 nodes: R = 434,624 label paths, 2.5 M packed rows).
+
+The oracle comparisons of test_hip_parity.py run 3-graph slices; here the size-dependent machinery of the production path --
+the persistent GRU layer-1 step kernel over all its launches, multi-chunk fp32 slots of heavy trie nodes, range sums over wide
+trie levels, the K = L*2d bank-gradient slab, split-K weight gradients -- is checked at the size bench.py runs:
+  * RelationEncoder forward of the WHOLE bank against the pinned fp32 oracle on the host cores (column chunks: paths are
+    independent sequences), bf16 trie path, bf16 per-row path and the fp32 per-row path;
+  * trie path == per-row path, forward and every parameter gradient (the per-row path is the one the slices pin to the oracle);
+  * one full bf16 Generator forward + backward at B = 64 against the fp32 HIP run of the same weights (fp32 is oracle-pinned at
+    4e-4 on the slices): loss and the whole flat gradient.
+Bars are written next to each assert together with the value measured when the test was introduced."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    assert torch.cuda.is_available(), "gpu-marked tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _rel_frob(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+_C2 = {}
+
+
+def c2_batch():
+    if "b" not in _C2:
+        from gtos_amd import synth
+        from gtos_amd.pathtrie import attach_path_trie
+        from gtos_amd.relindex import attach_relation_index
+        batch, stats = synth.make_config_batch("C2")
+        _C2["b"] = (attach_relation_index(attach_path_trie(batch)), stats)
+    return _C2["b"]
+
+
+def _encoder_pair():
+    """Oracle RelationEncoder (CPU) and the product module (GPU) at train.sh size with the same weights; the GRU matrices are
+    scaled up so that the recurrences matter (default init gives nearly linear cells)."""
+    from gtos_amd import synth
+    from gtos_amd.encoder import RelationEncoder
+    from oracle import gtos_oracle as O
+    V = synth.DEFAULT_VOCAB["relation"]
+    torch.manual_seed(5)
+    ref = O.RelationEncoder(O.VocabSpec(V, 0), 100, 512, 256, 2, 0.0)
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            if n.startswith("rnn.weight"):
+                p.mul_(2.0)
+    m = RelationEncoder(O.VocabSpec(V, 0), 100, 512, 256, 2, 0.0).to(dev())
+    m.load_state_dict(ref.state_dict())
+    return ref, m
+
+
+def _oracle_bank(ref, bank, length, chunk=40000):
+    torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
+    outs = []
+    with torch.no_grad():
+        for lo in range(0, bank.shape[1], chunk):
+            outs.append(ref(bank[:, lo:lo + chunk], length[lo:lo + chunk]))
+    return torch.cat(outs)
+
+
+def test_c2_full_bank_relation_encoder_vs_oracle_and_trie_equals_per_row(monkeypatch):
+    from gtos_amd import gru
+    batch, stats = c2_batch()
+    bank, length, trie = batch["relation_bank"], batch["relation_length"], batch["relation_trie"]
+    R = bank.shape[1]
+    assert R > 400000 and int(length.sum()) > 2000000
+    ref, m = _encoder_pair()
+    want = _oracle_bank(ref, bank, length)                                   # [R, 512] fp32, the whole bank on the host cores
+    bank_d, len_d, trie_d = bank.to(dev()), length.to(dev()), trie.to(dev())
+    wout = torch.randn(R, 512, generator=torch.Generator().manual_seed(1)).to(dev())
+    res = {}
+    for name, dtype, trie_on in (("bf16 trie", torch.bfloat16, True), ("bf16 per-row", torch.bfloat16, False),
+                                 ("fp32 per-row", torch.float32, False)):
+        monkeypatch.setattr(gru, "TRIE", trie_on)
+        m.compute_dtype = dtype
+        m.train()                                                           # dropout 0: train mode only to get the backward
+        m.zero_grad()
+        out = m(bank_d, len_d, trie=trie_d if trie_on else None)
+        (out.float() * wout).sum().backward()
+        torch.cuda.synchronize()
+        res[name] = (out.detach().float().cpu(), {k: p.grad.detach().float().cpu().clone() for k, p in m.named_parameters()})
+        err = (res[name][0] - want).abs()
+        print("C2 full bank, %s: max |err| %.3e, mean %.3e (|out| max %.2f)" % (name, float(err.max()), float(err.mean()),
+                                                                               float(want.abs().max())))
+    # forward vs the oracle: fp32 1e-3 (north_star); bf16 1e-2 of the output scale
+    scale = float(want.abs().max())
+    assert float((res["fp32 per-row"][0] - want).abs().max()) < 1e-3 * max(1.0, scale)
+    for name in ("bf16 trie", "bf16 per-row"):
+        assert float((res[name][0] - want).abs().max()) < 1e-2 * max(1.0, scale), name
+    # trie == per-row in bf16 (different summation trees, same function) ...
+    assert float((res["bf16 trie"][0] - res["bf16 per-row"][0]).abs().max()) < 1e-2 * max(1.0, scale)
+    # ... and every parameter gradient: both bf16 paths against the fp32 run of the same batch (oracle-pinned at slice size)
+    g32 = res["fp32 per-row"][1]
+    worst = {}
+    for k in g32:
+        e_t, e_r = _rel_frob(res["bf16 trie"][1][k], g32[k]), _rel_frob(res["bf16 per-row"][1][k], g32[k])
+        worst[k] = (e_t, e_r)
+    print("C2 full bank, relative gradient error vs fp32 (trie, per-row):",
+          ", ".join("%s %.3g/%.3g" % (k, a, b) for k, (a, b) in sorted(worst.items(), key=lambda kv: -kv[1][0])))
+    for k, (e_t, e_r) in worst.items():
+        assert e_t < max(3e-2, 1.5 * e_r), (k, e_t, e_r)
+
+
+def test_c2_full_batch_generator_bf16_vs_fp32_hip():
+    """One fwd + bwd of the full model at B = 64 (dropout 0): bf16 production path (tries, factored attention, K = 8192 bank
+    gradient slab) vs the fp32 parity path of the same library on the same weights and batch."""
+    from gtos_amd.config import build_generator
+    from gtos_amd.generator import Generator
+    batch, stats = c2_batch()
+    db = {k: v.to(dev()) for k, v in batch.items()}
+    res = {}
+    for dtype in (torch.float32, torch.bfloat16):
+        m = build_generator(Generator, "C2", dev(), dropout=0.0).to(dev())
+        m.set_compute_dtype(dtype)
+        m.train()
+        loss = m(db)
+        loss.backward()
+        torch.cuda.synchronize()
+        res[dtype] = (float(loss), {k: p.grad.detach().float().cpu() for k, p in m.named_parameters()})
+        del m, loss
+        torch.cuda.empty_cache()
+    l32, g32 = res[torch.float32]
+    l16, g16 = res[torch.bfloat16]
+    num = sum(float((g16[k].double() - g32[k].double()).pow(2).sum()) for k in g32)
+    den = sum(float(g32[k].double().pow(2).sum()) for k in g32)
+    glob = (num / den) ** 0.5
+    table = sorted(((_rel_frob(g16[k], g32[k]), k, float(g32[k].norm())) for k in g32), reverse=True)
+    print("C2 B=64: loss bf16 %.6f vs fp32 %.6f; global relative gradient error %.4f; worst tensors: %s" % (
+        l16, l32, glob, ", ".join("%s %.3g" % (k, e) for e, k, _ in table[:6])))
+    assert abs(l16 - l32) < 1e-2 * max(1.0, abs(l32)), (l16, l32)
+    assert glob < 6e-2, glob                       # the slices' bar (test_hip_parity.BF16_GRAD_GLOBAL)
+    gmax = max(nrm for _, _, nrm in table)
+    for e, k, nrm in table:
+        if nrm > 1e-4 * gmax:
+            assert e < 0.3, (k, e, nrm)

@@ -1193,6 +1193,41 @@ def test_bench_two_ranks_on_one_gpu_functional():
     assert "allreduce_exposed_ms_per_step" in d["config"]
 
 
+def _bench_line(args, env_extra=None, timeout=900):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_strong_scaling_two_ranks_on_one_gpu_functional():
+    """`--scaling strong`: the batch is B graphs in TOTAL (generator/train.py:183 divides the batch budget by the world
+    size), rank r holds graphs [r*B/N, (r+1)*B/N); per-rank timing and exposed all-reduce time are reported."""
+    d = _bench_line(["--gpus", "2", "--config", "C1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--scaling", "strong"],
+                    dict(GTOS_ONE_DEVICE="1", GTOS_DIST_BACKEND="gloo"))
+    c = d["config"]
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and c["global_batch"] == 8 and c["B_per_gpu"] == 4
+    assert len(c["per_rank_ms_per_step"]) == 2 and all(v > 0 for v in c["per_rank_ms_per_step"])
+    assert abs(d["ms_per_step"] - max(c["per_rank_ms_per_step"])) < 1e-6 and c["rank_spread_ms_per_step"] >= 0
+    assert d["value"] > 0 and np.isfinite(c["loss_last"])
+
+
+def test_bench_fresh_batches_loader_in_the_loop():
+    """`--fresh-batches`: AMRLoader thunks -> Prefetcher workers (C++ relation batch, tries, index; upload on a copy stream)
+    -> Trainer.step, a new batch every step."""
+    d = _bench_line(["--config", "C1", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--fresh-batches", "--workers", "2"],
+                    dict(GTOS_BENCH_NO_DETAIL="1"))
+    ld = d["config"]["loader"]
+    assert ld["workers"] == 2 and ld["host_assembly_s_per_batch"] > 0 and ld["consumer_wait_ms_per_step"] >= 0
+    assert d["config"]["B_per_gpu"] == 8 and d["value"] > 0 and np.isfinite(d["config"]["loss_last"])
+    assert "NEW loader-built batch" in d["config"]["workload"]
+
+
 @pytest.mark.parametrize("rows", [300, 40000 + 77])
 def test_gru_layer1_step_kernel_vs_torch(rows):
     """One forward step of the second GRU layer (gate tables gathered by node id) against plain torch fp32 on the same bf16
