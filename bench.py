@@ -481,11 +481,14 @@ def main():
     wait_s[0] = 0.0
     n_asm0 = len(asm_times) if feed is not None else 0
     t0 = time.perf_counter()
-    losses = []
+    pend = []
     for _ in range(a.steps):
-        losses.append(trainer.step(next_batch()))
+        # the abnormal-loss rule and the lr schedule run on the device (gtos_step_control): no host read of the loss inside
+        # the step; the values are read after the timed region
+        pend.append(trainer.step(next_batch(), sync=False))
     sync()
     elapsed = time.perf_counter() - t0
+    losses = [p_.value() for p_ in pend]
     my_elapsed = elapsed
     if feed is not None:
         done = asm_times[n_asm0:] or asm_times

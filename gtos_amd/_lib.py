@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgtos_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 c_p, c_i, c_l, c_f, c_u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_uint64
 
@@ -43,6 +43,8 @@ SIGNATURES = {
     "gtos_sqnorm": [c_l, c_p, c_p, c_p],
     "gtos_adam_step": [c_l, c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_f, c_p, c_p],
     "gtos_cast_f32_to_bf16": [c_l, c_p, c_p, c_p],
+    "gtos_step_control": [c_i, c_p, c_p, c_p, c_i, c_i, c_p, c_p],
+    "gtos_adam_step_ctl": [c_l, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_f, c_f, c_p, c_f, c_p, c_p],
 }
 
 _lib = None

@@ -568,7 +568,12 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(int64_t n, const float* __r
 // min(1, max_norm / (gscale*sqrt(sqnorm) + 1e-6)) read from device memory (no host sync).
 __global__ void adam_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, float lr, float b1, float b2, float eps, float wd, float gscale,
-                            const float* __restrict__ sqnorm, float max_norm, bf16_t* __restrict__ mirror) {
+                            const float* __restrict__ sqnorm, float max_norm, bf16_t* __restrict__ mirror,
+                            const float* __restrict__ ctl) {
+    if (ctl) {                                   // device-side step control: {lr of this step, skip flag} (step_control_kernel)
+        if (ctl[1] != 0.f) return;               // batch discarded: parameters and moments stay as they are
+        lr = ctl[0];
+    }
     float coef = gscale;
     if (sqnorm) { const float nrm = gscale * sqrtf(*sqnorm); coef *= fminf(1.f, max_norm / (nrm + 1e-6f)); }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -579,6 +584,34 @@ __global__ void adam_kernel(int64_t n, float* __restrict__ p, const float* __res
         m[i] = mi; v[i] = vi; p[i] = pi;
         if (mirror) mirror[i] = f2bf(pi);
     }
+}
+
+// The abnormal-loss rule and the learning-rate schedule of the training loop (/root/reference/generator/train.py:81-83,
+// 142-148) on the device, so the step needs no host read of the loss between forward and backward:
+//   phase 0: flag = batches_acm > warmup && loss > 5 * loss_acm / batches_acm        (this rank's decision)
+//   (data parallel: the caller all-reduces `flag` with MAX -- a rank-local skip would desynchronise the collectives)
+//   phase 1: flag != 0 -> discarded += 1, ctl = {*, 1};  else loss_acm += loss, batches_acm += 1,
+//            ctl = {embed^-0.5 * min(s^-0.5, s * warmup^-1.5) with s = batches_acm, 0}
+// state = {loss_acm, batches_acm, discarded} in double (the reference keeps Python floats).
+__global__ void step_control_kernel(int phase, const float* __restrict__ loss, double* __restrict__ state, float* __restrict__ flag,
+                                    double warmup, double embed_dim, float* __restrict__ ctl) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double l = (double)*loss;
+    if (phase == 0) {
+        *flag = (state[1] > warmup && l > 5.0 * (state[0] / state[1])) ? 1.f : 0.f;
+        return;
+    }
+    if (*flag != 0.f) {
+        state[2] += 1.0;
+        ctl[1] = 1.f;
+        return;
+    }
+    state[0] += l;
+    state[1] += 1.0;
+    const double s = state[1];
+    const double a = 1.0 / sqrt(s), b = s / (warmup * sqrt(warmup));
+    ctl[0] = (float)((1.0 / sqrt(embed_dim)) * (a < b ? a : b));
+    ctl[1] = 0.f;
 }
 
 __global__ void cast_bf16_kernel(int64_t n, const float* __restrict__ src, bf16_t* __restrict__ dst) {
@@ -777,7 +810,28 @@ extern "C" int gtos_adam_step(int64_t n, float* p, const float* g, float* m, flo
     if (n <= 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256 * 4)), dim3(256), 0, s, n, p, g, m, v, lr, beta1, beta2, eps, weight_decay,
-                       gscale, sqnorm, max_norm, (bf16_t*)bf16_mirror);
+                       gscale, sqnorm, max_norm, (bf16_t*)bf16_mirror, (const float*)nullptr);
+    GTOS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gtos_adam_step_ctl(int64_t n, float* p, const float* g, float* m, float* v, const float* ctl, float beta1, float beta2,
+                                  float eps, float weight_decay, float gscale, const float* sqnorm, float max_norm,
+                                  void* bf16_mirror, void* stream) {
+    if (n <= 0) return 0;
+    if (!ctl) return -23;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256 * 4)), dim3(256), 0, s, n, p, g, m, v, 0.f, beta1, beta2, eps, weight_decay,
+                       gscale, sqnorm, max_norm, (bf16_t*)bf16_mirror, ctl);
+    GTOS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gtos_step_control(int phase, const float* loss, double* state, float* flag, int warmup_steps, int embed_dim,
+                                 float* ctl, void* stream) {
+    if ((phase != 0 && phase != 1) || !loss || !state || !flag || !ctl || warmup_steps < 1 || embed_dim < 1) return -23;
+    hipLaunchKernelGGL(step_control_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), phase, loss, state, flag,
+                       (double)warmup_steps, (double)embed_dim, ctl);
     GTOS_CHECK_LAUNCH();
     return 0;
 }
@@ -790,4 +844,4 @@ extern "C" int gtos_cast_f32_to_bf16(int64_t n, const float* src, void* dst, voi
     return 0;
 }
 
-extern "C" int gtos_abi_version(void) { return 9; }
+extern "C" int gtos_abi_version(void) { return 10; }

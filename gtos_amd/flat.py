@@ -97,8 +97,10 @@ class FlatParams:
         call("gtos_sqnorm", self.total, ptr(self.grad), ptr(self.sqnorm), stream())
         return self.sqnorm.sqrt() * gscale
 
-    def step(self, lr, gscale=1.0, max_norm=1.0):
-        """gscale = 1/world_size after a SUM all-reduce.  Clips by global norm then applies Adam."""
+    def step(self, lr, gscale=1.0, max_norm=1.0, ctl=None):
+        """gscale = 1/world_size after a SUM all-reduce.  Clips by global norm then applies Adam.  ``ctl``: device fp32[2] =
+        {learning rate, skip flag} written by gtos_step_control (train.Trainer); then ``lr`` is ignored and a set skip flag
+        leaves parameters and moments untouched -- the whole decision stays on the device."""
         _ops.join_side()                   # deferred side-stream gradient work must have landed in self.grad
         if self.steps == 0:
             self.check_views()
@@ -108,6 +110,11 @@ class FlatParams:
         es = 4
         for lo, hi, wd in self.adam_ranges:
             mir = None if self.mirror is None else self.mirror.data_ptr() + lo * self.mirror.element_size()
+            if ctl is not None:
+                call("gtos_adam_step_ctl", hi - lo, self.param.data_ptr() + lo * es, self.grad.data_ptr() + lo * es,
+                     self.m.data_ptr() + lo * es, self.v.data_ptr() + lo * es, ptr(ctl), b1, b2, self.eps, wd,
+                     float(gscale), ptr(self.sqnorm), float(max_norm), mir, stream())
+                continue
             call("gtos_adam_step", hi - lo, self.param.data_ptr() + lo * es, self.grad.data_ptr() + lo * es,
                  self.m.data_ptr() + lo * es, self.v.data_ptr() + lo * es, float(lr), b1, b2, self.eps, wd,
                  float(gscale), ptr(self.sqnorm), float(max_norm), mir, stream())

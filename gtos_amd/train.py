@@ -6,8 +6,11 @@ Counterpart of the hot loop of /root/reference/generator/train.py:136-154: forwa
     sentence encoder -> graph encoder -> input encoders); each segment is all-reduced (RCCL over xGMI, async) from inside
     backward as soon as the autograd graph has passed the segment's boundary, so only the last segment's collective is
     exposed -- instead of 182 blocking per-parameter all-reduces after backward (train.py:74-79);
-  * the abnormal-loss skip (train.py:142-145) is decided COLLECTIVELY (max over ranks), because the reference's
-    rank-local ``continue`` would desynchronise the collective sequence;
+  * the abnormal-loss skip (train.py:142-145) and the lr schedule are evaluated ON THE DEVICE (gtos_step_control): the host
+    never reads the loss between forward and backward, so the launch queue stays full (the reference's ``loss.item()`` in
+    front of ``backward`` drains it every step).  A discarded batch still runs its backward; the Adam kernel reads the skip
+    flag and leaves parameters and moments untouched.  Data parallel, the decision is COLLECTIVE (MAX all-reduce of the
+    flag on the device), because the reference's rank-local ``continue`` would desynchronise the collective sequence;
   * dropout streams are decorrelated across ranks by seeding the hash stream with base + rank after the (identical)
     weight initialisation, like train.py:113-116.
 """
@@ -17,7 +20,8 @@ import torch
 import torch.distributed as dist
 
 from . import ops
-from .flat import FlatParams, inverse_sqrt_lr
+from ._lib import call, ptr, stream
+from .flat import FlatParams
 
 # segment 0 finishes first in backward.  The LAST segment is reduced after backward() returned (it holds everything whose
 # gradient is only known to be complete then: the input encoders, the relation GRU's side-stream weight gradients).
@@ -59,7 +63,11 @@ class Trainer:
             names = [n for n, _ in model.named_parameters()]
             segment_of = generator_segment_of if any(n.startswith("graph_encoder.") for n in names) else None
         self.flat = FlatParams(model, mirror_dtype=compute_dtype, segment_of=segment_of)
-        self.batches_acm, self.loss_acm, self.discarded = 0, 0.0, 0
+        dev = self.flat.param.device
+        self._state = torch.zeros(3, dtype=torch.float64, device=dev)       # {loss_acm, batches_acm, discarded}, device-resident
+        self._flag = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._ctl = torch.zeros(2, dtype=torch.float32, device=dev)         # {lr of this step, skip}
+        self.steps_issued = 0           # host-side count of step() calls: an upper bound of batches_acm (no device read needed)
         self.collective = world_size > 1 or force_collectives
         self.overlap = overlap and self.collective and len(self.flat.segments) > 1
         self._launched = 0              # segments [0, _launched) have their all-reduce in flight
@@ -114,23 +122,59 @@ class Trainer:
             self._comm_events = []
         return ms
 
-    def step(self, batch):
-        """Returns the loss value (float) of this step, or None when the batch was discarded."""
+    # ---- counters of the reference loop, kept on the device; reading them synchronises
+    @property
+    def batches_acm(self):
+        return int(self._state[1].item())
+
+    @property
+    def loss_acm(self):
+        return float(self._state[0].item())
+
+    @property
+    def discarded(self):
+        return int(self._state[2].item())
+
+    def set_counters(self, batches_acm, loss_acm, discarded=0):
+        """Resume from a checkpoint (train.py keeps batches_acm / loss_acm across restarts)."""
+        self._state.copy_(torch.tensor([float(loss_acm), float(batches_acm), float(discarded)], dtype=torch.float64))
+        self.steps_issued = int(batches_acm) + int(discarded)
+
+    def _control(self, phase, loss):
+        """gtos_step_control: phase 0 writes this rank's abnormal-loss flag, phase 1 applies the (all-reduced) flag to the
+        counters and writes {lr, skip} for the Adam kernel."""
+        call("gtos_step_control", phase, ptr(loss), ptr(self._state), ptr(self._flag), int(self.warmup_steps), int(self.embed_dim),
+             ptr(self._ctl), stream())
+
+    def step(self, batch, sync=True):
+        """One training step.  ``sync=True`` returns the loss value (float), or None when the batch was discarded -- one host
+        read AFTER every launch of the step has been queued.  ``sync=False`` returns a PendingLoss (``.value()`` reads it
+        later): the host runs ahead into the next step, which is what the launch-bound small configurations need."""
         loss = self.model(batch)
-        loss_value = loss.item()
-        abnormal = self.batches_acm > self.warmup_steps and loss_value > 5. * (self.loss_acm / self.batches_acm)
-        if self.collective and self.batches_acm > self.warmup_steps:
-            flag = torch.tensor([1.0 if abnormal else 0.0], device=loss.device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            abnormal = bool(flag.item() > 0)
-        if abnormal:
-            self.discarded += 1
-            return None
-        self.loss_acm += loss_value
-        self.batches_acm += 1
+        loss = loss if loss.dtype == torch.float32 else loss.float()
+        self._control(0, loss.detach())
+        if self.collective and self.steps_issued > self.warmup_steps:       # batches_acm <= steps_issued: never needed earlier
+            dist.all_reduce(self._flag, op=dist.ReduceOp.MAX)
+        self._control(1, loss.detach())
+        self.steps_issued += 1
         loss.backward()
         self.all_reduce_grads()
-        lr = inverse_sqrt_lr(self.embed_dim, self.batches_acm, self.warmup_steps)
-        self.flat.step(lr, gscale=1.0 / self.world_size, max_norm=1.0)
+        self.flat.step(None, gscale=1.0 / self.world_size, max_norm=1.0, ctl=self._ctl)
         self.flat.zero_grad()
-        return loss_value
+        res = PendingLoss(torch.cat([loss.detach().reshape(1), self._flag]))
+        return res.value() if sync else res
+
+
+class PendingLoss:
+    """Loss and skip flag of a step, still on the device."""
+
+    def __init__(self, pair):
+        self._pair, self._val = pair, False
+
+    def value(self):
+        """float, or None when the batch was discarded by the abnormal-loss rule."""
+        if self._val is False:
+            v, f = self._pair.tolist()
+            self._val = None if f > 0 else v
+            self._pair = None
+        return self._val

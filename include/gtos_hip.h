@@ -194,6 +194,20 @@ int gtos_adam_step(int64_t n, float* p, const float* g, float* m, float* v, floa
                    void* bf16_mirror, void* stream);
 int gtos_cast_f32_to_bf16(int64_t n, const float* src, void* dst, void* stream);
 
+/* The abnormal-loss rule and the learning-rate schedule of the training loop (generator/train.py:81-83,142-148) decided ON
+ * THE DEVICE, so no host read of the loss sits between forward and backward.  loss: fp32 scalar; state: double[3] =
+ * {loss_acm, batches_acm, discarded}; flag: fp32 scalar; ctl: fp32[2] = {learning rate of this step, skip}.
+ *   phase 0: flag = batches_acm > warmup_steps && loss > 5 * loss_acm / batches_acm
+ *   (data parallel: the caller MAX-all-reduces flag between the phases)
+ *   phase 1: flag != 0 -> discarded += 1, ctl[1] = 1; else loss_acm += loss, batches_acm += 1, ctl = {lr(batches_acm), 0}
+ *            with lr(s) = embed_dim^-0.5 * min(s^-0.5, s * warmup_steps^-1.5).
+ * gtos_adam_step_ctl = gtos_adam_step with the learning rate read from ctl[0] and no update at all when ctl[1] != 0. */
+int gtos_step_control(int phase, const float* loss, double* state, float* flag, int warmup_steps, int embed_dim,
+                      float* ctl, void* stream);
+int gtos_adam_step_ctl(int64_t n, float* p, const float* g, float* m, float* v, const float* ctl, float beta1, float beta2,
+                       float eps, float weight_decay, float gscale, const float* sqnorm, float max_norm,
+                       void* bf16_mirror, void* stream);
+
 /* Fused generate/copy mixture of TokenGenerator (generator/decoder.py:40-63): vocabulary softmax, 2-way diverter softmax,
  * gen_gate * p_vocab extended by the per-graph copy ids, scatter_add of copy_gate * alignment weights at cp_seq, log(p + 1e-12).
  * logits [T,B,V] (row stride ld_logits) and div [T,B,2] share `dtype`; align fp32 [T,B,S] (head-max alignment weights),

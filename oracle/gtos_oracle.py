@@ -581,10 +581,32 @@ def generator_work(model, data, vocabs, beam_size, max_time_step, min_time_step=
 
 
 # --------------------------------------------------------------------------------------
-# optimizer step   (generator/adam.py:28-87, generator/train.py:81-83,123-132,151)
+# optimizer step   (generator/adam.py:28-87, generator/train.py:81-83,123-132,136-148,151)
 # --------------------------------------------------------------------------------------
 def inverse_sqrt_lr(embed_size, step, warmup_steps):
     return embed_size ** -0.5 * min(step ** -0.5, step * (warmup_steps ** -1.5))
+
+
+class LoopCounters(object):
+    """The bookkeeping of the training loop around the optimizer (generator/train.py:136-148): a batch whose loss exceeds
+    5x the running mean after the warm-up is discarded (``continue`` before backward); otherwise loss_acm / batches_acm
+    advance and the learning rate of the update is inverse_sqrt_lr(embed, batches_acm, warmup)."""
+
+    def __init__(self, embed_size, warmup_steps):
+        self.embed_size, self.warmup_steps = embed_size, warmup_steps
+        self.loss_acm, self.batches_acm, self.discarded = 0.0, 0, 0
+
+    def abnormal(self, loss_value):
+        return self.batches_acm > self.warmup_steps and loss_value > 5. * (self.loss_acm / self.batches_acm)
+
+    def advance(self, loss_value, discard):
+        """-> learning rate of this step's update, or None when the batch is discarded."""
+        if discard:
+            self.discarded += 1
+            return None
+        self.loss_acm += loss_value
+        self.batches_acm += 1
+        return inverse_sqrt_lr(self.embed_size, self.batches_acm, self.warmup_steps)
 
 
 def adam_step(p, g, m, v, lr, weight_decay, beta1=0.9, beta2=0.999, eps=1e-6):

@@ -69,10 +69,32 @@ def test_flat_bucket_allreduce_matches_per_parameter():
 # Trainer.step itself with world_size 2 (SURVEY section 7 test vi): the HIP optimizer kernels are replaced by the oracle's
 # CPU Adam / clip (same arithmetic), everything else -- segment layout, boundary markers, async all-reduce launch order,
 # join_side, the 1/W fold, the collective abnormal-loss flag -- is the product code.
-def _cpu_flat_step(self, lr, gscale=1.0, max_norm=1.0):
+def _cpu_control(self, phase, loss):
+    """Trainer._control (gtos_step_control on the GPU) through the oracle's restatement of the loop bookkeeping
+    (generator/train.py:136-148), on the trainer's own state tensors."""
+    from oracle import gtos_oracle as O
+    c = O.LoopCounters(self.embed_dim, self.warmup_steps)
+    c.loss_acm, c.batches_acm, c.discarded = float(self._state[0]), int(self._state[1]), int(self._state[2])
+    if phase == 0:
+        self._flag[0] = 1.0 if c.abnormal(float(loss)) else 0.0
+        return
+    lr = c.advance(float(loss), bool(self._flag[0] > 0))
+    self._state.copy_(torch.tensor([c.loss_acm, c.batches_acm, c.discarded], dtype=torch.float64))
+    if lr is None:
+        self._ctl[1] = 1.0
+    else:
+        self._ctl[0], self._ctl[1] = lr, 0.0
+
+
+def _cpu_flat_step(self, lr, gscale=1.0, max_norm=1.0, ctl=None):
     from oracle import gtos_oracle as O
     from gtos_amd import ops
     ops.join_side()
+    if ctl is not None:
+        if float(ctl[1]) != 0.0:
+            self.steps += 1
+            return
+        lr = float(ctl[0])
     g = self.grad * gscale
     coef, _ = O.clip_coef([g], max_norm)
     for lo, hi, wd in self.adam_ranges:
@@ -114,6 +136,7 @@ def _trainer_worker(rank, world, port, q, kind, steps):
     import gtos_amd.train as train_mod
     from gtos_amd import ops
     flat_mod.FlatParams.step = _cpu_flat_step
+    train_mod.Trainer._control = _cpu_control
     log = []
     if world > 1:
         os.environ["MASTER_ADDR"] = "127.0.0.1"

@@ -1340,3 +1340,51 @@ def test_trainer_step_on_rccl_single_rank():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_step_check.py")], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "rccl step check ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_device_side_step_control_matches_the_reference_loop_bookkeeping():
+    """gtos_step_control + gtos_adam_step_ctl against the oracle's restatement of generator/train.py:136-148: running mean,
+    the 5x abnormal-loss rule after the warm-up, the lr schedule -- and a discarded batch leaves parameters, moments and the
+    bf16 mirror untouched while the counters advance exactly like the reference's."""
+    from gtos_amd.train import Trainer
+    from oracle import gtos_oracle as O
+    torch.manual_seed(3)
+    model = torch.nn.Sequential(torch.nn.Linear(16, 8), torch.nn.Tanh(), torch.nn.Linear(8, 1)).to(dev())
+
+    class Wrap(torch.nn.Module):
+        def __init__(self, net):
+            super().__init__()
+            self.net = net
+
+        def forward(self, batch):
+            x, scale = batch
+            return (self.net(x).pow(2).mean() + 1.0) * scale
+    m = Wrap(model)
+    tr = Trainer(m, 64, warmup_steps=3, compute_dtype=torch.bfloat16, segment_of=None)
+    ref = O.LoopCounters(64, 3)
+    x = torch.randn(32, 16, device=dev())
+    scales = [1.0, 1.1, 0.9, 1.0, 1.05, 40.0, 1.0, 30.0, 0.95]          # steps 5 and 7 exceed 5x the running mean after warm-up
+    pending = []
+    for k, sc in enumerate(scales):
+        before = (tr.flat.param.clone(), tr.flat.m.clone(), tr.flat.v.clone(), tr.flat.mirror.clone())
+        res = tr.step((x, torch.tensor(sc, device=dev())), sync=(k % 2 == 0))
+        val = res if (k % 2 == 0) else res.value()
+        # the oracle's view of the same step (the loss value is the device's own: this checks the bookkeeping, not the model)
+        lossv = val if val is not None else None
+        if lossv is None:
+            assert k in (5, 7), k
+            assert ref.abnormal(1e9)                                      # past the warm-up: a huge loss is abnormal for the oracle too
+            ref.advance(0.0, True)
+            for a, b in zip(before, (tr.flat.param, tr.flat.m, tr.flat.v, tr.flat.mirror)):
+                assert torch.equal(a, b)                                  # nothing moved
+        else:
+            assert not ref.abnormal(lossv), (k, lossv)
+            lr = ref.advance(lossv, False)
+            assert abs(float(tr._ctl[0]) - lr) < 1e-6 * lr
+            assert not torch.equal(before[0], tr.flat.param)
+        assert tr.batches_acm == ref.batches_acm and tr.discarded == ref.discarded
+        assert abs(tr.loss_acm - ref.loss_acm) < 1e-5 * max(1.0, abs(ref.loss_acm))
+        assert float(tr.flat.grad.abs().max()) == 0.0
+    assert tr.discarded == 2 and tr.batches_acm == 7 and tr.steps_issued == 9
+    tr.set_counters(100, 250.0, 3)
+    assert tr.batches_acm == 100 and tr.discarded == 3 and tr.steps_issued == 103
