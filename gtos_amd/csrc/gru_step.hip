@@ -37,6 +37,7 @@ struct StepArgs {
     const bf16_t* gf; const int* gf_idx; const bf16_t* gb; const int* gb_idx;     // MODE 2: xg = gf[gf_idx[m]] + gb[gb_idx[m]] + b_ih
     const bf16_t* h_in; const int* h_idx; const bf16_t* w_hh; const float* b_hh;   // h_idx: row m enters with h_in[h_idx[m]]
     bf16_t* h_out; int n_out; bf16_t* h_fin; bf16_t* gates; bf16_t* y; int64_t ldy;
+    int64_t ld_fin; const int* fin_idx;            // a finished row m goes to h_fin[(fin_idx ? fin_idx[m] : m) * ld_fin + channel]
     float p_drop; uint64_t seed; int64_t drop_base;
     int rows, hs; const void* zeros;
 };
@@ -271,7 +272,8 @@ __global__ __launch_bounds__(256, 2) void gru_step_fwd_kernel(StepArgs a) {
         }
         bf16_t* gp = a.gates + (int64_t)m * 4 * hs + cb;
         st16(gp, gr); st16(gp + hs, gz); st16(gp + 2 * hs, gn); st16(gp + 3 * hs, hn);
-        bf16_t* hdst = (m < a.n_out ? a.h_out : a.h_fin) + (int64_t)m * hs + cb;
+        bf16_t* hdst = m < a.n_out ? a.h_out + (int64_t)m * hs + cb
+                                   : a.h_fin + (int64_t)(a.fin_idx ? a.fin_idx[m] : m) * a.ld_fin + cb;
         st16(hdst, o);
         if (a.y) {
             if (a.p_drop > 0.f) {
@@ -431,7 +433,8 @@ __global__ __launch_bounds__(256, 1) void gru_l1_fwd_persistent_kernel(StepArgs 
             if (m < a.rows) {
                 bf16_t* gp = a.gates + (int64_t)m * 4 * HS + cb;
                 st16(gp, gr); st16(gp + HS, gz); st16(gp + 2 * HS, gn); st16(gp + 3 * HS, hn);
-                bf16_t* hdst = (m < a.n_out ? a.h_out : a.h_fin) + (int64_t)m * HS + cb;
+                bf16_t* hdst = m < a.n_out ? a.h_out + (int64_t)m * HS + cb
+                                           : a.h_fin + (int64_t)(a.fin_idx ? a.fin_idx[m] : m) * a.ld_fin + cb;
                 st16(hdst, o);
             }
         }
@@ -452,7 +455,8 @@ __global__ __launch_bounds__(256, 1) void gru_l1_fwd_persistent_kernel(StepArgs 
 struct StepBwdArgs {
     const bf16_t* d4_prev; int rows_prev; const bf16_t* wh_t;
     const bf16_t* gates; const bf16_t* hprev; const int* hprev_idx; const bf16_t* dy; int64_t ldy;
-    void* dh; int dh_bf16; bf16_t* d4; float* bias_part; int n_partials;
+    void* dh; int dh_bf16; int64_t ld_dh; bf16_t* d4; float* bias_part; int n_partials;
+    bf16_t* hp_out;                                // optional [rows,hs]: the (gathered) entering state of every row, written compactly
     float p_drop; uint64_t seed; int64_t drop_base;
     int rows, hs; const void* zeros;
 };
@@ -535,8 +539,8 @@ __global__ __launch_bounds__(256, 3) void gru_step_bwd_kernel(StepBwdArgs a) {
         const bf16_t* gp = a.gates + (int64_t)m * 4 * hs + cb;
         ld16(gp, gr); ld16(gp + hs, gz); ld16(gp + 2 * hs, gn); ld16(gp + 3 * hs, hn);
         ld16(a.hprev + (int64_t)(a.hprev_idx ? a.hprev_idx[m] : m) * hs + cb, hp);
-        float* dhp = static_cast<float*>(a.dh) + (int64_t)m * hs + cb;
-        bf16_t* dhb = static_cast<bf16_t*>(a.dh) + (int64_t)m * hs + cb;
+        float* dhp = static_cast<float*>(a.dh) + (int64_t)m * a.ld_dh + cb;
+        bf16_t* dhb = static_cast<bf16_t*>(a.dh) + (int64_t)m * a.ld_dh + cb;
         if (a.dh_bf16) ld16(dhb, g); else ldf16(dhp, g);
 #pragma unroll
         for (int i = 0; i < 16; ++i) g[i] += acc[mt][i >> 2][i & 3];
@@ -572,6 +576,7 @@ __global__ __launch_bounds__(256, 3) void gru_step_bwd_kernel(StepBwdArgs a) {
             }
             bf16_t* dp = a.d4 + (int64_t)m * 4 * hs + cb;
             st16(dp, dr_); st16(dp + hs, dz_); st16(dp + 2 * hs, dn_); st16(dp + 3 * hs, dhn);
+            if (a.hp_out) st16(a.hp_out + (int64_t)m * hs + cb, hp);     // operand rows of the recurrent weight gradient
         }
         if (a.bias_part) {
             // bias gradients: column sums of the values as stored (rounded), reduced over the 16 rows of this lane group
@@ -600,12 +605,13 @@ __global__ __launch_bounds__(256, 3) void gru_step_bwd_kernel(StepBwdArgs a) {
 extern "C" int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, int in_dim, const void* w_ih, const float* b_ih,
                                  const void* xg, const void* gf, const int* gf_idx, const void* gb, const int* gb_idx,
                                  const void* h_in, const int* h_idx, const void* w_hh, const float* b_hh,
-                                 void* h_out, int n_out, void* h_fin, void* gates, void* y, int64_t ldy,
+                                 void* h_out, int n_out, void* h_fin, int64_t ld_fin, const int* fin_idx, void* gates, void* y, int64_t ldy,
                                  float p_drop, uint64_t seed, int64_t drop_base, void* stream) {
     if (rows <= 0) return 0;
     if (hs <= 0 || hs % TC) return -22;
     if (!h_in || !w_hh || !b_hh || !gates) return -23;
     if ((n_out > 0 && !h_out) || (n_out < rows && !h_fin)) return -23;
+    if (h_fin && (ld_fin < hs || ld_fin % 8)) return -25;
     const int mode = x ? 1 : (gf ? 2 : 0);
     if (mode == 1) {
         if (!w_ih || !b_ih || in_dim <= 0 || in_dim % 8 || ldx % 8 || (uintptr_t)x % 16 || (uintptr_t)w_ih % 16) return -24;
@@ -620,6 +626,7 @@ extern "C" int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, i
     a.gf = (const bf16_t*)gf; a.gf_idx = gf_idx; a.gb = (const bf16_t*)gb; a.gb_idx = gb_idx;
     a.h_in = (const bf16_t*)h_in; a.h_idx = h_idx; a.w_hh = (const bf16_t*)w_hh; a.b_hh = b_hh;
     a.h_out = (bf16_t*)h_out; a.n_out = n_out; a.h_fin = (bf16_t*)h_fin; a.gates = (bf16_t*)gates; a.y = (bf16_t*)y; a.ldy = ldy;
+    a.ld_fin = ld_fin; a.fin_idx = fin_idx;
     a.p_drop = p_drop; a.seed = seed; a.drop_base = drop_base; a.rows = rows; a.hs = hs;
     a.zeros = gtos_zero_block();
     if (!a.zeros) return -5;
@@ -651,18 +658,19 @@ extern "C" int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, i
 
 extern "C" int gtos_gru_step_bwd(int rows, int hs, const void* d4_prev, int rows_prev, const void* w_hh_t,
                                  const void* gates, const void* hprev, const int* hprev_idx, const void* dy, int64_t ldy, void* dh, int dh_dtype,
-                                 void* d4, float p_drop, uint64_t seed, int64_t drop_base, float* bias_partials,
-                                 int n_partials, void* stream) {
+                                 int64_t ld_dh, void* d4, float p_drop, uint64_t seed, int64_t drop_base, float* bias_partials,
+                                 int n_partials, void* hprev_out, void* stream) {
     if (rows <= 0) return 0;
     if (hs <= 0 || hs % TC) return -22;
     if (!gates || !hprev || !dh || !d4 || (d4_prev && !w_hh_t)) return -23;
     if (bias_partials && n_partials < 1) return -26;
     if ((uintptr_t)d4_prev % 16 || (uintptr_t)w_hh_t % 16 || (uintptr_t)gates % 16 || (uintptr_t)hprev % 16 || (uintptr_t)dh % 16 ||
-        (uintptr_t)d4 % 16 || (dy && ((uintptr_t)dy % 16 || ldy % 8))) return -25;
+        (uintptr_t)d4 % 16 || (dy && ((uintptr_t)dy % 16 || ldy % 8)) || ld_dh < hs || ld_dh % 8 || (uintptr_t)hprev_out % 16) return -25;
     StepBwdArgs a;
     a.d4_prev = (const bf16_t*)d4_prev; a.rows_prev = d4_prev ? rows_prev : 0; a.wh_t = (const bf16_t*)w_hh_t;
     a.gates = (const bf16_t*)gates; a.hprev = (const bf16_t*)hprev; a.hprev_idx = hprev_idx; a.dy = (const bf16_t*)dy; a.ldy = ldy;
-    a.dh = dh; a.dh_bf16 = dh_dtype == GTOS_BF16; a.d4 = (bf16_t*)d4; a.bias_part = bias_partials; a.n_partials = n_partials;
+    a.dh = dh; a.dh_bf16 = dh_dtype == GTOS_BF16; a.ld_dh = ld_dh; a.d4 = (bf16_t*)d4; a.bias_part = bias_partials; a.n_partials = n_partials;
+    a.hp_out = (bf16_t*)hprev_out;
     a.p_drop = p_drop; a.seed = seed; a.drop_base = drop_base; a.rows = rows; a.hs = hs;
     a.zeros = gtos_zero_block();
     if (!a.zeros) return -5;

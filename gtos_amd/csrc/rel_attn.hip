@@ -26,6 +26,12 @@
 // lanes of a head.  If d < 512 a wave processes G = 64/LR keys at once.  The key loop is double buffered: two named
 // register sets of U keys, the loads of one in flight while the other is consumed.  Masks are staged in LDS once per
 // workgroup.  K/V rows come through L2: the block->(i,b) map keeps every graph's K/V on one XCD (8 XCDs, private L2s).
+//
+// Shapes.  The fast path above needs d and hd = d/H to be powers of two, hd >= 8, d <= 512 (every shipped configuration).
+// Everything else the reference accepts with hd % 8 == 0, hd <= 512 (graph_transformer.py:75 only asks d % H == 0) runs on
+// the GENERIC lane map: a head takes LH = pow2ceil(hd/8) lanes (the lanes past hd/8 idle), a key row takes nhs heads =
+// LR = nhs*LH <= 64 lanes, and the heads are processed in ceil(H/nhs) independent SLICES (blockIdx.y) -- attention heads
+// never mix, so a slice is the same kernel on its own channels.  Same arithmetic, same dropout counters.
 #include "common.h"
 #include <type_traits>
 
@@ -80,8 +86,28 @@ struct AttnArgs {
     float* pd;                  // scratch [T,S,B,H]: post-dropout probabilities
     float* gs;                  // scratch [T,S,B,H]: scale * dS
     int T, S, B, H, d, mode;
+    int hd, nhs, lr;            // generic lane map: head width, heads per slice, lanes per key row (= nhs * LH)
     float scale, p_drop; uint64_t seed;
 };
+
+// lane -> (key group g, lane in row cl, first channel c, head h); act: the lane owns 8 real channels; lead: first lane of a head
+struct LaneMap { int LR, g, cl, c, h; bool act, lead; };
+template <int LH, bool GEN>
+__device__ __forceinline__ LaneMap lane_map(int d, int H, int hd, int nhs, int lr, int lane) {
+    LaneMap m;
+    if constexpr (!GEN) {
+        m.LR = d >> 3; m.g = lane / m.LR; m.cl = lane % m.LR; m.c = m.cl * 8; m.h = m.cl / LH;
+        m.act = true; m.lead = (m.cl % LH) == 0;
+    } else {
+        m.LR = lr; m.g = lane / lr; m.cl = lane % lr;
+        const int hl = m.cl / LH, p = m.cl % LH;
+        m.h = (int)blockIdx.y * nhs + hl;
+        m.c = m.h * hd + p * 8;
+        m.act = m.h < H && p * 8 < hd;
+        m.lead = m.act && p == 0;
+    }
+    return m;
+}
 
 // Sum over the LH lanes of a head.  DPP lane permutes (VALU speed) for the steps inside a 16-lane row: hipcc lowers
 // __shfl_xor to ds_bpermute (an LDS-pipe round trip of ~100 cycles) even for constant offsets, and three of those per key
@@ -131,7 +157,7 @@ __device__ __forceinline__ bool key_dead(const AttnArgs& a, const unsigned char*
 }
 
 // ------------------------------------------------------------------------------------------- forward
-template <typename T, int LH>
+template <typename T, int LH, bool GEN>
 __global__ __launch_bounds__(256, 4) void rel_attn_fwd_kernel(AttnArgs a) {
     constexpr int U = Unroll<T>::U;
     __shared__ unsigned char smask[MAXS_LDS];
@@ -141,7 +167,9 @@ __global__ __launch_bounds__(256, 4) void rel_attn_fwd_kernel(AttnArgs a) {
     if (!map_block(a.T, a.B, i, b)) return;      // whole block
     const unsigned char* sm = stage_mask(a, i, b, smask);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int d = a.d, LR = d >> 3, G = 64 / LR, g = lane / LR, cl = lane % LR, c = cl * 8, h = cl / LH;
+    const LaneMap lm = lane_map<LH, GEN>(a.d, a.H, a.hd, a.nhs, a.lr, lane);
+    const int d = a.d, LR = lm.LR, G = 64 / LR, g = lm.g, c = lm.c, h = lm.h;
+    const bool act = lm.act, lead = lm.lead;
     const int KS = 4 * G;                        // keys taken per unroll slot by the whole block
     const T* qp = static_cast<const T*>(a.q) + ((int64_t)i * a.B + b) * a.ldq + c;
     const T* kb = static_cast<const T*>(a.k) + (int64_t)b * a.ldk + c;
@@ -152,7 +180,7 @@ __global__ __launch_bounds__(256, 4) void rel_attn_fwd_kernel(AttnArgs a) {
     const int joff = wv * G + g;                 // this lane group's key inside a slot
 
     float qf[8];
-    { Raw8<T> r; r.load(qp); r.get(qf); }
+    { Raw8<T> r; r.zero(); if (act) r.load(qp); r.get(qf); }
     float m = -INFINITY, l = 0.f, o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
     // Software pipeline over two register sets: the loads of the NEXT U keys are issued before the current U keys are
@@ -167,7 +195,7 @@ __global__ __launch_bounds__(256, 4) void rel_attn_fwd_kernel(AttnArgs a) {
         for (int u = 0; u < U; ++u) {
             const int j = jb + u * KS + joff;
             ks.ra[u].zero(); ks.rb[u].zero(); ks.k[u].zero(); ks.v[u].zero();
-            if (j < a.S) {
+            if (j < a.S && act) {
                 ks.k[u].load(kb + (int64_t)j * a.B * a.ldk);
                 ks.v[u].load(vb + (int64_t)j * a.B * a.ldv);
                 if (a.mode == 1) {
@@ -192,7 +220,7 @@ __global__ __launch_bounds__(256, 4) void rel_attn_fwd_kernel(AttnArgs a) {
             s = head_sum<LH>(s) * a.scale;
             const bool dead = (j >= a.S) || key_dead(a, sm, i, j, b);
             if (dead) s = -INFINITY;
-            if (a.w && j < a.S && (cl % LH) == 0) a.w[(((int64_t)i * a.S + j) * a.B + b) * a.H + h] = s;
+            if (a.w && j < a.S && lead) a.w[(((int64_t)i * a.S + j) * a.B + b) * a.H + h] = s;
             const float mn = fmaxf(m, s);
             float alpha = 1.f, pe = 0.f;
             if (mn != -INFINITY) { alpha = __expf(m - mn); pe = __expf(s - mn); }
@@ -246,17 +274,17 @@ __global__ __launch_bounds__(256, 4) void rel_attn_fwd_kernel(AttnArgs a) {
         }
         const float inv = l > 0.f ? 1.f / l : 0.f;
         fin[lane][0] = m; fin[lane][1] = inv;
-        if (g == 0) {
+        if (g == 0 && act) {
             float r[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) r[e] = o[e] * inv;
             Vec8<T>::store(static_cast<T*>(a.o) + ((int64_t)i * a.B + b) * a.ldo + c, r);
-            if ((cl % LH) == 0) a.lse[((int64_t)i * a.B + b) * a.H + h] = (l > 0.f) ? m + __logf(l) : -INFINITY;
+            if (lead) a.lse[((int64_t)i * a.B + b) * a.H + h] = (l > 0.f) ? m + __logf(l) : -INFINITY;
         }
     }
     if (a.w) {                                   // normalise the raw scores this same lane wrote above
         __syncthreads();
-        if ((cl % LH) == 0) {
+        if (lead) {
             const float mf = fin[lane][0], inv = fin[lane][1];
             for (int j = joff; j < a.S; j += KS) {
                 const int64_t off = (((int64_t)i * a.S + j) * a.B + b) * a.H + h;
@@ -272,7 +300,7 @@ __global__ __launch_bounds__(256, 4) void rel_attn_fwd_kernel(AttnArgs a) {
 // ------------------------------------------------------------------------------------------- backward, query-major
 // per (i,b): recompute p from lse; dS; dq_i = sum_j scale*dS*(k_j+rb); dense mode writes d_rarb rows;
 // stores pd (post-dropout p) and gs (= scale*dS) for the key-major and bank passes.
-template <typename T, int LH>
+template <typename T, int LH, bool GEN>
 __global__ __launch_bounds__(256) void rel_attn_bwd_q_kernel(AttnArgs a) {
     constexpr int U = Unroll<T>::U;
     __shared__ unsigned char smask[MAXS_LDS];
@@ -282,7 +310,9 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_q_kernel(AttnArgs a) {
     if (!map_block(a.T, a.B, i, b)) return;
     const unsigned char* sm = stage_mask(a, i, b, smask);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int d = a.d, LR = d >> 3, G = 64 / LR, g = lane / LR, cl = lane % LR, c = cl * 8, h = cl / LH;
+    const LaneMap lm = lane_map<LH, GEN>(a.d, a.H, a.hd, a.nhs, a.lr, lane);
+    const int d = a.d, LR = lm.LR, G = 64 / LR, g = lm.g, c = lm.c, h = lm.h;
+    const bool act = lm.act, lead = lm.lead;
     const int KS = 4 * G, joff = wv * G + g;
     const int64_t row = (int64_t)i * a.B + b;
     const T* kb = static_cast<const T*>(a.k) + (int64_t)b * a.ldk + c;
@@ -292,16 +322,16 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_q_kernel(AttnArgs a) {
     const float keep_scale = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
 
     float qf[8], dof[8], of[8];
-    { Raw8<T> r; r.load(static_cast<const T*>(a.q) + row * a.ldq + c); r.get(qf); }
-    { Raw8<T> r; r.load(static_cast<const T*>(a.d_o) + row * a.lddo + c); r.get(dof); }
-    { Raw8<T> r; r.load(static_cast<const T*>(a.o) + row * a.ldo + c); r.get(of); }
+    { Raw8<T> r; r.zero(); if (act) r.load(static_cast<const T*>(a.q) + row * a.ldq + c); r.get(qf); }
+    { Raw8<T> r; r.zero(); if (act) r.load(static_cast<const T*>(a.d_o) + row * a.lddo + c); r.get(dof); }
+    { Raw8<T> r; r.zero(); if (act) r.load(static_cast<const T*>(a.o) + row * a.ldo + c); r.get(of); }
     float D = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) D = fmaf(dof[e], of[e], D);
     D = head_sum<LH>(D);
     if (a.dw) {     // upstream gradient on the returned weights: D += sum_j w_ij * dw_ij (over ALL keys: 4 waves x G groups)
         float acc = 0.f;
-        for (int j = joff; j < a.S; j += KS) {
+        for (int j = joff; j < a.S && act; j += KS) {
             const int64_t off = (((int64_t)i * a.S + j) * a.B + b) * a.H + h;
             acc = fmaf(a.w[off], a.dw[off], acc);
         }
@@ -310,7 +340,7 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_q_kernel(AttnArgs a) {
         __syncthreads();
         D += redw[0][lane] + redw[1][lane] + redw[2][lane] + redw[3][lane];
     }
-    const float lse = a.lse[row * a.H + h];
+    const float lse = act ? a.lse[row * a.H + h] : -INFINITY;
     float dq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
     struct KeySet { Raw8<T> ra[U], rb[U], k[U], v[U]; int tn[U], tw[U]; };   // tn: ids prefetched for the NEXT issue; tw: ids of the rows in flight
@@ -323,7 +353,7 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_q_kernel(AttnArgs a) {
         for (int u = 0; u < U; ++u) {
             const int j = jb + u * KS + joff;
             ks.ra[u].zero(); ks.rb[u].zero(); ks.k[u].zero(); ks.v[u].zero();
-            if (j < a.S) {
+            if (j < a.S && act) {
                 ks.k[u].load(kb + (int64_t)j * a.B * a.ldk);
                 ks.v[u].load(vb + (int64_t)j * a.B * a.ldv);
                 if (a.mode == 1) {
@@ -359,13 +389,14 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_q_kernel(AttnArgs a) {
             float keep = 1.f;
             if (a.p_drop > 0.f) keep = drop_keep(a.seed, (uint64_t)off, a.p_drop) ? keep_scale : 0.f;
             float dp = dpv;
-            if (a.dw) dp += a.dw[off];
+            if (a.dw && act) dp += a.dw[off];
             const float gsc = a.scale * p * (keep * dp - D);
-            if ((cl % LH) == 0) { a.pd[off] = p * keep; a.gs[off] = gsc; }
+            if (lead) { a.pd[off] = p * keep; a.gs[off] = gsc; }
             float dra[8], drb[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) { dra[e] = gsc * rb[e]; drb[e] = gsc * ra[e]; dq[e] += dra[e]; }
-            if (a.mode == 1) {
+            if (!act) {
+            } else if (a.mode == 1) {
                 T* p2 = static_cast<T*>(a.d_rel) + (((int64_t)j * a.T + i) * a.B + b) * (2 * d) + c;
                 Vec8<T>::store(p2, dra);
                 Vec8<T>::store(p2 + d, drb);
@@ -396,7 +427,7 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_q_kernel(AttnArgs a) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[wv][lane][e] = dq[e];
     __syncthreads();
-    if (wv == 0 && g == 0) {
+    if (wv == 0 && g == 0 && act) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) dq[e] = red[0][lane][e] + red[1][lane][e] + red[2][lane][e] + red[3][lane][e];
         Vec8<T>::store(static_cast<T*>(a.dq) + row * a.lddq + c, dq);
@@ -405,14 +436,16 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_q_kernel(AttnArgs a) {
 
 // ------------------------------------------------------------------------------------------- backward, key-major
 // per (j,b): dv_j = sum_i pd_ij do_i ; dk_j = sum_i gs_ij (q_i + ra_ji); the 4 waves split the queries
-template <typename T, int LH>
+template <typename T, int LH, bool GEN>
 __global__ __launch_bounds__(256) void rel_attn_bwd_kv_kernel(AttnArgs a) {
     constexpr int U = Unroll<T>::U;
     __shared__ float red[4][64][16];
     int j, b;
     if (!map_block(a.S, a.B, j, b)) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int d = a.d, LR = d >> 3, G = 64 / LR, g = lane / LR, cl = lane % LR, c = cl * 8, h = cl / LH;
+    const LaneMap lm = lane_map<LH, GEN>(a.d, a.H, a.hd, a.nhs, a.lr, lane);
+    const int d = a.d, LR = lm.LR, G = 64 / LR, g = lm.g, c = lm.c, h = lm.h;
+    const bool act = lm.act;
     const int KS = 4 * G, ioff = wv * G + g;
     const int64_t row = (int64_t)j * a.B + b;
     const T* qb = static_cast<const T*>(a.q) + (int64_t)b * a.ldq + c;
@@ -428,7 +461,7 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_kv_kernel(AttnArgs a) {
         for (int u = 0; u < U; ++u) {
             const int i = ib + u * KS + ioff;
             rq[u].zero(); rdo[u].zero(); rra[u].zero(); pdv[u] = 0.f; gsv[u] = 0.f;
-            if (i < a.T) {
+            if (i < a.T && act) {
                 rq[u].load(qb + (int64_t)i * a.B * a.ldq);
                 rdo[u].load(dob + (int64_t)i * a.B * a.lddo);
                 const int64_t off = (((int64_t)i * a.S + j) * a.B + b) * a.H + h;
@@ -452,7 +485,7 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_kv_kernel(AttnArgs a) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) { red[wv][lane][e] = dk[e]; red[wv][lane][8 + e] = dv[e]; }
     __syncthreads();
-    if (wv == 0 && g == 0) {
+    if (wv == 0 && g == 0 && act) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             dk[e] = red[0][lane][e] + red[1][lane][e] + red[2][lane][e] + red[3][lane][e];
@@ -481,12 +514,15 @@ struct BankArgs {
     void* d_bank; int64_t ld_dbank;   // [R,2d] type T, row stride ld_dbank (a column block of a wider gradient slab)
     float* heavy;                // [n_heavy,2d] fp32, zero-initialised by the caller
     int nchunks, T, S, B, H, d;
+    int hd, nhs, lr;
 };
 
-template <typename T, int LH>
+template <typename T, int LH, bool GEN>
 __global__ __launch_bounds__(256) void rel_attn_bwd_bank_kernel(BankArgs a) {
     const int lane = threadIdx.x & 63;
-    const int d = a.d, LR = d >> 3, G = 64 / LR, g = lane / LR, cl = lane % LR, c = cl * 8, h = cl / LH;
+    const LaneMap lm = lane_map<LH, GEN>(a.d, a.H, a.hd, a.nhs, a.lr, lane);
+    const int d = a.d, LR = lm.LR, G = 64 / LR, g = lm.g, c = lm.c, h = lm.h;
+    const bool act = lm.act;
     // Most chunks hold one or two pairs, so a chunk is a chain of three dependent global loads (chunk record -> pair ids
     // and bank row -> q/k rows and gs) in front of a handful of FMAs.  Chunks are walked grid-stride and the chain is
     // software-pipelined over three consecutive chunks of a wave: while chunk i is reduced, the pair ids / bank row of
@@ -512,7 +548,8 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_bank_kernel(BankArgs a) {
     auto load_lvl2 = [&](const Meta& m) {
         Lvl2 l;
         const T* bp = static_cast<const T*>(a.bank) + (int64_t)m.t * (2 * d) + c;
-        l.rRA.load(bp); l.rRB.load(bp + d);
+        l.rRA.zero(); l.rRB.zero();
+        if (act) { l.rRA.load(bp); l.rRB.load(bp + d); }
         l.my_pid = lane < min(m.cnt, 64) ? a.pair_sorted[m.start + lane] : 0;     // one coalesced load of the chunk's (first 64) pair ids
         return l;
     };
@@ -539,7 +576,7 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_bank_kernel(BankArgs a) {
                     const int p = p0 + u * G + g;
                     const int pid = __shfl(my_pid, p < nb ? p : 0);
                     rk[u].zero(); rq[u].zero(); gsc[u] = 0.f;
-                    if (p < nb) {
+                    if (p < nb && act) {
                         const int b = pid % a.B, ji = pid / a.B, i = ji % a.T, j = ji / a.T;
                         gsc[u] = a.gs[(((int64_t)i * a.S + j) * a.B + b) * a.H + h];
                         rk[u].load(static_cast<const T*>(a.k) + ((int64_t)j * a.B + b) * a.ldk + c);
@@ -561,7 +598,7 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_bank_kernel(BankArgs a) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) { da[e] += __shfl_xor(da[e], off); db[e] += __shfl_xor(db[e], off); }
         }
-        if (g == 0) {
+        if (g == 0 && act) {
             float RA[8], RB[8];
             l1.rRA.get(RA); l1.rRB.get(RB);
             if (m1.slot >= 0) {
@@ -594,21 +631,36 @@ template <typename K> int dispatch_lh(int lh, K&& f) {
     return -11;
 }
 
-int check_shape(int d, int H) {
-    if (H <= 0 || d % H) return -10;
+// Lane geometry of a shape: LH lanes per head (power of two), heads per slice, lanes per key row, slices; `generic` = off the
+// power-of-two fast path.  -10: outside the boundary (H <= 0, d % H, head width not a multiple of 8 or above 512).
+struct Geo { int LH, nhs, lr, slices; bool generic; };
+int pow2ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+int geometry(int d, int H, Geo& g) {
+    if (H <= 0 || d <= 0 || d % H) return -10;
     const int hd = d / H;
-    if (d % 8 || d > 512 || (d & (d - 1)) || hd % 8 || (hd & (hd - 1))) return -10;   // d, hd powers of two, hd >= 8
+    if (hd % 8 || hd > 512) return -10;
+    g.generic = !(d <= 512 && (d & (d - 1)) == 0 && (hd & (hd - 1)) == 0);
+    if (!g.generic) { g.LH = hd / 8; g.nhs = H; g.lr = d / 8; g.slices = 1; return 0; }
+    g.LH = pow2ceil(hd / 8);
+    int nhs = 64 / g.LH;                      // heads that fit a 64-lane row ...
+    const int hp = pow2ceil(H);
+    if (nhs > hp) nhs = hp;                   // ... but no more lanes than the heads need (more key groups per wave instead)
+    g.nhs = nhs; g.lr = nhs * g.LH; g.slices = (H + nhs - 1) / nhs;
     return 0;
 }
+int check_shape(int d, int H) { Geo g; return geometry(d, H, g); }
 
 int nblocks(int rows, int B) { return rows * B; }
 
 }  // namespace
 
-static int fill_args(AttnArgs& a, int T_, int S, int B, int H, int d, int mode, float scale, float p_drop, uint64_t seed) {
+static int fill_args(AttnArgs& a, Geo& g, int T_, int S, int B, int H, int d, int mode, float scale, float p_drop, uint64_t seed) {
     a.T = T_; a.S = S; a.B = B; a.H = H; a.d = d; a.mode = mode; a.scale = scale; a.p_drop = p_drop; a.seed = seed;
     if (mode != 0 && T_ != S) return -12;
-    return check_shape(d, H);
+    const int rc = geometry(d, H, g);
+    if (rc) return rc;
+    a.hd = d / H; a.nhs = g.nhs; a.lr = g.lr;
+    return 0;
 }
 
 extern "C" int gtos_rel_attn_fwd(int dtype, int mode, int T_, int S, int B, int H, int d,
@@ -617,16 +669,22 @@ extern "C" int gtos_rel_attn_fwd(int dtype, int mode, int T_, int S, int B, int 
                                  float scale, float p_drop, uint64_t seed,
                                  void* o, int64_t ldo, float* lse, float* w, void* stream) {
     AttnArgs a = {};
-    int rc = fill_args(a, T_, S, B, H, d, mode, scale, p_drop, seed);
+    Geo geo;
+    int rc = fill_args(a, geo, T_, S, B, H, d, mode, scale, p_drop, seed);
     if (rc) return rc;
     a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.rel = rel; a.idx_q = idx_q;
     a.key_pad = key_pad; a.attn_mask = attn_mask; a.o = o; a.ldo = ldo; a.lse = lse; a.w = w;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int grid = nblocks(T_, B);
-    return dispatch_lh(d / H / 8, [&](auto lh) {
+    const dim3 grid(nblocks(T_, B), geo.slices);
+    return dispatch_lh(geo.LH, [&](auto lh) {
         constexpr int LH = decltype(lh)::value;
-        if (dtype == GTOS_BF16) hipLaunchKernelGGL((rel_attn_fwd_kernel<bf16_t, LH>), dim3(grid), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((rel_attn_fwd_kernel<float, LH>), dim3(grid), dim3(256), 0, s, a);
+        if (geo.generic) {
+            if (dtype == GTOS_BF16) hipLaunchKernelGGL((rel_attn_fwd_kernel<bf16_t, LH, true>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((rel_attn_fwd_kernel<float, LH, true>), grid, dim3(256), 0, s, a);
+        } else {
+            if (dtype == GTOS_BF16) hipLaunchKernelGGL((rel_attn_fwd_kernel<bf16_t, LH, false>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((rel_attn_fwd_kernel<float, LH, false>), grid, dim3(256), 0, s, a);
+        }
         GTOS_CHECK_LAUNCH();
         return 0;
     });
@@ -642,7 +700,8 @@ extern "C" int gtos_rel_attn_bwd(int dtype, int mode, int T_, int S, int B, int 
                                  void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv,
                                  void* d_rel, int64_t ld_drel, float* pd, float* gs, void* stream) {
     AttnArgs a = {};
-    int rc = fill_args(a, T_, S, B, H, d, mode, scale, p_drop, seed);
+    Geo geo;
+    int rc = fill_args(a, geo, T_, S, B, H, d, mode, scale, p_drop, seed);
     if (rc) return rc;
     a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.rel = rel; a.idx_q = idx_q; a.idx_k = idx_k;
     a.key_pad = key_pad; a.attn_mask = attn_mask; a.o = const_cast<void*>(o); a.ldo = ldo;
@@ -651,15 +710,14 @@ extern "C" int gtos_rel_attn_bwd(int dtype, int mode, int T_, int S, int B, int 
     if (mode == 2 && d_rel && (ld_drel < 2 * d || ld_drel % 8)) return -14;
     if (dw && !w) return -13;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    return dispatch_lh(d / H / 8, [&](auto lh) {
+    const dim3 gq(nblocks(T_, B), geo.slices), gk(nblocks(S, B), geo.slices);
+    return dispatch_lh(geo.LH, [&](auto lh) {
         constexpr int LH = decltype(lh)::value;
-        if (dtype == GTOS_BF16) {
-            hipLaunchKernelGGL((rel_attn_bwd_q_kernel<bf16_t, LH>), dim3(nblocks(T_, B)), dim3(256), 0, s, a);
-            hipLaunchKernelGGL((rel_attn_bwd_kv_kernel<bf16_t, LH>), dim3(nblocks(S, B)), dim3(256), 0, s, a);
-        } else {
-            hipLaunchKernelGGL((rel_attn_bwd_q_kernel<float, LH>), dim3(nblocks(T_, B)), dim3(256), 0, s, a);
-            hipLaunchKernelGGL((rel_attn_bwd_kv_kernel<float, LH>), dim3(nblocks(S, B)), dim3(256), 0, s, a);
-        }
+#define GTOS_BWD(TT, GG) do { hipLaunchKernelGGL((rel_attn_bwd_q_kernel<TT, LH, GG>), gq, dim3(256), 0, s, a); \
+                              hipLaunchKernelGGL((rel_attn_bwd_kv_kernel<TT, LH, GG>), gk, dim3(256), 0, s, a); } while (0)
+        if (geo.generic) { if (dtype == GTOS_BF16) GTOS_BWD(bf16_t, true); else GTOS_BWD(float, true); }
+        else { if (dtype == GTOS_BF16) GTOS_BWD(bf16_t, false); else GTOS_BWD(float, false); }
+#undef GTOS_BWD
         GTOS_CHECK_LAUNCH();
         return 0;
     });
@@ -671,7 +729,8 @@ extern "C" int gtos_rel_attn_bwd_bank(int dtype, int n, int B, int H, int d,
                                       const int* pair_sorted, const int* chunk_type, const int* chunk_start,
                                       const int* chunk_count, const int* chunk_slot, const int* xcd_off, int nchunks,
                                       void* d_bank, int64_t ld_dbank, float* heavy, void* stream) {
-    int rc = check_shape(d, H);
+    Geo geo;
+    int rc = geometry(d, H, geo);
     if (rc) return rc;
     if (ld_dbank < 2 * d || ld_dbank % 8) return -14;
     if (nchunks <= 0) return 0;
@@ -680,13 +739,20 @@ extern "C" int gtos_rel_attn_bwd_bank(int dtype, int n, int B, int H, int d,
     a.chunk_type = chunk_type; a.chunk_start = chunk_start; a.chunk_count = chunk_count; a.chunk_slot = chunk_slot;
     a.d_bank = d_bank; a.ld_dbank = ld_dbank; a.heavy = heavy; a.nchunks = nchunks; a.T = n; a.S = n; a.B = B; a.H = H; a.d = d;
     a.xcd_off = xcd_off;
+    a.hd = d / H; a.nhs = geo.nhs; a.lr = geo.lr;
     hipStream_t s = static_cast<hipStream_t>(stream);
     int grid = (nchunks + 3) / 4; if (grid > 4096) grid = 4096;
     if (xcd_off) grid = (grid + 7) / 8 * 8;
-    return dispatch_lh(d / H / 8, [&](auto lh) {
+    const dim3 g2(grid, geo.slices);
+    return dispatch_lh(geo.LH, [&](auto lh) {
         constexpr int LH = decltype(lh)::value;
-        if (dtype == GTOS_BF16) hipLaunchKernelGGL((rel_attn_bwd_bank_kernel<bf16_t, LH>), dim3(grid), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((rel_attn_bwd_bank_kernel<float, LH>), dim3(grid), dim3(256), 0, s, a);
+        if (geo.generic) {
+            if (dtype == GTOS_BF16) hipLaunchKernelGGL((rel_attn_bwd_bank_kernel<bf16_t, LH, true>), g2, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((rel_attn_bwd_bank_kernel<float, LH, true>), g2, dim3(256), 0, s, a);
+        } else {
+            if (dtype == GTOS_BF16) hipLaunchKernelGGL((rel_attn_bwd_bank_kernel<bf16_t, LH, false>), g2, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((rel_attn_bwd_bank_kernel<float, LH, false>), g2, dim3(256), 0, s, a);
+        }
         GTOS_CHECK_LAUNCH();
         return 0;
     });

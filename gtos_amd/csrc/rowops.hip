@@ -737,7 +737,9 @@ extern "C" int gtos_embed_rows_bwd(int dtype, int64_t n, int V, int dim, int dim
     const int use_lds = (size_t)V * dim * 4 <= 60 * 1024;     // private LDS table, else global atomics
     if (n <= 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    int64_t nb = (n + 2047) / 2048; if (nb > 1024) nb = 1024; if (nb < 1) nb = 1;
+    // LDS path: every block flushes its private V*dim table with global atomics onto the SAME V*dim addresses, so the flush
+    // cost grows with the block count (1024 blocks x 8.6 k atomics on 8.6 k addresses at the relation table): one block per CU
+    int64_t nb = (n + 2047) / 2048; if (nb > (use_lds ? 256 : 1024)) nb = use_lds ? 256 : 1024; if (nb < 1) nb = 1;
     const int64_t rpb = (n + nb - 1) / nb;
     dim3 grid((unsigned)((n + rpb - 1) / rpb)), block(256);
     const size_t sh = use_lds ? (size_t)V * dim * 4 : 0;

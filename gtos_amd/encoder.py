@@ -68,8 +68,8 @@ class RelationEncoder(nn.Module):
                     trie = None               # (path, position) below, like the reference's packed sequence
         if trie is not None and trie.matches(src_tokens, src_lengths) and self._trie_ok(src_tokens):
             p_e = self.dropout if self.training else 0.0
+            # final states [R, 2h], already in bank order (the step kernels scatter them through trie.seq_order)
             fin = trie_bigru_final(trie, self.rel_embed.weight, rel_dim + pad, p_e, self.hidden_size, p_e, self._weights(pad))
-            fin = ops.permute_rows(fin, trie.seq_pos, trie.seq_order)              # packed order -> bank order
             return ops.linear(fin, self.out_proj.weight, self.out_proj.bias)
         seq_len, bsz = src_tokens.size()
         sorted_len, indices = torch.sort(src_lengths, descending=True, stable=True)

@@ -42,27 +42,32 @@ SIDE_MIN_ROWS = 200000          # below this the GEMMs are launch-bound and the 
 
 
 def _step_fwd(A, hs, x, xg, h_in, wi, b_ih, wh, b_hh, h_out, n_out, h_fin, gates, y, y_off_elems, ldy, p, seed, drop_base,
-              h_idx=None, gf=None, gf_idx=None, gb=None, gb_idx=None):
+              h_idx=None, gf=None, gf_idx=None, gb=None, gb_idx=None, fin_idx=None):
+    """``h_fin``: [*, hs] or a column block of a wider matrix (its row stride is passed on); ``fin_idx``: int32 row map of the
+    finished rows (packed row m -> row fin_idx[m] of h_fin)."""
     yp = None if y is None else y.data_ptr() + y_off_elems * y.element_size()
     need_bi = x is not None or gf is not None
     with _Timed("gru_step_fwd_%s" % ("x" if x is not None else ("tables" if gf is not None else "xg")), detail=True, units=A):
         _step_fwd_call(A, hs, x, xg, h_in, wi, b_ih, wh, b_hh, h_out, n_out, h_fin, gates, yp, ldy, p, seed, drop_base,
-                       h_idx, gf, gf_idx, gb, gb_idx, need_bi)
+                       h_idx, gf, gf_idx, gb, gb_idx, need_bi, fin_idx)
 
 
 def _step_fwd_call(A, hs, x, xg, h_in, wi, b_ih, wh, b_hh, h_out, n_out, h_fin, gates, yp, ldy, p, seed, drop_base,
-                   h_idx, gf, gf_idx, gb, gb_idx, need_bi):
+                   h_idx, gf, gf_idx, gb, gb_idx, need_bi, fin_idx=None):
     call("gtos_gru_step_fwd", A, hs, ptr(x), 0 if x is None else x.stride(0), 0 if x is None else x.shape[1],
          ptr(wi) if x is not None else None, ptr(b_ih) if need_bi else None, ptr(xg),
          ptr(gf), ptr(gf_idx), ptr(gb), ptr(gb_idx), ptr(h_in), ptr(h_idx), ptr(wh), ptr(b_hh),
-         ptr(h_out), n_out, ptr(h_fin), ptr(gates), yp, ldy, float(p), seed, drop_base, stream())
+         ptr(h_out), n_out, ptr(h_fin), hs if h_fin is None else h_fin.stride(0), ptr(fin_idx), ptr(gates), yp, ldy,
+         float(p), seed, drop_base, stream())
 
 
-def _step_bwd(A, hs, d4_prev, rows_prev, wh_t, gates, hprev, dy_ptr, ldy, dh, d4, p, seed, drop_base, bpart, hprev_idx=None):
+def _step_bwd(A, hs, d4_prev, rows_prev, wh_t, gates, hprev, dy_ptr, ldy, dh, d4, p, seed, drop_base, bpart, hprev_idx=None, hp_out=None):
+    """``dh``: [rows, hs] or a column block of a wider matrix (row stride passed on); ``hp_out``: [rows, hs] receiving the
+    (gathered) entering state rows."""
     with _Timed("gru_step_bwd_%s" % ("trie" if hprev_idx is not None else "rows"), detail=True, units=A):
         call("gtos_gru_step_bwd", A, hs, ptr(d4_prev), rows_prev if d4_prev is not None else 0, ptr(wh_t), ptr(gates), ptr(hprev),
-             ptr(hprev_idx), dy_ptr, ldy, ptr(dh), dt(dh), ptr(d4), float(p), seed, drop_base,
-             ptr(bpart), N_BIAS_PARTIALS if bpart is not None else 0, stream())
+             ptr(hprev_idx), dy_ptr, ldy, ptr(dh), dt(dh), dh.stride(0), ptr(d4), float(p), seed, drop_base,
+             ptr(bpart), N_BIAS_PARTIALS if bpart is not None else 0, ptr(hp_out), stream())
 
 
 def _cell_bwd(A, hs, gates, hprev, dy, dy_off_elems, ldy, dh, dxg, dhg, p, seed, drop_base, bpart):
@@ -329,7 +334,7 @@ def _acc_bias_grads(grads, base, b_ih, b_hh, bsum, hs):
 
 class TrieBiGRUFn(torch.autograd.Function):
     """(trie, embedding table [V,dim], weights of a 2-layer bidirectional GRU) -> [R, 2*hs] final states of the top layer
-    in PACKED order (trie.seq_order).  weights as in BiGRUFinalFn; layer 0's w_ih zero-padded to dim_pad columns."""
+    in BANK order (row s = path s of relation_bank).  weights as in BiGRUFinalFn; layer 0's w_ih zero-padded to dim_pad columns."""
 
     @staticmethod
     def forward(ctx, trie, table, dim_pad, p_embed, hs, p_layer, *weights):
@@ -372,8 +377,10 @@ class TrieBiGRUFn(torch.autograd.Function):
             main.wait_stream(aux)      # layer 1 reads both sides; the suffix side's buffers live in the auxiliary stream's pool and
             #                            are only handed back after backward, when main has long passed this point
         src = [l0[d][3] if p_layer > 0 else l0[d][1][:sides[d].n_nodes] for d in (0, 1)]
-        # ---- layer 1: per-node input-gate tables, then the recurrent steps over the packed rows
-        finals, l1 = [], []
+        # ---- layer 1: per-node input-gate tables, then the recurrent steps over the packed rows.  A sequence's final state goes
+        # straight to its BANK row of fin [R, 2hs] (column block d): no torch.cat of the directions, no unsort gather
+        fin = torch.empty((R, 2 * hs), dtype=dtp, device=dev)
+        l1 = []
         for d in (0, 1):
             w_ih, w_hh, b_ih, b_hh = weights[8 + d * 4: 8 + d * 4 + 4]
             wi, wh = compute_weight(w_ih, dtp), compute_weight(w_hh, dtp)
@@ -381,7 +388,7 @@ class TrieBiGRUFn(torch.autograd.Function):
             Gb = gemm(src[1], wi[:, hs:], trans_b=True)         # [nodes of the suffix trie, 3hs]
             gates = torch.empty((N, 4 * hs), dtype=dtp, device=dev)
             hprev = torch.empty((N, hs), dtype=dtp, device=dev)
-            h = torch.empty((R, hs), dtype=dtp, device=dev)
+            h = fin[:, d * hs:(d + 1) * hs]
             bi, bh = b_ih.detach(), b_hh.detach()
             if d == 0:
                 hprev[:R].zero_()
@@ -396,13 +403,13 @@ class TrieBiGRUFn(torch.autograd.Function):
                 if 0 <= nxt < L:
                     h_out, n_out = hprev[offs[nxt]:], min(A, bs[nxt])
                 else:
-                    h_out, n_out = h, A
+                    h_out, n_out = None, 0                      # the direction's last step: every row is finished
                 _step_fwd(A, hs, None, None, hprev[off:off + A], None, bi, wh, bh, h_out, n_out, h, gates[off:off + A],
-                          None, 0, hs, 0.0, 0, 0, gf=Gf, gf_idx=trie.row_pf[off:off + A], gb=Gb, gb_idx=trie.row_sf[off:off + A])
-            finals.append(h)
+                          None, 0, hs, 0.0, 0, 0, gf=Gf, gf_idx=trie.row_pf[off:off + A], gb=Gb, gb_idx=trie.row_sf[off:off + A],
+                          fin_idx=trie.seq_order32)
             l1.append((gates, hprev, wi, weight_t(w_hh, wh)))
         ctx.cfg = (trie, table, dim_pad, p_embed, hs, p_layer, weights, l0, l1, offs)
-        return torch.cat(finals, 1)
+        return fin
 
     @staticmethod
     def backward(ctx, d_out):
@@ -416,7 +423,9 @@ class TrieBiGRUFn(torch.autograd.Function):
         L, R, N = trie.L, trie.R, trie.N
         bs = trie.batch_sizes
         sides = (trie.pf, trie.sf)
-        d_out = d_out.contiguous()
+        # bank order -> packed order, one gather of the [R, 2hs] gradient; its two column blocks are the running state
+        # gradients of the two directions (updated in place by the step kernels)
+        d_out = d_out.to(dtp).index_select(0, trie.seq_order)
         grads = [None] * len(weights)
         src = [l0[d][3] if p_layer > 0 else l0[d][1][:sides[d].n_nodes] for d in (0, 1)]
         dsrc = [None, None]
@@ -448,7 +457,7 @@ class TrieBiGRUFn(torch.autograd.Function):
             base = 8 + d * 4
             w_ih, w_hh, b_ih, b_hh = weights[base:base + 4]
             want_bias = b_ih.requires_grad or b_hh.requires_grad
-            dh = d_out[:, d * hs:(d + 1) * hs].to(dtp).contiguous()
+            dh = d_out[:, d * hs:(d + 1) * hs]
             d4 = torch.empty((N, 4 * hs), dtype=dtp, device=dev)
             bpart = torch.zeros((N_BIAS_PARTIALS, 4 * hs), dtype=torch.float32, device=dev) if want_bias else None
             prev = None
@@ -504,6 +513,7 @@ class TrieBiGRUFn(torch.autograd.Function):
             dhz = torch.zeros((n, hs), dtype=dtp, device=dev)        # per node: (state gradient) * z, what its parent receives directly
             widest = max(side.level_off[k + 1] - side.level_off[k] for k in range(L))
             S = torch.empty((widest, 4 * hs), dtype=dtp, device=dev)  # per parent of the current level: sum of its children's d4
+            hp = torch.empty((n, hs), dtype=dtp, device=dev)          # the state each node started from (written by the steps)
             bpart = torch.zeros((N_BIAS_PARTIALS, 4 * hs), dtype=torch.float32, device=dev) if want_bias else None
             dy = dsrc[d]
             for k in range(L - 1, -1, -1):
@@ -517,8 +527,7 @@ class TrieBiGRUFn(torch.autograd.Function):
                     _seg_ranges(A, rng_, d4, 4 * hs, S)
                     _seg_ranges(A, rng_, dhz, hs, dhz[lo:hi])
                 _step_bwd(A, hs, S if has_kids else None, A, wh_t, gates[lo:hi], H, dy.data_ptr() + lo * hs * dy.element_size(), hs,
-                          dhz[lo:hi], d4[lo:hi], p_layer, seed_y, lo * hs, bpart, hprev_idx=side.par[lo:hi])
-            hp = H.index_select(0, side.par_long)                    # the state each node started from, aligned with d4's rows
+                          dhz[lo:hi], d4[lo:hi], p_layer, seed_y, lo * hs, bpart, hprev_idx=side.par[lo:hi], hp_out=hp[lo:hi])
             with (on_side(d4, hp, X, bpart) if use_side else contextlib.nullcontext()):
                 _acc_weight_grad(grads, base + 1, w_hh, d4[:, :2 * hs], hp, rows=slice(0, 2 * hs))
                 _acc_weight_grad(grads, base + 1, w_hh, d4[:, 3 * hs:], hp, rows=slice(2 * hs, 3 * hs))

@@ -405,19 +405,24 @@ def layer_norm_residual(x, r, gamma, beta, p_drop=0.0, eps=1e-5):
 
 
 def check_attention_shape(embed_dim, num_heads):
-    """The attention kernels' hard shape boundary (include/gtos_hip.h, gtos_rel_attn_fwd): refuse at construction, loudly,
-    instead of failing at the first forward."""
+    """The attention kernels' shape boundary (include/gtos_hip.h, gtos_rel_attn_fwd): refuse at construction, loudly, instead
+    of failing at the first forward.  The reference asks embed_dim % heads == 0 (graph_transformer.py:75); the kernels read 8
+    channels per lane, so the head width must also be a multiple of 8 (and at most 512).  Power-of-two embed_dim <= 512 with a
+    power-of-two head width (every shipped configuration) runs on the fast lane map, everything else on the generic one."""
     hd = embed_dim // max(1, num_heads)
-    ok = (num_heads > 0 and embed_dim % num_heads == 0 and embed_dim <= 512 and embed_dim & (embed_dim - 1) == 0
-          and hd >= 8 and hd & (hd - 1) == 0)
+    ok = num_heads > 0 and embed_dim % num_heads == 0 and hd % 8 == 0 and hd <= 512
     if not ok:
-        raise _lib.GtosHipError("attention shape embed_dim=%d, heads=%d is outside the gfx950 kernels' boundary: embed_dim and "
-                                "embed_dim/heads must be powers of two, head size >= 8, embed_dim <= 512" % (embed_dim, num_heads))
+        raise _lib.GtosHipError("attention shape embed_dim=%d, heads=%d is outside the gfx950 kernels' boundary: embed_dim must "
+                                "be a multiple of heads and the head width a multiple of 8, at most 512" % (embed_dim, num_heads))
 
 
 def _u8(mask):
+    """Mask as uint8 bytes for the kernels.  A bool tensor IS one byte per element holding 0/1: reinterpreted, not copied (the
+    copy was one ATen launch per attention call)."""
     if mask is None:
         return None
+    if mask.dtype == torch.bool:
+        return mask.contiguous().view(torch.uint8)
     return mask.to(torch.uint8).contiguous()
 
 

@@ -58,11 +58,13 @@ class PathTrie(object):
     def __init__(self, L, R, N, batch_sizes, common, pf, sf):
         self.L, self.R, self.N = L, R, N
         self.batch_sizes = list(batch_sizes)
-        self.seq_order, self.seq_pos, self.row_pf, self.row_sf = common
+        self.seq_order, self.seq_pos, self.row_pf, self.row_sf = common[:4]
+        # int32 copy of seq_order for the step kernel's scatter of the final states (packed row m -> bank row seq_order[m])
+        self.seq_order32 = common[4] if len(common) > 4 else self.seq_order.to(torch.int32)
         self.pf, self.sf = pf, sf
 
     def to(self, device, *a, **k):
-        common = tuple(t.to(device) for t in (self.seq_order, self.seq_pos, self.row_pf, self.row_sf))
+        common = tuple(t.to(device) for t in (self.seq_order, self.seq_pos, self.row_pf, self.row_sf, self.seq_order32))
         return PathTrie(self.L, self.R, self.N, self.batch_sizes, common, self.pf.to(device), self.sf.to(device))
 
     def cpu(self):
@@ -118,7 +120,8 @@ def build_path_trie(bank, length, chunk=CHUNK):
         level_off = d.pop("level_off").tolist()
         sides.append(TrieSide(d, level_off))
     # seq_order / seq_pos feed index_select (int64); the row -> node maps stay int32 for the kernels
-    return PathTrie(Lm, R, N, common["batch_sizes"].tolist(), (wide(1), wide(2), common["row_pf"], common["row_sf"]), sides[0], sides[1])
+    return PathTrie(Lm, R, N, common["batch_sizes"].tolist(), (wide(1), wide(2), common["row_pf"], common["row_sf"], ts[1]),
+                    sides[0], sides[1])
 
 
 def attach_path_trie(batch):

@@ -174,11 +174,16 @@ class SelfAttentionMask(nn.Module):
         super().__init__()
         self.device = device
         self.weights = None
+        self._cut = {}
 
     def forward(self, size):
         if self.weights is None or size > self.weights.size(0):
             self.weights = torch.ones((max(size, 100), max(size, 100)), dtype=torch.bool, device=self.device).triu_(1)
-        return self.weights[:size, :size]
+            self._cut = {}
+        m = self._cut.get(size)
+        if m is None:                  # contiguous [size,size] copy made once per size: the kernels read it as bytes, every layer
+            m = self._cut[size] = self.weights[:size, :size].contiguous()
+        return m
 
 
 class SinusoidalPositionalEmbedding(nn.Module):

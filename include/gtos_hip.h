@@ -127,25 +127,31 @@ int gtos_gru_cell_fwd(int dtype, int rows, int hs, const void* xg, const void* h
  *   gf / gb: two bf16 tables [*,3hs] gathered per row, xg[m] = gf[gf_idx[m]] + gb[gb_idx[m]] + b_ih -- the second GRU layer
  *   on the path tries, whose input product splits into a prefix-node and a suffix-node term (gtos_amd/gru.py).
  * h_in [*,hs] is read-only; row m enters with h_in[h_idx[m]] (h_idx == NULL: h_in[m]; the trie's parent state).  The new
- * state of row m is written to h_out[m] when m < n_out (the next step's h_in slot) and to h_fin[m] otherwise (both
- * [*,hs]).  gates [rows,4hs] = r, z, n, hn as gtos_gru_cell_fwd saves them; y (optional, row stride ldy) receives
+ * state of row m is written to h_out[m] ([*,hs]) when m < n_out (the next step's h_in slot); otherwise the sequence is
+ * finished and its state goes to h_fin + (fin_idx ? fin_idx[m] : m) * ld_fin -- a column block of the [R, 2hs] "final states"
+ * matrix in BANK order, which replaces the reference's torch.cat of the two directions' h_n and the unsort of the packed
+ * order (generator/encoder.py:104-110).  gates [rows,4hs] = r, z, n, hn as gtos_gru_cell_fwd saves them; y (optional, row stride ldy) receives
  * dropout(h_new) with the same counter layout. */
 int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, int in_dim, const void* w_ih, const float* b_ih,
                       const void* xg, const void* gf, const int* gf_idx, const void* gb, const int* gb_idx,
                       const void* h_in, const int* h_idx, const void* w_hh, const float* b_hh,
-                      void* h_out, int n_out, void* h_fin, void* gates, void* y, int64_t ldy,
+                      void* h_out, int n_out, void* h_fin, int64_t ld_fin, const int* fin_idx, void* gates, void* y, int64_t ldy,
                       float p_drop, uint64_t seed, int64_t drop_base, void* stream);
 
 /* Fused backward GRU step, bf16 only, hs % 64 == 0 (gru_step.hip).  d4 [rows,4hs] = d r | d z | d n_x | d n_h in ONE
  * buffer (d(xg) = columns 0..3hs, d(hg) = columns 0..2hs and 3hs..4hs).  First adds d(hg) W_hh of the step processed
  * just before (d4_prev [rows_prev,4hs], may be NULL; w_hh_t = W_hh^T [hs,3hs]) to the running state gradient dh
- * [rows,hs] (dh_dtype: GTOS_F32 or GTOS_BF16) -- this replaces the per-step GEMM -- then runs the cell backward: dh += dropout-masked dy, writes d4,
+ * [rows,hs] (dh_dtype: GTOS_F32 or GTOS_BF16; row stride ld_dh, so a column block of the [R,2hs] gradient of the final states
+ * serves as the buffer) -- this replaces the per-step GEMM -- then runs the cell backward: dh += dropout-masked dy, writes d4,
  * leaves dh = dh_total * z.  The state row m entered the step with is hprev[hprev_idx[m]] (hprev_idx == NULL: hprev[m]).
  * bias_partials [n_partials,4hs] fp32 (optional, zeroed by the caller) accumulates the
- * column sums of d4 with atomics (sum over dim 0 = GRU bias gradients, as in gtos_gru_cell_bwd). */
+ * column sums of d4 with atomics (sum over dim 0 = GRU bias gradients, as in gtos_gru_cell_bwd).  hprev_out (optional,
+ * [rows,hs]): the entering state of every row written compactly -- the gathered operand of the recurrent weight gradient on
+ * the tries. */
 int gtos_gru_step_bwd(int rows, int hs, const void* d4_prev, int rows_prev, const void* w_hh_t,
-                      const void* gates, const void* hprev, const int* hprev_idx, const void* dy, int64_t ldy, void* dh, int dh_dtype, void* d4,
-                      float p_drop, uint64_t seed, int64_t drop_base, float* bias_partials, int n_partials, void* stream);
+                      const void* gates, const void* hprev, const int* hprev_idx, const void* dy, int64_t ldy, void* dh, int dh_dtype,
+                      int64_t ld_dh, void* d4, float p_drop, uint64_t seed, int64_t drop_base, float* bias_partials, int n_partials,
+                      void* hprev_out, void* stream);
 
 /* Segmented row sums for the trie-evaluated RelationEncoder's backward (generator/encoder.py:93-111 runs every path
  * separately; here the gradient of a shared trie node is the sum over the rows that share it).  bf16 rows, fp32

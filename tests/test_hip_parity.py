@@ -1132,13 +1132,82 @@ def test_factored_relation_host_index_equals_device_index():
 
 
 def test_attention_kernel_rejects_shapes_outside_the_boundary():
-    """The C ABI returns an error code (no launch, no fallback) for shapes outside the documented boundary."""
+    """The C ABI returns an error code (no launch, no fallback) for shapes outside the documented boundary: a head width
+    that is not a multiple of 8 (the kernels read 8 channels per lane) or above 512, d not a multiple of H."""
     from gtos_amd import ops
     from gtos_amd._lib import GtosHipError
-    for d, H in ((768, 8), (96, 4)):
+    from gtos_amd.graph_transformer import RelationMultiheadAttention
+    for d, H in ((36, 3), (40, 10), (1040, 1), (100, 8)):
         qkv = torch.randn(5, 2, 3 * d, device=dev())
         with pytest.raises(GtosHipError):
             ops.attention_core(qkv, None, (0, d, 2 * d), d, H, 1.0)
+    with pytest.raises(GtosHipError):
+        RelationMultiheadAttention(40, 10)                   # refused at construction
+
+
+@pytest.mark.parametrize("n,B,d,H,R", [(7, 3, 48, 6, 30), (11, 2, 96, 4, 50), (9, 8, 640, 5, 60), (6, 2, 1024, 8, 40), (13, 5, 768, 12, 80),
+                                       (5, 1, 24, 1, 9)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_graph_transformer_any_head_geometry_vs_oracle(n, B, d, H, R, dtype):
+    """Shapes off the power-of-two fast path -- the reference only asks d % H == 0 (graph_transformer.py:75): head widths
+    24 / 40 / 96 (idle lanes inside a head), 6 / 5 / 12 heads (idle heads in a slice), d = 640 / 768 / 1024 (two head slices,
+    blockIdx.y) -- factored and dense relation operands and the plain (mode 0) attention of the decoder blocks, forward and
+    every gradient against the pinned oracle."""
+    from gtos_amd.graph_transformer import GraphTransformer
+    from gtos_amd.transformer import TransformerLayer
+    from gtos_amd.ops import FactoredRelation
+    from oracle import gtos_oracle as O
+    bank, idx, x, pad = make_factored_case(n * 100 + d, n, B, d, R)
+    torch.manual_seed(5)
+    ref = O.GraphTransformer(2, d, 2 * d, H, 0.0)
+    for p in ref.parameters():
+        if p.dim() == 1:
+            p.data.add_(0.1 * torch.randn_like(p))
+    m = GraphTransformer(2, d, 2 * d, H, 0.0).to(dev())
+    m.load_state_dict(ref.state_dict())
+    if dtype == torch.bfloat16:
+        from gtos_amd.graph_transformer import set_compute_dtype
+        set_compute_dtype(m, dtype)
+    wout = torch.randn(n, B, d)
+    bank_r, x_r = bank.clone().requires_grad_(), x.clone().requires_grad_()
+    out_r = ref(x_r, O.relation_lookup_train(bank_r, idx), self_padding_mask=pad)
+    (out_r * wout).sum().backward()
+    tol = FP32 if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2)
+    gtol = GRAD if dtype == torch.float32 else None
+    for factored in (True, False):
+        m.zero_grad()
+        bank_d, x_d = bank.to(dev()).requires_grad_(), x.to(dev()).requires_grad_()
+        rel = FactoredRelation(bank_d, idx.to(dev())) if factored else bank_d.index_select(0, idx.to(dev()).reshape(-1)).view(n, n, B, d)
+        out_d = m(x_d, rel, self_padding_mask=pad.to(dev()))
+        (out_d.float() * wout.to(dev())).sum().backward()
+        torch.testing.assert_close(out_d.float().cpu(), out_r, **tol)
+        if gtol:
+            torch.testing.assert_close(x_d.grad.cpu(), x_r.grad, **gtol)
+            torch.testing.assert_close(bank_d.grad.cpu(), bank_r.grad, **gtol)
+            for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+                torch.testing.assert_close(p.grad.cpu(), q.grad, msg=lambda s_, k=k: "%s: %s" % (k, s_), **gtol)
+        else:
+            assert _rel_frob(x_d.grad.float().cpu(), x_r.grad) < 5e-2 and _rel_frob(bank_d.grad.float().cpu(), bank_r.grad) < 5e-2
+    if dtype == torch.float32:
+        # mode 0 with a causal mask + cross attention over the graph states (the decoder's blocks), returned head-max weights
+        torch.manual_seed(6)
+        rl = O.TransformerLayer(d, 2 * d, H, 0.0, with_external=True)
+        tl = TransformerLayer(d, 2 * d, H, 0.0, with_external=True).to(dev())
+        tl.load_state_dict(rl.state_dict())
+        T_ = 6
+        y = torch.randn(T_, B, d)
+        causal = torch.ones(T_, T_, dtype=torch.bool).triu_(1)
+        y_r, mem_r = y.clone().requires_grad_(), x.clone().requires_grad_()
+        o_r, _, ext_r = rl(y_r, self_attn_mask=causal, external_memories=mem_r, external_padding_mask=pad, need_weights=True)
+        (o_r.sum() + ext_r.sum()).backward()
+        y_d, mem_d = y.to(dev()).requires_grad_(), x.to(dev()).requires_grad_()
+        o_d, _, ext_d = tl(y_d, self_attn_mask=causal.to(dev()), external_memories=mem_d, external_padding_mask=pad.to(dev()),
+                           need_weights=True)
+        (o_d.sum() + ext_d.sum()).backward()
+        torch.testing.assert_close(o_d.cpu(), o_r, **FP32)
+        torch.testing.assert_close(ext_d.cpu(), ext_r, **FP32)
+        torch.testing.assert_close(y_d.grad.cpu(), y_r.grad, **GRAD)
+        torch.testing.assert_close(mem_d.grad.cpu(), mem_r.grad, **GRAD)
 
 
 def test_batched_bank_gradient_equals_per_layer_products(monkeypatch):
