@@ -4,8 +4,9 @@ HIP-backed modules.  Same constructor arguments and state_dict keys, so referenc
 Train-mode ``encode_step`` hands the graph encoder the relation in FACTORED form (bank + type ids): it is the
 exact same function as the reference's ``relation.index_select(0, idx).view(n,n,B,d)`` (generator.py:79) but the
 [n,n,B,d] tensor is never built.  Eval mode aggregates alternative shortest paths with the gather-mean kernel
-(generator.py:83-88).  Inference (work / decode_step, generator.py:96-167) runs the beam search of gtos_amd.search over
-projected K/V caches: the reference re-projects the whole prefix in every layer at every step.
+(generator.py:83-88).  Inference (work, generator.py:96-110) runs the beam search of gtos_amd.search over projected K/V caches
+(decode_step_batched): the reference re-projects the whole prefix in every layer at every step.  ``decode_step`` keeps the
+reference's signature (generator.py:119) for callers that bring their own search loop.
 """
 import math
 
@@ -166,32 +167,91 @@ class Generator(nn.Module):
         token_char = torch.tensor([rows], dtype=torch.int64)
         return token.to(self.device), token_char.to(self.device)
 
-    def decode_step(self, tokens, state, memory, beam_of_hyp, offset, topk):
-        """One step for N live hypotheses (generator.py:119-167).  tokens: their last token strings; state: None or
-        {'snt': [cache per sentence-encoder layer], 'inf': [cache per inference layer]}, every cache [t,N,2d];
-        beam_of_hyp [N]: graph index of each hypothesis.  Returns (state grown by one row, per hypothesis the top-k
-        [(token string, log-likelihood)])."""
-        step_token, step_token_char = self.prepare_incremental_input([[t] for t in tokens])
+    def decode_step_batched(self, tokens, state, memory, beam_of_hyp, offset, topk):
+        """One step for N live hypotheses of ALL beams (what gtos_amd.search.beam_search drives).  tokens: their last token
+        strings; state: None or {'snt': [cache per sentence-encoder layer], 'inf': [cache per inference layer]}, every cache
+        [t,N,2d]; memory: per GRAPH (``work``); beam_of_hyp [N]: graph index of each hypothesis.  Returns (state grown by one
+        row, per hypothesis the top-k [(token string, log-likelihood)])."""
+        inp = self.prepare_incremental_input([[t] for t in tokens])
         sel = lambda v: v.index_select(1, beam_of_hyp)
-        mem = {'graph_padding_mask': sel(memory['graph_padding_mask']), 'cp_seq': sel(memory['cp_seq']),
+        owners = beam_of_hyp.tolist()
+        mem = {'graph_padding_mask': sel(memory['graph_padding_mask']), 'cp_seq': sel(memory['cp_seq']), 'probe': sel(memory['probe']),
                'tot_ext': memory['tot_ext'], 'inf_ext_kv': [sel(v) for v in memory['inf_ext_kv']],
-               'align_kv': sel(memory['align_kv'])}
-        snt_ext = [sel(v) for v in memory['snt_ext_kv']]
-        probe = sel(memory['probe'])
+               'snt_ext_kv': [sel(v) for v in memory['snt_ext_kv']], 'align_kv': sel(memory['align_kv']),
+               'local_idx2token': [memory['local_idx2token'][bi] for bi in owners]}
+        snt, inf, results = self._decode_core(inp, None if state is None else state['snt'], None if state is None else state['inf'],
+                                              mem, offset, topk)
+        return {'snt': snt, 'inf': inf}, results
+
+    def _decode_core(self, inp, snt_state, inf_state, mem, offset, topk):
+        """inp = (step_token [1,N], step_token_char [1,N,C]); snt_state / inf_state: per layer [t,N,2d] or None; mem: everything
+        already per hypothesis.  -> (new sentence-encoder caches, new inference caches, top-k results)."""
+        step_token, step_token_char = inp
         pos = self.token_position(step_token, offset).to(self.compute_dtype)
         x = self.embed_scale * self.token_encoder(step_token, step_token_char) + pos
         ln = self.token_embed_layer_norm
         x = ops.layer_norm_residual(x, None, ln.weight, ln.bias, 0.0, ln.eps)
         snt_caches = []
         for li, layer in enumerate(self.snt_encoder.layers):
-            x, c = layer.step(x, x, None if state is None else state['snt'][li], snt_ext[li], mem['graph_padding_mask'])
+            x, c = layer.step(x, x, None if snt_state is None else snt_state[li], mem['snt_ext_kv'][li], mem['graph_padding_mask'])
             snt_caches.append(c)
-        ll, inf_caches = self.decoder.step(probe, x, None if state is None else state['inf'], mem)
+        ll, inf_caches = self.decoder.step(mem['probe'], x, inf_state, mem)
         topk_scores, topk_token = torch.topk(ll.squeeze(0).float(), topk, 1)
         vocab = self.vocabs['predictable_token']
-        owners = beam_of_hyp.tolist()
         results = []
-        for s, t, bi in zip(topk_scores.tolist(), topk_token.tolist(), owners):
-            local = memory['local_idx2token'][bi]
+        for s, t, local in zip(topk_scores.tolist(), topk_token.tolist(), mem['local_idx2token']):
             results.append([(local[i] if i in local else vocab.idx2token(i), sc) for sc, i in zip(s, t)])
-        return {'snt': snt_caches, 'inf': inf_caches}, results
+        return snt_caches, inf_caches, results
+
+    # ---- the reference's decoding interface (generator/generator.py:96-167, generator/search.py:113-166)
+    def reference_memory(self, data):
+        """``mem_dict`` as the reference's ``work`` builds it (generator.py:100-104: graph_state, graph_padding_mask, probe,
+        local_idx2token, cp_seq -- one column / entry per graph), extended by the K/V projections of the graph states for every
+        cross-attention that reads them.  The reference's ``search_by_batch`` treats the dictionary generically (tensors are
+        ``index_select``-ed along dim 1 per live hypothesis, lists are indexed), so the extra entries travel with the rest and
+        ``decode_step`` never re-projects the graph."""
+        with torch.no_grad():
+            concept_repr, concept_mask, probe = self.encode_step(data, train=False)
+            concept_repr = concept_repr.contiguous()
+            mem = {'graph_state': concept_repr, 'graph_padding_mask': concept_mask, 'probe': probe,
+                   'local_idx2token': data['local_idx2token'], 'cp_seq': data['cp_seq']}
+            for li, l in enumerate(self.snt_encoder.layers):
+                mem['snt_ext_kv_%d' % li] = l.external_attn.project_kv(concept_repr)
+            for li, l in enumerate(self.decoder.inference_core.layers):
+                mem['inf_ext_kv_%d' % li] = l.external_attn.project_kv(concept_repr)
+            mem['align_kv'] = self.decoder.token_generator.alignment_layer.project_kv(concept_repr)
+        return mem
+
+    def decode_step(self, inp, state_dict, mem_dict, offset, topk):
+        """The reference's signature and data flow (generator/generator.py:119-167): inp = (step_token [1,N], step_token_char
+        [1,N,C]) from ``prepare_incremental_input``; ``mem_dict``: the reference's keys, every entry already gathered per live
+        hypothesis by the caller; ``state_dict``: {} at the first step, afterwards what the previous call returned, split / joined
+        along dim 1 by the caller.  Returns (new_state_dict, per hypothesis the top-k [(token string, log-likelihood)]).
+
+        The state carried between steps is the PROJECTED K/V rows of every self-attention ('snt_kv_i', 'inf_kv_i', [t,N,2d]) in
+        place of the reference's unprojected 'token_repr_i' / 'token_state' histories -- the same information, so the reference
+        re-projecting the whole prefix in every layer at every step is not needed; any caller that treats the dictionary
+        opaquely (the reference's Beam / search_by_batch do) works unchanged.  ``mem_dict`` entries made by ``reference_memory``
+        are used as they are; with only the reference's own five keys the graph projections are computed here."""
+        with torch.no_grad():
+            dec = self.decoder
+            n_snt, n_inf = len(self.snt_encoder.layers), len(dec.inference_core.layers)
+            graph = mem_dict.get('graph_state')
+
+            def kv(key, attn):
+                v = mem_dict.get(key)
+                return v if v is not None else attn.project_kv(graph)
+            cp_seq = mem_dict['cp_seq']
+            mem = {'graph_padding_mask': mem_dict['graph_padding_mask'], 'cp_seq': cp_seq, 'probe': mem_dict['probe'],
+                   'local_idx2token': mem_dict['local_idx2token'],
+                   'tot_ext': 1 + int(cp_seq.max().item()),          # like decoder.py:48 on the live hypotheses' copy ids
+                   'snt_ext_kv': [kv('snt_ext_kv_%d' % i, l.external_attn) for i, l in enumerate(self.snt_encoder.layers)],
+                   'inf_ext_kv': [kv('inf_ext_kv_%d' % i, l.external_attn) for i, l in enumerate(dec.inference_core.layers)],
+                   'align_kv': kv('align_kv', dec.token_generator.alignment_layer)}
+            first = not state_dict
+            snt_state = None if first else [state_dict['snt_kv_%d' % i] for i in range(n_snt)]
+            inf_state = None if first else [state_dict['inf_kv_%d' % i] for i in range(n_inf)]
+            snt, inf, results = self._decode_core(inp, snt_state, inf_state, mem, offset, topk)
+            new_state = {'snt_kv_%d' % i: c for i, c in enumerate(snt)}
+            new_state.update({'inf_kv_%d' % i: c for i, c in enumerate(inf)})
+        return new_state, results

@@ -8,7 +8,7 @@ stops when it holds ``beam_size`` finished hypotheses or after ``max_time_step``
 score by ``(1 + len(seq)) ** alpha``.
 
 What differs is the machinery: hypotheses carry no tensors.  The decoder state of ALL live hypotheses of ALL sentences
-is one set of K/V-cache tensors ``[t, N, 2d]`` (gtos_amd.generator.Generator.decode_step); a step returns, per beam,
+is one set of K/V-cache tensors ``[t, N, 2d]`` (gtos_amd.generator.Generator.decode_step_batched); a step returns, per beam,
 the parent index of every surviving hypothesis, and the caches are re-gathered with ONE index_select per tensor
 instead of being split into per-hypothesis slices and concatenated again.
 """
@@ -74,7 +74,7 @@ class Beam(object):
 
 
 def beam_search(model, beams, memory):
-    """Runs all beams to completion.  ``model.decode_step(tokens, state, memory, beam_of_hyp, offset, topk)`` ->
+    """Runs all beams to completion.  ``model.decode_step_batched(tokens, state, memory, beam_of_hyp, offset, topk)`` ->
     (state, results); ``state`` is opaque here except that every tensor in it has the hypothesis axis at dim 1."""
     device = memory['probe'].device
     state = None
@@ -89,7 +89,7 @@ def beam_search(model, beams, memory):
         if not owners:
             break
         beam_of_hyp = torch.tensor(owners, dtype=torch.int64, device=device)
-        state, results = model.decode_step(tokens, state, memory, beam_of_hyp, offset, beams[0].beam_size)
+        state, results = model.decode_step_batched(tokens, state, memory, beam_of_hyp, offset, beams[0].beam_size)
         # hand every beam its slice of the results; collect the flat parent index of each survivor
         keep, pos = [], 0
         for bi, beam in enumerate(beams):

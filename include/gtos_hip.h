@@ -54,10 +54,12 @@ int gtos_gemm(int in_dtype, int out_dtype, int transA, int transB, int M, int N,
  * key_pad[S,B] / attn_mask[T,S] are uint8 (non-zero = masked, generator/graph_transformer.py:136-149).
  * Outputs o[T,B,d] (ldo), lse[T,B,H]; w (optional, [T,S,B,H] fp32) receives the post-dropout weights that
  * the reference returns with need_weights (generator/graph_transformer.py:168-172).
- * HARD SHAPE BOUNDARY (returns -10): d and d/H powers of two, d/H >= 8, d <= 512 -- a row of d channels is spread over
- * d/8 lanes of ONE 64-lane wave and the per-head reductions are DPP butterflies.  The reference only needs d % H == 0
- * (generator/graph_transformer.py:75); every configuration it ships or BASELINE.json names (d = 256 / 512, H = 8) is
- * inside the boundary, and the host modules refuse other shapes at construction (gtos_amd.ops.check_attention_shape).
+ * SHAPES (-10 outside): d % H == 0 like the reference (generator/graph_transformer.py:75), head width d/H a multiple of 8
+ * (a lane owns 8 channels) and at most 512.  d and d/H powers of two with d <= 512 -- every configuration the reference ships
+ * or BASELINE.json names (d = 256 / 512, H = 8) -- run on the fast lane map: a row of d channels over d/8 lanes of ONE 64-lane
+ * wave, per-head reductions as DPP butterflies.  Any other shape runs on the generic map: a head takes pow2ceil(d/H/8) lanes
+ * (the surplus lanes idle), a key row as many heads as fit 64 lanes, the remaining heads further slices on blockIdx.y.  The
+ * host modules refuse shapes outside at construction (gtos_amd.ops.check_attention_shape).
  * Modes 1,2 need T == S (-12). */
 int gtos_rel_attn_fwd(int dtype, int mode, int T, int S, int B, int H, int d,
                       const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,

@@ -202,6 +202,75 @@ def test_hip_beam_search_matches_reference(case, tmp_path):
             check_hyps(best, want["k_best"], tag + " k-best")
 
 
+def _search_by_batch_reference_style(model, beams, mem_dict):
+    """The data flow of the reference's search loop (generator/search.py:113-166) around ``model.decode_step(inp, state_dict,
+    mem_dict, offset, topk)``: every hypothesis carries its own state dict (slices along dim 1), the live ones are joined with
+    torch.cat before a step, the memory is gathered per hypothesis (tensors: index_select along dim 1; lists: indexed), and the
+    returned state is index_select-ed by the surviving parents and split again -- all generic over the dictionary keys."""
+    dev = mem_dict['probe'].device
+    states = [[{}] for _ in beams]                     # per beam, per live hypothesis
+    while True:
+        owners, hyp_states, last, offset = [], [], [], -1
+        for bi, beam in enumerate(beams):
+            if not beam.completed():
+                for h, st in zip(beam.hypotheses, states[bi]):
+                    owners.append(bi)
+                    hyp_states.append(st)
+                    last.append(h.seq[-1:])
+                    offset = len(h.seq) - 1
+        if not owners:
+            break
+        inp = model.prepare_incremental_input(last)
+        joined = {k: torch.cat([st[k] for st in hyp_states], 1 if hyp_states[0][k].dim() >= 3 else 0) for k in hyp_states[0]}
+        idx = torch.tensor(owners, device=dev)
+        cur_mem = {k: ([v[i] for i in owners] if isinstance(v, list) else v.index_select(1, idx)) for k, v in mem_dict.items()}
+        new_state, results = model.decode_step(inp, joined, cur_mem, offset, beams[0].beam_size)
+        pos = 0
+        for bi, beam in enumerate(beams):
+            if beam.completed():
+                continue
+            n = len(beam.hypotheses)
+            parents = beam.advance(results[pos:pos + n])
+            par = torch.tensor([pos + p for p in parents], dtype=torch.int64, device=dev)
+            states[bi] = []
+            if len(parents):
+                cut = {k: v.index_select(1 if v.dim() >= 3 else 0, par).split(1, dim=1 if v.dim() >= 3 else 0) for k, v in new_state.items()}
+                states[bi] = [{k: cut[k][j] for k in cut} for j in range(len(parents))]
+            pos += n
+    return beams
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_caches", [True, False])
+def test_decode_step_with_the_reference_signature_under_a_reference_style_search(with_caches, tmp_path):
+    """Generator.decode_step(inp, state_dict, mem_dict, offset, topk) -- the reference's signature (generator.py:119) -- driven
+    by a restatement of the reference's own search loop reproduces the reference's beams (beam_smatch goldens), with the
+    memory of ``reference_memory`` (projected graph K/V travel with it) and with only the reference's five memory keys."""
+    from gtos_amd.generator import Generator
+    from gtos_amd.search import Beam
+    meta, arrs = load_case("beam_smatch")
+    dev = torch.device("cuda:0")
+    vocabs = make_vocabs(meta, tmp_path)
+    cfg = meta["cfg"]
+    ga = [[tuple(f) for f in a] if isinstance(a, list) else a for a in cfg["gen_args"]]
+    model = Generator(vocabs, *ga, cfg["d"], cfg["ff"], cfg["H"], 0.0, cfg["snt_layers"], cfg["graph_layers"],
+                      cfg["inference_layers"], None, dev, depth_size=cfg.get("depth_size", 32)).to(dev)
+    model.load_state_dict(state_dict_of(arrs))
+    model.eval()
+    batch = batch_of(meta, arrs, dev)
+    for run in meta["runs"]:
+        mem = model.reference_memory(batch)
+        if not with_caches:
+            mem = {k: mem[k] for k in ('graph_state', 'graph_padding_mask', 'probe', 'local_idx2token', 'cp_seq')}
+        beams = [Beam(run["beam"], run["min_step"], run["max_step"]) for _ in range(mem['probe'].shape[1])]
+        _search_by_batch_reference_style(model, beams, mem)
+        for b, (beam, want) in enumerate(zip(beams, run["expect"])):
+            tag = "run %s sentence %d" % ((run["beam"], run["max_step"], run["min_step"]), b)
+            assert beam.steps == want["steps"], tag
+            check_hyps([(h.seq, h.score) for h in beam.completed_hypotheses], want["finished"], tag + " finished")
+            check_hyps([(h.seq, h.score) for h in beam.hypotheses], want["alive"], tag + " alive")
+
+
 @pytest.mark.gpu
 def test_hip_incremental_step_equals_full_prefix_recompute(tmp_path):
     """The K/V-cache decode step against the pinned oracle recomputing whole prefixes (teacher-forced random prefixes,
@@ -240,7 +309,7 @@ def test_hip_incremental_step_equals_full_prefix_recompute(tmp_path):
         own_t = torch.tensor(owners, device=dev)
         V = vocabs["predictable_token"].size
         for step in range(5):
-            state, results = model.decode_step([p[-1] for p in prefixes], state, memory, own_t, step, 6)
+            state, results = model.decode_step_batched([p[-1] for p in prefixes], state, memory, own_t, step, 6)
             for h, b in enumerate(owners):
                 want = O.next_token_ll(ref, rg[:, b:b + 1], rgm[:, b:b + 1], rpr[:, b:b + 1],
                                        batch_cpu['cp_seq'][:, b:b + 1], [prefixes[h]], vocabs)[0]

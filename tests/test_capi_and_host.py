@@ -179,15 +179,45 @@ def test_lr_schedule_and_decay_rule():
 
 
 def test_attention_shape_boundary_is_refused_at_construction():
-    """include/gtos_hip.h documents the kernels' hard shape boundary (d, d/H powers of two, d/H >= 8, d <= 512); the
-    modules must raise at construction for anything else (the reference only needs d % H == 0)."""
+    """include/gtos_hip.h documents the kernels' shape boundary (d % H == 0 like the reference, head width a multiple of 8
+    and at most 512); the modules must raise at construction for anything else."""
     import pytest
     from gtos_amd._lib import GtosHipError
     from gtos_amd.graph_transformer import RelationMultiheadAttention
     from gtos_amd.transformer import MultiheadAttention
     for cls in (RelationMultiheadAttention, MultiheadAttention):
-        cls(512, 8)
-        cls(64, 1)
-        for d, H in ((768, 8), (1024, 8), (96, 4), (32, 8)):
+        for d, H in ((512, 8), (64, 1), (768, 8), (1024, 8), (96, 4), (48, 6), (640, 5)):
+            cls(d, H)
+        for d, H in ((32, 8), (36, 3), (1040, 1)):
             with pytest.raises(GtosHipError):
                 cls(d, H)
+        with pytest.raises(AssertionError):
+            cls(100, 8)                         # the reference's own assert: embed_dim divisible by num_heads
+
+
+def test_reference_module_names_resolve_to_the_product_modules():
+    """The reference's bare import lines (generator/generator.py:6-9 and friends) resolve to gtos_amd after one call."""
+    import sys
+    import gtos_amd
+    saved = {n: sys.modules.get(n) for n in gtos_amd.REFERENCE_MODULE_NAMES}
+    try:
+        for n in gtos_amd.REFERENCE_MODULE_NAMES:
+            sys.modules.pop(n, None)
+        assert gtos_amd.install_reference_names() == list(gtos_amd.REFERENCE_MODULE_NAMES)
+        from graph_transformer import GraphTransformer, GraphTransformerLayer, RelationMultiheadAttention   # noqa: F401
+        from transformer import Transformer, TransformerLayer, MultiheadAttention, SinusoidalPositionalEmbedding, SelfAttentionMask  # noqa: F401
+        from encoder import RelationEncoder, TokenEncoder                                                   # noqa: F401
+        from decoder import DecodeLayer, TokenGenerator                                                     # noqa: F401
+        from generator import Generator
+        from search import Beam                                                                              # noqa: F401
+        import gtos_amd.generator as g
+        assert Generator is g.Generator
+        import types
+        sys.modules["encoder"] = types.ModuleType("encoder")          # a foreign module of that name is left alone ...
+        assert "encoder" not in gtos_amd.install_reference_names()
+        assert "encoder" in gtos_amd.install_reference_names(force=True)   # ... unless forced
+    finally:
+        gtos_amd.uninstall_reference_names()
+        for n, m in saved.items():
+            if m is not None:
+                sys.modules[n] = m
