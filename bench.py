@@ -70,7 +70,9 @@ def parse():
                     help="loader in the loop: a NEW batch every step, assembled by gtos_amd.data.AMRLoader (C++ relation batch, path "
                          "tries, relation index) on Prefetcher worker threads and uploaded on a copy stream, like the reference's "
                          "training loop (generator/train.py:136-140, generator/data.py:290-316); default: one pre-built device batch")
-    ap.add_argument("--workers", type=int, default=4, help="--fresh-batches: loader threads per rank")
+    ap.add_argument("--workers", type=int, default=4, help="--fresh-batches: loader workers per rank")
+    ap.add_argument("--loader", default="processes", choices=["processes", "threads"],
+                    help="--fresh-batches: worker processes (own interpreter each: no GIL contention with the launch thread) or threads")
     ap.add_argument("--depth", type=int, default=3, help="--fresh-batches: batches assembled ahead")
     ap.add_argument("--relbatch-threads", type=int, default=2, help="--fresh-batches: threads inside one relation-batch build")
     ap.add_argument("--pool", type=int, default=0, help="--fresh-batches: graphs in the per-rank item pool (default 4 batches)")
@@ -432,22 +434,27 @@ def main():
                                     rng=random.Random(19940117 + rank), n_threads=a.relbatch_threads, graphs=graphs)
         asm_times = []
 
-        def timed_thunks():
+        def timed_run(job):                                               # runs in the worker: reports its own assembly time
+            t_ = time.perf_counter()
+            out_ = loader.run_job(job)
+            out_["_assembly_s"] = time.perf_counter() - t_
+            return out_
+
+        def jobs():
             while True:                                                   # epochs over the pool: reshuffled, paths re-drawn
-                for f in loader.thunks():
-                    def g(f=f):
-                        t_ = time.perf_counter()
-                        out_ = f()
-                        asm_times.append(time.perf_counter() - t_)
-                        return out_
-                    yield g
-        feed = data_mod.Prefetcher(timed_thunks(), depth=a.depth, workers=a.workers, device=dev)
+                yield from loader.jobs()
+        if a.loader == "processes":
+            feed = data_mod.Prefetcher(jobs(), depth=a.depth, workers=a.workers, device=dev, processes=True, runner=timed_run)
+        else:
+            feed = data_mod.Prefetcher((lambda j=j: timed_run(j) for j in jobs()), depth=a.depth, workers=a.workers, device=dev)
         batch = next(feed)
         stats = {"n": int(batch["concept"].shape[0]), "B": int(batch["concept"].shape[1]), "T": int(batch["token_in"].shape[0]),
                  "R": int(batch["relation_bank"].shape[1]),
                  "mean_path_len": float(batch["relation_length"].float().mean())}
         assert stats["B"] == B_rank, stats
-        loader_info = {"workers": a.workers, "depth": a.depth, "relbatch_threads": a.relbatch_threads, "pool_graphs_per_rank": pool_n}
+        asm_times.append(batch.pop("_assembly_s"))
+        loader_info = {"workers": a.workers, "kind": a.loader, "depth": a.depth, "relbatch_threads": a.relbatch_threads,
+                       "pool_graphs_per_rank": pool_n}
     else:
         batch, stats = synth.make_config_batch(a.config, rank=rank, B=B_rank)   # rank r holds graphs [r*B_rank, (r+1)*B_rank)
         attach_relation_index(attach_path_trie(batch))   # host-side index preparation: batch assembly, like the relation bank itself
@@ -462,6 +469,7 @@ def main():
         t_ = time.perf_counter()
         b_ = next(feed)
         wait_s[0] += time.perf_counter() - t_
+        asm_times.append(b_.pop("_assembly_s"))
         return b_
 
     def sync():

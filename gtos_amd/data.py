@@ -142,6 +142,18 @@ class DependencyLoader(object):
             yield batchify_dependency([self.data[i] for i in b], self.vocabs, n_threads=self.n_threads,
                                       unk_rate=self.unk_rate, rng=self.rng, index_prep=self.index_prep)
 
+    def jobs(self):
+        """The same batches as small picklable job records for ``Prefetcher(..., runner=loader.run_job, processes=True)``:
+        (example indices, seed of a private <UNK>-noise generator), drawn from ``rng`` in batch order."""
+        for b in self.batch_indices():
+            yield (b, self.rng.getrandbits(63))
+
+    def run_job(self, job):
+        import random
+        b, unk_seed = job
+        return batchify_dependency([self.data[i] for i in b], self.vocabs, n_threads=self.n_threads, unk_rate=self.unk_rate,
+                                   rng=random.Random(unk_seed), index_prep=self.index_prep)
+
     def thunks(self):
         """The same batches as callables (``Prefetcher`` runs a callable on its worker thread, so several workers assemble
         batches in parallel; plain iteration assembles under the prefetcher's source lock, one at a time).  The <UNK> noise
@@ -297,6 +309,18 @@ class AMRLoader(object):
         for b in self.batch_indices():
             yield self._assemble([self.data[i] for i in b], self.rng.getrandbits(63), self.rng)
 
+    def jobs(self):
+        """Small picklable job records for ``Prefetcher(..., runner=loader.run_job, processes=True)``: (item indices,
+        path-sampling seed, seed of a private <UNK>-noise generator), drawn from ``rng`` in batch order -- the same draws as
+        ``thunks()``, so both give the same batches."""
+        for b in self.batch_indices():
+            yield (b, self.rng.getrandbits(63), self.rng.getrandbits(63))
+
+    def run_job(self, job):
+        import random
+        b, seed, unk_seed = job
+        return self._assemble([self.data[i] for i in b], seed, random.Random(unk_seed))
+
     def thunks(self):
         """The same batches as callables for ``Prefetcher(workers > 1)`` (see DependencyLoader.thunks): path-sampling seed and
         a private <UNK>-noise generator are drawn from ``rng`` when the thunk is created, in batch order."""
@@ -328,8 +352,23 @@ def _device_tensors(obj, seen=None):
             yield from _device_tensors(v, seen)
 
 
+def _process_worker(runner, jobq, resq):
+    """Main loop of a forked loader process: CPU work only (the parent's GPU context is never touched here)."""
+    torch.set_num_threads(1)
+    while True:
+        item = jobq.get()
+        if item is None:
+            break
+        k, job = item
+        try:
+            resq.put((k, runner(job), None))
+        except BaseException as e:                    # reported to the consumer through the receiver thread
+            import traceback
+            resq.put((k, None, "%r\n%s" % (e, traceback.format_exc())))
+
+
 class Prefetcher(object):
-    """Keeps ``depth`` batches assembled ahead of the consumer on background threads.
+    """Keeps ``depth`` batches assembled ahead of the consumer on background threads or worker processes.
 
     Batch assembly is host work -- graph paths + relation bank, path tries, relation index (csrc_host) -- and all of it runs
     inside libgtos_host.so, which ctypes calls with the GIL released, so it overlaps the GPU step driven by the main thread.
@@ -344,10 +383,17 @@ class Prefetcher(object):
       inside PathTrie / RelationIndex) is ``record_stream``-ed on the consumer's stream: the blocks live in the copy stream's
       pool, and without the record the caching allocator could hand them to a later upload while the consumer's kernels
       (backward, optimizer) still read them.
+    * ``processes=True`` with ``runner``: the source yields small picklable JOB records and ``runner(job)`` assembles the batch in
+      one of ``workers`` forked worker PROCESSES (``loader.jobs()`` / ``loader.run_job``).  Threads share the interpreter lock
+      with the training loop, whose ~1,200 kernel launches per step are Python work: every Python-level loop of the assembly
+      (token / character tensors, copy vocabularies) stalls the launch thread, and more worker threads make the step SLOWER
+      (measured at C2: 69.6 / 75.4 / 98.0 ms per step with 2 / 4 / 8 threads against 64.2 ms on a pre-built batch).  Worker
+      processes have their own interpreter; finished batches come back through shared memory (torch.multiprocessing) and a
+      single receiver thread uploads them.  The workers are forked at construction and must not touch the GPU.
     * Order of the batches is the iterable's order.  ``close()`` (also on garbage collection / context exit) stops the
       workers; batches already assembled are dropped."""
 
-    def __init__(self, batches, depth=2, workers=1, device=None):
+    def __init__(self, batches, depth=2, workers=1, device=None, processes=False, runner=None):
         import threading
         self._it = iter(batches)
         self._out = {}
@@ -357,7 +403,20 @@ class Prefetcher(object):
         self._device = torch.device(device) if device is not None else None
         self._copy_stream = torch.cuda.Stream(self._device) if self._device is not None and self._device.type == "cuda" else None
         self.workers = max(1, workers)
-        self._threads = [threading.Thread(target=self._work, daemon=True) for _ in range(self.workers)]
+        self._procs = []
+        if processes:
+            if runner is None:
+                raise ValueError("processes=True needs runner(job) -> batch (e.g. loader.run_job with loader.jobs() as the source)")
+            import torch.multiprocessing as mp
+            ctx = mp.get_context("fork")          # the runner and everything it references are inherited, not pickled
+            self._jobq, self._resq = ctx.Queue(), ctx.Queue()
+            self._procs = [ctx.Process(target=_process_worker, args=(runner, self._jobq, self._resq), daemon=True)
+                           for _ in range(self.workers)]
+            for p_ in self._procs:
+                p_.start()
+            self._threads = [threading.Thread(target=self._feed, daemon=True), threading.Thread(target=self._receive, daemon=True)]
+        else:
+            self._threads = [threading.Thread(target=self._work, daemon=True) for _ in range(self.workers)]
         for t in self._threads:
             t.start()
 
@@ -381,9 +440,9 @@ class Prefetcher(object):
 
     def _upload(self, batch):
         with torch.cuda.stream(self._copy_stream):
-            def up(v):
-                if isinstance(v, torch.Tensor):
-                    return v.pin_memory().to(self._device, non_blocking=True)
+            def up(v):                               # (no pin_memory(): a fresh pinned allocation per tensor and batch costs more
+                if isinstance(v, torch.Tensor):      #  than the staged copy it saves, and only this worker waits for the copy)
+                    return v.to(self._device, non_blocking=True)
                 return v.to(self._device) if hasattr(v, "to") else v
             if isinstance(batch, tuple):           # (batch, items) of a recording loader
                 out = (dict((n, up(v)) for n, v in batch[0].items()),) + tuple(batch[1:])
@@ -416,11 +475,67 @@ class Prefetcher(object):
             with self._cv:
                 self._cv.notify_all()
 
+    # ---- process mode: a feeder thread hands out jobs within ``depth`` of the consumer, a receiver thread collects results
+    def _feed(self):
+        try:
+            while True:
+                k, job = self._take()
+                if k is None:
+                    break
+                self._jobq.put((k, job))
+        except BaseException as e:
+            with self._cv:
+                self._err = e
+                self._cv.notify_all()
+
+    def _receive(self):
+        import queue
+        try:
+            while True:
+                with self._cv:
+                    if self._stop or self._err is not None:
+                        break
+                    if self._done and len(self._out) + self._next_out >= self._next_in:
+                        break
+                try:
+                    k, batch, err = self._resq.get(timeout=0.2)
+                except queue.Empty:
+                    if any(not p_.is_alive() for p_ in self._procs) and not self._stop:
+                        raise RuntimeError("a loader worker process died")
+                    continue
+                if err is not None:
+                    raise RuntimeError("loader worker failed: %s" % err)
+                ev = None
+                if self._copy_stream is not None:
+                    batch, ev = self._upload(batch)
+                with self._cv:
+                    if self._stop:
+                        break
+                    self._out[k] = (batch, ev)
+                    self._cv.notify_all()
+        except BaseException as e:
+            with self._cv:
+                self._err = e
+                self._cv.notify_all()
+        finally:
+            with self._cv:
+                self._cv.notify_all()
+
     def close(self):
         with self._cv:
             self._stop = True
             self._out.clear()
             self._cv.notify_all()
+        for p_ in self._procs:
+            try:
+                self._jobq.put(None)
+            except Exception:
+                pass
+        for p_ in self._procs:
+            p_.join(timeout=0.5)
+            if p_.is_alive():
+                p_.terminate()
+        self._procs = []
 
     def __del__(self):
         try:

@@ -11,8 +11,23 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def host_cores():
+    """CPU threads this process may really use: the affinity mask capped by the cgroup CPU quota.  The GPU box lists many more
+    CPUs than its quota grants, and torch's default of one thread per listed CPU makes every CPU oracle leg crawl (the round-3
+    full-size test spent 380 CPU-minutes that way)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    torch.set_num_threads(host_cores())
 
 
 def load_golden(name):

@@ -3,8 +3,9 @@
 The oracle comparisons of test_hip_parity.py run 3-graph slices; here the size-dependent machinery of the production path --
 the persistent GRU layer-1 step kernel over all its launches, multi-chunk fp32 slots of heavy trie nodes, range sums over wide
 trie levels, the K = L*2d bank-gradient slab, split-K weight gradients -- is checked at the size bench.py runs:
-  * RelationEncoder forward of the WHOLE bank against the pinned fp32 oracle on the host cores (column chunks: paths are
-    independent sequences), bf16 trie path, bf16 per-row path and the fp32 per-row path;
+  * RelationEncoder forward of the WHOLE bank on the GPU (bf16 trie path, bf16 per-row path, fp32 per-row path) against the
+    pinned fp32 oracle on the host cores for every 6th path (paths are independent sequences, 72 k of them keep the CPU leg
+    near half a minute), and against the fp32 HIP run -- itself within 3e-7 of the oracle -- for all of them;
   * trie path == per-row path, forward and every parameter gradient (the per-row path is the one the slices pin to the oracle);
   * one full bf16 Generator forward + backward at B = 64 against the fp32 HIP run of the same weights (fp32 is oracle-pinned at
     4e-4 on the slices): loss and the whole flat gradient.
@@ -13,6 +14,8 @@ import os
 
 import pytest
 import torch
+
+from conftest import host_cores  # noqa: F401  (conftest caps torch's thread count at the cgroup quota)
 
 pytestmark = pytest.mark.gpu
 
@@ -57,12 +60,16 @@ def _encoder_pair():
     return ref, m
 
 
-def _oracle_bank(ref, bank, length, chunk=40000):
-    torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
+ORACLE_STRIDE = 6      # the oracle evaluates every 6th path of the bank (72 k of 434 k paths, ~2 TFLOP on the host cores);
+
+
+def _oracle_bank(ref, bank, length, cols, chunk=24000):
+    """Oracle relation vectors of the bank columns ``cols`` (paths are independent sequences: any subset is exact)."""
     outs = []
     with torch.no_grad():
-        for lo in range(0, bank.shape[1], chunk):
-            outs.append(ref(bank[:, lo:lo + chunk], length[lo:lo + chunk]))
+        for lo in range(0, cols.numel(), chunk):
+            c = cols[lo:lo + chunk]
+            outs.append(ref(bank[:, c], length[c]))
     return torch.cat(outs)
 
 
@@ -73,7 +80,8 @@ def test_c2_full_bank_relation_encoder_vs_oracle_and_trie_equals_per_row(monkeyp
     R = bank.shape[1]
     assert R > 400000 and int(length.sum()) > 2000000
     ref, m = _encoder_pair()
-    want = _oracle_bank(ref, bank, length)                                   # [R, 512] fp32, the whole bank on the host cores
+    cols = torch.arange(0, R, ORACLE_STRIDE)
+    want = _oracle_bank(ref, bank, length, cols)                             # [R/6, 512] fp32 on the host cores; the GPU runs ALL paths
     bank_d, len_d, trie_d = bank.to(dev()), length.to(dev()), trie.to(dev())
     wout = torch.randn(R, 512, generator=torch.Generator().manual_seed(1)).to(dev())
     res = {}
@@ -87,16 +95,22 @@ def test_c2_full_bank_relation_encoder_vs_oracle_and_trie_equals_per_row(monkeyp
         (out.float() * wout).sum().backward()
         torch.cuda.synchronize()
         res[name] = (out.detach().float().cpu(), {k: p.grad.detach().float().cpu().clone() for k, p in m.named_parameters()})
-        err = (res[name][0] - want).abs()
+        err = (res[name][0][cols] - want).abs()
         print("C2 full bank, %s: max |err| %.3e, mean %.3e (|out| max %.2f)" % (name, float(err.max()), float(err.mean()),
                                                                                float(want.abs().max())))
-    # forward vs the oracle: fp32 1e-3 (north_star); bf16 1e-2 of the output scale
+    # forward vs the oracle (every 6th path).  fp32: 1e-3 (north_star; measured 3e-7).  bf16: north_star's 1e-2 absolute is
+    # loose on outputs of magnitude 0.2, so the bar is 2e-2 of the output scale (measured 1.25e-3 = 0.6e-2 of |out| max 0.20)
     scale = float(want.abs().max())
-    assert float((res["fp32 per-row"][0] - want).abs().max()) < 1e-3 * max(1.0, scale)
+    assert float((res["fp32 per-row"][0][cols] - want).abs().max()) < 1e-3 * max(1.0, scale)
     for name in ("bf16 trie", "bf16 per-row"):
-        assert float((res[name][0] - want).abs().max()) < 1e-2 * max(1.0, scale), name
+        assert float((res[name][0][cols] - want).abs().max()) < 2e-2 * scale, name
+    # the fp32 HIP run of ALL paths stands in for the oracle on the paths the oracle skipped: fp32 is within 3e-7 of the oracle
+    # on the sampled paths, and both bf16 paths must be within the same bar of it on every path
+    full32 = res["fp32 per-row"][0]
+    for name in ("bf16 trie", "bf16 per-row"):
+        assert float((res[name][0] - full32).abs().max()) < 2e-2 * scale, name
     # trie == per-row in bf16 (different summation trees, same function) ...
-    assert float((res["bf16 trie"][0] - res["bf16 per-row"][0]).abs().max()) < 1e-2 * max(1.0, scale)
+    assert float((res["bf16 trie"][0] - res["bf16 per-row"][0]).abs().max()) < 2e-2 * scale
     # ... and every parameter gradient: both bf16 paths against the fp32 run of the same batch (oracle-pinned at slice size)
     g32 = res["fp32 per-row"][1]
     worst = {}
@@ -105,8 +119,8 @@ def test_c2_full_bank_relation_encoder_vs_oracle_and_trie_equals_per_row(monkeyp
         worst[k] = (e_t, e_r)
     print("C2 full bank, relative gradient error vs fp32 (trie, per-row):",
           ", ".join("%s %.3g/%.3g" % (k, a, b) for k, (a, b) in sorted(worst.items(), key=lambda kv: -kv[1][0])))
-    for k, (e_t, e_r) in worst.items():
-        assert e_t < max(3e-2, 1.5 * e_r), (k, e_t, e_r)
+    for k, (e_t, e_r) in worst.items():          # measured: every tensor 0.2-0.6 % on both paths
+        assert e_t < max(1.5e-2, 1.5 * e_r), (k, e_t, e_r)
 
 
 def test_c2_full_batch_generator_bf16_vs_fp32_hip():
@@ -135,9 +149,11 @@ def test_c2_full_batch_generator_bf16_vs_fp32_hip():
     table = sorted(((_rel_frob(g16[k], g32[k]), k, float(g32[k].norm())) for k in g32), reverse=True)
     print("C2 B=64: loss bf16 %.6f vs fp32 %.6f; global relative gradient error %.4f; worst tensors: %s" % (
         l16, l32, glob, ", ".join("%s %.3g" % (k, e) for e, k, _ in table[:6])))
-    assert abs(l16 - l32) < 1e-2 * max(1.0, abs(l32)), (l16, l32)
-    assert glob < 6e-2, glob                       # the slices' bar (test_hip_parity.BF16_GRAD_GLOBAL)
+    # measured at introduction: loss 7.088692 vs 7.088733 (6e-6 relative), global gradient error 1.15e-2, worst tensor 0.116
+    # (concept_encoder.char_embed.weight: a sum over 90 k character rows with heavy cancellation)
+    assert abs(l16 - l32) < 1e-3 * max(1.0, abs(l32)), (l16, l32)
+    assert glob < 3e-2, glob
     gmax = max(nrm for _, _, nrm in table)
     for e, k, nrm in table:
         if nrm > 1e-4 * gmax:
-            assert e < 0.3, (k, e, nrm)
+            assert e < 0.2, (k, e, nrm)

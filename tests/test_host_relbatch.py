@@ -403,3 +403,35 @@ def test_trie_builder_rejection_falls_back_to_the_per_row_encoder(monkeypatch):
              "relation_length": torch.tensor([65, 1])}
     out = data._index_prep(dict(batch), True)
     assert "relation_trie" not in out and "relation_index" in out
+
+
+def test_prefetcher_process_workers_give_the_same_batches_in_order(tmp_path):
+    """processes=True: jobs -> forked worker processes (loader.run_job) -> shared memory -> consumer, same batches as the
+    thunks of the same rng state, in order; an exception in a worker surfaces in the consumer; close() reaps the workers."""
+    import json
+    import random
+    from conftest import GOLDEN
+    from gtos_amd import data
+    meta = json.load(open(os.path.join(GOLDEN, "host_amr_smatch_items.json")))
+    vocabs = _amr_vocabs(tmp_path, meta["relation_vocab"])
+    items = [dict(it, token=["a"] * (1 + k % 3)) for k, it in enumerate(meta["items"] * 3)]
+    unit = data.AMRLoader.size_of(items[0])
+
+    def loader():
+        return data.AMRLoader(vocabs, items, batch_size=2 * unit, for_train=True, rng=random.Random(11))
+    want = [f() for f in loader().thunks()]
+    ld = loader()
+    pf = data.Prefetcher(ld.jobs(), depth=3, workers=3, processes=True, runner=ld.run_job)
+    got = list(pf)
+    procs = list(pf._procs)
+    pf.close()
+    assert len(got) == len(want) >= 3
+    for a, b in zip(want, got):
+        assert torch.equal(a["relation"], b["relation"]) and torch.equal(a["token_in"], b["token_in"])
+        assert torch.equal(a["relation_trie"].row_sf, b["relation_trie"].row_sf) and a["relation_trie"].batch_sizes == b["relation_trie"].batch_sizes
+        assert torch.equal(a["relation_index"].pair_sorted, b["relation_index"].pair_sorted)
+        assert a["local_idx2token"] == b["local_idx2token"]
+    assert all(not p.is_alive() for p in procs)
+    dl = data.DependencyLoader(None, [(["a"], [0], ["x"], ["y"])] * 4, batch_size=2, for_train=False)
+    with pytest.raises(RuntimeError, match="loader worker failed"):          # vocabs=None: the worker raises, the consumer sees it
+        list(data.Prefetcher(dl.jobs(), depth=2, workers=1, processes=True, runner=dl.run_job))
