@@ -73,7 +73,9 @@ def parse():
     ap.add_argument("--workers", type=int, default=4, help="--fresh-batches: loader workers per rank")
     ap.add_argument("--loader", default="processes", choices=["processes", "threads"],
                     help="--fresh-batches: worker processes (own interpreter each: no GIL contention with the launch thread) or threads")
-    ap.add_argument("--depth", type=int, default=3, help="--fresh-batches: batches assembled ahead")
+    ap.add_argument("--depth", type=int, default=0,
+                    help="--fresh-batches: batches in flight (default 2 per worker: a batch spends ~0.2 s between job hand-out and "
+                         "upload, three step times at C2, so fewer than that starves the consumer whatever the worker count)")
     ap.add_argument("--relbatch-threads", type=int, default=2, help="--fresh-batches: threads inside one relation-batch build")
     ap.add_argument("--pool", type=int, default=0, help="--fresh-batches: graphs in the per-rank item pool (default 4 batches)")
     ap.add_argument("--dry-launch", action="store_true",
@@ -432,6 +434,7 @@ def main():
         unit = data_mod.AMRLoader.size_of(items[0])                       # every item of a config has the same size
         loader = data_mod.AMRLoader(vocabs_s, items, batch_size=B_rank * unit - unit // 2, for_train=True,
                                     rng=random.Random(19940117 + rank), n_threads=a.relbatch_threads, graphs=graphs)
+        a.depth = a.depth or 2 * a.workers
         asm_times = []
 
         def timed_run(job):                                               # runs in the worker: reports its own assembly time

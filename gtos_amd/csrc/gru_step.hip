@@ -457,6 +457,8 @@ struct StepBwdArgs {
     const bf16_t* gates; const bf16_t* hprev; const int* hprev_idx; const bf16_t* dy; int64_t ldy;
     void* dh; int dh_bf16; int64_t ld_dh; bf16_t* d4; float* bias_part; int n_partials;
     bf16_t* hp_out;                                // optional [rows,hs]: the (gathered) entering state of every row, written compactly
+    const int* sum_idx;                            // optional [rows]: row m takes its operand row from d4_prev[sum_idx[m]] and its incoming
+    const void* dh_src;                            //   state gradient from dh_src[sum_idx[m]] (row stride hs) instead of d4_prev[m] / dh[m]
     float p_drop; uint64_t seed; int64_t drop_base;
     int rows, hs; const void* zeros;
 };
@@ -501,10 +503,10 @@ __global__ __launch_bounds__(256, 3) void gru_step_bwd_kernel(StepBwdArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    if (a.d4_prev && m0 < a.rows_prev) {
+    if (a.d4_prev && m0 < (a.sum_idx ? a.rows : a.rows_prev)) {
         for (int kk = 0; kk < 3 * hs; kk += BK) {
             const int ak = kk < 2 * hs ? kk : kk + hs;                 // skip the d n_x block of d4
-            dma_rows(a.d4_prev, Z, 4 * (int64_t)hs, a.rows_prev, m0, ak, ak + BK, As, wave, lane);
+            dma_rows(a.d4_prev, Z, 4 * (int64_t)hs, a.sum_idx ? a.rows : a.rows_prev, m0, ak, ak + BK, As, wave, lane, a.sum_idx);
             dma_wt(a.wh_t, 3 * (int64_t)hs, c0, kk, Bs, wave, lane);
             __syncthreads();
 #pragma unroll
@@ -541,7 +543,11 @@ __global__ __launch_bounds__(256, 3) void gru_step_bwd_kernel(StepBwdArgs a) {
         ld16(a.hprev + (int64_t)(a.hprev_idx ? a.hprev_idx[m] : m) * hs + cb, hp);
         float* dhp = static_cast<float*>(a.dh) + (int64_t)m * a.ld_dh + cb;
         bf16_t* dhb = static_cast<bf16_t*>(a.dh) + (int64_t)m * a.ld_dh + cb;
-        if (a.dh_bf16) ld16(dhb, g); else ldf16(dhp, g);
+        if (a.sum_idx) {                                               // trie: the children's summed gradient lives in another row
+            const int64_t sr = a.sum_idx[m];
+            if (a.dh_bf16) ld16(static_cast<const bf16_t*>(a.dh_src) + sr * hs + cb, g);
+            else ldf16(static_cast<const float*>(a.dh_src) + sr * hs + cb, g);
+        } else if (a.dh_bf16) ld16(dhb, g); else ldf16(dhp, g);
 #pragma unroll
         for (int i = 0; i < 16; ++i) g[i] += acc[mt][i >> 2][i & 3];
         if (a.dy) {
@@ -659,18 +665,19 @@ extern "C" int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, i
 extern "C" int gtos_gru_step_bwd(int rows, int hs, const void* d4_prev, int rows_prev, const void* w_hh_t,
                                  const void* gates, const void* hprev, const int* hprev_idx, const void* dy, int64_t ldy, void* dh, int dh_dtype,
                                  int64_t ld_dh, void* d4, float p_drop, uint64_t seed, int64_t drop_base, float* bias_partials,
-                                 int n_partials, void* hprev_out, void* stream) {
+                                 int n_partials, void* hprev_out, const int* sum_idx, const void* dh_src, void* stream) {
     if (rows <= 0) return 0;
     if (hs <= 0 || hs % TC) return -22;
     if (!gates || !hprev || !dh || !d4 || (d4_prev && !w_hh_t)) return -23;
     if (bias_partials && n_partials < 1) return -26;
+    if (sum_idx && (!dh_src || (uintptr_t)dh_src % 16)) return -23;
     if ((uintptr_t)d4_prev % 16 || (uintptr_t)w_hh_t % 16 || (uintptr_t)gates % 16 || (uintptr_t)hprev % 16 || (uintptr_t)dh % 16 ||
         (uintptr_t)d4 % 16 || (dy && ((uintptr_t)dy % 16 || ldy % 8)) || ld_dh < hs || ld_dh % 8 || (uintptr_t)hprev_out % 16) return -25;
     StepBwdArgs a;
     a.d4_prev = (const bf16_t*)d4_prev; a.rows_prev = d4_prev ? rows_prev : 0; a.wh_t = (const bf16_t*)w_hh_t;
     a.gates = (const bf16_t*)gates; a.hprev = (const bf16_t*)hprev; a.hprev_idx = hprev_idx; a.dy = (const bf16_t*)dy; a.ldy = ldy;
     a.dh = dh; a.dh_bf16 = dh_dtype == GTOS_BF16; a.ld_dh = ld_dh; a.d4 = (bf16_t*)d4; a.bias_part = bias_partials; a.n_partials = n_partials;
-    a.hp_out = (bf16_t*)hprev_out;
+    a.hp_out = (bf16_t*)hprev_out; a.sum_idx = sum_idx; a.dh_src = dh_src;
     a.p_drop = p_drop; a.seed = seed; a.drop_base = drop_base; a.rows = rows; a.hs = hs;
     a.zeros = gtos_zero_block();
     if (!a.zeros) return -5;

@@ -212,6 +212,10 @@ def _grad_target(p):
 # bank-gradient kernel takes a row stride) and the bank's gradient is ONE product with K = L*2d = 8192 on the 256x256
 # deep-K kernel, accumulated in fp32 across all layers.  GTOS_BATCH_DX=0 restores the per-layer products.
 BATCH_DX = os.environ.get("GTOS_BATCH_DX", "1") != "0"
+# Layers per deep-K product of the slab (0: one product over all layers after the last one, the round-2 behaviour).  2 at the
+# reference's d = 512: K = 2 * 1024 = 2048 per product keeps the 256x256 deep-K kernel, and the bf16 accumulator is rounded L/2
+# times instead of once (the per-layer form rounds L times).
+DX_CHUNK = int(os.environ.get("GTOS_DX_CHUNK", "2"))
 
 
 class GradAccumGroup:
@@ -225,7 +229,8 @@ class GradAccumGroup:
         self.slab = None          # [R, members*w]: the members' output gradients side by side
         self.width = 0
         self.handed = 0           # column blocks handed out
-        self.pieces = []          # (column block, W^T [in, w]) of members whose backward has run
+        self.flushed = 0          # column blocks already folded into buf
+        self.pieces = []          # (column block, W^T [in, w]) of members whose backward has run and that are not folded in yet
 
     def register(self):
         self.pending += 1
@@ -261,22 +266,44 @@ class GradAccumGroup:
         else:
             gemm(dy2, wt, trans_b=True, out=self.buf, accumulate=True)
         self.pending -= 1
+        # The slab blocks are handed out in backward order, so blocks [done, done + DX_CHUNK) are complete as soon as DX_CHUNK
+        # more members have run: their K = DX_CHUNK * w product goes out NOW (the caller runs this on the auxiliary stream,
+        # beside the attention-backward kernels of the layers still to come) instead of ONE K = L * w product after the last
+        # layer, which nothing could overlap: 3.1 ms of an otherwise idle main stream at C2.
+        self._flush(final=self.pending == 0)
         if self.pending > 0:
             return None
-        if self.pieces:
-            pieces = sorted(self.pieces, key=lambda t: t[0])
-            if self.buf is None and [jj for jj, _ in pieces] == list(range(self.members)):
-                wcat = torch.cat([w_ for _, w_ in pieces], dim=1)              # [in, members*w]
-                self.buf = gemm(self.slab, wcat, trans_b=True)                 # one deep-K product, fp32 accumulation over all layers
-            else:                                                              # mixed: fold the slab blocks in one by one
-                for jj, w_ in pieces:
-                    blk = self.slab[:, jj * self.width:(jj + 1) * self.width]
-                    if self.buf is None:
-                        self.buf = gemm(blk, w_, trans_b=True)
-                    else:
-                        gemm(blk, w_, trans_b=True, out=self.buf, accumulate=True)
-        out, self.buf, self.slab, self.pieces = self.buf, None, None, []
+        out, self.buf, self.slab, self.pieces, self.flushed = self.buf, None, None, [], 0
         return out.view(shape)
+
+    def _fold(self, take):
+        """buf (+)= slab[:, consecutive blocks of ``take``] @ cat(their W^T)^T -- one deep-K product, fp32 accumulation inside it."""
+        j0 = take[0][0]
+        blk = self.slab[:, j0 * self.width:(j0 + len(take)) * self.width]
+        wcat = take[0][1] if len(take) == 1 else torch.cat([w_ for _, w_ in take], dim=1)          # [in, len(take) * w]
+        if self.buf is None:
+            self.buf = gemm(blk, wcat, trans_b=True)
+        else:
+            gemm(blk, wcat, trans_b=True, out=self.buf, accumulate=True)
+
+    def _flush(self, final):
+        pieces = sorted(self.pieces, key=lambda t: t[0])
+        run = []                                             # the blocks that continue the folded prefix without a gap
+        for jj, w_ in pieces:
+            if jj != self.flushed + len(run):
+                break
+            run.append((jj, w_))
+        rest = pieces[len(run):]
+        step = DX_CHUNK if DX_CHUNK > 0 else max(1, self.members)
+        while run and (len(run) >= step or final):
+            take, run = run[:step], run[step:]
+            self._fold(take)
+            self.flushed += len(take)
+        if final:
+            for piece in rest:                               # blocks that arrived out of order: one by one
+                self._fold([piece])
+            rest = []
+        self.pieces = run + rest
 
 
 class LinearFn(torch.autograd.Function):

@@ -36,9 +36,14 @@ def _lib():
 
 
 class TrieSide(object):
-    """One trie: int32 index tensors + the level offsets as Python ints (launch geometry, never read from the device)."""
+    """One trie: int32 index tensors + the level offsets as Python ints (launch geometry, never read from the device).
 
-    def __init__(self, arrays, level_off):
+    Derived at build time (numpy, on the host) for the backward walk of gtos_amd.gru: ``sum_idx`` [n] -- the row of the
+    ``[n + 1 + n_multi, .]`` gradient buffers that holds the SUM over node u's children: the child itself when there is one, row
+    n (all zero) for a leaf, row n + 1 + j for the j-th node with several children; ``multi_ranges`` [2 * n_multi] -- the child
+    ranges of those nodes in node order (so level-major); ``multi_level_off`` [L + 1] -- how many of them precede each level."""
+
+    def __init__(self, arrays, level_off, multi_level_off=None):
         self.__dict__.update(arrays)
         if self.tok.dtype != torch.int64:
             self.tok = self.tok.to(torch.int64)        # the embedding kernels take int64 token ids
@@ -48,10 +53,23 @@ class TrieSide(object):
         self.n_nodes = self.level_off[-1]
         self.n_chunks = int(self.chunk_node.numel())
         self.n_heavy = int(self.heavy_node.numel())
+        if "sum_idx" not in arrays:
+            n = self.n_nodes
+            co = self.child_off.cpu().numpy().reshape(-1, 2)[:n].astype(np.int64)
+            nc = co[:, 1] - co[:, 0]
+            multi = nc >= 2
+            slot = np.cumsum(multi) - 1
+            idx = np.where(nc == 1, co[:, 0], np.where(multi, n + 1 + slot, n))
+            self.sum_idx = torch.from_numpy(idx.astype(np.int32))
+            self.multi_ranges = torch.from_numpy(np.ascontiguousarray(co[multi].astype(np.int32).reshape(-1)))
+            before = np.concatenate([[0], np.cumsum(multi)])
+            multi_level_off = [int(before[o]) for o in self.level_off]
+        self.multi_level_off = list(multi_level_off)
+        self.n_multi = self.multi_level_off[-1]
 
     def to(self, device):
         arrays = {k: v.to(device) for k, v in self.__dict__.items() if isinstance(v, torch.Tensor)}
-        return TrieSide(arrays, self.level_off)
+        return TrieSide(arrays, self.level_off, self.multi_level_off)
 
 
 class PathTrie(object):

@@ -1282,7 +1282,7 @@ def test_bench_strong_scaling_two_ranks_on_one_gpu_functional():
     c = d["config"]
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and c["global_batch"] == 8 and c["B_per_gpu"] == 4
     assert len(c["per_rank_ms_per_step"]) == 2 and all(v > 0 for v in c["per_rank_ms_per_step"])
-    assert abs(d["ms_per_step"] - max(c["per_rank_ms_per_step"])) < 1e-6 and c["rank_spread_ms_per_step"] >= 0
+    assert abs(d["ms_per_step"] - max(c["per_rank_ms_per_step"])) < 1e-3 and c["rank_spread_ms_per_step"] >= 0    # (rounded to 3 decimals)
     assert d["value"] > 0 and np.isfinite(c["loss_last"])
 
 

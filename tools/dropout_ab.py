@@ -10,7 +10,8 @@ Three arms, identical in everything else (initial weights, batch order, <UNK> no
   row    GTOS_GRU_TRIE=0  per-row path: masks per (path, position), the reference's semantics
   none   RelationEncoder dropout 0 (everything else keeps dropout): how much this dropout matters at all
 Every --every steps: mean training loss since the last record and the held-out loss (eval mode).  Usage on the GPU box:
-    python tools/dropout_ab.py --steps 2000 --out gpurun_out/dropout_ab.json"""
+    python tools/dropout_ab.py --steps 2000 --out gpurun_out/dropout_ab.json                       (all 1,900 training trees)
+    python tools/dropout_ab.py --steps 3000 --train-trees 256 --out gpurun_out/dropout_ab_256.json  (over-fitting regime)"""
 import argparse
 import gzip
 import json
@@ -113,11 +114,14 @@ def main():
     ap.add_argument("--unk-rate", type=float, default=0.33)
     ap.add_argument("--warmup", type=int, default=400)
     ap.add_argument("--arms", default="node,row,none")
+    ap.add_argument("--train-trees", type=int, default=1900,
+                    help="size of the training subset (the held-out trees are always the last 269); a few hundred trees put the run in "
+                         "the over-fitting regime, where regularisation differences show in the held-out loss")
     ap.add_argument("--out", default="gpurun_out/dropout_ab.json")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     trees = [tuple(t) for t in json.load(gzip.open(os.path.join(ROOT, "tests", "golden", "dep_dev_trees.json.gz"), "rt", encoding="utf8"))]
-    train_trees, held_trees = trees[:1900], trees[1900:]
+    train_trees, held_trees = trees[:min(1900, a.train_trees)], trees[1900:]
     with tempfile.TemporaryDirectory() as tmp:
         vocabs = build_vocabs(train_trees, tmp)
     res = {"config": vars(a), "train_trees": len(train_trees), "held_out_trees": len(held_trees),
