@@ -81,7 +81,7 @@ __device__ __forceinline__ void dma_weights(const bf16_t* __restrict__ w, const 
 // DMA --, swizzled chunk, bounds): per k tile only the k bound of a partial last tile is left.
 struct RowSrc { const char* p[TM / 32]; int c[TM / 32]; };
 __device__ __forceinline__ RowSrc row_src(const bf16_t* __restrict__ base, int64_t ld, int rows_total, int row0, int wave, int lane,
-                                          const int* __restrict__ gather = nullptr) {
+                                          const int* __restrict__ gather = nullptr, int zero_row = -1) {
     RowSrc s;
 #pragma unroll
     for (int it = 0; it < TM / 32; ++it) {
@@ -90,7 +90,9 @@ __device__ __forceinline__ RowSrc row_src(const bf16_t* __restrict__ base, int64
         s.c[it] = (lane & 7) ^ swz(rl);
         const bool ok = r < rows_total;
         const int64_t sr = (gather && ok) ? gather[r] : r;
-        s.p[it] = ok ? reinterpret_cast<const char*>(base + sr * ld + s.c[it] * 8) : nullptr;      // null: rows past the end
+        // null: rows past the end, and rows whose source is the all-zero row (trie leaves: half of all nodes would otherwise
+        // hammer ONE 2 KB row of HBM)
+        s.p[it] = (ok && sr != zero_row) ? reinterpret_cast<const char*>(base + sr * ld + s.c[it] * 8) : nullptr;
     }
     return s;
 }
@@ -101,6 +103,19 @@ __device__ __forceinline__ void dma_rows_at(const RowSrc& s, const U128* __restr
         const void* src = ok ? static_cast<const void*>(s.p[it] + (int64_t)k0 * 2) : static_cast<const void*>(zeros);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(tile + (it * 4 + wave) * 1024), 16, 0, 0);
+    }
+}
+// the same for operands with many zero rows: a lane whose row is null writes its 16 bytes of zeros into its LDS slot itself
+// (the slot the DMA of an active lane would fill: tile + block * 1024 + lane * 16) instead of fetching them
+__device__ __forceinline__ void dma_rows_at_z(const RowSrc& s, int k0, char* tile, int wave, int lane) {
+#pragma unroll
+    for (int it = 0; it < TM / 32; ++it) {
+        char* blk = tile + (it * 4 + wave) * 1024;
+        if (s.p[it] != nullptr)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s.p[it] + (int64_t)k0 * 2),
+                                             (__attribute__((address_space(3))) void*)blk, 16, 0, 0);
+        else
+            *reinterpret_cast<uint4*>(blk + lane * 16) = make_uint4(0, 0, 0, 0);
     }
 }
 struct WSrc { uint32_t off[WROWS / 32]; int c[WROWS / 32]; };
@@ -459,6 +474,7 @@ struct StepBwdArgs {
     bf16_t* hp_out;                                // optional [rows,hs]: the (gathered) entering state of every row, written compactly
     const int* sum_idx;                            // optional [rows]: row m takes its operand row from d4_prev[sum_idx[m]] and its incoming
     const void* dh_src;                            //   state gradient from dh_src[sum_idx[m]] (row stride hs) instead of d4_prev[m] / dh[m]
+    int zero_row;                                  //   sum_idx value that stands for "all zero" (a leaf): nothing is fetched for it
     float p_drop; uint64_t seed; int64_t drop_base;
     int rows, hs; const void* zeros;
 };
@@ -503,10 +519,33 @@ __global__ __launch_bounds__(256, 3) void gru_step_bwd_kernel(StepBwdArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    if (a.d4_prev && m0 < (a.sum_idx ? a.rows : a.rows_prev)) {
+    if (a.d4_prev && a.sum_idx) {
+        // trie: operand rows through the children-sum indirection; the per-lane source addresses are computed once
+        const RowSrc src = row_src(a.d4_prev, 4 * (int64_t)hs, a.rows, m0, wave, lane, a.sum_idx, a.zero_row);
         for (int kk = 0; kk < 3 * hs; kk += BK) {
             const int ak = kk < 2 * hs ? kk : kk + hs;                 // skip the d n_x block of d4
-            dma_rows(a.d4_prev, Z, 4 * (int64_t)hs, a.sum_idx ? a.rows : a.rows_prev, m0, ak, ak + BK, As, wave, lane, a.sum_idx);
+            dma_rows_at_z(src, ak, As, wave, lane);
+            dma_wt(a.wh_t, 3 * (int64_t)hs, c0, kk, Bs, wave, lane);
+            __syncthreads();
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8_t fa[2], fb[4];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) fa[mt] = *reinterpret_cast<const bf16x8_t*>(As + lds_off(wave * 32 + mt * 16 + fr, ks * 4 + fq));
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) fb[nt] = *reinterpret_cast<const bf16x8_t*>(Bs + lds_off(nt * 16 + fr, ks * 4 + fq));
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+    } else if (a.d4_prev && m0 < a.rows_prev) {
+        for (int kk = 0; kk < 3 * hs; kk += BK) {
+            const int ak = kk < 2 * hs ? kk : kk + hs;                 // skip the d n_x block of d4
+            dma_rows(a.d4_prev, Z, 4 * (int64_t)hs, a.rows_prev, m0, ak, ak + BK, As, wave, lane);
             dma_wt(a.wh_t, 3 * (int64_t)hs, c0, kk, Bs, wave, lane);
             __syncthreads();
 #pragma unroll
@@ -545,7 +584,10 @@ __global__ __launch_bounds__(256, 3) void gru_step_bwd_kernel(StepBwdArgs a) {
         bf16_t* dhb = static_cast<bf16_t*>(a.dh) + (int64_t)m * a.ld_dh + cb;
         if (a.sum_idx) {                                               // trie: the children's summed gradient lives in another row
             const int64_t sr = a.sum_idx[m];
-            if (a.dh_bf16) ld16(static_cast<const bf16_t*>(a.dh_src) + sr * hs + cb, g);
+            if (sr == a.zero_row) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) g[i] = 0.f;
+            } else if (a.dh_bf16) ld16(static_cast<const bf16_t*>(a.dh_src) + sr * hs + cb, g);
             else ldf16(static_cast<const float*>(a.dh_src) + sr * hs + cb, g);
         } else if (a.dh_bf16) ld16(dhb, g); else ldf16(dhp, g);
 #pragma unroll
@@ -665,7 +707,7 @@ extern "C" int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, i
 extern "C" int gtos_gru_step_bwd(int rows, int hs, const void* d4_prev, int rows_prev, const void* w_hh_t,
                                  const void* gates, const void* hprev, const int* hprev_idx, const void* dy, int64_t ldy, void* dh, int dh_dtype,
                                  int64_t ld_dh, void* d4, float p_drop, uint64_t seed, int64_t drop_base, float* bias_partials,
-                                 int n_partials, void* hprev_out, const int* sum_idx, const void* dh_src, void* stream) {
+                                 int n_partials, void* hprev_out, const int* sum_idx, const void* dh_src, int zero_row, void* stream) {
     if (rows <= 0) return 0;
     if (hs <= 0 || hs % TC) return -22;
     if (!gates || !hprev || !dh || !d4 || (d4_prev && !w_hh_t)) return -23;
@@ -677,7 +719,7 @@ extern "C" int gtos_gru_step_bwd(int rows, int hs, const void* d4_prev, int rows
     a.d4_prev = (const bf16_t*)d4_prev; a.rows_prev = d4_prev ? rows_prev : 0; a.wh_t = (const bf16_t*)w_hh_t;
     a.gates = (const bf16_t*)gates; a.hprev = (const bf16_t*)hprev; a.hprev_idx = hprev_idx; a.dy = (const bf16_t*)dy; a.ldy = ldy;
     a.dh = dh; a.dh_bf16 = dh_dtype == GTOS_BF16; a.ld_dh = ld_dh; a.d4 = (bf16_t*)d4; a.bias_part = bias_partials; a.n_partials = n_partials;
-    a.hp_out = (bf16_t*)hprev_out; a.sum_idx = sum_idx; a.dh_src = dh_src;
+    a.hp_out = (bf16_t*)hprev_out; a.sum_idx = sum_idx; a.dh_src = dh_src; a.zero_row = sum_idx ? zero_row : -1;
     a.p_drop = p_drop; a.seed = seed; a.drop_base = drop_base; a.rows = rows; a.hs = hs;
     a.zeros = gtos_zero_block();
     if (!a.zeros) return -5;

@@ -401,20 +401,37 @@ __global__ __launch_bounds__(256) void embed_rows_bwd_kernel(int64_t n, int V, i
     }
     const float ks = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(n, r0 + rows_per_block);
-    for (int64_t t = r0 * vpr + threadIdx.x; t < r1 * vpr; t += 256) {
-        const int64_t row = t / vpr; const int ch = (int)(t % vpr), c = ch * 8;
-        float v[8];
-        Vec8<T>::load(dout + row * dim_pad + c, v);
-        const int64_t tk = tok[row];
-        float* gdst = dtable + tk * dim;
-        float* ldst = tab + tk * vpr + ch;
+    // four (row, chunk) items per thread and iteration: their loads are issued together, then the atomics -- one item per
+    // iteration was a dependent chain (token id -> row load -> 8 atomics) with at most one wave per SIMD to hide it
+    constexpr int UN = 4;
+    for (int64_t t0 = r0 * vpr + threadIdx.x; t0 < r1 * vpr; t0 += 256 * UN) {
+        float v[UN][8];
+        int64_t tk[UN], row[UN];
+        int ch[UN];
+        bool ok[UN];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            if (c + e < dim) {
-                float x = v[e];
-                if (p_drop > 0.f) x = drop_keep(seed, (uint64_t)row * dim_pad + c + e, p_drop) ? x * ks : 0.f;
-                if (use_lds) atomicAdd(ldst + e * plane, x);
-                else if (x != 0.f) atomicAdd(gdst + c + e, x);
+        for (int u = 0; u < UN; ++u) {
+            const int64_t t = t0 + (int64_t)u * 256;
+            ok[u] = t < r1 * vpr;
+            row[u] = ok[u] ? t / vpr : r0;
+            ch[u] = ok[u] ? (int)(t % vpr) : 0;
+            tk[u] = tok[row[u]];
+            Vec8<T>::load(dout + row[u] * dim_pad + ch[u] * 8, v[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            if (!ok[u]) continue;
+            const int c = ch[u] * 8;
+            float* gdst = dtable + tk[u] * dim;
+            float* ldst = tab + tk[u] * vpr + ch[u];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (c + e < dim) {
+                    float x = v[u][e];
+                    if (p_drop > 0.f) x = drop_keep(seed, (uint64_t)row[u] * dim_pad + c + e, p_drop) ? x * ks : 0.f;
+                    if (use_lds) atomicAdd(ldst + e * plane, x);
+                    else if (x != 0.f) atomicAdd(gdst + c + e, x);
+                }
             }
         }
     }
@@ -748,9 +765,9 @@ extern "C" int gtos_embed_rows_bwd(int dtype, int64_t n, int V, int dim, int dim
     const int use_lds = (size_t)V * dim_pad * 4 <= 60 * 1024;     // private LDS table, else global atomics
     if (n <= 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // LDS path: every block flushes its private V*dim table with global atomics onto the SAME V*dim addresses, so the flush
-    // cost grows with the block count (1024 blocks x 8.6 k atomics on 8.6 k addresses at the relation table): one block per CU
-    int64_t nb = (n + 2047) / 2048; if (nb > (use_lds ? 256 : 1024)) nb = use_lds ? 256 : 1024; if (nb < 1) nb = 1;
+    // rows per block: 512 -- at 2048 the relation table's 457 k rows made 224 blocks, under one wave per SIMD, and the launch ran
+    // at 0.16 TB/s (0.6 ms); the price is one table flush (V*dim global atomics) per block
+    int64_t nb = (n + 511) / 512; if (nb > 2048) nb = 2048; if (nb < 1) nb = 1;
     const int64_t rpb = (n + nb - 1) / nb;
     dim3 grid((unsigned)((n + rpb - 1) / rpb)), block(256);
     const size_t sh = use_lds ? (size_t)V * dim_pad * 4 : 0;

@@ -62,14 +62,14 @@ def _step_fwd_call(A, hs, x, xg, h_in, wi, b_ih, wh, b_hh, h_out, n_out, h_fin, 
 
 
 def _step_bwd(A, hs, d4_prev, rows_prev, wh_t, gates, hprev, dy_ptr, ldy, dh, d4, p, seed, drop_base, bpart, hprev_idx=None, hp_out=None,
-              sum_idx=None, dh_src=None):
+              sum_idx=None, dh_src=None, zero_row=-1):
     """``dh``: [rows, hs] or a column block of a wider matrix (row stride passed on); ``hp_out``: [rows, hs] receiving the
     (gathered) entering state rows; ``sum_idx`` / ``dh_src``: per-row source rows of the recurrent operand (in d4_prev) and of the
     incoming state gradient (in dh_src) -- the trie's children-sum indirection."""
     with _Timed("gru_step_bwd_%s" % ("trie" if hprev_idx is not None else "rows"), detail=True, units=A):
         call("gtos_gru_step_bwd", A, hs, ptr(d4_prev), rows_prev if d4_prev is not None else 0, ptr(wh_t), ptr(gates), ptr(hprev),
              ptr(hprev_idx), dy_ptr, ldy, ptr(dh), dt(dh), dh.stride(0), ptr(d4), float(p), seed, drop_base,
-             ptr(bpart), N_BIAS_PARTIALS if bpart is not None else 0, ptr(hp_out), ptr(sum_idx), ptr(dh_src), stream())
+             ptr(bpart), N_BIAS_PARTIALS if bpart is not None else 0, ptr(hp_out), ptr(sum_idx), ptr(dh_src), int(zero_row), stream())
 
 
 def _cell_bwd(A, hs, gates, hprev, dy, dy_off_elems, ldy, dh, dxg, dhg, p, seed, drop_base, bpart):
@@ -286,6 +286,10 @@ TRIE_SIDE = os.environ.get("GTOS_GRU_TRIE_SIDE", "0") == "1"
 # Layer 0 walks each trie level by level (<= 8 small launches per trie, the first levels far too small to fill the chip); the
 # prefix and the suffix trie are independent, so the suffix side runs on the auxiliary stream beside the prefix side.
 TRIE_L0_OVERLAP = os.environ.get("GTOS_GRU_L0_OVERLAP", "1") != "0"
+# Layer 1, forward: the input-gate table products of the reverse direction on the auxiliary stream beside the forward direction's steps.
+TRIE_L1_TABLE_OVERLAP = os.environ.get("GTOS_GRU_L1_TABLES", "1") != "0"
+# Layer 0, backward: children -> parent sums through the row indirection of pathtrie.TrieSide.sum_idx (0: a summed row per node).
+TRIE_SUM_INDEX = os.environ.get("GTOS_GRU_SUMIDX", "1") != "0"
 
 
 def _seg_rows(side, src, width, dst, src2=None, dst2=None):
@@ -383,11 +387,30 @@ class TrieBiGRUFn(torch.autograd.Function):
         # straight to its BANK row of fin [R, 2hs] (column block d): no torch.cat of the directions, no unsort gather
         fin = torch.empty((R, 2 * hs), dtype=dtp, device=dev)
         l1 = []
+        # input-gate tables of both directions first: direction 0's on the main stream, direction 1's on the auxiliary stream,
+        # where the two MFMA-bound products run beside direction 0's (HBM-bound) recurrent steps.  Their buffers come from the
+        # main stream's pool (the consumer's), the auxiliary stream only fills them.
+        tables = []
+        t_aux = _side_stream(dev) if (TRIE_L1_TABLE_OVERLAP and table.is_cuda and N >= SIDE_MIN_ROWS) else None
+        for d in (0, 1):
+            wi = compute_weight(weights[8 + d * 4], dtp)
+            Gf = torch.empty((sides[0].n_nodes, 3 * hs), dtype=dtp, device=dev)      # [nodes of the prefix trie, 3hs]
+            Gb = torch.empty((sides[1].n_nodes, 3 * hs), dtype=dtp, device=dev)      # [nodes of the suffix trie, 3hs]
+            if d == 1 and t_aux is not None:
+                t_aux.wait_stream(main)
+                with torch.cuda.stream(t_aux):
+                    gemm(src[0], wi[:, :hs], trans_b=True, out=Gf)
+                    gemm(src[1], wi[:, hs:], trans_b=True, out=Gb)
+            else:
+                gemm(src[0], wi[:, :hs], trans_b=True, out=Gf)
+                gemm(src[1], wi[:, hs:], trans_b=True, out=Gb)
+            tables.append((Gf, Gb))
         for d in (0, 1):
             w_ih, w_hh, b_ih, b_hh = weights[8 + d * 4: 8 + d * 4 + 4]
             wi, wh = compute_weight(w_ih, dtp), compute_weight(w_hh, dtp)
-            Gf = gemm(src[0], wi[:, :hs], trans_b=True)         # [nodes of the prefix trie, 3hs]
-            Gb = gemm(src[1], wi[:, hs:], trans_b=True)         # [nodes of the suffix trie, 3hs]
+            Gf, Gb = tables[d]
+            if d == 1 and t_aux is not None:
+                main.wait_stream(t_aux)
             gates = torch.empty((N, 4 * hs), dtype=dtp, device=dev)
             hprev = torch.empty((N, hs), dtype=dtp, device=dev)
             h = fin[:, d * hs:(d + 1) * hs]
@@ -511,33 +534,52 @@ class TrieBiGRUFn(torch.autograd.Function):
             base = d * 4
             w_ih, w_hh, b_ih, b_hh = weights[base:base + 4]
             want_bias = b_ih.requires_grad or b_hh.requires_grad
-            # Children -> parent sums without a pass over every level: node u reads its recurrent operand (sum of its children's
-            # d4 rows) and its incoming state gradient (sum of their dh * z) from row side.sum_idx[u] of the SAME buffers --
-            # its only child's row, the all-zero row n (a leaf), or one of the extra rows behind it that hold the sums of the
-            # parents with several children, the only ones gtos_segment_sum_ranges still visits (a third of the nodes at C2).
-            nm = side.n_multi
-            d4x = torch.empty((n + 1 + nm, 4 * hs), dtype=dtp, device=dev)
-            dhx = torch.empty((n + 1 + nm, hs), dtype=dtp, device=dev)   # per node: (state gradient) * z, what its parent receives directly
-            d4x[n].zero_()
-            dhx[n].zero_()
-            d4 = d4x[:n]
             hp = torch.empty((n, hs), dtype=dtp, device=dev)          # the state each node started from (written by the steps)
             bpart = torch.zeros((N_BIAS_PARTIALS, 4 * hs), dtype=torch.float32, device=dev) if want_bias else None
             dy = dsrc[d]
-            for k in range(L - 1, -1, -1):
-                lo, hi = side.level_off[k], side.level_off[k + 1]
-                A = hi - lo
-                if A == 0:
-                    continue
-                has_kids = k + 1 < L and side.level_off[k + 2] > side.level_off[k + 1]
-                mlo, mhi = side.multi_level_off[k], side.multi_level_off[k + 1]
-                if mhi > mlo:
-                    rng_ = side.multi_ranges[2 * mlo:2 * mhi]
-                    _seg_ranges(mhi - mlo, rng_, d4x, 4 * hs, d4x[n + 1 + mlo:])
-                    _seg_ranges(mhi - mlo, rng_, dhx, hs, dhx[n + 1 + mlo:])
-                _step_bwd(A, hs, d4x if has_kids else None, n + 1 + nm, wh_t, gates[lo:hi], H, dy.data_ptr() + lo * hs * dy.element_size(), hs,
-                          dhx[lo:hi], d4[lo:hi], p_layer, seed_y, lo * hs, bpart, hprev_idx=side.par[lo:hi], hp_out=hp[lo:hi],
-                          sum_idx=side.sum_idx[lo:hi], dh_src=dhx)
+            if TRIE_SUM_INDEX:
+                # Children -> parent sums without a pass over every node: node u reads its recurrent operand (sum of its
+                # children's d4 rows) and its incoming state gradient (sum of their dh * z) from row side.sum_idx[u] of the SAME
+                # buffers -- its only child's row, nothing at all for a leaf (sum_idx = n: zeros), or one of the extra rows behind
+                # row n that hold the sums of the nodes with several children, the only ones gtos_segment_sum_ranges still
+                # visits (a quarter of the nodes at C2; half are leaves).
+                nm = side.n_multi
+                d4x = torch.empty((n + 1 + nm, 4 * hs), dtype=dtp, device=dev)
+                dhx = torch.empty((n + 1 + nm, hs), dtype=dtp, device=dev)   # per node: (state gradient) * z, what its parent receives
+                d4 = d4x[:n]
+                for k in range(L - 1, -1, -1):
+                    lo, hi = side.level_off[k], side.level_off[k + 1]
+                    A = hi - lo
+                    if A == 0:
+                        continue
+                    has_kids = k + 1 < L and side.level_off[k + 2] > side.level_off[k + 1]
+                    mlo, mhi = side.multi_level_off[k], side.multi_level_off[k + 1]
+                    if mhi > mlo:
+                        rng_ = side.multi_ranges[2 * mlo:2 * mhi]
+                        _seg_ranges(mhi - mlo, rng_, d4x, 4 * hs, d4x[n + 1 + mlo:])
+                        _seg_ranges(mhi - mlo, rng_, dhx, hs, dhx[n + 1 + mlo:])
+                    _step_bwd(A, hs, d4x if has_kids else None, n + 1 + nm, wh_t, gates[lo:hi], H, dy.data_ptr() + lo * hs * dy.element_size(),
+                              hs, dhx[lo:hi], d4[lo:hi], p_layer, seed_y, lo * hs, bpart, hprev_idx=side.par[lo:hi], hp_out=hp[lo:hi],
+                              sum_idx=side.sum_idx[lo:hi], dh_src=dhx, zero_row=n)
+                held = (d4x, dhx, bpart, hp)
+            else:                                      # GTOS_GRU_SUMIDX=0: a summed row per node of every level (round-2 form)
+                d4 = torch.empty((n, 4 * hs), dtype=dtp, device=dev)
+                dhz = torch.zeros((n, hs), dtype=dtp, device=dev)
+                widest = max(side.level_off[k + 1] - side.level_off[k] for k in range(L))
+                S = torch.empty((widest, 4 * hs), dtype=dtp, device=dev)
+                for k in range(L - 1, -1, -1):
+                    lo, hi = side.level_off[k], side.level_off[k + 1]
+                    A = hi - lo
+                    if A == 0:
+                        continue
+                    has_kids = k + 1 < L and side.level_off[k + 2] > side.level_off[k + 1]
+                    if has_kids:
+                        rng_ = side.child_off[2 * lo:2 * hi]
+                        _seg_ranges(A, rng_, d4, 4 * hs, S)
+                        _seg_ranges(A, rng_, dhz, hs, dhz[lo:hi])
+                    _step_bwd(A, hs, S if has_kids else None, A, wh_t, gates[lo:hi], H, dy.data_ptr() + lo * hs * dy.element_size(), hs,
+                              dhz[lo:hi], d4[lo:hi], p_layer, seed_y, lo * hs, bpart, hprev_idx=side.par[lo:hi], hp_out=hp[lo:hi])
+                held = (d4, dhz, S, bpart, hp)
             with (on_side(d4, hp, X, bpart) if use_side else contextlib.nullcontext()):
                 _acc_weight_grad(grads, base + 1, w_hh, d4[:, :2 * hs], hp, rows=slice(0, 2 * hs))
                 _acc_weight_grad(grads, base + 1, w_hh, d4[:, 3 * hs:], hp, rows=slice(2 * hs, 3 * hs))
@@ -552,7 +594,7 @@ class TrieBiGRUFn(torch.autograd.Function):
                     call("gtos_embed_rows_bwd", dt(dX), n, table.shape[0], table.shape[1], dim_pad, ptr(side.tok), ptr(dX), ptr(tgt),
                          float(p_embed), seed_e, stream())
             if l0_overlap and d == 1:
-                keep.extend((d4x, dhx, bpart, hp))     # allocated in the auxiliary stream's pool: released after the join below
+                keep.extend(held)                      # allocated in the auxiliary stream's pool: released after the join below
         if l0_overlap:
             main.wait_stream(aux0)
             keep.clear()

@@ -212,10 +212,11 @@ def _grad_target(p):
 # bank-gradient kernel takes a row stride) and the bank's gradient is ONE product with K = L*2d = 8192 on the 256x256
 # deep-K kernel, accumulated in fp32 across all layers.  GTOS_BATCH_DX=0 restores the per-layer products.
 BATCH_DX = os.environ.get("GTOS_BATCH_DX", "1") != "0"
-# Layers per deep-K product of the slab (0: one product over all layers after the last one, the round-2 behaviour).  2 at the
-# reference's d = 512: K = 2 * 1024 = 2048 per product keeps the 256x256 deep-K kernel, and the bf16 accumulator is rounded L/2
-# times instead of once (the per-layer form rounds L times).
-DX_CHUNK = int(os.environ.get("GTOS_DX_CHUNK", "2"))
+# Layers per deep-K product of the slab; 0 (default) = ONE product over all layers after the last one, rounded once.  Chunks of
+# 2 layers (K = 2048 each, launched from inside backward on the auxiliary stream) were measured at C2: the products leave the
+# critical path but compete with the HBM-bound attention-backward kernels they run beside (4 x 1.45 ms of GEMM instead of 3.1 ms,
+# attention backward +1.2 ms per step): 66.23 vs 66.09 ms per step on the same box -- no gain, so the single rounding stays.
+DX_CHUNK = int(os.environ.get("GTOS_DX_CHUNK", "0"))
 
 
 class GradAccumGroup:

@@ -151,12 +151,12 @@ int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, int in_dim, 
  * [rows,hs]): the entering state of every row written compactly -- the gathered operand of the recurrent weight gradient on
  * the tries.  sum_idx (optional, [rows]) with dh_src ([*,hs], dh's dtype): row m takes its recurrent operand row from
  * d4_prev[sum_idx[m]] and its incoming state gradient from dh_src[sum_idx[m]] instead of d4_prev[m] / dh[m] -- on the tries a parent
- * with ONE child reads the child's rows in place, a leaf reads a zero row, and only parents with several children need summed rows
- * (gtos_segment_sum_ranges over those parents alone); dh[m] still receives dh_total * z. */
+ * with ONE child reads the child's rows in place, a leaf (sum_idx[m] == zero_row) takes zeros without a fetch, and only parents
+ * with several children need summed rows (gtos_segment_sum_ranges over those parents alone); dh[m] still receives dh_total * z. */
 int gtos_gru_step_bwd(int rows, int hs, const void* d4_prev, int rows_prev, const void* w_hh_t,
                       const void* gates, const void* hprev, const int* hprev_idx, const void* dy, int64_t ldy, void* dh, int dh_dtype,
                       int64_t ld_dh, void* d4, float p_drop, uint64_t seed, int64_t drop_base, float* bias_partials, int n_partials,
-                      void* hprev_out, const int* sum_idx, const void* dh_src, void* stream);
+                      void* hprev_out, const int* sum_idx, const void* dh_src, int zero_row, void* stream);
 
 /* Segmented row sums for the trie-evaluated RelationEncoder's backward (generator/encoder.py:93-111 runs every path
  * separately; here the gradient of a shared trie node is the sum over the rows that share it).  bf16 rows, fp32
