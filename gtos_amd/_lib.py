@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgtos_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 c_p, c_i, c_l, c_f, c_u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_uint64
 
@@ -40,6 +40,12 @@ SIGNATURES = {
     "gtos_copy_nll_fwd": [c_i, c_i, c_i, c_i, c_i, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_p, c_p, c_p, c_p],
     "gtos_copy_nll_bwd": [c_i, c_i, c_i, c_i, c_i, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "gtos_copy_ll_fwd": [c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_l, c_p, c_p, c_p, c_p, c_p],
+    "gtos_highway_fwd": [c_i, c_l, c_i, c_p, c_p, c_p, c_p],
+    "gtos_highway_bwd": [c_i, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p],
+    "gtos_max_relu_fwd": [c_i, c_l, c_i, c_i, c_p, c_p, c_p, c_p],
+    "gtos_max_relu_bwd": [c_i, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p],
+    "gtos_token_row_fwd": [c_i, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_f, c_u64, c_p],
+    "gtos_token_row_bwd": [c_i, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_f, c_u64, c_p],
     "gtos_sqnorm": [c_l, c_p, c_p, c_p],
     "gtos_adam_step": [c_l, c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_f, c_p, c_p],
     "gtos_cast_f32_to_bf16": [c_l, c_p, c_p, c_p],

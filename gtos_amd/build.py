@@ -5,7 +5,7 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libgtos_hip.so")
-SOURCES = ["gemm.hip", "rel_attn.hip", "rowops.hip", "gru_step.hip", "copy_nll.hip"]
+SOURCES = ["gemm.hip", "rel_attn.hip", "rowops.hip", "gru_step.hip", "copy_nll.hip", "tokenenc.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only"]
 

@@ -874,4 +874,4 @@ extern "C" int gtos_cast_f32_to_bf16(int64_t n, const float* src, void* dst, voi
     return 0;
 }
 
-extern "C" int gtos_abi_version(void) { return 10; }
+extern "C" int gtos_abi_version(void) { return 11; }

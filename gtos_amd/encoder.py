@@ -103,9 +103,13 @@ class Highway(nn.Module):
 
     def forward(self, x):
         for layer in self.layers:
-            new_x, gate = ops.linear(x, layer.weight, layer.bias).chunk(2, dim=-1)
-            gate = torch.sigmoid(gate)
-            x = gate * x + (1 - gate) * F.relu(new_x)
+            y = ops.linear(x, layer.weight, layer.bias)                  # [.., 2D] = [new_x | gate]
+            if x.is_cuda and self.input_dim % 8 == 0:
+                x = ops.highway_gate(y, x)                               # sigmoid(gate) * x + (1 - sigmoid(gate)) * relu(new_x), one kernel
+            else:
+                new_x, gate = y.chunk(2, dim=-1)
+                gate = torch.sigmoid(gate)
+                x = gate * x + (1 - gate) * F.relu(new_x)
         return x
 
 
@@ -134,8 +138,12 @@ class CNNEncoder(nn.Module):
             k = conv.kernel_size[0]
             win = input.unfold(1, k, 1)                                   # [N, L-k+1, C, k]
             y = ops.linear(win.reshape(N * (L - k + 1), C * k), conv.weight.view(conv.out_channels, C * k), conv.bias)
-            feats.append(F.relu(y.view(N, L - k + 1, -1).max(1)[0]))
-        x = self.highway(torch.cat(feats, dim=-1))
+            y = y.view(N, L - k + 1, -1)
+            if y.is_cuda and conv.out_channels % 8 == 0 and L - k + 1 <= 255:
+                feats.append(ops.max_relu(y))                            # max over time + ReLU, one kernel (argmax kept for backward)
+            else:
+                feats.append(F.relu(y.max(1)[0]))
+        x = self.highway(feats[0] if len(feats) == 1 else torch.cat(feats, dim=-1))
         return ops.linear(x, self.out_proj.weight, self.out_proj.bias)
 
 
@@ -168,10 +176,20 @@ class TokenEncoder(nn.Module):
         else:
             char_repr = ce(char_input.view(seq_len * bsz, -1)).to(cd)
         char_repr = self.char2token(char_repr).view(seq_len, bsz, -1)
-        token_repr = self.token_embed(token_input).to(cd)
-        token = F.dropout(torch.cat([char_repr, token_repr], -1), p=self.dropout, training=self.training)
-        pad = (-token.shape[-1]) % 8
+        te = self.token_embed
+        if char_repr.is_cuda and char_repr.shape[-1] % 8 == 0 and te.weight.dtype == torch.float32:
+            # cat([char_repr, token_embed(token)]) -> dropout -> zero-pad to a multiple of 8 columns, one kernel; the embedding's
+            # backward is the kernel's scatter into the fp32 table (no sort-based embedding_dense_backward)
+            token = ops.token_row(char_repr, token_input, te.weight, self.dropout if self.training else 0.0, te.padding_idx)
+        else:
+            token_repr = te(token_input).to(cd)
+            token = F.dropout(torch.cat([char_repr, token_repr], -1), p=self.dropout, training=self.training)
+            token = F.pad(token, (0, (-token.shape[-1]) % 8))
         w = self.out_proj.weight
+        pad = token.shape[-1] - w.shape[1]
         if pad:                                   # 428 = 128+300 is not a multiple of 8: keep GEMM rows 16-byte aligned
-            token, w = F.pad(token, (0, pad)), F.pad(w, (0, pad))
+            w = self._padded_weight(w, pad)
         return ops.linear(token, w, self.out_proj.bias)
+
+    def _padded_weight(self, w, pad):
+        return F.pad(w, (0, pad))

@@ -705,6 +705,105 @@ def embed_rows(tokens, table, dim_pad, p_drop, dtype, pad_idx=None):
     return EmbedRowsFn.apply(tokens, table, dim_pad, float(p_drop), dtype, pad_idx)
 
 
+class HighwayGateFn(torch.autograd.Function):
+    """out = sigmoid(gate) * x + (1 - sigmoid(gate)) * relu(new_x) with [new_x | gate] = y = layer(x): the elementwise half of a
+    Highway layer (generator/encoder.py:141-149), one kernel per direction."""
+
+    @staticmethod
+    def forward(ctx, y, x):
+        require_cuda(y, x)
+        D = x.shape[-1]
+        y2, x2 = y.reshape(-1, 2 * D).contiguous(), x.reshape(-1, D).contiguous()
+        out = torch.empty_like(x2)
+        call("gtos_highway_fwd", dt(x2), x2.shape[0], D, ptr(y2), ptr(x2), ptr(out), stream())
+        ctx.save_for_backward(y2, x2)
+        ctx.shapes = (y.shape, x.shape)
+        return out.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        y2, x2 = ctx.saved_tensors
+        D = x2.shape[1]
+        g = dout.reshape(-1, D).contiguous()
+        dy, dx = torch.empty_like(y2), torch.empty_like(x2)
+        call("gtos_highway_bwd", dt(x2), x2.shape[0], D, ptr(y2), ptr(x2), ptr(g), ptr(dy), ptr(dx), stream())
+        return dy.view(ctx.shapes[0]), dx.view(ctx.shapes[1])
+
+
+def highway_gate(y, x):
+    return HighwayGateFn.apply(y, x)
+
+
+class MaxReluFn(torch.autograd.Function):
+    """relu(y.max(dim=1)[0]) for y [N, L, F]: the char CNN's max over time + ReLU (generator/encoder.py:169-172)."""
+
+    @staticmethod
+    def forward(ctx, y):
+        require_cuda(y)
+        N, L, F_ = y.shape
+        y = y.contiguous()
+        out = torch.empty((N, F_), dtype=y.dtype, device=y.device)
+        arg = torch.empty((N, F_), dtype=torch.uint8, device=y.device)
+        call("gtos_max_relu_fwd", dt(y), N, L, F_, ptr(y), ptr(out), ptr(arg), stream())
+        ctx.save_for_backward(out, arg)
+        ctx.L = L
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        out, arg = ctx.saved_tensors
+        N, F_ = out.shape
+        g = dout.contiguous()
+        dy = torch.empty((N, ctx.L, F_), dtype=out.dtype, device=out.device)
+        call("gtos_max_relu_bwd", dt(out), N, ctx.L, F_, ptr(out), ptr(arg), ptr(g), ptr(dy), stream())
+        return dy
+
+
+def max_relu(y):
+    return MaxReluFn.apply(y)
+
+
+class TokenRowFn(torch.autograd.Function):
+    """dropout(cat([feat, table[tok]], -1)) zero-padded to a multiple of 8 columns, in feat's dtype: torch.cat + nn.Embedding +
+    F.dropout of TokenEncoder.forward (generator/encoder.py:196-199).  Backward: masked gradient back to ``feat`` and scattered
+    into the (fp32) embedding table; the padding row of the table takes none."""
+
+    @staticmethod
+    def forward(ctx, feat, tok, table, p_drop, pad_idx):
+        require_cuda(feat, tok, table)
+        lead, Cc = feat.shape[:-1], feat.shape[-1]
+        Ct = table.shape[1]
+        Cp = (Cc + Ct + 7) // 8 * 8
+        f2 = feat.reshape(-1, Cc).contiguous()
+        tk = tok.reshape(-1).contiguous()
+        out = torch.empty((f2.shape[0], Cp), dtype=feat.dtype, device=feat.device)
+        seed = next_seed() if p_drop > 0 else 0
+        call("gtos_token_row_fwd", dt(out), f2.shape[0], Cc, Ct, Cp, ptr(f2), ptr(tk), ptr(table), ptr(out), float(p_drop), seed, stream())
+        ctx.save_for_backward(tk)
+        ctx.cfg = (table, Cc, Ct, Cp, p_drop, seed, pad_idx, feat.shape)
+        return out.view(*lead, Cp)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (tk,) = ctx.saved_tensors
+        table, Cc, Ct, Cp, p_drop, seed, pad_idx, fshape = ctx.cfg
+        g = dout.reshape(-1, Cp).contiguous()
+        dfeat = torch.empty((g.shape[0], Cc), dtype=g.dtype, device=g.device) if ctx.needs_input_grad[0] else None
+        tgt, dtab = None, None
+        if ctx.needs_input_grad[2]:
+            tgt = _grad_target(table)
+            if tgt is None:
+                tgt = dtab = torch.zeros(table.shape, dtype=torch.float32, device=table.device)
+        call("gtos_token_row_bwd", dt(g), g.shape[0], Cc, Ct, Cp, ptr(g), ptr(tk), ptr(dfeat), ptr(tgt), float(p_drop), seed, stream())
+        if tgt is not None and pad_idx is not None:
+            tgt[pad_idx].zero_()          # nn.Embedding(padding_idx=...): the padding row takes no gradient
+        return (dfeat.view(fshape) if dfeat is not None else None), None, dtab, None, None
+
+
+def token_row(feat, tok, table, p_drop, pad_idx=None):
+    return TokenRowFn.apply(feat, tok, table, float(p_drop), pad_idx)
+
+
 class PermuteRowsFn(torch.autograd.Function):
     """y = x[perm] for a PERMUTATION perm with inverse inv: the backward is the gather g[inv] instead of the
     atomics-based index_add_ that autograd derives for a general index_select."""

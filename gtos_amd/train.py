@@ -77,6 +77,12 @@ class Trainer:
         if self.overlap and hasattr(model, "grad_sync"):
             model.grad_sync = self      # Generator.forward places the SegmentBoundaryFn markers
         if world_size > 1:
+            # Replicas must start identical.  The reference relies on every rank seeding torch alike before it builds the model
+            # (generator/train.py:98-100); here rank 0's flat parameter buffer is broadcast once (one collective over the whole
+            # model, like DistributedDataParallel does at construction), so a rank that was built differently -- another seed, a
+            # checkpoint loaded on rank 0 only -- cannot drift silently.
+            dist.broadcast(self.flat.param, src=0)
+            self.flat.sync_mirror()
             ops.set_seed(base_seed + rank)
 
     # ---- boundary markers (called from the model's forward)

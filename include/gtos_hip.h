@@ -195,6 +195,25 @@ int gtos_embed_rows_fwd(int dtype, int64_t n, int dim, int dim_pad, const int64_
 int gtos_embed_rows_bwd(int dtype, int64_t n, int V, int dim, int dim_pad, const int64_t* tok, const void* dout,
                         float* dtable, float p_drop, uint64_t seed, void* stream);
 
+/* Elementwise pieces of TokenEncoder / CNNEncoder / Highway (generator/encoder.py:123-201), each one kernel per direction in place
+ * of a dozen small ATen kernels; `dtype` rows are contiguous.
+ *   highway: y [N,2D] = layer(x) (columns [0,D) = new_x, [D,2D) = gate), out = sigmoid(gate) * x + (1 - sigmoid(gate)) * relu(new_x)
+ *            (encoder.py:141-149); _bwd writes dy [N,2D] and dx [N,D] (the direct gate * x path only).  D % 8 == 0.
+ *   max_relu: y [N,L,F] -> out [N,F] = relu(max over L) (the char CNN's max over time, encoder.py:169-172), arg [N,F] uint8 = first
+ *            maximising position; _bwd writes all of dy [N,L,F].  F % 8 == 0, L <= 255.
+ *   token_row: out [N,Cp] = dropout([feat [N,Cc] | table[tok[n], 0:Ct] | zeros]) with Cp = Cc + Ct rounded up to a multiple of 8
+ *            (torch.cat + nn.Embedding + F.dropout of encoder.py:196-199; table fp32 [V,Ct], tok int64 [N], Cc % 8 == 0; feat may be
+ *            NULL with Cc == 0); _bwd: dfeat [N,Cc] = mask * dout[:, 0:Cc], dtable[tok[n]] += mask * dout[n, Cc:Cc+Ct] (fp32
+ *            atomics; either output may be NULL). */
+int gtos_highway_fwd(int dtype, int64_t N, int D, const void* y, const void* x, void* out, void* stream);
+int gtos_highway_bwd(int dtype, int64_t N, int D, const void* y, const void* x, const void* dout, void* dy, void* dx, void* stream);
+int gtos_max_relu_fwd(int dtype, int64_t N, int L, int F, const void* y, void* out, uint8_t* arg, void* stream);
+int gtos_max_relu_bwd(int dtype, int64_t N, int L, int F, const void* out, const uint8_t* arg, const void* dout, void* dy, void* stream);
+int gtos_token_row_fwd(int dtype, int64_t N, int Cc, int Ct, int Cp, const void* feat, const int64_t* tok, const float* table,
+                       void* out, float p_drop, uint64_t seed, void* stream);
+int gtos_token_row_bwd(int dtype, int64_t N, int Cc, int Ct, int Cp, const void* dout, const int64_t* tok, void* dfeat,
+                       float* dtable, float p_drop, uint64_t seed, void* stream);
+
 /* Flat-buffer optimizer: sum of squares (clip_grad_norm_, generator/train.py:151) and the Adam variant of
  * generator/adam.py:66-87 (no bias correction, decoupled weight decay), with the gradient averaging of
  * generator/train.py:74-79 (gscale = 1/world_size) and the clip coefficient folded in; optionally refreshes a

@@ -251,3 +251,37 @@ def test_trainer_step_real_model_two_ranks_equal_one_rank():
     assert torch.equal(two[0][2], two[1][2])                          # replicas stay bit-identical
     for a, b, c in zip(two[0][1], two[1][1], one[1]):
         assert abs((a + b) / 2 - c) < 1e-4 * max(1.0, abs(c))
+
+
+def _bcast_worker(rank, world, port, q):
+    import gtos_amd.train as train_mod
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(1000 + rank)                      # ranks built DIFFERENTLY on purpose
+    model = _SegModel()
+    before = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()
+    trainer = train_mod.Trainer(model, 64, warmup_steps=10, world_size=world, rank=rank, segment_of=train_mod.generator_segment_of)
+    after = trainer.flat.param.detach().clone()
+    views = torch.cat([p.detach().reshape(-1) for _, p, _ in trainer.flat.entries])
+    q.put((rank, before.numpy(), after.numpy(), views.numpy()))
+    dist.destroy_process_group()
+
+
+def test_trainer_construction_broadcasts_rank0_parameters():
+    """Replicas start identical even when the ranks were built from different seeds: Trainer broadcasts rank 0's flat buffer."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bcast_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, b0, a0, v0), (_, b1, a1, v1) = res
+    assert not (b0 == b1).all()                          # they really were different
+    assert (a0 == a1).all() and (v0 == v1).all()         # ... and are rank 0's afterwards, in the flat buffer and through the views
+    import numpy as np
+    assert np.array_equal(np.sort(v0), np.sort(b0))      # rank 0 kept its own values (the flat layout only permutes them)

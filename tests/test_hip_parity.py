@@ -1457,3 +1457,69 @@ def test_device_side_step_control_matches_the_reference_loop_bookkeeping():
     assert tr.discarded == 2 and tr.batches_acm == 7 and tr.steps_issued == 9
     tr.set_counters(100, 250.0, 3)
     assert tr.batches_acm == 100 and tr.discarded == 3 and tr.steps_issued == 103
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_token_encoder_elementwise_kernels_vs_torch(dtype):
+    """gtos_highway_*, gtos_max_relu_*, gtos_token_row_* against the ATen op sequences of generator/encoder.py:141-149,169-172,
+    196-199 on the same operands (fp32: exact up to rounding; bf16: the kernel computes in fp32 from bf16 operands)."""
+    import torch.nn.functional as F
+    from gtos_amd import ops
+    g = torch.Generator().manual_seed(3)
+    tol = dict(rtol=1e-5, atol=1e-6) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    # highway gate
+    N, D = 77, 40
+    y = torch.randn(N, 2 * D, generator=g).to(dev(), dtype).requires_grad_()
+    x = torch.randn(N, D, generator=g).to(dev(), dtype).requires_grad_()
+    w = torch.randn(N, D, generator=g).to(dev())
+    out = ops.highway_gate(y, x)
+    (out.float() * w).sum().backward()
+    y2, x2 = y.detach().float().requires_grad_(), x.detach().float().requires_grad_()
+    nx, gate = y2.chunk(2, -1)
+    s = torch.sigmoid(gate)
+    ref = s * x2 + (1 - s) * F.relu(nx)
+    (ref * w).sum().backward()
+    torch.testing.assert_close(out.float(), ref, **tol)
+    torch.testing.assert_close(y.grad.float(), y2.grad, **tol)
+    torch.testing.assert_close(x.grad.float(), x2.grad, **tol)
+    # max over time + relu (ties: the first maximum, like torch.max)
+    N, L, Fc = 33, 12, 24
+    yy = torch.randn(N, L, Fc, generator=g)
+    yy[0, 3] = yy[0, 7] = 5.0                                   # a tie
+    yy[1] = -yy[1].abs()                                        # all negative: relu kills output and gradient
+    yd = yy.to(dev(), dtype).requires_grad_()
+    wo = torch.randn(N, Fc, generator=g).to(dev())
+    o = ops.max_relu(yd)
+    (o.float() * wo).sum().backward()
+    y3 = yd.detach().float().requires_grad_()
+    r = F.relu(y3.max(1)[0])
+    (r * wo).sum().backward()
+    torch.testing.assert_close(o.float(), r, **tol)
+    torch.testing.assert_close(yd.grad.float(), y3.grad, **tol)
+    # token row: cat + embedding + dropout + zero pad; p = 0 against torch, p > 0: mask statistics and fwd/bwd mask agreement
+    N, Cc, Ct, V = 50, 16, 30, 23
+    feat = torch.randn(N, Cc, generator=g).to(dev(), dtype).requires_grad_()
+    table = torch.randn(V, Ct, generator=g).to(dev()).requires_grad_()
+    tok = torch.randint(0, V, (N,), generator=g).to(dev())
+    tok[:5] = 0                                                 # padding rows
+    wt = torch.randn(N, 48, generator=g).to(dev())
+    row = ops.token_row(feat, tok, table, 0.0, pad_idx=0)
+    assert row.shape == (N, 48) and float(row[:, 46:].abs().max()) == 0.0
+    (row.float() * wt).sum().backward()
+    f2, t2 = feat.detach().float().requires_grad_(), table.detach().clone().requires_grad_()
+    emb = F.embedding(tok, t2, padding_idx=0).to(dtype).float()
+    ref = F.pad(torch.cat([f2, emb], -1), (0, 2))
+    (ref * wt).sum().backward()
+    torch.testing.assert_close(row.float(), ref, **tol)
+    torch.testing.assert_close(feat.grad.float(), f2.grad, **tol)
+    torch.testing.assert_close(table.grad, t2.grad, **tol)
+    assert float(table.grad[0].abs().max()) == 0.0
+    ops.set_seed(5)
+    big = torch.ones(4000, Cc, device=dev(), dtype=dtype).requires_grad_()
+    tb = torch.ones(V, Ct, device=dev()).requires_grad_()
+    tk = torch.randint(1, V, (4000,), generator=g).to(dev())
+    dr = ops.token_row(big, tk, tb, 0.25, pad_idx=None)
+    kept = (dr[:, :46] != 0).float().mean().item()
+    assert abs(kept - 0.75) < 0.01 and abs(float(dr[:, :46].float().max()) - 1 / 0.75) < 1e-2
+    dr.float().sum().backward()
+    torch.testing.assert_close(big.grad.float(), dr[:, :Cc].detach().float(), rtol=1e-2, atol=1e-2)   # same mask backward
