@@ -36,7 +36,7 @@ SIGNATURES = {
     "gtos_gru_cell_bwd": [c_i, c_i, c_i, c_p, c_p, c_p, c_l, c_p, c_p, c_p, c_f, c_u64, c_l, c_p, c_i, c_p],
     "gtos_relation_gather_mean": [c_i, c_l, c_i, c_i, c_p, c_p, c_i, c_p, c_p],
     "gtos_embed_rows_fwd": [c_i, c_l, c_i, c_i, c_p, c_p, c_p, c_f, c_u64, c_p],
-    "gtos_embed_rows_bwd": [c_i, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_f, c_u64, c_p],
+    "gtos_embed_rows_bwd": [c_i, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_f, c_u64, c_p, c_l, c_p],
     "gtos_copy_nll_fwd": [c_i, c_i, c_i, c_i, c_i, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_p, c_p, c_p, c_p],
     "gtos_copy_nll_bwd": [c_i, c_i, c_i, c_i, c_i, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "gtos_copy_ll_fwd": [c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_l, c_p, c_p, c_p, c_p, c_p],

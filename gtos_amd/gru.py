@@ -20,7 +20,8 @@ import torch
 
 from . import _lib
 from ._lib import call, dt, ptr, stream
-from .ops import gemm, compute_weight, next_seed, weight_t, _grad_target, _splitk, side_stream as _side_stream, defer_side_join, _Timed
+from .ops import (gemm, compute_weight, next_seed, weight_t, _grad_target, _splitk, side_stream as _side_stream, defer_side_join, _Timed,
+                  embed_bwd_workspace)
 
 
 def _cell_fwd(A, hs, xg, hg, h, y, y_off_elems, ldy, hprev, gates, p, seed, drop_base):
@@ -287,7 +288,7 @@ TRIE_SIDE = os.environ.get("GTOS_GRU_TRIE_SIDE", "0") == "1"
 # prefix and the suffix trie are independent, so the suffix side runs on the auxiliary stream beside the prefix side.
 TRIE_L0_OVERLAP = os.environ.get("GTOS_GRU_L0_OVERLAP", "1") != "0"
 # Layer 1, forward: the input-gate table products of the reverse direction on the auxiliary stream beside the forward direction's steps.
-TRIE_L1_TABLE_OVERLAP = os.environ.get("GTOS_GRU_L1_TABLES", "1") != "0"
+TRIE_L1_TABLE_OVERLAP = os.environ.get("GTOS_GRU_L1_TABLES", "0") == "1"     # measured at C2: 64.28 vs 64.29 ms per step -- no gain, off
 # Layer 0, backward: children -> parent sums through the row indirection of pathtrie.TrieSide.sum_idx (0: a summed row per node).
 TRIE_SUM_INDEX = os.environ.get("GTOS_GRU_SUMIDX", "1") != "0"
 
@@ -591,8 +592,9 @@ class TrieBiGRUFn(torch.autograd.Function):
                     tgt = _grad_target(table)
                     if tgt is None:
                         tgt = dtab
+                    ws = embed_bwd_workspace(n, table.shape[0], dim_pad, dev)
                     call("gtos_embed_rows_bwd", dt(dX), n, table.shape[0], table.shape[1], dim_pad, ptr(side.tok), ptr(dX), ptr(tgt),
-                         float(p_embed), seed_e, stream())
+                         float(p_embed), seed_e, ptr(ws), 0 if ws is None else ws.numel() * 4, stream())
             if l0_overlap and d == 1:
                 keep.extend(held)                      # allocated in the auxiliary stream's pool: released after the join below
         if l0_overlap:

@@ -88,10 +88,11 @@ def _workspace(device):
 
 
 _SIDE = {}
-# Opt-in (GTOS_PROJ_SIDE=1): prefetch every layer's relation projection on the side stream.  Measured at C2: 104.8 ->
-# 102.7 ms/step, but the attention kernels then share the chip with a GEMM and their own launches stretch from 259 to
-# 595 us, which would make the in-step roofline figure of bench.py meaningless -- so it is off by default.
-PROJ_SIDE = os.environ.get("GTOS_PROJ_SIDE", "0") == "1"
+# Prefetch every layer's relation projection on the side stream (they depend on the bank only, not on the layer chain): the
+# MFMA-bound GEMMs run beside the HBM-bound attention kernels.  Measured at C2 (same box, round 3): 64.29 -> 63.70 ms per step.
+# The attention launches of the timed steps then share the chip with a GEMM, so bench.py takes the in-step duration of the
+# roofline kernel from its detail pass, where the overlap is off.  GTOS_PROJ_SIDE=0 switches it off.
+PROJ_SIDE = os.environ.get("GTOS_PROJ_SIDE", "1") != "0"
 # Backward of the relation projections on the side stream (see LinearFn.backward): overlaps only backward kernels.
 BWD_SIDE = os.environ.get("GTOS_BWD_SIDE", "1") != "0"
 BWD_SIDE_MIN_ROWS = 100000
@@ -668,6 +669,13 @@ def relation_gather_mean(bank, idx, zero_row0):
     return out.view(*lead, bank.shape[1])
 
 
+def embed_bwd_workspace(n, V, dim_pad, device):
+    """Workspace gtos_embed_rows_bwd sums its per-block tables through (small tables only): one table per 512-row block."""
+    if V * dim_pad * 4 > 60 * 1024 or n <= 8 * 512:
+        return None
+    return torch.empty((min(2048, (n + 511) // 512), V * dim_pad), dtype=torch.float32, device=device)
+
+
 class EmbedRowsFn(torch.autograd.Function):
     """x[n, 0:dim_pad] = dropout(table[tokens[n]]) zero-padded, in the compute dtype: nn.Embedding + F.dropout of
     RelationEncoder (generator/encoder.py:99-100).  Backward scatters into the (small) table through LDS."""
@@ -694,8 +702,9 @@ class EmbedRowsFn(torch.autograd.Function):
         dtab = None
         if tgt is None:
             tgt = dtab = torch.zeros(table.shape, dtype=torch.float32, device=table.device)
+        ws = embed_bwd_workspace(tokens.numel(), V, dim_pad, dout.device)
         call("gtos_embed_rows_bwd", dt(dout), tokens.numel(), V, dim, dim_pad, ptr(tokens), ptr(dout), ptr(tgt),
-             float(p_drop), seed, stream())
+             float(p_drop), seed, ptr(ws), 0 if ws is None else ws.numel() * 4, stream())
         if pad_idx is not None:
             tgt[pad_idx].zero_()          # nn.Embedding(padding_idx=...): the padding row takes no gradient
         return None, dtab, None, None, None, None

@@ -189,11 +189,13 @@ int gtos_relation_gather_mean(int dtype, int64_t P, int K, int d, const void* ba
 
 /* Relation-label embedding rows for the packed GRU input: out[n, 0:dim_pad] = dropout(table[tok[n]]) zero-padded to
  * dim_pad (multiple of 8) in `dtype` (nn.Embedding + F.dropout, generator/encoder.py:99-100), and its backward
- * dtable[V,dim] += scatter of dout (the embedding's index_add backward) for small tables (V*dim*4 <= 60 KB). */
+ * dtable[V,dim] += scatter of dout (the embedding's index_add backward); small tables (V*dim_pad*4 <= 60 KB) are accumulated per
+ * block in LDS and, when the caller lends a workspace (optional; any size >= one table, more = more blocks), summed over the
+ * blocks by a second launch instead of flushed with global atomics onto the same few thousand addresses. */
 int gtos_embed_rows_fwd(int dtype, int64_t n, int dim, int dim_pad, const int64_t* tok, const float* table, void* out,
                         float p_drop, uint64_t seed, void* stream);
 int gtos_embed_rows_bwd(int dtype, int64_t n, int V, int dim, int dim_pad, const int64_t* tok, const void* dout,
-                        float* dtable, float p_drop, uint64_t seed, void* stream);
+                        float* dtable, float p_drop, uint64_t seed, float* workspace, int64_t workspace_bytes, void* stream);
 
 /* Elementwise pieces of TokenEncoder / CNNEncoder / Highway (generator/encoder.py:123-201), each one kernel per direction in place
  * of a dozen small ATen kernels; `dtype` rows are contiguous.

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Summarise the four rocprofv3 --pmc passes of tools/pmc_rel_attn.sh (dense|factored x FETCH_SIZE|WRITE_SIZE) into
-profiles/r2_rel_attn_pmc.json: HBM bytes per launch of every relation-attention kernel, per operand mode.
+profiles/rN_rel_attn_pmc.json: HBM bytes per launch of every relation-attention kernel, per operand mode.
 Units / corrections follow /opt/skills/guides/MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE are KiB; on gfx950
 FETCH_SIZE reports half the bytes of wide (16 B/lane) coalesced streaming reads -- these kernels read everything that way
 (8 bf16 channels per lane) -- so it is doubled; WRITE_SIZE is taken as is."""
