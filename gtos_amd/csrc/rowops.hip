@@ -456,10 +456,11 @@ __global__ void embed_reduce_kernel(int nb, int V, int dim, int dim_pad, const f
     const int vpr = dim_pad / 8, plane = V * vpr, total = 8 * plane;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
+    const int b0 = (int)((int64_t)nb * blockIdx.y / gridDim.y), b1 = (int)((int64_t)nb * (blockIdx.y + 1) / gridDim.y);
     float acc = 0.f;
-    for (int b = 0; b < nb; ++b) acc += partials[(int64_t)b * total + i];
+    for (int b = b0; b < b1; ++b) acc += partials[(int64_t)b * total + i];
     const int e = i / plane, rem = i % plane, tk = rem / vpr, chn = (rem % vpr) * 8 + e;
-    if (chn < dim && acc != 0.f) atomicAdd(dtable + (int64_t)tk * dim + chn, acc);   // (two launches on two streams may share dtable)
+    if (chn < dim && acc != 0.f) atomicAdd(dtable + (int64_t)tk * dim + chn, acc);   // (slices of the block range; two streams may share dtable)
 }
 
 // =========================================================================== segmented row sums (trie GRU backward)
@@ -802,7 +803,8 @@ extern "C" int gtos_embed_rows_bwd(int dtype, int64_t n, int V, int dim, int dim
     GTOS_CHECK_LAUNCH();
     if (partials) {
         const int total = V * dim_pad;
-        hipLaunchKernelGGL(embed_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, (int)grid.x, V, dim, dim_pad, partials, dtable);
+        const int slices = grid.x >= 64 ? 16 : 1;       // 16 slices of the block range per word: ~9 k x 16 short loops instead of 9 k long ones
+        hipLaunchKernelGGL(embed_reduce_kernel, dim3((total + 255) / 256, slices), dim3(256), 0, s, (int)grid.x, V, dim, dim_pad, partials, dtable);
         GTOS_CHECK_LAUNCH();
     }
     return 0;

@@ -289,6 +289,8 @@ TRIE_SIDE = os.environ.get("GTOS_GRU_TRIE_SIDE", "0") == "1"
 TRIE_L0_OVERLAP = os.environ.get("GTOS_GRU_L0_OVERLAP", "1") != "0"
 # Layer 1, forward: the input-gate table products of the reverse direction on the auxiliary stream beside the forward direction's steps.
 TRIE_L1_TABLE_OVERLAP = os.environ.get("GTOS_GRU_L1_TABLES", "0") == "1"     # measured at C2: 64.28 vs 64.29 ms per step -- no gain, off
+# Label-embedding gradient of the trie path as two GEMMs (one-hot product) instead of the LDS-atomics scatter kernel.
+EMBED_GRAD_GEMM = os.environ.get("GTOS_EMBED_GEMM", "1") != "0"
 # Layer 0, backward: children -> parent sums through the row indirection of pathtrie.TrieSide.sum_idx (0: a summed row per node).
 TRIE_SUM_INDEX = os.environ.get("GTOS_GRU_SUMIDX", "1") != "0"
 
@@ -525,6 +527,7 @@ class TrieBiGRUFn(torch.autograd.Function):
         # the two tries are independent: the suffix side runs on the auxiliary stream beside the prefix side (small launches per
         # level on both); with TRIE_SIDE the GEMMs go to the auxiliary stream instead and both sides stay on main
         l0_overlap = TRIE_L0_OVERLAP and not use_side and N >= SIDE_MIN_ROWS     # small banks are launch-bound: no stream hand-overs
+        emb_parts = []
         aux0 = _side_stream(dev) if l0_overlap else main
         if l0_overlap:
             aux0.wait_stream(main)
@@ -588,18 +591,35 @@ class TrieBiGRUFn(torch.autograd.Function):
                 if want_bias:
                     _acc_bias_grads(grads, base, b_ih, b_hh, bpart.sum(0), hs)
                 if table.requires_grad:
-                    dX = gemm(d4[:, :3 * hs], wi_t, trans_b=True)        # [n, dim_pad]
                     tgt = _grad_target(table)
                     if tgt is None:
                         tgt = dtab
-                    ws = embed_bwd_workspace(n, table.shape[0], dim_pad, dev)
-                    call("gtos_embed_rows_bwd", dt(dX), n, table.shape[0], table.shape[1], dim_pad, ptr(side.tok), ptr(dX), ptr(tgt),
-                         float(p_embed), seed_e, ptr(ws), 0 if ws is None else ws.numel() * 4, stream())
+                    V = table.shape[0]
+                    if EMBED_GRAD_GEMM and V <= 256:
+                        # label-embedding gradient = onehot(token)^T (mask * dX): two products on the MFMA GEMM.  The dropout
+                        # mask of the forward (counter row * dim_pad + column) is the GEMM epilogue's own counter; the scatter
+                        # kernel it replaces spent 0.4 ms per trie in LDS float atomics for 95 MB of input.
+                        dX = gemm(d4[:, :3 * hs], wi_t, trans_b=True, p_drop=p_embed, seed=seed_e)      # [n, dim_pad], masked
+                        Vp = (V + 7) // 8 * 8
+                        part = gemm(side.token_onehot(Vp, dtp), dX, trans_a=True, out_dtype=torch.float32, splitk=_splitk(Vp, dim_pad, n))
+                        emb_parts.append(part)           # added to the table gradient after the two sides have joined (one writer)
+                        held = held + (part,)
+                    else:
+                        dX = gemm(d4[:, :3 * hs], wi_t, trans_b=True)        # [n, dim_pad]
+                        ws = embed_bwd_workspace(n, V, dim_pad, dev)
+                        call("gtos_embed_rows_bwd", dt(dX), n, V, table.shape[1], dim_pad, ptr(side.tok), ptr(dX), ptr(tgt),
+                             float(p_embed), seed_e, ptr(ws), 0 if ws is None else ws.numel() * 4, stream())
             if l0_overlap and d == 1:
                 keep.extend(held)                      # allocated in the auxiliary stream's pool: released after the join below
         if l0_overlap:
             main.wait_stream(aux0)
-            keep.clear()
+        if emb_parts and use_side:
+            main.wait_stream(aux)          # (GTOS_GRU_TRIE_SIDE=1: the products above ran on the auxiliary stream)
+        for part in emb_parts:
+            tgt = _grad_target(table)
+            tgt = dtab if tgt is None else tgt
+            tgt += part[:table.shape[0], :table.shape[1]]
+        keep.clear()
         if use_side:
             if dtab is None and all(gr is None for gr in grads):
                 defer_side_join(dev, keep)     # every gradient went into the flat bucket: its readers join the side stream

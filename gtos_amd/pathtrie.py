@@ -68,8 +68,18 @@ class TrieSide(object):
         self.n_multi = self.multi_level_off[-1]
 
     def to(self, device):
-        arrays = {k: v.to(device) for k, v in self.__dict__.items() if isinstance(v, torch.Tensor)}
+        arrays = {k: v.to(device) for k, v in self.__dict__.items() if isinstance(v, torch.Tensor) and not k.startswith("_")}
         return TrieSide(arrays, self.level_off, self.multi_level_off)
+
+    def token_onehot(self, width, dtype):
+        """[n_nodes, width] one-hot rows of the node tokens (width >= vocabulary size, a multiple of 8), built once per batch:
+        the left operand that turns the label-embedding gradient into a product on the MFMA GEMM (gtos_amd.gru)."""
+        oh = getattr(self, "_onehot", None)
+        if oh is None or oh.shape[1] != width or oh.dtype != dtype or oh.device != self.tok.device:
+            oh = torch.zeros((self.n_nodes, width), dtype=dtype, device=self.tok.device)
+            oh.scatter_(1, self.tok.view(-1, 1), 1.0)
+            self._onehot = oh
+        return oh
 
 
 class PathTrie(object):
