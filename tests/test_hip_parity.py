@@ -14,8 +14,9 @@ pytestmark = pytest.mark.gpu
 
 FP32 = dict(rtol=1e-3, atol=1e-3)
 GRAD = dict(rtol=2e-3, atol=1e-3)
-BF16_ATTN_ABS = 1e-2      # attention weights (probabilities), absolute
-BF16_OUT_REL = 2e-2       # post-LN outputs, relative to max(1, |gold|); tightened to the measured values in round 3 (see the test)
+BF16_ATTN_ABS = 1e-3      # attention weights (probabilities), absolute; measured 1.2e-4 / 1.2e-4 / 1.6e-4 on gt_pad / gt_hd64 / gt_h8
+BF16_OUT_REL = 1.5e-2     # post-LN outputs, relative to max(1, |gold|); measured 8.0e-3 / 1.33e-2 / 9.6e-3 (absolute 1.7e-2 / 3.8e-2 /
+#                           2.2e-2 on outputs up to |2.7| / |4.6| / |4.8|, whose bf16 storage alone rounds by up to 1.6e-2)
 
 
 def dev():
@@ -184,9 +185,9 @@ def test_graph_transformer_bf16_vs_golden(name):
     rel_err = float((dx.float().cpu() - T(g["dx"])).norm() / T(g["dx"]).norm())
     print("bf16 vs golden %s: max |out err| %.3e (|out| max %.2f, relative to max(1,|gold|) %.3e), max |attn err| %.3e, dx rel %.3e" % (
         name, e_out, float(gold.abs().max()), e_rel, e_attn, rel_err))
-    # north_star: 1e-2 in bf16.  Attention weights are probabilities: 1e-2 absolute.  Post-LN outputs reach |3-4|, where ONE bf16
-    # rounding of the stored output is already 2^-8 * 4 = 1.6e-2 absolute, so the output bar is 1e-2 RELATIVE to max(1, |gold|)
-    # (measured values are printed above and listed in profiles/README.md).
+    # north_star: 1e-2 in bf16.  Attention weights are probabilities and sit an order of magnitude inside it.  Post-LN outputs reach
+    # |3-5|, where ONE bf16 rounding of the stored output is already up to 1.6e-2 absolute, so the output bar is relative to
+    # max(1, |gold|): 1e-2 holds on two of the three fixtures, the 4-layer hd=64 one measures 1.33e-2 (bar 1.5e-2).
     assert e_attn < BF16_ATTN_ABS, e_attn
     assert e_rel < BF16_OUT_REL, (e_out, e_rel)
     assert rel_err < 3e-2, rel_err
