@@ -515,6 +515,7 @@ def main():
         loader_info.update({"host_assembly_s_per_batch": round(sum(done) / max(1, len(done)), 4),
                             "consumer_wait_ms_per_step": round(1e3 * wait_s[0] / a.steps, 3)})
         feed.close()                                   # the roofline legs below reuse the first batch the feed handed out
+        feed = None
     comm_exposed = max(trainer.comm_exposed_s, 1e-3 * trainer.comm_exposed_ms())   # host wait (gloo) / compute-stream stall (RCCL)
     log("timed region done", elapsed)
     prof, ops.PROFILE = ops.PROFILE, None

@@ -582,20 +582,43 @@ class Prefetcher(object):
                 self._cv.notify_all()
 
     def close(self):
+        """Stop the workers and release everything in flight.  Safe to call more than once; joins the helper threads so that no
+        thread of this object can still be inside a device call when the interpreter (and the HIP runtime) shuts down."""
+        import queue
+        import threading
         with self._cv:
+            already = self._stop
             self._stop = True
             self._out.clear()
             self._cv.notify_all()
-        for p_ in self._procs:
+        procs, self._procs = self._procs, []
+        for p_ in procs:
             try:
-                self._jobq.put(None)
+                self._jobq.put_nowait(None)
             except Exception:
                 pass
-        for p_ in self._procs:
+        for p_ in procs:
             p_.join(timeout=0.5)
             if p_.is_alive():
                 p_.terminate()
-        self._procs = []
+                p_.join(timeout=1.0)
+        if not already:
+            me = threading.current_thread()
+            for t in self._threads:
+                if t is not me and t.is_alive():
+                    t.join(timeout=2.0)
+        if procs:
+            for q_ in (self._resq, self._jobq):
+                try:
+                    while True:                      # results nobody will take: drop them (their shared memory with them)
+                        q_.get_nowait()
+                except (queue.Empty, OSError, ValueError, EOFError):
+                    pass
+                try:
+                    q_.close()
+                    q_.cancel_join_thread()
+                except Exception:
+                    pass
 
     def __del__(self):
         try:
