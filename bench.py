@@ -404,6 +404,14 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if a.fresh_batches and not os.environ.get("GTOS_BENCH_NO_ROUNDUP"):
+        # every batch has its own bank size (R and the packed row count vary by a percent), so every large buffer of the step
+        # changes size from step to step; the caching allocator then keeps growing (a cached 890 MB block cannot serve an 895 MB
+        # request) until hipMalloc fails and the cache is flushed -- measured: 63 ms per step for one run, 120-140 ms for the next
+        # two on the same box.  Rounding request sizes up to 1/16 of a power of two makes consecutive steps reuse their blocks.
+        torch.cuda.memory._set_allocator_settings("roundup_power2_divisions:16")
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    log("device memory free %.1f of %.1f GB" % (free_b / 2 ** 30, total_b / 2 ** 30))
     if world > 1:
         dist.init_process_group(os.environ.get("GTOS_DIST_BACKEND", "nccl"), rank=rank, world_size=world)   # nccl = RCCL on ROCm
 
@@ -466,7 +474,8 @@ def main():
         assert stats["B"] == B_rank, stats
         asm_times.append(batch.pop("_assembly_s"))
         loader_info = {"workers": a.workers, "kind": a.loader, "depth": a.depth, "relbatch_threads": a.relbatch_threads,
-                       "pool_graphs_per_rank": pool_n}
+                       "pool_graphs_per_rank": pool_n, "device_memory_free_gb_at_start": round(free_b / 2 ** 30, 1),
+                       "allocator": "default" if os.environ.get("GTOS_BENCH_NO_ROUNDUP") else "roundup_power2_divisions:16"}
     else:
         batch, stats = synth.make_config_batch(a.config, rank=rank, B=B_rank)   # rank r holds graphs [r*B_rank, (r+1)*B_rank)
         attach_relation_index(attach_path_trie(batch))   # host-side index preparation: batch assembly, like the relation bank itself

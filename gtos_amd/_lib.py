@@ -5,6 +5,7 @@ There is NO fallback: if the library is missing or a kernel rejects a shape, an 
 """
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -54,6 +55,7 @@ SIGNATURES = {
 }
 
 _lib = None
+_load_lock = threading.Lock()
 
 
 class GtosHipError(RuntimeError):
@@ -63,7 +65,11 @@ class GtosHipError(RuntimeError):
 def load():
     """Load the shared library (once).  Raises GtosHipError when it has not been built."""
     global _lib
-    if _lib is None:
+    if _lib is not None:
+        return _lib
+    with _load_lock:
+        if _lib is not None:
+            return _lib
         if not os.path.exists(LIB_PATH):
             raise GtosHipError("%s is missing: run `python -m gtos_amd.build` (or __graft_entry__.build()); "
                                "there is no CPU fallback for the gtos hot path" % LIB_PATH)

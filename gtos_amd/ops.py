@@ -93,6 +93,9 @@ _SIDE = {}
 # The attention launches of the timed steps then share the chip with a GEMM, so bench.py takes the in-step duration of the
 # roofline kernel from its detail pass, where the overlap is off.  GTOS_PROJ_SIDE=0 switches it off.
 PROJ_SIDE = os.environ.get("GTOS_PROJ_SIDE", "1") != "0"
+# ... as long as all the layers' projections together stay small beside the rest of the step (7 GB at C2).  At C5 (R = 1.84 M:
+# 30 GB of projections alive at once on top of a 150 GB step) the prefetch made the step time scatter between 215 and 330 ms.
+PROJ_SIDE_MAX_BYTES = int(os.environ.get("GTOS_PROJ_SIDE_MAX_GB", "16")) << 30
 # Backward of the relation projections on the side stream (see LinearFn.backward): overlaps only backward kernels.
 BWD_SIDE = os.environ.get("GTOS_BWD_SIDE", "1") != "0"
 BWD_SIDE_MIN_ROWS = 100000
@@ -533,6 +536,8 @@ class FactoredRelation:
         dev = self.bank.device
         main, side = torch.cuda.current_stream(dev), side_stream(dev)
         if any(m.compute_dtype != self.bank.dtype for m in attns):
+            return
+        if sum(self.bank.shape[0] * m.relation_in_proj.weight.shape[0] for m in attns) * self.bank.element_size() > PROJ_SIDE_MAX_BYTES:
             return
         side.wait_stream(main)
         self.bank.record_stream(side)

@@ -15,24 +15,10 @@ from . import relbatch
 CHUNK = 64
 _COMMON = ("batch_sizes", "seq_order", "seq_pos", "row_pf", "row_sf")
 _PER_TRIE = ("level_off", "tok", "par", "child_off", "rows", "chunk_node", "chunk_start", "chunk_cnt", "chunk_slot", "heavy_node")
-_signed = False
 
 
 def _lib():
-    global _signed
-    lib = relbatch.load()
-    if not _signed:
-        P = ctypes.c_void_p
-        lib.gtos_pathtrie_build.restype = P
-        lib.gtos_pathtrie_build.argtypes = [ctypes.c_int, ctypes.c_int64, P, P, ctypes.c_int]
-        lib.gtos_pathtrie_sizes.restype = ctypes.c_int
-        lib.gtos_pathtrie_sizes.argtypes = [P, P]
-        lib.gtos_pathtrie_export.restype = ctypes.c_int
-        lib.gtos_pathtrie_export.argtypes = [P, P]
-        lib.gtos_pathtrie_free.restype = None
-        lib.gtos_pathtrie_free.argtypes = [P]
-        _signed = True
-    return lib
+    return relbatch.load()          # every signature of libgtos_host.so is set there, once, under a lock
 
 
 class TrieSide(object):

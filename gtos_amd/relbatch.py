@@ -2,6 +2,7 @@
 networkx all-pairs shortest paths + ``batchify`` relation section (SURVEY.md section 8f #1)."""
 import ctypes
 import os
+import threading
 
 import numpy as np
 import torch
@@ -10,11 +11,19 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc_host", "libgtos_host.so")
 PATH_FIRST, PATH_UNIFORM, PATH_ALL = 0, 1, 2
 _lib = None
+_load_lock = threading.Lock()
 
 
 def load():
+    """libgtos_host.so with EVERY entry's argument types set (relation batch, path tries, relation index), created once under a
+    lock: loader threads call in concurrently, and a second CDLL object whose pointer arguments were still untyped (ctypes then
+    passes them as 32-bit ints) segfaulted in gtos_pathtrie_build."""
     global _lib
-    if _lib is None:
+    if _lib is not None:
+        return _lib
+    with _load_lock:
+        if _lib is not None:
+            return _lib
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("%s is missing: run `python -m gtos_amd.build`" % LIB_PATH)
         lib = ctypes.CDLL(LIB_PATH)
@@ -27,6 +36,22 @@ def load():
         lib.gtos_relbatch_export.argtypes = [P] * 6
         lib.gtos_relbatch_free.restype = None
         lib.gtos_relbatch_free.argtypes = [P]
+        lib.gtos_pathtrie_build.restype = P
+        lib.gtos_pathtrie_build.argtypes = [ctypes.c_int, ctypes.c_int64, P, P, ctypes.c_int]
+        lib.gtos_pathtrie_sizes.restype = ctypes.c_int
+        lib.gtos_pathtrie_sizes.argtypes = [P, P]
+        lib.gtos_pathtrie_export.restype = ctypes.c_int
+        lib.gtos_pathtrie_export.argtypes = [P, P]
+        lib.gtos_pathtrie_free.restype = None
+        lib.gtos_pathtrie_free.argtypes = [P]
+        lib.gtos_relindex_build.restype = P
+        lib.gtos_relindex_build.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int64, P, ctypes.c_int]
+        lib.gtos_relindex_sizes.restype = ctypes.c_int
+        lib.gtos_relindex_sizes.argtypes = [P, P]
+        lib.gtos_relindex_export.restype = ctypes.c_int
+        lib.gtos_relindex_export.argtypes = [P, P]
+        lib.gtos_relindex_free.restype = None
+        lib.gtos_relindex_free.argtypes = [P]
         _lib = lib
     return _lib
 

@@ -15,24 +15,10 @@ from . import relbatch
 
 CHUNK = 32
 _NAMES = ("idx_q", "idx_k", "pair_sorted", "chunk_type", "chunk_start", "chunk_count", "chunk_slot", "xcd_off", "heavy_types")
-_signed = False
 
 
 def _lib():
-    global _signed
-    lib = relbatch.load()
-    if not _signed:
-        P = ctypes.c_void_p
-        lib.gtos_relindex_build.restype = P
-        lib.gtos_relindex_build.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int64, P, ctypes.c_int]
-        lib.gtos_relindex_sizes.restype = ctypes.c_int
-        lib.gtos_relindex_sizes.argtypes = [P, P]
-        lib.gtos_relindex_export.restype = ctypes.c_int
-        lib.gtos_relindex_export.argtypes = [P, P]
-        lib.gtos_relindex_free.restype = None
-        lib.gtos_relindex_free.argtypes = [P]
-        _signed = True
-    return lib
+    return relbatch.load()          # every signature of libgtos_host.so is set there, once, under a lock
 
 
 class RelationIndex(object):
