@@ -410,7 +410,14 @@ def main():
         # request) until hipMalloc fails and the cache is flushed -- measured: 63 ms per step for one run, 120-140 ms for the next
         # two on the same box.  Rounding request sizes up to 1/16 of a power of two makes consecutive steps reuse their blocks.
         torch.cuda.memory._set_allocator_settings("roundup_power2_divisions:16")
-    free_b, total_b = torch.cuda.mem_get_info(dev)
+    # the driver releases a finished process's device memory lazily (a 100 GB process still shows 35-40 % of the VRAM allocated a
+    # second after it has gone, none three seconds later): a run started back to back with another one would otherwise begin under
+    # memory pressure that is not its own
+    for _ in range(24):
+        free_b, total_b = torch.cuda.mem_get_info(dev)
+        if free_b > 0.9 * total_b:
+            break
+        time.sleep(0.5)
     log("device memory free %.1f of %.1f GB" % (free_b / 2 ** 30, total_b / 2 ** 30))
     if world > 1:
         dist.init_process_group(os.environ.get("GTOS_DIST_BACKEND", "nccl"), rank=rank, world_size=world)   # nccl = RCCL on ROCm
