@@ -78,6 +78,11 @@ def parse():
                          "upload, three step times at C2, so fewer than that starves the consumer whatever the worker count)")
     ap.add_argument("--relbatch-threads", type=int, default=2, help="--fresh-batches: threads inside one relation-batch build")
     ap.add_argument("--pool", type=int, default=0, help="--fresh-batches: graphs in the per-rank item pool (default 4 batches)")
+    ap.add_argument("--prewarm-seconds", type=float, default=20.0,
+                    help="untimed device pre-warm BEFORE the --warmup steps: windows of 5 training steps until two consecutive windows "
+                         "agree within 1.5 %% or this many seconds have passed (0 = off).  A box that has been idle runs its first "
+                         "minute 5-20 %% slow (measured: four back-to-back runs of this bench on a fresh box 74.7 / 67.5 / 64.5 / 61.7 ms per "
+                         "step); on a warm box this costs two windows")
     ap.add_argument("--dry-launch", action="store_true",
                     help="only check the rank launch / rendezvous (gloo, no GPU): every rank prints its rank and exits")
     return ap.parse_args()
@@ -506,6 +511,23 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    prewarm_steps = 0
+    if a.prewarm_seconds > 0:
+        t_begin, prev = time.perf_counter(), None
+        while True:
+            t_w = time.perf_counter()
+            for _ in range(5):
+                trainer.step(next_batch(), sync=False)
+            torch.cuda.synchronize()
+            tt = torch.tensor([time.perf_counter() - t_w, time.perf_counter() - t_begin], device=dev, dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)       # every rank takes the same decision (the steps hold collectives)
+            w_s, el_s = tt.tolist()
+            prewarm_steps += 5
+            log("prewarm window %.1f ms/step" % (200.0 * w_s))
+            if (prev is not None and abs(w_s - prev) <= 0.015 * prev) or el_s > a.prewarm_seconds:
+                break
+            prev = w_s
     for i in range(a.warmup):
         v = trainer.step(next_batch())
         log("warmup step", i, "loss", v)
@@ -582,6 +604,7 @@ def main():
                           "per_rank_allreduce_exposed_ms_per_step": [round(1e3 * r[1] / a.steps, 3) for r in per_rank],
                           "rank_spread_ms_per_step": round(1e3 * (max(r[0] for r in per_rank) - min(r[0] for r in per_rank)) / a.steps, 3),
                           "loader": loader_info,
+                          "prewarm_steps": prewarm_steps,
                           "loss_first": losses[0], "loss_last": losses[-1]},
                "roofline": roofline, "components": components}
         if world == 1 and not a.no_cpu_baseline:

@@ -1264,7 +1264,7 @@ def test_bench_two_ranks_on_one_gpu_functional():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(GTOS_ONE_DEVICE="1", GTOS_DIST_BACKEND="gloo")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "C1", "--steps", "3", "--warmup", "1",
-                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+                        "--no-cpu-baseline", "--prewarm-seconds", "1"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
@@ -1288,7 +1288,8 @@ def _bench_line(args, env_extra=None, timeout=900):
 def test_bench_strong_scaling_two_ranks_on_one_gpu_functional():
     """`--scaling strong`: the batch is B graphs in TOTAL (generator/train.py:183 divides the batch budget by the world
     size), rank r holds graphs [r*B/N, (r+1)*B/N); per-rank timing and exposed all-reduce time are reported."""
-    d = _bench_line(["--gpus", "2", "--config", "C1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--scaling", "strong"],
+    d = _bench_line(["--gpus", "2", "--config", "C1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--scaling", "strong",
+                     "--prewarm-seconds", "1"],
                     dict(GTOS_ONE_DEVICE="1", GTOS_DIST_BACKEND="gloo"))
     c = d["config"]
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and c["global_batch"] == 8 and c["B_per_gpu"] == 4
@@ -1300,7 +1301,8 @@ def test_bench_strong_scaling_two_ranks_on_one_gpu_functional():
 def test_bench_fresh_batches_loader_in_the_loop():
     """`--fresh-batches`: AMRLoader thunks -> Prefetcher workers (C++ relation batch, tries, index; upload on a copy stream)
     -> Trainer.step, a new batch every step."""
-    d = _bench_line(["--config", "C1", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--fresh-batches", "--workers", "2"],
+    d = _bench_line(["--config", "C1", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--fresh-batches", "--workers", "2",
+                     "--prewarm-seconds", "1"],
                     dict(GTOS_BENCH_NO_DETAIL="1"))
     ld = d["config"]["loader"]
     assert ld["workers"] == 2 and ld["host_assembly_s_per_batch"] > 0 and ld["consumer_wait_ms_per_step"] >= 0
