@@ -660,6 +660,34 @@ __global__ void step_control_kernel(int phase, const float* __restrict__ loss, d
     ctl[1] = 0.f;
 }
 
+// All 2-D weights' transposes in ONE launch: the bf16 mirror of the flat parameter buffer holds every weight [out, in]; dX = dY W
+// runs as an NT product on W^T [in, out], which used to cost one ATen transpose-copy launch per weight and step (~60).  desc[m] =
+// {offset of matrix m in the flat buffers (elements), rows, cols}; tile_start[m] = number of 32x32 tiles before matrix m.  The
+// transposed copy sits at the same offset of a second flat buffer.
+__global__ __launch_bounds__(256) void transpose_batch_kernel(int n_mat, const int64_t* __restrict__ desc, const int* __restrict__ tile_start,
+                                                              const bf16_t* __restrict__ src, bf16_t* __restrict__ dst) {
+    __shared__ bf16_t tile[32][33];
+    const int t = blockIdx.x;
+    int lo = 0, hi = n_mat - 1;                      // last m with tile_start[m] <= t
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tile_start[mid] <= t) lo = mid; else hi = mid - 1; }
+    const int64_t off = desc[3 * lo];
+    const int rows = (int)desc[3 * lo + 1], cols = (int)desc[3 * lo + 2];
+    const int tc_n = (cols + 31) / 32, lt = t - tile_start[lo];
+    const int r0 = (lt / tc_n) * 32, c0 = (lt % tc_n) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8 threads
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, c = c0 + tx;
+        if (r < rows && c < cols) tile[ty + 8 * k][tx] = src[off + (int64_t)r * cols + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, r = r0 + tx;             // dst [cols, rows]
+        if (r < rows && c < cols) dst[off + (int64_t)c * rows + r] = tile[tx][ty + 8 * k];
+    }
+}
+
 __global__ void cast_bf16_kernel(int64_t n, const float* __restrict__ src, bf16_t* __restrict__ dst) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = f2bf(src[i]);
 }
@@ -905,4 +933,14 @@ extern "C" int gtos_cast_f32_to_bf16(int64_t n, const float* src, void* dst, voi
     return 0;
 }
 
-extern "C" int gtos_abi_version(void) { return 11; }
+extern "C" int gtos_transpose_batch_bf16(int n_mat, const int64_t* desc, const int* tile_start, int total_tiles, const void* src,
+                                         void* dst, void* stream) {
+    if (n_mat <= 0 || total_tiles <= 0) return 0;
+    if (!desc || !tile_start || !src || !dst) return -23;
+    hipLaunchKernelGGL(transpose_batch_kernel, dim3((unsigned)total_tiles), dim3(256), 0, static_cast<hipStream_t>(stream), n_mat, desc,
+                       tile_start, (const bf16_t*)src, (bf16_t*)dst);
+    GTOS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gtos_abi_version(void) { return 12; }

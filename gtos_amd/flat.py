@@ -64,6 +64,21 @@ class FlatParams:
             p.grad = self.grad[o:o + k].view(p.shape)
             if self.mirror is not None:
                 p._gtos_mirror = self.mirror[o:o + k].view(p.shape)
+        # transposed bf16 mirror of every 2-D weight (the operand of dX = dY W as an NT product), refreshed by ONE launch
+        self.mirror_t, self._tr = None, None
+        if self.mirror is not None and self.mirror.dtype == torch.bfloat16 and self.param.is_cuda:
+            mats = [(o, p.shape[0], p.shape[1]) for n, p, o in self.entries if p.dim() == 2]
+            if mats:
+                self.mirror_t = torch.zeros_like(self.mirror)
+                desc = torch.tensor([[o, r, c] for o, r, c in mats], dtype=torch.int64)
+                tiles = [((r + 31) // 32) * ((c + 31) // 32) for _, r, c in mats]
+                starts = [0]
+                for t_ in tiles[:-1]:
+                    starts.append(starts[-1] + t_)
+                self._tr = (len(mats), desc.to(dev), torch.tensor(starts, dtype=torch.int32).to(dev), sum(tiles))
+                for n, p, o in self.entries:
+                    if p.dim() == 2:
+                        p._gtos_mirror_t = self.mirror_t[o:o + p.numel()].view(p.shape[1], p.shape[0])
         self.weight_decay, self.betas, self.eps = weight_decay, betas, eps
         self.steps = 0
         self.sync_mirror()
@@ -77,7 +92,13 @@ class FlatParams:
         self.check_views()
         if self.mirror is not None:
             call("gtos_cast_f32_to_bf16", self.total, ptr(self.param), ptr(self.mirror), stream())
+        self._refresh_transposes()
         _ops.PARAM_EPOCH[0] += 1
+
+    def _refresh_transposes(self):
+        if self._tr is not None:
+            n_mat, desc, starts, total = self._tr
+            call("gtos_transpose_batch_bf16", n_mat, ptr(desc), ptr(starts), total, ptr(self.mirror), ptr(self.mirror_t), stream())
 
     def check_views(self):
         """model.to()/.float() after construction would silently detach parameters from the flat buffers."""
@@ -118,5 +139,6 @@ class FlatParams:
             call("gtos_adam_step", hi - lo, self.param.data_ptr() + lo * es, self.grad.data_ptr() + lo * es,
                  self.m.data_ptr() + lo * es, self.v.data_ptr() + lo * es, float(lr), b1, b2, self.eps, wd,
                  float(gscale), ptr(self.sqnorm), float(max_norm), mir, stream())
+        self._refresh_transposes()
         self.steps += 1
         _ops.PARAM_EPOCH[0] += 1

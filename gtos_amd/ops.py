@@ -184,6 +184,18 @@ def weight_t(param, w, rows=None):
     """Contiguous transpose of the compute-dtype weight ``w`` derived from ``param`` (optionally its row block), cached
     ON the parameter object until the parameters change.  dX = dY W then runs as dY (W^T)^T through the all-DMA
     forward GEMM kernel instead of the slower transposing NN variant."""
+    mt = getattr(param, "_gtos_mirror_t", None)
+    if mt is not None and w.dtype == mt.dtype and getattr(param, "_gtos_mirror", None) is not None:
+        # the flat buffers keep a transposed bf16 mirror of every 2-D weight, refreshed by one launch per optimizer step
+        # (flat.FlatParams): views of it replace the per-weight transpose copies
+        if rows is None:
+            if w.shape == param.shape:
+                return mt
+        elif rows[0] == "cols":                 # transpose of a column block [.., width] of the weight = a row block of the mirror
+            width = w.shape[1]
+            return mt[rows[1] * width:(rows[1] + 1) * width]
+        elif w.shape[0] == rows[1] - rows[0]:   # transpose of a row block = a column block (row stride = out features)
+            return mt[:, rows[0]:rows[1]]
     stamp = (PARAM_EPOCH[0], param._version, param.data_ptr())
     cache = getattr(param, "_gtos_wt", None)
     if cache is None:

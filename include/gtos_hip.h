@@ -225,6 +225,12 @@ int gtos_adam_step(int64_t n, float* p, const float* g, float* m, float* v, floa
                    float eps, float weight_decay, float gscale, const float* sqnorm, float max_norm,
                    void* bf16_mirror, void* stream);
 int gtos_cast_f32_to_bf16(int64_t n, const float* src, void* dst, void* stream);
+/* Transposes of all 2-D bf16 weights of a flat buffer in one launch (the operands of dX = dY W as NT products; the reference gets
+ * them from autograd's mm backward, generator/graph_transformer.py:106-122 etc.).  desc (device, int64 [n_mat,3]) = {offset in
+ * elements, rows, cols} of every matrix in src; tile_start (device, int32 [n_mat]) = 32x32 tiles before matrix m; the [cols,rows]
+ * transpose of matrix m is written at the same offset of dst. */
+int gtos_transpose_batch_bf16(int n_mat, const int64_t* desc, const int* tile_start, int total_tiles, const void* src, void* dst,
+                              void* stream);
 
 /* The abnormal-loss rule and the learning-rate schedule of the training loop (generator/train.py:81-83,142-148) decided ON
  * THE DEVICE, so no host read of the loss sits between forward and backward.  loss: fp32 scalar; state: double[3] =

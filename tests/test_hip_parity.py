@@ -669,6 +669,20 @@ def test_trainer_two_steps_reduce_loss_and_keep_mirror_in_sync():
     assert all(l is not None and np.isfinite(l) for l in losses)
     assert losses[-1] < losses[0]
     assert float((tr.flat.param - before).abs().max()) > 0
+    # the bf16 mirror and its transposed twin (one batched launch per optimizer step) track the fp32 masters
+    n2 = 0
+    for name, p, o in tr.flat.entries:
+        assert torch.equal(p._gtos_mirror, p.detach().to(torch.bfloat16)), name
+        if p.dim() == 2:
+            assert torch.equal(p._gtos_mirror_t, p._gtos_mirror.t()), name
+            n2 += 1
+    assert n2 > 50
+    from gtos_amd import ops
+    lin = m.graph_encoder.layers[0].self_attn
+    wbf = ops.compute_weight(lin.in_proj_weight, torch.bfloat16)
+    d_ = lin.embed_dim
+    assert ops.weight_t(lin.in_proj_weight, wbf).data_ptr() == lin.in_proj_weight._gtos_mirror_t.data_ptr()
+    assert torch.equal(ops.weight_t(lin.in_proj_weight, wbf[d_:3 * d_], (d_, 3 * d_)), wbf[d_:3 * d_].t())
     torch.testing.assert_close(tr.flat.mirror.float(), tr.flat.param, rtol=1e-2, atol=1e-3)
     assert float(tr.flat.grad.abs().max()) == 0.0
 
