@@ -584,7 +584,6 @@ class Prefetcher(object):
     def close(self):
         """Stop the workers and release everything in flight.  Safe to call more than once; joins the helper threads so that no
         thread of this object can still be inside a device call when the interpreter (and the HIP runtime) shuts down."""
-        import queue
         import threading
         with self._cv:
             already = self._stop
@@ -608,12 +607,10 @@ class Prefetcher(object):
                 if t is not me and t.is_alive():
                     t.join(timeout=2.0)
         if procs:
+            # no draining: a worker terminated in the middle of a put leaves a PARTIAL message in the pipe, and a get on it blocks
+            # forever inside recv (round 3: bench.py --fresh-batches --workers 2 hung in close()).  Results nobody will take die
+            # with the queue; their shared-memory segments go with the workers' file descriptors.
             for q_ in (self._resq, self._jobq):
-                try:
-                    while True:                      # results nobody will take: drop them (their shared memory with them)
-                        q_.get_nowait()
-                except (queue.Empty, OSError, ValueError, EOFError):
-                    pass
                 try:
                     q_.close()
                     q_.cancel_join_thread()
