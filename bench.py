@@ -538,6 +538,8 @@ def main():
     trainer.comm_exposed_ms()
     wait_s[0] = 0.0
     n_asm0 = len(asm_times) if feed is not None else 0
+    torch.cuda.reset_peak_memory_stats(dev)
+    retries0 = torch.cuda.memory_stats(dev).get("num_alloc_retries", 0)
     t0 = time.perf_counter()
     pend = []
     for _ in range(a.steps):
@@ -547,6 +549,11 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     losses = [p_.value() for p_ in pend]
+    ms_ = torch.cuda.memory_stats(dev)
+    # allocator view of the timed region: a retry = hipMalloc failed, the cache was flushed (device-wide sync) and the request repeated
+    memory_info = {"peak_allocated_gb": round(ms_.get("allocated_bytes.all.peak", 0) / 2 ** 30, 1),
+                   "peak_reserved_gb": round(ms_.get("reserved_bytes.all.peak", 0) / 2 ** 30, 1),
+                   "alloc_retries_in_timed_region": int(ms_.get("num_alloc_retries", 0) - retries0)}
     my_elapsed = elapsed
     if feed is not None:
         done = asm_times[n_asm0:] or asm_times
@@ -604,7 +611,7 @@ def main():
                           "per_rank_allreduce_exposed_ms_per_step": [round(1e3 * r[1] / a.steps, 3) for r in per_rank],
                           "rank_spread_ms_per_step": round(1e3 * (max(r[0] for r in per_rank) - min(r[0] for r in per_rank)) / a.steps, 3),
                           "loader": loader_info,
-                          "prewarm_steps": prewarm_steps,
+                          "prewarm_steps": prewarm_steps, "device_memory": memory_info,
                           "loss_first": losses[0], "loss_last": losses[-1]},
                "roofline": roofline, "components": components}
         if world == 1 and not a.no_cpu_baseline:

@@ -553,6 +553,148 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(int n_chunks, const int* _
     }
 }
 
+// Streaming variant (round 3).  The chunk list is a CSR: chunks in node order, their rows consecutive in `rows`.  seg_sum_kernel
+// gives a wave one CHUNK at a time, so a wave of one- and two-row chunks (most trie nodes) has 1.5-3 KB in flight and the kernel
+// sits at 4.4 TB/s.  Here a wave owns a contiguous RANGE of chunks holding about the same number of rows as every other wave's
+// (wave_off, built with the trie) and streams through its rows UN at a time regardless of the chunk boundaries: the loads of
+// a group never wait for a chunk record, and every wave keeps UN rows in flight.  The sums are flushed where a chunk ends (a
+// wave-uniform test on the rows left in the chunk; chunk records and row ids arrive 64 at a time, one block ahead).  A row of
+// W = SLABS * 512 + (HALF ? 256 : 0) channels: a lane owns 8 channels of every full slab and 4 of the half slab, so W = 768 keeps
+// all 64 lanes loading (the slab version idles half of them on its second slab).
+// (separate const __restrict__ parameters: what lets hipcc read the wave-uniform chunk records with s_load)
+struct SegStreamArgs {
+    int n_chunks, total_rows, n_waves;
+    const int *rows, *chunk_node, *chunk_start, *chunk_cnt, *chunk_slot, *wave_off;
+    const bf16_t* src;
+    int64_t ld_src;
+    bf16_t* dst;
+    int64_t ld_dst;
+    float* heavy;
+};
+
+template <int SLABS, bool HALF>
+__global__ __launch_bounds__(256) void seg_sum_stream_kernel(int n_chunks, int total_rows, int n_waves, const int* __restrict__ rows_,
+                                                             const int* __restrict__ chunk_node_, const int* __restrict__ chunk_start_,
+                                                             const int* __restrict__ chunk_cnt_, const int* __restrict__ chunk_slot_,
+                                                             const int* __restrict__ wave_off_, const bf16_t* __restrict__ src_,
+                                                             int64_t ld_src, bf16_t* __restrict__ dst_, int64_t ld_dst,
+                                                             float* __restrict__ heavy_) {
+    struct { int n_chunks, total_rows, n_waves; const int* __restrict__ rows; const int* __restrict__ chunk_node;
+             const int* __restrict__ chunk_start; const int* __restrict__ chunk_cnt; const int* __restrict__ chunk_slot;
+             const int* __restrict__ wave_off; const bf16_t* __restrict__ src; int64_t ld_src; bf16_t* __restrict__ dst; int64_t ld_dst;
+             float* __restrict__ heavy; } a = {n_chunks, total_rows, n_waves, rows_, chunk_node_, chunk_start_, chunk_cnt_, chunk_slot_,
+                                               wave_off_, src_, ld_src, dst_, ld_dst, heavy_};
+    constexpr int W = SLABS * 512 + (HALF ? 256 : 0);
+    constexpr int UN = W <= 768 ? 8 : 4;
+    constexpr int NF = SLABS > 0 ? SLABS : 1;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (w >= a.n_waves) return;
+    int c = a.wave_off[w];
+    const int c1 = a.wave_off[w + 1];
+    if (c >= c1) return;
+    int p = a.chunk_start[c];
+    const int p1 = c1 < a.n_chunks ? a.chunk_start[c1] : a.total_rows;
+    auto ids_at = [&](int base) {                    // (clamped, unconditional: a load under a lane mask makes hipcc drain vmcnt at the join)
+        const int q = base + lane;
+        return a.rows[q < a.total_rows ? q : a.total_rows - 1];
+    };
+    int pb = p;
+    int idC = ids_at(pb);
+    int idN = ids_at(pb + 64);
+    float accF[NF][8], accH[4];
+#pragma unroll
+    for (int sl = 0; sl < NF; ++sl)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) accF[sl][e] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) accH[e] = 0.f;
+    // chunk records through the SCALAR cache (c is wave-uniform), one chunk ahead: their waits are lgkmcnt waits.  Read as vector
+    // loads a block ahead they shared vmcnt with the flushes' stores, and every wait for a record became a wait for those.
+    int rem = 0, node = 0, slot = -1, node_n, cnt_n, slot_n;
+    auto load_next = [&](int cn) {
+        cn = cn < a.n_chunks ? cn : a.n_chunks - 1;
+        node_n = a.chunk_node[cn]; cnt_n = a.chunk_cnt[cn]; slot_n = a.chunk_slot ? a.chunk_slot[cn] : -1;
+    };
+    auto fetch_chunk = [&]() {                       // make chunk c (c < c1) current, start the loads of the record of chunk c + 1
+        node = node_n; rem = cnt_n; slot = slot_n;
+        load_next(c + 1);
+    };
+    load_next(c);
+    auto flush = [&]() {
+        if (slot < 0) {
+            bf16_t* out = a.dst + (int64_t)node * a.ld_dst;
+#pragma unroll
+            for (int sl = 0; sl < SLABS; ++sl) Vec8<bf16_t>::store(out + sl * 512 + lane * 8, accF[sl]);
+            if (HALF) *reinterpret_cast<uint2*>(out + SLABS * 512 + lane * 4) = make_uint2(pack_bf(accH[0], accH[1]), pack_bf(accH[2], accH[3]));
+        } else {
+            float* out = a.heavy + (int64_t)slot * W;
+#pragma unroll
+            for (int sl = 0; sl < SLABS; ++sl)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) atomicAdd(out + sl * 512 + lane * 8 + e, accF[sl][e]);
+            if (HALF) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) atomicAdd(out + SLABS * 512 + lane * 4 + e, accH[e]);
+            }
+        }
+#pragma unroll
+        for (int sl = 0; sl < NF; ++sl)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) accF[sl][e] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) accH[e] = 0.f;
+    };
+    fetch_chunk();
+    while (rem == 0) {                               // a node without rows still gets its (zero) result
+        flush();
+        if (++c >= c1) return;
+        fetch_chunk();
+    }
+    for (;; pb += 64) {                              // one block of 64 row ids per outer iteration, the next one in flight
+      const int pe = pb + 64 < p1 ? pb + 64 : p1;
+      for (; p < pe; p += UN) {
+        uint4 rawF[UN][NF];
+        uint2 rawH[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const bool ok = p + u < p1;                                   // wave-uniform
+            const int64_t r = __builtin_amdgcn_readlane(idC, (p - pb + u) & 63);
+            const bf16_t* rp = a.src + r * a.ld_src;
+#pragma unroll
+            for (int sl = 0; sl < SLABS; ++sl)
+                rawF[u][sl] = ok ? *reinterpret_cast<const uint4*>(rp + sl * 512 + lane * 8) : make_uint4(0, 0, 0, 0);
+            if (HALF) rawH[u] = ok ? *reinterpret_cast<const uint2*>(rp + SLABS * 512 + lane * 4) : make_uint2(0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            if (p + u < p1) {
+#pragma unroll
+                for (int sl = 0; sl < SLABS; ++sl) {
+                    const uint4 v = rawF[u][sl];
+                    accF[sl][0] += lo_bf(v.x); accF[sl][1] += hi_bf(v.x); accF[sl][2] += lo_bf(v.y); accF[sl][3] += hi_bf(v.y);
+                    accF[sl][4] += lo_bf(v.z); accF[sl][5] += hi_bf(v.z); accF[sl][6] += lo_bf(v.w); accF[sl][7] += hi_bf(v.w);
+                }
+                if (HALF) {
+                    const uint2 v = rawH[u];
+                    accH[0] += lo_bf(v.x); accH[1] += hi_bf(v.x); accH[2] += lo_bf(v.y); accH[3] += hi_bf(v.y);
+                }
+                if (--rem == 0) {
+                    do {
+                        flush();
+                        if (++c >= c1) break;
+                        fetch_chunk();
+                    } while (rem == 0);
+                }
+            }
+        }
+      }
+      if (p >= p1) break;
+      idC = idN;
+      idN = ids_at(pb + 128);
+    }
+}
+
 // contiguous variant: segment s sums the consecutive rows ranges[2s] .. ranges[2s+1]-1 (the children of a trie node) into
 // dst row s; an empty range writes zeros
 template <int SLABS>
@@ -859,6 +1001,35 @@ extern "C" int gtos_segment_sum_rows(int n_chunks, const int* rows, const int* c
     return 0;
 }
 
+// Streaming form of gtos_segment_sum_rows for a CSR chunk list (chunks in node order, rows consecutive): wave_off[n_waves + 1] are
+// chunk indices cutting the list into ranges of about equal row counts (pathtrie.TrieSide.wave_off).  width in {256, 512, ..., 1536}.
+extern "C" int gtos_segment_sum_stream(int n_chunks, int total_rows, const int* rows, const int* chunk_node, const int* chunk_start,
+                                       const int* chunk_cnt, const int* chunk_slot, const int* wave_off, int n_waves, const void* src,
+                                       int64_t ld_src, int width, void* dst, int64_t ld_dst, float* heavy, void* stream) {
+    if (n_chunks <= 0 || n_waves <= 0) return 0;
+    if (width <= 0 || width % 256 || width > 1536 || ld_src % 8 || ld_dst % 8 || (uintptr_t)src % 16 || (uintptr_t)dst % 16) return -24;
+    if (!rows || !chunk_node || !chunk_start || !chunk_cnt || !wave_off || !src || !dst || (chunk_slot && !heavy) || total_rows <= 0) return -23;
+    SegStreamArgs a;
+    a.n_chunks = n_chunks; a.total_rows = total_rows; a.n_waves = n_waves;
+    a.rows = rows; a.chunk_node = chunk_node; a.chunk_start = chunk_start; a.chunk_cnt = chunk_cnt; a.chunk_slot = chunk_slot;
+    a.wave_off = wave_off; a.src = (const bf16_t*)src; a.ld_src = ld_src; a.dst = (bf16_t*)dst; a.ld_dst = ld_dst; a.heavy = heavy;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)((n_waves + 3) / 4)), block(256);
+#define GTOS_SEGS(S, H) hipLaunchKernelGGL((seg_sum_stream_kernel<S, H>), grid, block, 0, s, a.n_chunks, a.total_rows, a.n_waves, a.rows, \
+        a.chunk_node, a.chunk_start, a.chunk_cnt, a.chunk_slot, a.wave_off, a.src, a.ld_src, a.dst, a.ld_dst, a.heavy)
+    switch (width / 256) {
+        case 1: GTOS_SEGS(0, true); break;
+        case 2: GTOS_SEGS(1, false); break;
+        case 3: GTOS_SEGS(1, true); break;
+        case 4: GTOS_SEGS(2, false); break;
+        case 5: GTOS_SEGS(2, true); break;
+        default: GTOS_SEGS(3, false); break;
+    }
+#undef GTOS_SEGS
+    GTOS_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int gtos_segment_sum_finish(int n_heavy, const int* heavy_node, const float* heavy, int width, void* dst, int64_t ld_dst,
                                        void* stream) {
     if (n_heavy <= 0) return 0;
@@ -943,4 +1114,4 @@ extern "C" int gtos_transpose_batch_bf16(int n_mat, const int64_t* desc, const i
     return 0;
 }
 
-extern "C" int gtos_abi_version(void) { return 12; }
+extern "C" int gtos_abi_version(void) { return 13; }

@@ -63,9 +63,13 @@ extern "C" gtos_relindex* gtos_relindex_build(int n, int B, int64_t R, const int
                     h->pair_sorted[cur[relation[p]]++] = (int32_t)p;
                 }
     }
-    struct Chunk { int32_t type, start, cnt, slot; int64_t key; };
+    struct Chunk { int32_t type, start, cnt, slot; int64_t key; int32_t x_first, x_last; };
     std::vector<Chunk> chunks;
     chunks.reserve(R + P / chunk);
+    auto xcd_of = [&](int64_t pair) {                                        // the attention kernels' graph -> XCD map
+        const int64_t gb = pair % B;
+        return (int32_t)((B % 8 == 0) ? gb / (B / 8) : gb % 8);
+    };
     for (int64_t t = 0; t < R; ++t) {
         const int64_t lo = count[t], hi = count[t + 1];
         if (hi - lo == 1) continue;                                          // singleton: written by the attention backward
@@ -84,15 +88,46 @@ extern "C" gtos_relindex* gtos_relindex_build(int n, int B, int64_t R, const int
             const int64_t s = lo + c * csz;
             const int64_t cnt = std::max<int64_t>(0, std::min<int64_t>(csz, hi - s));
             const int64_t first = h->pair_sorted[std::min<int64_t>(s, P - 1)];
+            const int64_t lastp = h->pair_sorted[std::min<int64_t>(s + std::max<int64_t>(cnt, 1) - 1, P - 1)];
             const int64_t gb = first % B, j = first / ((int64_t)n * B);
-            const int64_t xcd = (B % 8 == 0) ? gb / (B / 8) : gb % 8;       // the attention kernels' graph -> XCD map
-            // GTOS_HEAVY_FIRST=1: inside an XCD the chunks of heavy types come first (a wave walks a 128-pair chunk in ~32 dependent
-            // rounds; at the front of the list every heavy chunk lands on a different wave of the first round)
-            // (round-3 A/B at C2: 62.36 / 62.31 ms per step with, 62.35 / 62.05 without -- the long chunks are NOT what bounds the
-            // kernel; opt-in only)
-            static const bool heavy_first = getenv("GTOS_HEAVY_FIRST") && getenv("GTOS_HEAVY_FIRST")[0] == '1';
-            const int64_t late = (heavy_first && slot < 0) ? 1 : 0;
-            chunks.push_back({(int32_t)t, (int32_t)s, (int32_t)cnt, slot, (xcd << 41) | (late << 40) | (gb << 20) | j});
+            chunks.push_back({(int32_t)t, (int32_t)s, (int32_t)cnt, slot, (gb << 20) | j, xcd_of(first), xcd_of(lastp)});
+        }
+    }
+    // Which XCD walks a chunk, and when.  The bank-gradient kernel gives every wave a chain of chunks and a chunk costs about
+    // ceil(cnt / 4) + 1 dependent load rounds, so the launch lasts as long as the longest chain on the busiest XCD.  Round 2
+    // sent every chunk to the XCD of its FIRST pair's graph; inside a type the pairs are graph-major, so a type shared by several
+    // graphs always went to the lowest one's XCD: XCD 0 got 2.6x the chunks of XCD 7 (C2: 11,638 vs 4,517) and 3x the rounds,
+    // and a wave could meet two 128-pair chunks (chains of 122 rounds where the mean is 31).  Now: a chunk whose pairs all live
+    // on one XCD stays there (its q/k rows are in that XCD's L2); a chunk that spans XCDs has no home and goes to the XCD with the
+    // fewest rounds so far, the longest first; inside an XCD the long chunks (> 8 pairs) come first, longest first, so each
+    // starts a different wave's chain, and the short ones follow in (graph, key row) order as before.  GTOS_BANK_BALANCE=0: round 2's order.
+    static const bool balance = !(getenv("GTOS_BANK_BALANCE") && getenv("GTOS_BANK_BALANCE")[0] == '0');
+    static const bool heavy_first = getenv("GTOS_HEAVY_FIRST") && getenv("GTOS_HEAVY_FIRST")[0] == '1';
+    auto cost = [](const Chunk& c) { return (int64_t)(c.cnt + 3) / 4 + 1; };
+    std::vector<int32_t> home(chunks.size());
+    if (balance) {
+        int64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        std::vector<int32_t> roam;
+        for (size_t c = 0; c < chunks.size(); ++c) {
+            if (chunks[c].x_first == chunks[c].x_last) { home[c] = chunks[c].x_first; load[home[c]] += cost(chunks[c]); }
+            else roam.push_back((int32_t)c);
+        }
+        std::stable_sort(roam.begin(), roam.end(), [&](int32_t a, int32_t b) { return chunks[a].cnt > chunks[b].cnt; });
+        for (int32_t c : roam) {
+            int best = 0;
+            for (int x = 1; x < 8; ++x) if (load[x] < load[best]) best = x;
+            home[c] = best; load[best] += cost(chunks[c]);
+        }
+        for (size_t c = 0; c < chunks.size(); ++c) {
+            const int64_t lng = chunks[c].cnt > 8 ? 0 : 1;                     // long chunks first, longest first
+            const int64_t rank = lng ? chunks[c].key : (int64_t)(0xfffff - std::min<int32_t>(chunks[c].cnt, 0xfffff)) << 20;
+            chunks[c].key = ((int64_t)home[c] << 42) | (lng << 41) | rank;
+        }
+    } else {
+        for (size_t c = 0; c < chunks.size(); ++c) {
+            const int64_t late = (heavy_first && chunks[c].slot < 0) ? 1 : 0;
+            home[c] = chunks[c].x_first;
+            chunks[c].key = ((int64_t)home[c] << 42) | (late << 41) | chunks[c].key;
         }
     }
     std::stable_sort(chunks.begin(), chunks.end(), [](const Chunk& a, const Chunk& b) { return a.key < b.key; });
@@ -102,7 +137,7 @@ extern "C" gtos_relindex* gtos_relindex_build(int n, int B, int64_t R, const int
     for (size_t c = 0; c < nc; ++c) {
         h->chunk_type[c] = chunks[c].type; h->chunk_start[c] = chunks[c].start;
         h->chunk_count[c] = chunks[c].cnt; h->chunk_slot[c] = chunks[c].slot;
-        h->xcd_off[(chunks[c].key >> 41) + 1]++;
+        h->xcd_off[(chunks[c].key >> 42) + 1]++;
     }
     for (int x = 0; x < 8; ++x) h->xcd_off[x + 1] += h->xcd_off[x];
     return h;

@@ -295,10 +295,21 @@ EMBED_GRAD_GEMM = os.environ.get("GTOS_EMBED_GEMM", "1") != "0"
 TRIE_SUM_INDEX = os.environ.get("GTOS_GRU_SUMIDX", "1") != "0"
 
 
+# Segmented sums of the gate gradients by the streaming kernel (a wave per range of ~256 rows) instead of a wave per chunk.
+SEG_STREAM = os.environ.get("GTOS_SEG_STREAM", "1") != "0"
+
+
 def _seg_rows(side, src, width, dst, src2=None, dst2=None):
     """dst[node] = sum of src rows of the node (row lists of the trie side), fp32 accumulation; (src2, dst2): a second
     matrix reduced over the same row lists in the same pass."""
     heavy = torch.zeros((2 if src2 is not None else 1, max(1, side.n_heavy), width), dtype=torch.float32, device=src.device)
+    if SEG_STREAM and src2 is None and width % 256 == 0:
+        with _Timed("segment_sum_rows", detail=True, units=int(side.rows.numel())):
+            call("gtos_segment_sum_stream", side.n_chunks, int(side.rows.numel()), ptr(side.rows), ptr(side.chunk_node), ptr(side.chunk_start),
+                 ptr(side.chunk_cnt), ptr(side.chunk_slot), ptr(side.wave_off), side.n_waves, ptr(src), src.stride(0), width, ptr(dst),
+                 dst.stride(0), ptr(heavy[0]), stream())
+            call("gtos_segment_sum_finish", side.n_heavy, ptr(side.heavy_node), ptr(heavy[0]), width, ptr(dst), dst.stride(0), stream())
+        return
     with _Timed("segment_sum_rows", detail=True, units=int(side.rows.numel()) * (2 if src2 is not None else 1)):
         call("gtos_segment_sum_rows", side.n_chunks, ptr(side.rows), ptr(side.chunk_node), ptr(side.chunk_start), ptr(side.chunk_cnt),
              ptr(side.chunk_slot), ptr(src), ptr(src2), src.stride(0), width, ptr(dst), ptr(dst2), dst.stride(0),

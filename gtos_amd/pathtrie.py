@@ -27,7 +27,10 @@ class TrieSide(object):
     Derived at build time (numpy, on the host) for the backward walk of gtos_amd.gru: ``sum_idx`` [n] -- the row of the
     ``[n + 1 + n_multi, .]`` gradient buffers that holds the SUM over node u's children: the child itself when there is one, row
     n (all zero) for a leaf, row n + 1 + j for the j-th node with several children; ``multi_ranges`` [2 * n_multi] -- the child
-    ranges of those nodes in node order (so level-major); ``multi_level_off`` [L + 1] -- how many of them precede each level."""
+    ranges of those nodes in node order (so level-major); ``multi_level_off`` [L + 1] -- how many of them precede each level.
+    For the streaming segmented sum (gtos_segment_sum_stream): ``wave_off`` [n_waves + 1] -- chunk indices cutting the chunk list
+    (a CSR over ``rows``) into ranges of about ``ROWS_PER_WAVE`` rows."""
+    ROWS_PER_WAVE = 256
 
     def __init__(self, arrays, level_off, multi_level_off=None):
         self.__dict__.update(arrays)
@@ -52,6 +55,14 @@ class TrieSide(object):
             multi_level_off = [int(before[o]) for o in self.level_off]
         self.multi_level_off = list(multi_level_off)
         self.n_multi = self.multi_level_off[-1]
+        if "wave_off" not in arrays:
+            starts = self.chunk_start.cpu().numpy().astype(np.int64)
+            total = int(self.rows.numel())
+            n_waves = max(1, -(-total // self.ROWS_PER_WAVE))
+            off = np.searchsorted(starts, np.arange(n_waves, dtype=np.int64) * self.ROWS_PER_WAVE, side="left")
+            off[0] = 0                   # (chunks without rows in front of the first row belong to the first wave)
+            self.wave_off = torch.from_numpy(np.concatenate([off, [self.n_chunks]]).astype(np.int32))
+        self.n_waves = int(self.wave_off.numel()) - 1
 
     def to(self, device):
         arrays = {k: v.to(device) for k, v in self.__dict__.items() if isinstance(v, torch.Tensor) and not k.startswith("_")}

@@ -169,6 +169,13 @@ int gtos_gru_step_bwd(int rows, int hs, const void* d4_prev, int rows_prev, cons
 int gtos_segment_sum_rows(int n_chunks, const int* rows, const int* chunk_node, const int* chunk_start, const int* chunk_cnt,
                           const int* chunk_slot, const void* src, const void* src2, int64_t ld_src, int width,
                           void* dst, void* dst2, int64_t ld_dst, float* heavy, float* heavy2, void* stream);
+/* _stream: the same reduction for a chunk list that is a CSR (chunks in node order, their rows consecutive in `rows`, as
+ * gtos_pathtrie_build emits them): wave_off[n_waves + 1] are chunk indices that cut the list into ranges of about equal row
+ * counts, one range per 64-lane wave (gtos_amd.pathtrie.TrieSide.wave_off); total_rows = the length of `rows`.
+ * width % 256 == 0, <= 1536. */
+int gtos_segment_sum_stream(int n_chunks, int total_rows, const int* rows, const int* chunk_node, const int* chunk_start,
+                            const int* chunk_cnt, const int* chunk_slot, const int* wave_off, int n_waves, const void* src,
+                            int64_t ld_src, int width, void* dst, int64_t ld_dst, float* heavy, void* stream);
 int gtos_segment_sum_finish(int n_heavy, const int* heavy_node, const float* heavy, int width, void* dst, int64_t ld_dst,
                             void* stream);
 int gtos_segment_sum_ranges(int n_seg, const int* ranges, const void* src, int64_t ld_src, int width, void* dst, int64_t ld_dst,

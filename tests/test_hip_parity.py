@@ -1065,13 +1065,24 @@ def test_segment_sum_kernels():
     batch, _ = synth.make_batch(3, 6, 40, 8)
     trie = build_path_trie(batch["relation_bank"], batch["relation_length"], chunk=16).to(dev())
     assert trie.pf.n_heavy > 0
+    from gtos_amd import gru as gru_mod
     from gtos_amd.gru import _seg_rows
     for side, row_node in ((trie.pf, trie.row_pf), (trie.sf, trie.row_sf)):
         d4 = torch.randn(trie.N, 1024, generator=g).to(dev(), torch.bfloat16)
-        out = torch.empty(side.n_nodes, 768, dtype=torch.bfloat16, device=dev())
-        _seg_rows(side, d4, 768, out)
         want = torch.zeros(side.n_nodes, 768, device=dev()).index_add_(0, row_node.long(), d4[:, :768].float())
-        torch.testing.assert_close(out.float(), want, rtol=1e-2, atol=1e-2 * want.abs().max().item())
+        outs = []
+        for stream_kernel in (True, False):                # a wave per range of rows (default) / a wave per chunk
+            out = torch.empty(side.n_nodes, 768, dtype=torch.bfloat16, device=dev())
+            keep, gru_mod.SEG_STREAM = gru_mod.SEG_STREAM, stream_kernel
+            try:
+                _seg_rows(side, d4, 768, out)
+            finally:
+                gru_mod.SEG_STREAM = keep
+            torch.testing.assert_close(out.float(), want, rtol=1e-2, atol=1e-2 * want.abs().max().item())
+            outs.append(out)
+        light = torch.ones(side.n_nodes, dtype=torch.bool)
+        light[side.heavy_node.cpu().long()] = False        # single-chunk nodes: the same fp32 sum in the same order, one rounding
+        assert torch.equal(outs[0][light.to(dev())], outs[1][light.to(dev())])
         # two sources over the same row lists in one pass
         d4b = torch.randn(trie.N, 1024, generator=g).to(dev(), torch.bfloat16)
         out_a, out_b = torch.empty_like(out), torch.empty_like(out)
@@ -1079,6 +1090,48 @@ def test_segment_sum_kernels():
         want_b = torch.zeros(side.n_nodes, 768, device=dev()).index_add_(0, row_node.long(), d4b[:, :768].float())
         torch.testing.assert_close(out_a.float(), want, rtol=1e-2, atol=1e-2 * want.abs().max().item())
         torch.testing.assert_close(out_b.float(), want_b, rtol=1e-2, atol=1e-2 * want_b.abs().max().item())
+
+
+@pytest.mark.parametrize("W", [256, 512, 768, 1024, 1280, 1536])
+@pytest.mark.parametrize("rows_per_wave", [8, 100, 256])
+def test_segment_sum_stream_kernel_on_a_synthetic_csr(W, rows_per_wave):
+    """gtos_segment_sum_stream against index_add: chunks without rows (in front, in the middle, at the end), one-row chunks, full
+    64-row chunks, multi-chunk (heavy) nodes, wave ranges that start and end anywhere, every supported width."""
+    import numpy as np
+    from gtos_amd._lib import call, ptr, stream
+    rng = np.random.RandomState(W + rows_per_wave)
+    counts = [0, 0] + rng.choice([0, 1, 1, 1, 2, 3, 5, 17, 64, 150, 700], size=400).tolist() + [0, 3, 0, 0]
+    chunk_node, chunk_start, chunk_cnt, chunk_slot, heavy_node = [], [], [], [], []
+    pos = 0
+    for u, n in enumerate(counts):
+        nch = max(1, -(-n // 64))
+        slot = -1
+        if nch > 1:
+            slot = len(heavy_node)
+            heavy_node.append(u)
+        for k in range(nch):
+            chunk_node.append(u); chunk_start.append(pos + 64 * k); chunk_cnt.append(max(0, min(64, n - 64 * k))); chunk_slot.append(slot)
+        pos += n
+    total, n_nodes, n_src = pos, len(counts), pos + 37
+    rows = rng.permutation(n_src)[:total].astype(np.int32)                 # a gather: every source row at most once
+    n_waves = max(1, -(-total // rows_per_wave))
+    off = np.searchsorted(np.asarray(chunk_start), np.arange(n_waves) * rows_per_wave, side="left")
+    off[0] = 0
+    wave_off = np.concatenate([off, [len(chunk_node)]]).astype(np.int32)
+    t = lambda a_: torch.tensor(np.asarray(a_), dtype=torch.int32, device=dev())
+    ld = W + 64
+    src = torch.randn(n_src, ld, generator=torch.Generator().manual_seed(W)).to(dev(), torch.bfloat16)
+    dst = torch.full((n_nodes, W), 3.0, dtype=torch.bfloat16, device=dev())
+    heavy = torch.zeros(max(1, len(heavy_node)), W, dtype=torch.float32, device=dev())
+    rows_t, cn, cs, cc, sl, wo, hn = t(rows), t(chunk_node), t(chunk_start), t(chunk_cnt), t(chunk_slot), t(wave_off), t(heavy_node)
+    call("gtos_segment_sum_stream", len(chunk_node), total, ptr(rows_t), ptr(cn), ptr(cs), ptr(cc), ptr(sl), ptr(wo), n_waves,
+         src.data_ptr() + 2 * 32, ld, W, ptr(dst), W, ptr(heavy), stream())
+    call("gtos_segment_sum_finish", len(heavy_node), ptr(hn), ptr(heavy), W, ptr(dst), W, stream())
+    node_of_pos = np.repeat(np.arange(n_nodes), counts)
+    want = torch.zeros(n_nodes, W, device=dev()).index_add_(0, torch.tensor(node_of_pos, device=dev()), src[rows_t.long(), 32:32 + W].float())
+    torch.testing.assert_close(dst.float(), want, rtol=1e-2, atol=1e-2 * want.abs().max().item())
+    empty = torch.tensor([n == 0 for n in counts], device=dev())
+    assert float(dst[empty].float().abs().max()) == 0.0
 
 
 # ------------------------------------------------------------------------------------------------ fused copy/generate mixture
