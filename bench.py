@@ -278,7 +278,7 @@ def build_roofline(a, cfg, stats, model, trainer, batch, prof, dev, cd, detail=T
                 note="per trie node: gates 4h + state h + dropped copy h written, parent state h gathered, embedding row read")
         hbm_row("gru_step_bwd_rows", "gru_step_bwd_kernel (GRU layer 1)", bytes_per_unit=(4 + 1 + 3 + 2 + 4) * hs * 2,
                 note="per active row: gates 4h + h_prev h read, later step's d(hg) 3h read (MFMA operand), dh read+written, d4 4h written")
-        hbm_row("segment_sum_rows", "seg_sum_kernel (gate-table gradients: rows -> trie nodes)",
+        hbm_row("segment_sum_rows", "seg_sum_stream_kernel (gate-table gradients: rows -> trie nodes)",
                 bytes_per_unit=3 * hs * 2 + 4, note="per row: d(xg) 3h read + row id; + nodes x 3h written (not counted)")
         grows = []
         for key_, evs in gp.items():
