@@ -77,6 +77,9 @@ def parse():
                     help="--fresh-batches: batches in flight (default 2 per worker: a batch spends ~0.2 s between job hand-out and "
                          "upload, three step times at C2, so fewer than that starves the consumer whatever the worker count)")
     ap.add_argument("--relbatch-threads", type=int, default=2, help="--fresh-batches: threads inside one relation-batch build")
+    ap.add_argument("--device-tries", action="store_true",
+                    help="--fresh-batches: the workers build the relation index only; the path tries are built on the GPU with torch ops on "
+                         "the loader's copy stream (gtos_amd.pathtrie_device)")
     ap.add_argument("--pool", type=int, default=0, help="--fresh-batches: graphs in the per-rank item pool (default 4 batches)")
     ap.add_argument("--prewarm-seconds", type=float, default=20.0,
                     help="untimed device pre-warm BEFORE the --warmup steps: windows of 5 training steps until two consecutive windows "
@@ -462,7 +465,8 @@ def main():
         items, graphs = synth.make_amr_items(a.config, pool_n, first_graph=rank * pool_n, vocabs=vocabs_s)
         unit = data_mod.AMRLoader.size_of(items[0])                       # every item of a config has the same size
         loader = data_mod.AMRLoader(vocabs_s, items, batch_size=B_rank * unit - unit // 2, for_train=True,
-                                    rng=random.Random(19940117 + rank), n_threads=a.relbatch_threads, graphs=graphs)
+                                    rng=random.Random(19940117 + rank), n_threads=a.relbatch_threads, graphs=graphs,
+                                    index_prep="device" if a.device_tries else True)
         a.depth = a.depth or 2 * a.workers
         asm_times = []
 
@@ -476,9 +480,11 @@ def main():
             while True:                                                   # epochs over the pool: reshuffled, paths re-drawn
                 yield from loader.jobs()
         if a.loader == "processes":
-            feed = data_mod.Prefetcher(jobs(), depth=a.depth, workers=a.workers, device=dev, processes=True, runner=timed_run)
+            feed = data_mod.Prefetcher(jobs(), depth=a.depth, workers=a.workers, device=dev, processes=True, runner=timed_run,
+                                       device_tries=a.device_tries)
         else:
-            feed = data_mod.Prefetcher((lambda j=j: timed_run(j) for j in jobs()), depth=a.depth, workers=a.workers, device=dev)
+            feed = data_mod.Prefetcher((lambda j=j: timed_run(j) for j in jobs()), depth=a.depth, workers=a.workers, device=dev,
+                                       device_tries=a.device_tries)
         batch = next(feed)
         stats = {"n": int(batch["concept"].shape[0]), "B": int(batch["concept"].shape[1]), "T": int(batch["token_in"].shape[0]),
                  "R": int(batch["relation_bank"].shape[1]),
@@ -486,6 +492,7 @@ def main():
         assert stats["B"] == B_rank, stats
         asm_times.append(batch.pop("_assembly_s"))
         loader_info = {"workers": a.workers, "kind": a.loader, "depth": a.depth, "relbatch_threads": a.relbatch_threads,
+                       "tries": "device (torch ops on the copy stream)" if a.device_tries else "host (worker)",
                        "pool_graphs_per_rank": pool_n, "device_memory_free_gb_at_start": round(free_b / 2 ** 30, 1),
                        "allocator": "default" if os.environ.get("GTOS_BENCH_NO_ROUNDUP") else "roundup_power2_divisions:16"}
     else:

@@ -12,7 +12,10 @@
 //   * the node of every packed row (sequence s, position t) in both tries,
 //   * the rows of every node (CSR), cut into chunks of <= `chunk` rows for the segmented gradient reduction.
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <thread>
@@ -196,6 +199,15 @@ struct gtos_pathtrie {
 
 extern "C" gtos_pathtrie* gtos_pathtrie_build(int L, int64_t R, const int64_t* bank, const int64_t* length, int chunk) {
     if (L <= 0 || L > 64 || R <= 0 || !bank || !length || chunk <= 0 || chunk > 64 || R > 0x7fffffffLL / L) return nullptr;
+    // GTOS_TRIE_TIMING=1: phase times of this call on stderr (unpack, sort, packed order, tries, row lists)
+    static const bool timing = getenv("GTOS_TRIE_TIMING") && getenv("GTOS_TRIE_TIMING")[0] == '1';
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "pathtrie %-12s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     Seqs fw, bw;
     fw.L = bw.L = L;
     fw.R = bw.R = R;
@@ -223,12 +235,14 @@ extern "C" gtos_pathtrie* gtos_pathtrie_build(int L, int64_t R, const int64_t* b
     h->L = maxlen;
     h->R = R;
     h->N = N;
+    lap("unpack");
     std::vector<int32_t> ord_f, ord_b;
     {
         std::thread tb([&] { ord_b = lex_order(bw); });
         ord_f = lex_order(fw);
         tb.join();
     }
+    lap("sort");
     // packed order: length descending, then lexicographic = counting sort by length over the sequences in lexicographic order
     h->seq_order.resize(R);
     {
@@ -249,14 +263,17 @@ extern "C" gtos_pathtrie* gtos_pathtrie_build(int L, int64_t R, const int64_t* b
     for (int t = 0; t < maxlen; ++t) offs[t + 1] = offs[t] + h->batch_sizes[t];
     h->row_pf.resize(N);
     h->row_sf.resize(N);
+    lap("packed order");
     {
         std::thread tb([&] { build_trie(bw, ord_b, h->seq_pos, offs, true, h->sf, h->row_sf); });
         build_trie(fw, ord_f, h->seq_pos, offs, false, h->pf, h->row_pf);
         tb.join();
     }
+    lap("tries");
     std::thread tr([&] { build_rows(h->row_sf, h->sf.n_nodes, chunk, h->sf); });
     build_rows(h->row_pf, h->pf.n_nodes, chunk, h->pf);
     tr.join();
+    lap("row lists");
     // level offsets beyond the longest sequence collapse
     h->pf.level_off.resize(maxlen + 1);
     h->sf.level_off.resize(maxlen + 1);

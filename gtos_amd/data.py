@@ -24,14 +24,30 @@ def _index_prep(batch, on):
     """Host-side index preparation of the bf16 training path (gtos_amd.pathtrie, gtos_amd.relindex): the path tries of the
     trie-evaluated RelationEncoder and the relation index of the factored attention operand.  ``on=False`` (fp32 / CPU use,
     ``GTOS_GRU_TRIE=0``) skips it; a bank the trie builder rejects (a path longer than 64 labels -- the translator flavour
-    puts no cap on path length --, an empty path) leaves the batch without ``relation_trie`` and RelationEncoder takes its per-row path."""
+    puts no cap on path length --, an empty path) leaves the batch without ``relation_trie`` and RelationEncoder takes its per-row path.
+    ``on="device"``: only the relation index is built here; the tries are left to the consumer's device (``Prefetcher(device_tries=
+    True)`` builds them with torch ops on its copy stream, gtos_amd.pathtrie_device) -- the tries are the larger half of the
+    host time of a batch (0.19 of 0.35 s per C2 batch on the development container)."""
     if not on:
         return batch
-    try:
-        batch['relation_trie'] = build_path_trie(batch['relation_bank'], batch['relation_length'])
-    except ValueError:
-        pass                  # no 'relation_trie' key: RelationEncoder.forward falls back to one row per (path, position)
+    if on != "device":
+        try:
+            batch['relation_trie'] = build_path_trie(batch['relation_bank'], batch['relation_length'])
+        except ValueError:
+            pass              # no 'relation_trie' key: RelationEncoder.forward falls back to one row per (path, position)
     return attach_relation_index(batch)
+
+
+def attach_device_tries(batch):
+    """``batch['relation_trie']`` built on the device the bank lives on (gtos_amd.pathtrie_device), for a batch that came without
+    one; a bank outside that builder's case (paths longer than 8 labels, label ids >= 255) is left alone."""
+    if 'relation_trie' not in batch and 'relation_bank' in batch:
+        from .pathtrie_device import build_path_trie_device
+        try:
+            batch['relation_trie'] = build_path_trie_device(batch['relation_bank'], batch['relation_length'])
+        except ValueError:
+            pass
+    return batch
 
 
 def batchify_dependency(trees, vocabs, n_threads=0, unk_rate=0., rng=None, replay_reference_draws=False, index_prep=True):
@@ -447,9 +463,10 @@ class Prefetcher(object):
     * Order of the batches is the iterable's order.  ``close()`` (also on garbage collection / context exit) stops the
       workers; batches already assembled are dropped."""
 
-    def __init__(self, batches, depth=2, workers=1, device=None, processes=False, runner=None):
+    def __init__(self, batches, depth=2, workers=1, device=None, processes=False, runner=None, device_tries=False):
         import threading
         self._it = iter(batches)
+        self._device_tries = device_tries
         self._out = {}
         self._cv = threading.Condition()          # ONE lock: depth reservation, source advance and hand-over are atomic
         self._next_in, self._next_out, self._done, self._err, self._stop = 0, 0, False, None, False
@@ -643,11 +660,30 @@ class Prefetcher(object):
             batch, ev, flat = self._out.pop(self._next_out)
             self._next_out += 1
             self._cv.notify_all()
+        extra = None
+        if self._device_tries:
+            # The tries of a batch that came without them, built HERE, by the consumer's thread, as torch ops on the copy stream
+            # (behind the batch's upload, beside the previous step's kernels).  Built on the upload thread they cost 0.2 s per
+            # batch: ~200 small torch calls, each waiting for the interpreter lock the training loop holds (round 3, C2,
+            # 2 worker processes: 230 ms per step).
+            b0 = batch[0] if isinstance(batch, tuple) else batch
+            if 'relation_trie' not in b0:
+                if self._copy_stream is not None:
+                    with torch.cuda.stream(self._copy_stream):
+                        attach_device_tries(b0)
+                        ev = torch.cuda.Event()
+                        ev.record(self._copy_stream)
+                else:
+                    attach_device_tries(b0)
+                extra = b0.get('relation_trie')
         if ev is not None:
             cur = torch.cuda.current_stream(self._device)
             cur.wait_event(ev)
             if flat is not None:
                 flat.record_stream(cur)              # one storage behind every tensor of the batch
+                for t in _device_tensors(extra):     # (device-built tries are not views of it)
+                    if t.is_cuda:
+                        t.record_stream(cur)
             else:
                 for t in _device_tensors(batch):
                     if t.is_cuda:

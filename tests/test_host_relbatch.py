@@ -435,3 +435,38 @@ def test_prefetcher_process_workers_give_the_same_batches_in_order(tmp_path):
     dl = data.DependencyLoader(None, [(["a"], [0], ["x"], ["y"])] * 4, batch_size=2, for_train=False)
     with pytest.raises(RuntimeError, match="loader worker failed"):          # vocabs=None: the worker raises, the consumer sees it
         list(data.Prefetcher(dl.jobs(), depth=2, workers=1, processes=True, runner=dl.run_job))
+
+
+def test_prefetcher_builds_the_tries_itself_when_the_loader_leaves_them_out(tmp_path):
+    """index_prep="device": the loader (threads or worker processes) ships the relation index only, Prefetcher(device_tries=True)
+    adds the tries with the torch-op builder (on the consumer's device; here the CPU) -- the same tries the host builder gives."""
+    import json
+    import random
+    from conftest import GOLDEN
+    from gtos_amd import data
+    from test_pathtrie import _same_object
+    meta = json.load(open(os.path.join(GOLDEN, "host_amr_smatch_items.json")))
+    vocabs = _amr_vocabs(tmp_path, meta["relation_vocab"])
+    items = [dict(it, token=["a"] * (1 + k % 3)) for k, it in enumerate(meta["items"] * 3)]
+    unit = data.AMRLoader.size_of(items[0])
+
+    def loader(prep):
+        return data.AMRLoader(vocabs, items, batch_size=2 * unit, for_train=True, rng=random.Random(11), index_prep=prep)
+    want = [f() for f in loader(True).thunks()]
+    bare = [f() for f in loader("device").thunks()]
+    assert all("relation_trie" not in b and "relation_index" in b for b in bare)
+    ld = loader("device")
+    with data.Prefetcher(ld.jobs(), depth=3, workers=2, processes=True, runner=ld.run_job, device_tries=True) as pf:
+        got_p = list(pf)
+    ld = loader("device")
+    with data.Prefetcher(ld.thunks(), depth=2, workers=2, device_tries=True) as pf:
+        got_t = list(pf)
+    assert len(got_p) == len(got_t) == len(want) >= 3
+    for a, b, c in zip(want, got_p, got_t):
+        assert torch.equal(a["relation"], b["relation"]) and torch.equal(a["relation"], c["relation"])
+        assert _same_object(a["relation_trie"], b["relation_trie"]) == [] and _same_object(a["relation_trie"], c["relation_trie"]) == []
+    # a batch that already has its tries is left alone
+    ld = loader(True)
+    with data.Prefetcher(ld.thunks(), depth=2, workers=1, device_tries=True) as pf:
+        first = next(pf)
+    assert _same_object(first["relation_trie"], want[0]["relation_trie"]) == []

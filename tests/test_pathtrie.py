@@ -102,6 +102,52 @@ def test_pathtrie_rejects_bad_lengths():
         build_path_trie(torch.ones(3, 4, dtype=torch.int64), torch.tensor([1, 4, 2, 3]))
 
 
+# ------------------------------------------------------------------------------------------------ device builder (torch ops)
+def _same_object(a, b, path=""):
+    """every public attribute of two index objects: tensors equal in dtype, shape and value, everything else ==."""
+    bad = []
+    for k in sorted(set(vars(a)) | set(vars(b))):
+        if k.startswith("_"):
+            continue
+        x, y = vars(a).get(k), vars(b).get(k)
+        if isinstance(x, torch.Tensor):
+            if not (isinstance(y, torch.Tensor) and x.dtype == y.dtype and x.shape == y.shape and torch.equal(x, y)):
+                bad.append(path + k)
+        elif hasattr(x, "__dict__") and not isinstance(x, (int, float, list, tuple)):
+            bad += _same_object(x, y, path + k + ".")
+        elif x != y:
+            bad.append(path + k)
+    return bad
+
+
+@pytest.mark.parametrize("seed,R,L,V", [(1, 1, 1, 5), (2, 40, 4, 6), (3, 300, 8, 5), (4, 500, 8, 250), (5, 700, 7, 9)])
+@pytest.mark.parametrize("chunk", [8, 64])
+def test_device_trie_builder_equals_the_host_builder(seed, R, L, V, chunk):
+    """gtos_amd.pathtrie_device (torch ops, here on CPU tensors) against csrc_host/pathtrie.cpp: every array of both tries, the
+    packed order, the row -> node maps, the chunk lists and the derived backward indices (sum_idx, multi_ranges, wave_off)."""
+    from gtos_amd.pathtrie_device import build_path_trie_device
+    seqs, bank, length = _random_bank(seed, R, L, V)
+    host, dev_ = build_path_trie(bank, length, chunk=chunk), build_path_trie_device(bank, length, chunk=chunk)
+    assert _same_object(host, dev_) == []
+    _check(seqs, dev_, chunk=chunk)
+
+
+def test_device_trie_builder_on_an_amr_bank_and_its_limits():
+    from gtos_amd import synth
+    from gtos_amd.pathtrie_device import build_path_trie_device
+    batch, _ = synth.make_batch(3, 6, 40, 8)
+    assert _same_object(build_path_trie(batch["relation_bank"], batch["relation_length"]),
+                        build_path_trie_device(batch["relation_bank"], batch["relation_length"])) == []
+    wide = torch.cat([batch["relation_bank"], torch.zeros(3, batch["relation_bank"].shape[1], dtype=torch.int64)])   # L > 8 rows, paths <= 8
+    assert _same_object(build_path_trie(wide, batch["relation_length"]), build_path_trie_device(wide, batch["relation_length"])) == []
+    with pytest.raises(ValueError):                                       # label ids the one-byte keys cannot hold
+        build_path_trie_device(torch.full((2, 3), 300, dtype=torch.int64), torch.tensor([1, 2, 2]))
+    with pytest.raises(ValueError):                                       # a path of 9 labels
+        build_path_trie_device(torch.ones(9, 2, dtype=torch.int64), torch.tensor([9, 1]))
+    with pytest.raises(ValueError):
+        build_path_trie_device(torch.ones(3, 4, dtype=torch.int64), torch.tensor([1, 0, 2, 3]))
+
+
 # ------------------------------------------------------------------------------------------------ relation index (host)
 @pytest.mark.parametrize("B", [5, 8])
 def test_relation_index_groups_pairs_by_type(B):
