@@ -186,6 +186,146 @@ void build_rows(const std::vector<int32_t>& row_node, int64_t n_nodes, int chunk
     }
 }
 
+// ------------------------------------------------------------------------------------------------ fast path (L <= 8, labels < 255)
+// A path is ONE 64-bit key: byte 7-t holds label t + 1, 0 behind the end -- integer order == lexicographic order with "a proper
+// prefix first".  Everything the generic path reads from the [R, L] token rows through the sorted order (random 32-byte reads)
+// comes out of the sorted keys themselves, front to back: length = 8 - trailing zero bytes, lcp with the predecessor = leading
+// zero bytes of the XOR, label k = byte 7-k.
+struct KeyId { uint64_t key; int64_t id; };
+
+// LSD radix sort of (key, id), stable in id; the histograms of all eight bytes come from ONE pass, bytes that are the same
+// everywhere are skipped (two of eight at C2 have a handful of values, none is constant)
+void sort_keys(std::vector<KeyId>& a) {
+    const size_t n = a.size();
+    std::vector<uint32_t> hist(8 * 256, 0);
+    for (size_t i = 0; i < n; ++i) {
+        const uint64_t k = a[i].key;
+        for (int b = 0; b < 8; ++b) hist[b * 256 + ((k >> (8 * b)) & 0xff)]++;
+    }
+    std::vector<KeyId> tmp(n);
+    KeyId *src = a.data(), *dst = tmp.data();
+    for (int b = 0; b < 8; ++b) {
+        uint32_t* h = &hist[b * 256];
+        bool constant = false;
+        for (int d = 0; d < 256; ++d) if (h[d] == n) constant = true;
+        if (constant) continue;
+        uint32_t pos[256];
+        uint32_t run = 0;
+        for (int d = 0; d < 256; ++d) { pos[d] = run; run += h[d]; }
+        const int sh = 8 * b;
+        for (size_t i = 0; i < n; ++i) dst[pos[(src[i].key >> sh) & 0xff]++] = src[i];
+        std::swap(src, dst);
+    }
+    if (src != a.data()) std::memcpy(a.data(), src, n * sizeof(KeyId));
+}
+
+inline int key_len(uint64_t k) { return 8 - (__builtin_ctzll(k) >> 3); }          // k != 0: every path has a label
+
+// The trie of the sorted keys: nodes numbered level-major, lexicographic inside a level (as build_trie), `node_tab[i*8 + k]` = the
+// node of the i-th sorted path at level k, `cnt[u]` = paths through node u (= its rows in the packed layout).
+void trie_of_sorted_keys(const std::vector<KeyId>& a, int L, Trie& tr, std::vector<int32_t>& node_tab, std::vector<int64_t>& cnt) {
+    const int64_t R = (int64_t)a.size();
+    std::vector<uint8_t> lcps(R);
+    int64_t per_level[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t prev = 0;
+    for (int64_t i = 0; i < R; ++i) {
+        const uint64_t k = a[i].key;
+        const int len = key_len(k);
+        int lcp = 0;
+        if (i) {
+            const uint64_t x = k ^ prev;
+            lcp = x ? (__builtin_clzll(x) >> 3) : 8;
+            if (lcp > len) lcp = len;
+        }
+        lcps[i] = (uint8_t)lcp;
+        for (int q = lcp; q < len; ++q) per_level[q]++;
+        prev = k;
+    }
+    tr.level_off.assign(L + 1, 0);
+    for (int q = 0; q < L; ++q) tr.level_off[q + 1] = tr.level_off[q] + (q < 8 ? per_level[q] : 0);
+    const int64_t next = tr.level_off[L];
+    tr.n_nodes = next;
+    tr.tok.resize(next);
+    tr.par.resize(next);
+    cnt.assign(next + 1, 0);
+    node_tab.resize(R * 8);
+    int64_t fill[8];
+    for (int q = 0; q < 8; ++q) fill[q] = q < L ? tr.level_off[q] : next;
+    int32_t cur[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+    for (int64_t i = 0; i < R; ++i) {
+        const uint64_t k = a[i].key;
+        const int len = key_len(k), lcp = lcps[i];
+        for (int q = lcp; q < len; ++q) {
+            const int32_t v = (int32_t)fill[q]++;
+            cur[q] = v;
+            tr.tok[v] = (int32_t)((k >> (8 * (7 - q))) & 0xff) - 1;
+            tr.par[v] = q ? cur[q - 1] : (int32_t)next;       // level 0: the all-zero row behind the last node
+        }
+        int32_t* nt = &node_tab[i * 8];
+        for (int q = 0; q < 8; ++q) nt[q] = q < len ? cur[q] : -1;
+        for (int q = 0; q < len; ++q) cnt[cur[q]]++;
+    }
+    tr.child_off.assign(2 * next, 0);
+    for (int64_t v = 0; v < next; ++v) {
+        const int64_t p = tr.par[v];
+        if (p >= next) continue;
+        if (tr.child_off[2 * p + 1] == 0) tr.child_off[2 * p] = (int32_t)v;
+        tr.child_off[2 * p + 1] = (int32_t)(v + 1);
+    }
+}
+
+// rows of every node from the per-node counts (no histogram pass over the rows), cut into chunks
+void build_rows_counted(const std::vector<int32_t>& row_node, const std::vector<int64_t>& cnt, int64_t n_nodes, int chunk, Trie& tr,
+                        bool by_level) {
+    const int64_t N = (int64_t)row_node.size();
+    std::vector<int64_t> off(n_nodes + 1, 0);
+    for (int64_t u = 0; u < n_nodes; ++u) off[u + 1] = off[u] + cnt[u];
+    tr.rows.resize(N);
+    if (!by_level) {
+        // prefix trie: the rows of level k are one contiguous range of p, so the scatter already stays inside one level's rows
+        std::vector<int64_t> cur(off.begin(), off.end() - 1);
+        for (int64_t p = 0; p < N; ++p) tr.rows[cur[row_node[p]]++] = (int32_t)p;
+    } else {
+        // suffix trie: a step's rows mix all levels, and a one-pass scatter jumps over the whole 10 MB row list.  First the rows
+        // of every level (ascending p, sequential writes), then the scatter level by level -- inside a cache-sized window
+        const int nl = (int)tr.level_off.size() - 1;
+        std::vector<uint8_t> lvl(n_nodes);
+        std::vector<int64_t> lo(nl + 1, 0);
+        for (int q = 0; q < nl; ++q) {
+            for (int64_t u = tr.level_off[q]; u < tr.level_off[q + 1]; ++u) lvl[u] = (uint8_t)q;
+            lo[q + 1] = off[tr.level_off[q + 1]];                           // rows of the levels below q + 1
+        }
+        std::vector<int32_t> by(N);
+        {
+            std::vector<int64_t> w(lo.begin(), lo.end() - 1);
+            for (int64_t p = 0; p < N; ++p) by[w[lvl[row_node[p]]]++] = (int32_t)p;
+        }
+        std::vector<int64_t> cur(off.begin(), off.end() - 1);
+        for (int64_t e = 0; e < N; ++e) { const int32_t p = by[e]; tr.rows[cur[row_node[p]]++] = p; }
+    }
+    tr.chunk_node.clear(); tr.chunk_start.clear(); tr.chunk_cnt.clear(); tr.chunk_slot.clear(); tr.heavy_node.clear();
+    {
+        const size_t cap = (size_t)(n_nodes + N / chunk + 1);
+        tr.chunk_node.reserve(cap); tr.chunk_start.reserve(cap); tr.chunk_cnt.reserve(cap); tr.chunk_slot.reserve(cap);
+    }
+    for (int64_t u = 0; u < n_nodes; ++u) {
+        const int64_t lo = off[u], hi = off[u + 1];
+        const int64_t nch = hi > lo ? (hi - lo + chunk - 1) / chunk : 1;
+        int32_t slot = -1;
+        if (nch > 1) {
+            slot = (int32_t)tr.heavy_node.size();
+            tr.heavy_node.push_back((int32_t)u);
+        }
+        for (int64_t c = 0; c < nch; ++c) {
+            const int64_t s = lo + c * chunk;
+            tr.chunk_node.push_back((int32_t)u);
+            tr.chunk_start.push_back((int32_t)s);
+            tr.chunk_cnt.push_back((int32_t)std::max<int64_t>(0, std::min<int64_t>(chunk, hi - s)));
+            tr.chunk_slot.push_back(slot);
+        }
+    }
+}
+
 }  // namespace
 
 struct gtos_pathtrie {
@@ -208,6 +348,105 @@ extern "C" gtos_pathtrie* gtos_pathtrie_build(int L, int64_t R, const int64_t* b
         fprintf(stderr, "pathtrie %-12s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
         t_prev = now;
     };
+    if (L <= 8) {
+        // ---- fast path: every path as one 64-bit key (see sort_keys / trie_of_sorted_keys above)
+        std::vector<KeyId> kf(R), kb(R);
+        std::vector<uint8_t> len8(R);
+        int64_t N = 0;
+        int maxlen = 0;
+        bool fast = true;
+        for (int64_t s = 0; s < R && fast; ++s) {
+            const int64_t l = length[s];
+            if (l < 1 || l > L) return nullptr;
+            len8[s] = (uint8_t)l;
+            N += l;
+            maxlen = std::max<int>(maxlen, (int)l);
+            uint64_t f = 0, b = 0;
+            for (int t = 0; t < (int)l; ++t) {                               // bank is [L, R]: L strided streams, one pass over the keys
+                const int64_t v = bank[(int64_t)t * R + s];
+                if (v < 0 || v > 0x7fffffff) return nullptr;
+                if (v >= 255) { fast = false; break; }                      // a label the one-byte digits cannot hold: generic path
+                f |= (uint64_t)(v + 1) << (8 * (7 - t));
+                b |= (uint64_t)(v + 1) << (8 * (7 - ((int)l - 1 - t)));
+            }
+            kf[s] = {f, s};
+            kb[s] = {b, s};
+        }
+        if (fast && N > 0x7fffffffLL) return nullptr;
+        if (fast) {
+            auto* h = new gtos_pathtrie();
+            h->L = maxlen;
+            h->R = R;
+            h->N = N;
+            lap("unpack");
+            {
+                std::thread tb([&] { sort_keys(kb); });
+                sort_keys(kf);
+                tb.join();
+            }
+            lap("sort");
+            // packed order: length descending, then lexicographic = counting sort by length over the lexicographic order; the
+            // lexicographic index of every packed position comes with it
+            h->seq_order.resize(R);
+            h->seq_pos.resize(R);
+            std::vector<int32_t> lexf_of_m(R), lexb(R);
+            {
+                std::vector<int64_t> start(L + 2, 0);
+                for (int64_t s = 0; s < R; ++s) start[L - len8[s] + 1]++;
+                for (int b = 0; b <= L; ++b) start[b + 1] += start[b];
+                for (int64_t i = 0; i < R; ++i) {
+                    const int64_t s = kf[i].id;
+                    const int64_t m = start[L - len8[s]]++;
+                    h->seq_order[m] = (int32_t)s;
+                    lexf_of_m[m] = (int32_t)i;
+                    h->seq_pos[s] = (int32_t)m;
+                }
+                for (int64_t i = 0; i < R; ++i) lexb[kb[i].id] = (int32_t)i;
+            }
+            h->batch_sizes.assign(maxlen, 0);
+            for (int64_t s = 0; s < R; ++s) h->batch_sizes[len8[s] - 1]++;
+            for (int t = maxlen - 2; t >= 0; --t) h->batch_sizes[t] += h->batch_sizes[t + 1];
+            std::vector<int64_t> offs(L + 1, 0);
+            for (int t = 0; t < maxlen; ++t) offs[t + 1] = offs[t] + h->batch_sizes[t];
+            lap("packed order");
+            std::vector<int32_t> tab_f, tab_b;
+            std::vector<int64_t> cnt_f, cnt_b;
+            h->row_pf.resize(N);
+            h->row_sf.resize(N);
+            {
+                // the node of every packed row, written in PACKED order: one random 32-byte read of the path's node list, up to
+                // eight sequential write streams (the generic path scatters 4-byte writes from the lexicographic order)
+                std::thread tb([&] {
+                    trie_of_sorted_keys(kb, L, h->sf, tab_b, cnt_b);
+                    for (int64_t m = 0; m < R; ++m) {
+                        const int64_t s = h->seq_order[m];
+                        const int len = len8[s];
+                        const int32_t* nt = &tab_b[(int64_t)lexb[s] * 8];
+                        for (int q = 0; q < len; ++q) h->row_sf[offs[len - 1 - q] + m] = nt[q];
+                    }
+                });
+                trie_of_sorted_keys(kf, L, h->pf, tab_f, cnt_f);
+                for (int64_t m = 0; m < R; ++m) {
+                    const int len = len8[h->seq_order[m]];
+                    const int32_t* nt = &tab_f[(int64_t)lexf_of_m[m] * 8];
+                    for (int q = 0; q < len; ++q) h->row_pf[offs[q] + m] = nt[q];
+                }
+                tb.join();
+            }
+            lap("tries");
+            {
+                std::thread tr([&] { build_rows_counted(h->row_sf, cnt_b, h->sf.n_nodes, chunk, h->sf, true); });
+                build_rows_counted(h->row_pf, cnt_f, h->pf.n_nodes, chunk, h->pf, false);
+                tr.join();
+            }
+            lap("row lists");
+            h->pf.level_off.resize(maxlen + 1);
+            h->sf.level_off.resize(maxlen + 1);
+            h->pf.level_off[maxlen] = h->pf.n_nodes;
+            h->sf.level_off[maxlen] = h->sf.n_nodes;
+            return h;
+        }
+    }
     Seqs fw, bw;
     fw.L = bw.L = L;
     fw.R = bw.R = R;
@@ -316,6 +555,58 @@ extern "C" int gtos_pathtrie_export(const gtos_pathtrie* h, int32_t** out) {
         put(out[k++], t->chunk_cnt);
         put(out[k++], t->chunk_slot);
         put(out[k++], t->heavy_node);
+    }
+    return k;
+}
+
+namespace {
+int64_t count_multi(const Trie& t) {
+    int64_t m = 0;
+    for (int64_t u = 0; u < t.n_nodes; ++u) m += t.child_off[2 * u + 1] - t.child_off[2 * u] >= 2;
+    return m;
+}
+int64_t waves_of(int64_t N, int rows_per_wave) { return std::max<int64_t>(1, (N + rows_per_wave - 1) / rows_per_wave); }
+}  // namespace
+
+extern "C" int gtos_pathtrie_derived_sizes(const gtos_pathtrie* h, int rows_per_wave, int64_t* sizes) {
+    if (!h || !sizes || rows_per_wave <= 0) return -1;
+    sizes[0] = count_multi(h->pf); sizes[1] = waves_of(h->N, rows_per_wave);
+    sizes[2] = count_multi(h->sf); sizes[3] = waves_of(h->N, rows_per_wave);
+    return 0;
+}
+
+extern "C" int gtos_pathtrie_export_derived(const gtos_pathtrie* h, int rows_per_wave, int32_t** out) {
+    if (!h || !out || rows_per_wave <= 0) return -1;
+    int k = 0;
+    for (const Trie* t : {&h->pf, &h->sf}) {
+        const int64_t n = t->n_nodes;
+        int32_t *sum_idx = out[k], *ranges = out[k + 1], *mlo = out[k + 2], *wave = out[k + 3];
+        k += 4;
+        int64_t multi = 0;
+        size_t lvl = 0;
+        for (int64_t u = 0; u <= n; ++u) {
+            while (mlo && lvl < t->level_off.size() && t->level_off[lvl] == u) mlo[lvl++] = (int32_t)multi;
+            if (u == n) break;
+            const int32_t lo = t->child_off[2 * u], hi = t->child_off[2 * u + 1];
+            const int32_t nc = hi - lo;
+            if (sum_idx) sum_idx[u] = nc == 1 ? lo : (nc >= 2 ? (int32_t)(n + 1 + multi) : (int32_t)n);
+            if (nc >= 2) {
+                if (ranges) { ranges[2 * multi] = lo; ranges[2 * multi + 1] = hi; }
+                ++multi;
+            }
+        }
+        if (wave) {
+            // first chunk whose start is >= w * rows_per_wave (the chunk starts ascend); chunks without rows in front of the first
+            // row belong to the first wave
+            const int64_t nw = waves_of(h->N, rows_per_wave), nc = (int64_t)t->chunk_start.size();
+            int64_t c = 0;
+            for (int64_t w = 0; w < nw; ++w) {
+                const int64_t target = w * (int64_t)rows_per_wave;
+                while (c < nc && t->chunk_start[c] < target) ++c;
+                wave[w] = (int32_t)(w == 0 ? 0 : c);
+            }
+            wave[nw] = (int32_t)nc;
+        }
     }
     return k;
 }

@@ -128,6 +128,15 @@ def build_path_trie(bank, length, chunk=CHUNK):
         ptrs = (ctypes.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
         got = lib.gtos_pathtrie_export(h, ptrs)
         assert got == len(arrs)
+        # the indices of the backward walk and of the streaming segmented sum (TrieSide derives them with numpy when they are missing)
+        dsz = np.zeros(4, dtype=np.int64)
+        lib.gtos_pathtrie_derived_sizes(h, TrieSide.ROWS_PER_WAVE, dsz.ctypes.data)
+        dshapes = []
+        for n, (nm, nw) in zip((nPF, nSF), ((int(dsz[0]), int(dsz[1])), (int(dsz[2]), int(dsz[3])))):
+            dshapes += [n, 2 * nm, Lm + 1, nw + 1]
+        darrs = [np.empty(max(1, s), dtype=np.int32) for s in dshapes]
+        dptrs = (ctypes.c_void_p * len(darrs))(*[a.ctypes.data for a in darrs])
+        assert lib.gtos_pathtrie_export_derived(h, TrieSide.ROWS_PER_WAVE, dptrs) == len(darrs)
     finally:
         lib.gtos_pathtrie_free(h)
     nps = [a[:s] for a, s in zip(arrs, shapes)]
@@ -143,7 +152,9 @@ def build_path_trie(bank, length, chunk=CHUNK):
         d["tok"] = wide(names["tok"])              # the embedding kernels take int64 token ids
         d["par_long"] = wide(names["par"])         # index_select operand (the parent-state gather of the weight gradient)
         level_off = d.pop("level_off").tolist()
-        sides.append(TrieSide(d, level_off))
+        dv = [torch.from_numpy(a[:s_]) for a, s_ in zip(darrs[4 * k:4 * k + 4], dshapes[4 * k:4 * k + 4])]
+        d["sum_idx"], d["multi_ranges"], d["wave_off"] = dv[0], dv[1], dv[3]
+        sides.append(TrieSide(d, level_off, dv[2].tolist()))
     # seq_order / seq_pos feed index_select (int64); the row -> node maps stay int32 for the kernels
     return PathTrie(Lm, R, N, common["batch_sizes"].tolist(), (wide(1), wide(2), common["row_pf"], common["row_sf"], ts[1]),
                     sides[0], sides[1])

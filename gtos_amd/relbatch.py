@@ -42,6 +42,10 @@ def load():
         lib.gtos_pathtrie_sizes.argtypes = [P, P]
         lib.gtos_pathtrie_export.restype = ctypes.c_int
         lib.gtos_pathtrie_export.argtypes = [P, P]
+        lib.gtos_pathtrie_derived_sizes.restype = ctypes.c_int
+        lib.gtos_pathtrie_derived_sizes.argtypes = [P, ctypes.c_int, P]
+        lib.gtos_pathtrie_export_derived.restype = ctypes.c_int
+        lib.gtos_pathtrie_export_derived.argtypes = [P, ctypes.c_int, P]
         lib.gtos_pathtrie_free.restype = None
         lib.gtos_pathtrie_free.argtypes = [P]
         lib.gtos_relindex_build.restype = P

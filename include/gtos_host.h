@@ -77,6 +77,18 @@ int gtos_pathtrie_sizes(const gtos_pathtrie* h, int64_t* sizes);
  *   heavy_node[heavy]   node of every heavy slot.
  * Returns the number of arrays (25). */
 int gtos_pathtrie_export(const gtos_pathtrie* h, int32_t** out);
+
+/* What the backward walk of the trie GRU and the streaming segmented sum read besides the arrays above, per trie:
+ *   sum_idx[n]            row of the [n + 1 + n_multi, .] gradient buffers holding the SUM over node u's children: the child
+ *                         itself when there is one, row n (all zero) for a leaf, row n + 1 + j for the j-th node with several
+ *   multi_ranges[2*n_multi]  the child ranges [start, end) of those nodes, in node order
+ *   multi_level_off[L+1]  how many of them precede each level
+ *   wave_off[n_waves+1]   chunk indices cutting the chunk list into ranges of about rows_per_wave rows (gtos_segment_sum_stream);
+ *                         n_waves = max(1, ceil(N / rows_per_wave))
+ * _derived_sizes: sizes[4] = {n_multi (prefix trie), n_waves, n_multi (suffix trie), n_waves}.  _export_derived fills the 8
+ * caller-allocated int32 arrays (prefix trie's four, then the suffix trie's), returns 8. */
+int gtos_pathtrie_derived_sizes(const gtos_pathtrie* h, int rows_per_wave, int64_t* sizes);
+int gtos_pathtrie_export_derived(const gtos_pathtrie* h, int rows_per_wave, int32_t** out);
 void gtos_pathtrie_free(gtos_pathtrie* h);
 
 /* ---- Index preparation of the factored relation operand (gtos_amd/csrc_host/relindex.cpp): what the attention kernels
@@ -92,7 +104,9 @@ int gtos_relindex_sizes(const gtos_relindex* h, int64_t* sizes);
  *             the batch (no chunk below: gtos_rel_attn_bwd writes their bank-gradient row itself)
  *   pair_sorted[P]  flat pair indices (j*n+i)*B+b grouped by type, graph-major inside a type
  *   chunk_type/start/count/slot[chunks]  gradient chunks over pair_sorted (slot = heavy slot, -1 for single-chunk types),
- *                   ordered by (XCD of the first pair's graph, graph, key row)
+ *                   grouped by the XCD that walks them: the XCD of the pairs' graphs when they share one, else the XCD with the
+ *                   fewest load rounds so far; inside an XCD the chunks of more than 8 pairs first (longest first), then
+ *                   (graph, key row) order
  *   xcd_off[9]      chunk ranges per XCD      heavy_types[heavy]  type id of every heavy slot.  Returns 9. */
 int gtos_relindex_export(const gtos_relindex* h, int32_t** out);
 void gtos_relindex_free(gtos_relindex* h);
