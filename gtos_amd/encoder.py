@@ -3,6 +3,8 @@
 Drop-in for /root/reference/generator/encoder.py (same signatures and state_dict keys, including nn.GRU's
 native parameter names ``rnn.weight_ih_l0`` ...).  The pretrained-embedding file loader is out of scope.
 """
+import os
+
 import torch
 from torch import nn
 import torch.nn.functional as F
@@ -12,6 +14,11 @@ from . import gru as _gru
 from .gru import bigru_final, trie_bigru_final
 from .pathtrie import build_path_trie
 from .transformer import Embedding
+
+# A bank that arrives WITHOUT its tries (a caller feeding the reference's own batches): 1 = build them with torch ops on the device
+# (gtos_amd.pathtrie_device: ~12 ms of GPU time at C2) instead of the host round trip below (bank to the host, ~0.1-0.2 s of C++,
+# tries back).  Off by default: round 3 ran that builder on the GPU only through the loader's Prefetcher at C2.
+TRIE_DEVICE = os.environ.get("GTOS_TRIE_DEVICE", "0") == "1"
 
 
 def AMREmbedding(vocab, embedding_dim, pretrained_file=None, amr=False, dump_file=None):
@@ -62,10 +69,18 @@ class RelationEncoder(nn.Module):
         pad = (-rel_dim) % 8                                                       # 16-byte rows for the GEMM
         if self._trie_ok(src_tokens):
             if trie is None or not trie.matches(src_tokens, src_lengths):
-                try:
-                    trie = build_path_trie(src_tokens, src_lengths).to(src_tokens.device)
-                except ValueError:            # a bank the trie builder rejects (paths longer than 64 labels): one row per
-                    trie = None               # (path, position) below, like the reference's packed sequence
+                trie = None
+                if TRIE_DEVICE:
+                    try:
+                        from .pathtrie_device import build_path_trie_device
+                        trie = build_path_trie_device(src_tokens, src_lengths)
+                    except ValueError:        # more than 8 labels per path / label ids >= 255: the host builder's business
+                        trie = None
+                if trie is None:
+                    try:
+                        trie = build_path_trie(src_tokens, src_lengths).to(src_tokens.device)
+                    except ValueError:        # a bank the trie builder rejects (paths longer than 64 labels): one row per
+                        trie = None           # (path, position) below, like the reference's packed sequence
         if trie is not None and trie.matches(src_tokens, src_lengths) and self._trie_ok(src_tokens):
             p_e = self.dropout if self.training else 0.0
             # final states [R, 2h], already in bank order (the step kernels scatter them through trie.seq_order)
