@@ -4,6 +4,7 @@ File format and semantics of /root/reference/generator/data.py:12-110 (the trans
 ``token<TAB>count`` per line; ids are [<PAD>, <UNK>] + specials + every token whose count reaches the threshold, in
 file order; ``priority`` keeps the raw count of every token; ``coverage`` is the kept fraction of the token mass.
 """
+import numpy as np
 import torch
 
 PAD, UNK = '<PAD>', '<UNK>'
@@ -105,22 +106,37 @@ def lists_to_tensor(xs, vocab=None, local_vocabs=None, unk_rate=0., rng=None):
     noisy = vocab is not None and unk_rate > 0.
     if noisy and rng is None:
         import random as rng
-    rows = []
+    # the lookups go straight to the vocabulary's dict when it has one (Vocab, synth.SynthVocab): a method call per token is what
+    # this function costs (6.4 k tokens per call at C2, 10 calls per batch)
+    table = getattr(vocab, "_token2idx", None) if vocab is not None else None
+    unk = getattr(vocab, "_unk_idx", None) if table is not None else None
+    if table is not None and unk is None:
+        unk = vocab.token2idx(object())           # whatever this vocabulary answers for a token it has never seen
+    out = np.full((len(xs), width), pad, dtype=np.int64)
     for i, x in enumerate(xs):
         if vocab is None:
             ids = list(x)
         else:
             local = local_vocabs[i] if local_vocabs is not None else None
-            ids = []
-            for w in x:
-                if noisy and rng.random() < unk_rate:
-                    ids.append(vocab.unk_idx)
-                elif local is not None and w in local:
-                    ids.append(local[w])
+            if noisy:
+                ids = []
+                for w in x:
+                    if rng.random() < unk_rate:
+                        ids.append(vocab.unk_idx)
+                    elif local is not None and w in local:
+                        ids.append(local[w])
+                    else:
+                        ids.append(vocab.token2idx(w))
+            elif table is not None:
+                if local:
+                    ids = [local[w] if w in local else table.get(w, unk) for w in x]
                 else:
-                    ids.append(vocab.token2idx(w))
-        rows.append(ids + [pad] * (width - len(x)))
-    return torch.tensor(rows, dtype=torch.int64).t().contiguous()
+                    ids = [table.get(w, unk) for w in x]
+            else:
+                ids = [local[w] if (local is not None and w in local) else vocab.token2idx(w) for w in x]
+        if ids:
+            out[i, :len(ids)] = ids
+    return torch.from_numpy(np.ascontiguousarray(out.T))
 
 
 _CHAR_ROWS = {}       # (id(vocab), max_string_len) -> {string: id row}; strings repeat heavily (Zipf), the lookup is what costs
@@ -134,20 +150,32 @@ def strings_to_char_tensor(xs, vocab, max_string_len=20):
     key = (id(vocab), max_string_len)
     ent = _CHAR_ROWS.get(key)
     if ent is None or ent[0] is not vocab:
-        ent = _CHAR_ROWS[key] = (vocab, {})
-    rows = ent[1]
+        ent = _CHAR_ROWS[key] = [vocab, {}, [], None]        # vocabulary, string -> row index, rows (lists), rows as one array
+    index, rows = ent[1], ent[2]
     if len(rows) > 2000000:
-        rows.clear()
+        index.clear()
+        del rows[:]
+        ent[3] = None
 
-    def row_of(z):
-        r = rows.get(z)
-        if r is None:
+    def ix(z):
+        k = index.get(z)
+        if k is None:
             chars = list(z[:max_string_len])
-            r = rows[z] = vocab.token2idx([STR] + chars + [END]) + [vocab.padding_idx] * (max_string_len - len(chars))
-        return r
-    pad_row = row_of(PAD)
-    out = [[row_of(z) for z in x] + [pad_row] * (width - len(x)) for x in xs]
-    return torch.tensor(out, dtype=torch.int64).transpose(0, 1).contiguous()
+            k = index[z] = len(rows)
+            rows.append(vocab.token2idx([STR] + chars + [END]) + [vocab.padding_idx] * (max_string_len - len(chars)))
+        return k
+    pad_ix = ix(PAD)
+    # one small index matrix from the Python side (a dict lookup per string), the [B, width, chars] tensor by ONE gather from the
+    # table of id rows: the nested-list conversion of the full tensor was 22 x the elements
+    idx = np.full((len(xs), width), pad_ix, dtype=np.int64)
+    for i, x in enumerate(xs):
+        if x:
+            idx[i, :len(x)] = [ix(z) for z in x]
+    table = ent[3]
+    if table is None or table.shape[0] < len(rows):
+        fresh = np.asarray(rows[0 if table is None else table.shape[0]:], dtype=np.int64).reshape(-1, max_string_len + 2)
+        table = ent[3] = fresh if table is None else np.concatenate([table, fresh])
+    return torch.from_numpy(np.ascontiguousarray(table[idx].transpose(1, 0, 2)))
 
 
 def copy_vocab(concepts, vocab):
