@@ -148,6 +148,16 @@ def test_device_trie_builder_on_an_amr_bank_and_its_limits():
         build_path_trie_device(torch.ones(3, 4, dtype=torch.int64), torch.tensor([1, 0, 2, 3]))
 
 
+def test_device_trie_builder_equals_the_host_builder_at_c2_size():
+    """The bank bench.py trains on (64 graphs, 434,624 paths, 2.5 M rows): both builders, every array."""
+    from gtos_amd import synth
+    from gtos_amd.pathtrie_device import build_path_trie_device
+    batch, st = synth.make_config_batch("C2", rank=0, B=64)
+    host = build_path_trie(batch["relation_bank"], batch["relation_length"])
+    assert host.R == st["R"] and host.pf.n_heavy > 0 and host.sf.n_multi > 0
+    assert _same_object(host, build_path_trie_device(batch["relation_bank"], batch["relation_length"])) == []
+
+
 # ------------------------------------------------------------------------------------------------ relation index (host)
 @pytest.mark.parametrize("B", [5, 8])
 def test_relation_index_groups_pairs_by_type(B):
