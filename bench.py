@@ -77,9 +77,10 @@ def parse():
                     help="--fresh-batches: batches in flight (default 2 per worker: a batch spends ~0.2 s between job hand-out and "
                          "upload, three step times at C2, so fewer than that starves the consumer whatever the worker count)")
     ap.add_argument("--relbatch-threads", type=int, default=2, help="--fresh-batches: threads inside one relation-batch build")
-    ap.add_argument("--device-tries", action="store_true",
-                    help="--fresh-batches: the workers build the relation index only; the path tries are built on the GPU with torch ops on "
-                         "the loader's copy stream (gtos_amd.pathtrie_device)")
+    ap.add_argument("--device-tries", nargs="?", const="torch", default="", choices=["torch", "hip"],
+                    help="--fresh-batches: the workers build the relation index only; the path tries are built on the GPU on the loader's "
+                         "copy stream: 'torch' (default when the flag is given bare) = torch ops (gtos_amd.pathtrie_device), 'hip' = the "
+                         "staged HIP builder (gtos_amd.pathtrie_hip: rocPRIM sorts / scans + stage kernels, 2 host reads)")
     ap.add_argument("--pool", type=int, default=0, help="--fresh-batches: graphs in the per-rank item pool (default 4 batches)")
     ap.add_argument("--prewarm-seconds", type=float, default=20.0,
                     help="untimed device pre-warm BEFORE the --warmup steps: windows of 5 training steps until two consecutive windows "
@@ -481,10 +482,10 @@ def main():
                 yield from loader.jobs()
         if a.loader == "processes":
             feed = data_mod.Prefetcher(jobs(), depth=a.depth, workers=a.workers, device=dev, processes=True, runner=timed_run,
-                                       device_tries=a.device_tries)
+                                       device_tries=a.device_tries or False)
         else:
             feed = data_mod.Prefetcher((lambda j=j: timed_run(j) for j in jobs()), depth=a.depth, workers=a.workers, device=dev,
-                                       device_tries=a.device_tries)
+                                       device_tries=a.device_tries or False)
         batch = next(feed)
         stats = {"n": int(batch["concept"].shape[0]), "B": int(batch["concept"].shape[1]), "T": int(batch["token_in"].shape[0]),
                  "R": int(batch["relation_bank"].shape[1]),
@@ -492,7 +493,8 @@ def main():
         assert stats["B"] == B_rank, stats
         asm_times.append(batch.pop("_assembly_s"))
         loader_info = {"workers": a.workers, "kind": a.loader, "depth": a.depth, "relbatch_threads": a.relbatch_threads,
-                       "tries": "device (torch ops on the copy stream)" if a.device_tries else "host (worker)",
+                       "tries": {"torch": "device (torch ops on the copy stream)", "hip": "device (staged HIP builder on the copy stream)",
+                                 "": "host (worker)"}[a.device_tries],
                        "pool_graphs_per_rank": pool_n, "device_memory_free_gb_at_start": round(free_b / 2 ** 30, 1),
                        "allocator": "default" if os.environ.get("GTOS_BENCH_NO_ROUNDUP") else "roundup_power2_divisions:16"}
     else:

@@ -5,7 +5,7 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libgtos_hip.so")
-SOURCES = ["gemm.hip", "rel_attn.hip", "rowops.hip", "gru_step.hip", "copy_nll.hip", "tokenenc.hip"]
+SOURCES = ["gemm.hip", "rel_attn.hip", "rowops.hip", "gru_step.hip", "copy_nll.hip", "tokenenc.hip", "pathtrie_dev.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only"]
 
@@ -35,13 +35,13 @@ def build_host(force=False, verbose=True):
 
 def build(force=False, verbose=True):
     build_host(force, verbose)
-    hdr = os.path.join(CSRC, "common.h")
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "trie_kernels.h")]
     objs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(o)
-        if force or _stale(o, [s, hdr]):
+        if force or _stale(o, [s] + hdrs):
             cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)

@@ -35,16 +35,26 @@ def _index_prep(batch, on):
             batch['relation_trie'] = build_path_trie(batch['relation_bank'], batch['relation_length'])
         except ValueError:
             pass              # no 'relation_trie' key: RelationEncoder.forward falls back to one row per (path, position)
+    else:
+        batch['relation_rows'] = int(batch['relation_length'].sum())      # host integer the staged device builder would have to read back
     return attach_relation_index(batch)
 
 
-def attach_device_tries(batch):
-    """``batch['relation_trie']`` built on the device the bank lives on (gtos_amd.pathtrie_device), for a batch that came without
-    one; a bank outside that builder's case (paths longer than 8 labels, label ids >= 255) is left alone."""
+def attach_device_tries(batch, how=True):
+    """``batch['relation_trie']`` built on the device the bank lives on, for a batch that came without one; a bank outside the
+    device builders' case (paths longer than 8 labels, label ids >= 255) is left alone.  ``how``: True / "torch" = the torch-op
+    builder (gtos_amd.pathtrie_device, ~12 ms of small ATen kernels and 6 host reads per C2 batch); "hip" = the staged HIP builder
+    (gtos_amd.pathtrie_hip: rocPRIM sorts / scans + the stage kernels of csrc/trie_kernels.h, 2 host reads).  ``batch[
+    'relation_rows']`` (sum of the path lengths, known to the loader on the host) saves the staged builder a device read."""
     if 'relation_trie' not in batch and 'relation_bank' in batch:
-        from .pathtrie_device import build_path_trie_device
         try:
-            batch['relation_trie'] = build_path_trie_device(batch['relation_bank'], batch['relation_length'])
+            if how == "hip":
+                from .pathtrie_hip import HipBackend, build_path_trie_staged
+                batch['relation_trie'] = build_path_trie_staged(batch['relation_bank'], batch['relation_length'], HipBackend.shared(),
+                                                                n_rows=batch.get('relation_rows'))
+            else:
+                from .pathtrie_device import build_path_trie_device
+                batch['relation_trie'] = build_path_trie_device(batch['relation_bank'], batch['relation_length'])
         except ValueError:
             pass
     return batch
@@ -670,11 +680,11 @@ class Prefetcher(object):
             if 'relation_trie' not in b0:
                 if self._copy_stream is not None:
                     with torch.cuda.stream(self._copy_stream):
-                        attach_device_tries(b0)
+                        attach_device_tries(b0, self._device_tries)
                         ev = torch.cuda.Event()
                         ev.record(self._copy_stream)
                 else:
-                    attach_device_tries(b0)
+                    attach_device_tries(b0, self._device_tries)
                 extra = b0.get('relation_trie')
         if ev is not None:
             cur = torch.cuda.current_stream(self._device)

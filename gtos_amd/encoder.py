@@ -18,7 +18,8 @@ from .transformer import Embedding
 # A bank that arrives WITHOUT its tries (a caller feeding the reference's own batches): 1 = build them with torch ops on the device
 # (gtos_amd.pathtrie_device: ~12 ms of GPU time at C2) instead of the host round trip below (bank to the host, ~0.1-0.2 s of C++,
 # tries back).  Off by default: round 3 ran that builder on the GPU only through the loader's Prefetcher at C2.
-TRIE_DEVICE = os.environ.get("GTOS_TRIE_DEVICE", "0") == "1"
+# "hip": the staged HIP builder (gtos_amd.pathtrie_hip) instead of the torch ops.
+TRIE_DEVICE = {"1": "torch", "torch": "torch", "hip": "hip"}.get(os.environ.get("GTOS_TRIE_DEVICE", "0"), "")
 
 
 def AMREmbedding(vocab, embedding_dim, pretrained_file=None, amr=False, dump_file=None):
@@ -72,8 +73,12 @@ class RelationEncoder(nn.Module):
                 trie = None
                 if TRIE_DEVICE:
                     try:
-                        from .pathtrie_device import build_path_trie_device
-                        trie = build_path_trie_device(src_tokens, src_lengths)
+                        if TRIE_DEVICE == "hip":
+                            from .pathtrie_hip import HipBackend, build_path_trie_staged
+                            trie = build_path_trie_staged(src_tokens, src_lengths, HipBackend.shared())
+                        else:
+                            from .pathtrie_device import build_path_trie_device
+                            trie = build_path_trie_device(src_tokens, src_lengths)
                     except ValueError:        # more than 8 labels per path / label ids >= 255: the host builder's business
                         trie = None
                 if trie is None:

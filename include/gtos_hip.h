@@ -100,6 +100,18 @@ int gtos_rel_attn_bwd_bank(int dtype, int n, int B, int H, int d,
                            const int* chunk_count, const int* chunk_slot, const int* xcd_off, int nchunks,
                            void* d_bank, int64_t ld_dbank, float* heavy, void* stream);
 
+/* ---- Path tries of a relation bank built on the GPU (csrc/pathtrie_dev.hip; stages in csrc/trie_kernels.h): the device-side
+ * counterpart of gtos_pathtrie_build in include/gtos_host.h (generator/encoder.py:66-119's index preparation), same arrays.
+ * Two phases with one host read between them; gtos_amd/pathtrie_hip.py drives them.  common / pf / sf are tables of device
+ * pointers in the order of the C_* / T_* enums of trie_kernels.h; sizes is int32[65] on the device (SZ_* / S_* there);
+ * workspace = rocPRIM temporary storage of at least _workspace bytes.  Covered: paths of 1..8 labels with ids in [0, 255)
+ * (sizes[0] != 0 after phase A otherwise).  Opt-in (see the file's header for the measured status). */
+int gtos_pathtrie_dev_workspace(int64_t R, int64_t N, int64_t* bytes_out);
+int gtos_pathtrie_dev_phase_a(int L, int64_t R, const int64_t* bank, const int64_t* length, void** common, void** pf, void** sf,
+                              int32_t* sizes, void* workspace, size_t workspace_bytes, void* stream);
+int gtos_pathtrie_dev_phase_b(int64_t R, int64_t N, int n_pf, int n_sf, int chunk, int rows_per_wave, void** common, void** pf,
+                              void** sf, int32_t* sizes, void* workspace, size_t workspace_bytes, void* stream);
+
 /* y = LayerNorm(x + dropout(r)) * gamma + beta (r may be NULL), saving mean/rstd per row.
  * Replaces F.dropout + nn.LayerNorm(residual + x): generator/graph_transformer.py:57-58,64-65;
  * generator/transformer.py:57-58,63-64,70-71; generator/decoder.py:35-36; generator/generator.py:73,172. */

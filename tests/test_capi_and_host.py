@@ -62,7 +62,8 @@ def test_ctypes_binding_mirrors_header(lib_path):
         if "*" in arg:
             return ctypes.c_void_p
         base = arg.split()[-2] if len(arg.split()) > 1 else arg
-        return {"int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float, "uint64_t": ctypes.c_uint64}[base]
+        return {"int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float, "uint64_t": ctypes.c_uint64,
+                "size_t": ctypes.c_size_t}[base]
     for name, args in funcs.items():
         want = [kind(a) for a in args]
         assert want == _lib.SIGNATURES[name], name

@@ -158,6 +158,62 @@ def test_device_trie_builder_equals_the_host_builder_at_c2_size():
     assert _same_object(host, build_path_trie_device(batch["relation_bank"], batch["relation_length"])) == []
 
 
+# ------------------------------------------------------------------------------------------------ staged GPU builder, emulated
+class _EmulBackend(object):
+    """oracle/trie_emul.cpp: the per-thread stages of csrc/trie_kernels.h (the code the HIP kernels wrap) as serial host loops."""
+
+    def __init__(self):
+        import ctypes
+        import os
+        import subprocess
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        src, out = os.path.join(root, "oracle", "trie_emul.cpp"), os.path.join(root, "oracle", "_build", "libtrie_emul.so")
+        hdr = os.path.join(root, "gtos_amd", "csrc", "trie_kernels.h")
+        if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+            os.makedirs(os.path.dirname(out), exist_ok=True)
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", src, "-o", out])
+        self.lib = ctypes.CDLL(out)
+        P, I, L_ = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+        self.lib.gtos_trie_emul_phase_a.argtypes = [I, L_, P, P, P, P, P, P]
+        self.lib.gtos_trie_emul_phase_b.argtypes = [L_, L_, I, I, I, I, P, P, P, P]
+
+    def phase_a(self, L, R, N, bank, length, common, pf, sf, sizes):
+        from gtos_amd.pathtrie_hip import _table, _COMMON, _SIDE
+        assert self.lib.gtos_trie_emul_phase_a(L, R, bank.data_ptr(), length.data_ptr(), _table(_COMMON, common), _table(_SIDE, pf),
+                                               _table(_SIDE, sf), sizes.data_ptr()) == 0
+
+    def phase_b(self, R, N, n_pf, n_sf, chunk, rows_per_wave, common, pf, sf, sizes):
+        from gtos_amd.pathtrie_hip import _table, _COMMON, _SIDE
+        assert self.lib.gtos_trie_emul_phase_b(R, N, n_pf, n_sf, chunk, rows_per_wave, _table(_COMMON, common), _table(_SIDE, pf), _table(_SIDE, sf),
+                                               sizes.data_ptr()) == 0
+
+
+@pytest.mark.parametrize("seed,R,L,V", [(1, 1, 1, 5), (2, 40, 4, 6), (3, 300, 8, 5), (4, 500, 8, 250), (6, 900, 6, 12)])
+@pytest.mark.parametrize("chunk", [8, 64])
+def test_staged_gpu_trie_builder_stages_equal_the_host_builder(seed, R, L, V, chunk):
+    """The stage code of the HIP trie builder (csrc/trie_kernels.h) driven by the product's Python glue (gtos_amd/pathtrie_hip.py)
+    with the sorts / scans emulated on the host: every array equals the host builder's."""
+    from gtos_amd.pathtrie_hip import build_path_trie_staged
+    seqs, bank, length = _random_bank(seed, R, L, V)
+    host = build_path_trie(bank, length, chunk=chunk)
+    staged = build_path_trie_staged(bank, length, _EmulBackend(), chunk=chunk)
+    assert _same_object(host, staged) == []
+    _check(seqs, staged, chunk=chunk)
+
+
+def test_staged_gpu_trie_builder_stages_at_c2_size_and_limits():
+    from gtos_amd import synth
+    from gtos_amd.pathtrie_hip import build_path_trie_staged
+    batch, st = synth.make_config_batch("C2", rank=0, B=64)
+    host = build_path_trie(batch["relation_bank"], batch["relation_length"])
+    staged = build_path_trie_staged(batch["relation_bank"], batch["relation_length"], _EmulBackend(), n_rows=host.N)
+    assert _same_object(host, staged) == []
+    with pytest.raises(ValueError):                                       # label ids the one-byte keys cannot hold
+        build_path_trie_staged(torch.full((2, 3), 300, dtype=torch.int64), torch.tensor([1, 2, 2]), _EmulBackend())
+    with pytest.raises(ValueError):                                       # a path of 9 labels
+        build_path_trie_staged(torch.ones(9, 2, dtype=torch.int64), torch.tensor([9, 1]), _EmulBackend())
+
+
 # ------------------------------------------------------------------------------------------------ relation index (host)
 @pytest.mark.parametrize("B", [5, 8])
 def test_relation_index_groups_pairs_by_type(B):
