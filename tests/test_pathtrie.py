@@ -164,14 +164,8 @@ class _EmulBackend(object):
 
     def __init__(self):
         import ctypes
-        import os
-        import subprocess
-        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        src, out = os.path.join(root, "oracle", "trie_emul.cpp"), os.path.join(root, "oracle", "_build", "libtrie_emul.so")
-        hdr = os.path.join(root, "gtos_amd", "csrc", "trie_kernels.h")
-        if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
-            os.makedirs(os.path.dirname(out), exist_ok=True)
-            subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", src, "-o", out])
+        from oracle.build_emul import build
+        out = build()
         self.lib = ctypes.CDLL(out)
         P, I, L_ = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
         self.lib.gtos_trie_emul_phase_a.argtypes = [I, L_, P, P, P, P, P, P]
