@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgtos_hip.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 c_p, c_i, c_l, c_f, c_u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_uint64
 
@@ -21,6 +21,12 @@ SIGNATURES = {
     "gtos_pathtrie_dev_workspace": [c_l, c_l, c_p],
     "gtos_pathtrie_dev_phase_a": [c_i, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, ctypes.c_size_t, c_p],
     "gtos_pathtrie_dev_phase_b": [c_l, c_l, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, ctypes.c_size_t, c_p],
+    "gtos_relbatch_dev_workspace": [c_l, c_p],
+    "gtos_relbatch_dev_phase_a": [c_p, c_p, c_p, ctypes.c_size_t, c_p],
+    "gtos_relbatch_dev_phase_b": [c_p, c_l, c_p, c_p, ctypes.c_size_t, c_p],
+    "gtos_relindex_dev_workspace": [c_l, c_p],
+    "gtos_relindex_dev_phase_a": [c_p, c_p, c_p, ctypes.c_size_t, c_p],
+    "gtos_relindex_dev_phase_b": [c_p, c_l, c_p, c_p, ctypes.c_size_t, c_p],
     "gtos_gemm": [c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_i, c_f, c_u64, c_i, c_i, c_p, c_l, c_p],
     "gtos_rel_attn_fwd": [c_i] * 7 + [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_f, c_f, c_u64, c_p, c_l, c_p, c_p, c_p],
     "gtos_rel_attn_bwd": [c_i] * 7 + [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_u64,

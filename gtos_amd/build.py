@@ -5,7 +5,8 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libgtos_hip.so")
-SOURCES = ["gemm.hip", "rel_attn.hip", "rowops.hip", "gru_step.hip", "copy_nll.hip", "tokenenc.hip", "pathtrie_dev.hip"]
+SOURCES = ["gemm.hip", "rel_attn.hip", "rowops.hip", "gru_step.hip", "copy_nll.hip", "tokenenc.hip", "pathtrie_dev.hip", "relbatch_dev.hip", "relindex_dev.hip"]
+EXACT_FP = {"relbatch_dev.hip"}      # double comparisons that must branch like the host builder: no fast-math, no contraction
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only"]
 
@@ -35,14 +36,16 @@ def build_host(force=False, verbose=True):
 
 def build(force=False, verbose=True):
     build_host(force, verbose)
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "trie_kernels.h")]
+    own_hdr = {"pathtrie_dev.hip": "trie_kernels.h", "relbatch_dev.hip": "relbatch_kernels.h",
+               "relindex_dev.hip": "relindex_kernels.h"}     # the others include common.h
     objs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(o)
-        if force or _stale(o, [s] + hdrs):
-            cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+        if force or _stale(o, [s, os.path.join(CSRC, own_hdr.get(src, "common.h"))]):
+            flags = [f for f in FLAGS if f not in ("-ffast-math", "-fno-finite-math-only")] + ["-ffp-contract=off"] if src in EXACT_FP else FLAGS
+            cmd = [HIPCC] + flags + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

@@ -98,10 +98,10 @@ int bits_for(int64_t n) {                 // radix-sort key bits that can be set
 extern "C" int gtos_pathtrie_dev_workspace(int64_t R, int64_t N, int64_t* bytes_out) {
     if (R <= 0 || N <= 0 || !bytes_out) return -1;
     size_t a = 0, b = 0, c = 0;
-    rocprim::radix_sort_pairs(nullptr, a, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr,
+    (void)rocprim::radix_sort_pairs(nullptr, a, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr,
                               (size_t)R, 0, 64, (hipStream_t)0);
-    rocprim::inclusive_scan(nullptr, b, (const V8*)nullptr, (V8*)nullptr, (size_t)(R > N ? R : N), Add8(), (hipStream_t)0);
-    rocprim::radix_sort_pairs(nullptr, c, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr,
+    (void)rocprim::inclusive_scan(nullptr, b, (const V8*)nullptr, (V8*)nullptr, (size_t)(R > N ? R : N), Add8(), (hipStream_t)0);
+    (void)rocprim::radix_sort_pairs(nullptr, c, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr,
                               (size_t)N, 0, 32, (hipStream_t)0);
     size_t m = a > b ? a : b;
     m = m > c ? m : c;

@@ -1,0 +1,148 @@
+// The relation tensors of a batch built on the GPU: the launch glue around the per-thread stages of relbatch_kernels.h (whose logic
+// tests/test_relbatch_dev.py proves equal to csrc_host/relbatch.cpp on the host, running the same code as serial loops) plus rocPRIM's
+// radix sort and scan.  Two phases with one host read between them (gtos_amd/relbatch_hip.py): phase A is the all-pairs work (a BFS
+// per (graph, source), a key per pair), the key sort and the scan that counts the distinct keys; the host then allocates the bank
+// and phase B numbers the types in first-seen order and writes relation / bank / length.
+//
+// Compiled WITHOUT -ffast-math (gtos_amd/build.py): the uniform choice among alternative shortest paths compares running sums of
+// doubles and must take the same branch as the host builder.
+//
+// STATUS (end of round 3): compiles for gfx950; written after the round's GPU minutes were spent, so it has not run yet.  Opt-in.
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/functional.hpp>
+
+#include "relbatch_kernels.h"
+
+using namespace gtos_relbatch_dev;
+
+namespace {
+
+#define GTOS_RB_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return 100 + (int)e_; } while (0)
+#define GTOS_RB_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return 100 + (int)e_; } while (0)
+
+inline dim3 grid_for(int64_t n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
+
+__global__ void k_special(Geom G, uint64_t* key, int32_t* posn, int32_t* len_seen) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) special_keys(G, key, posn, len_seen);
+}
+// one thread per (graph, source): 64-thread blocks so that a batch's few thousand searches spread over the CUs
+__global__ void k_bfs(Geom G, Graphs gr, Scratch sc) {
+    const int32_t s = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (s < G.S) bfs_source(s, G, gr, sc);
+}
+__global__ void k_pair_key(Geom G, Graphs gr, Scratch sc, uint64_t* key, int32_t* posn, int32_t* len_seen) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < G.P) pair_key(p, G, gr, sc, key, posn, len_seen);
+}
+__global__ void k_head_flag(int64_t total, const uint64_t* key, uint32_t* flag) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < total) head_flag(e, key, flag);
+}
+__global__ void k_segment_first(int64_t total, const uint64_t* key, const int32_t* posn, const uint32_t* cum, uint32_t* first_pos, int32_t* seg_id,
+                                uint64_t* seg_key) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < total) segment_first(e, key, posn, cum, first_pos, seg_id, seg_key);
+}
+__global__ void k_sizes(const uint32_t* cum, int64_t total, const int32_t* len_seen, int32_t* sizes) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) sizes_after_scan(cum, total, len_seen, sizes);
+}
+__global__ void k_type_of_segment(int64_t R, const int32_t* sorted_seg, const uint64_t* seg_key, int32_t* type_of_seg, int64_t* bank, int64_t* length) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < R) type_of_segment(r, sorted_seg, seg_key, type_of_seg, R, bank, length);
+}
+__global__ void k_scatter_relation(int64_t total, Geom G, Graphs gr, const int32_t* posn, const uint32_t* cum, const int32_t* type_of_seg,
+                                   int64_t* relation) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < total) scatter_relation(e, G, gr, posn, cum, type_of_seg, relation);
+}
+__global__ void k_cls_cells(Geom G, Graphs gr, int64_t* relation) {
+    const int32_t s = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (s < G.S) cls_cells(s, G, gr, relation);
+}
+
+int bits_for(int64_t n) {                 // radix-sort key bits that can be set in values below n
+    int b = 1;
+    while ((1ll << b) < n && b < 32) ++b;
+    return b;
+}
+
+}  // namespace
+
+// bytes_out[0] = rocPRIM temporary storage the two phases need for `total` = pairs + 3 elements.
+extern "C" int gtos_relbatch_dev_workspace(int64_t total, int64_t* bytes_out) {
+    if (total <= 0 || !bytes_out) return -1;
+    size_t a = 0, b = 0, c = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, a, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr,
+                              (size_t)total, 0, 64, (hipStream_t)0);
+    (void)rocprim::inclusive_scan(nullptr, b, (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)total, rocprim::plus<uint32_t>(), (hipStream_t)0);
+    (void)rocprim::radix_sort_pairs(nullptr, c, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr,
+                              (size_t)total, 0, 32, (hipStream_t)0);
+    size_t m = a > b ? a : b;
+    m = m > c ? m : c;
+    bytes_out[0] = (int64_t)(m + 256);
+    return 0;
+}
+
+// Phase A.  geom: int64[GE_COUNT] host integers; tab: host table of device pointers (enum T_* of relbatch_kernels.h); relation is
+// zero-filled by the caller.  Afterwards sizes[RZ_R] = distinct paths (bank columns), sizes[RZ_L] = the longest of them.
+extern "C" int gtos_relbatch_dev_phase_a(const int64_t* geom, void** tab, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!geom || !tab || !workspace) return -1;
+    const Geom G = geom_of(geom);
+    if (!geom_ok(G)) return -1;
+    for (int k = 0; k <= T_SEG_KEY; ++k) if (!tab[k]) return -1;
+    if (!tab[T_LEN_SEEN] || !tab[T_SIZES]) return -1;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Graphs gr = graphs_of(tab);
+    const Scratch sc = scratch_of(tab);
+    uint64_t *key = (uint64_t*)tab[T_KEY], *skey = (uint64_t*)tab[T_SKEY], *seg_key = (uint64_t*)tab[T_SEG_KEY];
+    int32_t *posn = (int32_t*)tab[T_POSN], *spos = (int32_t*)tab[T_SPOS], *seg_id = (int32_t*)tab[T_SEG_ID];
+    uint32_t *flag = (uint32_t*)tab[T_FLAG], *cum = (uint32_t*)tab[T_CUM], *first_pos = (uint32_t*)tab[T_FIRST_POS];
+    int32_t *len_seen = (int32_t*)tab[T_LEN_SEEN], *sizes = (int32_t*)tab[T_SIZES];
+    const int64_t total = G.P + N_SPECIAL;
+    GTOS_RB_HIP(hipMemsetAsync(len_seen, 0, 8 * sizeof(int32_t), s));
+    GTOS_RB_HIP(hipMemsetAsync(sizes, 0, RZ_TOTAL * sizeof(int32_t), s));
+    hipLaunchKernelGGL(k_special, dim3(1), dim3(64), 0, s, G, key, posn, len_seen);
+    GTOS_RB_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bfs, grid_for(G.S, 64), dim3(64), 0, s, G, gr, sc);
+    GTOS_RB_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_pair_key, grid_for(G.P, 256), dim3(256), 0, s, G, gr, sc, key, posn, len_seen);
+    GTOS_RB_LAUNCH_CHECK();
+    size_t bytes = workspace_bytes;
+    GTOS_RB_HIP(rocprim::radix_sort_pairs(workspace, bytes, (const uint64_t*)key, skey, (const int32_t*)posn, spos, (size_t)total, 0, 64, s));
+    hipLaunchKernelGGL(k_head_flag, grid_for(total, 256), dim3(256), 0, s, total, (const uint64_t*)skey, flag);
+    GTOS_RB_LAUNCH_CHECK();
+    bytes = workspace_bytes;
+    GTOS_RB_HIP(rocprim::inclusive_scan(workspace, bytes, (const uint32_t*)flag, cum, (size_t)total, rocprim::plus<uint32_t>(), s));
+    hipLaunchKernelGGL(k_segment_first, grid_for(total, 256), dim3(256), 0, s, total, (const uint64_t*)skey, (const int32_t*)spos, (const uint32_t*)cum,
+                       first_pos, seg_id, seg_key);
+    GTOS_RB_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_sizes, dim3(1), dim3(64), 0, s, (const uint32_t*)cum, total, (const int32_t*)len_seen, sizes);
+    GTOS_RB_LAUNCH_CHECK();
+    return 0;
+}
+
+// Phase B: R = sizes[RZ_R] as the host read it; bank int64 [8, R] zero-filled, length int64 [R], first_alt / sorted_seg / type_of_seg [R].
+extern "C" int gtos_relbatch_dev_phase_b(const int64_t* geom, int64_t R, void** tab, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!geom || !tab || !workspace || R < N_SPECIAL) return -1;
+    const Geom G = geom_of(geom);
+    if (!geom_ok(G)) return -1;
+    for (int k = 0; k < T_TABLE_COUNT; ++k) if (!tab[k]) return -1;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Graphs gr = graphs_of(tab);
+    const int64_t total = G.P + N_SPECIAL;
+    if (R > total) return -1;
+    size_t bytes = workspace_bytes;
+    GTOS_RB_HIP(rocprim::radix_sort_pairs(workspace, bytes, (const uint32_t*)tab[T_FIRST_POS], (uint32_t*)tab[T_FIRST_ALT], (const int32_t*)tab[T_SEG_ID],
+                                          (int32_t*)tab[T_SORTED_SEG], (size_t)R, 0, bits_for(total), s));
+    hipLaunchKernelGGL(k_type_of_segment, grid_for(R, 256), dim3(256), 0, s, R, (const int32_t*)tab[T_SORTED_SEG], (const uint64_t*)tab[T_SEG_KEY],
+                       (int32_t*)tab[T_TYPE_OF_SEG], (int64_t*)tab[T_BANK], (int64_t*)tab[T_LENGTH]);
+    GTOS_RB_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_scatter_relation, grid_for(total, 256), dim3(256), 0, s, total, G, gr, (const int32_t*)tab[T_SPOS], (const uint32_t*)tab[T_CUM],
+                       (const int32_t*)tab[T_TYPE_OF_SEG], (int64_t*)tab[T_RELATION]);
+    GTOS_RB_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_cls_cells, grid_for(G.S, 256), dim3(256), 0, s, G, gr, (int64_t*)tab[T_RELATION]);
+    GTOS_RB_LAUNCH_CHECK();
+    return 0;
+}

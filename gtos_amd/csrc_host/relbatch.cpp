@@ -320,3 +320,29 @@ extern "C" int gtos_relbatch_export(const gtos_relbatch* h, int64_t* relation, i
 }
 
 extern "C" void gtos_relbatch_free(gtos_relbatch* h) { delete h; }
+
+// The batch's graphs as the GPU relation-batch builder reads them (gtos_amd/csrc/relbatch_kernels.h struct Graphs): the same ordered
+// adjacency and BFS order as gtos_relbatch_build uses, flattened.  The all-pairs work stays with the caller.
+extern "C" int64_t gtos_relbatch_csr(int B, const int* n_nodes, const int* roots, const int64_t* edge_off, const int* e_src, const int* e_dst,
+                                     const int* e_label, int32_t* node_off, int32_t* adj_base, int32_t* adj_off, int32_t* adj_dst,
+                                     int32_t* adj_lab, int32_t* order, int32_t* depth) {
+    if (B <= 0 || !n_nodes || !roots || !edge_off || !node_off || !adj_base || !adj_off || !adj_dst || !adj_lab || !order || !depth) return -1;
+    int64_t nodes = 0, adj = 0;
+    Graph g;
+    for (int b = 0; b < B; ++b) {
+        if (!build_graph(g, n_nodes[b], roots[b], edge_off[b], edge_off[b + 1], e_src, e_dst, e_label)) return -1;
+        if (nodes + g.n > 0x7fffffffLL || g.n > 32767 || g.adj_off[g.n] > 32767) return -1;   // the device scratch holds int16 ids
+        node_off[b] = (int32_t)nodes;
+        adj_base[b] = (int32_t)adj;
+        std::memcpy(adj_off + nodes + b, g.adj_off.data(), (size_t)(g.n + 1) * sizeof(int32_t));
+        std::memcpy(adj_dst + adj, g.adj_dst.data(), g.adj_dst.size() * sizeof(int32_t));
+        std::memcpy(adj_lab + adj, g.adj_lab.data(), g.adj_lab.size() * sizeof(int32_t));
+        std::memcpy(order + nodes, g.order.data(), (size_t)g.n * sizeof(int32_t));
+        std::memcpy(depth + nodes, g.depth.data(), (size_t)g.n * sizeof(int32_t));
+        nodes += g.n;
+        adj += (int64_t)g.adj_dst.size();
+    }
+    node_off[B] = (int32_t)nodes;
+    adj_base[B] = (int32_t)adj;
+    return adj;
+}

@@ -28,9 +28,9 @@ def _index_prep(batch, on):
     ``on="device"``: only the relation index is built here; the tries are left to the consumer's device (``Prefetcher(device_tries=
     True)`` builds them with torch ops on its copy stream, gtos_amd.pathtrie_device) -- the tries are the larger half of the
     host time of a batch (0.19 of 0.35 s per C2 batch on the development container)."""
-    if not on:
+    if not on or 'relation_graphs' in batch:      # ("device_all": nothing to index yet -- the relation tensors do not exist on the host)
         return batch
-    if on != "device":
+    if on not in ("device", "device_all"):
         try:
             batch['relation_trie'] = build_path_trie(batch['relation_bank'], batch['relation_length'])
         except ValueError:
@@ -55,6 +55,47 @@ def attach_device_tries(batch, how=True):
             else:
                 from .pathtrie_device import build_path_trie_device
                 batch['relation_trie'] = build_path_trie_device(batch['relation_bank'], batch['relation_length'])
+        except ValueError:
+            pass
+    return batch
+
+
+class RelationGraphs(object):
+    """The graphs of a batch flattened for the GPU relation-batch builder (gtos_amd.relbatch_hip.graphs_csr: ordered adjacency + BFS
+    order, a few thousand integers) with the arguments of the build: what a loader ships instead of relation / bank / length when the
+    all-pairs work is left to the consumer's device (``index_prep="device_all"``).  Host data; ``.to()`` returns self so that
+    ``{k: v.to(device) for k, v in batch.items()}`` passes it through."""
+
+    def __init__(self, csr, special_ids, path_mode, seed, max_len=8):
+        self.csr, self.special_ids, self.path_mode, self.seed, self.max_len = csr, tuple(int(v) for v in special_ids), path_mode, int(seed), max_len
+
+    def to(self, *a, **k):
+        return self
+
+
+def attach_device_relations(batch, device=None):
+    """``relation`` / ``relation_bank`` / ``relation_length`` of a batch that came with ``relation_graphs`` instead, built on ``device``
+    (default: the device of the batch's concept tensor) by the staged HIP builder (gtos_amd.relbatch_hip) on the current stream."""
+    rg = batch.get('relation_graphs')
+    if rg is None or 'relation' in batch:
+        return batch
+    from .relbatch_hip import HipBackend, build_relation_batch_staged
+    dev = batch['concept'].device if device is None else torch.device(device)
+    rel = build_relation_batch_staged(None, rg.special_ids, HipBackend.shared(), path_mode=rg.path_mode, seed=rg.seed, max_len=rg.max_len,
+                                      device=dev, csr=rg.csr)
+    batch['relation'], batch['relation_bank'], batch['relation_length'] = rel['relation'], rel['relation_bank'], rel['relation_length']
+    del batch['relation_graphs']
+    return batch
+
+
+def attach_device_relation_index(batch):
+    """``batch['relation_index']`` of a train-mode batch whose ``relation`` lives on the device, by the staged HIP builder
+    (gtos_amd.relindex_hip) on the current stream; outside that builder's case the batch is left alone (ops.FactoredRelation then
+    derives an index with torch ops)."""
+    if 'relation_index' not in batch and batch['relation'].dim() == 3:
+        from .relindex_hip import HipBackend, build_relation_index_staged
+        try:
+            batch['relation_index'] = build_relation_index_staged(batch['relation'], batch['relation_bank'].shape[1], HipBackend.shared())
         except ValueError:
             pass
     return batch
@@ -234,12 +275,22 @@ def batchify_amr(items, vocabs, train=True, seed=0, n_threads=0, unk_rate=0., rn
     (the model averages over K, so neither is observable)."""
     rv = vocabs['relation']
     graphs = [_item_graph(x, rv, graph_cache) for x in items]
-    rel = relbatch.build_relation_batch(graphs, relation_special_ids(rv),
-                                        path_mode=relbatch.PATH_UNIFORM if train else relbatch.PATH_ALL, seed=seed,
-                                        n_threads=n_threads)
-    for b, x in enumerate(items):
-        n = len(x['concept'])
-        assert rel['order'][b, :n].tolist() == list(range(n)), "items must list their concepts in BFS order"
+    if index_prep == "device_all" and train:
+        # the all-pairs work, the bank, the tries and the relation index are all left to the consumer's device: ship the graphs
+        from .relbatch_hip import graphs_csr
+        csr = graphs_csr(graphs)
+        for b, x in enumerate(items):
+            lo, hi = int(csr['node_off'][b]), int(csr['node_off'][b + 1])
+            assert csr['order'][lo:hi].tolist() == list(range(len(x['concept']))), "items must list their concepts in BFS order"
+        rel = {'relation_graphs': RelationGraphs(csr, relation_special_ids(rv), relbatch.PATH_UNIFORM, seed)}
+    else:
+        rel = relbatch.build_relation_batch(graphs, relation_special_ids(rv),
+                                            path_mode=relbatch.PATH_UNIFORM if train else relbatch.PATH_ALL, seed=seed,
+                                            n_threads=n_threads)
+        for b, x in enumerate(items):
+            n = len(x['concept'])
+            assert rel['order'][b, :n].tolist() == list(range(n)), "items must list their concepts in BFS order"
+        rel = {k: rel[k] for k in ('relation', 'relation_bank', 'relation_length')}
     cps, t2is, i2ts = [], [], []
     for x in items:
         cp_seq, t2i, i2t = copy_vocab(x['concept'], vocabs['predictable_token'])
@@ -250,7 +301,7 @@ def batchify_amr(items, vocabs, train=True, seed=0, n_threads=0, unk_rate=0., rn
         'concept': lists_to_tensor(with_cls, vocabs['concept'], unk_rate=unk_rate, rng=rng),
         'concept_char': strings_to_char_tensor(with_cls, vocabs['concept_char']),
         'concept_depth': lists_to_tensor([[0] + list(x['depth']) for x in items]),
-        'relation': rel['relation'], 'relation_bank': rel['relation_bank'], 'relation_length': rel['relation_length'],
+        **rel,
         'local_idx2token': i2ts, 'local_token2idx': t2is,
         'token_in': lists_to_tensor(aug, vocabs['token'], unk_rate=unk_rate, rng=rng)[:-1],
         'token_char_in': strings_to_char_tensor(aug, vocabs['token_char'])[:-1],
@@ -671,21 +722,33 @@ class Prefetcher(object):
             self._next_out += 1
             self._cv.notify_all()
         extra = None
-        if self._device_tries:
-            # The tries of a batch that came without them, built HERE, by the consumer's thread, as torch ops on the copy stream
-            # (behind the batch's upload, beside the previous step's kernels).  Built on the upload thread they cost 0.2 s per
-            # batch: ~200 small torch calls, each waiting for the interpreter lock the training loop holds (round 3, C2,
-            # 2 worker processes: 230 ms per step).
-            b0 = batch[0] if isinstance(batch, tuple) else batch
-            if 'relation_trie' not in b0:
+        b0 = batch[0] if isinstance(batch, tuple) else batch
+        if self._device_tries or 'relation_graphs' in b0:
+            # Index preparation left to the device, done HERE, by the consumer's thread, on the copy stream (behind the batch's upload,
+            # beside the previous step's kernels): the relation tensors of a batch that ships its graphs (index_prep="device_all":
+            # gtos_amd.relbatch_hip), the relation index of those (gtos_amd.relindex_hip) and the tries of a batch that came without
+            # them.  Built on the upload thread the torch-op tries cost 0.2 s per batch: ~200 small torch calls, each waiting for the
+            # interpreter lock the training loop holds (round 3, C2, 2 worker processes: 230 ms per step).
+            def prep():
+                made = []
+                if 'relation_graphs' in b0:
+                    attach_device_relations(b0, self._device)
+                    made += [b0['relation'], b0['relation_bank'], b0['relation_length']]
+                    if 'relation_index' not in b0:
+                        attach_device_relation_index(b0)
+                        made.append(b0.get('relation_index'))
+                if 'relation_trie' not in b0:
+                    attach_device_tries(b0, self._device_tries or "hip")
+                    made.append(b0.get('relation_trie'))
+                return made
+            if 'relation_trie' not in b0 or 'relation_graphs' in b0:
                 if self._copy_stream is not None:
                     with torch.cuda.stream(self._copy_stream):
-                        attach_device_tries(b0, self._device_tries)
+                        extra = prep()
                         ev = torch.cuda.Event()
                         ev.record(self._copy_stream)
                 else:
-                    attach_device_tries(b0, self._device_tries)
-                extra = b0.get('relation_trie')
+                    extra = prep()
         if ev is not None:
             cur = torch.cuda.current_stream(self._device)
             cur.wait_event(ev)

@@ -36,6 +36,8 @@ def load():
         lib.gtos_relbatch_export.argtypes = [P] * 6
         lib.gtos_relbatch_free.restype = None
         lib.gtos_relbatch_free.argtypes = [P]
+        lib.gtos_relbatch_csr.restype = ctypes.c_int64
+        lib.gtos_relbatch_csr.argtypes = [ctypes.c_int] + [P] * 13
         lib.gtos_pathtrie_build.restype = P
         lib.gtos_pathtrie_build.argtypes = [ctypes.c_int, ctypes.c_int64, P, P, ctypes.c_int]
         lib.gtos_pathtrie_sizes.restype = ctypes.c_int

@@ -112,6 +112,31 @@ int gtos_pathtrie_dev_phase_a(int L, int64_t R, const int64_t* bank, const int64
 int gtos_pathtrie_dev_phase_b(int64_t R, int64_t N, int n_pf, int n_sf, int chunk, int rows_per_wave, void** common, void** pf,
                               void** sf, int32_t* sizes, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- The relation tensors of a batch built on the GPU (csrc/relbatch_dev.hip; stages in csrc/relbatch_kernels.h): the device-side
+ * counterpart of gtos_relbatch_build in include/gtos_host.h for the one-path-per-pair modes (GTOS_PATH_FIRST / GTOS_PATH_UNIFORM), i.e.
+ * the relation section of batchify (generator/data.py:134-176, translator/data.py:132-176) over the all-pairs shortest label paths
+ * (generator/AMRGraph.py:100-115, translator/dependencyGraph.py:54-74).  The graphs arrive flattened by gtos_relbatch_csr
+ * (include/gtos_host.h).  Two phases with one host read between them; gtos_amd/relbatch_hip.py drives them.  geom = int64[13] host
+ * integers (enum GE_*), tab = host table of device pointers (enum T_*), both in csrc/relbatch_kernels.h; workspace = rocPRIM temporary
+ * storage of at least _workspace(pairs + 3) bytes.  After phase A sizes[0] = R (distinct paths), sizes[1] = L (the longest); phase B
+ * takes R back and fills relation int64 [n,n,B] (zero-filled by the caller), bank int64 [8,R] (zero-filled; rows >= L stay zero),
+ * length int64 [R].  Same type numbering (first-seen order) and the same uniform choice among alternative shortest paths (splitmix64
+ * stream keyed by seed, graph, source, target) as the host builder.  Opt-in (see the file's header for the measured status). */
+int gtos_relbatch_dev_workspace(int64_t total, int64_t* bytes_out);
+int gtos_relbatch_dev_phase_a(const int64_t* geom, void** tab, void* workspace, size_t workspace_bytes, void* stream);
+int gtos_relbatch_dev_phase_b(const int64_t* geom, int64_t R, void** tab, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- The relation index of the factored attention operand built on the GPU (csrc/relindex_dev.hip; stages in
+ * csrc/relindex_kernels.h): the device-side counterpart of gtos_relindex_build in include/gtos_host.h, same arrays (the index
+ * preparation that stands in for the dense expansion of generator/generator.py:79).  Two phases with one host read between them;
+ * gtos_amd/relindex_hip.py drives them.  geom = int64[6] host integers (enum GE_*), tab = host table of device pointers (enum T_*), both
+ * in csrc/relindex_kernels.h; workspace = rocPRIM temporary storage of at least _workspace(max(P, R)) bytes.  After phase A sizes =
+ * {error flag (a type id outside [0,R)), chunks, heavy types, -}; phase B takes the chunk count back.  Default chunk order of the host
+ * builder only (GTOS_BANK_BALANCE on, GTOS_HEAVY_FIRST off).  Opt-in (see the file's header for the measured status). */
+int gtos_relindex_dev_workspace(int64_t n, int64_t* bytes_out);
+int gtos_relindex_dev_phase_a(const int64_t* geom, void** tab, void* workspace, size_t workspace_bytes, void* stream);
+int gtos_relindex_dev_phase_b(const int64_t* geom, int64_t nchunks, void** tab, void* workspace, size_t workspace_bytes, void* stream);
+
 /* y = LayerNorm(x + dropout(r)) * gamma + beta (r may be NULL), saving mean/rstd per row.
  * Replaces F.dropout + nn.LayerNorm(residual + x): generator/graph_transformer.py:57-58,64-65;
  * generator/transformer.py:57-58,63-64,70-71; generator/decoder.py:35-36; generator/generator.py:73,172. */

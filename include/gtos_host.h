@@ -47,6 +47,18 @@ int gtos_relbatch_export(const gtos_relbatch* h, int64_t* relation, int64_t* ban
 
 void gtos_relbatch_free(gtos_relbatch* h);
 
+/* The batch's graphs flattened for the GPU relation-batch builder (include/gtos_hip.h gtos_relbatch_dev_*): the ordered adjacency
+ * (networkx insertion order, a repeated (src,dst) overwriting the label in place) and the BFS order / depth from the root that
+ * gtos_relbatch_build uses itself (generator/AMRGraph.py:76-98, translator/dependencyGraph.py:30-52).  Inputs as gtos_relbatch_build.
+ *   node_off [B+1]  prefix sums of n_nodes               adj_base [B+1]  first adjacency entry of graph g
+ *   adj_off  [S+B]  per graph n+1 LOCAL offsets, graph g's block at node_off[g] + g      (S = sum of n_nodes)
+ *   adj_dst, adj_lab [<= edge_off[B]]                     order, depth [S]  node id / BFS depth at each BFS position
+ * Returns the number of adjacency entries, -1 on invalid input (as gtos_relbatch_build; also a graph of more than 32,767 nodes or
+ * adjacency entries). */
+int64_t gtos_relbatch_csr(int B, const int* n_nodes, const int* roots, const int64_t* edge_off, const int* e_src, const int* e_dst,
+                          const int* e_label, int32_t* node_off, int32_t* adj_base, int32_t* adj_off, int32_t* adj_dst,
+                          int32_t* adj_lab, int32_t* order, int32_t* depth);
+
 /* ---- Prefix / suffix tries of a relation bank (gtos_amd/csrc_host/pathtrie.cpp).
  * Index preparation for the RelationEncoder of generator/encoder.py:66-119 on MI355X: the first bi-GRU layer runs once
  * per trie node instead of once per (sequence, position), the second layer's input-gate product splits into a

@@ -1,0 +1,63 @@
+// TEST INFRASTRUCTURE (oracle/): the GPU relation-batch builder's per-thread stages (gtos_amd/csrc/relbatch_kernels.h) run as serial
+// loops on the host, std::stable_sort and a running sum standing in for rocPRIM.  tests/test_relbatch_dev.py drives it through the
+// same Python glue as the HIP library (gtos_amd/relbatch_hip.py) and compares relation / bank / length with csrc_host/relbatch.cpp.
+// Not part of the product: nothing under gtos_amd/ loads this file.
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#include "../gtos_amd/csrc/relbatch_kernels.h"
+
+using namespace gtos_relbatch_dev;
+
+namespace {
+template <typename K, typename V>
+void sort_pairs(const K* key, const V* val, K* key_out, V* val_out, int64_t n) {
+    std::vector<int64_t> idx(n);
+    std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](int64_t a, int64_t b) { return key[a] < key[b]; });
+    for (int64_t i = 0; i < n; ++i) { key_out[i] = key[idx[i]]; val_out[i] = val[idx[i]]; }
+}
+}  // namespace
+
+extern "C" int gtos_relbatch_emul_phase_a(const int64_t* geom, void** tab) {
+    const Geom G = geom_of(geom);
+    if (!geom_ok(G)) return -1;
+    const Graphs gr = graphs_of(tab);
+    const Scratch sc = scratch_of(tab);
+    uint64_t *key = (uint64_t*)tab[T_KEY], *skey = (uint64_t*)tab[T_SKEY], *seg_key = (uint64_t*)tab[T_SEG_KEY];
+    int32_t *posn = (int32_t*)tab[T_POSN], *spos = (int32_t*)tab[T_SPOS], *seg_id = (int32_t*)tab[T_SEG_ID];
+    uint32_t *flag = (uint32_t*)tab[T_FLAG], *cum = (uint32_t*)tab[T_CUM], *first_pos = (uint32_t*)tab[T_FIRST_POS];
+    int32_t *len_seen = (int32_t*)tab[T_LEN_SEEN], *sizes = (int32_t*)tab[T_SIZES];
+    const int64_t total = G.P + N_SPECIAL;
+    std::memset(len_seen, 0, 8 * sizeof(int32_t));
+    std::memset(sizes, 0, RZ_TOTAL * sizeof(int32_t));
+    special_keys(G, key, posn, len_seen);
+    for (int32_t s = 0; s < G.S; ++s) bfs_source(s, G, gr, sc);
+    for (int64_t p = 0; p < G.P; ++p) pair_key(p, G, gr, sc, key, posn, len_seen);
+    sort_pairs(key, posn, skey, spos, total);
+    for (int64_t e = 0; e < total; ++e) head_flag(e, skey, flag);
+    uint32_t run = 0;
+    for (int64_t e = 0; e < total; ++e) { run += flag[e]; cum[e] = run; }
+    for (int64_t e = 0; e < total; ++e) segment_first(e, skey, spos, cum, first_pos, seg_id, seg_key);
+    sizes_after_scan(cum, total, len_seen, sizes);
+    return 0;
+}
+
+extern "C" int gtos_relbatch_emul_phase_b(const int64_t* geom, int64_t R, void** tab) {
+    const Geom G = geom_of(geom);
+    if (!geom_ok(G) || R < N_SPECIAL) return -1;
+    const Graphs gr = graphs_of(tab);
+    const int64_t total = G.P + N_SPECIAL;
+    if (((const int32_t*)tab[T_SIZES])[RZ_R] != R) return -2;             // the count the host read after phase A
+    sort_pairs((const uint32_t*)tab[T_FIRST_POS], (const int32_t*)tab[T_SEG_ID], (uint32_t*)tab[T_FIRST_ALT], (int32_t*)tab[T_SORTED_SEG], R);
+    for (int64_t r = 0; r < R; ++r)
+        type_of_segment(r, (const int32_t*)tab[T_SORTED_SEG], (const uint64_t*)tab[T_SEG_KEY], (int32_t*)tab[T_TYPE_OF_SEG], R, (int64_t*)tab[T_BANK],
+                        (int64_t*)tab[T_LENGTH]);
+    for (int64_t e = 0; e < total; ++e)
+        scatter_relation(e, G, gr, (const int32_t*)tab[T_SPOS], (const uint32_t*)tab[T_CUM], (const int32_t*)tab[T_TYPE_OF_SEG], (int64_t*)tab[T_RELATION]);
+    for (int32_t s = 0; s < G.S; ++s) cls_cells(s, G, gr, (int64_t*)tab[T_RELATION]);
+    return 0;
+}

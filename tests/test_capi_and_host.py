@@ -45,7 +45,7 @@ def test_host_library_exports_every_declared_symbol():
     src = open(os.path.join(ROOT, "include", "gtos_host.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     names = re.findall(r"\b(gtos_(?:relbatch|pathtrie|relindex)_\w+)\s*\(", src)
-    assert set(names) == {"gtos_relbatch_build", "gtos_relbatch_dims", "gtos_relbatch_export", "gtos_relbatch_free",
+    assert set(names) == {"gtos_relbatch_build", "gtos_relbatch_dims", "gtos_relbatch_export", "gtos_relbatch_free", "gtos_relbatch_csr",
                           "gtos_pathtrie_build", "gtos_pathtrie_sizes", "gtos_pathtrie_export", "gtos_pathtrie_free",
                           "gtos_pathtrie_derived_sizes", "gtos_pathtrie_export_derived",
                           "gtos_relindex_build", "gtos_relindex_sizes", "gtos_relindex_export", "gtos_relindex_free"}

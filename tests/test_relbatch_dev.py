@@ -1,0 +1,134 @@
+"""The staged GPU relation-batch builder (gtos_amd/relbatch_hip.py, csrc/relbatch_kernels.h) on the CPU: its per-thread stage code run
+as serial host loops (oracle/relbatch_emul.cpp) through the product's Python glue == the host builder (csrc_host/relbatch.cpp, itself
+bit-exact with the reference's batchify: tests/test_host_relbatch.py), array for array."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from gtos_amd import relbatch, synth
+from gtos_amd.relbatch_hip import PATH_FIRST, PATH_UNIFORM, _geom, _table, build_relation_batch_staged, graphs_csr
+
+IDS = (0, 2, 3, 4, 5)           # pad, cls, rcls, self, tl
+
+
+class EmulBackend(object):
+    def __init__(self):
+        from oracle.build_emul import build
+        self.lib = ctypes.CDLL(build("relbatch"))
+        P = ctypes.c_void_p
+        self.lib.gtos_relbatch_emul_phase_a.argtypes = [P, P]
+        self.lib.gtos_relbatch_emul_phase_b.argtypes = [P, ctypes.c_int64, P]
+
+    def phase_a(self, geom, bufs, total):
+        assert self.lib.gtos_relbatch_emul_phase_a(_geom(geom), _table(bufs)) == 0
+
+    def phase_b(self, geom, R, bufs, total):
+        assert self.lib.gtos_relbatch_emul_phase_b(_geom(geom), R, _table(bufs)) == 0
+
+
+def _random_graphs(seed, B, nlo, nhi, extra, labels=40, tree_only=False):
+    """connected labelled graphs in the builder's input form: a random rooted tree plus ``extra`` re-entrancy edges per node, every edge
+    doubled with a reverse label (generator/AMRGraph.py:76-80); a repeated (src, dst) now and then (networkx overwrites the label)."""
+    rng = np.random.RandomState(seed)
+    graphs = []
+    for _ in range(B):
+        n = int(rng.randint(nlo, nhi + 1))
+        edges = []
+        for v in range(1, n):
+            u = int(rng.randint(0, v))
+            l = int(rng.randint(6, 6 + labels))
+            edges += [(v, u, l), (u, v, l + labels)]
+        if not tree_only:
+            for _ in range(int(extra * n)):
+                u, v = int(rng.randint(0, n)), int(rng.randint(0, n))
+                if u != v:
+                    l = int(rng.randint(6, 6 + labels))
+                    edges += [(u, v, l), (v, u, l + labels)]
+        perm = rng.permutation(n)                      # node ids are not in BFS order
+        edges = [(int(perm[a]), int(perm[b]), l) for a, b, l in edges]
+        graphs.append((n, int(perm[0]), np.array(edges, dtype=np.int32).reshape(-1, 3)))
+    return graphs
+
+
+def _same(a, b):
+    bad = []
+    for k in ("relation", "relation_bank", "relation_length", "order", "depth"):
+        x, y = a[k], b[k]
+        if not (x.dtype == y.dtype and x.shape == y.shape and torch.equal(x.cpu(), y.cpu())):
+            bad.append((k, tuple(x.shape), tuple(y.shape)))
+    return bad
+
+
+@pytest.mark.parametrize("mode", [PATH_FIRST, PATH_UNIFORM])
+@pytest.mark.parametrize("seed,B,nlo,nhi,extra", [(1, 1, 1, 1, 0.0), (2, 3, 2, 9, 0.3), (3, 5, 10, 30, 0.1), (4, 4, 20, 40, 1.0), (5, 8, 30, 30, 0.1)])
+def test_staged_relation_batch_stages_equal_the_host_builder(mode, seed, B, nlo, nhi, extra):
+    graphs = _random_graphs(seed, B, nlo, nhi, extra)
+    host = relbatch.build_relation_batch(graphs, IDS, path_mode=mode, seed=1234 + seed, n_threads=1)
+    staged = build_relation_batch_staged(graphs, IDS, EmulBackend(), path_mode=mode, seed=1234 + seed)
+    assert _same(host, staged) == []
+
+
+def test_staged_relation_batch_long_paths_high_seed_and_limits():
+    graphs = _random_graphs(7, 3, 40, 60, 0.0, tree_only=True)               # deep trees: distances beyond 8 collapse to <TL>
+    for max_len in (8, 3, 1):
+        for seed in (0, (1 << 64) - 3):
+            host = relbatch.build_relation_batch(graphs, IDS, path_mode=PATH_UNIFORM, seed=seed, max_len=max_len, n_threads=1)
+            staged = build_relation_batch_staged(graphs, IDS, EmulBackend(), path_mode=PATH_UNIFORM, seed=seed, max_len=max_len)
+            assert _same(host, staged) == []
+    with pytest.raises(ValueError):
+        build_relation_batch_staged(graphs, IDS, EmulBackend(), path_mode=relbatch.PATH_ALL)
+    with pytest.raises(ValueError):                                          # a disconnected graph
+        build_relation_batch_staged([(3, 0, np.array([[0, 1, 7], [1, 0, 8]], np.int32))], IDS, EmulBackend())
+    with pytest.raises(ValueError):
+        build_relation_batch_staged(graphs, (0, 2, 2, 4, 5), EmulBackend())
+
+
+def test_staged_relation_batch_on_the_synthetic_amr_batches():
+    """the loader's own graphs (synth items of a BASELINE config, through data._item_graph) in training mode"""
+    from gtos_amd import data
+    vocabs = synth.synth_vocabs()
+    items, graphs = synth.make_amr_items("C1", 8, first_graph=0, vocabs=vocabs)
+    rv = vocabs['relation']
+    assert [g[0] for g in graphs] == [len(x['concept']) for x in items]
+    ids = data.relation_special_ids(rv)
+    host = relbatch.build_relation_batch(graphs, ids, path_mode=PATH_UNIFORM, seed=99, n_threads=2)
+    staged = build_relation_batch_staged(graphs, ids, EmulBackend(), path_mode=PATH_UNIFORM, seed=99)
+    assert _same(host, staged) == []
+    c = graphs_csr(graphs)
+    assert c["S"] == sum(g[0] for g in graphs) and c["P"] == sum(g[0] ** 2 for g in graphs)
+
+
+def test_device_all_loader_path_equals_the_host_loader(monkeypatch):
+    """index_prep="device_all": the loader ships the flattened graphs only; attach_device_relations / attach_device_relation_index /
+    attach_device_tries (here with the emulation backends on CPU tensors) rebuild relation, bank, length, index and tries equal to what
+    the host loader ships for the same job."""
+    import random
+    from gtos_amd import data, pathtrie_hip, relbatch_hip, relindex_hip
+    from test_pathtrie import _EmulBackend as TrieEmul, _same_object
+    from test_relindex_dev import EmulBackend as IndexEmul
+    monkeypatch.setattr(relbatch_hip.HipBackend, "shared", classmethod(lambda cls: EmulBackend()))
+    monkeypatch.setattr(relindex_hip.HipBackend, "shared", classmethod(lambda cls: IndexEmul()))
+    monkeypatch.setattr(pathtrie_hip.HipBackend, "shared", classmethod(lambda cls: TrieEmul()))
+    vocabs = synth.synth_vocabs()
+    items, graphs = synth.make_amr_items("C1", 16, first_graph=0, vocabs=vocabs)
+    unit = data.AMRLoader.size_of(items[0])
+
+    def loader(prep):
+        return data.AMRLoader(vocabs, items, batch_size=8 * unit - unit // 2, for_train=True, rng=random.Random(5), n_threads=1, graphs=graphs,
+                              index_prep=prep)
+    host_ld, dev_ld = loader(True), loader("device_all")
+    for jh, jd in zip(list(host_ld.jobs())[:2], list(dev_ld.jobs())[:2]):
+        assert jh == jd
+        want, got = host_ld.run_job(jh), dev_ld.run_job(jd)
+        assert 'relation' not in got and 'relation_index' not in got and 'relation_trie' not in got
+        got = {k: (v.to("cpu") if hasattr(v, "to") else v) for k, v in got.items()}          # RelationGraphs passes through
+        data.attach_device_relations(got, "cpu")
+        data.attach_device_relation_index(got)
+        data.attach_device_tries(got, "hip")
+        assert 'relation_graphs' not in got
+        for k in ("relation", "relation_bank", "relation_length", "concept", "token_in", "token_out", "cp_seq", "concept_depth"):
+            assert torch.equal(want[k], got[k]), k
+        assert _same_object(want["relation_index"], got["relation_index"]) == []
+        assert _same_object(want["relation_trie"], got["relation_trie"]) == []

@@ -1,0 +1,58 @@
+"""The staged GPU relation-index builder (gtos_amd/relindex_hip.py, csrc/relindex_kernels.h) on the CPU: its per-thread stage code run as
+serial host loops (oracle/relindex_emul.cpp) through the product's Python glue == the host builder (csrc_host/relindex.cpp), array for
+array."""
+import ctypes
+
+import pytest
+import torch
+
+from gtos_amd import synth
+from gtos_amd.relindex import build_relation_index
+from gtos_amd.relindex_hip import _geom, _table, build_relation_index_staged
+from test_pathtrie import _same_object
+
+
+class EmulBackend(object):
+    def __init__(self):
+        from oracle.build_emul import build
+        self.lib = ctypes.CDLL(build("relindex"))
+        P = ctypes.c_void_p
+        self.lib.gtos_relindex_emul_phase_a.argtypes = [P, P]
+        self.lib.gtos_relindex_emul_phase_b.argtypes = [P, ctypes.c_int64, P]
+
+    def phase_a(self, geom, bufs):
+        assert self.lib.gtos_relindex_emul_phase_a(_geom(geom), _table(bufs)) == 0
+
+    def phase_b(self, geom, nchunks, bufs):
+        assert self.lib.gtos_relindex_emul_phase_b(_geom(geom), nchunks, _table(bufs)) == 0
+
+
+def _random_relation(seed, n, B, R, heavy=0.3):
+    """type ids with a few very frequent types (the <CLS> / <SELF> / <TL> pattern), many rare ones and some that never occur"""
+    g = torch.Generator().manual_seed(seed)
+    rel = torch.randint(0, R, (n, n, B), generator=g)
+    hot = torch.rand((n, n, B), generator=g) < heavy
+    rel[hot] = torch.randint(0, min(R, 4), (int(hot.sum()),), generator=g)
+    return rel
+
+
+@pytest.mark.parametrize("seed,n,B,R", [(1, 1, 1, 1), (2, 5, 3, 40), (3, 9, 8, 300), (4, 13, 16, 2000), (5, 21, 7, 50), (6, 30, 64, 20000)])
+@pytest.mark.parametrize("chunk", [32, 4])
+def test_staged_relation_index_stages_equal_the_host_builder(seed, n, B, R, chunk):
+    rel = _random_relation(seed, n, B, R)
+    host = build_relation_index(rel, R, chunk=chunk)
+    staged = build_relation_index_staged(rel, R, EmulBackend(), chunk=chunk)
+    assert _same_object(host, staged) == []
+
+
+def test_staged_relation_index_on_amr_batches_and_limits(monkeypatch):
+    for name, B in (("C1", 8), ("C2", 16)):
+        batch, _ = synth.make_config_batch(name, rank=0, B=B)
+        R = batch["relation_bank"].shape[1]
+        host = build_relation_index(batch["relation"], R)
+        assert _same_object(host, build_relation_index_staged(batch["relation"], R, EmulBackend())) == []
+    with pytest.raises(ValueError):
+        build_relation_index_staged(torch.full((2, 2, 2), 7), 5, EmulBackend())
+    monkeypatch.setenv("GTOS_BANK_BALANCE", "0")
+    with pytest.raises(ValueError):
+        build_relation_index_staged(torch.zeros((2, 2, 2), dtype=torch.int64), 5, EmulBackend())
