@@ -81,6 +81,10 @@ def parse():
                     help="--fresh-batches: the workers build the relation index only; the path tries are built on the GPU on the loader's "
                          "copy stream: 'torch' (default when the flag is given bare) = torch ops (gtos_amd.pathtrie_device), 'hip' = the "
                          "staged HIP builder (gtos_amd.pathtrie_hip: rocPRIM sorts / scans + stage kernels, 2 host reads)")
+    ap.add_argument("--device-relations", action="store_true",
+                    help="--fresh-batches: the loader ships the flattened graphs only (index_prep='device_all'); relation / bank / length "
+                         "(gtos_amd.relbatch_hip), the relation index (gtos_amd.relindex_hip) and the tries (gtos_amd.pathtrie_hip) are built on "
+                         "the GPU on the loader's copy stream -- the host keeps the token / character tensors")
     ap.add_argument("--pool", type=int, default=0, help="--fresh-batches: graphs in the per-rank item pool (default 4 batches)")
     ap.add_argument("--prewarm-seconds", type=float, default=20.0,
                     help="untimed device pre-warm BEFORE the --warmup steps: windows of 5 training steps until two consecutive windows "
@@ -467,7 +471,7 @@ def main():
         unit = data_mod.AMRLoader.size_of(items[0])                       # every item of a config has the same size
         loader = data_mod.AMRLoader(vocabs_s, items, batch_size=B_rank * unit - unit // 2, for_train=True,
                                     rng=random.Random(19940117 + rank), n_threads=a.relbatch_threads, graphs=graphs,
-                                    index_prep="device" if a.device_tries else True)
+                                    index_prep="device_all" if a.device_relations else ("device" if a.device_tries else True))
         a.depth = a.depth or 2 * a.workers
         asm_times = []
 
@@ -482,10 +486,10 @@ def main():
                 yield from loader.jobs()
         if a.loader == "processes":
             feed = data_mod.Prefetcher(jobs(), depth=a.depth, workers=a.workers, device=dev, processes=True, runner=timed_run,
-                                       device_tries=a.device_tries or False)
+                                       device_tries=a.device_tries or ("hip" if a.device_relations else False))
         else:
             feed = data_mod.Prefetcher((lambda j=j: timed_run(j) for j in jobs()), depth=a.depth, workers=a.workers, device=dev,
-                                       device_tries=a.device_tries or False)
+                                       device_tries=a.device_tries or ("hip" if a.device_relations else False))
         batch = next(feed)
         stats = {"n": int(batch["concept"].shape[0]), "B": int(batch["concept"].shape[1]), "T": int(batch["token_in"].shape[0]),
                  "R": int(batch["relation_bank"].shape[1]),
@@ -494,7 +498,8 @@ def main():
         asm_times.append(batch.pop("_assembly_s"))
         loader_info = {"workers": a.workers, "kind": a.loader, "depth": a.depth, "relbatch_threads": a.relbatch_threads,
                        "tries": {"torch": "device (torch ops on the copy stream)", "hip": "device (staged HIP builder on the copy stream)",
-                                 "": "host (worker)"}[a.device_tries],
+                                 "": "host (worker)"}[a.device_tries or ("hip" if a.device_relations else "")],
+                       "relations": "device (staged HIP builders: relation / bank / index)" if a.device_relations else "host (worker)",
                        "pool_graphs_per_rank": pool_n, "device_memory_free_gb_at_start": round(free_b / 2 ** 30, 1),
                        "allocator": "default" if os.environ.get("GTOS_BENCH_NO_ROUNDUP") else "roundup_power2_divisions:16"}
     else:

@@ -36,23 +36,23 @@ __global__ void k_pair_key(Geom G, Graphs gr, Scratch sc, uint64_t* key, int32_t
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p < G.P) pair_key(p, G, gr, sc, key, posn, len_seen);
 }
-__global__ void k_head_flag(int64_t total, const uint64_t* key, uint32_t* flag) {
+__global__ void k_head_flag(int64_t total, const uint64_t* key, uint64_t* flag) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e < total) head_flag(e, key, flag);
 }
-__global__ void k_segment_first(int64_t total, const uint64_t* key, const int32_t* posn, const uint32_t* cum, uint32_t* first_pos, int32_t* seg_id,
+__global__ void k_segment_first(int64_t total, const uint64_t* key, const int32_t* posn, const uint64_t* cum, uint32_t* first_pos, int32_t* seg_id,
                                 uint64_t* seg_key) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e < total) segment_first(e, key, posn, cum, first_pos, seg_id, seg_key);
 }
-__global__ void k_sizes(const uint32_t* cum, int64_t total, const int32_t* len_seen, int32_t* sizes) {
+__global__ void k_sizes(const uint64_t* cum, int64_t total, const int32_t* len_seen, int32_t* sizes) {
     if (blockIdx.x == 0 && threadIdx.x == 0) sizes_after_scan(cum, total, len_seen, sizes);
 }
 __global__ void k_type_of_segment(int64_t R, const int32_t* sorted_seg, const uint64_t* seg_key, int32_t* type_of_seg, int64_t* bank, int64_t* length) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r < R) type_of_segment(r, sorted_seg, seg_key, type_of_seg, R, bank, length);
 }
-__global__ void k_scatter_relation(int64_t total, Geom G, Graphs gr, const int32_t* posn, const uint32_t* cum, const int32_t* type_of_seg,
+__global__ void k_scatter_relation(int64_t total, Geom G, Graphs gr, const int32_t* posn, const uint64_t* cum, const int32_t* type_of_seg,
                                    int64_t* relation) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e < total) scatter_relation(e, G, gr, posn, cum, type_of_seg, relation);
@@ -76,7 +76,7 @@ extern "C" int gtos_relbatch_dev_workspace(int64_t total, int64_t* bytes_out) {
     size_t a = 0, b = 0, c = 0;
     (void)rocprim::radix_sort_pairs(nullptr, a, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr,
                               (size_t)total, 0, 64, (hipStream_t)0);
-    (void)rocprim::inclusive_scan(nullptr, b, (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)total, rocprim::plus<uint32_t>(), (hipStream_t)0);
+    (void)rocprim::inclusive_scan(nullptr, b, (const uint64_t*)nullptr, (uint64_t*)nullptr, (size_t)total, rocprim::plus<uint64_t>(), (hipStream_t)0);
     (void)rocprim::radix_sort_pairs(nullptr, c, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr,
                               (size_t)total, 0, 32, (hipStream_t)0);
     size_t m = a > b ? a : b;
@@ -98,7 +98,8 @@ extern "C" int gtos_relbatch_dev_phase_a(const int64_t* geom, void** tab, void* 
     const Scratch sc = scratch_of(tab);
     uint64_t *key = (uint64_t*)tab[T_KEY], *skey = (uint64_t*)tab[T_SKEY], *seg_key = (uint64_t*)tab[T_SEG_KEY];
     int32_t *posn = (int32_t*)tab[T_POSN], *spos = (int32_t*)tab[T_SPOS], *seg_id = (int32_t*)tab[T_SEG_ID];
-    uint32_t *flag = (uint32_t*)tab[T_FLAG], *cum = (uint32_t*)tab[T_CUM], *first_pos = (uint32_t*)tab[T_FIRST_POS];
+    uint64_t *flag = (uint64_t*)tab[T_FLAG], *cum = (uint64_t*)tab[T_CUM];
+    uint32_t* first_pos = (uint32_t*)tab[T_FIRST_POS];
     int32_t *len_seen = (int32_t*)tab[T_LEN_SEEN], *sizes = (int32_t*)tab[T_SIZES];
     const int64_t total = G.P + N_SPECIAL;
     GTOS_RB_HIP(hipMemsetAsync(len_seen, 0, 8 * sizeof(int32_t), s));
@@ -114,11 +115,11 @@ extern "C" int gtos_relbatch_dev_phase_a(const int64_t* geom, void** tab, void* 
     hipLaunchKernelGGL(k_head_flag, grid_for(total, 256), dim3(256), 0, s, total, (const uint64_t*)skey, flag);
     GTOS_RB_LAUNCH_CHECK();
     bytes = workspace_bytes;
-    GTOS_RB_HIP(rocprim::inclusive_scan(workspace, bytes, (const uint32_t*)flag, cum, (size_t)total, rocprim::plus<uint32_t>(), s));
-    hipLaunchKernelGGL(k_segment_first, grid_for(total, 256), dim3(256), 0, s, total, (const uint64_t*)skey, (const int32_t*)spos, (const uint32_t*)cum,
+    GTOS_RB_HIP(rocprim::inclusive_scan(workspace, bytes, (const uint64_t*)flag, cum, (size_t)total, rocprim::plus<uint64_t>(), s));
+    hipLaunchKernelGGL(k_segment_first, grid_for(total, 256), dim3(256), 0, s, total, (const uint64_t*)skey, (const int32_t*)spos, (const uint64_t*)cum,
                        first_pos, seg_id, seg_key);
     GTOS_RB_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_sizes, dim3(1), dim3(64), 0, s, (const uint32_t*)cum, total, (const int32_t*)len_seen, sizes);
+    hipLaunchKernelGGL(k_sizes, dim3(1), dim3(64), 0, s, (const uint64_t*)cum, total, (const int32_t*)len_seen, sizes);
     GTOS_RB_LAUNCH_CHECK();
     return 0;
 }
@@ -139,7 +140,7 @@ extern "C" int gtos_relbatch_dev_phase_b(const int64_t* geom, int64_t R, void** 
     hipLaunchKernelGGL(k_type_of_segment, grid_for(R, 256), dim3(256), 0, s, R, (const int32_t*)tab[T_SORTED_SEG], (const uint64_t*)tab[T_SEG_KEY],
                        (int32_t*)tab[T_TYPE_OF_SEG], (int64_t*)tab[T_BANK], (int64_t*)tab[T_LENGTH]);
     GTOS_RB_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_scatter_relation, grid_for(total, 256), dim3(256), 0, s, total, G, gr, (const int32_t*)tab[T_SPOS], (const uint32_t*)tab[T_CUM],
+    hipLaunchKernelGGL(k_scatter_relation, grid_for(total, 256), dim3(256), 0, s, total, G, gr, (const int32_t*)tab[T_SPOS], (const uint64_t*)tab[T_CUM],
                        (const int32_t*)tab[T_TYPE_OF_SEG], (int64_t*)tab[T_RELATION]);
     GTOS_RB_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_cls_cells, grid_for(G.S, 256), dim3(256), 0, s, G, gr, (int64_t*)tab[T_RELATION]);

@@ -26,7 +26,7 @@ namespace gtos_relbatch_dev {
 
 enum { MODE_FIRST = 0, MODE_UNIFORM = 1 };
 // sizes[] written on the device, read by the host once per batch
-enum { RZ_R = 0, RZ_L = 1, RZ_TOTAL = 4 };
+enum { RZ_R = 0, RZ_L = 1, RZ_N = 2, RZ_TOTAL = 4 };     // distinct paths, longest path, sum of their lengths
 enum { N_SPECIAL = 3 };                                   // <CLS>, <rCLS>, <SELF> are interned before any pair (relbatch.cpp phase b)
 
 struct Geom {
@@ -167,19 +167,30 @@ GTOS_RB_HD void special_keys(const Geom& G, uint64_t* key, int32_t* posn, int32_
     len_seen[0] = 1;
 }
 
-// ---- stage 3 (after the stable key sort): element e opens a distinct key
-GTOS_RB_HD void head_flag(int64_t e, const uint64_t* key, uint32_t* flag) { flag[e] = (e == 0 || key[e] != key[e - 1]) ? 1u : 0u; }
-
-// after the inclusive scan of the flags: segment of e = cum[e] - 1; a head records its segment's key and first position
-GTOS_RB_HD void segment_first(int64_t e, const uint64_t* key, const int32_t* posn, const uint32_t* cum, uint32_t* first_pos, int32_t* seg_id,
-                              uint64_t* seg_key) {
-    const uint32_t sg = cum[e] - 1;
-    if (e == 0 || cum[e] != cum[e - 1]) { first_pos[sg] = (uint32_t)posn[e]; seg_id[sg] = (int32_t)sg; seg_key[sg] = key[e]; }
+GTOS_RB_HD int32_t key_labels(uint64_t k) {                // labels of a packed path (>= 1: key 0 is a one-label path of id 0)
+    int32_t l = 0;
+    while (k) { ++l; k >>= 8; }
+    return l < 1 ? 1 : l;
 }
 
-// one thread: R = distinct keys, L = the longest path among them (len_seen[l - 1]: a key of l labels exists)
-GTOS_RB_HD void sizes_after_scan(const uint32_t* cum, int64_t total, const int32_t* len_seen, int32_t* sizes) {
-    sizes[RZ_R] = (int32_t)cum[total - 1];
+// ---- stage 3 (after the stable key sort): element e opens a distinct key.  The scan input carries two counters in one 64-bit word:
+// low half 1 per distinct key, high half the key's length -- the inclusive plus-scan then gives the segment of every element (low)
+// and, at the end, the row count of the bank (high: sum of the path lengths, < 2^32).
+GTOS_RB_HD void head_flag(int64_t e, const uint64_t* key, uint64_t* flag) {
+    flag[e] = (e == 0 || key[e] != key[e - 1]) ? (((uint64_t)key_labels(key[e]) << 32) | 1ull) : 0ull;
+}
+
+// after the inclusive scan of the flags: segment of e = low(cum[e]) - 1; a head records its segment's key and first position
+GTOS_RB_HD void segment_first(int64_t e, const uint64_t* key, const int32_t* posn, const uint64_t* cum, uint32_t* first_pos, int32_t* seg_id,
+                              uint64_t* seg_key) {
+    const uint32_t c = (uint32_t)cum[e];
+    if (e == 0 || c != (uint32_t)cum[e - 1]) { first_pos[c - 1] = (uint32_t)posn[e]; seg_id[c - 1] = (int32_t)(c - 1); seg_key[c - 1] = key[e]; }
+}
+
+// one thread: R = distinct keys, N = sum of their lengths, L = the longest path among them (len_seen[l - 1]: a key of l labels exists)
+GTOS_RB_HD void sizes_after_scan(const uint64_t* cum, int64_t total, const int32_t* len_seen, int32_t* sizes) {
+    sizes[RZ_R] = (int32_t)(uint32_t)cum[total - 1];
+    sizes[RZ_N] = (int32_t)(cum[total - 1] >> 32);
     int32_t L = 1;
     for (int32_t l = 0; l < 8; ++l) if (len_seen[l]) L = l + 1;
     sizes[RZ_L] = L;
@@ -198,7 +209,7 @@ GTOS_RB_HD void type_of_segment(int64_t r, const int32_t* sorted_seg, const uint
 }
 
 // ---- stage 5: relation[a = j + 1][c = i + 1][g] = type of the pair's key (element e of the sorted list)
-GTOS_RB_HD void scatter_relation(int64_t e, const Geom& G, const Graphs& gr, const int32_t* posn, const uint32_t* cum, const int32_t* type_of_seg,
+GTOS_RB_HD void scatter_relation(int64_t e, const Geom& G, const Graphs& gr, const int32_t* posn, const uint64_t* cum, const int32_t* type_of_seg,
                                  int64_t* relation) {
     const int32_t pos = posn[e];
     if (pos < N_SPECIAL) return;
@@ -207,7 +218,7 @@ GTOS_RB_HD void scatter_relation(int64_t e, const Geom& G, const Graphs& gr, con
     const int32_t n = gr.ng[g];
     const int64_t q = p - gr.pair_off[g];
     const int32_t i = (int32_t)(q / n), j = (int32_t)(q % n);
-    relation[((int64_t)(j + 1) * G.n + (i + 1)) * G.B + g] = type_of_seg[cum[e] - 1];
+    relation[((int64_t)(j + 1) * G.n + (i + 1)) * G.B + g] = type_of_seg[(uint32_t)cum[e] - 1];
 }
 
 // the <CLS> row / column of graph g at node position a - 1: brs[0] = [<SELF>, <CLS> ...], brs[c][0] = <rCLS> (relbatch.cpp phase b).
@@ -247,8 +258,8 @@ enum { T_NG = 0,          // int32 [B]
        T_POSN,            // int32 [P + 3]
        T_SKEY,            // uint64 [P + 3]   sorted by key (stable)
        T_SPOS,            // int32 [P + 3]
-       T_FLAG,            // uint32 [P + 3]
-       T_CUM,             // uint32 [P + 3]
+       T_FLAG,            // uint64 [P + 3]   (length << 32 | 1) on the first element of a distinct key
+       T_CUM,             // uint64 [P + 3]   its inclusive scan
        T_FIRST_POS,       // uint32 [P + 3]  (R used)
        T_SEG_ID,          // int32 [P + 3]
        T_SEG_KEY,         // uint64 [P + 3]

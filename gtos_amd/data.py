@@ -84,6 +84,7 @@ def attach_device_relations(batch, device=None):
     rel = build_relation_batch_staged(None, rg.special_ids, HipBackend.shared(), path_mode=rg.path_mode, seed=rg.seed, max_len=rg.max_len,
                                       device=dev, csr=rg.csr)
     batch['relation'], batch['relation_bank'], batch['relation_length'] = rel['relation'], rel['relation_bank'], rel['relation_length']
+    batch['relation_rows'] = rel['relation_rows']                          # sum of the path lengths: saves the trie builder a device read
     del batch['relation_graphs']
     return batch
 

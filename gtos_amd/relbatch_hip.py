@@ -139,11 +139,11 @@ def build_relation_batch_staged(graphs, special_ids, backend, path_mode=PATH_FIR
     bufs["pair_off"] = pair_host.to(dev, non_blocking=True)
     bufs.update(level=E((S, nmax), i16), count=E((S, nmax), f64), head=E((S, nmax), i16), tail=E((S, nmax), i16), queue=E((S, nmax), i16),
                 dpred=E((S, emax), i16), dnext=E((S, emax), i16), dlab=E((S, emax), i8),
-                key=E(total, i64), posn=E(total, i32), skey=E(total, i64), spos=E(total, i32), flag=E(total, i32), cum=E(total, i32),
+                key=E(total, i64), posn=E(total, i32), skey=E(total, i64), spos=E(total, i32), flag=E(total, i64), cum=E(total, i64),
                 first_pos=E(total, i32), seg_id=E(total, i32), seg_key=E(total, i64), len_seen=E(8, i32), sizes=E(4, i32),
                 relation=torch.zeros((n, n, B), dtype=i64, device=dev))
     backend.phase_a(geom, bufs, total)
-    R, L = bufs["sizes"][:2].tolist()                                     # the one host read: distinct paths, longest path
+    R, L, N = bufs["sizes"][:3].tolist()                                  # the one host read: distinct paths, longest, bank rows
     del flat_host, pair_host
     bufs.update(first_alt=E(R, i32), sorted_seg=E(R, i32), type_of_seg=E(R, i32), bank=torch.zeros((8, R), dtype=i64, device=dev),
                 length=E(R, i64))
@@ -154,5 +154,5 @@ def build_relation_batch_staged(graphs, special_ids, backend, path_mode=PATH_FIR
         lo, hi = int(c["node_off"][b]), int(c["node_off"][b + 1])
         order[b, :hi - lo] = c["order"][lo:hi]
         depth[b, :hi - lo] = c["depth"][lo:hi]
-    return dict(relation=bufs["relation"], relation_bank=bufs["bank"][:L], relation_length=bufs["length"],
+    return dict(relation=bufs["relation"], relation_bank=bufs["bank"][:L], relation_length=bufs["length"], relation_rows=N,
                 order=torch.from_numpy(order), depth=torch.from_numpy(depth))

@@ -29,7 +29,8 @@ extern "C" int gtos_relbatch_emul_phase_a(const int64_t* geom, void** tab) {
     const Scratch sc = scratch_of(tab);
     uint64_t *key = (uint64_t*)tab[T_KEY], *skey = (uint64_t*)tab[T_SKEY], *seg_key = (uint64_t*)tab[T_SEG_KEY];
     int32_t *posn = (int32_t*)tab[T_POSN], *spos = (int32_t*)tab[T_SPOS], *seg_id = (int32_t*)tab[T_SEG_ID];
-    uint32_t *flag = (uint32_t*)tab[T_FLAG], *cum = (uint32_t*)tab[T_CUM], *first_pos = (uint32_t*)tab[T_FIRST_POS];
+    uint64_t *flag = (uint64_t*)tab[T_FLAG], *cum = (uint64_t*)tab[T_CUM];
+    uint32_t* first_pos = (uint32_t*)tab[T_FIRST_POS];
     int32_t *len_seen = (int32_t*)tab[T_LEN_SEEN], *sizes = (int32_t*)tab[T_SIZES];
     const int64_t total = G.P + N_SPECIAL;
     std::memset(len_seen, 0, 8 * sizeof(int32_t));
@@ -39,7 +40,7 @@ extern "C" int gtos_relbatch_emul_phase_a(const int64_t* geom, void** tab) {
     for (int64_t p = 0; p < G.P; ++p) pair_key(p, G, gr, sc, key, posn, len_seen);
     sort_pairs(key, posn, skey, spos, total);
     for (int64_t e = 0; e < total; ++e) head_flag(e, skey, flag);
-    uint32_t run = 0;
+    uint64_t run = 0;
     for (int64_t e = 0; e < total; ++e) { run += flag[e]; cum[e] = run; }
     for (int64_t e = 0; e < total; ++e) segment_first(e, skey, spos, cum, first_pos, seg_id, seg_key);
     sizes_after_scan(cum, total, len_seen, sizes);
@@ -57,7 +58,7 @@ extern "C" int gtos_relbatch_emul_phase_b(const int64_t* geom, int64_t R, void**
         type_of_segment(r, (const int32_t*)tab[T_SORTED_SEG], (const uint64_t*)tab[T_SEG_KEY], (int32_t*)tab[T_TYPE_OF_SEG], R, (int64_t*)tab[T_BANK],
                         (int64_t*)tab[T_LENGTH]);
     for (int64_t e = 0; e < total; ++e)
-        scatter_relation(e, G, gr, (const int32_t*)tab[T_SPOS], (const uint32_t*)tab[T_CUM], (const int32_t*)tab[T_TYPE_OF_SEG], (int64_t*)tab[T_RELATION]);
+        scatter_relation(e, G, gr, (const int32_t*)tab[T_SPOS], (const uint64_t*)tab[T_CUM], (const int32_t*)tab[T_TYPE_OF_SEG], (int64_t*)tab[T_RELATION]);
     for (int32_t s = 0; s < G.S; ++s) cls_cells(s, G, gr, (int64_t*)tab[T_RELATION]);
     return 0;
 }

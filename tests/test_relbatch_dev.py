@@ -58,6 +58,8 @@ def _same(a, b):
         x, y = a[k], b[k]
         if not (x.dtype == y.dtype and x.shape == y.shape and torch.equal(x.cpu(), y.cpu())):
             bad.append((k, tuple(x.shape), tuple(y.shape)))
+    if "relation_rows" in b and b["relation_rows"] != int(a["relation_length"].sum()):
+        bad.append("relation_rows")
     return bad
 
 
@@ -132,3 +134,13 @@ def test_device_all_loader_path_equals_the_host_loader(monkeypatch):
             assert torch.equal(want[k], got[k]), k
         assert _same_object(want["relation_index"], got["relation_index"]) == []
         assert _same_object(want["relation_trie"], got["relation_trie"]) == []
+    # the same through the Prefetcher's consumer-side preparation (no device here: CPU tensors, emulation backends)
+    host_ld, dev_ld = loader(True), loader("device_all")
+    want = [host_ld.run_job(j) for j in host_ld.jobs()]
+    with data.Prefetcher(dev_ld.thunks(), depth=2, workers=1, device_tries="hip") as pf:
+        got = list(pf)
+    assert len(got) == len(want) == 2
+    for w, g in zip(want, got):
+        assert 'relation_graphs' not in g and g['relation_rows'] == int(w['relation_length'].sum())
+        assert torch.equal(w["relation"], g["relation"]) and torch.equal(w["relation_bank"], g["relation_bank"])
+        assert _same_object(w["relation_index"], g["relation_index"]) == [] and _same_object(w["relation_trie"], g["relation_trie"]) == []
