@@ -117,10 +117,19 @@ def batchify_dependency(trees, vocabs, n_threads=0, unk_rate=0., rng=None, repla
         ids = rv.token2idx(list(dep))
         rev = rv.token2idx([r + '_r_' for r in dep])
         graphs.append(relbatch.dependency_edges(list(head), ids, rev))
-    rel = relbatch.build_relation_batch(graphs, relation_special_ids(rv), path_mode=relbatch.PATH_FIRST, n_threads=n_threads)
+    if index_prep == "device_all":
+        # the all-pairs work, the bank, the tries and the relation index are left to the consumer's device: ship the graphs
+        from .relbatch_hip import graphs_csr
+        csr = graphs_csr(graphs)
+        orders = [csr['order'][int(csr['node_off'][b]):int(csr['node_off'][b + 1])].tolist() for b in range(len(trees))]
+        rel = {'relation_graphs': RelationGraphs(csr, relation_special_ids(rv), relbatch.PATH_FIRST, 0)}
+    else:
+        full = relbatch.build_relation_batch(graphs, relation_special_ids(rv), path_mode=relbatch.PATH_FIRST, n_threads=n_threads)
+        orders = [full['order'][b, :len(t[2])].tolist() for b, t in enumerate(trees)]
+        rel = {k: full[k] for k in ('relation', 'relation_bank', 'relation_length')}
     concepts, depths, cps, t2is, i2ts = [], [], [], [], []
     for b, (dep, head, tok, tgt) in enumerate(trees):
-        order = rel['order'][b, :len(tok)].tolist()
+        order = orders[b]
         conc = [tok[n] for n in order]
         concepts.append(conc)
         depths.append(order)                              # "we just use the sequential order" (dependencyGraph.py:72)
@@ -139,7 +148,7 @@ def batchify_dependency(trees, vocabs, n_threads=0, unk_rate=0., rng=None, repla
         'concept': concept,
         'concept_char': strings_to_char_tensor(with_cls, vocabs['concept_char']),
         'concept_depth': lists_to_tensor([[0] + d for d in depths]),
-        'relation': rel['relation'], 'relation_bank': rel['relation_bank'], 'relation_length': rel['relation_length'],
+        **rel,
         'local_idx2token': i2ts, 'local_token2idx': t2is,
         'token_in': lists_to_tensor(aug, vocabs['token'], unk_rate=unk_rate, rng=rng)[:-1],
         'token_char_in': strings_to_char_tensor(aug, vocabs['token_char'])[:-1],

@@ -7,7 +7,7 @@ The host flattens the graphs (ordered adjacency + BFS order, ``gtos_relbatch_csr
 the device does the all-pairs work: a BFS per (graph, source), a key per pair, a key sort, the distinct keys numbered in first-seen
 order by a second sort, the scatter into ``relation[n,n,B]`` and the bank.  One host read (R and L) between the two phases.
 The result equals the host builder's array for array (tests/test_relbatch_dev.py runs the SAME stage code as serial host loops
-through the test suite's emulation library; tests/test_zz_hip_relbatch.py runs the HIP library on the GPU).
+through the test suite's emulation library; tests/test_zzz_hip_relbatch.py runs the HIP library on the GPU).
 
 Status: written at the end of round 3 without GPU time left -- the HIP entry points compile for gfx950 and have not run yet.
 Opt-in: nothing selects this module by default.

@@ -5,7 +5,7 @@ Two phases with one host read between them (the chunk and heavy-type counts): ph
 type), writes the query- / key-major ids and the chunk records in type order; phase B places the chunks on the XCDs (a chunk whose
 pairs live on one XCD stays there; the others go to the least loaded XCD, longest first -- a serial walk over a few thousand chunks,
 one thread) and sorts them into their final order.  tests/test_relindex_dev.py runs the SAME stage code as serial host loops through the
-test suite's emulation library and compares with the host builder array for array; tests/test_zz_hip_relbatch.py runs the HIP library
+test suite's emulation library and compares with the host builder array for array; tests/test_zzz_hip_relbatch.py runs the HIP library
 on the GPU.
 
 Status: written at the end of round 3 without GPU time left -- the HIP entry points compile for gfx950 and have not run yet.

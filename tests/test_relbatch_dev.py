@@ -144,3 +144,43 @@ def test_device_all_loader_path_equals_the_host_loader(monkeypatch):
         assert 'relation_graphs' not in g and g['relation_rows'] == int(w['relation_length'].sum())
         assert torch.equal(w["relation"], g["relation"]) and torch.equal(w["relation_bank"], g["relation_bank"])
         assert _same_object(w["relation_index"], g["relation_index"]) == [] and _same_object(w["relation_trie"], g["relation_trie"]) == []
+
+
+def test_device_all_dependency_flavour_reproduces_the_reference_batch(monkeypatch, tmp_path):
+    """translator flavour (one shortest path per pair by first discovery): batchify_dependency(index_prep="device_all") + the device-side
+    attachments (emulated) reproduce the batch the REFERENCE's batchify made from the same dev.txt trees (tests/golden/beam_dep_dev),
+    and the staged builder alone reproduces the reference's relation tensors of the host_dep_dev fixture."""
+    from conftest import load_golden
+    from gtos_amd import data, pathtrie_hip, relbatch_hip, relindex_hip
+    from test_beam_and_vocab import T, load_case, make_vocabs
+    from test_pathtrie import _EmulBackend as TrieEmul, _same_object
+    from test_relindex_dev import EmulBackend as IndexEmul
+    monkeypatch.setattr(relbatch_hip.HipBackend, "shared", classmethod(lambda cls: EmulBackend()))
+    monkeypatch.setattr(relindex_hip.HipBackend, "shared", classmethod(lambda cls: IndexEmul()))
+    monkeypatch.setattr(pathtrie_hip.HipBackend, "shared", classmethod(lambda cls: TrieEmul()))
+    meta, arrs = load_case("beam_dep_dev")
+    vocabs = make_vocabs(meta, tmp_path)
+    trees = [(d, h, t, g) for d, h, t, g in meta["trees"]]
+    host = data.batchify_dependency(trees, vocabs, n_threads=1)
+    got = data.batchify_dependency(trees, vocabs, n_threads=1, index_prep="device_all")
+    assert 'relation' not in got
+    data.attach_device_relations(got, "cpu")
+    data.attach_device_relation_index(got)
+    data.attach_device_tries(got, "hip")
+    for k in ("concept", "concept_char", "concept_depth", "relation", "relation_bank", "relation_length", "cp_seq", "token_in", "token_char_in",
+              "token_out"):
+        assert torch.equal(got[k], T(arrs["batch/" + k])), k
+    assert _same_object(host["relation_index"], got["relation_index"]) == []
+    assert ("relation_trie" in host) == ("relation_trie" in got)
+    if "relation_trie" in host:
+        assert _same_object(host["relation_trie"], got["relation_trie"]) == []
+    g = load_golden("host_dep_dev")
+    for bi in (0, 1):
+        p = "b%d/" % bi
+        off = g[p + "off"]
+        graphs = [relbatch.dependency_edges(g[p + "heads"][off[k]:off[k + 1]].tolist(), g[p + "dep_ids"][off[k]:off[k + 1]].tolist(),
+                                            g[p + "rev_ids"][off[k]:off[k + 1]].tolist()) for k in range(len(off) - 1)]
+        for mode in (PATH_FIRST, PATH_UNIFORM):                                     # shortest paths in a tree are unique
+            out = build_relation_batch_staged(graphs, g["special_ids"].tolist(), EmulBackend(), path_mode=mode, seed=7)
+            for k in ("relation", "relation_bank", "relation_length"):
+                assert torch.equal(out[k], torch.from_numpy(g[p + k])), (bi, mode, k)
