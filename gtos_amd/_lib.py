@@ -106,8 +106,24 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = None     # torch._C._cuda_getCurrentRawStream once it has been checked against the public API; False: not usable
+
+
 def stream():
-    return torch.cuda.current_stream().cuda_stream
+    """The current HIP stream's handle, once per launch: the public route builds a torch.cuda.Stream object every time (~1.5 us, as
+    much as the ctypes call it feeds); the raw getter returns the integer directly.  It is adopted only after it has agreed with the
+    public API on this process's first launch; any surprise keeps the public route."""
+    global _raw_stream
+    if _raw_stream:
+        return _raw_stream(torch.cuda.current_device())
+    pub = torch.cuda.current_stream().cuda_stream
+    if _raw_stream is None:
+        try:
+            raw = torch._C._cuda_getCurrentRawStream
+            _raw_stream = raw if raw(torch.cuda.current_device()) == pub else False
+        except Exception:
+            _raw_stream = False
+    return pub
 
 
 def dt(t):

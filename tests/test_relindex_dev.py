@@ -56,3 +56,47 @@ def test_staged_relation_index_on_amr_batches_and_limits(monkeypatch):
     monkeypatch.setenv("GTOS_BANK_BALANCE", "0")
     with pytest.raises(ValueError):
         build_relation_index_staged(torch.zeros((2, 2, 2), dtype=torch.int64), 5, EmulBackend())
+
+
+def test_staged_builders_equal_the_host_builders_property_based():
+    """hypothesis: arbitrary small connected graphs (self-loops, repeated edges, every node order), relation tensors and banks through the
+    three staged builders' stage code (emulated) == the host builders."""
+    import numpy as np
+    from hypothesis import given, settings, strategies as st
+    from gtos_amd import relbatch
+    from gtos_amd.pathtrie import build_path_trie
+    from gtos_amd.pathtrie_hip import build_path_trie_staged
+    from gtos_amd.relbatch_hip import build_relation_batch_staged
+    from test_pathtrie import _EmulBackend as TrieEmul
+    from test_relbatch_dev import EmulBackend as RelEmul, IDS, _same
+    trie_emul, rel_emul, idx_emul = TrieEmul(), RelEmul(), EmulBackend()
+
+    @st.composite
+    def graph(draw):
+        n = draw(st.integers(1, 7))
+        parents = [draw(st.integers(0, v - 1)) for v in range(1, n)]
+        edges = []
+        for v, u in enumerate(parents, start=1):                       # a spanning tree keeps the graph connected
+            l = draw(st.integers(6, 12))
+            edges += [(v, u, l), (u, v, l + 20)]
+        for _ in range(draw(st.integers(0, 6))):                       # anything on top: re-entrancies, repeats, self-loops
+            u, v, l = draw(st.integers(0, n - 1)), draw(st.integers(0, n - 1)), draw(st.integers(6, 12))
+            edges += [(u, v, l), (v, u, l + 20)]
+        perm = draw(st.permutations(list(range(n))))
+        return n, perm[0], np.array([(perm[a], perm[b], l) for a, b, l in edges], dtype=np.int32).reshape(-1, 3)
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.lists(graph(), min_size=1, max_size=4), st.sampled_from([relbatch.PATH_FIRST, relbatch.PATH_UNIFORM]), st.integers(0, 2 ** 64 - 1),
+           st.integers(1, 8), st.integers(1, 5))
+    def check(graphs, mode, seed, max_len, chunk):
+        host = relbatch.build_relation_batch(graphs, IDS, path_mode=mode, seed=seed, max_len=max_len, n_threads=1)
+        staged = build_relation_batch_staged(graphs, IDS, rel_emul, path_mode=mode, seed=seed, max_len=max_len)
+        assert _same(host, staged) == []
+        R = host["relation_bank"].shape[1]
+        assert _same_object(build_relation_index(host["relation"], R, chunk=chunk),
+                            build_relation_index_staged(staged["relation"], R, idx_emul, chunk=chunk)) == []
+        assert _same_object(build_path_trie(host["relation_bank"], host["relation_length"], chunk=chunk),
+                            build_path_trie_staged(staged["relation_bank"], staged["relation_length"], trie_emul, chunk=chunk,
+                                                   n_rows=staged["relation_rows"])) == []
+
+    check()
