@@ -139,8 +139,11 @@ def test_device_all_loader_path_equals_the_host_loader(monkeypatch):
     want = [host_ld.run_job(j) for j in host_ld.jobs()]
     with data.Prefetcher(dev_ld.thunks(), depth=2, workers=1, device_tries="hip") as pf:
         got = list(pf)
-    assert len(got) == len(want) == 2
-    for w, g in zip(want, got):
+    dev_ld2 = loader("device_all")
+    with data.Prefetcher(dev_ld2.jobs(), depth=2, workers=2, processes=True, runner=dev_ld2.run_job, device_tries="hip") as pf:
+        got2 = list(pf)                                    # worker processes: the flattened graphs travel pickled beside the packed tensors
+    assert len(got) == len(got2) == len(want) == 2
+    for w, g in list(zip(want, got)) + list(zip(want, got2)):
         assert 'relation_graphs' not in g and g['relation_rows'] == int(w['relation_length'].sum())
         assert torch.equal(w["relation"], g["relation"]) and torch.equal(w["relation_bank"], g["relation_bank"])
         assert _same_object(w["relation_index"], g["relation_index"]) == [] and _same_object(w["relation_trie"], g["relation_trie"]) == []
