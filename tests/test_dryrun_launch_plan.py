@@ -1,0 +1,82 @@
+"""The GPU path's Python glue exercised on the CPU (tests/dryrun.py): a full training step of a BASELINE configuration with every
+libgtos_hip.so launch recorded instead of executed.  No numbers are checked (kernel outputs are uninitialised memory) -- what is:
+every ``call()`` site the step reaches passes the binding's signature (argument count and kind), the production switches select the
+entry points DESIGN.md says they do, and the launch plan of a step is a pure function of the batch (two steps, same plan)."""
+import torch
+
+from dryrun import DryRun
+from gtos_amd import synth
+
+
+def _trainer(cfg, dtype=torch.bfloat16, factored=True):
+    from gtos_amd.config import build_generator
+    from gtos_amd.generator import Generator
+    from gtos_amd.train import Trainer
+    dev = torch.device("cpu")
+    model = build_generator(Generator, cfg, dev, factored_relation=factored).to(dev)
+    model.set_compute_dtype(dtype)
+    model.train()
+    return Trainer(model, synth.CONFIGS[cfg]["d"], warmup_steps=2000, compute_dtype=dtype, world_size=1, rank=0)
+
+
+def _plan(rec, n0):
+    """the recorded calls from index n0 on as (name, scalar arguments): pointers dropped (addresses change from step to step)"""
+    import ctypes
+    from gtos_amd import _lib
+    out = []
+    for name, args in rec.calls[n0:]:
+        sig = _lib.SIGNATURES[name]
+        out.append((name,) + tuple(a for c, a in zip(sig, args) if c is not ctypes.c_void_p and c is not ctypes.c_uint64))   # (uint64: dropout seeds)
+    return out
+
+
+def test_training_step_launch_plan_c1_bf16_trie_factored():
+    from gtos_amd.pathtrie import attach_path_trie
+    from gtos_amd.relindex import attach_relation_index
+    with DryRun() as rec:
+        trainer = _trainer("C1")
+        batch, _ = synth.make_config_batch("C1", rank=0)
+        attach_relation_index(attach_path_trie(batch))
+        trainer.step(batch, sync=False)
+        n1 = len(rec.calls)
+        trainer.step(batch, sync=False)
+        n2 = len(rec.calls)
+        trainer.step(batch, sync=False)
+        plan_a, plan_b = _plan(rec, n1)[:n2 - n1], _plan(rec, n2)
+        hist = {}
+        for name, _ in rec.calls[n2:]:
+            hist[name] = hist.get(name, 0) + 1
+    assert plan_a == plan_b                                       # same batch, same plan (shapes, flags, split-K factors, launch order)
+    L = synth.CONFIGS["C1"]["layers"]
+    # the production path of DESIGN.md: factored attention (one bank-gradient launch per graph layer), trie-evaluated GRU (level
+    # steps, never the per-row cell kernels), fused copy / NLL, device-side step control and ONE fused optimizer sweep per segment
+    assert hist["gtos_rel_attn_bwd_bank"] == L
+    assert hist["gtos_rel_attn_fwd"] == hist["gtos_rel_attn_bwd"] >= L
+    assert hist.get("gtos_gru_step_fwd", 0) > 0 and hist.get("gtos_gru_step_bwd", 0) > 0
+    assert "gtos_gru_cell_fwd" not in hist and "gtos_relation_gather_mean" not in hist
+    assert hist["gtos_copy_nll_fwd"] == hist["gtos_copy_nll_bwd"] == 1
+    assert hist["gtos_step_control"] == 2 and "gtos_adam_step" not in hist and hist["gtos_adam_step_ctl"] >= 1   # (flag phase + apply phase)
+    assert 300 < sum(hist.values()) < 800, sum(hist.values())     # 507 at the end of round 3
+
+
+def test_training_step_launch_plan_fp32_per_row_dense():
+    """the fp32 parity mode takes the other branches: dense relation operand, per-row GRU (cell kernels), no trie / index needed"""
+    with DryRun() as rec:
+        trainer = _trainer("C1", dtype=torch.float32, factored=False)
+        batch, _ = synth.make_config_batch("C1", rank=0)
+        trainer.step(batch, sync=False)
+        n1 = len(rec.calls)
+        trainer.step(batch, sync=False)
+        hist = {}
+        for name, _ in rec.calls[n1:]:
+            hist[name] = hist.get(name, 0) + 1
+    assert hist.get("gtos_gru_cell_fwd", 0) > 0 and "gtos_gru_step_fwd" not in hist
+    assert "gtos_rel_attn_bwd_bank" not in hist and hist["gtos_rel_attn_fwd"] == hist["gtos_rel_attn_bwd"]
+
+
+def test_dryrun_restores_what_it_patched():
+    before = (torch.cuda.current_stream, torch.cuda.Event, torch.Tensor.is_cuda)
+    with DryRun():
+        assert torch.zeros(1).is_cuda
+    assert (torch.cuda.current_stream, torch.cuda.Event, torch.Tensor.is_cuda) == before
+    assert not torch.zeros(1).is_cuda
