@@ -14,7 +14,8 @@ TARGETS = {"trie": ("trie_emul.cpp", "trie_kernels.h", "libtrie_emul.so"),
 def build(which="trie", force=False):
     src, hdr, out = TARGETS[which]
     src, hdr, out = os.path.join(HERE, src), os.path.join(ROOT, "gtos_amd", "csrc", hdr), os.path.join(HERE, "_build", out)
-    if force or not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    deps = [src, hdr, os.path.join(HERE, "emul_order.h")]
+    if force or not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
         os.makedirs(os.path.dirname(out), exist_ok=True)
         tmp = out + ".%d.tmp" % os.getpid()                  # xdist workers may build at once: write aside, then rename
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", src, "-o", tmp])

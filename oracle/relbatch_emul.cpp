@@ -9,8 +9,11 @@
 #include <vector>
 
 #include "../gtos_amd/csrc/relbatch_kernels.h"
+#include "emul_order.h"
 
 using namespace gtos_relbatch_dev;
+using gtos_emul::for_each;
+GTOS_EMUL_ORDER_ENTRY(gtos_relbatch_emul)
 
 namespace {
 template <typename K, typename V>
@@ -36,13 +39,13 @@ extern "C" int gtos_relbatch_emul_phase_a(const int64_t* geom, void** tab) {
     std::memset(len_seen, 0, 8 * sizeof(int32_t));
     std::memset(sizes, 0, RZ_TOTAL * sizeof(int32_t));
     special_keys(G, key, posn, len_seen);
-    for (int32_t s = 0; s < G.S; ++s) bfs_source(s, G, gr, sc);
-    for (int64_t p = 0; p < G.P; ++p) pair_key(p, G, gr, sc, key, posn, len_seen);
+    for_each(G.S, [&](int64_t s) { bfs_source((int32_t)s, G, gr, sc); });
+    for_each(G.P, [&](int64_t p) { pair_key(p, G, gr, sc, key, posn, len_seen); });
     sort_pairs(key, posn, skey, spos, total);
-    for (int64_t e = 0; e < total; ++e) head_flag(e, skey, flag);
+    for_each(total, [&](int64_t e) { head_flag(e, skey, flag); });
     uint64_t run = 0;
     for (int64_t e = 0; e < total; ++e) { run += flag[e]; cum[e] = run; }
-    for (int64_t e = 0; e < total; ++e) segment_first(e, skey, spos, cum, first_pos, seg_id, seg_key);
+    for_each(total, [&](int64_t e) { segment_first(e, skey, spos, cum, first_pos, seg_id, seg_key); });
     sizes_after_scan(cum, total, len_seen, sizes);
     return 0;
 }
@@ -54,11 +57,13 @@ extern "C" int gtos_relbatch_emul_phase_b(const int64_t* geom, int64_t R, void**
     const int64_t total = G.P + N_SPECIAL;
     if (((const int32_t*)tab[T_SIZES])[RZ_R] != R) return -2;             // the count the host read after phase A
     sort_pairs((const uint32_t*)tab[T_FIRST_POS], (const int32_t*)tab[T_SEG_ID], (uint32_t*)tab[T_FIRST_ALT], (int32_t*)tab[T_SORTED_SEG], R);
-    for (int64_t r = 0; r < R; ++r)
+    for_each(R, [&](int64_t r) {
         type_of_segment(r, (const int32_t*)tab[T_SORTED_SEG], (const uint64_t*)tab[T_SEG_KEY], (int32_t*)tab[T_TYPE_OF_SEG], R, (int64_t*)tab[T_BANK],
                         (int64_t*)tab[T_LENGTH]);
-    for (int64_t e = 0; e < total; ++e)
+    });
+    for_each(total, [&](int64_t e) {
         scatter_relation(e, G, gr, (const int32_t*)tab[T_SPOS], (const uint64_t*)tab[T_CUM], (const int32_t*)tab[T_TYPE_OF_SEG], (int64_t*)tab[T_RELATION]);
-    for (int32_t s = 0; s < G.S; ++s) cls_cells(s, G, gr, (int64_t*)tab[T_RELATION]);
+    });
+    for_each(G.S, [&](int64_t s) { cls_cells((int32_t)s, G, gr, (int64_t*)tab[T_RELATION]); });
     return 0;
 }

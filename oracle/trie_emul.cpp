@@ -9,8 +9,11 @@
 #include <vector>
 
 #include "../gtos_amd/csrc/trie_kernels.h"
+#include "emul_order.h"
 
 using namespace gtos_trie;
+using gtos_emul::for_each;
+GTOS_EMUL_ORDER_ENTRY(gtos_trie_emul)
 
 namespace {
 void scan_v8(const V8* in, V8* out, int64_t n) {
@@ -36,24 +39,25 @@ extern "C" int gtos_trie_emul_phase_a(int L, int64_t R, const int64_t* bank, con
     V8* scratch = (V8*)common[C_SCRATCH];
     Side F = side_of(pf), B = side_of(sf);
     for (int q = 0; q < SZ_TOTAL; ++q) sizes[q] = 0;
-    for (int64_t s = 0; s < R; ++s) make_keys(s, L, R, bank, length, F.key, B.key, F.order, B.order, len8, &sizes[SZ_ERR]);
+    for_each(R, [&](int64_t s) { make_keys(s, L, R, bank, length, F.key, B.key, F.order, B.order, len8, &sizes[SZ_ERR]); });
     if (sizes[SZ_ERR]) return 0;
     sort_pairs_u64(F.key, F.order, R);
     sort_pairs_u64(B.key, B.order, R);
     int k = 0;
     for (Side* t : {&F, &B}) {
-        for (int64_t i = 0; i < R; ++i) open_flags(i, t->key, t->newmask, scratch);
+        for_each(R, [&](int64_t i) { open_flags(i, t->key, t->newmask, scratch); });
         scan_v8(scratch, t->cum, R);
         level_offsets(t->cum, R, t->lvl, sizes + (k++ ? SZ_SF : SZ_PF));
     }
     V8* cumlen = (V8*)common[C_CUMLEN];
-    for (int64_t i = 0; i < R; ++i) length_onehot(i, F.order, len8, scratch);
+    for_each(R, [&](int64_t i) { length_onehot(i, F.order, len8, scratch); });
     scan_v8(scratch, cumlen, R);
     packed_geometry(cumlen, R, (int32_t*)common[C_START], (int32_t*)common[C_BATCH], (int64_t*)common[C_OFFS]);
-    for (int64_t i = 0; i < R; ++i)
+    for_each(R, [&](int64_t i) {
         packed_position(i, F.order, len8, cumlen, (const int32_t*)common[C_START], (int32_t*)common[C_SEQ_ORDER],
                         (int32_t*)common[C_SEQ_POS], (int64_t*)common[C_SEQ_ORDER64], (int64_t*)common[C_SEQ_POS64], (int32_t*)common[C_LEXF]);
-    for (int64_t i = 0; i < R; ++i) lex_position(i, B.order, (int32_t*)common[C_LEXB]);
+    });
+    for_each(R, [&](int64_t i) { lex_position(i, B.order, (int32_t*)common[C_LEXB]); });
     return 0;
 }
 
@@ -65,13 +69,14 @@ extern "C" int gtos_trie_emul_phase_b(int64_t R, int64_t N, int n_pf, int n_sf, 
     F.row_node = (int32_t*)common[C_ROW_PF];
     B.row_node = (int32_t*)common[C_ROW_SF];
     for (Side* t : {&F, &B}) {
-        for (int64_t i = 0; i < R; ++i) write_nodes(i, *t);
+        for_each(R, [&](int64_t i) { write_nodes(i, *t); });
         const int64_t n = t->lvl[8];
-        for (int64_t v = 0; v < n; ++v) children(v, *t);
+        for_each(n, [&](int64_t v) { children(v, *t); });
     }
-    for (int64_t m = 0; m < R; ++m)
+    for_each(R, [&](int64_t m) {
         fill_rows(m, (const int32_t*)common[C_SEQ_ORDER], len8, (const int32_t*)common[C_LEXF], (const int32_t*)common[C_LEXB],
                   (const int64_t*)common[C_OFFS], F.node_tab, B.node_tab, F.row_node, B.row_node);
+    });
     const int64_t n_waves = std::max<int64_t>(1, (N + rows_per_wave - 1) / rows_per_wave);
     int k = 0;
     for (Side* t : {&F, &B}) {
@@ -82,12 +87,12 @@ extern "C" int gtos_trie_emul_phase_b(int64_t R, int64_t N, int n_pf, int n_sf, 
         std::iota(idx.begin(), idx.end(), 0);
         std::stable_sort(idx.begin(), idx.end(), [&](int64_t a, int64_t b) { return t->row_node[a] < t->row_node[b]; });
         for (int64_t e = 0; e < N; ++e) { t->row_key[e] = (uint32_t)t->row_node[idx[e]]; t->rows[e] = (int32_t)idx[e]; }
-        for (int64_t e = 0; e < N; ++e) node_offsets(e, N, t->row_key, t->off, (int32_t)n);
-        for (int64_t u = 0; u < n; ++u) node_counts(u, chunk, *t);
+        for_each(N, [&](int64_t e) { node_offsets(e, N, t->row_key, t->off, (int32_t)n); });
+        for_each(n, [&](int64_t u) { node_counts(u, chunk, *t); });
         scan_v8(t->aux, t->aux_cum, n);
-        for (int64_t u = 0; u < n; ++u) node_records(u, chunk, *t);
+        for_each(n, [&](int64_t u) { node_records(u, chunk, *t); });
         side_sizes(*t, sz);
-        for (int64_t w = 0; w <= n_waves; ++w) wave_range(w, n_waves, rows_per_wave, *t, sz);
+        for_each((n_waves) + 1, [&](int64_t w) { wave_range(w, n_waves, rows_per_wave, *t, sz); });
     }
     return 0;
 }

@@ -162,7 +162,7 @@ def test_device_trie_builder_equals_the_host_builder_at_c2_size():
 class _EmulBackend(object):
     """oracle/trie_emul.cpp: the per-thread stages of csrc/trie_kernels.h (the code the HIP kernels wrap) as serial host loops."""
 
-    def __init__(self):
+    def __init__(self, order=0):
         import ctypes
         from oracle.build_emul import build
         out = build()
@@ -170,6 +170,9 @@ class _EmulBackend(object):
         P, I, L_ = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
         self.lib.gtos_trie_emul_phase_a.argtypes = [I, L_, P, P, P, P, P, P]
         self.lib.gtos_trie_emul_phase_b.argtypes = [L_, L_, I, I, I, I, P, P, P, P]
+        self.lib.gtos_trie_emul_set_order.argtypes = [ctypes.c_uint64]
+        self.lib.gtos_trie_emul_set_order.restype = None
+        self.lib.gtos_trie_emul_set_order(order)        # 0: ascending thread order, 1: descending, > 1: a seeded permutation
 
     def phase_a(self, L, R, N, bank, length, common, pf, sf, sizes):
         from gtos_amd.pathtrie_hip import _table, _COMMON, _SIDE

@@ -14,12 +14,15 @@ IDS = (0, 2, 3, 4, 5)           # pad, cls, rcls, self, tl
 
 
 class EmulBackend(object):
-    def __init__(self):
+    def __init__(self, order=0):
         from oracle.build_emul import build
         self.lib = ctypes.CDLL(build("relbatch"))
         P = ctypes.c_void_p
         self.lib.gtos_relbatch_emul_phase_a.argtypes = [P, P]
         self.lib.gtos_relbatch_emul_phase_b.argtypes = [P, ctypes.c_int64, P]
+        self.lib.gtos_relbatch_emul_set_order.argtypes = [ctypes.c_uint64]
+        self.lib.gtos_relbatch_emul_set_order.restype = None
+        self.lib.gtos_relbatch_emul_set_order(order)                   # 0: ascending thread order, 1: descending, > 1: a seeded permutation
 
     def phase_a(self, geom, bufs, total):
         assert self.lib.gtos_relbatch_emul_phase_a(_geom(geom), _table(bufs)) == 0

@@ -13,12 +13,15 @@ from test_pathtrie import _same_object
 
 
 class EmulBackend(object):
-    def __init__(self):
+    def __init__(self, order=0):
         from oracle.build_emul import build
         self.lib = ctypes.CDLL(build("relindex"))
         P = ctypes.c_void_p
         self.lib.gtos_relindex_emul_phase_a.argtypes = [P, P]
         self.lib.gtos_relindex_emul_phase_b.argtypes = [P, ctypes.c_int64, P]
+        self.lib.gtos_relindex_emul_set_order.argtypes = [ctypes.c_uint64]
+        self.lib.gtos_relindex_emul_set_order.restype = None
+        self.lib.gtos_relindex_emul_set_order(order)                   # 0: ascending thread order, 1: descending, > 1: a seeded permutation
 
     def phase_a(self, geom, bufs):
         assert self.lib.gtos_relindex_emul_phase_a(_geom(geom), _table(bufs)) == 0
@@ -100,3 +103,34 @@ def test_staged_builders_equal_the_host_builders_property_based():
                                                    n_rows=staged["relation_rows"])) == []
 
     check()
+
+
+@pytest.mark.parametrize("order", [1, 2, 77, 12345])
+def test_staged_builders_do_not_depend_on_the_thread_order(order):
+    """A GPU runs the threads of a stage in no particular order.  The emulation libraries visit them descending / in seeded random
+    permutations (oracle/emul_order.h): every array of all three builders must come out the same as under the ascending loop, i.e. no
+    stage has two threads writing different values to one location or reading what another thread of the same stage writes."""
+    from gtos_amd import data, relbatch
+    from gtos_amd.pathtrie import build_path_trie
+    from gtos_amd.pathtrie_hip import build_path_trie_staged
+    from gtos_amd.relbatch_hip import build_relation_batch_staged
+    from test_pathtrie import _EmulBackend as TrieEmul
+    from test_relbatch_dev import EmulBackend as RelEmul, _random_graphs, _same, IDS
+    try:
+        graphs = _random_graphs(11, 6, 15, 40, 0.4)
+        host = relbatch.build_relation_batch(graphs, IDS, path_mode=relbatch.PATH_UNIFORM, seed=3, n_threads=1)
+        staged = build_relation_batch_staged(graphs, IDS, RelEmul(order), path_mode=relbatch.PATH_UNIFORM, seed=3)
+        assert _same(host, staged) == []
+        R = host["relation_bank"].shape[1]
+        for chunk in (32, 3):
+            assert _same_object(build_relation_index(host["relation"], R, chunk=chunk),
+                                build_relation_index_staged(host["relation"], R, EmulBackend(order), chunk=chunk)) == []
+            assert _same_object(build_path_trie(host["relation_bank"], host["relation_length"], chunk=chunk),
+                                build_path_trie_staged(host["relation_bank"], host["relation_length"], TrieEmul(order), chunk=chunk)) == []
+        batch, _ = synth.make_config_batch("C2", rank=0, B=8)
+        R = batch["relation_bank"].shape[1]
+        assert _same_object(build_relation_index(batch["relation"], R), build_relation_index_staged(batch["relation"], R, EmulBackend(order))) == []
+        assert _same_object(build_path_trie(batch["relation_bank"], batch["relation_length"]),
+                            build_path_trie_staged(batch["relation_bank"], batch["relation_length"], TrieEmul(order))) == []
+    finally:
+        RelEmul(0), EmulBackend(0), TrieEmul(0)          # back to the ascending order for the tests that follow
