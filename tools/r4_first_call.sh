@@ -6,7 +6,7 @@
 # Usage: gpurun --timeout 420 -- 'bash tools/r4_first_call.sh'
 O=gpurun_out/r4a; mkdir -p $O
 export PYTHONPATH=$PWD
-timeout 150 python -m pytest tests/test_zz_hip_trie_builder.py tests/test_zzz_hip_relbatch.py -m gpu -q --tb=short -p no:cacheprovider > $O/gpu_tests_builders.log 2>&1
+timeout 150 python -m pytest tests/test_zz_hip_trie_builder.py tests/zzz_hip_relbatch_cases.py -m gpu -q --tb=short -p no:cacheprovider > $O/gpu_tests_builders.log 2>&1
 tail -5 $O/gpu_tests_builders.log
 timeout 60 python tools/hip_relbatch_check.py $O/hip_relbatch_check.json 2> $O/hip_relbatch_check.err | cut -c1-1500
 B="python bench.py --fresh-batches --no-cpu-baseline --steps 30 --warmup 3"
