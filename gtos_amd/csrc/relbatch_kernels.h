@@ -77,44 +77,82 @@ GTOS_RB_HD int32_t graph_of(const T* off, int32_t B, T x) {
     return lo;
 }
 
-// ---- stage 1: BFS from the node at position i of graph g (slot s): levels, path counts, shortest-path DAG in discovery order.
-// Mirrors the level loop of csrc_host/relbatch.cpp graph_paths (nx.predecessor): a queue visits the nodes in the same order as
-// the frontier / next lists there, so every DAG list and every floating-point sum is built in the same order.
-GTOS_RB_HD void bfs_source(int32_t s, const Geom& G, const Graphs& gr, const Scratch& sc) {
-    const int32_t g = graph_of<int32_t>(gr.node_off, G.B, s);
-    const int32_t i = s - gr.node_off[g], n = gr.ng[g];
-    const int32_t* off = gr.adj_off + gr.node_off[g] + g;
-    const int32_t* dst = gr.adj_dst + gr.adj_base[g];
-    const int32_t* lab = gr.adj_lab + gr.adj_base[g];
-    int16_t* level = sc.level + (int64_t)s * G.nmax;
-    double* count = sc.count + (int64_t)s * G.nmax;
-    int16_t* head = sc.head + (int64_t)s * G.nmax;
-    int16_t* tail = sc.tail + (int64_t)s * G.nmax;
-    int16_t* queue = sc.queue + (int64_t)s * G.nmax;
-    int16_t* dpred = sc.dpred + (int64_t)s * G.emax;
-    int16_t* dnext = sc.dnext + (int64_t)s * G.emax;
-    uint8_t* dlab = sc.dlab + (int64_t)s * G.emax;
-    for (int32_t v = 0; v < n; ++v) { level[v] = -1; head[v] = -1; tail[v] = -1; count[v] = 0.0; }
-    const int32_t src = gr.order[gr.node_off[g] + i];
-    level[src] = 0; count[src] = 1.0;
+struct Slot {                                             // the scratch of ONE (graph, source) search
+    int16_t *level, *head, *tail, *queue, *dpred, *dnext;
+    double* count;
+    uint8_t* dlab;
+};
+
+// ---- stage 1 core: BFS from node ``src`` of a graph of n nodes (LOCAL adjacency offsets off[n + 1], dst / lab): levels, path counts,
+// shortest-path DAG in discovery order.  The level loop of nx.predecessor (generator/AMRGraph.py:100-115 via networkx): a queue visits
+// the nodes in the order of the frontier lists, so every DAG list and every floating-point sum is built in one fixed order.
+// Shared by the GPU kernels, their emulation and the host builder (csrc_host/relbatch.cpp, one-path-per-pair modes).
+GTOS_RB_HD void bfs_core(int32_t n, const int32_t* off, const int32_t* dst, const int32_t* lab, int32_t src, const Slot& sl) {
+    for (int32_t v = 0; v < n; ++v) { sl.level[v] = -1; sl.head[v] = -1; sl.tail[v] = -1; sl.count[v] = 0.0; }
+    sl.level[src] = 0; sl.count[src] = 1.0;
     int32_t qh = 0, qt = 0, ne = 0;
-    queue[qt++] = (int16_t)src;
+    sl.queue[qt++] = (int16_t)src;
     while (qh < qt) {
-        const int32_t v = queue[qh++];
-        const int32_t lev = level[v] + 1;
+        const int32_t v = sl.queue[qh++];
+        const int32_t lev = sl.level[v] + 1;
         for (int32_t k = off[v]; k < off[v + 1]; ++k) {
             const int32_t w = dst[k];
             bool edge = false;
-            if (level[w] < 0) { level[w] = (int16_t)lev; count[w] = count[v]; queue[qt++] = (int16_t)w; edge = true; }
-            else if (level[w] == lev) { count[w] += count[v]; edge = true; }
+            if (sl.level[w] < 0) { sl.level[w] = (int16_t)lev; sl.count[w] = sl.count[v]; sl.queue[qt++] = (int16_t)w; edge = true; }
+            else if (sl.level[w] == lev) { sl.count[w] += sl.count[v]; edge = true; }
             if (edge) {
-                dpred[ne] = (int16_t)v; dlab[ne] = (uint8_t)lab[k]; dnext[ne] = -1;
-                if (tail[w] < 0) head[w] = (int16_t)ne; else dnext[tail[w]] = (int16_t)ne;
-                tail[w] = (int16_t)ne;
+                sl.dpred[ne] = (int16_t)v; sl.dlab[ne] = (uint8_t)lab[k]; sl.dnext[ne] = -1;
+                if (sl.tail[w] < 0) sl.head[w] = (int16_t)ne; else sl.dnext[sl.tail[w]] = (int16_t)ne;
+                sl.tail[w] = (int16_t)ne;
                 ++ne;
             }
         }
     }
+}
+
+// ---- stage 2 core: the key of the path from the slot's source (BFS position i of graph g) to node t (BFS position j): first
+// discovery, or uniform among the alternatives (generator/data.py:149-150) by a splitmix64 stream keyed by (seed, g, i, j);
+// <SELF> for distance 0, <TL> beyond max_len (data.py:151-154).  *d_out = the distance.
+GTOS_RB_HD uint64_t key_core(int32_t g, int32_t i, int32_t j, int32_t t, const Slot& sl, int32_t mode, int32_t max_len, uint64_t seed,
+                             uint64_t self_key, uint64_t tl_key, int32_t* d_out) {
+    const int32_t d = sl.level[t];
+    *d_out = d;
+    if (d == 0) return self_key;
+    if (d > max_len) return tl_key;
+    uint64_t k64 = 0;
+    uint64_t st = seed ^ (0x100000001B3ull * (uint64_t)(g + 1)) ^ ((uint64_t)i << 40) ^ ((uint64_t)j << 20);
+    int32_t v = t;
+    for (int32_t k = d - 1; k >= 0; --k) {
+        int32_t e = sl.head[v];
+        if (mode == MODE_UNIFORM) {
+            const double u01 = (double)(splitmix(st) >> 11) * (1.0 / 9007199254740992.0);
+            const double target = u01 * sl.count[v];
+            double acc = 0.0;
+            for (;;) {
+                acc += sl.count[sl.dpred[e]];
+                if (target < acc || sl.dnext[e] < 0) break;
+                e = sl.dnext[e];
+            }
+        }
+        k64 |= (uint64_t)sl.dlab[e] << (8 * k);               // label k of the path in byte k (first label in the low byte)
+        v = sl.dpred[e];
+    }
+    return k64;
+}
+
+GTOS_RB_HD Slot slot_of(const Scratch& sc, int64_t s, int32_t nmax, int32_t emax) {
+    Slot sl;
+    sl.level = sc.level + s * nmax; sl.count = sc.count + s * nmax; sl.head = sc.head + s * nmax; sl.tail = sc.tail + s * nmax;
+    sl.queue = sc.queue + s * nmax; sl.dpred = sc.dpred + s * emax; sl.dnext = sc.dnext + s * emax; sl.dlab = sc.dlab + s * emax;
+    return sl;
+}
+
+// ---- stage 1: BFS from the node at position i of graph g (slot s of the batch-wide scratch)
+GTOS_RB_HD void bfs_source(int32_t s, const Geom& G, const Graphs& gr, const Scratch& sc) {
+    const int32_t g = graph_of<int32_t>(gr.node_off, G.B, s);
+    const int32_t i = s - gr.node_off[g];
+    bfs_core(gr.ng[g], gr.adj_off + gr.node_off[g] + g, gr.adj_dst + gr.adj_base[g], gr.adj_lab + gr.adj_base[g], gr.order[gr.node_off[g] + i],
+             slot_of(sc, s, G.nmax, G.emax));
 }
 
 // ---- stage 2: the key of pair p (graph g, source position i, target position j) and its first-seen position
@@ -123,39 +161,9 @@ GTOS_RB_HD void pair_key(int64_t p, const Geom& G, const Graphs& gr, const Scrat
     const int32_t n = gr.ng[g];
     const int64_t q = p - gr.pair_off[g];
     const int32_t i = (int32_t)(q / n), j = (int32_t)(q % n);
-    const int32_t s = gr.node_off[g] + i;
-    const int16_t* level = sc.level + (int64_t)s * G.nmax;
-    const double* count = sc.count + (int64_t)s * G.nmax;
-    const int16_t* head = sc.head + (int64_t)s * G.nmax;
-    const int16_t* dpred = sc.dpred + (int64_t)s * G.emax;
-    const int16_t* dnext = sc.dnext + (int64_t)s * G.emax;
-    const uint8_t* dlab = sc.dlab + (int64_t)s * G.emax;
-    const int32_t t = gr.order[gr.node_off[g] + j];
-    const int32_t d = level[t];
-    uint64_t k64;
-    if (d == 0) k64 = G.self_key;
-    else if (d > G.max_len) k64 = G.tl_key;
-    else {
-        k64 = 0;
-        uint64_t st = G.seed ^ (0x100000001B3ull * (uint64_t)(g + 1)) ^ ((uint64_t)i << 40) ^ ((uint64_t)j << 20);
-        int32_t v = t;
-        for (int32_t k = d - 1; k >= 0; --k) {
-            int32_t e = head[v];
-            if (G.mode == MODE_UNIFORM) {
-                const double u01 = (double)(splitmix(st) >> 11) * (1.0 / 9007199254740992.0);
-                const double target = u01 * count[v];
-                double acc = 0.0;
-                for (;;) {
-                    acc += count[dpred[e]];
-                    if (target < acc || dnext[e] < 0) break;
-                    e = dnext[e];
-                }
-            }
-            k64 |= (uint64_t)dlab[e] << (8 * k);             // label k of the path in byte k (first label in the low byte)
-            v = dpred[e];
-        }
-    }
-    key[N_SPECIAL + p] = k64;
+    int32_t d;
+    key[N_SPECIAL + p] = key_core(g, i, j, gr.order[gr.node_off[g] + j], slot_of(sc, gr.node_off[g] + i, G.nmax, G.emax), G.mode, G.max_len, G.seed,
+                                  G.self_key, G.tl_key, &d);
     posn[N_SPECIAL + p] = (int32_t)(N_SPECIAL + p);
     len_seen[d >= 1 && d <= G.max_len ? d - 1 : 0] = 1;       // benign race: every writer stores 1 (<SELF> / <TL>: one label)
 }

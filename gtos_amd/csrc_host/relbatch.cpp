@@ -4,25 +4,32 @@
 // (c) in parallel over the rows of relation[a][c][b][k]: translate and write contiguous memory.
 // See include/gtos_host.h for the contract and the reference lines this replaces.  Pure integer work.
 #include "../../include/gtos_host.h"
+#include "../csrc/relbatch_kernels.h"     // bfs_core / key_core: the search and the path choice shared with the GPU builder
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <thread>
 #include <vector>
 
 namespace {
 
-struct Graph {
+struct alignas(128) Graph {                          // (neighbours in the per-batch vector belong to different worker threads:
     int n = 0, root = 0;
     std::vector<int> adj_off, adj_dst, adj_lab;     // CSR in networkx adjacency (insertion) order
     std::vector<int> order, pos, depth;             // BFS order from the root, position of each node, BFS depth
 };
 
-struct PairPaths {                                   // per graph: for every (i,j) in BFS-position space, its packed paths
+struct alignas(128) PairPaths {                      //  no two of them on one cache line)  per graph: for every (i,j) in BFS-position space, its packed paths
     std::vector<uint32_t> off;                       // [n*n+1]
     std::vector<uint64_t> keys;
     std::vector<uint32_t> lid;                       // per key: index into uniq
+    uint64_t* kview = nullptr;                       // one-path-per-pair modes: this graph's n*n keys / local ids inside the batch-wide
+    uint32_t* lview = nullptr;                       // arrays (allocated once, first touched by the workers), no offset table
     std::vector<uint64_t> uniq;                      // this graph's distinct keys in first-seen (i, j, alternative) order
     std::vector<int32_t> gid;                        // per uniq entry: batch-wide type id (phase b)
 };
@@ -32,7 +39,13 @@ struct FlatMap {
     std::vector<uint64_t> key;
     std::vector<int32_t> val;
     size_t mask = 0;
-    void init(size_t n) { size_t cap = 16; while (cap < 2 * n + 2) cap <<= 1; key.assign(cap, 0); val.assign(cap, 0); mask = cap - 1; }
+    void init(size_t n) {                          // (re)usable: a map that is already large enough is only cleared -- no fresh pages
+        size_t cap = 16;
+        while (cap < 2 * n + 2) cap <<= 1;
+        if (cap <= val.size()) { cap = val.size(); std::fill(val.begin(), val.end(), 0); }
+        else { key.assign(cap, 0); val.assign(cap, 0); }
+        mask = cap - 1;
+    }
     static inline size_t hash(uint64_t k) { k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33; return (size_t)k; }
     inline int find(uint64_t k) const {
         for (size_t p = hash(k) & mask;; p = (p + 1) & mask) { if (!val[p]) return -1; if (key[p] == k) return val[p] - 1; }
@@ -90,6 +103,38 @@ bool build_graph(Graph& g, int n, int root, int64_t e0, int64_t e1, const int* s
 }
 
 // All-pairs label paths of one graph.
+// Per-thread scratch of the one-path-per-pair modes: the flat search state of gtos_relbatch_dev::Slot, reused for every source.
+struct SlotBuf {
+    std::vector<int16_t> i16;
+    std::vector<double> count;
+    std::vector<uint8_t> dlab;
+    gtos_relbatch_dev::Slot slot(int n, int e) {
+        i16.resize((size_t)4 * n + 2 * (size_t)e);
+        count.resize(n);
+        dlab.resize(e);
+        gtos_relbatch_dev::Slot sl;
+        sl.level = i16.data(); sl.head = sl.level + n; sl.tail = sl.head + n; sl.queue = sl.tail + n; sl.dpred = sl.queue + n; sl.dnext = sl.dpred + e;
+        sl.count = count.data(); sl.dlab = dlab.data();
+        return sl;
+    }
+};
+
+// One path per pair (GTOS_PATH_FIRST / GTOS_PATH_UNIFORM): no per-pair lists -- a flat search state per source (a few KB, reused) and one
+// key per pair written in place.  The same bfs_core / key_core as the GPU builder runs (csrc/relbatch_kernels.h).
+void graph_paths_single(const Graph& g, int mode, uint64_t seed, int gid, int max_len, uint64_t self_key, uint64_t tl_key, PairPaths& out, SlotBuf& buf) {
+    using namespace gtos_relbatch_dev;
+    const int n = g.n;
+    const int e = std::max(1, g.adj_off[n]);
+    const Slot sl = buf.slot(n, e);
+    const int m = mode == GTOS_PATH_UNIFORM ? MODE_UNIFORM : MODE_FIRST;
+    for (int i = 0; i < n; ++i) {
+        bfs_core(n, g.adj_off.data(), g.adj_dst.data(), g.adj_lab.data(), g.order[i], sl);
+        uint64_t* row = out.kview + (size_t)i * n;
+        int d;
+        for (int j = 0; j < n; ++j) row[j] = key_core(gid, i, j, g.order[j], sl, m, max_len, seed, self_key, tl_key, &d);
+    }
+}
+
 void graph_paths(const Graph& g, int mode, uint64_t seed, int gid, int max_len, uint64_t self_key, uint64_t tl_key, PairPaths& out) {
     const int n = g.n;
     out.off.assign((size_t)n * n + 1, 0);
@@ -175,7 +220,8 @@ void graph_paths(const Graph& g, int mode, uint64_t seed, int gid, int max_len, 
 
 struct gtos_relbatch {
     int B = 0, n = 0, R = 0, L = 0, K = 1;
-    std::vector<int64_t> relation, bank, length;
+    std::vector<int64_t> relation, length;
+    std::vector<uint64_t> type_key;               // packed label path of every type: the bank is written from it at export time
     std::vector<int32_t> order, depth;
 };
 
@@ -186,26 +232,55 @@ extern "C" gtos_relbatch* gtos_relbatch_build(int B, const int* n_nodes, const i
     if (path_mode < 0 || path_mode > 2) return nullptr;
     const int pad_id = ids[0], cls_id = ids[1], rcls_id = ids[2], self_id = ids[3], tl_id = ids[4];
     const uint64_t self_key = (uint64_t)self_id, tl_key = (uint64_t)tl_id;
+    static const bool timing = getenv("GTOS_RELBATCH_TIMING") != nullptr;      // phase times on stderr
+    auto t_start = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "relbatch %-18s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_start).count());
+        t_start = now;
+    };
     std::vector<Graph> graphs(B);
     std::vector<PairPaths> pp(B);
     std::atomic<int> next(0), bad(0);
     auto work = [&]() {
+        SlotBuf slotbuf;
+        FlatMap local;                               // this thread's per-graph dedup map, reused from graph to graph
+        std::vector<uint64_t> uniq;
+        int done = 0;
+        double t_graph = 0, t_paths = 0;
+        auto t0 = std::chrono::steady_clock::now();
         for (;;) {
             const int g = next.fetch_add(1);
-            if (g >= B) return;
+            if (g >= B) {
+                if (timing) fprintf(stderr, "relbatch   worker: %d graphs in %.2f ms (graph build %.2f, paths %.2f)\n", done,
+                                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), t_graph, t_paths);
+                return;
+            }
+            ++done;
+            auto ta = std::chrono::steady_clock::now();
             if (!build_graph(graphs[g], n_nodes[g], roots[g], edge_off[g], edge_off[g + 1], e_src, e_dst, e_label)) { bad = 1; continue; }
-            graph_paths(graphs[g], path_mode, seed, g, max_len, self_key, tl_key, pp[g]);
+            auto tb = std::chrono::steady_clock::now();
+            if (path_mode == GTOS_PATH_ALL) graph_paths(graphs[g], path_mode, seed, g, max_len, self_key, tl_key, pp[g]);
+            else graph_paths_single(graphs[g], path_mode, seed, g, max_len, self_key, tl_key, pp[g], slotbuf);
+            auto tc = std::chrono::steady_clock::now();
+            t_graph += std::chrono::duration<double, std::milli>(tb - ta).count();
+            t_paths += std::chrono::duration<double, std::milli>(tc - tb).count();
             // phase (a), second half: this graph's distinct keys, in the order the reference would first meet them
             PairPaths& P = pp[g];
-            FlatMap local;
-            local.init(P.keys.size());
-            P.lid.resize(P.keys.size());
-            P.uniq.clear();
-            for (size_t q = 0; q < P.keys.size(); ++q) {
-                int id = local.find(P.keys[q]);
-                if (id < 0) { id = (int)P.uniq.size(); local.insert(P.keys[q], id); P.uniq.push_back(P.keys[q]); }
-                P.lid[q] = (uint32_t)id;
+            const bool single = path_mode != GTOS_PATH_ALL;
+            const size_t nk = single ? (size_t)graphs[g].n * graphs[g].n : P.keys.size();
+            const uint64_t* keys = single ? P.kview : P.keys.data();
+            if (!single) P.lid.resize(nk);
+            uint32_t* lid = single ? P.lview : P.lid.data();
+            local.init(nk);
+            uniq.clear();                            // (a thread-local list: push_back on a member of pp[g] would write the vector's
+            for (size_t q = 0; q < nk; ++q) {        //  end pointer, next to another thread's pp[g + 1], for every new key)
+                int id = local.find(keys[q]);
+                if (id < 0) { id = (int)uniq.size(); local.insert(keys[q], id); uniq.push_back(keys[q]); }
+                lid[q] = (uint32_t)id;
             }
+            P.uniq.assign(uniq.begin(), uniq.end());
         }
     };
     if (n_threads < 1) n_threads = (int)std::thread::hardware_concurrency();
@@ -216,8 +291,19 @@ extern "C" gtos_relbatch* gtos_relbatch_build(int B, const int* n_nodes, const i
         fn();
         for (auto& t : pool) t.join();
     };
+    std::unique_ptr<uint64_t[]> all_keys;
+    std::unique_ptr<uint32_t[]> all_lid;
+    if (path_mode != GTOS_PATH_ALL) {
+        size_t P = 0;
+        for (int g = 0; g < B; ++g) { if (n_nodes[g] <= 0) return nullptr; P += (size_t)n_nodes[g] * n_nodes[g]; }
+        all_keys.reset(new uint64_t[P]);             // uninitialised on purpose: the workers touch their own slices first
+        all_lid.reset(new uint32_t[P]);
+        size_t at = 0;
+        for (int g = 0; g < B; ++g) { pp[g].kview = all_keys.get() + at; pp[g].lview = all_lid.get() + at; at += (size_t)n_nodes[g] * n_nodes[g]; }
+    }
     run_parallel(work);
     if (bad) return nullptr;
+    lap("paths (parallel)");
 
     auto* h = new gtos_relbatch();
     h->B = B;
@@ -252,6 +338,7 @@ extern "C" gtos_relbatch* gtos_relbatch_build(int B, const int* n_nodes, const i
         P.gid.resize(P.uniq.size());
         for (size_t u = 0; u < P.uniq.size(); ++u) P.gid[u] = intern(P.uniq[u]);
     }
+    lap("type table (serial)");
     h->relation.assign((size_t)n * n * B * K, 0);
     h->order.assign((size_t)B * (n - 1), -1);
     h->depth.assign((size_t)B * (n - 1), 0);
@@ -280,6 +367,7 @@ extern "C" gtos_relbatch* gtos_relbatch_build(int B, const int* n_nodes, const i
                     if (i >= ng || j >= ng) continue;
                     const PairPaths& P = pp[b];
                     const size_t k = (size_t)i * ng + j;
+                    if (!all) { dst[b] = P.gid[P.lview[k]]; continue; }                 // one key per pair (K == 1)
                     const uint32_t b0 = k ? P.off[k] : 0u, b1 = P.off[k + 1];
                     for (uint32_t q = b0; q < b1; ++q) dst[(size_t)b * K + (q - b0)] = P.gid[P.lid[q]];
                 }
@@ -287,18 +375,17 @@ extern "C" gtos_relbatch* gtos_relbatch_build(int B, const int* n_nodes, const i
         }
     };
     run_parallel(fill);
+    lap("relation fill");
     const int R = (int)type_key.size();
     h->R = R;
     int L = 1;
     std::vector<int> len(R);
     for (int t = 0; t < R; ++t) { int l = 0; uint64_t k = type_key[t]; while (k) { ++l; k >>= 8; } len[t] = std::max(l, 1); L = std::max(L, len[t]); }
     h->L = L;
-    h->bank.assign((size_t)L * R, 0);
     h->length.resize(R);
-    for (int t = 0; t < R; ++t) {
-        h->length[t] = len[t];
-        for (int i = 0; i < len[t]; ++i) h->bank[(size_t)i * R + t] = (int64_t)((type_key[t] >> (8 * i)) & 0xff);
-    }
+    for (int t = 0; t < R; ++t) h->length[t] = len[t];
+    h->type_key.swap(type_key);                       // (the bank itself is written straight into the caller's buffer by _export)
+    lap("bank");
     return h;
 }
 
@@ -312,7 +399,12 @@ extern "C" int gtos_relbatch_export(const gtos_relbatch* h, int64_t* relation, i
                                     int32_t* order, int32_t* depth) {
     if (!h) return -1;
     if (relation) std::memcpy(relation, h->relation.data(), h->relation.size() * sizeof(int64_t));
-    if (bank) std::memcpy(bank, h->bank.data(), h->bank.size() * sizeof(int64_t));
+    if (bank)
+        for (int i = 0; i < h->L; ++i) {                                    // row by row: sequential writes (0 past a path's end)
+            int64_t* row = bank + (size_t)i * h->R;
+            const uint64_t* tk = h->type_key.data();
+            for (int t = 0; t < h->R; ++t) row[t] = (int64_t)((tk[t] >> (8 * i)) & 0xff);
+        }
     if (length) std::memcpy(length, h->length.data(), h->length.size() * sizeof(int64_t));
     if (order) std::memcpy(order, h->order.data(), h->order.size() * sizeof(int32_t));
     if (depth) std::memcpy(depth, h->depth.data(), h->depth.size() * sizeof(int32_t));
