@@ -285,3 +285,90 @@ def test_trainer_construction_broadcasts_rank0_parameters():
     assert (a0 == a1).all() and (v0 == v1).all()         # ... and are rank 0's afterwards, in the flat buffer and through the views
     import numpy as np
     assert np.array_equal(np.sort(v0), np.sort(b0))      # rank 0 kept its own values (the flat layout only permutes them)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The PRODUCT Generator data-parallel on two gloo ranks, under tests/dryrun.py: every kernel launch is recorded instead of executed
+# (numbers are meaningless), but the segment markers of gtos_amd/generator.py, the parameter -> segment map, the async all-reduces
+# launched from inside the real model's backward, the collective flag and the optimizer's joins are all the product's own code.
+def _product_worker(rank, world, port, q, steps):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from dryrun import DryRun
+    import gtos_amd.train as train_mod
+    from gtos_amd import synth
+    from gtos_amd.config import build_generator
+    from gtos_amd.generator import Generator
+    from gtos_amd.pathtrie import attach_path_trie
+    from gtos_amd.relindex import attach_relation_index
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    log = []
+    real_ar = dist.all_reduce
+
+    def logged_all_reduce(t, op=dist.ReduceOp.SUM, async_op=False, **kw):
+        t.nan_to_num_(0.0, 0.0, 0.0) if t.is_floating_point() else None       # (uninitialised kernel outputs: keep gloo's arithmetic quiet)
+        log.append(("all_reduce", t.numel(), "max" if op == dist.ReduceOp.MAX else "sum", bool(async_op)))
+        return real_ar(t, op=op, async_op=async_op, **kw)
+    train_mod.dist.all_reduce = logged_all_reduce
+    real_backward = torch.Tensor.backward
+
+    def marked_backward(self_, *a, **kw):
+        r = real_backward(self_, *a, **kw)
+        log.append(("backward_end",))
+        return r
+    torch.Tensor.backward = marked_backward
+    dev = torch.device("cpu")
+    with DryRun() as rec:
+        torch.manual_seed(19940117)
+        model = build_generator(Generator, "C1", dev, factored_relation=True).to(dev)
+        model.set_compute_dtype(torch.bfloat16)
+        model.train()
+        trainer = train_mod.Trainer(model, synth.CONFIGS["C1"]["d"], warmup_steps=1, compute_dtype=torch.bfloat16, world_size=world, rank=rank)
+        batch, _ = synth.make_config_batch("C1", rank=rank, B=4)            # rank r holds graphs [4 r, 4 r + 4)
+        attach_relation_index(attach_path_trie(batch))
+        launches = []
+        for _ in range(steps):
+            log.append(("step_begin",))
+            n0 = len(rec.calls)
+            trainer.step(batch, sync=False)
+            launches.append(len(rec.calls) - n0)
+        seg_sizes = [hi - lo for lo, hi in trainer.flat.segments]
+        q.put((rank, log, seg_sizes, launches, bool(trainer.overlap), float(batch["concept"].sum())))
+    dist.destroy_process_group()
+
+
+def test_product_generator_two_ranks_collective_sequence_under_dry_run():
+    world, port, steps = 2, _free_port(), 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_product_worker, args=(r, world, port, q, steps)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, log0, seg0, launches0, overlap0, sig0), (_, log1, seg1, launches1, overlap1, sig1) = res
+    assert overlap0 and overlap1 and seg0 == seg1 and len(seg0) == 4 and all(s > 0 for s in seg0)
+    assert sig0 != sig1                                                   # the ranks hold different graphs
+    assert [e for e in log0 if e[0] != "backward_end"] == [e for e in log1 if e[0] != "backward_end"]    # same collectives, same order
+    per_step, cur = [], None
+    for e in log0:
+        if e == ("step_begin",):
+            cur = []
+            per_step.append(cur)
+        else:
+            cur.append(e)
+    assert len(per_step) == steps
+    for s, ev in enumerate(per_step):
+        flags = [e for e in ev if e[0] == "all_reduce" and e[2] == "max"]
+        sums = [e for e in ev if e[0] == "all_reduce" and e[2] == "sum"]
+        assert len(flags) <= 1                                            # the collective abnormal-loss flag (after the warm-up steps)
+        assert [e[1] for e in sums] == seg0 and all(e[3] for e in sums)   # the four gradient segments, in order, async
+        k = ev.index(("backward_end",))
+        inside = [e for e in ev[:k] if e[0] == "all_reduce" and e[2] == "sum"]
+        assert [e[1] for e in inside] == seg0[:3], (s, ev)               # three of them launched from INSIDE the real model's backward
+    # each rank repeats its own launch plan every step; the two plans differ (rank-local graphs: other trie depths), the collectives do not
+    assert len(set(launches0)) == 1 and len(set(launches1)) == 1 and min(launches0 + launches1) > 300
