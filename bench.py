@@ -572,7 +572,10 @@ def main():
     if feed is not None:
         done = asm_times[n_asm0:] or asm_times
         loader_info.update({"host_assembly_s_per_batch": round(sum(done) / max(1, len(done)), 4),
-                            "consumer_wait_ms_per_step": round(1e3 * wait_s[0] / a.steps, 3)})
+                            "consumer_wait_ms_per_step": round(1e3 * wait_s[0] / a.steps, 3),
+                            # of which (whole run, per batch): waiting for a finished batch / host side of the device-side preparation
+                            "queue_wait_ms_per_batch": round(1e3 * feed.stats["queue_wait_s"] / max(1, feed.stats["batches"]), 3),
+                            "device_prep_ms_per_batch": round(1e3 * feed.stats["device_prep_s"] / max(1, feed.stats["batches"]), 3)})
         feed.close()                                   # the roofline legs below reuse the first batch the feed handed out
         feed = None
     comm_exposed = max(trainer.comm_exposed_s, 1e-3 * trainer.comm_exposed_ms())   # host wait (gloo) / compute-stream stall (RCCL)

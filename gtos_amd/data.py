@@ -538,6 +538,7 @@ class Prefetcher(object):
         import threading
         self._it = iter(batches)
         self._device_tries = device_tries
+        self.stats = {"batches": 0, "queue_wait_s": 0.0, "device_prep_s": 0.0}     # where __next__ spent the consumer's time
         self._out = {}
         self._cv = threading.Condition()          # ONE lock: depth reservation, source advance and hand-over are atomic
         self._next_in, self._next_out, self._done, self._err, self._stop = 0, 0, False, None, False
@@ -721,6 +722,8 @@ class Prefetcher(object):
         return self
 
     def __next__(self):
+        import time
+        t_in = time.perf_counter()
         with self._cv:
             self._cv.wait_for(lambda: self._next_out in self._out or self._err is not None or self._stop or
                               (self._done and self._next_out >= self._next_in))
@@ -732,6 +735,9 @@ class Prefetcher(object):
             self._next_out += 1
             self._cv.notify_all()
         extra = None
+        t_got = time.perf_counter()
+        self.stats["batches"] += 1
+        self.stats["queue_wait_s"] += t_got - t_in            # the consumer waited for a finished batch (loader too slow / too shallow)
         b0 = batch[0] if isinstance(batch, tuple) else batch
         if self._device_tries or 'relation_graphs' in b0:
             # Index preparation left to the device, done HERE, by the consumer's thread, on the copy stream (behind the batch's upload,
@@ -759,6 +765,7 @@ class Prefetcher(object):
                         ev.record(self._copy_stream)
                 else:
                     extra = prep()
+        self.stats["device_prep_s"] += time.perf_counter() - t_got      # host side of the device-side preparation (launches + host reads)
         if ev is not None:
             cur = torch.cuda.current_stream(self._device)
             cur.wait_event(ev)
