@@ -36,7 +36,7 @@ def _index_prep(batch, on):
         except ValueError:
             pass              # no 'relation_trie' key: RelationEncoder.forward falls back to one row per (path, position)
     else:
-        batch['relation_rows'] = int(batch['relation_length'].sum())      # host integer the staged device builder would have to read back
+        batch['relation_rows'] = HostInt(batch['relation_length'].sum())   # host integer the staged device builder would have to read back
     return attach_relation_index(batch)
 
 
@@ -58,6 +58,13 @@ def attach_device_tries(batch, how=True):
         except ValueError:
             pass
     return batch
+
+
+class HostInt(int):
+    """A host integer that rides in a batch dict (``relation_rows``): ``.to()`` returns it unchanged, so ``{k: v.to(device) ...}`` works."""
+
+    def to(self, *a, **k):
+        return self
 
 
 class RelationGraphs(object):
@@ -84,7 +91,7 @@ def attach_device_relations(batch, device=None):
     rel = build_relation_batch_staged(None, rg.special_ids, HipBackend.shared(), path_mode=rg.path_mode, seed=rg.seed, max_len=rg.max_len,
                                       device=dev, csr=rg.csr)
     batch['relation'], batch['relation_bank'], batch['relation_length'] = rel['relation'], rel['relation_bank'], rel['relation_length']
-    batch['relation_rows'] = rel['relation_rows']                          # sum of the path lengths: saves the trie builder a device read
+    batch['relation_rows'] = HostInt(rel['relation_rows'])                 # sum of the path lengths: saves the trie builder a device read
     del batch['relation_graphs']
     return batch
 

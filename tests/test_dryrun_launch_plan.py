@@ -80,3 +80,19 @@ def test_dryrun_restores_what_it_patched():
         assert torch.zeros(1).is_cuda
     assert (torch.cuda.current_stream, torch.cuda.Event, torch.Tensor.is_cuda) == before
     assert not torch.zeros(1).is_cuda
+
+
+def test_training_step_launch_plan_dependency_flavour_and_padded_batch():
+    """C3 (translator flavour: dependency trees, depth ids up to the sentence length) and a padded AMR batch (graphs of different sizes:
+    masks, ragged tries) reach their kernels with well-formed arguments too."""
+    from gtos_amd.pathtrie import attach_path_trie
+    from gtos_amd.relindex import attach_relation_index
+    with DryRun() as rec:
+        for cfg, kw in (("C3", dict(B=4)), ("C1", dict(padded=True))):
+            trainer = _trainer(cfg)
+            batch, _ = synth.make_config_batch(cfg, rank=0, **kw)
+            attach_relation_index(attach_path_trie(batch))
+            n0 = len(rec.calls)
+            trainer.step(batch, sync=False)
+            names = {n for n, _ in rec.calls[n0:]}
+            assert {"gtos_rel_attn_fwd", "gtos_rel_attn_bwd_bank", "gtos_gru_step_fwd", "gtos_copy_nll_fwd", "gtos_adam_step_ctl"} <= names, cfg
