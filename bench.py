@@ -91,6 +91,10 @@ def parse():
                          "agree within 1.5 %% or this many seconds have passed (0 = off).  A box that has been idle runs its first "
                          "minute 5-20 %% slow (measured: four back-to-back runs of this bench on a fresh box 74.7 / 67.5 / 64.5 / 61.7 ms per "
                          "step); on a warm box this costs two windows")
+    ap.add_argument("--prewarm-min-seconds", type=float, default=8.0,
+                    help="the pre-warm runs at least this long before the two-windows criterion may end it: two windows of 5 steps agree within "
+                         "1.5 %% after a second of work even on a box whose step time is still drifting down slowly (0 = criterion only, as in "
+                         "rounds 2-3)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="only check the rank launch / rendezvous (gloo, no GPU): every rank prints its rank and exits")
     return ap.parse_args()
@@ -539,7 +543,8 @@ def main():
             w_s, el_s = tt.tolist()
             prewarm_steps += 5
             log("prewarm window %.1f ms/step" % (200.0 * w_s))
-            if (prev is not None and abs(w_s - prev) <= 0.015 * prev) or el_s > a.prewarm_seconds:
+            settled = prev is not None and abs(w_s - prev) <= 0.015 * prev
+            if (settled and el_s >= min(a.prewarm_min_seconds, a.prewarm_seconds)) or el_s > a.prewarm_seconds:
                 break
             prev = w_s
     for i in range(a.warmup):
