@@ -112,7 +112,7 @@ _raw_stream = None     # torch._C._cuda_getCurrentRawStream once it has been che
 def stream():
     """The current HIP stream's handle, once per launch: the public route builds a torch.cuda.Stream object every time (~1.5 us, as
     much as the ctypes call it feeds); the raw getter returns the integer directly.  It is adopted only after it has agreed with the
-    public API on this process's first launch; any surprise keeps the public route."""
+    public API on this process's first launch, on the current stream and on a probe stream; any surprise keeps the public route."""
     global _raw_stream
     if _raw_stream:
         return _raw_stream(torch.cuda.current_device())
@@ -120,7 +120,12 @@ def stream():
     if _raw_stream is None:
         try:
             raw = torch._C._cuda_getCurrentRawStream
-            _raw_stream = raw if raw(torch.cuda.current_device()) == pub else False
+            ok = raw(torch.cuda.current_device()) == pub
+            probe = torch.cuda.Stream()                      # ... and it must follow a stream switch (the default stream's handle is 0:
+            with torch.cuda.stream(probe):                   # agreeing there proves little)
+                ok = ok and raw(torch.cuda.current_device()) == probe.cuda_stream == torch.cuda.current_stream().cuda_stream
+            ok = ok and raw(torch.cuda.current_device()) == pub
+            _raw_stream = raw if ok else False
         except Exception:
             _raw_stream = False
     return pub
