@@ -128,9 +128,9 @@ GTOS_RB_HD uint64_t key_core(int32_t g, int32_t i, int32_t j, int32_t t, const S
             const double u01 = (double)(splitmix(st) >> 11) * (1.0 / 9007199254740992.0);
             const double target = u01 * sl.count[v];
             double acc = 0.0;
-            for (;;) {
+            for (int32_t guard = 0;; ++guard) {                // (guard: a DAG list has at most 32,767 entries -- a corrupted one must not spin)
                 acc += sl.count[sl.dpred[e]];
-                if (target < acc || sl.dnext[e] < 0) break;
+                if (target < acc || sl.dnext[e] < 0 || guard >= 32767) break;
                 e = sl.dnext[e];
             }
         }
