@@ -33,11 +33,17 @@ def plan(cfg):
         trainer.step(batch, sync=False)
         n0, t0 = len(rec.calls), time.perf_counter()
         trainer.step(batch, sync=False)
-        hist = {}
-        for name, _ in rec.calls[n0:]:
+        hist, gemms = {}, {}
+        for name, args in rec.calls[n0:]:
             hist[name] = hist.get(name, 0) + 1
+            if name == "gtos_gemm":                        # (dtype_a, dtype_out, trans_a, trans_b, M, N, K, ..., splitk at index 18)
+                key = ("T" if args[2] else "N") + ("T" if args[3] else "N"), args[4], args[5], args[6], args[18]
+                gemms[key] = gemms.get(key, 0) + 1
+    shapes = sorted(({"op": k[0], "M": k[1], "N": k[2], "K": k[3], "splitk": k[4], "calls": v, "gflop": round(2e-9 * k[1] * k[2] * k[3] * v, 1)}
+                     for k, v in gemms.items()), key=lambda r: -r["gflop"])
     return {"config": cfg, "batch": {k: st[k] for k in ("n", "B", "T", "R")}, "entry_point_calls_per_step": sum(hist.values()),
-            "host_seconds_of_the_dry_step": round(time.perf_counter() - t0, 2), "by_entry": dict(sorted(hist.items(), key=lambda kv: -kv[1]))}
+            "host_seconds_of_the_dry_step": round(time.perf_counter() - t0, 2), "by_entry": dict(sorted(hist.items(), key=lambda kv: -kv[1])),
+            "gemm_tflop_per_step": round(sum(r["gflop"] for r in shapes) / 1e3, 2), "gemm_shapes": shapes[:24]}
 
 
 if __name__ == "__main__":
