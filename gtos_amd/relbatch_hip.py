@@ -118,8 +118,8 @@ def build_relation_batch_staged(graphs, special_ids, backend, path_mode=PATH_FIR
     B, S, P, nmax, emax = c["B"], c["S"], c["P"], c["nmax"], c["emax"]
     n = nmax + 1
     total = P + 3
-    if total > 0x7fffffff:
-        raise ValueError("too many pairs for the builder's 32-bit positions")
+    if 8 * total >= 1 << 32:                    # 32-bit positions, and the bank's row count (<= 8 per pair) rides in half a 64-bit word
+        raise ValueError("too many pairs for the builder's 32-bit counters")
     geom = dict(B=B, n=n, nmax=nmax, emax=emax, max_len=max_len, mode=1 if path_mode == PATH_UNIFORM else 0, S=S, P=P,
                 seed=int(seed) & 0xffffffffffffffff, cls=cls, rcls=rcls, tl=tl)
     geom["self"] = self_
