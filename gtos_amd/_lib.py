@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgtos_hip.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 c_p, c_i, c_l, c_f, c_u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_uint64
 
@@ -24,6 +24,9 @@ SIGNATURES = {
     "gtos_relbatch_dev_workspace": [c_l, c_p],
     "gtos_relbatch_dev_phase_a": [c_p, c_p, c_p, ctypes.c_size_t, c_p],
     "gtos_relbatch_dev_phase_b": [c_p, c_l, c_p, c_p, ctypes.c_size_t, c_p],
+    "gtos_relbatch_dev_all_count": [c_p, c_p, c_p, ctypes.c_size_t, c_p],
+    "gtos_relbatch_dev_all_keys": [c_p, c_p, c_p, ctypes.c_size_t, c_p],
+    "gtos_relbatch_dev_all_fill": [c_p, c_l, c_p, c_p, ctypes.c_size_t, c_p],
     "gtos_relindex_dev_workspace": [c_l, c_p],
     "gtos_relindex_dev_phase_a": [c_p, c_p, c_p, ctypes.c_size_t, c_p],
     "gtos_relindex_dev_phase_b": [c_p, c_l, c_p, c_p, ctypes.c_size_t, c_p],

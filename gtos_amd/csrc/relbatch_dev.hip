@@ -62,6 +62,31 @@ __global__ void k_cls_cells(Geom G, Graphs gr, int64_t* relation) {
     if (s < G.S) cls_cells(s, G, gr, relation);
 }
 
+__global__ void k_pair_alt_count(Geom G, Graphs gr, Scratch sc, uint32_t* nalt, uint64_t* nalt64) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < G.P) pair_alt_count(p, G, gr, sc, nalt, nalt64);
+}
+__global__ void k_sizes_count(const uint64_t* cum, const uint32_t* cmax, int64_t P, int32_t* sizes) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) sizes_count(cum, cmax, P, sizes);
+}
+__global__ void k_special_all(Geom G, uint64_t* key, int32_t* posn, int32_t* len_seen) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) special_keys_all(G, key, posn, len_seen);
+}
+__global__ void k_pair_alt_keys(Geom G, Graphs gr, Scratch sc, const uint64_t* cum_alt, const uint32_t* nalt, uint64_t* key, int32_t* posn,
+                                int32_t* len_seen) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < G.P) pair_alt_keys(p, G, gr, sc, cum_alt, nalt, key, posn, len_seen);
+}
+__global__ void k_scatter_relation_all(int64_t total, Geom G, Graphs gr, const int32_t* posn, const uint64_t* cum_flag, const int32_t* type_of_seg,
+                                       const uint64_t* cum_alt, int64_t* relation) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < total) scatter_relation_all(e, G, gr, posn, cum_flag, type_of_seg, cum_alt, relation);
+}
+__global__ void k_cls_cells_all(Geom G, Graphs gr, int64_t* relation) {
+    const int32_t s = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (s < G.S) cls_cells_all(s, G, gr, relation);
+}
+
 int bits_for(int64_t n) {                 // radix-sort key bits that can be set in values below n
     int b = 1;
     while ((1ll << b) < n && b < 32) ++b;
@@ -90,7 +115,7 @@ extern "C" int gtos_relbatch_dev_workspace(int64_t total, int64_t* bytes_out) {
 extern "C" int gtos_relbatch_dev_phase_a(const int64_t* geom, void** tab, void* workspace, size_t workspace_bytes, void* stream) {
     if (!geom || !tab || !workspace) return -1;
     const Geom G = geom_of(geom);
-    if (!geom_ok(G)) return -1;
+    if (!geom_ok(G) || G.mode == MODE_ALL) return -1;
     for (int k = 0; k <= T_SEG_KEY; ++k) if (!tab[k]) return -1;
     if (!tab[T_LEN_SEEN] || !tab[T_SIZES]) return -1;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -128,8 +153,8 @@ extern "C" int gtos_relbatch_dev_phase_a(const int64_t* geom, void** tab, void* 
 extern "C" int gtos_relbatch_dev_phase_b(const int64_t* geom, int64_t R, void** tab, void* workspace, size_t workspace_bytes, void* stream) {
     if (!geom || !tab || !workspace || R < N_SPECIAL) return -1;
     const Geom G = geom_of(geom);
-    if (!geom_ok(G)) return -1;
-    for (int k = 0; k < T_TABLE_COUNT; ++k) if (!tab[k]) return -1;
+    if (!geom_ok(G) || G.mode == MODE_ALL) return -1;
+    for (int k = 0; k <= T_LENGTH; ++k) if (!tab[k]) return -1;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const Graphs gr = graphs_of(tab);
     const int64_t total = G.P + N_SPECIAL;
@@ -144,6 +169,94 @@ extern "C" int gtos_relbatch_dev_phase_b(const int64_t* geom, int64_t R, void** 
                        (const int32_t*)tab[T_TYPE_OF_SEG], (int64_t*)tab[T_RELATION]);
     GTOS_RB_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_cls_cells, grid_for(G.S, 256), dim3(256), 0, s, G, gr, (int64_t*)tab[T_RELATION]);
+    GTOS_RB_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- GTOS_PATH_ALL (every shortest path of every pair; relation int64 [n,n,B,K]): three phases with a host read after the first two.
+// Counting phase: the searches, the number of shortest paths of every pair, their running sum and maximum.  Afterwards sizes[RZ_T] =
+// paths in total (-1: more than 2^31), sizes[RZ_K] = most of one pair; the caller sizes the key arrays (T + 4) from them.
+extern "C" int gtos_relbatch_dev_all_count(const int64_t* geom, void** tab, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!geom || !tab || !workspace) return -1;
+    const Geom G = geom_of(geom);
+    if (!geom_ok(G) || G.mode != MODE_ALL) return -1;
+    for (int k = 0; k <= T_DLAB; ++k) if (!tab[k]) return -1;
+    if (!tab[T_NALT] || !tab[T_CUM_ALT] || !tab[T_CMAX_ALT] || !tab[T_NALT64] || !tab[T_SIZES]) return -1;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Graphs gr = graphs_of(tab);
+    const Scratch sc = scratch_of(tab);
+    uint32_t *nalt = (uint32_t*)tab[T_NALT], *cmax = (uint32_t*)tab[T_CMAX_ALT];
+    uint64_t *nalt64 = (uint64_t*)tab[T_NALT64], *cum = (uint64_t*)tab[T_CUM_ALT];
+    hipLaunchKernelGGL(k_bfs, grid_for(G.S, 64), dim3(64), 0, s, G, gr, sc);
+    GTOS_RB_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_pair_alt_count, grid_for(G.P, 256), dim3(256), 0, s, G, gr, sc, nalt, nalt64);
+    GTOS_RB_LAUNCH_CHECK();
+    size_t bytes = workspace_bytes;
+    GTOS_RB_HIP(rocprim::inclusive_scan(workspace, bytes, (const uint64_t*)nalt64, cum, (size_t)G.P, rocprim::plus<uint64_t>(), s));
+    bytes = workspace_bytes;
+    GTOS_RB_HIP(rocprim::inclusive_scan(workspace, bytes, (const uint32_t*)nalt, cmax, (size_t)G.P, rocprim::maximum<uint32_t>(), s));
+    hipLaunchKernelGGL(k_sizes_count, dim3(1), dim3(64), 0, s, (const uint64_t*)cum, (const uint32_t*)cmax, G.P, (int32_t*)tab[T_SIZES]);
+    GTOS_RB_LAUNCH_CHECK();
+    return 0;
+}
+
+// Key phase (geom carries T and K as the host read them): the keys of every path, the key sort, the distinct keys.  Afterwards
+// sizes[RZ_R / RZ_L / RZ_N] as after gtos_relbatch_dev_phase_a.
+extern "C" int gtos_relbatch_dev_all_keys(const int64_t* geom, void** tab, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!geom || !tab || !workspace) return -1;
+    const Geom G = geom_of(geom);
+    if (!geom_ok(G) || G.mode != MODE_ALL || G.T < G.P || G.K < 1 || G.T + N_SPECIAL_ALL > 0x7fffffffLL) return -1;
+    for (int k = 0; k <= T_SEG_KEY; ++k) if (!tab[k]) return -1;
+    if (!tab[T_LEN_SEEN] || !tab[T_SIZES] || !tab[T_NALT] || !tab[T_CUM_ALT]) return -1;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Graphs gr = graphs_of(tab);
+    const Scratch sc = scratch_of(tab);
+    uint64_t *key = (uint64_t*)tab[T_KEY], *skey = (uint64_t*)tab[T_SKEY], *seg_key = (uint64_t*)tab[T_SEG_KEY];
+    int32_t *posn = (int32_t*)tab[T_POSN], *spos = (int32_t*)tab[T_SPOS], *seg_id = (int32_t*)tab[T_SEG_ID];
+    uint64_t *flag = (uint64_t*)tab[T_FLAG], *cum = (uint64_t*)tab[T_CUM];
+    uint32_t* first_pos = (uint32_t*)tab[T_FIRST_POS];
+    int32_t *len_seen = (int32_t*)tab[T_LEN_SEEN], *sizes = (int32_t*)tab[T_SIZES];
+    const int64_t total = G.T + N_SPECIAL_ALL;
+    GTOS_RB_HIP(hipMemsetAsync(len_seen, 0, 8 * sizeof(int32_t), s));
+    hipLaunchKernelGGL(k_special_all, dim3(1), dim3(64), 0, s, G, key, posn, len_seen);
+    GTOS_RB_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_pair_alt_keys, grid_for(G.P, 256), dim3(256), 0, s, G, gr, sc, (const uint64_t*)tab[T_CUM_ALT], (const uint32_t*)tab[T_NALT], key,
+                       posn, len_seen);
+    GTOS_RB_LAUNCH_CHECK();
+    size_t bytes = workspace_bytes;
+    GTOS_RB_HIP(rocprim::radix_sort_pairs(workspace, bytes, (const uint64_t*)key, skey, (const int32_t*)posn, spos, (size_t)total, 0, 64, s));
+    hipLaunchKernelGGL(k_head_flag, grid_for(total, 256), dim3(256), 0, s, total, (const uint64_t*)skey, flag);
+    GTOS_RB_LAUNCH_CHECK();
+    bytes = workspace_bytes;
+    GTOS_RB_HIP(rocprim::inclusive_scan(workspace, bytes, (const uint64_t*)flag, cum, (size_t)total, rocprim::plus<uint64_t>(), s));
+    hipLaunchKernelGGL(k_segment_first, grid_for(total, 256), dim3(256), 0, s, total, (const uint64_t*)skey, (const int32_t*)spos, (const uint64_t*)cum,
+                       first_pos, seg_id, seg_key);
+    GTOS_RB_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_sizes, dim3(1), dim3(64), 0, s, (const uint64_t*)cum, total, (const int32_t*)len_seen, sizes);
+    GTOS_RB_LAUNCH_CHECK();
+    return 0;
+}
+
+// Fill phase: R as the host read it; relation int64 [n,n,B,K] and bank int64 [8,R] zero-filled by the caller.
+extern "C" int gtos_relbatch_dev_all_fill(const int64_t* geom, int64_t R, void** tab, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!geom || !tab || !workspace || R < N_SPECIAL_ALL) return -1;
+    const Geom G = geom_of(geom);
+    if (!geom_ok(G) || G.mode != MODE_ALL || G.K < 1) return -1;
+    for (int k = 0; k < T_TABLE_COUNT; ++k) if (!tab[k]) return -1;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Graphs gr = graphs_of(tab);
+    const int64_t total = G.T + N_SPECIAL_ALL;
+    if (R > total) return -1;
+    size_t bytes = workspace_bytes;
+    GTOS_RB_HIP(rocprim::radix_sort_pairs(workspace, bytes, (const uint32_t*)tab[T_FIRST_POS], (uint32_t*)tab[T_FIRST_ALT], (const int32_t*)tab[T_SEG_ID],
+                                          (int32_t*)tab[T_SORTED_SEG], (size_t)R, 0, bits_for(total), s));
+    hipLaunchKernelGGL(k_type_of_segment, grid_for(R, 256), dim3(256), 0, s, R, (const int32_t*)tab[T_SORTED_SEG], (const uint64_t*)tab[T_SEG_KEY],
+                       (int32_t*)tab[T_TYPE_OF_SEG], (int64_t*)tab[T_BANK], (int64_t*)tab[T_LENGTH]);
+    GTOS_RB_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_scatter_relation_all, grid_for(total, 256), dim3(256), 0, s, total, G, gr, (const int32_t*)tab[T_SPOS], (const uint64_t*)tab[T_CUM],
+                       (const int32_t*)tab[T_TYPE_OF_SEG], (const uint64_t*)tab[T_CUM_ALT], (int64_t*)tab[T_RELATION]);
+    GTOS_RB_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_cls_cells_all, grid_for(G.S, 256), dim3(256), 0, s, G, gr, (int64_t*)tab[T_RELATION]);
     GTOS_RB_LAUNCH_CHECK();
     return 0;
 }

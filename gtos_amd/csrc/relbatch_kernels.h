@@ -24,16 +24,19 @@
 
 namespace gtos_relbatch_dev {
 
-enum { MODE_FIRST = 0, MODE_UNIFORM = 1 };
+enum { MODE_FIRST = 0, MODE_UNIFORM = 1, MODE_ALL = 2 };   // (ALL: every shortest path of a pair -- the eval-mode batches, own entry points)
 // sizes[] written on the device, read by the host once per batch
-enum { RZ_R = 0, RZ_L = 1, RZ_N = 2, RZ_TOTAL = 4 };     // distinct paths, longest path, sum of their lengths
-enum { N_SPECIAL = 3 };                                   // <CLS>, <rCLS>, <SELF> are interned before any pair (relbatch.cpp phase b)
+enum { RZ_R = 0, RZ_L = 1, RZ_N = 2, RZ_T = 3, RZ_K = 4, RZ_TOTAL = 8 };     // distinct paths, longest path, sum of their lengths; ALL: paths in total, most per pair
+enum { N_SPECIAL = 3, N_SPECIAL_ALL = 4 };               // <CLS>, <rCLS>, <SELF> are interned before any pair (relbatch.cpp phase b); ALL: <PAD> first
 
 struct Geom {
     int32_t B, n, nmax, emax, max_len, mode;              // n = 1 + most nodes of a graph (index 0 = <CLS>); nmax / emax: scratch strides
     int32_t S;                                            // (graph, source) slots = sum of the node counts
     int64_t P;                                            // pairs = sum of the squared node counts
     uint64_t seed, cls_key, rcls_key, self_key, tl_key;
+    int64_t T;                                            // MODE_ALL: paths of all pairs together (known after the counting phase)
+    int32_t K;                                            // MODE_ALL: most paths of one pair
+    uint64_t pad_key;
 };
 
 struct Graphs {                                           // device (or host) arrays describing the batch's graphs
@@ -239,12 +242,117 @@ GTOS_RB_HD void cls_cells(int32_t s, const Geom& G, const Graphs& gr, int64_t* r
     if (a == 1) relation[g] = 2;
 }
 
+// =====================================================================================================================================
+// MODE_ALL: every shortest path of every pair, in networkx's enumeration order (generator/data.py:178-232: the eval-mode batches,
+// relation[n,n,B,K] with type 0 = <PAD> behind a pair's last alternative).  Counting phase -> host read (T, K) -> key phase -> host
+// read (R, L, N) -> fill phase.
+
+// ---- the number of shortest paths of pair p = the BFS path count of its target (1 for <SELF> / <TL>)
+GTOS_RB_HD void pair_alt_count(int64_t p, const Geom& G, const Graphs& gr, const Scratch& sc, uint32_t* nalt, uint64_t* nalt64) {
+    const int32_t g = graph_of<int64_t>(gr.pair_off, G.B, p);
+    const int32_t n = gr.ng[g];
+    const int64_t q = p - gr.pair_off[g];
+    const int32_t i = (int32_t)(q / n), j = (int32_t)(q % n);
+    const Slot sl = slot_of(sc, gr.node_off[g] + i, G.nmax, G.emax);
+    const int32_t t = gr.order[gr.node_off[g] + j];
+    const int32_t d = sl.level[t];
+    const double c = sl.count[t];
+    nalt[p] = (d == 0 || d > G.max_len) ? 1u : (c >= 4294967295.0 ? 0xffffffffu : (uint32_t)c);
+    nalt64[p] = nalt[p];                                      // (the sum scan runs in 64 bits)
+}
+
+// one thread: totals of the counting phase (cum = inclusive sum scan, cmax = inclusive max scan of nalt)
+GTOS_RB_HD void sizes_count(const uint64_t* cum, const uint32_t* cmax, int64_t P, int32_t* sizes) {
+    const uint64_t T = cum[P - 1];
+    sizes[RZ_T] = T > 0x7fffffffull ? -1 : (int32_t)T;
+    sizes[RZ_K] = (int32_t)(cmax[P - 1] > 0x7fffffffu ? 0x7fffffffu : cmax[P - 1]);
+}
+
+// ---- the keys of pair p, all of them, in the order of nx.all_shortest_paths: a depth-first walk over the predecessor lists from the
+// target back to the source (an explicit stack of (node, next list entry)), emitting a path whenever the source is reached --
+// csrc_host/relbatch.cpp graph_paths, GTOS_PATH_ALL.  cum = inclusive scan of the counts: the pair's keys start at cum[p] - nalt[p].
+GTOS_RB_HD void pair_alt_keys(int64_t p, const Geom& G, const Graphs& gr, const Scratch& sc, const uint64_t* cum, const uint32_t* nalt,
+                              uint64_t* key, int32_t* posn, int32_t* len_seen) {
+    const int32_t g = graph_of<int64_t>(gr.pair_off, G.B, p);
+    const int32_t n = gr.ng[g];
+    const int64_t q = p - gr.pair_off[g];
+    const int32_t i = (int32_t)(q / n), j = (int32_t)(q % n);
+    const Slot sl = slot_of(sc, gr.node_off[g] + i, G.nmax, G.emax);
+    const int32_t s = gr.order[gr.node_off[g] + i], t = gr.order[gr.node_off[g] + j];
+    const int32_t d = sl.level[t];
+    int64_t at = N_SPECIAL_ALL + (int64_t)(cum[p] - nalt[p]);
+    const int64_t end = at + nalt[p];
+    if (d == 0 || d > G.max_len) {
+        key[at] = d == 0 ? G.self_key : G.tl_key;
+        posn[at] = (int32_t)at;
+        len_seen[0] = 1;
+        return;
+    }
+    int32_t st_node[10], st_edge[10], st_lab[10];            // depth <= max_len <= 8
+    int32_t top = 0;
+    st_node[0] = t; st_edge[0] = sl.head[t]; st_lab[0] = 0;
+    while (top >= 0) {
+        const int32_t node = st_node[top];
+        if (node == s && at < end) {                            // labels along the stack from the source side
+            uint64_t k64 = 0;
+            for (int32_t k = 0; k < top; ++k) k64 |= (uint64_t)(st_lab[top - k] & 0xff) << (8 * k);
+            key[at] = k64;
+            posn[at] = (int32_t)at;
+            ++at;
+        }
+        const int32_t e = node == s ? -1 : st_edge[top];       // (the source has no predecessor in the DAG)
+        if (e >= 0) {
+            st_edge[top] = sl.dnext[e];
+            ++top;
+            st_node[top] = sl.dpred[e]; st_edge[top] = sl.head[sl.dpred[e]]; st_lab[top] = sl.dlab[e];
+        } else {
+            --top;
+        }
+    }
+    len_seen[d - 1] = 1;
+}
+
+GTOS_RB_HD void special_keys_all(const Geom& G, uint64_t* key, int32_t* posn, int32_t* len_seen) {
+    key[0] = G.pad_key; key[1] = G.cls_key; key[2] = G.rcls_key; key[3] = G.self_key;
+    posn[0] = 0; posn[1] = 1; posn[2] = 2; posn[3] = 3;
+    len_seen[0] = 1;
+}
+
+// ---- relation[a = j + 1][c = i + 1][g][k] = type of the k-th path of the pair (element e of the sorted list)
+GTOS_RB_HD void scatter_relation_all(int64_t e, const Geom& G, const Graphs& gr, const int32_t* posn, const uint64_t* cum_flag, const int32_t* type_of_seg,
+                                     const uint64_t* cum_alt, int64_t* relation) {
+    const int32_t pos = posn[e];
+    if (pos < N_SPECIAL_ALL) return;
+    const uint64_t x = (uint64_t)(pos - N_SPECIAL_ALL);        // index among all paths: pair = first p with cum_alt[p] > x
+    int64_t lo = 0, hi = G.P - 1;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (cum_alt[mid] > x) hi = mid; else lo = mid + 1;
+    }
+    const int64_t p = lo;
+    const int64_t k = (int64_t)x - (int64_t)(p ? cum_alt[p - 1] : 0);
+    const int32_t g = graph_of<int64_t>(gr.pair_off, G.B, p);
+    const int32_t n = gr.ng[g];
+    const int64_t q = p - gr.pair_off[g];
+    const int32_t i = (int32_t)(q / n), j = (int32_t)(q % n);
+    relation[(((int64_t)(j + 1) * G.n + (i + 1)) * G.B + g) * G.K + k] = type_of_seg[(uint32_t)cum_flag[e] - 1];
+}
+
+// the <CLS> row / column: <PAD>, <CLS>, <rCLS>, <SELF> sit at first-seen positions 0..3 (different ids, checked by the caller): types 0..3
+GTOS_RB_HD void cls_cells_all(int32_t s, const Geom& G, const Graphs& gr, int64_t* relation) {
+    const int32_t g = graph_of<int32_t>(gr.node_off, G.B, s);
+    const int32_t a = s - gr.node_off[g] + 1;
+    relation[(((int64_t)a * G.n + 0) * G.B + g) * G.K] = 1;
+    relation[(((int64_t)0 * G.n + a) * G.B + g) * G.K] = 2;
+    if (a == 1) relation[(int64_t)g * G.K] = 3;
+}
+
 }  // namespace gtos_relbatch_dev
 
 // ---- the two-phase C ABI (gtos_relbatch_dev_phase_a / _b and their emulation)
 // geom[]: host integers, int64 each
 namespace gtos_relbatch_dev {
-enum { GE_B = 0, GE_N, GE_NMAX, GE_EMAX, GE_MAX_LEN, GE_MODE, GE_S, GE_P, GE_SEED, GE_CLS, GE_RCLS, GE_SELF, GE_TL, GE_COUNT };
+enum { GE_B = 0, GE_N, GE_NMAX, GE_EMAX, GE_MAX_LEN, GE_MODE, GE_S, GE_P, GE_SEED, GE_CLS, GE_RCLS, GE_SELF, GE_TL, GE_T, GE_K, GE_PAD, GE_COUNT };
 // tab[]: device (or host) pointers
 enum { T_NG = 0,          // int32 [B]
        T_NODE_OFF,        // int32 [B + 1]
@@ -279,6 +387,10 @@ enum { T_NG = 0,          // int32 [B]
        T_RELATION,        // int64 [n, n, B]  ZERO-FILLED by the caller
        T_BANK,            // int64 [8, R]     ZERO-FILLED by the caller (phase B)
        T_LENGTH,          // int64 [R]
+       T_NALT,            // uint32 [P]   MODE_ALL: shortest paths of every pair
+       T_CUM_ALT,         // uint64 [P]   their inclusive sum
+       T_CMAX_ALT,        // uint32 [P]   their inclusive maximum
+       T_NALT64,          // uint64 [P]   the counts again, as the 64-bit input of the sum scan
        T_TABLE_COUNT };
 
 inline Geom geom_of(const int64_t* g) {
@@ -287,6 +399,7 @@ inline Geom geom_of(const int64_t* g) {
     G.max_len = (int32_t)g[GE_MAX_LEN]; G.mode = (int32_t)g[GE_MODE]; G.S = (int32_t)g[GE_S]; G.P = g[GE_P];
     G.seed = (uint64_t)g[GE_SEED]; G.cls_key = (uint64_t)g[GE_CLS]; G.rcls_key = (uint64_t)g[GE_RCLS];
     G.self_key = (uint64_t)g[GE_SELF]; G.tl_key = (uint64_t)g[GE_TL];
+    G.T = g[GE_T]; G.K = (int32_t)g[GE_K]; G.pad_key = (uint64_t)g[GE_PAD];
     return G;
 }
 inline Graphs graphs_of(void** t) {
@@ -304,6 +417,6 @@ inline Scratch scratch_of(void** t) {
 }
 inline bool geom_ok(const Geom& G) {
     return G.B > 0 && G.n > 1 && G.nmax > 0 && G.nmax <= 32767 && G.emax > 0 && G.emax <= 32767 && G.max_len >= 1 && G.max_len <= 8 &&
-           (G.mode == MODE_FIRST || G.mode == MODE_UNIFORM) && G.S > 0 && G.P > 0 && G.P + N_SPECIAL <= 0x7fffffffLL;
+           (G.mode == MODE_FIRST || G.mode == MODE_UNIFORM || G.mode == MODE_ALL) && G.S > 0 && G.P > 0 && G.P + N_SPECIAL_ALL <= 0x7fffffffLL;
 }
 }  // namespace gtos_relbatch_dev

@@ -1114,4 +1114,4 @@ extern "C" int gtos_transpose_batch_bf16(int n_mat, const int64_t* desc, const i
     return 0;
 }
 
-extern "C" int gtos_abi_version(void) { return 15; }
+extern "C" int gtos_abi_version(void) { return 16; }

@@ -86,10 +86,13 @@ def attach_device_relations(batch, device=None):
     rg = batch.get('relation_graphs')
     if rg is None or 'relation' in batch:
         return batch
-    from .relbatch_hip import HipBackend, build_relation_batch_staged
+    from .relbatch_hip import HipBackend, build_relation_batch_all_staged, build_relation_batch_staged
     dev = batch['concept'].device if device is None else torch.device(device)
-    rel = build_relation_batch_staged(None, rg.special_ids, HipBackend.shared(), path_mode=rg.path_mode, seed=rg.seed, max_len=rg.max_len,
-                                      device=dev, csr=rg.csr)
+    if rg.path_mode == relbatch.PATH_ALL:        # an eval batch: every shortest path, relation [n,n,B,K]
+        rel = build_relation_batch_all_staged(None, rg.special_ids, HipBackend.shared(), max_len=rg.max_len, device=dev, csr=rg.csr)
+    else:
+        rel = build_relation_batch_staged(None, rg.special_ids, HipBackend.shared(), path_mode=rg.path_mode, seed=rg.seed, max_len=rg.max_len,
+                                          device=dev, csr=rg.csr)
     batch['relation'], batch['relation_bank'], batch['relation_length'] = rel['relation'], rel['relation_bank'], rel['relation_length']
     batch['relation_rows'] = HostInt(rel['relation_rows'])                 # sum of the path lengths: saves the trie builder a device read
     del batch['relation_graphs']
@@ -100,7 +103,7 @@ def attach_device_relation_index(batch):
     """``batch['relation_index']`` of a train-mode batch whose ``relation`` lives on the device, by the staged HIP builder
     (gtos_amd.relindex_hip) on the current stream; outside that builder's case the batch is left alone (ops.FactoredRelation then
     derives an index with torch ops)."""
-    if 'relation_index' not in batch and batch['relation'].dim() == 3:
+    if 'relation_index' not in batch and batch['relation'].dim() == 3:        # (eval batches are [n,n,B,K]: not factored)
         from .relindex_hip import HipBackend, build_relation_index_staged
         try:
             batch['relation_index'] = build_relation_index_staged(batch['relation'], batch['relation_bank'].shape[1], HipBackend.shared())
@@ -292,14 +295,14 @@ def batchify_amr(items, vocabs, train=True, seed=0, n_threads=0, unk_rate=0., rn
     (the model averages over K, so neither is observable)."""
     rv = vocabs['relation']
     graphs = [_item_graph(x, rv, graph_cache) for x in items]
-    if index_prep == "device_all" and train:
+    if index_prep == "device_all":
         # the all-pairs work, the bank, the tries and the relation index are all left to the consumer's device: ship the graphs
         from .relbatch_hip import graphs_csr
         csr = graphs_csr(graphs)
         for b, x in enumerate(items):
             lo, hi = int(csr['node_off'][b]), int(csr['node_off'][b + 1])
             assert csr['order'][lo:hi].tolist() == list(range(len(x['concept']))), "items must list their concepts in BFS order"
-        rel = {'relation_graphs': RelationGraphs(csr, relation_special_ids(rv), relbatch.PATH_UNIFORM, seed)}
+        rel = {'relation_graphs': RelationGraphs(csr, relation_special_ids(rv), relbatch.PATH_UNIFORM if train else relbatch.PATH_ALL, seed)}
     else:
         rel = relbatch.build_relation_batch(graphs, relation_special_ids(rv),
                                             path_mode=relbatch.PATH_UNIFORM if train else relbatch.PATH_ALL, seed=seed,

@@ -1,6 +1,7 @@
 """The relation tensors of a batch built by the staged GPU builder (csrc/relbatch_dev.hip; per-thread stages in
-csrc/relbatch_kernels.h): the device-side counterpart of ``relbatch.build_relation_batch`` for the one-path-per-pair modes
-(PATH_FIRST: translator flavour; PATH_UNIFORM: generator flavour in training), i.e. the relation section of the reference's batchify
+csrc/relbatch_kernels.h): the device-side counterpart of ``relbatch.build_relation_batch`` -- the one-path-per-pair modes
+(PATH_FIRST: translator flavour; PATH_UNIFORM: generator flavour in training) through ``build_relation_batch_staged``, the every-path
+mode of the eval batches (PATH_ALL) through ``build_relation_batch_all_staged`` --, i.e. the relation section of the reference's batchify
 (generator/data.py:134-176, translator/data.py:132-176) and the all-pairs shortest label paths under it.
 
 The host flattens the graphs (ordered adjacency + BFS order, ``gtos_relbatch_csr`` of libgtos_host.so: a few thousand integers);
@@ -19,13 +20,13 @@ import torch
 
 from . import relbatch
 
-PATH_FIRST, PATH_UNIFORM = relbatch.PATH_FIRST, relbatch.PATH_UNIFORM
+PATH_FIRST, PATH_UNIFORM, PATH_ALL = relbatch.PATH_FIRST, relbatch.PATH_UNIFORM, relbatch.PATH_ALL
 # order of geom[] and of the pointer table: csrc/relbatch_kernels.h (enum GE_* / T_*)
-_GEOM = ("B", "n", "nmax", "emax", "max_len", "mode", "S", "P", "seed", "cls", "rcls", "self", "tl")
+_GEOM = ("B", "n", "nmax", "emax", "max_len", "mode", "S", "P", "seed", "cls", "rcls", "self", "tl", "T", "K", "pad")
 _TABLE = ("ng", "node_off", "pair_off", "adj_base", "adj_off", "adj_dst", "adj_lab", "order",
           "level", "count", "head", "tail", "queue", "dpred", "dnext", "dlab",
           "key", "posn", "skey", "spos", "flag", "cum", "first_pos", "seg_id", "seg_key", "first_alt", "sorted_seg", "type_of_seg",
-          "len_seen", "sizes", "relation", "bank", "length")
+          "len_seen", "sizes", "relation", "bank", "length", "nalt", "cum_alt", "cmax_alt", "nalt64")
 
 
 def _table(bufs):
@@ -33,7 +34,7 @@ def _table(bufs):
 
 
 def _geom(g):
-    vals = [int(g[k]) for k in _GEOM]
+    vals = [int(g.get(k, 0)) for k in _GEOM]
     return (ctypes.c_int64 * len(_GEOM))(*[v - (1 << 64) if v >= 1 << 63 else v for v in vals])    # (the seed is a uint64 bit pattern)
 
 
@@ -101,6 +102,15 @@ class HipBackend(object):
         if rc:
             raise RuntimeError("gtos_relbatch_dev_phase_b failed: %d" % rc)
 
+    def all_phase(self, which, geom, bufs, n, R=0):
+        """the three phases of the every-shortest-path mode: 'count', 'keys', 'fill'"""
+        ws = self._workspace(n, bufs["nalt"].device)
+        fn = getattr(self._lib, "gtos_relbatch_dev_all_" + which)
+        rc = (fn(_geom(geom), R, _table(bufs), ws.data_ptr(), ws.numel(), self._stream()) if which == "fill" else
+              fn(_geom(geom), _table(bufs), ws.data_ptr(), ws.numel(), self._stream()))
+        if rc:
+            raise RuntimeError("gtos_relbatch_dev_all_%s failed: %d" % (which, rc))
+
 
 def build_relation_batch_staged(graphs, special_ids, backend, path_mode=PATH_FIRST, seed=0, max_len=8, device="cpu", csr=None):
     """As ``relbatch.build_relation_batch`` (same arguments, same dict of tensors: relation [n,n,B], relation_bank [L,R],
@@ -140,7 +150,7 @@ def build_relation_batch_staged(graphs, special_ids, backend, path_mode=PATH_FIR
     bufs.update(level=E((S, nmax), i16), count=E((S, nmax), f64), head=E((S, nmax), i16), tail=E((S, nmax), i16), queue=E((S, nmax), i16),
                 dpred=E((S, emax), i16), dnext=E((S, emax), i16), dlab=E((S, emax), i8),
                 key=E(total, i64), posn=E(total, i32), skey=E(total, i64), spos=E(total, i32), flag=E(total, i64), cum=E(total, i64),
-                first_pos=E(total, i32), seg_id=E(total, i32), seg_key=E(total, i64), len_seen=E(8, i32), sizes=E(4, i32),
+                first_pos=E(total, i32), seg_id=E(total, i32), seg_key=E(total, i64), len_seen=E(8, i32), sizes=E(8, i32),
                 relation=torch.zeros((n, n, B), dtype=i64, device=dev))
     backend.phase_a(geom, bufs, total)
     R, L, N = bufs["sizes"][:3].tolist()                                  # the one host read: distinct paths, longest, bank rows
@@ -148,6 +158,62 @@ def build_relation_batch_staged(graphs, special_ids, backend, path_mode=PATH_FIR
     bufs.update(first_alt=E(R, i32), sorted_seg=E(R, i32), type_of_seg=E(R, i32), bank=torch.zeros((8, R), dtype=i64, device=dev),
                 length=E(R, i64))
     backend.phase_b(geom, R, bufs, total)
+    order = np.full((B, n - 1), -1, np.int32)
+    depth = np.zeros((B, n - 1), np.int32)
+    for b in range(B):
+        lo, hi = int(c["node_off"][b]), int(c["node_off"][b + 1])
+        order[b, :hi - lo] = c["order"][lo:hi]
+        depth[b, :hi - lo] = c["depth"][lo:hi]
+    return dict(relation=bufs["relation"], relation_bank=bufs["bank"][:L], relation_length=bufs["length"], relation_rows=N,
+                order=torch.from_numpy(order), depth=torch.from_numpy(depth))
+
+
+def build_relation_batch_all_staged(graphs, special_ids, backend, max_len=8, device="cpu", csr=None):
+    """``relbatch.build_relation_batch(..., path_mode=PATH_ALL)`` on the device: EVERY shortest path of every pair in networkx's
+    enumeration order (generator/data.py:178-232, the eval-mode batches): relation [n,n,B,K] with type 0 = <PAD> behind a pair's
+    last alternative, relation_bank [L,R], relation_length [R].  Three phases, two host reads (paths in total and most per pair; then R,
+    L, N)."""
+    if not 1 <= max_len <= 8:
+        raise ValueError("max_len must be in 1..8")
+    pad, cls, rcls, self_, tl = [int(v) for v in special_ids]
+    if len({pad, cls, rcls, self_}) != 4 or min(pad, cls, rcls, self_, tl) < 0 or max(pad, cls, rcls, self_, tl) > 255:
+        raise ValueError("<PAD>, <CLS>, <rCLS>, <SELF> must be four different one-byte ids")
+    c = graphs_csr(graphs) if csr is None else csr
+    dev = torch.device(device)
+    B, S, P, nmax, emax = c["B"], c["S"], c["P"], c["nmax"], c["emax"]
+    n = nmax + 1
+    geom = dict(B=B, n=n, nmax=nmax, emax=emax, max_len=max_len, mode=2, S=S, P=P, seed=0, cls=cls, rcls=rcls, tl=tl, T=0, K=0, pad=pad)
+    geom["self"] = self_
+    i8, i16, i32, i64, f64 = torch.uint8, torch.int16, torch.int32, torch.int64, torch.float64
+
+    def E(shape, dt):
+        return torch.empty(shape, dtype=dt, device=dev)
+    names = ("ng", "node_off", "adj_base", "adj_off", "adj_dst", "adj_lab", "order")
+    flat_host = torch.from_numpy(np.concatenate([c[k] for k in names]))
+    pair_host = torch.from_numpy(c["pair_off"])
+    flat = flat_host.to(dev, non_blocking=True)
+    bufs, at = {}, 0
+    for k in names:
+        bufs[k] = flat[at:at + c[k].size]
+        at += c[k].size
+    bufs["pair_off"] = pair_host.to(dev, non_blocking=True)
+    bufs.update(level=E((S, nmax), i16), count=E((S, nmax), f64), head=E((S, nmax), i16), tail=E((S, nmax), i16), queue=E((S, nmax), i16),
+                dpred=E((S, emax), i16), dnext=E((S, emax), i16), dlab=E((S, emax), i8), nalt=E(P, i32), cum_alt=E(P, i64), cmax_alt=E(P, i32), nalt64=E(P, i64),
+                len_seen=E(8, i32), sizes=torch.zeros(8, dtype=i32, device=dev))
+    backend.all_phase("count", geom, bufs, P)
+    T, K = bufs["sizes"][3:5].tolist()                                    # host read 1: paths in total, most of one pair
+    del flat_host, pair_host
+    if T < 0 or 8 * (T + 4) >= 1 << 32:
+        raise ValueError("too many shortest paths for the builder's 32-bit counters")
+    geom["T"], geom["K"] = T, K
+    total = T + 4
+    bufs.update(key=E(total, i64), posn=E(total, i32), skey=E(total, i64), spos=E(total, i32), flag=E(total, i64), cum=E(total, i64),
+                first_pos=E(total, i32), seg_id=E(total, i32), seg_key=E(total, i64))
+    backend.all_phase("keys", geom, bufs, total)
+    R, L, N = bufs["sizes"][:3].tolist()                                  # host read 2: distinct paths, longest, bank rows
+    bufs.update(first_alt=E(R, i32), sorted_seg=E(R, i32), type_of_seg=E(R, i32), bank=torch.zeros((8, R), dtype=i64, device=dev),
+                length=E(R, i64), relation=torch.zeros((n, n, B, K), dtype=i64, device=dev))
+    backend.all_phase("fill", geom, bufs, total, R)
     order = np.full((B, n - 1), -1, np.int32)
     depth = np.zeros((B, n - 1), np.int32)
     for b in range(B):

@@ -116,7 +116,7 @@ int gtos_pathtrie_dev_phase_b(int64_t R, int64_t N, int n_pf, int n_sf, int chun
  * counterpart of gtos_relbatch_build in include/gtos_host.h for the one-path-per-pair modes (GTOS_PATH_FIRST / GTOS_PATH_UNIFORM), i.e.
  * the relation section of batchify (generator/data.py:134-176, translator/data.py:132-176) over the all-pairs shortest label paths
  * (generator/AMRGraph.py:100-115, translator/dependencyGraph.py:54-74).  The graphs arrive flattened by gtos_relbatch_csr
- * (include/gtos_host.h).  Two phases with one host read between them; gtos_amd/relbatch_hip.py drives them.  geom = int64[13] host
+ * (include/gtos_host.h).  Two phases with one host read between them; gtos_amd/relbatch_hip.py drives them.  geom = int64[16] host
  * integers (enum GE_*), tab = host table of device pointers (enum T_*), both in csrc/relbatch_kernels.h; workspace = rocPRIM temporary
  * storage of at least _workspace(pairs + 3) bytes.  After phase A sizes[0] = R (distinct paths), sizes[1] = L (the longest); phase B
  * takes R back and fills relation int64 [n,n,B] (zero-filled by the caller), bank int64 [8,R] (zero-filled; rows >= L stay zero),
@@ -125,6 +125,13 @@ int gtos_pathtrie_dev_phase_b(int64_t R, int64_t N, int n_pf, int n_sf, int chun
 int gtos_relbatch_dev_workspace(int64_t total, int64_t* bytes_out);
 int gtos_relbatch_dev_phase_a(const int64_t* geom, void** tab, void* workspace, size_t workspace_bytes, void* stream);
 int gtos_relbatch_dev_phase_b(const int64_t* geom, int64_t R, void** tab, void* workspace, size_t workspace_bytes, void* stream);
+/* The eval-mode batches (GTOS_PATH_ALL: EVERY shortest path of every pair in networkx's enumeration order, relation int64 [n,n,B,K], type
+ * 0 = <PAD> behind a pair's last alternative; generator/data.py:178-232): three phases, a host read after each of the first two.
+ * _all_count: the searches and the number of paths per pair -> sizes[3] = paths in total T, sizes[4] = most of one pair K; geom[13], [14]
+ * carry T and K into _all_keys (keys, key sort, distinct keys -> sizes[0..2] = R, L, N) and _all_fill (numbering, relation, bank). */
+int gtos_relbatch_dev_all_count(const int64_t* geom, void** tab, void* workspace, size_t workspace_bytes, void* stream);
+int gtos_relbatch_dev_all_keys(const int64_t* geom, void** tab, void* workspace, size_t workspace_bytes, void* stream);
+int gtos_relbatch_dev_all_fill(const int64_t* geom, int64_t R, void** tab, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- The relation index of the factored attention operand built on the GPU (csrc/relindex_dev.hip; stages in
  * csrc/relindex_kernels.h): the device-side counterpart of gtos_relindex_build in include/gtos_host.h, same arrays (the index

@@ -30,6 +30,11 @@ class EmulBackend(object):
     def phase_b(self, geom, R, bufs, total):
         assert self.lib.gtos_relbatch_emul_phase_b(_geom(geom), R, _table(bufs)) == 0
 
+    def all_phase(self, which, geom, bufs, n, R=0):
+        fn = getattr(self.lib, "gtos_relbatch_emul_all_" + which)
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p] if which == "fill" else [ctypes.c_void_p, ctypes.c_void_p]
+        assert (fn(_geom(geom), R, _table(bufs)) if which == "fill" else fn(_geom(geom), _table(bufs))) == 0
+
 
 def _random_graphs(seed, B, nlo, nhi, extra, labels=40, tree_only=False):
     """connected labelled graphs in the builder's input form: a random rooted tree plus ``extra`` re-entrancy edges per node, every edge
@@ -190,3 +195,57 @@ def test_device_all_dependency_flavour_reproduces_the_reference_batch(monkeypatc
             out = build_relation_batch_staged(graphs, g["special_ids"].tolist(), EmulBackend(), path_mode=mode, seed=7)
             for k in ("relation", "relation_bank", "relation_length"):
                 assert torch.equal(out[k], torch.from_numpy(g[p + k])), (bi, mode, k)
+
+
+@pytest.mark.parametrize("order", [0, 1, 4242])
+@pytest.mark.parametrize("seed,B,nlo,nhi,extra", [(1, 1, 1, 1, 0.0), (2, 3, 2, 9, 0.3), (3, 5, 10, 30, 0.1), (4, 4, 12, 24, 1.0), (5, 6, 20, 20, 0.3)])
+def test_staged_relation_batch_every_shortest_path_mode_equals_the_host_builder(order, seed, B, nlo, nhi, extra):
+    """GTOS_PATH_ALL (the eval-mode batches: relation [n,n,B,K], every alternative in networkx's enumeration order, <PAD> = type 0)"""
+    from gtos_amd.relbatch_hip import build_relation_batch_all_staged
+    graphs = _random_graphs(seed, B, nlo, nhi, extra, labels=3)            # few labels: many alternative shortest paths
+    try:
+        for max_len in (8, 2):
+            host = relbatch.build_relation_batch(graphs, IDS, path_mode=relbatch.PATH_ALL, max_len=max_len, n_threads=1)
+            staged = build_relation_batch_all_staged(graphs, IDS, EmulBackend(order), max_len=max_len)
+            assert host["relation"].dim() == 4 and _same(host, staged) == []
+    finally:
+        EmulBackend(0)
+    with pytest.raises(ValueError):
+        build_relation_batch_all_staged(graphs, (2, 2, 3, 4, 5), EmulBackend())
+
+
+def test_staged_every_shortest_path_mode_reproduces_the_reference_eval_batch():
+    """the reference's own eval-mode batchify on real AMRs (tests/golden/host_amr_smatch, made by generator/data.py:178-232 under
+    networkx): relation [n,n,B,K], bank and lengths from the staged builder's stage code, bit for bit"""
+    from conftest import load_golden
+    from gtos_amd.relbatch_hip import build_relation_batch_all_staged
+    g = load_golden("host_amr_smatch")
+    eo = g["edge_off"]
+    graphs = [(int(g["n_nodes"][k]), int(g["roots"][k]), g["edges"][eo[k]:eo[k + 1]]) for k in range(len(g["n_nodes"]))]
+    out = build_relation_batch_all_staged(graphs, g["special_ids"].tolist(), EmulBackend())
+    assert torch.equal(out["relation"], torch.from_numpy(g["relation"]))
+    assert torch.equal(out["relation_bank"], torch.from_numpy(g["relation_bank"]))
+    assert torch.equal(out["relation_length"], torch.from_numpy(g["relation_length"]))
+    assert torch.equal(out["depth"].long(), torch.from_numpy(g["concept_depth"])[1:].t())
+
+
+def test_device_all_eval_batch_equals_the_host_eval_batch(monkeypatch):
+    """batchify_amr(train=False, index_prep="device_all"): the eval batch ([n,n,B,K], every alternative) rebuilt by the device-side
+    attachments (emulated) == the host eval batch"""
+    from gtos_amd import data, pathtrie_hip, relbatch_hip
+    from test_pathtrie import _EmulBackend as TrieEmul, _same_object
+    monkeypatch.setattr(relbatch_hip.HipBackend, "shared", classmethod(lambda cls: EmulBackend()))
+    monkeypatch.setattr(pathtrie_hip.HipBackend, "shared", classmethod(lambda cls: TrieEmul()))
+    vocabs = synth.synth_vocabs()
+    items, graphs = synth.make_amr_items("C1", 6, first_graph=0, vocabs=vocabs)
+    cache = {id(d): (vocabs['relation'], d, g) for d, g in zip(items, graphs)}
+    want = data.batchify_amr(items, vocabs, train=False, n_threads=1, graph_cache=cache)
+    got = data.batchify_amr(items, vocabs, train=False, n_threads=1, graph_cache=cache, index_prep="device_all")
+    assert 'relation' not in got and want['relation'].dim() == 4
+    data.attach_device_relations(got, "cpu")
+    data.attach_device_relation_index(got)                 # (no index for eval batches)
+    data.attach_device_tries(got, "hip")
+    assert 'relation_index' not in got
+    for k in ("relation", "relation_bank", "relation_length", "concept", "token_in"):
+        assert torch.equal(want[k], got[k]), k
+    assert _same_object(want["relation_trie"], got["relation_trie"]) == []

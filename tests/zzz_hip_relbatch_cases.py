@@ -51,6 +51,24 @@ def test_hip_relation_batch_at_c2_size_long_paths_and_seeds():
                                                        device=dev())) == []
 
 
+@pytest.mark.parametrize("seed,B,nlo,nhi,extra", [(1, 1, 1, 1, 0.0), (2, 3, 2, 9, 0.3), (3, 5, 10, 30, 0.1), (4, 4, 12, 24, 1.0), (5, 6, 20, 20, 0.3)])
+def test_hip_relation_batch_every_shortest_path_mode_equals_the_host_builder(seed, B, nlo, nhi, extra):
+    """GTOS_PATH_ALL (eval-mode batches, relation [n,n,B,K]) incl. the reference's own eval batch of real AMRs"""
+    from conftest import load_golden
+    from gtos_amd.relbatch_hip import HipBackend, build_relation_batch_all_staged
+    graphs = _random_graphs(seed, B, nlo, nhi, extra, labels=3)
+    for max_len in (8, 2):
+        host = relbatch.build_relation_batch(graphs, IDS, path_mode=relbatch.PATH_ALL, max_len=max_len, n_threads=1)
+        assert _same(host, build_relation_batch_all_staged(graphs, IDS, HipBackend.shared(), max_len=max_len, device=dev())) == []
+    if seed == 1:
+        g = load_golden("host_amr_smatch")
+        eo = g["edge_off"]
+        graphs = [(int(g["n_nodes"][k]), int(g["roots"][k]), g["edges"][eo[k]:eo[k + 1]]) for k in range(len(g["n_nodes"]))]
+        out = build_relation_batch_all_staged(graphs, g["special_ids"].tolist(), HipBackend.shared(), device=dev())
+        for k in ("relation", "relation_bank", "relation_length"):
+            assert torch.equal(out[k].cpu(), torch.from_numpy(g[k])), k
+
+
 @pytest.mark.parametrize("seed,n,B,R", [(1, 1, 1, 1), (2, 5, 3, 40), (3, 9, 8, 300), (4, 13, 16, 2000), (5, 21, 7, 50), (6, 30, 64, 20000)])
 @pytest.mark.parametrize("chunk", [32, 4])
 def test_hip_relation_index_equals_the_host_builder(seed, n, B, R, chunk):
