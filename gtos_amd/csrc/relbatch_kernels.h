@@ -11,8 +11,8 @@
 //     the alternatives by the same splitmix64 stream as the host builder), <SELF> / <TL> for distance 0 / beyond max_len;
 //   key sort -> distinct keys -> numbered in FIRST-SEEN order (graph, source, target: the order the reference's dict meets them,
 //     which fixes the type ids) by a second sort of the first positions -> relation[n,n,B], relation_bank[L,R], relation_length[R].
-// Covered: GTOS_PATH_FIRST and GTOS_PATH_UNIFORM (one path per pair: the train-mode batches); the eval-mode enumeration of every
-// alternative stays on the host.
+// Covered: GTOS_PATH_FIRST and GTOS_PATH_UNIFORM (one path per pair: the train-mode batches) and GTOS_PATH_ALL (every shortest path of a
+// pair, the eval-mode batches: own stages further down).
 #pragma once
 #include <cstdint>
 

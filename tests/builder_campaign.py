@@ -9,7 +9,7 @@ import numpy as np, torch
 from gtos_amd import relbatch
 from gtos_amd.pathtrie import build_path_trie
 from gtos_amd.pathtrie_hip import build_path_trie_staged
-from gtos_amd.relbatch_hip import build_relation_batch_staged
+from gtos_amd.relbatch_hip import build_relation_batch_all_staged, build_relation_batch_staged
 from gtos_amd.relindex import build_relation_index
 from gtos_amd.relindex_hip import build_relation_index_staged
 from test_pathtrie import _EmulBackend as TrieEmul, _same_object
@@ -27,6 +27,9 @@ while time.time()-t0 < float(sys.argv[2]):
     host=relbatch.build_relation_batch(graphs, IDS, path_mode=mode, seed=seed, max_len=max_len, n_threads=int(rng.choice([1,2,3])))
     st=build_relation_batch_staged(graphs, IDS, rel_e, path_mode=mode, seed=seed, max_len=max_len)
     bad=_same(host, st)
+    if rng.rand() < 0.3:                                   # the every-shortest-path mode (eval batches) on the same graphs
+        host_all = relbatch.build_relation_batch(graphs, IDS, path_mode=relbatch.PATH_ALL, max_len=max_len, n_threads=1)
+        bad += ["all:" + str(b) for b in _same(host_all, build_relation_batch_all_staged(graphs, IDS, rel_e, max_len=max_len))]
     R=host["relation_bank"].shape[1]; chunk=int(rng.choice([32,32,7,1,64]))
     ichunk=int(rng.choice([32,32,5,1,128]))
     bad+=_same_object(build_relation_index(host["relation"],R,chunk=ichunk), build_relation_index_staged(st["relation"],R,idx_e,chunk=ichunk))
