@@ -1,6 +1,7 @@
 """Randomised equality campaign of the three staged index builders (stage code run by the emulation libraries, under ascending /
 descending / random thread orders) against the host builders: python tests/builder_campaign.py <seed> <seconds>.  Not collected by
-pytest (long-running); the closing session of round 3 ran 2 x 900 s = 327,359 cases, all equal."""
+pytest (long-running); the closing session of round 3 ran 2 x 900 s = 327,359 cases and, with the
+every-shortest-path mode on 30 % of them, 2 x 500 s = 143,534 more: all equal."""
 import sys, time
 import os
 HERE = os.path.dirname(os.path.abspath(__file__))

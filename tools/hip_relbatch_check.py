@@ -78,10 +78,23 @@ def main():
             return pathtrie_hip.build_path_trie_staged(hip["relation_bank"], hip["relation_length"], pathtrie_hip.HipBackend.shared(),
                                                        n_rows=hip["relation_rows"])
         out["tries_differing"] = differing(host_trie, tries())
+        # the eval-mode batch of the same graphs: every shortest path of a pair, relation [n,n,B,K]
+        sub = graphs[:16]
+        csr16 = relbatch_hip.graphs_csr(sub)
+        t0 = time.perf_counter()
+        host_all = relbatch.build_relation_batch(sub, ids, path_mode=relbatch.PATH_ALL, n_threads=2)
+        out["host_relbatch_all_s_16_graphs"] = round(time.perf_counter() - t0, 4)
+
+        def rel_all():
+            return relbatch_hip.build_relation_batch_all_staged(None, ids, relbatch_hip.HipBackend.shared(), device=dev, csr=csr16)
+        hip_all = rel_all()
+        out["relbatch_all_differing"] = [k for k in ("relation", "relation_bank", "relation_length") if not torch.equal(host_all[k], hip_all[k].cpu())]
+        out["relbatch_all_K"] = int(host_all["relation"].shape[3])
+        out["hip_relbatch_all_ms"] = timed(rel_all, 3)
         out["c2"] = {"R": R, "N": hip["relation_rows"], "nchunks": host_idx.nchunks}
         out["hip_relbatch_ms"], out["hip_relindex_ms"], out["hip_tries_ms"] = timed(rel), timed(idx), timed(tries)
         out["hip_all_ms"] = timed(lambda: (rel(), idx(), tries()))
-        out["ok"] = not (out["relbatch_differing"] or out["relindex_differing"] or out["tries_differing"])
+        out["ok"] = not (out["relbatch_differing"] or out["relindex_differing"] or out["tries_differing"] or out["relbatch_all_differing"])
     except Exception:
         out["ok"] = False
         out["error"] = traceback.format_exc()
