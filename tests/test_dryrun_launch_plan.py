@@ -134,3 +134,22 @@ def test_training_step_glue_over_random_model_shapes():
             trainer.step(batch, sync=False)
             trainer.step(batch, sync=False)
             assert len(rec.calls) > 100, (it, len(rec.calls))
+
+
+def test_eval_mode_encoder_glue_on_an_every_alternative_batch():
+    """eval mode (no grad) on an eval batch (relation [n,n,B,K]: the K-path mean of generator/generator.py:76-78 as a derived bank +
+    the factored kernels): the encoder half of ``Generator.work`` under the dry run, bf16 and fp32"""
+    from gtos_amd.config import build_generator
+    from gtos_amd.generator import Generator
+    from gtos_amd.pathtrie import attach_path_trie
+    for dtype in (torch.bfloat16, torch.float32):
+        with DryRun() as rec:
+            model = build_generator(Generator, "C1", torch.device("cpu"))
+            model.set_compute_dtype(dtype)
+            model.eval()
+            batch, _ = synth.make_config_batch("C1", train=False)
+            assert batch["relation"].dim() == 4
+            with torch.no_grad():
+                model.encode_step(attach_path_trie(batch), train=False)
+            names = {n for n, _ in rec.calls}
+        assert "gtos_rel_attn_fwd" in names and "gtos_relation_gather_mean" in names and "gtos_rel_attn_bwd" not in names
