@@ -749,7 +749,7 @@ class Prefetcher(object):
         self.stats["batches"] += 1
         self.stats["queue_wait_s"] += t_got - t_in            # the consumer waited for a finished batch (loader too slow / too shallow)
         b0 = batch[0] if isinstance(batch, tuple) else batch
-        if self._device_tries or 'relation_graphs' in b0:
+        if isinstance(b0, dict) and (self._device_tries or 'relation_graphs' in b0):
             # Index preparation left to the device, done HERE, by the consumer's thread, on the copy stream (behind the batch's upload,
             # beside the previous step's kernels): the relation tensors of a batch that ships its graphs (index_prep="device_all":
             # gtos_amd.relbatch_hip), the relation index of those (gtos_amd.relindex_hip) and the tries of a batch that came without
