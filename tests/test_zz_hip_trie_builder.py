@@ -78,3 +78,18 @@ def test_relation_encoder_on_hip_built_tries_equals_host_built_tries():
     assert _rel_frob(res[1][0], res[0][0]) < 1e-3          # (equal index arrays; a bar instead of torch.equal in case a forward kernel sums in fp32 atomics)
     for k in res[0][1]:
         assert _rel_frob(res[1][1][k], res[0][1][k]) < 1e-3, k
+
+
+def test_launch_stream_handle_follows_the_current_stream():
+    """_lib.stream() (the raw current-stream getter once adopted, the public API otherwise) is the handle of torch's current stream on the
+    default stream, inside a side-stream context and after leaving it -- what every launch of the library is queued on."""
+    from gtos_amd import _lib
+    dev()                                       # (a CUDA context)
+    torch.zeros(1, device=dev())
+    for _ in range(2):                          # first call adopts (or rejects) the raw getter, second uses it
+        assert _lib.stream() == torch.cuda.current_stream().cuda_stream
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            assert _lib.stream() == side.cuda_stream == torch.cuda.current_stream().cuda_stream
+        assert _lib.stream() == torch.cuda.current_stream().cuda_stream
+    print("raw stream getter adopted:", bool(_lib._raw_stream))
