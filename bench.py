@@ -85,6 +85,9 @@ def parse():
                     help="--fresh-batches: the loader ships the flattened graphs only (index_prep='device_all'); relation / bank / length "
                          "(gtos_amd.relbatch_hip), the relation index (gtos_amd.relindex_hip) and the tries (gtos_amd.pathtrie_hip) are built on "
                          "the GPU on the loader's copy stream -- the host keeps the token / character tensors")
+    ap.add_argument("--prep-in-worker", action="store_true",
+                    help="--fresh-batches with --device-tries / --device-relations: the device-side preparation (and its host reads) on the "
+                         "loader's upload thread instead of the training thread")
     ap.add_argument("--pool", type=int, default=0, help="--fresh-batches: graphs in the per-rank item pool (default 4 batches)")
     ap.add_argument("--prewarm-seconds", type=float, default=20.0,
                     help="untimed device pre-warm BEFORE the --warmup steps: windows of 5 training steps until two consecutive windows "
@@ -490,10 +493,10 @@ def main():
                 yield from loader.jobs()
         if a.loader == "processes":
             feed = data_mod.Prefetcher(jobs(), depth=a.depth, workers=a.workers, device=dev, processes=True, runner=timed_run,
-                                       device_tries=a.device_tries or ("hip" if a.device_relations else False))
+                                       device_tries=a.device_tries or ("hip" if a.device_relations else False), prep_in_worker=a.prep_in_worker)
         else:
             feed = data_mod.Prefetcher((lambda j=j: timed_run(j) for j in jobs()), depth=a.depth, workers=a.workers, device=dev,
-                                       device_tries=a.device_tries or ("hip" if a.device_relations else False))
+                                       device_tries=a.device_tries or ("hip" if a.device_relations else False), prep_in_worker=a.prep_in_worker)
         batch = next(feed)
         stats = {"n": int(batch["concept"].shape[0]), "B": int(batch["concept"].shape[1]), "T": int(batch["token_in"].shape[0]),
                  "R": int(batch["relation_bank"].shape[1]),
@@ -504,6 +507,7 @@ def main():
                        "tries": {"torch": "device (torch ops on the copy stream)", "hip": "device (staged HIP builder on the copy stream)",
                                  "": "host (worker)"}[a.device_tries or ("hip" if a.device_relations else "")],
                        "relations": "device (staged HIP builders: relation / bank / index)" if a.device_relations else "host (worker)",
+                       "device_prep_thread": "upload thread" if a.prep_in_worker else "training thread",
                        "pool_graphs_per_rank": pool_n, "device_memory_free_gb_at_start": round(free_b / 2 ** 30, 1),
                        "allocator": "default" if os.environ.get("GTOS_BENCH_NO_ROUNDUP") else "roundup_power2_divisions:16"}
     else:

@@ -544,11 +544,16 @@ class Prefetcher(object):
     * Order of the batches is the iterable's order.  ``close()`` (also on garbage collection / context exit) stops the
       workers; batches already assembled are dropped."""
 
-    def __init__(self, batches, depth=2, workers=1, device=None, processes=False, runner=None, device_tries=False):
+    def __init__(self, batches, depth=2, workers=1, device=None, processes=False, runner=None, device_tries=False, prep_in_worker=False):
         import threading
         self._it = iter(batches)
         self._device_tries = device_tries
         self.stats = {"batches": 0, "queue_wait_s": 0.0, "device_prep_s": 0.0}     # where __next__ spent the consumer's time
+        # device-side preparation (relation tensors / index / tries of a batch that ships without them) on the upload thread instead of
+        # the consumer's: its host reads then stall the loader thread, not the training loop (the HIP builders are a few dozen
+        # allocations and ctypes calls per batch; the torch-op trie builder's ~200 small calls belonged on the consumer, see __next__)
+        self._prep_in_worker = bool(prep_in_worker)
+        self._prep_lock = threading.Lock()
         self._out = {}
         self._cv = threading.Condition()          # ONE lock: depth reservation, source advance and hand-over are atomic
         self._next_in, self._next_out, self._done, self._err, self._stop = 0, 0, False, None, False
@@ -591,6 +596,35 @@ class Prefetcher(object):
             self._next_in += 1
             return k, item
 
+    def _needs_prep(self, b0):
+        return (isinstance(b0, dict) and (self._device_tries or 'relation_graphs' in b0) and
+                ('relation_graphs' in b0 or ('relation_trie' not in b0 and 'relation_bank' in b0)))
+
+    def _device_prep(self, b0):
+        """The relation tensors of a batch that ships its graphs (index_prep="device_all": gtos_amd.relbatch_hip), their relation index
+        (gtos_amd.relindex_hip) and the tries of a batch that came without them, built on the copy stream by the calling thread.
+        Returns (what was made, an event behind it or None without a device)."""
+        def prep():
+            made = []
+            if 'relation_graphs' in b0:
+                attach_device_relations(b0, self._device)
+                made += [b0['relation'], b0['relation_bank'], b0['relation_length']]
+                if 'relation_index' not in b0:
+                    attach_device_relation_index(b0)
+                    made.append(b0.get('relation_index'))
+            if 'relation_trie' not in b0:
+                attach_device_tries(b0, self._device_tries or "hip")
+                made.append(b0.get('relation_trie'))
+            return made
+        with self._prep_lock:
+            if self._copy_stream is not None:
+                with torch.cuda.stream(self._copy_stream):
+                    made = prep()
+                    ev = torch.cuda.Event()
+                    ev.record(self._copy_stream)
+                return made, ev
+            return prep(), None
+
     def _upload(self, batch):
         with torch.cuda.stream(self._copy_stream):
             def up(v):                               # (no pin_memory(): a fresh pinned allocation per tensor and batch costs more
@@ -615,10 +649,15 @@ class Prefetcher(object):
                 ev = None
                 if self._copy_stream is not None:
                     batch, ev = self._upload(batch)
+                extra = None
+                b0 = batch[0] if isinstance(batch, tuple) else batch
+                if self._prep_in_worker and self._needs_prep(b0):
+                    extra, ev2 = self._device_prep(b0)
+                    ev = ev2 if ev2 is not None else ev
                 with self._cv:
                     if self._stop:
                         break
-                    self._out[k] = (batch, ev, None)
+                    self._out[k] = (batch, ev, None, extra)
                     self._cv.notify_all()
         except BaseException as e:            # surfaced in the consumer
             with self._cv:
@@ -667,10 +706,15 @@ class Prefetcher(object):
                         ev = torch.cuda.Event()
                         ev.record(self._copy_stream)
                 batch = _unpack_batch(meta, flat)
+                extra = None
+                b0 = batch[0] if isinstance(batch, tuple) else batch
+                if self._prep_in_worker and self._needs_prep(b0):
+                    extra, ev2 = self._device_prep(b0)
+                    ev = ev2 if ev2 is not None else ev
                 with self._cv:
                     if self._stop:
                         break
-                    self._out[k] = (batch, ev, flat)         # every tensor of the batch is a view of `flat`
+                    self._out[k] = (batch, ev, flat, extra)  # every tensor of the batch is a view of `flat` (or listed in `extra`)
                     self._cv.notify_all()
         except BaseException as e:
             with self._cv:
@@ -741,40 +785,20 @@ class Prefetcher(object):
                 raise self._err
             if self._next_out not in self._out:       # source exhausted (or closed) and everything taken from it handed out
                 raise StopIteration
-            batch, ev, flat = self._out.pop(self._next_out)
+            batch, ev, flat, extra = self._out.pop(self._next_out)
             self._next_out += 1
             self._cv.notify_all()
-        extra = None
         t_got = time.perf_counter()
         self.stats["batches"] += 1
         self.stats["queue_wait_s"] += t_got - t_in            # the consumer waited for a finished batch (loader too slow / too shallow)
         b0 = batch[0] if isinstance(batch, tuple) else batch
-        if isinstance(b0, dict) and (self._device_tries or 'relation_graphs' in b0):
+        if self._needs_prep(b0):
             # Index preparation left to the device, done HERE, by the consumer's thread, on the copy stream (behind the batch's upload,
-            # beside the previous step's kernels): the relation tensors of a batch that ships its graphs (index_prep="device_all":
-            # gtos_amd.relbatch_hip), the relation index of those (gtos_amd.relindex_hip) and the tries of a batch that came without
-            # them.  Built on the upload thread the torch-op tries cost 0.2 s per batch: ~200 small torch calls, each waiting for the
-            # interpreter lock the training loop holds (round 3, C2, 2 worker processes: 230 ms per step).
-            def prep():
-                made = []
-                if 'relation_graphs' in b0:
-                    attach_device_relations(b0, self._device)
-                    made += [b0['relation'], b0['relation_bank'], b0['relation_length']]
-                    if 'relation_index' not in b0:
-                        attach_device_relation_index(b0)
-                        made.append(b0.get('relation_index'))
-                if 'relation_trie' not in b0:
-                    attach_device_tries(b0, self._device_tries or "hip")
-                    made.append(b0.get('relation_trie'))
-                return made
-            if 'relation_trie' not in b0 or 'relation_graphs' in b0:
-                if self._copy_stream is not None:
-                    with torch.cuda.stream(self._copy_stream):
-                        extra = prep()
-                        ev = torch.cuda.Event()
-                        ev.record(self._copy_stream)
-                else:
-                    extra = prep()
+            # beside the previous step's kernels) unless prep_in_worker moved it to the upload thread.  Built on the upload thread the
+            # torch-op tries cost 0.2 s per batch: ~200 small torch calls, each waiting for the interpreter lock the training loop
+            # holds (round 3, C2, 2 worker processes: 230 ms per step).
+            extra, ev2 = self._device_prep(b0)
+            ev = ev2 if ev2 is not None else ev
         self.stats["device_prep_s"] += time.perf_counter() - t_got      # host side of the device-side preparation (launches + host reads)
         if ev is not None:
             cur = torch.cuda.current_stream(self._device)

@@ -150,8 +150,14 @@ def test_device_all_loader_path_equals_the_host_loader(monkeypatch):
     dev_ld2 = loader("device_all")
     with data.Prefetcher(dev_ld2.jobs(), depth=2, workers=2, processes=True, runner=dev_ld2.run_job, device_tries="hip") as pf:
         got2 = list(pf)                                    # worker processes: the flattened graphs travel pickled beside the packed tensors
-    assert len(got) == len(got2) == len(want) == 2
-    for w, g in list(zip(want, got)) + list(zip(want, got2)):
+    dev_ld3, dev_ld4 = loader("device_all"), loader("device_all")
+    with data.Prefetcher(dev_ld3.thunks(), depth=2, workers=2, device_tries="hip", prep_in_worker=True) as pf:
+        got3 = list(pf)                                    # the preparation on the loader threads instead of the consumer
+        assert pf.stats["batches"] == 2
+    with data.Prefetcher(dev_ld4.jobs(), depth=2, workers=2, processes=True, runner=dev_ld4.run_job, device_tries="hip", prep_in_worker=True) as pf:
+        got4 = list(pf)                                    # ... and on the receiver thread of the worker-process mode
+    assert len(got) == len(got2) == len(got3) == len(got4) == len(want) == 2
+    for w, g in list(zip(want, got)) + list(zip(want, got2)) + list(zip(want, got3)) + list(zip(want, got4)):
         assert 'relation_graphs' not in g and g['relation_rows'] == int(w['relation_length'].sum())
         assert torch.equal(w["relation"], g["relation"]) and torch.equal(w["relation_bank"], g["relation_bank"])
         assert _same_object(w["relation_index"], g["relation_index"]) == [] and _same_object(w["relation_trie"], g["relation_trie"]) == []

@@ -28,4 +28,6 @@ leg hiptries_w2 --workers 2 --device-tries hip --prewarm-seconds 3
 leg hiptries_w1 --workers 1 --device-tries hip --prewarm-seconds 3
 leg devrel_w1 --workers 1 --device-relations --prewarm-seconds 3
 leg devrel_w1_threads --workers 1 --loader threads --device-relations --prewarm-seconds 3
+leg devrel_w1_prepworker --workers 1 --device-relations --prep-in-worker --prewarm-seconds 3
+leg hiptries_w2_prepworker --workers 2 --device-tries hip --prep-in-worker --prewarm-seconds 3
 leg host_w4_again --workers 4 --prewarm-seconds 3
