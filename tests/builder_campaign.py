@@ -1,7 +1,8 @@
 """Randomised equality campaign of the three staged index builders (stage code run by the emulation libraries, under ascending /
 descending / random thread orders) against the host builders: python tests/builder_campaign.py <seed> <seconds>.  Not collected by
 pytest (long-running); the closing session of round 3 ran 2 x 900 s = 327,359 cases and, with the
-every-shortest-path mode on 30 % of them, 2 x 500 s = 143,534 more: all equal."""
+every-shortest-path mode on 30 % of them, 2 x 500 s = 143,534 more, then 2 x 1,500 s = 222,031
+with graphs of up to 150 nodes mixed in: all equal (693 k cases in total)."""
 import sys, time
 import os
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -21,7 +22,8 @@ rng=np.random.RandomState(int(sys.argv[1]))
 while time.time()-t0 < float(sys.argv[2]):
     order=int(rng.choice([0,1,int(rng.randint(2,10**6))]))
     rel_e, idx_e, trie_e = RelEmul(order), IdxEmul(order), TrieEmul(order)
-    B=int(rng.randint(1,7)); nlo=int(rng.randint(1,20)); nhi=nlo+int(rng.randint(0,40)); extra=float(rng.choice([0.0,0.1,0.5,1.5]))
+    big = len(sys.argv) > 3 and rng.rand() < 0.2           # (a third argument: a fifth of the cases with graphs of up to 150 nodes)
+    B=int(rng.randint(1,7)); nlo=int(rng.randint(1,20)); nhi=nlo+int(rng.randint(0,130 if big else 40)); extra=float(rng.choice([0.0,0.1,0.5,1.5]))
     labels=int(rng.choice([2,5,40,100]))
     graphs=_random_graphs(int(rng.randint(0,2**31-1)), B, nlo, nhi, extra, labels=labels, tree_only=bool(rng.rand()<0.2))
     mode=int(rng.choice([relbatch.PATH_FIRST, relbatch.PATH_UNIFORM])); seed=int(rng.randint(0,2**63-1))*2+int(rng.randint(0,2)); max_len=int(rng.choice([8,8,8,5,2,1]))
