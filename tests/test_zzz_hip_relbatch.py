@@ -18,10 +18,10 @@ def test_hip_relation_builders_in_a_child_process():
     cmd = [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "zzz_hip_relbatch_cases.py"), "-m", "gpu", "-q", "--tb=short", "-p",
            "no:cacheprovider"]
     try:
-        out = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        out = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=150)
     except subprocess.TimeoutExpired as e:
         print((e.stdout or b"").decode(errors="replace")[-4000:])
-        pytest.fail("the child did not finish in 300 s (killed)")
+        pytest.fail("the child did not finish in 150 s (killed)")
     text = out.stdout.decode(errors="replace")
     print(text[-6000:])
     try:                                                    # (kept beside the other GPU logs when the box has the directory)
