@@ -339,7 +339,7 @@ def test_pathtrie_and_relation_index_invariants_property_based():
 
     seqs_st = st.lists(st.lists(st.integers(1, 6), min_size=1, max_size=5).map(tuple), min_size=1, max_size=40, unique=True)
 
-    @settings(max_examples=40, deadline=None)
+    @settings(max_examples=40, deadline=None, derandomize=True)
     @given(seqs_st, st.integers(1, 5))
     def check_trie(seqs, chunk):
         Lm = max(len(s) for s in seqs)
@@ -348,7 +348,7 @@ def test_pathtrie_and_relation_index_invariants_property_based():
             bank[:len(s), r] = torch.tensor(s)
         _check(list(seqs), build_path_trie(bank, torch.tensor([len(s) for s in seqs]), chunk=chunk), chunk=chunk)
 
-    @settings(max_examples=40, deadline=None)
+    @settings(max_examples=40, deadline=None, derandomize=True)
     @given(st.integers(1, 5), st.integers(1, 9), st.integers(1, 12), st.integers(0, 10 ** 6), st.integers(1, 4))
     def check_index(n, B, R, seed, chunk):
         g = torch.Generator().manual_seed(seed)
