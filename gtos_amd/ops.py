@@ -52,8 +52,9 @@ def _row_major(t):
     """2-D view usable by the GEMM: unit inner stride; returns (tensor, leading dimension)."""
     if t.dim() != 2:
         raise _lib.GtosHipError("gemm operands must be 2-D")
-    if t.stride(1) != 1 and t.shape[1] != 1:
-        t = t.contiguous()
+    if (t.stride(1) != 1 and t.shape[1] != 1) or (t.stride(0) == 0 and t.shape[0] > 1):
+        t = t.contiguous()           # (also a row-broadcast view -- an expanded probe at batch size 1 -- : the kernels are only ever
+                                     #  tested with a positive leading dimension; found by the dry run's operand-extent check)
     ld = t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
     return t, ld
 

@@ -67,6 +67,35 @@ def _kind_ok(ctype, v):
 class Recorder(object):
     def __init__(self):
         self.calls = []
+        self.extents = {}        # data_ptr -> (end of the storage the pointer was taken from): filled by the patched _lib.ptr
+        self.extent_checks = 0
+
+    def note_ptr(self, t):
+        if t is None:
+            return None
+        p = t.data_ptr()
+        st = t.untyped_storage()
+        end = st.data_ptr() + st.nbytes()
+        self.extents[p] = max(self.extents.get(p, 0), end)
+        return p
+
+    def _check_gemm(self, args):
+        """every operand of a gtos_gemm call lies inside the storage its pointer came from: rows x columns with the leading dimension the
+        wrapper passed (A: [M,K] or, transposed, [K,M]; B: [K,N] or [N,K]; C: [M,N]; bias [N] fp32)"""
+        in_dt, out_dt, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias = args[:14]
+        if M <= 0 or N <= 0 or K <= 0:
+            return
+        es_in, es_out = (4, 2)[in_dt], (4, 2)[out_dt]
+        for name, p, rows, cols, ld, es in (("A", A, K if ta else M, M if ta else K, lda, es_in), ("B", B, N if tb else K, K if tb else N, ldb, es_in),
+                                            ("C", C, M, N, ldc, es_out)):
+            assert p in self.extents, "gtos_gemm: operand %s did not come through ptr()" % name
+            assert ld >= cols or rows == 1, "gtos_gemm: leading dimension %d of %s below its %d columns" % (ld, name, cols)
+            need = p + ((rows - 1) * ld + cols) * es
+            assert need <= self.extents[p], "gtos_gemm: operand %s [%d x %d, ld %d] runs %d bytes past its storage" % (
+                name, rows, cols, ld, need - self.extents[p])
+        if bias is not None:
+            assert bias in self.extents and bias + 4 * N <= self.extents[bias], "gtos_gemm: bias shorter than N"
+        self.extent_checks += 1
 
     def __getattr__(self, name):
         if name == "gtos_abi_version":
@@ -79,6 +108,8 @@ class Recorder(object):
             assert len(args) == len(sig), "%s: %d arguments for a %d-argument signature" % (name, len(args), len(sig))
             for k, (c, v) in enumerate(zip(sig, args)):
                 assert _kind_ok(c, v), "%s: argument %d is %r, signature says %s" % (name, k, v, c.__name__)
+            if name == "gtos_gemm" and self.extents:
+                self._check_gemm(args)
             self.calls.append((name, args))
             return 0
         return fn
@@ -102,6 +133,13 @@ def DryRun():
         saved[(obj, name)] = (getattr(obj, name), name in vars(obj) if isinstance(obj, type) else True)
         setattr(obj, name, value)
     patch(_lib, "_lib", rec)                                   # load() hands out the recorder
+    import gtos_amd.flat
+    import gtos_amd.gru
+    import gtos_amd.ops
+    import gtos_amd.train
+    for mod in (_lib, gtos_amd.ops, gtos_amd.gru, gtos_amd.flat, gtos_amd.train):      # every module took its own reference to ptr()
+        if hasattr(mod, "ptr"):
+            patch(mod, "ptr", rec.note_ptr)
     patch(_lib, "_raw_stream", False)
     patch(torch.cuda, "current_stream", lambda device=None: FakeStream())
     patch(torch.cuda, "Stream", FakeStream)

@@ -47,6 +47,7 @@ def test_training_step_launch_plan_c1_bf16_trie_factored():
         for name, _ in rec.calls[n2:]:
             hist[name] = hist.get(name, 0) + 1
     assert plan_a == plan_b                                       # same batch, same plan (shapes, flags, split-K factors, launch order)
+    assert rec.extent_checks > 400                                # every GEMM operand of the three steps lay inside its storage
     L = synth.CONFIGS["C1"]["layers"]
     # the production path of DESIGN.md: factored attention (one bank-gradient launch per graph layer), trie-evaluated GRU (level
     # steps, never the per-row cell kernels), fused copy / NLL, device-side step control and ONE fused optimizer sweep per segment
@@ -153,3 +154,23 @@ def test_eval_mode_encoder_glue_on_an_every_alternative_batch():
                 model.encode_step(attach_path_trie(batch), train=False)
             names = {n for n, _ in rec.calls}
         assert "gtos_rel_attn_fwd" in names and "gtos_relation_gather_mean" in names and "gtos_rel_attn_bwd" not in names
+
+
+def test_dryrun_checks_gemm_operand_extents():
+    """the recorder knows the storage behind every pointer that went through ptr(): a gtos_gemm operand whose rows x leading dimension
+    run past its storage is refused (the real launches of the plans above all pass this check: column blocks of gradient slabs, row blocks
+    of packed projections, transposed weight views)"""
+    import pytest
+    from gtos_amd import ops
+    from gtos_amd._lib import call
+    with DryRun() as rec:
+        a, w = torch.zeros(6, 16, dtype=torch.bfloat16), torch.zeros(8, 16, dtype=torch.bfloat16)
+        ops.gemm(a, w, trans_b=True)
+        view = torch.zeros(6, 16, dtype=torch.bfloat16)[:, :8]                  # a column block: [6, 8] with row stride 16
+        ops.gemm(view, torch.zeros(4, 8, dtype=torch.bfloat16), trans_b=True)
+        assert rec.extent_checks == 2
+        b4, c7 = torch.zeros(4, 8, dtype=torch.bfloat16), torch.zeros(7, 4, dtype=torch.bfloat16)
+        with pytest.raises(AssertionError, match="past its storage"):           # 7 rows claimed of a 6-row operand
+            call("gtos_gemm", 1, 1, 0, 1, 7, 4, 8, ops.ptr(view), 16, ops.ptr(b4), 8, ops.ptr(c7), 4, None, 0, 0.0, 0, 0, 1, None, 0, 0)
+        with pytest.raises(AssertionError, match="leading dimension"):
+            call("gtos_gemm", 1, 1, 0, 1, 6, 4, 8, ops.ptr(view), 4, ops.ptr(b4), 8, ops.ptr(c7), 4, None, 0, 0.0, 0, 0, 1, None, 0, 0)
