@@ -67,17 +67,23 @@ def _kind_ok(ctype, v):
 class Recorder(object):
     def __init__(self):
         self.calls = []
-        self.extents = {}        # data_ptr -> (end of the storage the pointer was taken from): filled by the patched _lib.ptr
+        self.recent = {}         # storage base -> end, of every tensor whose data_ptr() was taken since the last recorded launch
+        self.check_extents = True
+        self.unknown_ptrs = 0
         self.extent_checks = 0
 
-    def note_ptr(self, t):
-        if t is None:
-            return None
-        p = t.data_ptr()
+    def note_storage(self, t):
+        """called for EVERY Tensor.data_ptr() under the dry run: the storage [base, end) a launch argument can have been computed from.
+        The table is cleared after every recorded launch, so an argument only ever resolves to a storage whose tensor was alive when
+        the arguments of THAT launch were evaluated (the CPU allocator reuses freed memory at once)."""
         st = t.untyped_storage()
-        end = st.data_ptr() + st.nbytes()
-        self.extents[p] = max(self.extents.get(p, 0), end)
-        return p
+        self.recent[st.data_ptr()] = st.data_ptr() + st.nbytes()
+
+    def _end_of(self, p):
+        for base, end in self.recent.items():
+            if base <= p < end:
+                return end
+        return None
 
     def _check_gemm(self, args):
         """every operand of a gtos_gemm call lies inside the storage its pointer came from: rows x columns with the leading dimension the
@@ -88,13 +94,52 @@ class Recorder(object):
         es_in, es_out = (4, 2)[in_dt], (4, 2)[out_dt]
         for name, p, rows, cols, ld, es in (("A", A, K if ta else M, M if ta else K, lda, es_in), ("B", B, N if tb else K, K if tb else N, ldb, es_in),
                                             ("C", C, M, N, ldc, es_out)):
-            assert p in self.extents, "gtos_gemm: operand %s did not come through ptr()" % name
-            assert ld >= cols or rows == 1, "gtos_gemm: leading dimension %d of %s below its %d columns" % (ld, name, cols)
-            need = p + ((rows - 1) * ld + cols) * es
-            assert need <= self.extents[p], "gtos_gemm: operand %s [%d x %d, ld %d] runs %d bytes past its storage" % (
-                name, rows, cols, ld, need - self.extents[p])
+            self._rows("gtos_gemm: operand " + name, p, rows, cols, ld, es)
         if bias is not None:
-            assert bias in self.extents and bias + 4 * N <= self.extents[bias], "gtos_gemm: bias shorter than N"
+            self._rows("gtos_gemm: bias", bias, 1, N, N, 4)
+        self.extent_checks += 1
+
+    def _rows(self, what, p, rows, cols, ld, es):
+        """a [rows, cols] operand with leading dimension ld (elements of es bytes) behind pointer p lies inside its storage"""
+        if p is None or rows <= 0 or cols <= 0:
+            return
+        end = self._end_of(p)
+        if end is None:                 # a buffer that never went through ptr() (an offset into a fresh torch.empty): nothing to check against
+            self.unknown_ptrs += 1
+            return
+        assert ld >= cols or rows == 1, "%s: leading dimension %d below its %d columns" % (what, ld, cols)
+        need = p + ((rows - 1) * ld + cols) * es
+        assert need <= end, "%s [%d x %d, ld %d] runs %d bytes past its storage" % (what, rows, cols, ld, need - end)
+
+    def _check_other(self, name, a):
+        es = lambda dtc: (4, 2)[dtc]                                          # noqa: E731
+        if name == "gtos_rel_attn_fwd":
+            dtc, mode, T, S, B, H, d = a[:7]
+            for what, p, ld, rows in (("q", a[7], a[8], T * B), ("k", a[9], a[10], S * B), ("v", a[11], a[12], S * B), ("o", a[20], a[21], T * B)):
+                self._rows("gtos_rel_attn_fwd: " + what, p, rows, d, ld, es(dtc))
+            self._rows("gtos_rel_attn_fwd: lse", a[22], 1, T * B * H, T * B * H, 4)
+            self._rows("gtos_rel_attn_fwd: key_pad", a[15], 1, S * B, S * B, 1)
+            self._rows("gtos_rel_attn_fwd: attn_mask", a[16], 1, T * S, T * S, 1)
+            if mode == 2:
+                self._rows("gtos_rel_attn_fwd: idx_q", a[14], 1, T * B * S, T * B * S, 4)
+        elif name == "gtos_rel_attn_bwd":
+            dtc, mode, T, S, B, H, d = a[:7]
+            for what, p, ld, rows in (("q", a[7], a[8], T * B), ("k", a[9], a[10], S * B), ("v", a[11], a[12], S * B), ("o", a[21], a[22], T * B),
+                                      ("d_o", a[25], a[26], T * B), ("dq", a[28], a[29], T * B), ("dk", a[30], a[31], S * B), ("dv", a[32], a[33], S * B)):
+                self._rows("gtos_rel_attn_bwd: " + what, p, rows, d, ld, es(dtc))
+            self._rows("gtos_rel_attn_bwd: lse", a[23], 1, T * B * H, T * B * H, 4)
+        elif name == "gtos_colsum":
+            dtc, rows, N, ld, dy, out = a[:6]
+            self._rows("gtos_colsum: dy", dy, rows, N, ld, es(dtc))
+            self._rows("gtos_colsum: out", out, 1, N, N, 4)
+        elif name == "gtos_ln_residual_fwd":
+            dtc, rows, d = a[:3]
+            for what, p in (("x", a[3]), ("r", a[4]), ("y", a[10])):
+                self._rows("gtos_ln_residual_fwd: " + what, p, rows, d, d, es(dtc))
+            for what, p, n in (("gamma", a[7], d), ("beta", a[8], d), ("mean", a[11], rows), ("rstd", a[12], rows)):
+                self._rows("gtos_ln_residual_fwd: " + what, p, 1, n, n, 4)
+        else:
+            return
         self.extent_checks += 1
 
     def __getattr__(self, name):
@@ -108,8 +153,12 @@ class Recorder(object):
             assert len(args) == len(sig), "%s: %d arguments for a %d-argument signature" % (name, len(args), len(sig))
             for k, (c, v) in enumerate(zip(sig, args)):
                 assert _kind_ok(c, v), "%s: argument %d is %r, signature says %s" % (name, k, v, c.__name__)
-            if name == "gtos_gemm" and self.extents:
-                self._check_gemm(args)
+            if self.check_extents:
+                if name == "gtos_gemm":
+                    self._check_gemm(args)
+                else:
+                    self._check_other(name, args)
+            self.recent.clear()
             self.calls.append((name, args))
             return 0
         return fn
@@ -133,13 +182,12 @@ def DryRun():
         saved[(obj, name)] = (getattr(obj, name), name in vars(obj) if isinstance(obj, type) else True)
         setattr(obj, name, value)
     patch(_lib, "_lib", rec)                                   # load() hands out the recorder
-    import gtos_amd.flat
-    import gtos_amd.gru
-    import gtos_amd.ops
-    import gtos_amd.train
-    for mod in (_lib, gtos_amd.ops, gtos_amd.gru, gtos_amd.flat, gtos_amd.train):      # every module took its own reference to ptr()
-        if hasattr(mod, "ptr"):
-            patch(mod, "ptr", rec.note_ptr)
+    real_data_ptr = torch.Tensor.data_ptr
+
+    def data_ptr(self):
+        rec.note_storage(self)
+        return real_data_ptr(self)
+    patch(torch.Tensor, "data_ptr", data_ptr)                  # every launch argument starts as some tensor's data_ptr()
     patch(_lib, "_raw_stream", False)
     patch(torch.cuda, "current_stream", lambda device=None: FakeStream())
     patch(torch.cuda, "Stream", FakeStream)
