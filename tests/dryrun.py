@@ -4,7 +4,10 @@
 (name, args) after its arguments were checked against the binding's ctypes signature), fakes the torch.cuda stream / event API
 and lets CPU tensors report ``is_cuda``.  Kernel outputs stay uninitialised memory, so numbers mean nothing; what the harness
 gives without a GPU is (1) every ``call()`` site of the branches a training step takes exercised against ``_lib.SIGNATURES`` (argument
-count and kind), (2) the launch plan of a step -- which entry points, how often, with which shapes -- as data, (3) the host time of
+count and kind) and, for the GEMM, attention, bank-gradient, LayerNorm, column-sum, GRU-step and segment-sum launches (85 % of a step), a
+BOUNDS CHECK of every operand: rows x leading dimension inside the storage of the tensor the pointer came from, every gathered row
+index (read from the real index arrays of the batch: trie row lists, parent / children-sum indices, chunk lists, pair lists) inside
+its table, (2) the launch plan of a step -- which entry points, how often, with which shapes -- as data, (3) the host time of
 a step's Python glue, which is what bounds the launch-bound configurations.  Nothing under gtos_amd/ knows about this module."""
 import contextlib
 import ctypes
@@ -138,9 +141,133 @@ class Recorder(object):
                 self._rows("gtos_ln_residual_fwd: " + what, p, rows, d, d, es(dtc))
             for what, p, n in (("gamma", a[7], d), ("beta", a[8], d), ("mean", a[11], rows), ("rstd", a[12], rows)):
                 self._rows("gtos_ln_residual_fwd: " + what, p, 1, n, n, 4)
+        elif name == "gtos_gru_step_fwd":
+            (rows, hs, x, ldx, in_dim, w_ih, b_ih, xg, gf, gf_idx, gb, gb_idx, h_in, h_idx, w_hh, b_hh, h_out, n_out, h_fin, ld_fin, fin_idx,
+             gates, y, ldy) = a[:24]
+            W = "gtos_gru_step_fwd: "
+            self._rows(W + "x", x, rows, in_dim, ldx, 2)
+            self._rows(W + "w_ih", w_ih if x is not None else None, 3 * hs, in_dim, in_dim, 2)
+            self._rows(W + "b_ih", b_ih, 1, 3 * hs, 3 * hs, 4)
+            self._rows(W + "xg", xg, rows, 3 * hs, 3 * hs, 2)
+            self._gather(W + "gf", gf, gf_idx, 0, rows, 3 * hs, 3 * hs, 2)
+            self._gather(W + "gb", gb, gb_idx, 0, rows, 3 * hs, 3 * hs, 2)
+            if h_idx is not None:
+                self._gather(W + "h_in", h_in, h_idx, 0, rows, hs, hs, 2)
+            else:
+                self._rows(W + "h_in", h_in, rows, hs, hs, 2)
+            self._rows(W + "w_hh", w_hh, 3 * hs, hs, hs, 2)
+            self._rows(W + "b_hh", b_hh, 1, 3 * hs, 3 * hs, 4)
+            self._rows(W + "h_out", h_out, min(rows, n_out), hs, hs, 2)
+            if rows > n_out:
+                if fin_idx is not None:
+                    self._gather(W + "h_fin", h_fin, fin_idx, n_out, rows, hs, ld_fin, 2)
+                else:
+                    self._rows(W + "h_fin", h_fin, rows, hs, ld_fin, 2)
+            self._rows(W + "gates", gates, rows, 4 * hs, 4 * hs, 2)
+            self._rows(W + "y", y, rows, hs, ldy, 2)
+        elif name == "gtos_gru_step_bwd":
+            (rows, hs, d4_prev, rows_prev, w_hh_t, gates, hprev, hprev_idx, dy, ldy, dh, dh_dtype, ld_dh, d4, p_drop, seed, drop_base,
+             bias_partials, n_partials, hprev_out, sum_idx, dh_src, zero_row) = a[:23]
+            W = "gtos_gru_step_bwd: "
+            es_dh = (4, 2)[dh_dtype]
+            self._rows(W + "w_hh_t", w_hh_t if d4_prev is not None else None, hs, 3 * hs, 3 * hs, 2)
+            self._rows(W + "gates", gates, rows, 4 * hs, 4 * hs, 2)
+            if hprev_idx is not None:
+                self._gather(W + "hprev", hprev, hprev_idx, 0, rows, hs, hs, 2)
+            else:
+                self._rows(W + "hprev", hprev, rows, hs, hs, 2)
+            self._rows(W + "dy", dy, rows, hs, ldy, 2)
+            self._rows(W + "dh", dh, rows, hs, ld_dh, es_dh)
+            self._rows(W + "d4", d4, rows, 4 * hs, 4 * hs, 2)
+            self._rows(W + "bias_partials", bias_partials, n_partials, 4 * hs, 4 * hs, 4)
+            self._rows(W + "hprev_out", hprev_out, rows, hs, hs, 2)
+            if sum_idx is not None:       # rows equal to zero_row take zeros without a fetch
+                self._gather(W + "d4_prev", d4_prev, sum_idx, 0, rows, 4 * hs, 4 * hs, 2, skip=zero_row)
+                self._gather(W + "dh_src", dh_src, sum_idx, 0, rows, hs, hs, es_dh, skip=zero_row)
+            elif d4_prev is not None:
+                self._rows(W + "d4_prev", d4_prev, min(rows, rows_prev), 4 * hs, 4 * hs, 2)
+        elif name in ("gtos_segment_sum_stream", "gtos_segment_sum_rows"):
+            import ctypes
+            import numpy as np
+            if name == "gtos_segment_sum_stream":
+                (n_chunks, total_rows, rows_p, chunk_node, chunk_start, chunk_cnt, chunk_slot, wave_off, n_waves, src, ld_src, width, dst, ld_dst,
+                 heavy) = a[:15]
+                self._rows(name + ": wave_off", wave_off, 1, n_waves + 1, n_waves + 1, 4)
+            else:
+                (n_chunks, rows_p, chunk_node, chunk_start, chunk_cnt, chunk_slot, src, src2, ld_src, width, dst, dst2, ld_dst, heavy, heavy2) = a[:15]
+                total_rows = None
+            if n_chunks > 0:
+                arr = lambda p_, n_: np.ctypeslib.as_array((ctypes.c_int32 * n_).from_address(p_))      # noqa: E731
+                for what, p_ in (("chunk_node", chunk_node), ("chunk_start", chunk_start), ("chunk_cnt", chunk_cnt), ("chunk_slot", chunk_slot)):
+                    self._rows(name + ": " + what, p_, 1, n_chunks, n_chunks, 4)
+                cs, cc = arr(chunk_start, n_chunks), arr(chunk_cnt, n_chunks)
+                n_rows = int((cs + cc).max())
+                assert int(cs.min()) >= 0 and int(cc.min()) >= 0 and (total_rows is None or n_rows <= total_rows), name + ": chunk ranges"
+                self._rows(name + ": rows", rows_p, 1, n_rows, n_rows, 4)
+                if n_rows:
+                    self._gather(name + ": src", src, rows_p, 0, n_rows, width, ld_src, 2)
+                self._gather(name + ": dst", dst, chunk_node, 0, n_chunks, width, ld_dst, 2)
+                slots = arr(chunk_slot, n_chunks)
+                if heavy is not None and int(slots.max()) >= 0:
+                    self._rows(name + ": heavy", heavy, int(slots.max()) + 1, width, width, 4)
+        elif name == "gtos_rel_attn_bwd_bank":
+            import ctypes
+            import numpy as np
+            (dtc, n, B, H, d, q, ldq, k, ldk, bank, gs, pair_sorted, chunk_type, chunk_start, chunk_count, chunk_slot, xcd_off, nchunks, d_bank,
+             ld_dbank, heavy) = a[:21]
+            W, P = name + ": ", n * n * B
+            self._rows(W + "q", q, n * B, d, ldq, es(dtc))
+            self._rows(W + "k", k, n * B, d, ldk, es(dtc))
+            self._rows(W + "gs", gs, 1, P * H, P * H, 4)
+            self._rows(W + "xcd_off", xcd_off, 1, 9, 9, 4)
+            if nchunks > 0:
+                arr = lambda p_, n_: np.ctypeslib.as_array((ctypes.c_int32 * n_).from_address(p_))      # noqa: E731
+                for what, p_ in (("chunk_type", chunk_type), ("chunk_start", chunk_start), ("chunk_count", chunk_count), ("chunk_slot", chunk_slot)):
+                    self._rows(W + what, p_, 1, nchunks, nchunks, 4)
+                cs, cc = arr(chunk_start, nchunks), arr(chunk_count, nchunks)
+                assert int(cs.min()) >= 0 and int(cc.min()) >= 0 and int((cs + cc).max()) <= P, W + "chunk ranges outside the pair list"
+                self._rows(W + "pair_sorted", pair_sorted, 1, P, P, 4)
+                ps = arr(pair_sorted, P)
+                assert int(ps.min()) >= 0 and int(ps.max()) < P, W + "pair ids outside [0, n*n*B)"
+                assert int(arr(xcd_off, 9)[8]) == nchunks, W + "xcd_off does not cover the chunk list"
+                self._gather(W + "bank", bank, chunk_type, 0, nchunks, 2 * d, 2 * d, es(dtc))
+                self._gather(W + "d_bank", d_bank, chunk_type, 0, nchunks, 2 * d, ld_dbank, es(dtc))
+                slots = arr(chunk_slot, nchunks)
+                if heavy is not None and int(slots.max()) >= 0:
+                    self._rows(W + "heavy", heavy, int(slots.max()) + 1, 2 * d, 2 * d, 4)
+        elif name == "gtos_segment_sum_ranges":
+            n_seg, ranges, src, ld_src, width, dst, ld_dst = a[:7]
+            if n_seg > 0:
+                import ctypes
+                import numpy as np
+                self._rows(name + ": ranges", ranges, 1, 2 * n_seg, 2 * n_seg, 4)
+                r = np.ctypeslib.as_array((ctypes.c_int32 * (2 * n_seg)).from_address(ranges))
+                assert int(r.min()) >= 0 and bool((r[1::2] >= r[0::2]).all()), name + ": ranges not ordered"
+                self._rows(name + ": src", src, int(r[1::2].max()), width, ld_src, 2)
+                self._rows(name + ": dst", dst, n_seg, width, ld_dst, 2)
         else:
             return
         self.extent_checks += 1
+
+    def _gather(self, what, table, idx, lo, hi, cols, ld, es, skip=None):
+        """table rows idx[lo:hi] (int32 indices read from the real index array) of `cols` elements, row stride ld, lie inside the table"""
+        if table is None or idx is None or hi <= lo:
+            return
+        import ctypes
+        import numpy as np
+        self._rows(what + " index", idx, 1, hi, hi, 4)
+        end = self._end_of(table)
+        if end is None:
+            self.unknown_ptrs += 1
+            return
+        ix = np.ctypeslib.as_array((ctypes.c_int32 * hi).from_address(idx))[lo:hi]
+        if skip is not None:
+            ix = ix[ix != skip]
+            if ix.size == 0:
+                return
+        assert int(ix.min()) >= 0, "%s: negative row index %d" % (what, int(ix.min()))
+        need = table + (int(ix.max()) * ld + cols) * es
+        assert need <= end, "%s: row index %d reaches %d bytes past the table" % (what, int(ix.max()), need - end)
 
     def __getattr__(self, name):
         if name == "gtos_abi_version":
