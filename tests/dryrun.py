@@ -100,6 +100,11 @@ class Recorder(object):
             self._rows("gtos_gemm: operand " + name, p, rows, cols, ld, es)
         if bias is not None:
             self._rows("gtos_gemm: bias", bias, 1, N, N, 4)
+        # the product is never written over one of its own operands
+        span = lambda p_, rows, cols, ld, es: (p_, p_ + ((rows - 1) * ld + cols) * es)      # noqa: E731
+        c0, c1 = span(C, M, N, ldc, es_out)
+        for name, (x0, x1) in (("A", span(A, K if ta else M, M if ta else K, lda, es_in)), ("B", span(B, N if tb else K, K if tb else N, ldb, es_in))):
+            assert x1 <= c0 or c1 <= x0, "gtos_gemm: C overlaps operand %s" % name
         self.extent_checks += 1
 
     def _rows(self, what, p, rows, cols, ld, es):
