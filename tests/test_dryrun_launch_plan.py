@@ -176,3 +176,26 @@ def test_dryrun_checks_gemm_operand_extents():
             call("gtos_gemm", 1, 1, 0, 1, 7, 4, 8, ops.ptr(view), 16, ops.ptr(b4), 8, ops.ptr(c7), 4, None, 0, 0.0, 0, 0, 1, None, 0, 0)
         with pytest.raises(AssertionError, match="leading dimension"):
             call("gtos_gemm", 1, 1, 0, 1, 6, 4, 8, ops.ptr(view), 4, ops.ptr(b4), 8, ops.ptr(c7), 4, None, 0, 0.0, 0, 0, 1, None, 0, 0)
+
+
+def test_beam_search_glue_under_the_dry_run():
+    """``Generator.work`` (encode once, incremental decoding with K/V caches, beam bookkeeping of gtos_amd/search.py) on an eval batch:
+    the hypotheses are meaningless (kernel outputs are uninitialised memory) but every launch of the decode loop is well-formed and in
+    bounds -- cached-key attention with growing S, the copy / generate likelihood rows, the beam reorders."""
+    from gtos_amd.config import generator_args
+    from gtos_amd.generator import Generator
+    from gtos_amd.pathtrie import attach_path_trie
+    with DryRun() as rec:
+        vocabs = synth.synth_vocabs()
+        torch.manual_seed(1)
+        model = Generator(vocabs, device=torch.device("cpu"), depth_size=32, **generator_args(synth.CONFIGS["C1"]))
+        model.set_compute_dtype(torch.bfloat16)
+        model.eval()
+        batch, _ = synth.make_config_batch("C1", train=False)
+        batch = attach_path_trie(batch)
+        pv, cp = vocabs['predictable_token'], batch['cp_seq']
+        batch['local_idx2token'] = [{int(i): "copy%d" % int(i) for i in cp[:, b].tolist() if i >= pv.size} for b in range(cp.shape[1])]
+        beams = model.work(batch, 4, 5)
+        hist = rec.histogram()
+    assert len(beams) == batch['concept'].shape[1] and max(b.steps for b in beams) == 5
+    assert hist["gtos_copy_ll_fwd"] == 5 and "gtos_rel_attn_bwd" not in hist and rec.extent_checks > 300 and rec.unknown_ptrs == 0
