@@ -240,6 +240,18 @@ class Recorder(object):
                 slots = arr(chunk_slot, nchunks)
                 if heavy is not None and int(slots.max()) >= 0:
                     self._rows(W + "heavy", heavy, int(slots.max()) + 1, 2 * d, 2 * d, 4)
+        elif name == "gtos_embed_rows_fwd":
+            dtc, n, dim, dim_pad, tok, table, out = a[:7]
+            self._gather(name + ": table", table, tok, 0, n, dim, dim, 4, itype=8)
+            self._rows(name + ": out", out, n, dim_pad, dim_pad, es(dtc))
+        elif name == "gtos_token_row_fwd":
+            dtc, N, Cc, Ct, Cp, feat, tok, table = a[:8]
+            self._rows(name + ": feat", feat, N, Cc, Cc, es(dtc))
+            self._gather(name + ": table", table, tok, 0, N, Ct, Ct, 4, itype=8)
+        elif name == "gtos_relation_gather_mean":
+            dtc, P, K, d, bank, idx, zero_row0, out = a[:8]
+            self._gather(name + ": bank", bank, idx, 0, P * K, d, d, es(dtc), itype=8)
+            self._rows(name + ": out", out, P, d, d, es(dtc))
         elif name == "gtos_segment_sum_ranges":
             n_seg, ranges, src, ld_src, width, dst, ld_dst = a[:7]
             if n_seg > 0:
@@ -254,18 +266,18 @@ class Recorder(object):
             return
         self.extent_checks += 1
 
-    def _gather(self, what, table, idx, lo, hi, cols, ld, es, skip=None):
+    def _gather(self, what, table, idx, lo, hi, cols, ld, es, skip=None, itype=4):
         """table rows idx[lo:hi] (int32 indices read from the real index array) of `cols` elements, row stride ld, lie inside the table"""
         if table is None or idx is None or hi <= lo:
             return
         import ctypes
         import numpy as np
-        self._rows(what + " index", idx, 1, hi, hi, 4)
+        self._rows(what + " index", idx, 1, hi, hi, itype)
         end = self._end_of(table)
         if end is None:
             self.unknown_ptrs += 1
             return
-        ix = np.ctypeslib.as_array((ctypes.c_int32 * hi).from_address(idx))[lo:hi]
+        ix = np.ctypeslib.as_array(((ctypes.c_int32 if itype == 4 else ctypes.c_int64) * hi).from_address(idx))[lo:hi]
         if skip is not None:
             ix = ix[ix != skip]
             if ix.size == 0:
