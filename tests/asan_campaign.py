@@ -8,7 +8,9 @@ corruption.  Not collected by pytest.  Usage (from the repo root):
     LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 python tests/asan_campaign.py 150 big
 
 The closing session of round 3 ran it (150 random cases in all three path modes, two chunk sizes, then C2-sized banks of 16 graphs): no
-report.  (torch aligns CPU allocations to 64 bytes: an overrun of fewer bytes than the padding behind a buffer goes unseen.)"""
+report.  The PRODUCT's host library passed the same way: libgtos_host.so compiled with -fsanitize=address,undefined (same three
+sources, -O1 -g), ``relbatch.LIB_PATH`` pointed at it, the host test files (test_host_relbatch / test_pathtrie / test_relindex_dev /
+test_relbatch_dev, 90 tests incl. the reference goldens and the C2-size banks) under libasan + libubsan: no report.  (torch aligns CPU allocations to 64 bytes: an overrun of fewer bytes than the padding behind a buffer goes unseen.)"""
 import sys, os
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE); sys.path.insert(0, os.path.dirname(HERE))
