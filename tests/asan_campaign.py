@@ -10,7 +10,8 @@ corruption.  Not collected by pytest.  Usage (from the repo root):
 The closing session of round 3 ran it (150 random cases in all three path modes, two chunk sizes, then C2-sized banks of 16 graphs): no
 report.  The PRODUCT's host library passed the same way: libgtos_host.so compiled with -fsanitize=address,undefined (same three
 sources, -O1 -g), ``relbatch.LIB_PATH`` pointed at it, the host test files (test_host_relbatch / test_pathtrie / test_relindex_dev /
-test_relbatch_dev, 90 tests incl. the reference goldens and the C2-size banks) under libasan + libubsan: no report.  (torch aligns CPU allocations to 64 bytes: an overrun of fewer bytes than the padding behind a buffer goes unseen.)"""
+test_relbatch_dev, 90 tests incl. the reference goldens and the C2-size banks) under libasan + libubsan: no report; and with -fsanitize=thread under libtsan (relation batches of all three modes with 4 threads, the
+two-sided trie build, the relation index): no report.  (torch aligns CPU allocations to 64 bytes: an overrun of fewer bytes than the padding behind a buffer goes unseen.)"""
 import sys, os
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE); sys.path.insert(0, os.path.dirname(HERE))
