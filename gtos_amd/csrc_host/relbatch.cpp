@@ -391,7 +391,10 @@ extern "C" gtos_relbatch* gtos_relbatch_build(int B, const int* n_nodes, const i
 
 extern "C" int gtos_relbatch_dims(const gtos_relbatch* h, int* n, int* R, int* L, int* K) {
     if (!h) return -1;
-    if (n) *n = h->n; if (R) *R = h->R; if (L) *L = h->L; if (K) *K = h->K;
+    if (n) *n = h->n;
+    if (R) *R = h->R;
+    if (L) *L = h->L;
+    if (K) *K = h->K;
     return 0;
 }
 
