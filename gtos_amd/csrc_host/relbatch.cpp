@@ -423,6 +423,8 @@ extern "C" int64_t gtos_relbatch_csr(int B, const int* n_nodes, const int* roots
                                      int32_t* adj_lab, int32_t* order, int32_t* depth) {
     if (B <= 0 || !n_nodes || !roots || !edge_off || !node_off || !adj_base || !adj_off || !adj_dst || !adj_lab || !order || !depth) return -1;
     int64_t nodes = 0, adj = 0;
+    for (int b = 0; b < B; ++b)                      // sizes first: the caller sized the outputs by the sums of these
+        if (n_nodes[b] <= 0 || edge_off[b] < 0 || edge_off[b + 1] < edge_off[b]) return -1;
     Graph g;
     for (int b = 0; b < B; ++b) {
         if (!build_graph(g, n_nodes[b], roots[b], edge_off[b], edge_off[b + 1], e_src, e_dst, e_label)) return -1;
@@ -430,8 +432,10 @@ extern "C" int64_t gtos_relbatch_csr(int B, const int* n_nodes, const int* roots
         node_off[b] = (int32_t)nodes;
         adj_base[b] = (int32_t)adj;
         std::memcpy(adj_off + nodes + b, g.adj_off.data(), (size_t)(g.n + 1) * sizeof(int32_t));
-        std::memcpy(adj_dst + adj, g.adj_dst.data(), g.adj_dst.size() * sizeof(int32_t));
-        std::memcpy(adj_lab + adj, g.adj_lab.data(), g.adj_lab.size() * sizeof(int32_t));
+        if (!g.adj_dst.empty()) {                     // (a single node has no adjacency: no copy from a null vector)
+            std::memcpy(adj_dst + adj, g.adj_dst.data(), g.adj_dst.size() * sizeof(int32_t));
+            std::memcpy(adj_lab + adj, g.adj_lab.data(), g.adj_lab.size() * sizeof(int32_t));
+        }
         std::memcpy(order + nodes, g.order.data(), (size_t)g.n * sizeof(int32_t));
         std::memcpy(depth + nodes, g.depth.data(), (size_t)g.n * sizeof(int32_t));
         nodes += g.n;

@@ -50,6 +50,8 @@ def graphs_csr(graphs):
     off[1:] = np.cumsum([len(e) for e in edges])
     allE = np.concatenate(edges) if off[-1] else np.zeros((0, 3), np.int32)
     src, dst, lab = [np.ascontiguousarray(allE[:, k]) for k in range(3)]
+    if B == 0 or int(n_nodes.min()) <= 0:
+        raise ValueError("every graph needs at least one node")
     S, E = int(n_nodes.sum()), int(off[-1])
     out = dict(ng=n_nodes, node_off=np.zeros(B + 1, np.int32), adj_base=np.zeros(B + 1, np.int32), adj_off=np.zeros(S + B, np.int32),
                adj_dst=np.zeros(max(1, E), np.int32), adj_lab=np.zeros(max(1, E), np.int32), order=np.zeros(S, np.int32),

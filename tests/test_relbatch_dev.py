@@ -255,3 +255,16 @@ def test_device_all_eval_batch_equals_the_host_eval_batch(monkeypatch):
     for k in ("relation", "relation_bank", "relation_length", "concept", "token_in"):
         assert torch.equal(want[k], got[k]), k
     assert _same_object(want["relation_trie"], got["relation_trie"]) == []
+
+
+def test_flattened_graphs_refuse_invalid_node_counts_before_writing():
+    """gtos_relbatch_csr sizes nothing from unvalidated counts (found by the sanitizer fuzz of the host ABI: a batch whose second graph has
+    a non-positive node count used to overrun the outputs sized from the sum)"""
+    good = (3, 0, np.array([[0, 1, 7], [1, 0, 8], [1, 2, 7], [2, 1, 8]], np.int32))
+    for bad_n in (0, -1):
+        with pytest.raises(ValueError):
+            graphs_csr([good, (bad_n, 0, np.zeros((0, 3), np.int32))])
+    with pytest.raises(ValueError):
+        graphs_csr([])
+    c = graphs_csr([good, (1, 0, np.zeros((0, 3), np.int32))])          # a single node: no adjacency at all
+    assert c["S"] == 4 and c["P"] == 10 and c["adj_base"].tolist() == [0, 4, 4]
