@@ -260,6 +260,9 @@ extern "C" gtos_relbatch* gtos_relbatch_build(int B, const int* n_nodes, const i
             ++done;
             auto ta = std::chrono::steady_clock::now();
             if (!build_graph(graphs[g], n_nodes[g], roots[g], edge_off[g], edge_off[g + 1], e_src, e_dst, e_label)) { bad = 1; continue; }
+            // the flat search of the one-path-per-pair modes keeps node ids and shortest-path-DAG edge ids in int16 scratch (shared with the
+            // GPU builder): refuse what does not fit instead of wrapping (include/gtos_host.h states the limit)
+            if (path_mode != GTOS_PATH_ALL && (graphs[g].n > 32767 || graphs[g].adj_off[graphs[g].n] > 32767)) { bad = 1; continue; }
             auto tb = std::chrono::steady_clock::now();
             if (path_mode == GTOS_PATH_ALL) graph_paths(graphs[g], path_mode, seed, g, max_len, self_key, tl_key, pp[g]);
             else graph_paths_single(graphs[g], path_mode, seed, g, max_len, self_key, tl_key, pp[g], slotbuf);

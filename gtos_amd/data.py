@@ -555,7 +555,8 @@ class Prefetcher(object):
         self._prep_in_worker = bool(prep_in_worker)
         self._prep_lock = threading.Lock()
         self._out = {}
-        self._cv = threading.Condition()          # ONE lock: depth reservation, source advance and hand-over are atomic
+        self._cv = threading.Condition()          # hand-over lock: depth reservation, finished batches, the consumer's wait
+        self._src_lock = threading.Lock()         # source advance (taken before _cv by the workers: keeps slots and items in order)
         self._next_in, self._next_out, self._done, self._err, self._stop = 0, 0, False, None, False
         self._depth = max(1, depth)
         self._device = torch.device(device) if device is not None else None
@@ -579,21 +580,33 @@ class Prefetcher(object):
             t.start()
 
     def _take(self):
-        """Reserve a slot within ``depth`` of the consumer and take the next source item -- under one lock, so N workers can
-        never run more than ``depth`` batches ahead."""
-        with self._cv:
-            self._cv.wait_for(lambda: self._stop or self._done or self._err is not None or
-                              self._next_in - self._next_out < self._depth)
-            if self._stop or self._done or self._err is not None:
-                return None, None
+        """Reserve a slot within ``depth`` of the consumer, then take the next source item.  The slot is reserved under the
+        hand-over lock ``_cv`` (held for a few instructions only); the source advances under ``_src_lock``, which every worker takes
+        FIRST, so reservations and source items stay in the same order while the consumer's ``__next__`` -- which needs ``_cv`` alone
+        -- never waits for a source that assembles a whole batch inside its ``__next__`` (``iter(AMRLoader)``)."""
+        with self._src_lock:
+            with self._cv:
+                self._cv.wait_for(lambda: self._stop or self._done or self._err is not None or
+                                  self._next_in - self._next_out < self._depth)
+                if self._stop or self._done or self._err is not None:
+                    return None, None
+                k = self._next_in
+                self._next_in += 1
             try:
                 item = next(self._it)
             except StopIteration:
-                self._done = True
-                self._cv.notify_all()
+                with self._cv:
+                    self._next_in -= 1                   # nobody else reserved meanwhile: _src_lock is still held
+                    self._done = True
+                    self._cv.notify_all()
                 return None, None
-            k = self._next_in
-            self._next_in += 1
+            except BaseException as e:                   # a failing source: hand the error to the consumer like a failing worker
+                with self._cv:
+                    self._next_in -= 1
+                    if self._err is None:
+                        self._err = e
+                    self._cv.notify_all()
+                return None, None
             return k, item
 
     def _needs_prep(self, b0):

@@ -68,6 +68,7 @@ class Trainer:
         self._flag = torch.zeros(1, dtype=torch.float32, device=dev)
         self._ctl = torch.zeros(2, dtype=torch.float32, device=dev)         # {lr of this step, skip}
         self.steps_issued = 0           # host-side count of step() calls: an upper bound of batches_acm (no device read needed)
+        self._counters, self._counters_at = None, -1
         self.collective = world_size > 1 or force_collectives
         self.overlap = overlap and self.collective and len(self.flat.segments) > 1
         self._launched = 0              # segments [0, _launched) have their all-reduce in flight
@@ -128,23 +129,36 @@ class Trainer:
             self._comm_events = []
         return ms
 
-    # ---- counters of the reference loop, kept on the device; reading them synchronises
+    # ---- counters of the reference loop, kept on the device.  READING THEM SYNCHRONISES (one device -> host copy): use
+    # ``steps_issued`` (host-side, no read) for per-step cadence checks like the reference's ``batches_acm % print_every`` and read
+    # the counters only when something is printed / evaluated.  One read serves all three: ``counters()`` copies the state once
+    # per issued step and the properties share that copy, so reference-style logging that touches batches_acm, loss_acm and
+    # discarded in one iteration costs one synchronisation, not three.  (A discarded batch still ran its backward and its
+    # gradient all-reduce -- only the Adam kernel is skipped)
+    def counters(self):
+        """(loss_acm, batches_acm, discarded) as of the last issued step: ONE host read, cached until the next ``step()``."""
+        if self._counters_at != self.steps_issued or self._counters is None:
+            la, ba, di = self._state.tolist()
+            self._counters, self._counters_at = (float(la), int(ba), int(di)), self.steps_issued
+        return self._counters
+
     @property
     def batches_acm(self):
-        return int(self._state[1].item())
+        return self.counters()[1]
 
     @property
     def loss_acm(self):
-        return float(self._state[0].item())
+        return self.counters()[0]
 
     @property
     def discarded(self):
-        return int(self._state[2].item())
+        return self.counters()[2]
 
     def set_counters(self, batches_acm, loss_acm, discarded=0):
         """Resume from a checkpoint (train.py keeps batches_acm / loss_acm across restarts)."""
         self._state.copy_(torch.tensor([float(loss_acm), float(batches_acm), float(discarded)], dtype=torch.float64))
         self.steps_issued = int(batches_acm) + int(discarded)
+        self._counters = None
 
     def _control(self, phase, loss):
         """gtos_step_control: phase 0 writes this rank's abnormal-loss flag, phase 1 applies the (all-reduced) flag to the

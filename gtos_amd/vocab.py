@@ -4,6 +4,8 @@ File format and semantics of /root/reference/generator/data.py:12-110 (the trans
 ``token<TAB>count`` per line; ids are [<PAD>, <UNK>] + specials + every token whose count reaches the threshold, in
 file order; ``priority`` keeps the raw count of every token; ``coverage`` is the kept fraction of the token mass.
 """
+import threading
+
 import numpy as np
 import torch
 
@@ -139,30 +141,38 @@ def lists_to_tensor(xs, vocab=None, local_vocabs=None, unk_rate=0., rng=None):
     return torch.from_numpy(np.ascontiguousarray(out.T))
 
 
-_CHAR_ROWS = {}       # (id(vocab), max_string_len) -> {string: id row}; strings repeat heavily (Zipf), the lookup is what costs
+_CHAR_ROWS = {}       # (id(vocab), max_string_len) -> [vocab, {string: id row}, rows, rows as one array, lock]
+_CHAR_ROWS_LOCK = threading.Lock()
 
 
 def strings_to_char_tensor(xs, vocab, max_string_len=20):
     """Ragged lists of strings -> int64 [max_len, batch, max_string_len + 2] of <STR> chars <END> ids (data.py:100-112).
     The id row of a string is computed once per (vocabulary, width) and kept (bounded): batch assembly runs on loader threads
-    beside the training loop, and every Python-level loop it avoids is GIL time the launch thread gets back."""
+    beside the training loop, and every Python-level loop it avoids is GIL time the launch thread gets back.
+
+    Thread safety (loader THREADS share this cache: ``Prefetcher(loader.thunks(), workers > 1)``, ``bench.py --loader threads``):
+    hits are plain dict reads; a miss builds its row outside the lock, then appends it and only THEN publishes its index under
+    the entry's lock, so no reader can see an index whose row does not exist yet and two strings can never take the same index;
+    the bounded-size reset and the growth of the gather table happen under the same lock, and a call works on the (index, rows)
+    objects it fetched at its start -- a reset by another thread swaps in new objects instead of clearing the ones in use."""
     width = max(len(x) for x in xs)
     key = (id(vocab), max_string_len)
-    ent = _CHAR_ROWS.get(key)
-    if ent is None or ent[0] is not vocab:
-        ent = _CHAR_ROWS[key] = [vocab, {}, [], None]        # vocabulary, string -> row index, rows (lists), rows as one array
-    index, rows = ent[1], ent[2]
-    if len(rows) > 2000000:
-        index.clear()
-        del rows[:]
-        ent[3] = None
+    with _CHAR_ROWS_LOCK:
+        ent = _CHAR_ROWS.get(key)
+        if ent is None or ent[0] is not vocab or len(ent[2]) > 2000000:
+            ent = _CHAR_ROWS[key] = [vocab, {}, [], None, threading.Lock()]
+    _, index, rows, _, lock = ent
 
     def ix(z):
         k = index.get(z)
         if k is None:
             chars = list(z[:max_string_len])
-            k = index[z] = len(rows)
-            rows.append(vocab.token2idx([STR] + chars + [END]) + [vocab.padding_idx] * (max_string_len - len(chars)))
+            row = vocab.token2idx([STR] + chars + [END]) + [vocab.padding_idx] * (max_string_len - len(chars))
+            with lock:
+                k = index.get(z)
+                if k is None:
+                    rows.append(row)
+                    k = index[z] = len(rows) - 1
         return k
     pad_ix = ix(PAD)
     # one small index matrix from the Python side (a dict lookup per string), the [B, width, chars] tensor by ONE gather from the
@@ -171,10 +181,15 @@ def strings_to_char_tensor(xs, vocab, max_string_len=20):
     for i, x in enumerate(xs):
         if x:
             idx[i, :len(x)] = [ix(z) for z in x]
+    need = int(idx.max()) + 1
     table = ent[3]
-    if table is None or table.shape[0] < len(rows):
-        fresh = np.asarray(rows[0 if table is None else table.shape[0]:], dtype=np.int64).reshape(-1, max_string_len + 2)
-        table = ent[3] = fresh if table is None else np.concatenate([table, fresh])
+    if table is None or table.shape[0] < need:
+        with lock:
+            table = ent[3]
+            if table is None or table.shape[0] < need:
+                have = 0 if table is None else table.shape[0]
+                fresh = np.asarray(rows[have:len(rows)], dtype=np.int64).reshape(-1, max_string_len + 2)
+                table = ent[3] = fresh if table is None else np.concatenate([table, fresh])
     return torch.from_numpy(np.ascontiguousarray(table[idx].transpose(1, 0, 2)))
 
 

@@ -30,7 +30,10 @@ typedef struct gtos_relbatch gtos_relbatch;
  *   (the reference inserts (src,des,rel) then (des,src,rel+'_reverse_'/'_r_')).  Labels are relation-vocabulary ids in
  *   [1,255].  A repeated (src,dst) overwrites the earlier label in place (networkx DiGraph semantics).
  *   ids: {pad, cls, rcls, self, tl} relation-vocabulary ids; max_len: paths longer than this collapse to <TL> (8).
- * Returns NULL on invalid input (disconnected graph, label out of range, ...). */
+ * Returns NULL on invalid input (disconnected graph, label out of range, ...); in the one-path-per-pair modes (GTOS_PATH_FIRST /
+ * GTOS_PATH_UNIFORM) also for a graph of more than 32,767 nodes or more than 32,767 adjacency entries (its shortest-path DAG has at
+ * most that many edges): the flat search shared with the GPU builder keeps node and DAG-edge ids in 16 bits.  GTOS_PATH_ALL has no
+ * such limit.  AMR / dependency graphs have tens to a few hundred nodes. */
 gtos_relbatch* gtos_relbatch_build(int B, const int* n_nodes, const int* roots, const int64_t* edge_off,
                                    const int* e_src, const int* e_dst, const int* e_label,
                                    int path_mode, uint64_t seed, const int* special_ids5, int max_len, int n_threads);

@@ -502,3 +502,40 @@ def test_unk_rate_noise_matches_the_reference_loader(tmp_path):
     b = next(iter(dl))
     assert torch.equal(b["concept"], T(g["1/concept"]))
     assert abs(float((b["token_in"] == vocabs['token'].unk_idx).float().mean()) - float((T(g["1/token_in"]) == vocabs['token'].unk_idx).float().mean())) < 0.1
+
+
+def test_char_row_cache_is_thread_safe(tmp_path):
+    """Loader THREADS share the string -> id-row cache of strings_to_char_tensor (round-3 advisor finding: an index could be published
+    before its row existed, or taken twice): eight threads on a cold cache must give the single-thread tensors."""
+    import random
+    import sys
+    import threading
+    from gtos_amd import vocab as V
+    from gtos_amd.vocab import Vocab, strings_to_char_tensor
+    chars = [chr(ord('a') + i) for i in range(26)]
+    f = tmp_path / "char_vocab"
+    f.write_text("".join("%s\t10\n" % c for c in chars))
+    cv = Vocab(str(f), 1, [V.STR, V.END])
+    rng = random.Random(3)
+    words = ["".join(rng.choice(chars) for _ in range(rng.randint(1, 9))) for _ in range(3000)]
+    batches = [[[rng.choice(words) for _ in range(rng.randint(1, 12))] for _ in range(6)] for _ in range(160)]
+    V._CHAR_ROWS.clear()
+    want = [strings_to_char_tensor(b, cv) for b in batches]
+    old = sys.getswitchinterval()
+    sys.setswitchinterval(1e-6)
+    try:
+        for _ in range(3):
+            V._CHAR_ROWS.clear()
+            got = [None] * len(batches)
+
+            def work(t):
+                for i in range(t, len(batches), 8):
+                    got[i] = strings_to_char_tensor(batches[i], cv)
+            ths = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+            assert all(torch.equal(a, b) for a, b in zip(want, got))
+    finally:
+        sys.setswitchinterval(old)

@@ -301,6 +301,29 @@ def test_prefetcher_keeps_order_defers_assembly_and_propagates_errors():
         list(Prefetcher([make(0), boom, make(2)], depth=2))
 
 
+def test_prefetcher_hands_out_finished_batches_while_a_slow_source_assembles_the_next():
+    """A source that assembles inside its own __next__ (iter(AMRLoader)) must not hold the hand-over lock: with batches ready, the
+    consumer's next() returns at once although a worker sits inside the source (round-3 advisor finding: it waited a whole assembly)."""
+    import time
+    from gtos_amd.data import Prefetcher
+
+    def slow_source():
+        for i in range(8):
+            time.sleep(0.25)
+            yield {"i": torch.tensor([i])}
+    pf = Prefetcher(slow_source(), depth=3, workers=1)
+    time.sleep(0.9)                                   # three batches finished (depth), the worker is blocked on the depth bound
+    waits = []
+    got = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        got.append(int(next(pf)["i"]))                # each take frees a slot: the worker re-enters the slow source right away
+        waits.append(time.perf_counter() - t0)
+    assert got == [0, 1, 2]
+    assert max(waits) < 0.1, waits                    # ready batches are handed over without waiting for the source's 0.25 s
+    assert [int(b["i"]) for b in pf] == [3, 4, 5, 6, 7]
+
+
 def test_prefetcher_over_the_real_loader_matches_direct_iteration():
     from gtos_amd import synth
     from gtos_amd.data import Prefetcher
