@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgtos_hip.so")
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 c_p, c_i, c_l, c_f, c_u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_uint64
 
@@ -37,6 +37,8 @@ SIGNATURES = {
     "gtos_rel_attn_bwd_bank": [c_i] * 5 + [c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_p, c_p],  # ... nchunks, d_bank, ld, heavy, stream
     "gtos_ln_residual_fwd": [c_i, c_i, c_i, c_p, c_p, c_f, c_u64, c_p, c_p, c_f, c_p, c_p, c_p, c_p],
     "gtos_ln_residual_bwd": [c_i, c_i, c_i, c_p, c_p, c_p, c_f, c_u64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "gtos_ln_residual_fwd2": [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_u64, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p],
+    "gtos_ln_residual_bwd2": [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_f, c_u64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "gtos_relu_dropout_bwd": [c_i, c_l, c_p, c_p, c_f, c_p],
     "gtos_colsum": [c_i, c_i, c_i, c_l, c_p, c_p, c_p],
     "gtos_gru_cell_fwd": [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_l, c_p, c_p, c_f, c_u64, c_l, c_p],

@@ -892,6 +892,190 @@ __global__ __launch_bounds__(512) void gemm256p_nt_kernel(GemmArgs a) {
     }
 }
 
+// ---- gemm_p2_nt_kernel (round 4): the forward shape with a SHORT reduction (K = 256 .. 1024: relation projection, GRU gate tables,
+//      RelationEncoder output projection), where a tile's output write costs as much as its k loop.  Measured picture behind it
+//      (tools/probes/membw_probe.hip): the chip streams reads at 6.0-6.3 TB/s but WRITES at 4.4 TB/s, so [R,1024] bf16 = 0.89 GB of
+//      output is 0.20 ms of HBM time against 0.19 ms of MFMA time at the peak -- the two must overlap, and inside one workgroup they
+//      cannot (the accumulators are the data being stored).  So: TWO independent 4-wave workgroups per CU (one wave of each per SIMD),
+//      each on its own 128 x 256 tile with its own three-stage LDS ring (32-k stages, 72 KB); they drift apart by themselves, and
+//      while one drains its tile through the store queue the other has the matrix pipes.  The single-stage 128x128 kernel above
+//      has four co-resident workgroups but no prefetch of its own (its k loop waits for every tile), the 256x256 ping-pong kernel
+//      has the prefetch but one workgroup per CU (nothing runs beside its epilogue): 0.55 / 0.63 ms at the relation projection.
+//      Stages are separate static arrays and every wait is explicit, as in gemm256p_nt_kernel (hipcc would otherwise drain all
+//      LDS-DMA in front of each ds_read).  Step s of a wave: wait for its own pieces of stage s (vmcnt(6): the 6 pieces of stage
+//      s+1 stay in flight), barrier (stage s complete; every wave is past its reads of stage s-1), issue stage s+2 into the slot of
+//      stage s-1, 12 fragment reads, 32 MFMAs.  Rows past M / N re-read the last valid row (never stored); stages past K re-read the
+//      last stage (never multiplied).  K % 32 == 0.
+constexpr int P2_BM = 128, P2_BN = 256, P2_A = P2_BM * ROW3, P2_ST = (P2_BM + P2_BN) * ROW3;   // 8 KB + 16 KB per stage
+const bool g_use_p2 = !(getenv("GTOS_GEMM_P2") && getenv("GTOS_GEMM_P2")[0] == '0');
+const int g_p2_maxk = getenv("GTOS_GEMM_P2_MAXK") ? atoi(getenv("GTOS_GEMM_P2_MAXK")) : 1023;
+
+__global__ __launch_bounds__(256, 2) void gemm_p2_nt_kernel(GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) char st0[P2_ST];
+    __shared__ __attribute__((aligned(16))) char st1[P2_ST];
+    __shared__ __attribute__((aligned(16))) char st2[P2_ST];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 128;
+    const int nN = (a.N + P2_BN - 1) / P2_BN;
+    const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
+    const int m0 = ((sq / nN) * 8 + xcd) * P2_BM, n0 = (sq % nN) * P2_BN;       // an XCD walks the N tiles of its M panels: A rows stay in its L2
+    if (m0 >= a.M) return;
+    const char* Ab = reinterpret_cast<const char*>(static_cast<const bf16_t*>(a.A) + (int64_t)m0 * a.lda);
+    const char* Bb = reinterpret_cast<const char*>(static_cast<const bf16_t*>(a.B) + (int64_t)n0 * a.ldb);
+    const int amax = a.M - 1 - m0, bmax = a.N - 1 - n0;
+    const uint32_t lda2 = (uint32_t)a.lda * 2u, ldb2 = (uint32_t)a.ldb * 2u;
+    const int nk = a.K / 32;
+    // DMA: a wave instruction fills 1 KB = 16 rows x 64 B; lane l -> row l >> 2, physical chunk l & 3.  Wave w owns 16-row blocks
+    // w and w + 4 of A (8 blocks) and w, w + 4, w + 8, w + 12 of B (16 blocks).
+    const int drow = lane >> 2;
+    const uint32_t dchunk = (uint32_t)(((lane & 3) ^ ((-(lane >> 4)) & 3)) << 4);
+    uint32_t aoff[2], boff[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) aoff[i] = (uint32_t)min((wave + 4 * i) * 16 + drow, amax) * lda2 + dchunk;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) boff[i] = (uint32_t)min((wave + 4 * i) * 16 + drow, bmax) * ldb2 + dchunk;
+    const int foff = fr * ROW3 + ((fq ^ ((-(fr >> 2)) & 3)) << 4);
+
+    f32x4_t acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    bf16x8_t fa[4], fb[8];
+
+#define GTOS_DMA1(src, dst)                                                                                                   \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),                                    \
+                                     (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+#define GTOS_P2_DMA(stage, s_)                                                                                                \
+    {                                                                                                                         \
+        const int kb_ = min((s_), nk - 1) * 64;            /* byte offset of the stage's k range; past the end: dummy re-read */ \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) GTOS_DMA1(Ab + kb_ + aoff[i_], (stage) + (wave + 4 * i_) * 1024);            \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) GTOS_DMA1(Bb + kb_ + boff[i_], (stage) + P2_A + (wave + 4 * i_) * 1024);     \
+    }
+#define GTOS_P2_STEP(slot_s, slot_d, s_)                                                                                      \
+    {                                                                                                                         \
+        GTOS_VMCNT(6);                                     /* own pieces of stage s_ (stage s_+1's six stay in flight) */      \
+        __builtin_amdgcn_s_barrier();                      /* everybody's; and every wave has read its fragments of s_-1 */   \
+        GTOS_P2_DMA(slot_d, (s_) + 2);                                                                                        \
+        _Pragma("unroll") for (int t = 0; t < 8; ++t)                                                                         \
+            fb[t] = *reinterpret_cast<const bf16x8_t*>((slot_s) + P2_A + (wn + t * 16) * ROW3 + foff);                        \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                                         \
+            fa[t] = *reinterpret_cast<const bf16x8_t*>((slot_s) + (wm + t * 16) * ROW3 + foff);                               \
+        __builtin_amdgcn_s_waitcnt(0xc07f);                /* lgkmcnt(0): fragments in registers */                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                                    \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                                      \
+            _Pragma("unroll") for (int nt = 0; nt < 8; ++nt)                                                                  \
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    }
+
+    GTOS_P2_DMA(st0, 0);
+    GTOS_P2_DMA(st1, 1);
+    int s = 0;
+    for (; s + 3 <= nk; s += 3) {                          // whole triples: one path through the body for the wait-count pass
+        GTOS_P2_STEP(st0, st2, s);
+        GTOS_P2_STEP(st1, st0, s + 1);
+        GTOS_P2_STEP(st2, st1, s + 2);
+    }
+    if (s < nk) {
+        GTOS_P2_STEP(st0, st2, s);
+        if (s + 1 < nk) GTOS_P2_STEP(st1, st0, s + 1);
+    }
+    GTOS_VMCNT(0);                                         // the dummy prefetches of the last steps
+    __syncthreads();                                       // every wave is done with the stages: st0 becomes the output staging
+#undef GTOS_P2_STEP
+#undef GTOS_P2_DMA
+#undef GTOS_DMA1
+
+    // ---- epilogue (bf16 out): 16 rows x 128 columns of the wave tile at a time through LDS (wave-private rows), 256-byte row segments out
+    bf16_t* C = static_cast<bf16_t*>(a.C);
+    const float keep_scale = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
+    constexpr int CP = 128 * 2 + 16;                       // bytes per staged row
+    char* cs = st0 + wave * 16 * CP;
+    const bool plain = !a.bias && !a.relu && !(a.p_drop > 0.f);
+    if (plain && !a.accumulate && m0 + P2_BM <= a.M && n0 + P2_BN <= a.N) {
+        // interior tile of a plain product (the relation projections, the gate tables): no per-element conditions, addresses once
+        char* wr = cs + fr * CP + fq * 8;
+        const char* rd = cs + (lane >> 4) * CP + (lane & 15) * 16;
+        bf16_t* cp0 = C + (int64_t)(m0 + wm + (lane >> 4)) * a.ldc + n0 + wn + (lane & 15) * 8;
+        const int64_t ld4 = 4 * a.ldc;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) {
+                const f32x4_t v = acc[mt][nt];
+                *reinterpret_cast<uint2*>(wr + nt * 32) = make_uint2(pack_bf(v[0], v[1]), pack_bf(v[2], v[3]));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0)
+            const U128 v0 = *reinterpret_cast<const U128*>(rd), v1 = *reinterpret_cast<const U128*>(rd + 4 * CP);
+            const U128 v2 = *reinterpret_cast<const U128*>(rd + 8 * CP), v3 = *reinterpret_cast<const U128*>(rd + 12 * CP);
+            __builtin_amdgcn_s_waitcnt(0xc07f);            // read back before the next row block overwrites the staging rows
+            *reinterpret_cast<U128*>(cp0 + (mt * 4 + 0) * ld4) = v0;
+            *reinterpret_cast<U128*>(cp0 + (mt * 4 + 1) * ld4) = v1;
+            *reinterpret_cast<U128*>(cp0 + (mt * 4 + 2) * ld4) = v2;
+            *reinterpret_cast<U128*>(cp0 + (mt * 4 + 3) * ld4) = v3;
+        }
+        return;
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) {
+            float v[4] = {acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]};
+            if (!plain) {
+                const int m = m0 + wm + mt * 16 + fr, n = n0 + wn + nt * 16 + fq * 4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (a.bias && n + i < a.N) v[i] += a.bias[n + i];
+                    if (a.relu) v[i] = fmaxf(v[i], 0.f);
+                    if (a.p_drop > 0.f)
+                        v[i] = drop_keep(a.seed, (uint64_t)m * (uint64_t)a.N + (uint64_t)(n + i), a.p_drop) ? v[i] * keep_scale : 0.f;
+                }
+            }
+            *reinterpret_cast<uint2*>(cs + fr * CP + (nt * 16 + fq * 4) * 2) = make_uint2(pack_bf(v[0], v[1]), pack_bf(v[2], v[3]));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0)
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int row = pass * 4 + (lane >> 4), col = (lane & 15) * 8;
+            const int m = m0 + wm + mt * 16 + row, n = n0 + wn + col;
+            if (m >= a.M || n >= a.N) continue;
+            uint4 val = *reinterpret_cast<const uint4*>(cs + row * CP + col * 2);
+            bf16_t* cp = C + (int64_t)m * a.ldc + n;
+            if (n + 8 <= a.N) {
+                if (a.accumulate) {
+                    const uint4 old = *reinterpret_cast<const uint4*>(cp);
+                    val = make_uint4(pack_bf(lo_bf(val.x) + lo_bf(old.x), hi_bf(val.x) + hi_bf(old.x)),
+                                     pack_bf(lo_bf(val.y) + lo_bf(old.y), hi_bf(val.y) + hi_bf(old.y)),
+                                     pack_bf(lo_bf(val.z) + lo_bf(old.z), hi_bf(val.z) + hi_bf(old.z)),
+                                     pack_bf(lo_bf(val.w) + lo_bf(old.w), hi_bf(val.w) + hi_bf(old.w)));
+                }
+                *reinterpret_cast<uint4*>(cp) = val;
+            } else {
+                const bf16_t* e = reinterpret_cast<const bf16_t*>(cs + row * CP + col * 2);
+                for (int i = 0; i < 8 && n + i < a.N; ++i) {
+                    float o = bf2f(e[i]);
+                    if (a.accumulate) o += bf2f(cp[i]);
+                    cp[i] = f2bf(o);
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                // the reads are done before the next row block overwrites the staging rows
+    }
+}
+
+int launch_p2(const GemmArgs& a, hipStream_t s) {
+    const long long nMt = (a.M + P2_BM - 1) / P2_BM, nNt = (a.N + P2_BN - 1) / P2_BN;
+    const long long nblk = ((nMt + 7) / 8) * 8 * nNt;
+    if (nblk > 0x7fffffffLL) return -6;
+    hipLaunchKernelGGL(gemm_p2_nt_kernel, dim3((unsigned)nblk), dim3(256), 0, s, a);
+    GTOS_CHECK_LAUNCH();
+    return 0;
+}
+
 int launch256p(const GemmArgs& a, hipStream_t s) {
     const long long nMt = (a.M + BM2 - 1) / BM2, nNt = (a.N + BN2 - 1) / BN2;
     const long long nblk = ((nMt + 7) / 8) * 8 * nNt;
@@ -1127,6 +1311,10 @@ extern "C" int gtos_gemm(int in_dtype, int out_dtype, int transA, int transB, in
             lda < (1 << 22) && ldb < (1 << 22) &&
             ((t256 >= 512 && K >= g_min_kpipe) || (t256 <= g_pipe_small_max && K >= 256 && M >= 256)))
             return launch256p(a, s);
+        // short reduction, many tiles: two pipelined workgroups per CU, one's output write beside the other's k loop
+        if (g_use_p2 && !transA && transB && a.vecA && a.vecB && a.vecC && splitk == 1 && N >= 256 && K % 32 == 0 && K >= 128 && K <= g_p2_maxk &&
+            lda < (1 << 22) && ldb < (1 << 22) && ((long long)(M + P2_BM - 1) / P2_BM) * ((N + P2_BN - 1) / P2_BN) >= 1024)
+            return launch_p2(a, s);
         if (g_use256 && !transA && transB && a.vecA && a.vecB && a.vecC && splitk == 1 && t256 >= 1024 && N >= 256 && K >= g_min_k256)
             return launch256(a, s);
         return launch<bf16_t, bf16_t>(a, transA, transB, s);

@@ -11,10 +11,13 @@ namespace {
 // One wave per row; d % 8 == 0, d <= 1024 (each lane holds up to 2 chunks of 8 channels).
 constexpr int LN_MAXC = 2;
 
-template <typename T>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int d, const T* __restrict__ x, const T* __restrict__ r,
+// Mixed storage types (round 4): TX = residual stream (x, y, dx), TR = sub-layer output (r, dr), so that bf16 activations can
+// ride on an fp32 residual stream (x [rows,d] is a few MB per layer: free) -- y2 is an optional bf16 copy of y for the next GEMM
+// operand, dy2 its gradient (added to dy in registers).  All arithmetic in fp32 as before.
+template <typename TX, typename TR, typename TY>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int d, const TX* __restrict__ x, const TR* __restrict__ r,
                                                      float p_drop, uint64_t seed, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, float eps, T* __restrict__ y,
+                                                     const float* __restrict__ beta, float eps, TY* __restrict__ y, bf16_t* __restrict__ y2,
                                                      float* __restrict__ mean, float* __restrict__ rstd) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -28,10 +31,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int d, const T* _
 #pragma unroll
         for (int e = 0; e < 8; ++e) z[cI][e] = 0.f;
         if (c < d) {
-            Vec8<T>::load(x + (int64_t)row * d + c, z[cI]);
+            Vec8<TX>::load(x + (int64_t)row * d + c, z[cI]);
             if (r) {
                 float rv[8];
-                Vec8<T>::load(r + (int64_t)row * d + c, rv);
+                Vec8<TR>::load(r + (int64_t)row * d + c, rv);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float t = rv[e];
@@ -63,19 +66,21 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int d, const T* _
             Vec8<float>::load(beta + c, bt);
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = fmaf((z[cI][e] - mu) * rs, gm[e], bt[e]);
-            Vec8<T>::store(y + (int64_t)row * d + c, o);
+            Vec8<TY>::store(y + (int64_t)row * d + c, o);
+            if (y2) Vec8<bf16_t>::store(y2 + (int64_t)row * d + c, o);
         }
     }
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
-// backward: dz = rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dy*gamma; dx = dz; dr = dz * dropmask.
+// backward: dz = rstd * (g - mean(g) - xhat * mean(g*xhat)), g = (dy + dy2)*gamma; dx = dz; dr = dz * dropmask.
 // Each wave walks rows grid-stride and keeps dgamma/dbeta partials in registers -> one atomicAdd per lane-channel.
-template <typename T>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int d, const T* __restrict__ dy, const T* __restrict__ x,
-                                                     const T* __restrict__ r, float p_drop, uint64_t seed,
+template <typename TX, typename TR, typename TY>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int d, const TY* __restrict__ dy, const bf16_t* __restrict__ dy2,
+                                                     const TX* __restrict__ x,
+                                                     const TR* __restrict__ r, float p_drop, uint64_t seed,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                     const float* __restrict__ rstd, T* __restrict__ dx, T* __restrict__ dr,
+                                                     const float* __restrict__ rstd, TX* __restrict__ dx, TR* __restrict__ dr,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta) {
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
@@ -99,11 +104,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int d, const T* _
             for (int e = 0; e < 8; ++e) { g[cI][e] = 0.f; xh[cI][e] = 0.f; }
             if (c < d) {
                 float z[8], dyv[8];
-                Vec8<T>::load(x + (int64_t)row * d + c, z);
-                Vec8<T>::load(dy + (int64_t)row * d + c, dyv);
+                Vec8<TX>::load(x + (int64_t)row * d + c, z);
+                if (dy) Vec8<TY>::load(dy + (int64_t)row * d + c, dyv);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) dyv[e] = 0.f;
+                }
+                if (dy2) {
+                    float t2[8];
+                    Vec8<bf16_t>::load(dy2 + (int64_t)row * d + c, t2);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) dyv[e] += t2[e];
+                }
                 if (r) {
                     float rv[8];
-                    Vec8<T>::load(r + (int64_t)row * d + c, rv);
+                    Vec8<TR>::load(r + (int64_t)row * d + c, rv);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         float t = rv[e];
@@ -128,12 +143,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int d, const T* _
                 float dz[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) dz[e] = rs * (g[cI][e] - s1 - xh[cI][e] * s2);
-                Vec8<T>::store(dx + (int64_t)row * d + c, dz);
+                if (dx) Vec8<TX>::store(dx + (int64_t)row * d + c, dz);
                 if (dr) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
                         if (p_drop > 0.f) dz[e] = drop_keep(seed, (uint64_t)row * d + c + e, p_drop) ? dz[e] * ks : 0.f;
-                    Vec8<T>::store(dr + (int64_t)row * d + c, dz);
+                    Vec8<TR>::store(dr + (int64_t)row * d + c, dz);
                 }
             }
         }
@@ -838,35 +853,67 @@ inline int grid_for(int64_t work, int block) { int64_t g = (work + block - 1) / 
 
 }  // namespace
 
+// dtype triple -> kernel instance.  Supported: all three equal (fp32 parity mode / plain bf16), and the fp32 residual stream of bf16
+// activations: x fp32 or bf16, r bf16 (or none), y fp32.
+#define GTOS_LN_COMBOS(X)              \
+    X(GTOS_F32, GTOS_F32, GTOS_F32, float, float, float)        \
+    X(GTOS_BF16, GTOS_BF16, GTOS_BF16, bf16_t, bf16_t, bf16_t)  \
+    X(GTOS_F32, GTOS_BF16, GTOS_F32, float, bf16_t, float)      \
+    X(GTOS_BF16, GTOS_BF16, GTOS_F32, bf16_t, bf16_t, float)
+
+extern "C" int gtos_ln_residual_fwd2(int x_dtype, int r_dtype, int y_dtype, int rows, int d, const void* x, const void* r, float p_drop,
+                                     uint64_t seed, const float* gamma, const float* beta, float eps, void* y, void* y2_bf16,
+                                     float* mean, float* rstd, void* stream) {
+    if (d % 8 || d > 512 * LN_MAXC) return -20;
+    if (rows <= 0) return 0;
+    if ((uintptr_t)x % 16 || (uintptr_t)r % 16 || (uintptr_t)y % 16 || (uintptr_t)y2_bf16 % 16) return -25;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    dim3 grid((rows + 3) / 4), block(256);
+#define X(dx_, dr_, dy_, TX, TR, TY)                                                                                                   \
+    if (x_dtype == dx_ && r_dtype == dr_ && y_dtype == dy_) {                                                                          \
+        hipLaunchKernelGGL((ln_fwd_kernel<TX, TR, TY>), grid, block, 0, s, rows, d, (const TX*)x, (const TR*)r, p_drop, seed, gamma,   \
+                           beta, eps, (TY*)y, (bf16_t*)y2_bf16, mean, rstd);                                                           \
+        GTOS_CHECK_LAUNCH();                                                                                                           \
+        return 0;                                                                                                                      \
+    }
+    GTOS_LN_COMBOS(X)
+#undef X
+    return -21;
+}
+
 extern "C" int gtos_ln_residual_fwd(int dtype, int rows, int d, const void* x, const void* r, float p_drop, uint64_t seed,
                                     const float* gamma, const float* beta, float eps, void* y, float* mean, float* rstd,
                                     void* stream) {
+    return gtos_ln_residual_fwd2(dtype, dtype, dtype, rows, d, x, r, p_drop, seed, gamma, beta, eps, y, nullptr, mean, rstd, stream);
+}
+
+extern "C" int gtos_ln_residual_bwd2(int x_dtype, int r_dtype, int y_dtype, int rows, int d, const void* dy, const void* dy2_bf16,
+                                     const void* x, const void* r, float p_drop, uint64_t seed, const float* gamma, const float* mean,
+                                     const float* rstd, void* dx, void* dr, float* dgamma, float* dbeta, void* stream) {
     if (d % 8 || d > 512 * LN_MAXC) return -20;
     if (rows <= 0) return 0;
+    if (!dy && !dy2_bf16) return -23;
+    if ((uintptr_t)x % 16 || (uintptr_t)r % 16 || (uintptr_t)dy % 16 || (uintptr_t)dy2_bf16 % 16 || (uintptr_t)dx % 16 || (uintptr_t)dr % 16) return -25;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    dim3 grid((rows + 3) / 4), block(256);
-    if (dtype == GTOS_BF16)
-        hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, block, 0, s, rows, d, (const bf16_t*)x, (const bf16_t*)r, p_drop, seed, gamma, beta, eps, (bf16_t*)y, mean, rstd);
-    else
-        hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, block, 0, s, rows, d, (const float*)x, (const float*)r, p_drop, seed, gamma, beta, eps, (float*)y, mean, rstd);
-    GTOS_CHECK_LAUNCH();
-    return 0;
+    int nb = (rows + 31) / 32; if (nb > 256) nb = 256; if (nb < 1) nb = 1;   // >= 8 rows per wave: few atomics
+    dim3 grid(nb), block(256);
+#define X(dx_, dr_, dy_, TX, TR, TY)                                                                                                   \
+    if (x_dtype == dx_ && r_dtype == dr_ && y_dtype == dy_) {                                                                          \
+        hipLaunchKernelGGL((ln_bwd_kernel<TX, TR, TY>), grid, block, 0, s, rows, d, (const TY*)dy, (const bf16_t*)dy2_bf16,            \
+                           (const TX*)x, (const TR*)r, p_drop, seed, gamma, mean, rstd, (TX*)dx, (TR*)dr, dgamma, dbeta);              \
+        GTOS_CHECK_LAUNCH();                                                                                                           \
+        return 0;                                                                                                                      \
+    }
+    GTOS_LN_COMBOS(X)
+#undef X
+    return -21;
 }
 
 extern "C" int gtos_ln_residual_bwd(int dtype, int rows, int d, const void* dy, const void* x, const void* r, float p_drop,
                                     uint64_t seed, const float* gamma, const float* mean, const float* rstd,
                                     void* dx, void* dr, float* dgamma, float* dbeta, void* stream) {
-    if (d % 8 || d > 512 * LN_MAXC) return -20;
-    if (rows <= 0) return 0;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    int nb = (rows + 31) / 32; if (nb > 256) nb = 256; if (nb < 1) nb = 1;   // >= 8 rows per wave: few atomics
-    dim3 grid(nb), block(256);
-    if (dtype == GTOS_BF16)
-        hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, grid, block, 0, s, rows, d, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)r, p_drop, seed, gamma, mean, rstd, (bf16_t*)dx, (bf16_t*)dr, dgamma, dbeta);
-    else
-        hipLaunchKernelGGL(ln_bwd_kernel<float>, grid, block, 0, s, rows, d, (const float*)dy, (const float*)x, (const float*)r, p_drop, seed, gamma, mean, rstd, (float*)dx, (float*)dr, dgamma, dbeta);
-    GTOS_CHECK_LAUNCH();
-    return 0;
+    return gtos_ln_residual_bwd2(dtype, dtype, dtype, rows, d, dy, nullptr, x, r, p_drop, seed, gamma, mean, rstd, dx, dr, dgamma, dbeta,
+                                 stream);
 }
 
 extern "C" int gtos_relu_dropout_bwd(int dtype, int64_t n, void* dh, const void* h, float p_drop, void* stream) {
@@ -1114,4 +1161,4 @@ extern "C" int gtos_transpose_batch_bf16(int n_mat, const int64_t* desc, const i
     return 0;
 }
 
-extern "C" int gtos_abi_version(void) { return 16; }
+extern "C" int gtos_abi_version(void) { return 17; }

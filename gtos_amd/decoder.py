@@ -40,6 +40,8 @@ class TokenGenerator(nn.Module):
     def forward(self, outs, graph_state, graph_padding_mask, copy_seq, target=None, work=False, align_kv=None,
                 tot_ext=None):
         p = self.dropout if self.training else 0.0
+        cd = self.alignment_layer.compute_dtype
+        outs_s, outs = ops.split_stream(outs, cd)      # (residual stream -- fp32 in bf16 mode --, GEMM operand)
         if align_kv is not None:       # incremental decoding: the graph states' K/V projection is cached
             x, alignment_weight = self.alignment_layer.attend_cached(outs, align_kv, key_padding_mask=graph_padding_mask,
                                                                      need_weights=True)
@@ -47,7 +49,7 @@ class TokenGenerator(nn.Module):
             x, alignment_weight = self.alignment_layer(outs, graph_state, graph_state,
                                                        key_padding_mask=graph_padding_mask, need_weights=True)
         ln = self.alignment_layer_norm
-        outs = ops.layer_norm_residual(outs.to(x.dtype), x, ln.weight, ln.bias, p, ln.eps)
+        outs = ops.layer_norm_stream(outs_s, x, ln.weight, ln.bias, p, ln.eps, cd)[1]
         hidden = torch.tanh(ops.linear(outs, self.transfer.weight, self.transfer.bias))
         hidden = F.dropout(hidden, p=self.dropout, training=self.training)
         logits = _padded_linear(hidden, self.generator)              # [T,B,V] vocabulary scores

@@ -92,6 +92,8 @@ class Generator(nn.Module):
             relation = ops.relation_gather_mean(bank.detach(), inp['relation'], zero_row0=inp['relation'].dim() == 4)
         with ops._Timed("graph_encoder_fwd"):
             concept_repr = self.graph_encoder(concept_repr, relation, self_padding_mask=concept_mask)
+        # (bf16 mode: the encoder returns its fp32 residual stream carrying the bf16 twin; everything downstream is a GEMM operand)
+        concept_repr = ops.split_stream(concept_repr, self.compute_dtype)[1]
         probe = torch.tanh(ops.linear(concept_repr[:1], self.probe_generator.weight, self.probe_generator.bias))
         return concept_repr[1:], concept_mask[1:], probe
 
@@ -118,6 +120,7 @@ class Generator(nn.Module):
             token_repr, concept_repr, probe = gs.boundary(1, token_repr, concept_repr, probe)
         token_repr = self.snt_encoder(token_repr, self_padding_mask=token_mask, self_attn_mask=attn_mask,
                                       external_memories=concept_repr, external_padding_mask=concept_mask)
+        token_repr = ops.split_stream(token_repr, self.compute_dtype)[1]
         probe = probe.expand_as(token_repr)
         if gs is not None:          # downstream: the decoder only
             probe, concept_repr, token_repr = gs.boundary(0, probe, concept_repr, token_repr)

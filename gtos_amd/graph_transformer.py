@@ -94,16 +94,20 @@ class GraphTransformerLayer(nn.Module):
 
     def forward(self, x, relation, kv=None, self_padding_mask=None, self_attn_mask=None, need_weights=False):
         p = self.dropout if self.training else 0.0
-        x = x.to(self.self_attn.compute_dtype)
+        cd = self.self_attn.compute_dtype
+        # xs: the residual stream (fp32 also in bf16 mode, ops.FP32_STREAM), x: the same values in the compute dtype for the GEMMs
+        xs, x = ops.split_stream(x, cd)
         src = x if kv is None else kv
         a, self_attn = self.self_attn(query=x, key=src, value=src, relation=relation,
                                       key_padding_mask=self_padding_mask, attn_mask=self_attn_mask,
                                       need_weights=need_weights)
-        x = ops.layer_norm_residual(x, a, self.attn_layer_norm.weight, self.attn_layer_norm.bias, p, self.attn_layer_norm.eps)
+        ln = self.attn_layer_norm
+        xs, x = ops.layer_norm_stream(xs, a, ln.weight, ln.bias, p, ln.eps, cd)
         h = ops.linear(x, self.fc1.weight, self.fc1.bias, relu=True, p_drop=p)
         f = ops.linear(h, self.fc2.weight, self.fc2.bias)
-        x = ops.layer_norm_residual(x, f, self.ff_layer_norm.weight, self.ff_layer_norm.bias, p, self.ff_layer_norm.eps)
-        return x, self_attn
+        ln = self.ff_layer_norm
+        xs, x = ops.layer_norm_stream(xs, f, ln.weight, ln.bias, p, ln.eps, cd)
+        return ops.join_stream(xs, x), self_attn
 
 
 class GraphTransformer(nn.Module):

@@ -407,46 +407,106 @@ def linear(x, weight, bias=None, relu=False, p_drop=0.0, rows=None, group=None):
 
 
 class LayerNormResidualFn(torch.autograd.Function):
-    """y = LayerNorm(x + dropout(r)) (generator/graph_transformer.py:57-58,64-65)."""
+    """y = LayerNorm(x + dropout(r)) (generator/graph_transformer.py:57-58,64-65).
+
+    ``out32``: bf16 activations on an fp32 residual stream -- x may be fp32 or bf16, r is bf16, and the function returns the pair
+    (y fp32 = the next residual / the layer's output, y16 = its bf16 copy, the next projection's MFMA operand); backward adds the
+    two incoming gradients inside the kernel.  Without it: one output in x's dtype, as before."""
 
     @staticmethod
-    def forward(ctx, x, r, gamma, beta, p_drop, eps):
+    def forward(ctx, x, r, gamma, beta, p_drop, eps, out32):
         d = x.shape[-1]
         x = x.contiguous()
         r = r.contiguous() if r is not None else None
         rows = x.numel() // d
-        y = torch.empty_like(x)
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
         seed = next_seed() if (p_drop > 0 and r is not None) else 0
-        call("gtos_ln_residual_fwd", dt(x), rows, d, ptr(x), ptr(r), float(p_drop), seed, ptr(gamma), ptr(beta),
-             float(eps), ptr(y), ptr(mean), ptr(rstd), stream())
+        ctx.set_materialize_grads(False)
+        if out32:
+            y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+            y16 = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+            rdt = dt(r) if r is not None else _lib.dt(y16)
+            call("gtos_ln_residual_fwd2", dt(x), rdt, dt(y), rows, d, ptr(x), ptr(r), float(p_drop), seed, ptr(gamma), ptr(beta),
+                 float(eps), ptr(y), ptr(y16), ptr(mean), ptr(rstd), stream())
+        else:
+            y, y16 = torch.empty_like(x), None
+            call("gtos_ln_residual_fwd", dt(x), rows, d, ptr(x), ptr(r), float(p_drop), seed, ptr(gamma), ptr(beta),
+                 float(eps), ptr(y), ptr(mean), ptr(rstd), stream())
         ctx.save_for_backward(x, r, mean, rstd)
-        ctx.cfg = (p_drop, seed, gamma, beta)
-        return y
+        ctx.cfg = (p_drop, seed, gamma, beta, out32)
+        return (y, y16) if out32 else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dy16=None):
         x, r, mean, rstd = ctx.saved_tensors
-        p_drop, seed, gamma, beta = ctx.cfg
+        p_drop, seed, gamma, beta, out32 = ctx.cfg
         d = x.shape[-1]
         rows = x.numel() // d
-        dy = dy.contiguous()
-        dx = torch.empty_like(x)
+        if dy is None and dy16 is None:
+            return None, None, None, None, None, None, None
         need_dr = r is not None and ctx.needs_input_grad[1]
-        dr = torch.empty_like(x) if (need_dr and p_drop > 0) else None
         tg, tb = _grad_target(gamma), _grad_target(beta)
         dg = tg if tg is not None else torch.zeros(d, dtype=torch.float32, device=x.device)
         db = tb if tb is not None else torch.zeros(d, dtype=torch.float32, device=x.device)
-        call("gtos_ln_residual_bwd", dt(x), rows, d, ptr(dy), ptr(x), ptr(r), float(p_drop), seed, ptr(gamma),
-             ptr(mean), ptr(rstd), ptr(dx), ptr(dr), ptr(dg), ptr(db), stream())
-        if need_dr and dr is None:
-            dr = dx
-        return dx, dr, (None if tg is not None else dg), (None if tb is not None else db), None, None
+        dx = torch.empty_like(x)
+        if out32:
+            dy = dy.contiguous().float() if dy is not None else None
+            dy16 = dy16.contiguous() if dy16 is not None else None
+            # the gradient of the sub-layer branch equals dx unless dropout masks it; it leaves in r's dtype (bf16), so it is always
+            # its own buffer when the stream is fp32
+            dr = torch.empty_like(r) if need_dr else None
+            rdt = dt(r) if r is not None else 1
+            call("gtos_ln_residual_bwd2", dt(x), rdt, 0, rows, d, ptr(dy), ptr(dy16), ptr(x), ptr(r), float(p_drop), seed, ptr(gamma),
+                 ptr(mean), ptr(rstd), ptr(dx), ptr(dr), ptr(dg), ptr(db), stream())
+        else:
+            dy = dy.contiguous()
+            dr = torch.empty_like(x) if (need_dr and p_drop > 0) else None
+            call("gtos_ln_residual_bwd", dt(x), rows, d, ptr(dy), ptr(x), ptr(r), float(p_drop), seed, ptr(gamma),
+                 ptr(mean), ptr(rstd), ptr(dx), ptr(dr), ptr(dg), ptr(db), stream())
+            if need_dr and dr is None:
+                dr = dx
+        return dx, dr, (None if tg is not None else dg), (None if tb is not None else db), None, None, None
 
 
 def layer_norm_residual(x, r, gamma, beta, p_drop=0.0, eps=1e-5):
-    return LayerNormResidualFn.apply(x, r, gamma, beta, float(p_drop), eps)
+    return LayerNormResidualFn.apply(x, r, gamma, beta, float(p_drop), eps, False)
+
+
+# bf16 activations on an fp32 residual stream (round 4).  The reference's post-LN layers keep x = LayerNorm(x + sublayer(x)) in fp32;
+# storing that stream in bf16 costs one rounding of an |x| <= 4 value per layer (1.6e-2 absolute) that the next layer's residual add
+# carries on -- the measured bf16 output error of the graph encoder (8e-3 .. 1.3e-2 relative) came from there, not from the bf16
+# MFMA operands.  The stream is [rows, d]: 6.6 MB per layer at C2 next to a 0.9 GB relation stream.  GTOS_FP32_STREAM=0: bf16 stream.
+FP32_STREAM = os.environ.get("GTOS_FP32_STREAM", "1") != "0"
+
+
+def split_stream(x, cd):
+    """(residual-stream tensor, GEMM operand in the compute dtype ``cd``) of a layer input: in fp32 mode both are x; in bf16 mode the
+    operand is the bf16 twin an earlier ``layer_norm_stream`` attached to its fp32 output, or a cast of x."""
+    if cd == torch.float32:
+        x = x if x.dtype == cd else x.to(cd)
+        return x, x
+    twin = getattr(x, "_gtos_twin", None)
+    if twin is not None and twin.dtype == cd and twin.shape == x.shape:
+        return (x if FP32_STREAM else twin), twin
+    x16 = x if x.dtype == cd else x.to(cd)
+    return (x if (FP32_STREAM and x.dtype == torch.float32) else x16), x16
+
+
+def join_stream(x32, x16):
+    """What a layer hands on: the stream tensor, carrying its compute-dtype twin so that the next consumer needs no cast."""
+    if x32 is not x16:
+        x32._gtos_twin = x16
+    return x32
+
+
+def layer_norm_stream(xs, r, gamma, beta, p_drop, eps, cd):
+    """LayerNorm(xs + dropout(r)) -> (stream tensor, compute-dtype operand): the fp32 pair in bf16 mode with FP32_STREAM, else one
+    tensor in ``cd`` returned twice."""
+    if cd == torch.bfloat16 and FP32_STREAM:
+        return LayerNormResidualFn.apply(xs, r, gamma, beta, float(p_drop), eps, True)
+    y = LayerNormResidualFn.apply(xs if xs.dtype == cd else xs.to(cd), r, gamma, beta, float(p_drop), eps, False)
+    return y, y
 
 
 def check_attention_shape(embed_dim, num_heads):

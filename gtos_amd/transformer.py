@@ -104,24 +104,26 @@ class TransformerLayer(nn.Module):
     def forward(self, x, kv=None, self_padding_mask=None, self_attn_mask=None,
                 external_memories=None, external_padding_mask=None, need_weights=False):
         p = self.dropout if self.training else 0.0
-        x = x.to(self.self_attn.compute_dtype)
+        cd = self.self_attn.compute_dtype
+        # xs: the residual stream (fp32 also in bf16 mode, ops.FP32_STREAM), x: the same values in the compute dtype for the GEMMs
+        xs, x = ops.split_stream(x, cd)
         src = x if kv is None else kv
         a, self_attn = self.self_attn(query=x, key=src, value=src, key_padding_mask=self_padding_mask,
                                       attn_mask=self_attn_mask, need_weights=need_weights)
         ln = self.attn_layer_norm
-        x = ops.layer_norm_residual(x, a, ln.weight, ln.bias, p, ln.eps)
+        xs, x = ops.layer_norm_stream(xs, a, ln.weight, ln.bias, p, ln.eps, cd)
         if self.with_external:
             a, external_attn = self.external_attn(query=x, key=external_memories, value=external_memories,
                                                   key_padding_mask=external_padding_mask, need_weights=need_weights)
             ln = self.external_layer_norm
-            x = ops.layer_norm_residual(x, a, ln.weight, ln.bias, p, ln.eps)
+            xs, x = ops.layer_norm_stream(xs, a, ln.weight, ln.bias, p, ln.eps, cd)
         else:
             external_attn = None
         h = ops.linear(x, self.fc1.weight, self.fc1.bias, relu=True, p_drop=p)
         f = ops.linear(h, self.fc2.weight, self.fc2.bias)
         ln = self.ff_layer_norm
-        x = ops.layer_norm_residual(x, f, ln.weight, ln.bias, p, ln.eps)
-        return x, self_attn, external_attn
+        xs, x = ops.layer_norm_stream(xs, f, ln.weight, ln.bias, p, ln.eps, cd)
+        return ops.join_stream(xs, x), self_attn, external_attn
 
 
     def step(self, x, new_kv_src, self_cache, ext_kv, ext_mask):

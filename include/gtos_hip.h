@@ -154,6 +154,19 @@ int gtos_ln_residual_bwd(int dtype, int rows, int d, const void* dy, const void*
                          uint64_t seed, const float* gamma, const float* mean, const float* rstd,
                          void* dx, void* dr, float* dgamma, float* dbeta, void* stream);
 
+/* The same pair with MIXED storage types (round 4): x_dtype = the residual stream (x, and dx), r_dtype = the sub-layer output (r, and
+ * dr), y_dtype = the output (y, and dy).  Supported triples: all equal; (F32, BF16, F32) and (BF16, BF16, F32) = bf16 activations on
+ * an fp32 residual stream -- the post-LN outputs of the reference's layers (same lines as above) reach |3-4|, where a bf16 store per
+ * layer alone costs 1.6e-2 absolute; the stream is [rows, d], a few MB per layer.  y2_bf16 (optional): a bf16 copy of y, the next
+ * projection's MFMA operand; dy2_bf16 (optional) its gradient, added to dy in registers (dy itself may then be NULL).  -21: triple not
+ * supported. */
+int gtos_ln_residual_fwd2(int x_dtype, int r_dtype, int y_dtype, int rows, int d, const void* x, const void* r, float p_drop,
+                          uint64_t seed, const float* gamma, const float* beta, float eps, void* y, void* y2_bf16,
+                          float* mean, float* rstd, void* stream);
+int gtos_ln_residual_bwd2(int x_dtype, int r_dtype, int y_dtype, int rows, int d, const void* dy, const void* dy2_bf16,
+                          const void* x, const void* r, float p_drop, uint64_t seed, const float* gamma, const float* mean,
+                          const float* rstd, void* dx, void* dr, float* dgamma, float* dbeta, void* stream);
+
 /* In place dh *= (h > 0)/(1-p): backward of relu + dropout (generator/graph_transformer.py:61-62) given the saved output. */
 int gtos_relu_dropout_bwd(int dtype, int64_t n, void* dh, const void* h, float p_drop, void* stream);
 

@@ -146,6 +146,20 @@ class Recorder(object):
                 self._rows("gtos_ln_residual_fwd: " + what, p, rows, d, d, es(dtc))
             for what, p, n in (("gamma", a[7], d), ("beta", a[8], d), ("mean", a[11], rows), ("rstd", a[12], rows)):
                 self._rows("gtos_ln_residual_fwd: " + what, p, 1, n, n, 4)
+        elif name == "gtos_ln_residual_fwd2":
+            xd, rd, yd, rows, d = a[:5]
+            for what, p, e in (("x", a[5], es(xd)), ("r", a[6], es(rd)), ("y", a[12], es(yd)), ("y2", a[13], 2)):
+                self._rows("gtos_ln_residual_fwd2: " + what, p, rows, d, d, e)
+            for what, p, n in (("gamma", a[9], d), ("beta", a[10], d), ("mean", a[14], rows), ("rstd", a[15], rows)):
+                self._rows("gtos_ln_residual_fwd2: " + what, p, 1, n, n, 4)
+        elif name == "gtos_ln_residual_bwd2":
+            xd, rd, yd, rows, d = a[:5]
+            assert a[5] is not None or a[6] is not None, "gtos_ln_residual_bwd2: no incoming gradient"
+            for what, p, e in (("dy", a[5], es(yd)), ("dy2", a[6], 2), ("x", a[7], es(xd)), ("r", a[8], es(rd)), ("dx", a[14], es(xd)),
+                               ("dr", a[15], es(rd))):
+                self._rows("gtos_ln_residual_bwd2: " + what, p, rows, d, d, e)
+            for what, p, n in (("gamma", a[11], d), ("mean", a[12], rows), ("rstd", a[13], rows), ("dgamma", a[16], d), ("dbeta", a[17], d)):
+                self._rows("gtos_ln_residual_bwd2: " + what, p, 1, n, n, 4)
         elif name == "gtos_gru_step_fwd":
             (rows, hs, x, ldx, in_dim, w_ih, b_ih, xg, gf, gf_idx, gb, gb_idx, h_in, h_idx, w_hh, b_hh, h_out, n_out, h_fin, ld_fin, fin_idx,
              gates, y, ldy) = a[:24]

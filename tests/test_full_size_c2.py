@@ -157,3 +157,50 @@ def test_c2_full_batch_generator_bf16_vs_fp32_hip():
     for e, k, nrm in table:
         if nrm > 1e-4 * gmax:
             assert e < 0.2, (k, e, nrm)
+
+
+def test_c2_full_size_graph_encoder_vs_oracle_on_a_graph_subset():
+    """The 8-layer graph encoder at FULL C2 size (B = 64, R = 434,624: the factored operand with the host index, the prefetched
+    projections on the auxiliary stream, 6,464 workgroups per attention launch) in the bf16 production mode, against the pinned
+    oracle on the CPU for a SUBSET of the graphs: graphs never interact inside the encoder (attention is per graph, the bank rows
+    a graph uses are gathered for it alone), so the oracle on graphs {0, 21, 63} with their dense [n,n,3,d] relation tensors is
+    exact for those columns of the full-size run.  Outputs and every layer's attention weights; bf16 bar = north_star's 1e-2
+    relative to max(1, |oracle|), fp32 1e-3."""
+    from gtos_amd.graph_transformer import GraphTransformer, set_compute_dtype
+    from gtos_amd.ops import FactoredRelation
+    from oracle import gtos_oracle as O
+    batch, stats = c2_batch()
+    rel, index = batch["relation"], batch["relation_index"]            # [n,n,B] type ids
+    n, _, B = rel.shape
+    R = batch["relation_bank"].shape[1]
+    L, d, ff, H = 8, 512, 1024, 8
+    g = torch.Generator().manual_seed(11)
+    bank = 0.5 * torch.randn(R, d, generator=g)                       # relation vectors of RelationEncoder's output scale
+    x = torch.randn(n, B, d, generator=g)
+    pad = batch["concept"].eq(0)                                       # [n,B] key padding of the real batch (all False at C2: equal sizes)
+    torch.manual_seed(3)
+    ref = O.GraphTransformer(L, d, ff, H, 0.0)
+    ref.eval()
+    pick = torch.tensor([0, 21, 63])
+    with torch.no_grad():
+        dense = bank[rel[:, :, pick].reshape(-1)].view(n, n, pick.numel(), d)
+        want = ref(x[:, pick], dense, self_padding_mask=pad[:, pick])
+        want_attn = ref.get_attn_weights(x[:, pick], dense, self_padding_mask=pad[:, pick])      # [L, n, n, 3, H]
+    m = GraphTransformer(L, d, ff, H, 0.0).to(dev())
+    m.load_state_dict(ref.state_dict())
+    m.eval()
+    for dtype, bar_out, bar_attn in ((torch.float32, 1e-3, 1e-3), (torch.bfloat16, 1e-2, 1e-2)):
+        set_compute_dtype(m, dtype)
+        with torch.no_grad():
+            fact = FactoredRelation(bank.to(dev(), dtype), rel.to(dev()), index=index.to(dev()))
+            out = m(x.to(dev()), fact, self_padding_mask=pad.to(dev()))
+            attn = m.get_attn_weights(x.to(dev()), FactoredRelation(bank.to(dev(), dtype), rel.to(dev()), index=index.to(dev())),
+                                      self_padding_mask=pad.to(dev()))
+        torch.cuda.synchronize()
+        got = out.float().cpu()[:, pick]
+        e_out = float(((got - want).abs() / want.abs().clamp_min(1.0)).max())
+        e_attn = float((attn.float().cpu()[:, :, :, pick] - want_attn).abs().max())
+        print("C2 full-size graph encoder %s vs oracle on graphs %s: max relative output error %.3e (|out| max %.2f), max |attn err| %.3e" % (
+            dtype, pick.tolist(), e_out, float(want.abs().max()), e_attn))
+        assert e_out < bar_out, (dtype, e_out)
+        assert e_attn < bar_attn, (dtype, e_attn)
