@@ -70,7 +70,8 @@ def parse():
                     help="loader in the loop: a NEW batch every step, assembled by gtos_amd.data.AMRLoader (C++ relation batch, path "
                          "tries, relation index) on Prefetcher worker threads and uploaded on a copy stream, like the reference's "
                          "training loop (generator/train.py:136-140, generator/data.py:290-316); default: one pre-built device batch")
-    ap.add_argument("--workers", type=int, default=4, help="--fresh-batches: loader workers per rank")
+    ap.add_argument("--workers", type=int, default=0,
+                    help="--fresh-batches: loader workers per rank (default: 1 with the relation section on the device, 4 with --host-relations)")
     ap.add_argument("--loader", default="processes", choices=["processes", "threads"],
                     help="--fresh-batches: worker processes (own interpreter each: no GIL contention with the launch thread) or threads")
     ap.add_argument("--depth", type=int, default=0,
@@ -81,6 +82,19 @@ def parse():
                     help="--fresh-batches: the workers build the relation index only; the path tries are built on the GPU on the loader's "
                          "copy stream: 'torch' (default when the flag is given bare) = torch ops (gtos_amd.pathtrie_device), 'hip' = the "
                          "staged HIP builder (gtos_amd.pathtrie_hip: rocPRIM sorts / scans + stage kernels, 2 host reads)")
+    ap.add_argument("--host-relations", action="store_true",
+                    help="--fresh-batches: the loader workers build relation / bank / index / tries with the C++ host builders (the route of "
+                         "rounds 1-3: 0.10 s of host time per C2 batch, 3-4 worker processes per GPU).  Default since round 4: everything on "
+                         "the device (= --device-relations --prep-in-worker, ONE worker process), as the loaders themselves default to")
+    ap.add_argument("--relation-masks", default="node", choices=["node", "path"],
+                    help="training-mode dropout masks of the RelationEncoder: 'path' = drawn per (path, position) like the reference "
+                         "(generator/encoder.py:91-92,105; the LIBRARY default: one GRU row per path and position), 'node' = drawn per node of "
+                         "the prefix / suffix trie and shared by the paths through it (opt-in, gtos_amd.encoder.set_relation_mask_sharing: "
+                         "layer 0 once per trie node, layer-1 input gates from per-node tables).  The headline runs 'node' and says so; the "
+                         "other mode is measured right after the timed region and reported as `reference_masks` / `node_masks`")
+    ap.add_argument("--no-masks-leg", action="store_true", help="skip the leg that measures the other --relation-masks mode")
+    ap.add_argument("--no-loader-leg", action="store_true",
+                    help="skip the loader-in-the-loop leg that follows the timed region of the default (pre-built batch) run")
     ap.add_argument("--device-relations", action="store_true",
                     help="--fresh-batches: the loader ships the flattened graphs only (index_prep='device_all'); relation / bank / length "
                          "(gtos_amd.relbatch_hip), the relation index (gtos_amd.relindex_hip) and the tries (gtos_amd.pathtrie_hip) are built on "
@@ -391,6 +405,69 @@ def decode_bench(a):
     print(json.dumps(out))
 
 
+def _gather_ints(value, world, dev):
+    """every rank's integer, on every rank (one all-reduce of a rank-indexed vector)"""
+    t = torch.zeros(world, device=dev, dtype=torch.float64)
+    t[int(os.environ.get("RANK", "0"))] = float(value)
+    dist.all_reduce(t)
+    return t.tolist()
+
+
+def make_feed(a, cfg, rank, B_rank, dev, asm_times, free_b=0):
+    """Loader in the loop (generator/train.py:136-140 builds every batch inside the step loop; translator/train.py:85-89,144-146 feeds
+    them through a producer process and a queue): a pool of synthetic items of the config -> AMRLoader / DependencyLoader (reference
+    batching policy, paths re-drawn per batch) -> Prefetcher worker process(es) -> upload on a copy stream.  Route: everything of the
+    relation section on the device (default, ONE worker) or on the host (--host-relations).  Returns (feed, loader_info)."""
+    import random
+    from gtos_amd import data as data_mod
+    from gtos_amd import synth
+    device_all = a.device_relations or not (a.host_relations or a.device_tries)
+    prep_in_worker = a.prep_in_worker or (device_all and not a.device_relations)        # the default route: preparation on the upload thread
+    workers = a.workers or (1 if device_all else 4)
+    depth = a.depth or 2 * workers
+    pool_n = a.pool or 4 * B_rank
+    pool_n -= pool_n % B_rank
+    prep = "device_all" if device_all else ("device" if a.device_tries else True)
+    if cfg["kind"] == "amr":
+        vocabs_s = synth.synth_vocabs()
+        items, graphs = synth.make_amr_items(a.config, pool_n, first_graph=rank * pool_n, vocabs=vocabs_s)
+        unit = data_mod.AMRLoader.size_of(items[0])                       # every item of a config has the same size
+        loader = data_mod.AMRLoader(vocabs_s, items, batch_size=B_rank * unit - unit // 2, for_train=True,
+                                    rng=random.Random(19940117 + rank), n_threads=a.relbatch_threads, graphs=graphs, index_prep=prep)
+    else:
+        vocabs_s = synth.dep_vocabs()
+        trees = synth.make_dep_trees(a.config, pool_n, first_graph=rank * pool_n, vocabs=vocabs_s)
+        unit = data_mod.DependencyLoader.size_of(trees[0])
+        loader = data_mod.DependencyLoader(vocabs_s, trees, batch_size=B_rank * unit - unit // 2, for_train=True,
+                                           rng=random.Random(19940117 + rank), n_threads=a.relbatch_threads, index_prep=prep)
+
+    def timed_run(job):                                               # runs in the worker: reports its own assembly time
+        t_ = time.perf_counter()
+        out_ = loader.run_job(job)
+        out_["_assembly_s"] = time.perf_counter() - t_
+        return out_
+
+    def jobs():
+        while True:                                                   # epochs over the pool: reshuffled, paths re-drawn
+            yield from loader.jobs()
+    tries = a.device_tries or ("hip" if device_all else False)
+    if a.loader == "processes":
+        feed = data_mod.Prefetcher(jobs(), depth=depth, workers=workers, device=dev, processes=True, runner=timed_run,
+                                   device_tries=tries, prep_in_worker=prep_in_worker)
+    else:
+        feed = data_mod.Prefetcher((lambda j=j: timed_run(j) for j in jobs()), depth=depth, workers=workers, device=dev,
+                                   device_tries=tries, prep_in_worker=prep_in_worker)
+    info = {"workers": workers, "kind": a.loader, "depth": depth, "relbatch_threads": a.relbatch_threads,
+            "loader_class": type(loader).__name__,
+            "tries": {"torch": "device (torch ops on the copy stream)", "hip": "device (staged HIP builder on the copy stream)",
+                      False: "host (worker)"}[tries],
+            "relations": "device (staged HIP builders: relation / bank / index)" if device_all else "host (worker)",
+            "device_prep_thread": "upload thread" if prep_in_worker else "training thread",
+            "pool_graphs_per_rank": pool_n, "device_memory_free_gb_at_start": round(free_b / 2 ** 30, 1),
+            "allocator": "default" if os.environ.get("GTOS_BENCH_NO_ROUNDUP") else "roundup_power2_divisions:16"}
+    return feed, info
+
+
 def main():
     a = parse()
     if a.decode:
@@ -424,7 +501,7 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if a.fresh_batches and not os.environ.get("GTOS_BENCH_NO_ROUNDUP"):
+    if (a.fresh_batches or not a.no_loader_leg) and not os.environ.get("GTOS_BENCH_NO_ROUNDUP"):
         # every batch has its own bank size (R and the packed row count vary by a percent), so every large buffer of the step
         # changes size from step to step; the caching allocator then keeps growing (a cached 890 MB block cannot serve an 895 MB
         # request) until hipMalloc fails and the cache is flushed -- measured: 63 ms per step for one run, 120-140 ms for the next
@@ -454,6 +531,8 @@ def main():
     model = build_generator(Generator, a.config, dev, factored_relation=not a.dense).to(dev)
     model.set_compute_dtype(cd)
     model.train()
+    from gtos_amd.encoder import set_relation_mask_sharing
+    set_relation_mask_sharing(model, a.relation_masks)
     trainer = Trainer(model, cfg["d"], warmup_steps=2000, compute_dtype=cd, world_size=world, rank=rank)
     B_cfg = cfg["B"]
     if a.scaling == "strong":
@@ -466,50 +545,15 @@ def main():
     from gtos_amd.pathtrie import attach_path_trie
     from gtos_amd.relindex import attach_relation_index
     loader_info, feed = None, None
+    asm_times = []
     if a.fresh_batches:
-        import random
-        from gtos_amd import data as data_mod
-        if cfg["kind"] != "amr":
-            raise SystemExit("--fresh-batches drives the generator-flavour loader (AMR configs)")
-        vocabs_s = synth.synth_vocabs()
-        pool_n = a.pool or 4 * B_rank
-        pool_n -= pool_n % B_rank
-        items, graphs = synth.make_amr_items(a.config, pool_n, first_graph=rank * pool_n, vocabs=vocabs_s)
-        unit = data_mod.AMRLoader.size_of(items[0])                       # every item of a config has the same size
-        loader = data_mod.AMRLoader(vocabs_s, items, batch_size=B_rank * unit - unit // 2, for_train=True,
-                                    rng=random.Random(19940117 + rank), n_threads=a.relbatch_threads, graphs=graphs,
-                                    index_prep="device_all" if a.device_relations else ("device" if a.device_tries else True))
-        a.depth = a.depth or 2 * a.workers
-        asm_times = []
-
-        def timed_run(job):                                               # runs in the worker: reports its own assembly time
-            t_ = time.perf_counter()
-            out_ = loader.run_job(job)
-            out_["_assembly_s"] = time.perf_counter() - t_
-            return out_
-
-        def jobs():
-            while True:                                                   # epochs over the pool: reshuffled, paths re-drawn
-                yield from loader.jobs()
-        if a.loader == "processes":
-            feed = data_mod.Prefetcher(jobs(), depth=a.depth, workers=a.workers, device=dev, processes=True, runner=timed_run,
-                                       device_tries=a.device_tries or ("hip" if a.device_relations else False), prep_in_worker=a.prep_in_worker)
-        else:
-            feed = data_mod.Prefetcher((lambda j=j: timed_run(j) for j in jobs()), depth=a.depth, workers=a.workers, device=dev,
-                                       device_tries=a.device_tries or ("hip" if a.device_relations else False), prep_in_worker=a.prep_in_worker)
+        feed, loader_info = make_feed(a, cfg, rank, B_rank, dev, asm_times, free_b)
         batch = next(feed)
         stats = {"n": int(batch["concept"].shape[0]), "B": int(batch["concept"].shape[1]), "T": int(batch["token_in"].shape[0]),
                  "R": int(batch["relation_bank"].shape[1]),
                  "mean_path_len": float(batch["relation_length"].float().mean())}
         assert stats["B"] == B_rank, stats
         asm_times.append(batch.pop("_assembly_s"))
-        loader_info = {"workers": a.workers, "kind": a.loader, "depth": a.depth, "relbatch_threads": a.relbatch_threads,
-                       "tries": {"torch": "device (torch ops on the copy stream)", "hip": "device (staged HIP builder on the copy stream)",
-                                 "": "host (worker)"}[a.device_tries or ("hip" if a.device_relations else "")],
-                       "relations": "device (staged HIP builders: relation / bank / index)" if a.device_relations else "host (worker)",
-                       "device_prep_thread": "upload thread" if a.prep_in_worker else "training thread",
-                       "pool_graphs_per_rank": pool_n, "device_memory_free_gb_at_start": round(free_b / 2 ** 30, 1),
-                       "allocator": "default" if os.environ.get("GTOS_BENCH_NO_ROUNDUP") else "roundup_power2_divisions:16"}
     else:
         batch, stats = synth.make_config_batch(a.config, rank=rank, B=B_rank)   # rank r holds graphs [r*B_rank, (r+1)*B_rank)
         attach_relation_index(attach_path_trie(batch))   # host-side index preparation: batch assembly, like the relation bank itself
@@ -590,6 +634,100 @@ def main():
     comm_exposed = max(trainer.comm_exposed_s, 1e-3 * trainer.comm_exposed_ms())   # host wait (gloo) / compute-stream stall (RCCL)
     log("timed region done", elapsed)
     prof, ops.PROFILE = ops.PROFILE, None
+    # ---- N > 1: the OTHER scaling mode in the same run, so that one command gives both (weak: B graphs per GPU, the translator's
+    # policy; strong: B graphs in total, the generator's, generator/train.py:183), and what the collective layer really saw
+    other_scaling, rccl_info = None, None
+    if world > 1:
+        seen = torch.ones(1, device=dev)
+        dist.all_reduce(seen)
+        rccl_info = {"backend": dist.get_backend(), "ranks_seen_by_allreduce": int(seen.item()), "world_size": world,
+                     "devices": sorted(set(int(x) for x in _gather_ints(local, world, dev)))}
+        try:
+            rccl_info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:                     # noqa: BLE001
+            pass
+        if not a.fresh_batches and B_cfg % world == 0:
+            B_other = B_cfg // world if a.scaling == "weak" else B_cfg
+            b2, st2 = synth.make_config_batch(a.config, rank=rank, B=B_other)
+            attach_relation_index(attach_path_trie(b2))
+            b2 = {k: v.to(dev) for k, v in b2.items()}
+            for _ in range(3):
+                trainer.step(b2, sync=False)
+            sync()
+            t_o = time.perf_counter()
+            for _ in range(a.steps):
+                trainer.step(b2, sync=False)
+            sync()
+            to = torch.tensor([time.perf_counter() - t_o], device=dev, dtype=torch.float64)
+            dist.all_reduce(to, op=dist.ReduceOp.MAX)
+            dt_o = float(to.item())
+            other_scaling = {"scaling": "strong" if a.scaling == "weak" else "weak", "B_per_gpu": B_other, "global_batch": world * B_other,
+                             "ms_per_step": round(1e3 * dt_o / a.steps, 3), "value": round(world * B_other * a.steps / dt_o, 1),
+                             "unit": "graphs/s", "steps": a.steps}
+            del b2
+    # ---- the OTHER dropout-mask mode of the RelationEncoder, same batch, same K steps, right after the timed region (every rank)
+    masks_leg = None
+    if not a.no_masks_leg and cd == torch.bfloat16 and not a.fresh_batches:
+        other = "path" if a.relation_masks == "node" else "node"
+        set_relation_mask_sharing(model, other)
+        for _ in range(3):
+            trainer.step(batch, sync=False)
+        sync()
+        t_m = time.perf_counter()
+        for _ in range(a.steps):
+            trainer.step(batch, sync=False)
+        sync()
+        tm = torch.tensor([time.perf_counter() - t_m], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        dt_m = float(tm.item())
+        set_relation_mask_sharing(model, a.relation_masks)
+        masks_leg = {"relation_masks": other, "ms_per_step": round(1e3 * dt_m / a.steps, 3), "steps": a.steps,
+                     "value": round(world * stats["B"] * a.steps / dt_m, 1), "unit": "graphs/s",
+                     "vs_headline": round(dt_m / elapsed, 4),
+                     "note": ("masks per (path, position): the reference's dropout (generator/encoder.py:91-92,105), the library default; "
+                              "one GRU row per path and position in both layers" if other == "path" else
+                              "masks per trie node (opt-in): layer 0 once per trie node, layer-1 input gates from per-node tables")}
+    # ---- loader in the loop, AFTER the timed region of the default run (every rank: the steps hold collectives): the same K steps,
+    # each on a NEW batch from the default loader route (relation section on the device, ONE worker process per GPU).  The headline
+    # above is the pre-built batch SURVEY 8d prescribes; this leg says what feeding costs on top of it.
+    loader_leg = None
+    if not a.fresh_batches and not a.no_loader_leg and cd == torch.bfloat16 and not a.dense:
+        try:
+            asm2 = []
+            feed2, info2 = make_feed(a, cfg, rank, B_rank, dev, asm2, free_b)
+            for _ in range(3):
+                b_ = next(feed2); b_.pop("_assembly_s", None)
+                trainer.step(b_, sync=False)
+            sync()
+            wait2, t_l = 0.0, time.perf_counter()
+            for _ in range(a.steps):
+                t_ = time.perf_counter()
+                b_ = next(feed2)
+                wait2 += time.perf_counter() - t_
+                asm2.append(b_.pop("_assembly_s"))
+                trainer.step(b_, sync=False)
+            sync()
+            dt_l = time.perf_counter() - t_l
+            tl = torch.tensor([dt_l], device=dev, dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+            dt_l = float(tl.item())
+            loader_leg = {"ms_per_step": round(1e3 * dt_l / a.steps, 3), "steps": a.steps, "value": round(world * B_rank * a.steps / dt_l, 1),
+                          "unit": "graphs/s", "vs_prebuilt_batch": round(dt_l / elapsed, 4),
+                          "workers_per_gpu": info2["workers"], "worker_kind": info2["kind"], "loader_class": info2["loader_class"],
+                          "relations": info2["relations"], "tries": info2["tries"], "device_prep_thread": info2["device_prep_thread"],
+                          "host_assembly_s_per_batch": round(sum(asm2) / max(1, len(asm2)), 4),
+                          "consumer_wait_ms_per_step": round(1e3 * wait2 / a.steps, 3),
+                          "device_prep_ms_per_batch": round(1e3 * feed2.stats["device_prep_s"] / max(1, feed2.stats["batches"]), 3),
+                          "note": "every step a new batch (new graphs order, paths re-drawn, new bank: R varies by a percent), like "
+                                  "generator/train.py:136-140; same rank count, same steps, right after the timed region"}
+            feed2.close()
+            del b_
+        except Exception as e:                  # noqa: BLE001  (the leg must never cost the headline line)
+            loader_leg = {"error": "%s: %s" % (type(e).__name__, e)}
+            if world > 1:
+                raise
     # per-rank view: wall time of the timed region and the compute-stream stall on gradient collectives, gathered on rank 0
     table = torch.zeros((world, 2), device=dev, dtype=torch.float64)
     table[rank, 0], table[rank, 1] = my_elapsed, comm_exposed
@@ -622,16 +760,20 @@ def main():
                "unit": "graphs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": a.scaling,
                "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-               "config": {"workload": "%s: generator/ %dx%d-node synthetic AMR graphs %s, %d-layer d=%d %d-head, "
+               "config": {"workload": "%s: %s %dx%d-node synthetic %s %s, %d-layer d=%d %d-head, "
                                       "full train step (fwd+bwd+allreduce+clip+Adam), dropout 0.2%s" % (
-                                          a.config, B, cfg["N"], "per GPU" if a.scaling == "weak" else
+                                          a.config, "generator/" if cfg["kind"] == "amr" else "translator/", B, cfg["N"],
+                                          "AMR graphs" if cfg["kind"] == "amr" else "dependency trees", "per GPU" if a.scaling == "weak" else
                                           "per GPU = %d in total over %d GPUs (generator/train.py:183)" % (world * B, world),
                                           cfg["layers"], d, H,
                                           ", a NEW loader-built batch every step" if a.fresh_batches else ", one pre-built device batch"),
                           "n": n, "B_per_gpu": B, "global_batch": world * B, "P": P, "R": R,
                           "mean_path_len": round(stats["mean_path_len"], 2), "T": stats["T"],
                           "relation_operand": "dense" if a.dense else "factored", "parallelism": "dp%d" % world,
-                          "relation_gru": "trie (dropout masks per trie node)" if gru_mod.TRIE else "per row",
+                          "relation_gru": ("trie evaluation, dropout masks drawn per trie node and shared by the paths through it (OPT-IN, "
+                                           "--relation-masks node; the library default draws them per (path, position) like the reference: "
+                                           "see reference_masks)" if (gru_mod.TRIE and a.relation_masks == "node") else
+                                           "one row per (path, position), dropout masks per (path, position) like the reference"),
                           "allreduce_exposed_ms_per_step": round(1e3 * max(r[1] for r in per_rank) / a.steps, 3),
                           "per_rank_ms_per_step": [round(1e3 * r[0] / a.steps, 3) for r in per_rank],
                           "per_rank_allreduce_exposed_ms_per_step": [round(1e3 * r[1] / a.steps, 3) for r in per_rank],
@@ -639,7 +781,9 @@ def main():
                           "loader": loader_info,
                           "prewarm_steps": prewarm_steps, "device_memory": memory_info,
                           "loss_first": losses[0], "loss_last": losses[-1]},
-               "roofline": roofline, "components": components}
+               "roofline": roofline, "components": components, "loader_in_loop": loader_leg,
+               ("reference_masks" if a.relation_masks == "node" else "node_masks"): masks_leg,
+               "other_scaling": other_scaling, "collectives": rccl_info}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.config, a.cpu_graphs, a.cpu_steps, a.cpu_budget, a.cpu_warmup)
         print(json.dumps(out))

@@ -892,49 +892,62 @@ __global__ __launch_bounds__(512) void gemm256p_nt_kernel(GemmArgs a) {
     }
 }
 
-// ---- gemm_p2_nt_kernel (round 4): the forward shape with a SHORT reduction (K = 256 .. 1024: relation projection, GRU gate tables,
+// ---- gemm_p2_nt_kernel (round 4): the forward shape with a SHORT reduction (K = 128 .. 1023: relation projection, GRU gate tables,
 //      RelationEncoder output projection), where a tile's output write costs as much as its k loop.  Measured picture behind it
 //      (tools/probes/membw_probe.hip): the chip streams reads at 6.0-6.3 TB/s but WRITES at 4.4 TB/s, so [R,1024] bf16 = 0.89 GB of
 //      output is 0.20 ms of HBM time against 0.19 ms of MFMA time at the peak -- the two must overlap, and inside one workgroup they
 //      cannot (the accumulators are the data being stored).  So: TWO independent 4-wave workgroups per CU (one wave of each per SIMD),
-//      each on its own 128 x 256 tile with its own three-stage LDS ring (32-k stages, 72 KB); they drift apart by themselves, and
-//      while one drains its tile through the store queue the other has the matrix pipes.  The single-stage 128x128 kernel above
-//      has four co-resident workgroups but no prefetch of its own (its k loop waits for every tile), the 256x256 ping-pong kernel
-//      has the prefetch but one workgroup per CU (nothing runs beside its epilogue): 0.55 / 0.63 ms at the relation projection.
-//      Stages are separate static arrays and every wait is explicit, as in gemm256p_nt_kernel (hipcc would otherwise drain all
-//      LDS-DMA in front of each ds_read).  Step s of a wave: wait for its own pieces of stage s (vmcnt(6): the 6 pieces of stage
-//      s+1 stay in flight), barrier (stage s complete; every wave is past its reads of stage s-1), issue stage s+2 into the slot of
-//      stage s-1, 12 fragment reads, 32 MFMAs.  Rows past M / N re-read the last valid row (never stored); stages past K re-read the
-//      last stage (never multiplied).  K % 32 == 0.
-constexpr int P2_BM = 128, P2_BN = 256, P2_A = P2_BM * ROW3, P2_ST = (P2_BM + P2_BN) * ROW3;   // 8 KB + 16 KB per stage
-const bool g_use_p2 = !(getenv("GTOS_GEMM_P2") && getenv("GTOS_GEMM_P2")[0] == '0');
+//      each on its own 128 x 256 tile; they drift apart by themselves, and while one drains its tile through the store queue the
+//      other has the matrix pipes.  First version (three 32-k stages, every wave loading its share of A and B): 0.65 ms at the
+//      relation projection, no better than the single-stage kernel -- the A operand streams from HBM (2+ us under load) and two
+//      stages of prefetch cover 0.4 us of MFMA time, so every step waited.  A wave's vmcnt retires loads IN ORDER, so one wave
+//      cannot hold a deep A prefetch and a shallow B one at once; hence the ROLE SPLIT: waves 0-1 load only A into a SIX-slot ring
+//      (five 8 KB stages = 40 KB of HBM reads in flight per workgroup), waves 2-3 load only B (the weight, L2-resident: two 16 KB
+//      slots are enough); all four multiply.  80 KB of LDS per workgroup.  Stages are separate static arrays and every wait is
+//      explicit, as in gemm256p_nt_kernel (hipcc would otherwise drain all LDS-DMA in front of each ds_read).  Step s: loaders wait
+//      for their own pieces of stage s (A: vmcnt(16) = four newer stages stay in flight; B: vmcnt(0)), barrier (stage s complete,
+//      every wave past its reads of stage s-1), A(s+5) / B(s+1) issued into the slots of stage s-1, 12 fragment reads, 32 MFMAs.
+//      Rows past M / N re-read the last valid row (never stored); stages past K re-read the last stage (never multiplied).
+constexpr int P2_BM = 128, P2_BN = 256, P2_AS = P2_BM * ROW3, P2_BS = P2_BN * ROW3;   // 8 KB / 16 KB per stage
+// Measured (profiles/r4c_gemm_p2_*.txt, r4d_gemm_p2_*.txt; same box, back to back): relation projection 0.653 ms (three-stage
+// version, every wave loading A and B) and 0.706 ms (this role-split version) against 0.637-0.644 ms for the single-stage 128x128
+// kernel and 0.65-0.69 ms for torch.matmul; t(K) slope 1.04 us per k against 0.96 (0.36 at the MFMA peak) -- the deep A ring changed
+// nothing, so the k loop of all these kernels is not waiting for HBM latency; in the training step: graph encoder forward -0.3..-0.5 ms,
+// RelationEncoder +0.2, step unchanged (61.0 / 60.8 vs 60.95 ms).  Kept as an opt-in (GTOS_GEMM_P2=1) with its parity test.
+const bool g_use_p2 = getenv("GTOS_GEMM_P2") && getenv("GTOS_GEMM_P2")[0] == '1';
 const int g_p2_maxk = getenv("GTOS_GEMM_P2_MAXK") ? atoi(getenv("GTOS_GEMM_P2_MAXK")) : 1023;
 
 __global__ __launch_bounds__(256, 2) void gemm_p2_nt_kernel(GemmArgs a) {
-    __shared__ __attribute__((aligned(16))) char st0[P2_ST];
-    __shared__ __attribute__((aligned(16))) char st1[P2_ST];
-    __shared__ __attribute__((aligned(16))) char st2[P2_ST];
+    __shared__ __attribute__((aligned(16))) char a0[P2_AS];
+    __shared__ __attribute__((aligned(16))) char a1[P2_AS];
+    __shared__ __attribute__((aligned(16))) char a2[P2_AS];
+    __shared__ __attribute__((aligned(16))) char a3[P2_AS];
+    __shared__ __attribute__((aligned(16))) char a4[P2_AS];
+    __shared__ __attribute__((aligned(16))) char a5[P2_AS];
+    __shared__ __attribute__((aligned(16))) char b0[P2_BS];
+    __shared__ __attribute__((aligned(16))) char b1[P2_BS];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fr = lane & 15, fq = lane >> 4;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 128;
+    const bool isA = wave < 2;                             // loader role (wave-uniform)
+    const int lw = wave & 1;                               // loader index inside its role
     const int nN = (a.N + P2_BN - 1) / P2_BN;
     const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
     const int m0 = ((sq / nN) * 8 + xcd) * P2_BM, n0 = (sq % nN) * P2_BN;       // an XCD walks the N tiles of its M panels: A rows stay in its L2
     if (m0 >= a.M) return;
     const char* Ab = reinterpret_cast<const char*>(static_cast<const bf16_t*>(a.A) + (int64_t)m0 * a.lda);
     const char* Bb = reinterpret_cast<const char*>(static_cast<const bf16_t*>(a.B) + (int64_t)n0 * a.ldb);
-    const int amax = a.M - 1 - m0, bmax = a.N - 1 - n0;
-    const uint32_t lda2 = (uint32_t)a.lda * 2u, ldb2 = (uint32_t)a.ldb * 2u;
+    const char* Lb = isA ? Ab : Bb;                        // this wave's operand
+    const int lmax = isA ? a.M - 1 - m0 : a.N - 1 - n0;
+    const uint32_t ld2 = (uint32_t)(isA ? a.lda : a.ldb) * 2u;
     const int nk = a.K / 32;
-    // DMA: a wave instruction fills 1 KB = 16 rows x 64 B; lane l -> row l >> 2, physical chunk l & 3.  Wave w owns 16-row blocks
-    // w and w + 4 of A (8 blocks) and w, w + 4, w + 8, w + 12 of B (16 blocks).
+    // DMA: a wave instruction fills 1 KB = 16 rows x 64 B; lane l -> row l >> 2, physical chunk l & 3.  Loader lw of a role owns the
+    // 16-row blocks lw, lw + 2, ... of its operand's stage: 4 of A's 8, 8 of B's 16.
     const int drow = lane >> 2;
     const uint32_t dchunk = (uint32_t)(((lane & 3) ^ ((-(lane >> 4)) & 3)) << 4);
-    uint32_t aoff[2], boff[4];
+    uint32_t off[8];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) aoff[i] = (uint32_t)min((wave + 4 * i) * 16 + drow, amax) * lda2 + dchunk;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) boff[i] = (uint32_t)min((wave + 4 * i) * 16 + drow, bmax) * ldb2 + dchunk;
+    for (int i = 0; i < 8; ++i) off[i] = (uint32_t)min((lw + 2 * i) * 16 + drow, lmax) * ld2 + dchunk;
     const int foff = fr * ROW3 + ((fq ^ ((-(fr >> 2)) & 3)) << 4);
 
     f32x4_t acc[4][8];
@@ -947,22 +960,31 @@ __global__ __launch_bounds__(256, 2) void gemm_p2_nt_kernel(GemmArgs a) {
 #define GTOS_DMA1(src, dst)                                                                                                   \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),                                    \
                                      (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
-#define GTOS_P2_DMA(stage, s_)                                                                                                \
+#define GTOS_P2_DMA_A(slot, s_)                                                                                               \
     {                                                                                                                         \
         const int kb_ = min((s_), nk - 1) * 64;            /* byte offset of the stage's k range; past the end: dummy re-read */ \
-        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) GTOS_DMA1(Ab + kb_ + aoff[i_], (stage) + (wave + 4 * i_) * 1024);            \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) GTOS_DMA1(Bb + kb_ + boff[i_], (stage) + P2_A + (wave + 4 * i_) * 1024);     \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) GTOS_DMA1(Lb + kb_ + off[i_], (slot) + (lw + 2 * i_) * 1024);        \
     }
-#define GTOS_P2_STEP(slot_s, slot_d, s_)                                                                                      \
+#define GTOS_P2_DMA_B(slot, s_)                                                                                               \
     {                                                                                                                         \
-        GTOS_VMCNT(6);                                     /* own pieces of stage s_ (stage s_+1's six stay in flight) */      \
+        const int kb_ = min((s_), nk - 1) * 64;                                                                               \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) GTOS_DMA1(Lb + kb_ + off[i_], (slot) + (lw + 2 * i_) * 1024);        \
+    }
+// sa: A slot of stage s_, da: A slot that takes stage s_+5 (= slot of s_-1); sb / db likewise for B's two slots
+#define GTOS_P2_STEP(sa, da, sb, db, s_)                                                                                      \
+    {                                                                                                                         \
+        if (isA) { GTOS_VMCNT(16); } else { GTOS_VMCNT(0); }   /* own pieces of stage s_ (A: 4 newer stages stay in flight) */ \
         __builtin_amdgcn_s_barrier();                      /* everybody's; and every wave has read its fragments of s_-1 */   \
-        GTOS_P2_DMA(slot_d, (s_) + 2);                                                                                        \
-        _Pragma("unroll") for (int t = 0; t < 8; ++t)                                                                         \
-            fb[t] = *reinterpret_cast<const bf16x8_t*>((slot_s) + P2_A + (wn + t * 16) * ROW3 + foff);                        \
-        _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                                         \
-            fa[t] = *reinterpret_cast<const bf16x8_t*>((slot_s) + (wm + t * 16) * ROW3 + foff);                               \
+        if (isA) { GTOS_P2_DMA_A(da, (s_) + 5); } else { GTOS_P2_DMA_B(db, (s_) + 1); }                                       \
+        {                                                                                                                     \
+            const uint32_t ab_ = GTOS_LDS_ADDR(sb) + fbase_b, aa_ = GTOS_LDS_ADDR(sa) + fbase_a;                              \
+            GTOS_DSR128(fb[0], ab_, 0); GTOS_DSR128(fb[1], ab_, 1024); GTOS_DSR128(fb[2], ab_, 2048); GTOS_DSR128(fb[3], ab_, 3072);   \
+            GTOS_DSR128(fb[4], ab_, 4096); GTOS_DSR128(fb[5], ab_, 5120); GTOS_DSR128(fb[6], ab_, 6144); GTOS_DSR128(fb[7], ab_, 7168); \
+            GTOS_DSR128(fa[0], aa_, 0); GTOS_DSR128(fa[1], aa_, 1024); GTOS_DSR128(fa[2], aa_, 2048); GTOS_DSR128(fa[3], aa_, 3072);   \
+        }                                                                                                                     \
         __builtin_amdgcn_s_waitcnt(0xc07f);                /* lgkmcnt(0): fragments in registers */                            \
+        asm volatile("" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]),   \
+                          "+v"(fb[4]), "+v"(fb[5]), "+v"(fb[6]), "+v"(fb[7]));   /* the MFMAs below consume values defined AFTER the wait */ \
         __builtin_amdgcn_sched_barrier(0);                                                                                    \
         _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                                      \
             _Pragma("unroll") for (int nt = 0; nt < 8; ++nt)                                                                  \
@@ -970,29 +992,53 @@ __global__ __launch_bounds__(256, 2) void gemm_p2_nt_kernel(GemmArgs a) {
         __builtin_amdgcn_sched_barrier(0);                                                                                    \
     }
 
-    GTOS_P2_DMA(st0, 0);
-    GTOS_P2_DMA(st1, 1);
+    // The fragment reads are inline assembly: hipcc's wait-count pass, which cannot know that a wave only ever issues DMA into ITS
+    // role's slots, put s_waitcnt vmcnt(0) in front of every other step's ds_read (checked in the ISA) and with it drained the deep
+    // A ring.  Reads it does not see get no waits; the waits needed are the explicit ones of GTOS_P2_STEP.
+    const uint32_t fbase_a = (uint32_t)(wm * ROW3 + foff), fbase_b = (uint32_t)(wn * ROW3 + foff);
+#define GTOS_LDS_ADDR(p_) ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)(p_))
+#define GTOS_DSR128(dst_, addr_, imm_) asm volatile("ds_read_b128 %0, %1 offset:" #imm_ : "=v"(dst_) : "v"(addr_))
+
+    if (isA) {
+        GTOS_P2_DMA_A(a0, 0); GTOS_P2_DMA_A(a1, 1); GTOS_P2_DMA_A(a2, 2); GTOS_P2_DMA_A(a3, 3); GTOS_P2_DMA_A(a4, 4);
+    } else {
+        GTOS_P2_DMA_B(b0, 0);
+    }
     int s = 0;
-    for (; s + 3 <= nk; s += 3) {                          // whole triples: one path through the body for the wait-count pass
-        GTOS_P2_STEP(st0, st2, s);
-        GTOS_P2_STEP(st1, st0, s + 1);
-        GTOS_P2_STEP(st2, st1, s + 2);
+    for (; s + 6 <= nk; s += 6) {                          // whole sextuples: one path through the body for the wait-count pass
+        GTOS_P2_STEP(a0, a5, b0, b1, s);
+        GTOS_P2_STEP(a1, a0, b1, b0, s + 1);
+        GTOS_P2_STEP(a2, a1, b0, b1, s + 2);
+        GTOS_P2_STEP(a3, a2, b1, b0, s + 3);
+        GTOS_P2_STEP(a4, a3, b0, b1, s + 4);
+        GTOS_P2_STEP(a5, a4, b1, b0, s + 5);
     }
     if (s < nk) {
-        GTOS_P2_STEP(st0, st2, s);
-        if (s + 1 < nk) GTOS_P2_STEP(st1, st0, s + 1);
+        GTOS_P2_STEP(a0, a5, b0, b1, s);
+        if (s + 1 < nk) {
+            GTOS_P2_STEP(a1, a0, b1, b0, s + 1);
+            if (s + 2 < nk) {
+                GTOS_P2_STEP(a2, a1, b0, b1, s + 2);
+                if (s + 3 < nk) {
+                    GTOS_P2_STEP(a3, a2, b1, b0, s + 3);
+                    if (s + 4 < nk) GTOS_P2_STEP(a4, a3, b0, b1, s + 4);
+                }
+            }
+        }
     }
     GTOS_VMCNT(0);                                         // the dummy prefetches of the last steps
-    __syncthreads();                                       // every wave is done with the stages: st0 becomes the output staging
+    __syncthreads();                                       // every wave is done with the stages: a0..a2 become the output staging
 #undef GTOS_P2_STEP
-#undef GTOS_P2_DMA
+#undef GTOS_DSR128
+#undef GTOS_LDS_ADDR
+#undef GTOS_P2_DMA_A
+#undef GTOS_P2_DMA_B
 #undef GTOS_DMA1
-
     // ---- epilogue (bf16 out): 16 rows x 128 columns of the wave tile at a time through LDS (wave-private rows), 256-byte row segments out
     bf16_t* C = static_cast<bf16_t*>(a.C);
     const float keep_scale = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
     constexpr int CP = 128 * 2 + 16;                       // bytes per staged row
-    char* cs = st0 + wave * 16 * CP;
+    char* cs = wave == 0 ? a0 : (wave == 1 ? a1 : (wave == 2 ? a2 : a3));      // 16 x 272 B of a free 8 KB stage slot per wave
     const bool plain = !a.bias && !a.relu && !(a.p_drop > 0.f);
     if (plain && !a.accumulate && m0 + P2_BM <= a.M && n0 + P2_BN <= a.N) {
         // interior tile of a plain product (the relation projections, the gate tables): no per-element conditions, addresses once

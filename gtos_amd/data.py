@@ -7,6 +7,8 @@ reference on its own data (tests/test_host_relbatch.py, tests/test_beam_and_voca
 of the per-graph copy ids, which the reference takes from a ``set`` iteration (extract.py:56-62) and this module assigns
 in first-occurrence order.
 """
+import os
+
 import torch
 
 from . import relbatch
@@ -18,6 +20,41 @@ from .vocab import CLS, rCLS, SEL, TL, STR, END, lists_to_tensor, strings_to_cha
 def relation_special_ids(rel_vocab):
     return (rel_vocab.padding_idx, rel_vocab.token2idx(CLS), rel_vocab.token2idx(rCLS), rel_vocab.token2idx(SEL),
             rel_vocab.token2idx(TL))
+
+
+def resolve_index_prep(index_prep):
+    """``index_prep="auto"`` (the loaders' default since round 4): the relation section of every batch -- all-pairs label paths, type
+    numbering, bank, relation index, path tries -- is left to the consumer's GPU (``"device_all"``: the loader ships the flattened graphs,
+    ~30 KB, and the token / character tensors; gtos_amd.relbatch_hip / relindex_hip / pathtrie_hip build the rest in ~6 ms of device
+    time per C2 batch, array for array equal to the host builders) when this process can see a GPU and libgtos_hip.so loads; on a
+    host without one the C++ host builders run as before (``True``).  ``GTOS_INDEX_PREP=host|device|device_all`` overrides "auto";
+    an explicit argument always wins.  Resolved ONCE, in the process that constructs the loader (worker processes inherit the value)."""
+    if index_prep != "auto":
+        return index_prep
+    env = os.environ.get("GTOS_INDEX_PREP", "")
+    if env:
+        return {"host": True, "device": "device", "device_all": "device_all", "off": False}[env]
+    try:
+        if torch.cuda.is_available():
+            from . import _lib
+            _lib.load()
+            return "device_all"
+    except Exception:
+        pass
+    return True
+
+
+def complete_on_device(batch, device=None, tries="hip"):
+    """A batch that reached its consumer with ``relation_graphs`` instead of relation / bank / length (``index_prep="device_all"`` without
+    a ``Prefetcher`` in between, e.g. ``for batch in loader: model({k: v.to(dev) ...})``): build them, the relation index and the path
+    tries on the batch's device, on the current stream.  A complete batch is returned unchanged."""
+    if 'relation_graphs' not in batch:
+        return batch
+    train = batch['relation_graphs'].path_mode != relbatch.PATH_ALL
+    attach_device_relations(batch, device)
+    if train:
+        attach_device_relation_index(batch)
+    return attach_device_tries(batch, tries)
 
 
 def _index_prep(batch, on):
@@ -188,14 +225,14 @@ class DependencyLoader(object):
     shuffled.  Both shuffles draw from ``rng`` (default: the ``random`` module, like the reference) BEFORE the first batch is
     assembled, so under the same seed the batches and their order are the reference's.  Yields batchify_dependency dicts."""
 
-    def __init__(self, vocabs, filename, batch_size, for_train, rng=None, n_threads=0, index_prep=True):
+    def __init__(self, vocabs, filename, batch_size, for_train, rng=None, n_threads=0, index_prep="auto"):
         import random
         self.data = read_dependency_file(filename) if isinstance(filename, str) else list(filename)
         self.vocabs, self.batch_size, self.train = vocabs, batch_size, for_train
         self.rng = rng if rng is not None else random
         self.n_threads = n_threads
         self.unk_rate = 0.
-        self.index_prep = index_prep          # path tries + relation index of the bf16 training path (see _index_prep)
+        self.index_prep = resolve_index_prep(index_prep)   # relation section on the consumer's GPU when there is one (see resolve_index_prep)
 
     def set_unk_rate(self, x):
         """translator/data.py:218-219; train.py:128 calls it with --unk_rate (0.33 in train.sh)."""
@@ -340,7 +377,7 @@ class AMRLoader(object):
     ``record()``: (batch, items) pairs, data.py:287-288,313-316); the path sampling of a training batch is seeded from
     ``rng`` per batch.  The graph of every item is recovered from its path lists once, at load time."""
 
-    def __init__(self, vocabs, filename, batch_size, for_train, rng=None, n_threads=0, index_prep=True, graphs=None):
+    def __init__(self, vocabs, filename, batch_size, for_train, rng=None, n_threads=0, index_prep="auto", graphs=None):
         """``graphs``: (n, root, edges) per item when the caller already holds them (gtos_amd.synth.make_amr_items): the items
         then need no 'relation' path lists."""
         import json
@@ -355,7 +392,7 @@ class AMRLoader(object):
         self.n_threads = n_threads
         self.unk_rate = 0.
         self.record_flag = False
-        self.index_prep = index_prep
+        self.index_prep = resolve_index_prep(index_prep)
         self._graphs = {}
         if graphs is not None:
             assert len(graphs) == len(self.data)

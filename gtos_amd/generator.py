@@ -70,6 +70,9 @@ class Generator(nn.Module):
         return c, torch.eq(inp['concept'], self.vocabs['concept'].padding_idx)
 
     def encode_step(self, inp, train=True):
+        if 'relation_graphs' in inp:           # a loader batch whose relation section was left to this device (index_prep="device_all")
+            from .data import complete_on_device
+            complete_on_device(inp, inp['concept'].device)
         concept_repr, concept_mask = self._concepts(inp)
         with ops._Timed("relation_encoder_fwd"):
             bank = self.relation_encoder(inp['relation_bank'], inp['relation_length'], trie=inp.get('relation_trie'))   # [R, d]
@@ -99,6 +102,9 @@ class Generator(nn.Module):
 
     def encoder_attn(self, inp):
         with torch.no_grad():
+            if 'relation_graphs' in inp:
+                from .data import complete_on_device
+                complete_on_device(inp, inp['concept'].device)
             concept_repr, concept_mask = self._concepts(inp)
             bank = self.relation_encoder(inp['relation_bank'], inp['relation_length'], trie=inp.get('relation_trie'))
             relation = (ops.factored_eval_relation(bank, inp['relation']) if self.factored_relation

@@ -384,3 +384,48 @@ def make_amr_items(name, count, first_graph=0, vocabs=None):
         items.append({"concept": concept, "depth": depth, "token": token})
         graphs.append((N, 0, np.array(edges, dtype=np.int32).reshape(-1, 3)))
     return items, graphs
+
+
+def dep_vocabs(vocab=None):
+    """synth_vocabs() with a relation vocabulary whose strings pair up like the translator's: the arc label of a word (child -> head) is
+    ``d<k>`` and its reverse ``d<k>_r_`` (translator/dependencyGraph.py:30-34), with the ids ``_dep_tree`` gives the two directions."""
+    vs = synth_vocabs(vocab)
+    rv = vs['relation']
+    n_labels = (rv.size - REL_FIRST_LABEL) // 2
+    toks = list(rv._idx2token)
+    for k in range(n_labels):
+        toks[REL_FIRST_LABEL + n_labels + k] = "d%d" % k          # child -> head: what extract.py reads from the treebank
+        toks[REL_FIRST_LABEL + k] = "d%d_r_" % k                  # head -> child
+    rv._idx2token = toks
+    rv._token2idx = {t: i for i, t in enumerate(toks)}
+    return vs
+
+
+def make_dep_trees(name, count, first_graph=0, vocabs=None):
+    """A pool of ``count`` synthetic dependency trees of a BASELINE config ("C3") for the LOADER path (gtos_amd.data.DependencyLoader ->
+    batchify_dependency): the same tree family as make_batch(kind="dep") (same seeds, same generator), as the 4-tuples translator/
+    extract.py's reader yields -- (arc labels, 1-based heads with 0 = root, source tokens, target tokens), all strings of ``vocabs``
+    (``dep_vocabs()``)."""
+    c = CONFIGS[name]
+    assert c["kind"] == "dep", name
+    vocabs = vocabs or dep_vocabs()
+    sizes = {k: v.size for k, v in vocabs.items()}
+    n_labels = (sizes["relation"] - REL_FIRST_LABEL) // 2
+    lab_cdf = _zipf_table(n_labels)
+    c_cdf, p_cdf = _zipf_table(sizes["concept"] - 3), _zipf_table(sizes["predictable_token"] - 3)
+    rv = vocabs["relation"]
+    trees = []
+    for g in range(count):
+        rng = SplitMix64(c["id"] * 10 ** 6 + first_graph + g)
+        N, T = c["N"], c["T"]
+        adj = _dep_tree(rng, N, n_labels, lab_cdf)
+        head, dep = [0] * N, [rv.idx2token(REL_FIRST_LABEL + n_labels)] * N        # the root's label is never used (head 0: no arc)
+        for u in range(N):
+            for v, lab in adj[u]:
+                if v > u:                                  # u is v's head (a word attaches to an EARLIER node of the right frontier)
+                    head[v] = u + 1
+                    dep[v] = rv.idx2token(lab + n_labels)  # the child -> head label; adj[u] holds the head -> child one
+        tok = vocabs["concept"].idx2token((3 + _zipf(rng, c_cdf, N)).tolist())
+        tgt = vocabs["predictable_token"].idx2token((3 + _zipf(rng, p_cdf, T - 1)).tolist())
+        trees.append((dep, head, tok, tgt))
+    return trees

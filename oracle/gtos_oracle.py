@@ -37,8 +37,21 @@ VocabSpec = namedtuple("VocabSpec", ["size", "padding_idx"])
 NEG_INF = float("-inf")
 
 
-def _drop(x, p, training):
-    return F.dropout(x, p=p, training=training) if (training and p > 0) else x
+# Mask injection (tests only): MASK_HOOK(tag, x) -> a keep mask (bool / 0-1 tensor broadcastable to x) or None.  With a hook, a tagged
+# dropout site applies x * keep / (1 - p) instead of drawing from torch's generator, so that a test can hand the oracle exactly the masks
+# the product's counter-based hash draws (tests/test_hip_parity.py: the RelationEncoder's training-mode function, reference masks per
+# (path, position) and the opt-in trie-shared ones).  Without a hook nothing changes.
+MASK_HOOK = None
+
+
+def _drop(x, p, training, tag=None):
+    if not (training and p > 0):
+        return x
+    if MASK_HOOK is not None and tag is not None:
+        keep = MASK_HOOK(tag, x)
+        if keep is not None:
+            return x * keep.to(x.dtype) / (1.0 - p)
+    return F.dropout(x, p=p, training=True)
 
 
 # --------------------------------------------------------------------------------------
@@ -322,18 +335,25 @@ class RelationEncoder(nn.Module):
         self.out_proj = nn.Linear(2 * hidden_size, embed_dim)   # default init: reset never called
 
     def forward(self, src_tokens, src_lengths):
-        x = _drop(self.rel_embed(src_tokens), self.dropout, self.training)   # [L,R,rel_dim]
+        emb = self.rel_embed(src_tokens)                                      # [L,R,rel_dim]
+        x = _drop(emb, self.dropout, self.training, "relenc.embed")
+        xr = x                                                                # the reverse direction reads the same dropped embeddings ...
+        if MASK_HOOK is not None and self.training and self.dropout > 0:
+            keep = MASK_HOOK("relenc.embed.reverse", emb)                     # ... unless a test injects a separate mask for it (the trie-
+            if keep is not None:                                              # shared variant draws one per direction)
+                xr = emb * keep.to(emb.dtype) / (1.0 - self.dropout)
         fin = None
         for l in range(self.num_layers):
             p = lambda n, s="": getattr(self.rnn, "%s_l%d%s" % (n, l, s))
             of, hf = gru_direction(x, src_lengths, p("weight_ih"), p("weight_hh"),
                                    p("bias_ih"), p("bias_hh"), False)
-            ob, hb = gru_direction(x, src_lengths, p("weight_ih", "_reverse"), p("weight_hh", "_reverse"),
+            ob, hb = gru_direction(xr, src_lengths, p("weight_ih", "_reverse"), p("weight_hh", "_reverse"),
                                    p("bias_ih", "_reverse"), p("bias_hh", "_reverse"), True)
             fin = torch.cat([hf, hb], 1)
             x = torch.cat([of, ob], 2)
             if l + 1 < self.num_layers:
-                x = _drop(x, self.dropout, self.training)
+                x = _drop(x, self.dropout, self.training, "relenc.layer%d" % l)
+            xr = x
         return self.out_proj(fin)
 
 

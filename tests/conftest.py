@@ -25,6 +25,12 @@ def host_cores():
     return max(1, n)
 
 
+# The loaders' default (index_prep="auto") leaves the relation section of a batch to the GPU when one is visible; the host-side tests of
+# this suite compare the HOST builders' arrays with the reference's, whatever box they run on.  GPU tests that want the device route
+# pass index_prep="device_all" explicitly (tests/test_zzz_hip_relbatch.py, test_loader_default_*).
+os.environ.setdefault("GTOS_INDEX_PREP", "host")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     torch.set_num_threads(host_cores())

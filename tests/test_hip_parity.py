@@ -117,12 +117,22 @@ def test_gemm_pipelined_256_tile(M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(140037, 1024, 512), (131072, 768, 256), (270003, 520, 128), (263000, 264, 736), (132000, 512, 992), (434624, 1024, 512)])
-def test_gemm_short_k_two_workgroups_per_cu(M, N, K):
+def test_gemm_short_k_two_workgroups_per_cu(M, N, K, monkeypatch):
     """Forward-shaped products with a SHORT reduction (K % 32 == 0, 128 <= K < 1024) and >= 1024 tiles of 128 x 256 take
     gemm_p2_nt_kernel (round 4: two pipelined 4-wave workgroups per CU, three 32-k LDS stages each): every remainder of the 3-step
     unrolled loop (K/32 = 16, 8, 4, 23, 31), ragged M / N tails, strided A, fused bias + ReLU, bf16 accumulate, the dropout mask of
     the other kernels; against fp32 matmul of the same bf16 operands.  The same shapes again with GTOS_GEMM_P2=0 semantics are covered by
     test_gemm / test_gemm_256_macro_tile (the dispatcher's other branches)."""
+    import subprocess
+    import sys
+    if os.environ.get("GTOS_GEMM_P2") != "1":
+        # the kernel is an opt-in read once when the library loads: run this case in a child process with the switch set
+        env = dict(os.environ, GTOS_GEMM_P2="1")
+        r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-m", "gpu", "-q", "-p", "no:cacheprovider", "-k",
+                            "test_gemm_short_k_two_workgroups_per_cu and %d-%d-%d" % (M, N, K)], env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, timeout=300)
+        assert r.returncode == 0, r.stdout.decode(errors="replace")[-3000:]
+        return
     from gtos_amd import ops
     torch.manual_seed(M % 83)
     wide = (torch.randn(M, K + 64, device=dev()) * 0.5).to(torch.bfloat16)
@@ -385,7 +395,7 @@ def _rel_frob(a, b):
 @pytest.mark.parametrize("fuse", ["x", "h", "off"])
 def test_relation_encoder_bf16_fused_step_vs_golden(fuse, monkeypatch):
     """bf16 GRU: the fused MFMA step kernel (gtos_gru_step_fwd, input product fused or not) and the GEMM + cell path
-    against the reference vectors; bf16 bar = 2e-2 abs on outputs, 3e-2 relative Frobenius on gradients."""
+    against the reference vectors; bf16 bar = 2e-3 abs on outputs (north_star 1e-2; measured 8.1e-4), 3e-2 relative Frobenius on gradients."""
     from gtos_amd import gru
     from gtos_amd.encoder import RelationEncoder
     from oracle.gtos_oracle import VocabSpec
@@ -397,7 +407,7 @@ def test_relation_encoder_bf16_fused_step_vs_golden(fuse, monkeypatch):
     m.compute_dtype = torch.bfloat16
     out = m(T(g["tokens"]).to(dev()), T(g["lengths"]).to(dev()))
     measured("relation_encoder bf16 fuse=%s vs golden" % fuse, out, T(g["out"]))
-    torch.testing.assert_close(out.float().cpu(), T(g["out"]), rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(out.float().cpu(), T(g["out"]), rtol=0, atol=2e-3)          # measured 8.1e-4 on outputs up to |0.17|
     (out.float() * T(g["wout"]).to(dev())).sum().backward()
     want = sub(g, "grad/")
     for k, p in m.named_parameters():
@@ -438,7 +448,7 @@ def test_gru_fused_step_matches_unfused_many_tiles(monkeypatch):
     for fuse in ("h", "x"):
         got = run(fuse, 0.3)
         measured("gru fused %s vs unfused (p=0.3)" % fuse, got[0], ref[0])
-        torch.testing.assert_close(got[0], ref[0], rtol=2e-2, atol=2e-2)
+        torch.testing.assert_close(got[0], ref[0], rtol=0, atol=1e-2)                     # measured 5.9e-3 on states up to |0.95|
         assert _rel_frob(got[1], ref[1]) < 3e-2
         for a, b in zip(got[2], ref[2]):
             assert _rel_frob(a, b) < 3e-2
@@ -469,7 +479,7 @@ def test_gru_fused_step_matches_unfused_many_tiles(monkeypatch):
     for fuse in ("x", "h"):
         got = run(fuse, 0.0)
         measured("gru fused %s vs oracle (hs=256, outputs O(1))" % fuse, got[0], want)
-        torch.testing.assert_close(got[0], want.detach(), rtol=3e-2, atol=3e-2)
+        torch.testing.assert_close(got[0], want.detach(), rtol=0, atol=1e-2)              # measured 6.1e-3 / 6.8e-3 on states up to |0.93|
         assert _rel_frob(got[1], xs.grad) < 4e-2
         for a, b in zip(got[2], wo):
             assert _rel_frob(a, b.grad) < 4e-2
@@ -811,7 +821,10 @@ def _oracle_slice(cfg_name, B):
 # reference's N(0, 0.02) initialisation).  Rounding each term to 2^-9 leaves an error of 2^-9 * |terms| * sqrt(count)
 # against a true sum that is that much smaller than the terms -- 10-20 % here, with every kernel bit-exact in structure
 # (the fp32 run of the same code agrees with the oracle to 4e-4).
-BF16_GRAD_GLOBAL = 6e-2
+# Measured in round 4 (fp32 residual stream; profiles/r4c_bf16_grad_table.tsv): global 2.67e-2 / 1.87e-2 / 2.04e-2 and worst tensor
+# 0.169 / 0.227 / 0.184 (a relation_in_proj.weight each time, or the character embedding) on C2 B=3 / C5 B=1 / C3 B=3: the bars
+# keep 1.5x / 1.3x of headroom over the largest value.
+BF16_GRAD_GLOBAL = 4e-2
 BF16_GRAD_REL = 0.3
 
 
@@ -1063,6 +1076,7 @@ def test_trie_gru_dropout_is_deterministic_and_backward_matches_forward():
     ref, m = _relenc_pair(bank, length)
     m.compute_dtype = torch.bfloat16
     m.dropout = 0.3
+    m.mask_sharing = "node"                                # the opt-in this test is about (default: masks per (path, position), one row each)
     m.train()
     trie = build_path_trie(bank, length).to(dev())
     wout = torch.randn(bank.shape[1], 64, generator=torch.Generator().manual_seed(1)).to(dev())
@@ -1387,6 +1401,12 @@ def test_bench_two_ranks_on_one_gpu_functional():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 * d["config"]["B_per_gpu"] and d["scaling"] == "weak"
     assert d["value"] > 0 and np.isfinite(d["config"]["loss_last"])
     assert "allreduce_exposed_ms_per_step" in d["config"]
+    # round 4: one command, one line, both scaling modes + what the collective layer saw + the secondary legs
+    assert d["collectives"]["ranks_seen_by_allreduce"] == 2 and d["collectives"]["backend"] == "gloo"
+    o = d["other_scaling"]
+    assert o["scaling"] == "strong" and o["global_batch"] == d["config"]["B_per_gpu"] and o["value"] > 0
+    assert d["reference_masks"]["relation_masks"] == "path" and d["reference_masks"]["ms_per_step"] > 0
+    assert d["loader_in_loop"]["workers_per_gpu"] == 1 and d["loader_in_loop"]["ms_per_step"] > 0, d["loader_in_loop"]
 
 
 def _bench_line(args, env_extra=None, timeout=900):
@@ -1652,3 +1672,162 @@ def test_token_encoder_elementwise_kernels_vs_torch(dtype):
     assert abs(kept - 0.75) < 0.01 and abs(float(dr[:, :46].float().max()) - 1 / 0.75) < 1e-2
     dr.float().sum().backward()
     torch.testing.assert_close(big.grad.float(), dr[:, :Cc].detach().float(), rtol=1e-2, atol=1e-2)   # same mask backward
+
+
+# ------------------------------------------------------------------------------------------------ RelationEncoder, TRAINING mode (dropout > 0)
+def _hash_keep(seed, idx, p):
+    """numpy restatement of csrc/common.h drop_keep(seed, idx, p): the counter-based mask every kernel regenerates."""
+    M = np.uint64(0xFFFFFFFF)
+
+    def mix32(h):
+        h = h ^ (h >> np.uint64(16)); h = (h * np.uint64(0x7feb352d)) & M
+        h = h ^ (h >> np.uint64(15)); h = (h * np.uint64(0x846ca68b)) & M
+        return h ^ (h >> np.uint64(16))
+    idx = np.asarray(idx).astype(np.uint64)
+    seed = np.uint64(seed)
+    h = mix32((idx & M) ^ (seed & M))
+    h = mix32((h + (idx >> np.uint64(32)) * np.uint64(0x9E3779B9) + (seed >> np.uint64(32))) & M)
+    r = (h >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    return torch.from_numpy(r >= np.float32(p))
+
+
+def _relenc_case(seed=3, R=150, L=6, V=40, hid=64):
+    g = torch.Generator().manual_seed(seed)
+    length = torch.randint(1, L + 1, (R,), generator=g)
+    length[0] = L
+    bank = torch.randint(6, V, (L, R), generator=g)
+    bank[:, 1] = bank[:, 0]                                 # paths 0 and 1: the SAME label sequence (same length), path 2 shares a prefix
+    length[1] = length[0]
+    bank[:3, 2] = bank[:3, 0]
+    for r in range(R):
+        bank[int(length[r]):, r] = 0
+    return bank, length
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_relation_encoder_training_mode_reference_masks_vs_oracle(dtype):
+    """The RelationEncoder's TRAINING-mode function with the reference's dropout semantics (masks per (path, position, channel) on the
+    label embeddings and between the GRU layers, generator/encoder.py:91-92,105) -- the library default, ``mask_sharing="path"``: the HIP
+    path under its counter-based masks against the pinned oracle given EXACTLY those masks (oracle.MASK_HOOK), outputs and every
+    parameter gradient.  p = 0.3; fp32 1e-3, bf16 1e-2 of the output scale."""
+    from gtos_amd import ops
+    from gtos_amd.encoder import RelationEncoder
+    from oracle import gtos_oracle as O
+    bank, length = _relenc_case()
+    L, R = bank.shape
+    V, rel_dim, d, hid, p = 40, 100, 64, 64, 0.3
+    dim_pad = rel_dim + (-rel_dim) % 8
+    torch.manual_seed(5)
+    ref = O.RelationEncoder(O.VocabSpec(V, 0), rel_dim, d, hid, 2, p)
+    with torch.no_grad():
+        for n_, q in ref.named_parameters():
+            if n_.startswith("rnn.weight"):
+                q.mul_(2.0)
+    m = RelationEncoder(O.VocabSpec(V, 0), rel_dim, d, hid, 2, p).to(dev())
+    m.load_state_dict(ref.state_dict())
+    m.compute_dtype = dtype
+    assert m.mask_sharing == "path"                         # the default IS the reference's function
+    m.train(); ref.train()
+    # the seeds the product will draw: embedding dropout first, then the inter-layer dropout of layer 0
+    ops.set_seed(99)
+    s_e, s_y = ops.next_seed(), ops.next_seed()
+    ops.set_seed(99)
+    # packed row of (position t, path r): the module sorts by length (stable, descending) and packs time-major
+    sl, order = torch.sort(length, descending=True, stable=True)
+    rank = torch.empty(R, dtype=torch.long); rank[order] = torch.arange(R)
+    bs = [int((sl > t).sum()) for t in range(L)]
+    offs = np.concatenate([[0], np.cumsum(bs)])
+    row = torch.from_numpy(offs[:L]).view(L, 1) + rank.view(1, R)                     # [L,R] (meaningless past a path's end: masked by lengths)
+
+    def hook(tag, x):
+        if tag == "relenc.embed":
+            idx = row.unsqueeze(-1) * dim_pad + torch.arange(rel_dim)
+            return _hash_keep(s_e, idx.numpy(), p)
+        if tag == "relenc.layer0":
+            idx = row.unsqueeze(-1) * (2 * hid) + torch.arange(2 * hid)
+            return _hash_keep(s_y, idx.numpy(), p)
+        return None
+    wout = torch.randn(R, d, generator=torch.Generator().manual_seed(1))
+    O.MASK_HOOK = hook
+    try:
+        want = ref(bank, length)
+        (want * wout).sum().backward()
+    finally:
+        O.MASK_HOOK = None
+    out = m(bank.to(dev()), length.to(dev()))
+    (out.float() * wout.to(dev())).sum().backward()
+    measured("relation_encoder TRAIN p=0.3 reference masks %s vs oracle" % dtype, out, want)
+    scale = float(want.abs().max())
+    tol = 1e-3 if dtype == torch.float32 else 1e-2
+    assert float((out.float().cpu() - want).abs().max()) < tol * max(scale, 0.1), (float((out.float().cpu() - want).abs().max()), scale)
+    wg = dict(ref.named_parameters())
+    for k, q in m.named_parameters():
+        e = _rel_frob(q.grad.cpu(), wg[k].grad)
+        assert e < (2e-3 if dtype == torch.float32 else 4e-2), (k, e)
+    # and the masks really are per (path, position): paths 0 and 1 are the same label sequence, their vectors differ under dropout
+    assert float((out[0] - out[1]).abs().max()) > 1e-3
+
+
+def test_relation_encoder_training_mode_trie_shared_masks_vs_oracle():
+    """The opt-in ``mask_sharing="node"`` (masks per trie node, shared by the paths through it; separate embedding masks for the two
+    directions): the trie evaluation under its counter-based masks against the oracle given the SAME masks expanded to (path, position) --
+    so the opt-in is a fully specified function too, not only a statistical claim.  bf16, p = 0.3."""
+    from gtos_amd import ops
+    from gtos_amd.encoder import RelationEncoder
+    from gtos_amd.pathtrie import build_path_trie
+    from oracle import gtos_oracle as O
+    bank, length = _relenc_case()
+    L, R = bank.shape
+    V, rel_dim, d, hid, p = 40, 100, 64, 64, 0.3
+    dim_pad = rel_dim + (-rel_dim) % 8
+    torch.manual_seed(5)
+    ref = O.RelationEncoder(O.VocabSpec(V, 0), rel_dim, d, hid, 2, p)
+    with torch.no_grad():
+        for n_, q in ref.named_parameters():
+            if n_.startswith("rnn.weight"):
+                q.mul_(2.0)
+    m = RelationEncoder(O.VocabSpec(V, 0), rel_dim, d, hid, 2, p).to(dev())
+    m.load_state_dict(ref.state_dict())
+    m.compute_dtype = torch.bfloat16
+    m.mask_sharing = "node"
+    m.train(); ref.train()
+    trie = build_path_trie(bank, length)
+    ops.set_seed(123)
+    se_pf, sy_pf, se_sf, sy_sf = ops.next_seed(), ops.next_seed(), ops.next_seed(), ops.next_seed()
+    ops.set_seed(123)
+    bs = trie.batch_sizes
+    offs = np.concatenate([[0], np.cumsum(bs)])
+    rank = torch.empty(R, dtype=torch.long); rank[trie.seq_order.long()] = torch.arange(R)
+    row = (torch.from_numpy(offs[:len(bs)]).view(-1, 1) + rank.view(1, R)).clamp(max=trie.N - 1)       # [L,R]; rows past a path's end are never used
+    live = torch.arange(len(bs)).view(-1, 1) < length.view(1, R)
+    pn = torch.where(live, trie.row_pf.long()[row], torch.zeros_like(row))
+    sn = torch.where(live, trie.row_sf.long()[row], torch.zeros_like(row))
+
+    def hook(tag, x):
+        if tag == "relenc.embed":
+            return _hash_keep(se_pf, (pn.unsqueeze(-1) * dim_pad + torch.arange(rel_dim)).numpy(), p)
+        if tag == "relenc.embed.reverse":
+            return _hash_keep(se_sf, (sn.unsqueeze(-1) * dim_pad + torch.arange(rel_dim)).numpy(), p)
+        if tag == "relenc.layer0":
+            kf = _hash_keep(sy_pf, (pn.unsqueeze(-1) * hid + torch.arange(hid)).numpy(), p)
+            kb = _hash_keep(sy_sf, (sn.unsqueeze(-1) * hid + torch.arange(hid)).numpy(), p)
+            return torch.cat([kf, kb], -1)
+        return None
+    wout = torch.randn(R, d, generator=torch.Generator().manual_seed(1))
+    O.MASK_HOOK = hook
+    try:
+        want = ref(bank[:len(bs)], length)
+        (want * wout).sum().backward()
+    finally:
+        O.MASK_HOOK = None
+    out = m(bank.to(dev()), length.to(dev()), trie=trie.to(dev()))
+    (out.float() * wout.to(dev())).sum().backward()
+    measured("relation_encoder TRAIN p=0.3 trie-shared masks bf16 vs oracle", out, want)
+    scale = float(want.abs().max())
+    assert float((out.float().cpu() - want).abs().max()) < 1e-2 * max(scale, 0.1)
+    wg = dict(ref.named_parameters())
+    for k, q in m.named_parameters():
+        e = _rel_frob(q.grad.cpu(), wg[k].grad)
+        assert e < 4e-2, (k, e)
+    # the sharing itself: paths 0 and 1 are the same label sequence -> the same nodes -> the same masks -> the same vector
+    assert float((out[0] - out[1]).abs().max()) == 0.0

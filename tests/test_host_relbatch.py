@@ -493,3 +493,19 @@ def test_prefetcher_builds_the_tries_itself_when_the_loader_leaves_them_out(tmp_
     with data.Prefetcher(ld.thunks(), depth=2, workers=1, device_tries=True) as pf:
         first = next(pf)
     assert _same_object(first["relation_trie"], want[0]["relation_trie"]) == []
+
+
+def test_index_prep_auto_resolution(monkeypatch):
+    """The loaders' default: "device_all" only where a GPU (and libgtos_hip.so) is visible, the host builders elsewhere; the
+    environment override; an explicit argument wins."""
+    from gtos_amd import data
+    monkeypatch.delenv("GTOS_INDEX_PREP", raising=False)
+    want = "device_all" if torch.cuda.is_available() else True
+    assert data.resolve_index_prep("auto") == want
+    for env, val in (("host", True), ("device", "device"), ("device_all", "device_all"), ("off", False)):
+        monkeypatch.setenv("GTOS_INDEX_PREP", env)
+        assert data.resolve_index_prep("auto") == val
+        assert data.resolve_index_prep(True) is True and data.resolve_index_prep("device") == "device"
+    monkeypatch.setenv("GTOS_INDEX_PREP", "host")
+    dl = data.DependencyLoader(None, [(["a"], [0], ["x"], ["y"])] * 4, batch_size=2, for_train=False)
+    assert dl.index_prep is True

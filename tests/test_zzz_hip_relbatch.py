@@ -112,3 +112,33 @@ def test_device_all_loader_through_the_prefetcher_equals_the_host_loader():
             assert torch.equal(w[k], g[k].cpu()), k
         assert _same_object(w["relation_index"], g["relation_index"].cpu()) == []
         assert _same_object(w["relation_trie"], g["relation_trie"].to(torch.device("cpu"))) == []
+
+
+def test_loader_default_leaves_the_relation_section_to_the_device_and_the_model_completes_the_batch(monkeypatch):
+    """Round 4: ``AMRLoader(...)`` / ``DependencyLoader(...)`` without an ``index_prep`` argument resolve to "device_all" on a GPU box
+    (the suite pins GTOS_INDEX_PREP=host for the host-side tests; cleared here).  A batch taken straight from the loader -- no
+    Prefetcher -- carries ``relation_graphs``; ``Generator.forward`` builds relation / bank / index / tries on its device and gives the
+    loss of the host-prepared batch (same graphs, same path draws)."""
+    from gtos_amd import data
+    from gtos_amd.config import build_generator
+    from gtos_amd.generator import Generator
+    monkeypatch.delenv("GTOS_INDEX_PREP", raising=False)
+    assert data.resolve_index_prep("auto") == "device_all"
+    vocabs = synth.synth_vocabs()
+    items, graphs = synth.make_amr_items("C1", 16, first_graph=0, vocabs=vocabs)
+    unit = data.AMRLoader.size_of(items[0])
+    dev_ld = data.AMRLoader(vocabs, items, batch_size=8 * unit - unit // 2, for_train=True, rng=random.Random(5), n_threads=1, graphs=graphs)
+    host_ld = data.AMRLoader(vocabs, items, batch_size=8 * unit - unit // 2, for_train=True, rng=random.Random(5), n_threads=1, graphs=graphs,
+                             index_prep=True)
+    assert dev_ld.index_prep == "device_all" and host_ld.index_prep is True
+    m = build_generator(Generator, "C1", dev(), dropout=0.0).to(dev())
+    m.set_compute_dtype(torch.bfloat16)
+    m.train()
+    for bd, bh in zip(dev_ld, host_ld):
+        assert 'relation_graphs' in bd and 'relation' not in bd
+        bd = {k: (v.to(dev()) if hasattr(v, "to") else v) for k, v in bd.items()}
+        loss_d = m(bd)
+        assert 'relation_graphs' not in bd and bd['relation'].is_cuda and 'relation_trie' in bd and 'relation_index' in bd
+        assert torch.equal(bd['relation'].cpu(), bh['relation']) and torch.equal(bd['relation_bank'].cpu(), bh['relation_bank'])
+        loss_h = m({k: (v.to(dev()) if hasattr(v, "to") else v) for k, v in bh.items()})
+        assert abs(float(loss_d) - float(loss_h)) <= 1e-5 * max(1.0, abs(float(loss_h))), (float(loss_d), float(loss_h))
