@@ -490,7 +490,11 @@ class TrieBiGRUFn(torch.autograd.Function):
                 wt_ = weights[base + slot]
                 if wt_.requires_grad and _grad_target(wt_) is None and grads[base + slot] is None:
                     grads[base + slot] = torch.zeros(wt_.shape, dtype=torch.float32, device=dev)
-        d4s = []
+        # Per direction: BPTT steps -> recurrent weight gradient -> the gate-table gradients of BOTH tries (segmented sums over this
+        # direction's d4), then d4, gates and the saved states of the direction are released before the other direction allocates its
+        # own (round 4: at C5 a direction's d4 + gates + states are 49 GB; rounds 2-3 kept both directions' alive until the sums).
+        dGs = [[None, None], [None, None]]                 # [trie side][direction]
+        wis = [l1[0][2], l1[1][2]]
         for d in (0, 1):
             gates, hprev, wi, wh_t = l1[d]
             base = 8 + d * 4
@@ -510,17 +514,20 @@ class TrieBiGRUFn(torch.autograd.Function):
                 _acc_weight_grad(grads, base + 1, w_hh, d4[:, 3 * hs:], hprev, rows=slice(2 * hs, 3 * hs))
                 if want_bias:
                     _acc_bias_grads(grads, base, b_ih, b_hh, bpart.sum(0), hs)
-            d4s.append(d4)
-        # gradient of the per-node input-gate tables: sum of d(xg) = d4[:, :3hs] over the rows of each node, both directions
-        # in one pass per trie
+            # gradient of the per-node input-gate tables: sum of d(xg) = d4[:, :3hs] over the rows of each node
+            # (one pass over both directions -- _seg_rows(..., src2, dst2) -- measured slower: 3.09 vs 2 x 1.33 ms)
+            for s_, side_t in enumerate(sides):
+                dGs[s_][d] = torch.empty((side_t.n_nodes, 3 * hs), dtype=dtp, device=dev)
+                _seg_rows(side_t, d4, 3 * hs, dGs[s_][d])
+            if not use_side:                      # (with the auxiliary stream reading them they stay in `keep` until the join)
+                l1[d] = None
+            del d4, gates, hprev, bpart
         for s_, side_t in enumerate(sides):
-            dG = [torch.empty((side_t.n_nodes, 3 * hs), dtype=dtp, device=dev) for _ in (0, 1)]
-            for d in (0, 1):       # (one pass over both directions -- _seg_rows(..., src2, dst2) -- measured slower: 3.09 vs 2 x 1.33 ms)
-                _seg_rows(side_t, d4s[d], 3 * hs, dG[d])
+            dG = dGs[s_]
             cols = slice(0, hs) if s_ == 0 else slice(hs, 2 * hs)
             with on_side(dG[0], dG[1], src[s_]):
                 for d in (0, 1):
-                    w_ih, wi = weights[8 + d * 4], l1[d][2]
+                    w_ih, wi = weights[8 + d * 4], wis[d]
                     _acc_weight_grad(grads, 8 + d * 4, w_ih, dG[d], src[s_], cols=cols)
                     wt = weight_t(w_ih, wi[:, cols], rows=("cols", s_))                 # [hs, 3hs]
                     if dsrc[s_] is None:
@@ -529,7 +536,7 @@ class TrieBiGRUFn(torch.autograd.Function):
                         gemm(dG[d], wt, trans_b=True, out=dsrc[s_], accumulate=True)
         if use_side:
             main.wait_stream(aux)                  # layer 0 consumes dsrc; everything in `keep` is done with
-        del d4s
+        del dGs
         keep.clear()
         # ---- layer 0 on the tries, deepest level first
         dtab = None

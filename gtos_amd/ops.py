@@ -123,6 +123,18 @@ def defer_side_join(device, keep_alive=None):
         _HELD.setdefault(device, []).extend(keep_alive)
 
 
+def behind_side(device):
+    """Context for launching an asynchronous collective on gradients that deferred side-stream work still writes (the batched
+    relation-projection weight gradient): the launch happens ON the side stream -- after making it wait for the main stream -- so the
+    process group's stream orders the collective behind both, and the main stream is not stalled.  Without pending work: no-op."""
+    import contextlib
+    if device not in _PENDING_SIDE or not torch.cuda.is_available():
+        return contextlib.nullcontext()
+    side = side_stream(device)
+    side.wait_stream(torch.cuda.current_stream(device))
+    return torch.cuda.stream(side)
+
+
 def join_side(device=None):
     """Make the current stream wait for deferred side-stream work (no-op when there is none)."""
     for dev in list(_PENDING_SIDE):
@@ -234,6 +246,17 @@ BATCH_DX = os.environ.get("GTOS_BATCH_DX", "1") != "0"
 # critical path but compete with the HBM-bound attention-backward kernels they run beside (4 x 1.45 ms of GEMM instead of 3.1 ms,
 # attention backward +1.2 ms per step): 66.23 vs 66.09 ms per step on the same box -- no gain, so the single rounding stays.
 DX_CHUNK = int(os.environ.get("GTOS_DX_CHUNK", "0"))
+# ... as long as the slab stays small beside the step's memory (7 GB at C2); above this the layers fall back to one K = 2d product each
+# with a single [R, 2d] output gradient alive at a time (C5: R = 1.88 M, the slab would be 30 GB).
+SLAB_MAX_BYTES = int(os.environ.get("GTOS_SLAB_MAX_GB", "16")) << 30
+# The same slab also gives the layers' relation_in_proj WEIGHT gradients as one product (GradAccumGroup.finish_dw), launched behind the
+# input gradient: round 3's trace shows the eight per-layer products queued in FRONT of it on the side stream (their 128 KB-LDS workgroups
+# cannot start beside the attention-backward kernels, so all eight run when those are done) with the main stream waiting 5.9 ms for the
+# bank's gradient.  MEASURED (round 4, same box, two alternating pairs, profiles/r4f_*): 61.14 / 61.21 ms per step WITH it against
+# 60.67 / 60.55 without -- the main stream does start the RelationEncoder's backward ~3 ms earlier, but the 3.65 TFLOP product then
+# competes with the HBM-bound GRU kernels it was meant to hide behind (its 128 KB-LDS workgroups wait for whole CUs) and the step gets
+# 0.55 ms LONGER: the step is work-conserving, not latency-bound, at this point.  Off by default; GTOS_BATCH_DW=1 enables it.
+BATCH_DW = os.environ.get("GTOS_BATCH_DW", "0") == "1"
 
 
 class GradAccumGroup:
@@ -249,6 +272,8 @@ class GradAccumGroup:
         self.handed = 0           # column blocks handed out
         self.flushed = 0          # column blocks already folded into buf
         self.pieces = []          # (column block, W^T [in, w]) of members whose backward has run and that are not folded in yet
+        self.dw_jobs = []         # (column block, weight parameter, row block or None): members that left their weight gradient to finish_dw
+        self.done_slab = None     # the complete slab, kept for finish_dw after add() has handed the input gradient on
 
     def register(self):
         self.pending += 1
@@ -259,6 +284,8 @@ class GradAccumGroup:
         R, w = like.shape
         if not BATCH_DX or self.members < 2 or like.dtype != torch.bfloat16:
             return None
+        if self.slab is None and R * self.members * w * like.element_size() > SLAB_MAX_BYTES:
+            return None            # (C5: 30 GB for 8 layers; the per-member products with one [R, w] gradient alive at a time instead)
         if self.slab is None:
             self.slab = torch.empty((R, self.members * w), dtype=like.dtype, device=like.device)
             self.width, self.handed = w, 0
@@ -275,8 +302,15 @@ class GradAccumGroup:
         step = self.width * dy2.element_size()
         return off // step if (0 <= off < self.slab.stride(0) * dy2.element_size() and off % step == 0) else None
 
-    def add(self, dy2, wt, shape):
+    def defers_dw(self, dy2):
+        """True when this member's weight gradient can wait for finish_dw(): its output gradient sits in the slab and the slab is
+        consumed in one piece at the end (BATCH_DW, no chunked folds)."""
+        return BATCH_DW and DX_CHUNK == 0 and self._block_of(dy2) is not None
+
+    def add(self, dy2, wt, shape, dw_job=None):
         j = self._block_of(dy2)
+        if j is not None and dw_job is not None:
+            self.dw_jobs.append((j,) + tuple(dw_job))
         if j is not None:
             self.pieces.append((j, wt))
         elif self.buf is None:
@@ -291,8 +325,29 @@ class GradAccumGroup:
         self._flush(final=self.pending == 0)
         if self.pending > 0:
             return None
-        out, self.buf, self.slab, self.pieces, self.flushed = self.buf, None, None, [], 0
+        out, self.done_slab = self.buf, self.slab
+        self.buf, self.slab, self.pieces, self.flushed = None, None, [], 0
         return out.view(shape)
+
+    def finish_dw(self, x2):
+        """The members' weight gradients as ONE product over the slab: dW_all [members*w, in] = slab^T x  (x = the shared input, the
+        relation bank) instead of one [w, R] x [R, in] product per member -- the bank is read once instead of once per layer, the
+        split-K partial tiles of one well-shaped product replace those of L small ones, and (the point) the product no longer sits in
+        front of the input gradient on the side stream: the caller launches it AFTER the main stream has been released behind dX, so it
+        runs beside the RelationEncoder's backward instead of in front of it.  Returns the tensors that must outlive the launches."""
+        jobs, slab, self.dw_jobs, self.done_slab = self.dw_jobs, self.done_slab, [], None
+        if not jobs or slab is None:
+            return []
+        w = self.width
+        lo, hi = min(j for j, _, _ in jobs), max(j for j, _, _ in jobs) + 1
+        blk = slab[:, lo * w:hi * w]
+        dw_all = gemm(blk, x2, trans_a=True, out_dtype=torch.float32, splitk=_splitk((hi - lo) * w, x2.shape[1], x2.shape[0]))
+        for j, weight, rows in jobs:
+            tgt = _grad_target(weight)
+            if rows is not None:
+                tgt = tgt[rows[0]:rows[1]]
+            tgt += dw_all[(j - lo) * w:(j - lo + 1) * w]
+        return [slab, dw_all, x2]
 
     def _fold(self, take):
         """buf (+)= slab[:, consecutive blocks of ``take``] @ cat(their W^T)^T -- one deep-K product, fp32 accumulation inside it."""
@@ -371,15 +426,21 @@ class LinearFn(torch.autograd.Function):
             main, side = torch.cuda.current_stream(dev), side_stream(dev)
             side.wait_stream(main)
             dy2.record_stream(side)
+            later = group.defers_dw(dy2)
             with torch.cuda.stream(side):
-                dx = group.add(dy2, wt, shp)
-                tgt = _grad_target(weight)
-                if rows is not None:
-                    tgt = tgt[rows[0]:rows[1]]
-                gemm(dy2, x2, trans_a=True, out=tgt, accumulate=True, splitk=_splitk(n_out, x2.shape[1], dy2.shape[0]))
+                dx = group.add(dy2, wt, shp, dw_job=(weight, rows) if later else None)
+                if not later:
+                    tgt = _grad_target(weight)
+                    if rows is not None:
+                        tgt = tgt[rows[0]:rows[1]]
+                    gemm(dy2, x2, trans_a=True, out=tgt, accumulate=True, splitk=_splitk(n_out, x2.shape[1], dy2.shape[0]))
             if dx is not None:
-                main.wait_stream(side)
+                main.wait_stream(side)           # the main chain continues behind the input gradient ...
                 dx.record_stream(main)
+                with torch.cuda.stream(side):    # ... and the batched weight gradient runs beside it; the bucket's readers join the side stream
+                    held = group.finish_dw(x2)
+                if held:
+                    defer_side_join(dev, held)
             return dx, None, None, None, None, None, None
         if ctx.needs_input_grad[0]:
             dx = group.add(dy2, wt, shp) if group is not None else gemm(dy2, wt, trans_b=True).view(shp)

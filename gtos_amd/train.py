@@ -99,8 +99,11 @@ class Trainer:
             lo, hi = self.flat.segments[self._launched]
             self._launched += 1
             if hi > lo and self.collective:
-                # async: enqueued on the process group's own stream after the work already on the current stream
-                self._works.append(dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+                # async: enqueued on the process group's own stream after the work already on the current stream -- and, when a
+                # deferred side-stream product still writes into the bucket (ops.GradAccumGroup.finish_dw), behind that stream too,
+                # without stalling this one (ops.behind_side)
+                with ops.behind_side(self.flat.grad.device):
+                    self._works.append(dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
 
     def all_reduce_grads(self):
         """After backward(): launch what backward did not (at least the last segment) and wait for everything."""
