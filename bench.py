@@ -589,6 +589,11 @@ def main():
             if world > 1:
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)       # every rank takes the same decision (the steps hold collectives)
             w_s, el_s = tt.tolist()
+            if prewarm_steps == 0 and not os.environ.get("GTOS_BENCH_KEEP_COLD_CACHE"):
+                # the first steps of a process allocate in a different order than the steady state (lazy workspaces, first-use caches,
+                # autotuned splits) and leave the caching allocator holding blocks the steady state never reuses: hand them back once
+                # (C5: 274 GB reserved for 94 GB allocated otherwise)
+                torch.cuda.empty_cache()
             prewarm_steps += 5
             log("prewarm window %.1f ms/step" % (200.0 * w_s))
             settled = prev is not None and abs(w_s - prev) <= 0.015 * prev
@@ -667,7 +672,10 @@ def main():
             del b2
     # ---- the OTHER dropout-mask mode of the RelationEncoder, same batch, same K steps, right after the timed region (every rank)
     masks_leg = None
-    if not a.no_masks_leg and cd == torch.bfloat16 and not a.fresh_batches:
+    # (N > 1 runs keep to the legs that cannot strand a rank inside a collective: the other scaling mode above; the mask-mode and loader
+    #  legs run at N = 1 -- or everywhere with GTOS_BENCH_ALL_LEGS=1)
+    all_legs = world == 1 or bool(os.environ.get("GTOS_BENCH_ALL_LEGS"))
+    if not a.no_masks_leg and cd == torch.bfloat16 and not a.fresh_batches and all_legs:
         other = "path" if a.relation_masks == "node" else "node"
         set_relation_mask_sharing(model, other)
         for _ in range(3):
@@ -692,7 +700,7 @@ def main():
     # each on a NEW batch from the default loader route (relation section on the device, ONE worker process per GPU).  The headline
     # above is the pre-built batch SURVEY 8d prescribes; this leg says what feeding costs on top of it.
     loader_leg = None
-    if not a.fresh_batches and not a.no_loader_leg and cd == torch.bfloat16 and not a.dense:
+    if not a.fresh_batches and not a.no_loader_leg and cd == torch.bfloat16 and not a.dense and all_legs:
         try:
             asm2 = []
             feed2, info2 = make_feed(a, cfg, rank, B_rank, dev, asm2, free_b)

@@ -34,7 +34,6 @@
 // never mix, so a slice is the same kernel on its own channels.  Same arithmetic, same dropout counters.
 #include "common.h"
 #include <type_traits>
-#include <stdlib.h>
 
 namespace {
 
@@ -158,13 +157,9 @@ __device__ __forceinline__ bool key_dead(const AttnArgs& a, const unsigned char*
 }
 
 // ------------------------------------------------------------------------------------------- forward
-// M0 (round 4): compile-time "no relation operand" (mode 0: the decoder's self / cross attention, T x S = 50 x 50..100).  Those launches are
-// latency-bound, not bandwidth-bound: a wave walks S/4 keys with ONE key per register set in flight, 13-25 dependent L2 round trips for a
-// few KB of K/V (88 us per launch at C2 for 3,200 workgroups).  Without the relation rows a key costs 8 VGPRs instead of 16, so the
-// specialisation keeps FOUR keys per set in flight (two sets: the whole key axis of a decoder launch in 2-4 round trips).
-template <typename T, int LH, bool GEN, bool M0 = false>
-__global__ __launch_bounds__(256, M0 ? 3 : 4) void rel_attn_fwd_kernel(AttnArgs a) {
-    constexpr int U = M0 ? 4 : Unroll<T>::U;
+template <typename T, int LH, bool GEN>
+__global__ __launch_bounds__(256, 4) void rel_attn_fwd_kernel(AttnArgs a) {
+    constexpr int U = Unroll<T>::U;
     __shared__ unsigned char smask[MAXS_LDS];
     __shared__ float red[4][64][10];             // per wave, per lane: m, l, o[8]
     __shared__ float fin[64][2];                 // merged m and 1/l per lane (for the weights pass)
@@ -180,7 +175,7 @@ __global__ __launch_bounds__(256, M0 ? 3 : 4) void rel_attn_fwd_kernel(AttnArgs 
     const T* kb = static_cast<const T*>(a.k) + (int64_t)b * a.ldk + c;
     const T* vb = static_cast<const T*>(a.v) + (int64_t)b * a.ldv + c;
     const T* rel = static_cast<const T*>(a.rel);
-    const int* iq = (!M0 && a.mode == 2) ? a.idx_q + ((int64_t)i * a.B + b) * a.S : nullptr;
+    const int* iq = a.mode == 2 ? a.idx_q + ((int64_t)i * a.B + b) * a.S : nullptr;
     const float keep_scale = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
     const int joff = wv * G + g;                 // this lane group's key inside a slot
 
@@ -192,28 +187,23 @@ __global__ __launch_bounds__(256, M0 ? 3 : 4) void rel_attn_fwd_kernel(AttnArgs 
     // reduced, so every wave always has a set of loads in flight (the un-pipelined loop had none while it computed).
     struct KeySet { Raw8<T> ra[U], rb[U], k[U], v[U]; int tn[U]; };
     auto load_idx = [&](int jb, KeySet& ks) {
-        if constexpr (!M0) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) { const int j = jb + u * KS + joff; ks.tn[u] = (iq && j < a.S) ? iq[j] : 0; }   // bit 31: singleton type
-        }
+        for (int u = 0; u < U; ++u) { const int j = jb + u * KS + joff; ks.tn[u] = (iq && j < a.S) ? iq[j] : 0; }   // bit 31: singleton type
     };
     auto issue = [&](int jb, KeySet& ks) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int j = jb + u * KS + joff;
-            ks.k[u].zero(); ks.v[u].zero();
-            if constexpr (!M0) { ks.ra[u].zero(); ks.rb[u].zero(); }
+            ks.ra[u].zero(); ks.rb[u].zero(); ks.k[u].zero(); ks.v[u].zero();
             if (j < a.S && act) {
                 ks.k[u].load(kb + (int64_t)j * a.B * a.ldk);
                 ks.v[u].load(vb + (int64_t)j * a.B * a.ldv);
-                if constexpr (!M0) {
-                    if (a.mode == 1) {
-                        const T* p = rel + (((int64_t)j * a.T + i) * a.B + b) * (2 * d) + c;
-                        ks.ra[u].load(p); ks.rb[u].load(p + d);
-                    } else if (a.mode == 2) {
-                        const T* p = rel + (int64_t)(ks.tn[u] & 0x7fffffff) * (2 * d) + c;
-                        ks.ra[u].load(p); ks.rb[u].load(p + d);
-                    }
+                if (a.mode == 1) {
+                    const T* p = rel + (((int64_t)j * a.T + i) * a.B + b) * (2 * d) + c;
+                    ks.ra[u].load(p); ks.rb[u].load(p + d);
+                } else if (a.mode == 2) {
+                    const T* p = rel + (int64_t)(ks.tn[u] & 0x7fffffff) * (2 * d) + c;
+                    ks.ra[u].load(p); ks.rb[u].load(p + d);
                 }
             }
         }
@@ -222,18 +212,11 @@ __global__ __launch_bounds__(256, M0 ? 3 : 4) void rel_attn_fwd_kernel(AttnArgs 
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int j = jb + u * KS + joff;
-            float kf[8], vf[8];
-            ks.k[u].get(kf); ks.v[u].get(vf);
+            float ra[8], rb[8], kf[8], vf[8];
+            ks.ra[u].get(ra); ks.rb[u].get(rb); ks.k[u].get(kf); ks.v[u].get(vf);
             float s = 0.f;
-            if constexpr (M0) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) s = fmaf(qf[e], kf[e], s);
-            } else {
-                float ra[8], rb[8];
-                ks.ra[u].get(ra); ks.rb[u].get(rb);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) s = fmaf(qf[e] + ra[e], kf[e] + rb[e], s);
-            }
+            for (int e = 0; e < 8; ++e) s = fmaf(qf[e] + ra[e], kf[e] + rb[e], s);
             s = head_sum<LH>(s) * a.scale;
             const bool dead = (j >= a.S) || key_dead(a, sm, i, j, b);
             if (dead) s = -INFINITY;
@@ -317,9 +300,9 @@ __global__ __launch_bounds__(256, M0 ? 3 : 4) void rel_attn_fwd_kernel(AttnArgs 
 // ------------------------------------------------------------------------------------------- backward, query-major
 // per (i,b): recompute p from lse; dS; dq_i = sum_j scale*dS*(k_j+rb); dense mode writes d_rarb rows;
 // stores pd (post-dropout p) and gs (= scale*dS) for the key-major and bank passes.
-template <typename T, int LH, bool GEN, bool M0 = false>
+template <typename T, int LH, bool GEN>
 __global__ __launch_bounds__(256) void rel_attn_bwd_q_kernel(AttnArgs a) {
-    constexpr int U = M0 ? 4 : Unroll<T>::U;
+    constexpr int U = Unroll<T>::U;
     __shared__ unsigned char smask[MAXS_LDS];
     __shared__ float red[4][64][8];
     __shared__ float redw[4][64];
@@ -335,7 +318,7 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_q_kernel(AttnArgs a) {
     const T* kb = static_cast<const T*>(a.k) + (int64_t)b * a.ldk + c;
     const T* vb = static_cast<const T*>(a.v) + (int64_t)b * a.ldv + c;
     const T* rel = static_cast<const T*>(a.rel);
-    const int* iq = (!M0 && a.mode == 2) ? a.idx_q + row * a.S : nullptr;
+    const int* iq = a.mode == 2 ? a.idx_q + row * a.S : nullptr;
     const float keep_scale = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
 
     float qf[8], dof[8], of[8];
@@ -362,29 +345,24 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_q_kernel(AttnArgs a) {
 
     struct KeySet { Raw8<T> ra[U], rb[U], k[U], v[U]; int tn[U], tw[U]; };   // tn: ids prefetched for the NEXT issue; tw: ids of the rows in flight
     auto load_idx = [&](int jb, KeySet& ks) {
-        if constexpr (!M0) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) { const int j = jb + u * KS + joff; ks.tn[u] = (iq && j < a.S) ? iq[j] : 0; }   // bit 31: singleton type
-        }
+        for (int u = 0; u < U; ++u) { const int j = jb + u * KS + joff; ks.tn[u] = (iq && j < a.S) ? iq[j] : 0; }   // bit 31: singleton type
     };
     auto issue = [&](int jb, KeySet& ks) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int j = jb + u * KS + joff;
-            ks.k[u].zero(); ks.v[u].zero();
-            if constexpr (!M0) { ks.ra[u].zero(); ks.rb[u].zero(); }
+            ks.ra[u].zero(); ks.rb[u].zero(); ks.k[u].zero(); ks.v[u].zero();
             if (j < a.S && act) {
                 ks.k[u].load(kb + (int64_t)j * a.B * a.ldk);
                 ks.v[u].load(vb + (int64_t)j * a.B * a.ldv);
-                if constexpr (!M0) {
-                    if (a.mode == 1) {
-                        const T* p = rel + (((int64_t)j * a.T + i) * a.B + b) * (2 * d) + c;
-                        ks.ra[u].load(p); ks.rb[u].load(p + d);
-                    } else if (a.mode == 2) {
-                        const T* p = rel + (int64_t)(ks.tn[u] & 0x7fffffff) * (2 * d) + c;
-                        ks.ra[u].load(p); ks.rb[u].load(p + d);
-                        ks.tw[u] = ks.tn[u];
-                    }
+                if (a.mode == 1) {
+                    const T* p = rel + (((int64_t)j * a.T + i) * a.B + b) * (2 * d) + c;
+                    ks.ra[u].load(p); ks.rb[u].load(p + d);
+                } else if (a.mode == 2) {
+                    const T* p = rel + (int64_t)(ks.tn[u] & 0x7fffffff) * (2 * d) + c;
+                    ks.ra[u].load(p); ks.rb[u].load(p + d);
+                    ks.tw[u] = ks.tn[u];
                 }
             }
         }
@@ -395,13 +373,7 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_q_kernel(AttnArgs a) {
             const int j = jb + u * KS + joff;
             if (j >= a.S) continue;
             float ra[8], rb[8], kf[8], vf[8];
-            ks.k[u].get(kf); ks.v[u].get(vf);
-            if constexpr (M0) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { ra[e] = 0.f; rb[e] = 0.f; }
-            } else {
-                ks.ra[u].get(ra); ks.rb[u].get(rb);
-            }
+            ks.ra[u].get(ra); ks.rb[u].get(rb); ks.k[u].get(kf); ks.v[u].get(vf);
             float s = 0.f, dpv = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -423,7 +395,7 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_q_kernel(AttnArgs a) {
             float dra[8], drb[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) { dra[e] = gsc * rb[e]; drb[e] = gsc * ra[e]; dq[e] += dra[e]; }
-            if (M0 || !act) {
+            if (!act) {
             } else if (a.mode == 1) {
                 T* p2 = static_cast<T*>(a.d_rel) + (((int64_t)j * a.T + i) * a.B + b) * (2 * d) + c;
                 Vec8<T>::store(p2, dra);
@@ -464,9 +436,9 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_q_kernel(AttnArgs a) {
 
 // ------------------------------------------------------------------------------------------- backward, key-major
 // per (j,b): dv_j = sum_i pd_ij do_i ; dk_j = sum_i gs_ij (q_i + ra_ji); the 4 waves split the queries
-template <typename T, int LH, bool GEN, bool M0 = false>
+template <typename T, int LH, bool GEN>
 __global__ __launch_bounds__(256) void rel_attn_bwd_kv_kernel(AttnArgs a) {
-    constexpr int U = M0 ? 4 : Unroll<T>::U;
+    constexpr int U = Unroll<T>::U;
     __shared__ float red[4][64][16];
     int j, b;
     if (!map_block(a.S, a.B, j, b)) return;
@@ -479,7 +451,7 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_kv_kernel(AttnArgs a) {
     const T* qb = static_cast<const T*>(a.q) + (int64_t)b * a.ldq + c;
     const T* dob = static_cast<const T*>(a.d_o) + (int64_t)b * a.lddo + c;
     const T* rel = static_cast<const T*>(a.rel);
-    const int* ik = (!M0 && a.mode == 2) ? a.idx_k + row * a.T : nullptr;
+    const int* ik = a.mode == 2 ? a.idx_k + row * a.T : nullptr;
     float dk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
     for (int ib = 0; ib < a.T; ib += KS * U) {
@@ -494,10 +466,8 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_kv_kernel(AttnArgs a) {
                 rdo[u].load(dob + (int64_t)i * a.B * a.lddo);
                 const int64_t off = (((int64_t)i * a.S + j) * a.B + b) * a.H + h;
                 pdv[u] = a.pd[off]; gsv[u] = a.gs[off];
-                if constexpr (!M0) {
-                    if (a.mode == 1) rra[u].load(rel + (((int64_t)j * a.T + i) * a.B + b) * (2 * d) + c);
-                    else if (a.mode == 2) rra[u].load(rel + (int64_t)(ik[i] & 0x7fffffff) * (2 * d) + c);
-                }
+                if (a.mode == 1) rra[u].load(rel + (((int64_t)j * a.T + i) * a.B + b) * (2 * d) + c);
+                else if (a.mode == 2) rra[u].load(rel + (int64_t)(ik[i] & 0x7fffffff) * (2 * d) + c);
             }
         }
 #pragma unroll
@@ -684,9 +654,6 @@ int nblocks(int rows, int B) { return rows * B; }
 
 }  // namespace
 
-// A/B switch of the mode-0 specialisation (GTOS_ATTN_M0=0: the generic kernels for mode 0 as in rounds 1-3)
-static const bool g_attn_m0 = !(getenv("GTOS_ATTN_M0") && getenv("GTOS_ATTN_M0")[0] == '0');
-
 static int fill_args(AttnArgs& a, Geo& g, int T_, int S, int B, int H, int d, int mode, float scale, float p_drop, uint64_t seed) {
     a.T = T_; a.S = S; a.B = B; a.H = H; a.d = d; a.mode = mode; a.scale = scale; a.p_drop = p_drop; a.seed = seed;
     if (mode != 0 && T_ != S) return -12;
@@ -715,8 +682,7 @@ extern "C" int gtos_rel_attn_fwd(int dtype, int mode, int T_, int S, int B, int 
             if (dtype == GTOS_BF16) hipLaunchKernelGGL((rel_attn_fwd_kernel<bf16_t, LH, true>), grid, dim3(256), 0, s, a);
             else hipLaunchKernelGGL((rel_attn_fwd_kernel<float, LH, true>), grid, dim3(256), 0, s, a);
         } else {
-            if (dtype == GTOS_BF16 && mode == 0 && g_attn_m0) hipLaunchKernelGGL((rel_attn_fwd_kernel<bf16_t, LH, false, true>), grid, dim3(256), 0, s, a);
-            else if (dtype == GTOS_BF16) hipLaunchKernelGGL((rel_attn_fwd_kernel<bf16_t, LH, false>), grid, dim3(256), 0, s, a);
+            if (dtype == GTOS_BF16) hipLaunchKernelGGL((rel_attn_fwd_kernel<bf16_t, LH, false>), grid, dim3(256), 0, s, a);
             else hipLaunchKernelGGL((rel_attn_fwd_kernel<float, LH, false>), grid, dim3(256), 0, s, a);
         }
         GTOS_CHECK_LAUNCH();
@@ -750,10 +716,6 @@ extern "C" int gtos_rel_attn_bwd(int dtype, int mode, int T_, int S, int B, int 
 #define GTOS_BWD(TT, GG) do { hipLaunchKernelGGL((rel_attn_bwd_q_kernel<TT, LH, GG>), gq, dim3(256), 0, s, a); \
                               hipLaunchKernelGGL((rel_attn_bwd_kv_kernel<TT, LH, GG>), gk, dim3(256), 0, s, a); } while (0)
         if (geo.generic) { if (dtype == GTOS_BF16) GTOS_BWD(bf16_t, true); else GTOS_BWD(float, true); }
-        else if (dtype == GTOS_BF16 && mode == 0 && g_attn_m0) {
-            hipLaunchKernelGGL((rel_attn_bwd_q_kernel<bf16_t, LH, false, true>), gq, dim3(256), 0, s, a);
-            hipLaunchKernelGGL((rel_attn_bwd_kv_kernel<bf16_t, LH, false, true>), gk, dim3(256), 0, s, a);
-        }
         else { if (dtype == GTOS_BF16) GTOS_BWD(bf16_t, false); else GTOS_BWD(float, false); }
 #undef GTOS_BWD
         GTOS_CHECK_LAUNCH();

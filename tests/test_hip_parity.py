@@ -1392,7 +1392,7 @@ def test_bench_two_ranks_on_one_gpu_functional():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(GTOS_ONE_DEVICE="1", GTOS_DIST_BACKEND="gloo")
+    env.update(GTOS_ONE_DEVICE="1", GTOS_DIST_BACKEND="gloo", GTOS_BENCH_ALL_LEGS="1")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "C1", "--steps", "3", "--warmup", "1",
                         "--no-cpu-baseline", "--prewarm-seconds", "1"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -1831,3 +1831,33 @@ def test_relation_encoder_training_mode_trie_shared_masks_vs_oracle():
         assert e < 4e-2, (k, e)
     # the sharing itself: paths 0 and 1 are the same label sequence -> the same nodes -> the same masks -> the same vector
     assert float((out[0] - out[1]).abs().max()) == 0.0
+
+
+def test_batched_relation_projection_weight_gradient_opt_in(monkeypatch):
+    """GTOS_BATCH_DW (opt-in): the eight relation projections' weight gradients as ONE [L*2d, R] x [R, d] product over the
+    gradient slab, launched on the auxiliary stream behind the bank's input gradient -- same gradients as the per-layer products.  A
+    16-graph C2 batch (R > 100,000: the side-stream branch of LinearFn.backward), full model, bf16, dropout 0."""
+    from gtos_amd import ops, synth
+    from gtos_amd.config import build_generator
+    from gtos_amd.generator import Generator
+    from gtos_amd.pathtrie import attach_path_trie
+    from gtos_amd.relindex import attach_relation_index
+    batch, stats = synth.make_config_batch("C2", B=16)
+    assert stats["R"] > ops.BWD_SIDE_MIN_ROWS
+    db = {k: v.to(dev()) for k, v in attach_relation_index(attach_path_trie(batch)).items()}
+    m = build_generator(Generator, "C2", dev(), dropout=0.0).to(dev())
+    m.set_compute_dtype(torch.bfloat16)
+    m.train()
+    res = {}
+    for flag in (False, True):
+        monkeypatch.setattr(ops, "BATCH_DW", flag)
+        m.zero_grad()
+        loss = m(db)
+        loss.backward()
+        ops.join_side()
+        torch.cuda.synchronize()
+        res[flag] = (float(loss), {k: p.grad.detach().float().cpu().clone() for k, p in m.named_parameters()})
+    assert res[True][0] == res[False][0]
+    for k in res[False][1]:
+        a, b = res[True][1][k], res[False][1][k]
+        assert _rel_frob(a, b) < (2e-3 if "relation_in_proj" in k else 1e-2), (k, _rel_frob(a, b))     # (split-K order / atomics differ run to run)
