@@ -499,18 +499,11 @@ __device__ __forceinline__ void dma_wt(const bf16_t* __restrict__ w, int64_t ld,
     }
 }
 
-// Round 4: the k loop is DOUBLE BUFFERED over two separate static LDS stages (hipcc tracks LDS-DMA per LDS object, so the fragment
-// reads of one stage do not wait for the DMA in flight into the other): the operand tiles of k tile t+1 are issued before the MFMAs of
-// k tile t and land while they run, and there is ONE barrier per k tile instead of two.  Before, every one of the 12 k tiles of a
-// workgroup exposed a full L2 / HBM round trip that only the two other resident workgroups could cover (GTOS_GRU_BWD_PIPE=0: that form).
-const bool g_bwd_pipe = !(getenv("GTOS_GRU_BWD_PIPE") && getenv("GTOS_GRU_BWD_PIPE")[0] == '0');
-
-template <bool PIPE>
 __global__ __launch_bounds__(256, 3) void gru_step_bwd_kernel(StepBwdArgs a) {
-    constexpr int STG = A_BYTES + TC * ROWB;                           // 24 KB: 128 operand rows + 64 weight rows, 64 k each
-    __shared__ __attribute__((aligned(16))) char lds0[STG];
-    __shared__ __attribute__((aligned(16))) char lds1[PIPE ? STG : 16];
+    __shared__ __attribute__((aligned(16))) char lds[A_BYTES + TC * ROWB];
     __shared__ float btab[4 * TC];
+    char* As = lds;
+    char* Bs = lds + A_BYTES;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fr = lane & 15, fq = lane >> 4;
     const int hs = a.hs, nC = hs / TC;
@@ -526,55 +519,49 @@ __global__ __launch_bounds__(256, 3) void gru_step_bwd_kernel(StepBwdArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    auto mma = [&](const char* st) {
-        const char* As = st;
-        const char* Bs = st + A_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8_t fa[2], fb[4];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) fa[mt] = *reinterpret_cast<const bf16x8_t*>(As + lds_off(wave * 32 + mt * 16 + fr, ks * 4 + fq));
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) fb[nt] = *reinterpret_cast<const bf16x8_t*>(Bs + lds_off(nt * 16 + fr, ks * 4 + fq));
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
-        }
-    };
-    const bool trie = a.d4_prev && a.sum_idx;
-    const bool have = a.d4_prev && (trie || m0 < a.rows_prev);
-    if (have) {
-        // trie: operand rows through the children-sum indirection (per-lane source addresses computed once); otherwise the packed rows
-        RowSrc src;
-        if (trie) src = row_src(a.d4_prev, 4 * (int64_t)hs, a.rows, m0, wave, lane, a.sum_idx, a.zero_row);
-        auto dma = [&](int kk, char* st) {
+    if (a.d4_prev && a.sum_idx) {
+        // trie: operand rows through the children-sum indirection; the per-lane source addresses are computed once
+        const RowSrc src = row_src(a.d4_prev, 4 * (int64_t)hs, a.rows, m0, wave, lane, a.sum_idx, a.zero_row);
+        for (int kk = 0; kk < 3 * hs; kk += BK) {
             const int ak = kk < 2 * hs ? kk : kk + hs;                 // skip the d n_x block of d4
-            if (trie) dma_rows_at_z(src, ak, st, wave, lane);
-            else dma_rows(a.d4_prev, Z, 4 * (int64_t)hs, a.rows_prev, m0, ak, ak + BK, st, wave, lane);
-            dma_wt(a.wh_t, 3 * (int64_t)hs, c0, kk, st + A_BYTES, wave, lane);
-        };
-        const int kend = 3 * hs;
-        if constexpr (PIPE) {
-            dma(0, lds0);
-            __syncthreads();                                           // (hipcc drains the DMA in front of the barrier)
-            for (int kk = 0; kk < kend; kk += 2 * BK) {
-                if (kk + BK < kend) dma(kk + BK, lds1);                // flies during the MFMAs below
-                mma(lds0);
-                __syncthreads();                                       // tile kk+BK has landed; every wave is done reading lds0
-                if (kk + BK >= kend) break;
-                if (kk + 2 * BK < kend) dma(kk + 2 * BK, lds0);
-                mma(lds1);
-                __syncthreads();
+            dma_rows_at_z(src, ak, As, wave, lane);
+            dma_wt(a.wh_t, 3 * (int64_t)hs, c0, kk, Bs, wave, lane);
+            __syncthreads();
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8_t fa[2], fb[4];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) fa[mt] = *reinterpret_cast<const bf16x8_t*>(As + lds_off(wave * 32 + mt * 16 + fr, ks * 4 + fq));
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) fb[nt] = *reinterpret_cast<const bf16x8_t*>(Bs + lds_off(nt * 16 + fr, ks * 4 + fq));
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
             }
-        } else {
-            for (int kk = 0; kk < kend; kk += BK) {
-                dma(kk, lds0);
-                __syncthreads();
-                mma(lds0);
-                __syncthreads();
+            __syncthreads();
+        }
+    } else if (a.d4_prev && m0 < a.rows_prev) {
+        for (int kk = 0; kk < 3 * hs; kk += BK) {
+            const int ak = kk < 2 * hs ? kk : kk + hs;                 // skip the d n_x block of d4
+            dma_rows(a.d4_prev, Z, 4 * (int64_t)hs, a.rows_prev, m0, ak, ak + BK, As, wave, lane);
+            dma_wt(a.wh_t, 3 * (int64_t)hs, c0, kk, Bs, wave, lane);
+            __syncthreads();
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8_t fa[2], fb[4];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) fa[mt] = *reinterpret_cast<const bf16x8_t*>(As + lds_off(wave * 32 + mt * 16 + fr, ks * 4 + fq));
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) fb[nt] = *reinterpret_cast<const bf16x8_t*>(Bs + lds_off(nt * 16 + fr, ks * 4 + fq));
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
             }
+            __syncthreads();
         }
     } else if (a.bias_part) {
         __syncthreads();                                               // btab zeroed before anyone adds to it
@@ -739,8 +726,7 @@ extern "C" int gtos_gru_step_bwd(int rows, int hs, const void* d4_prev, int rows
     const long long nM = (rows + TM - 1) / TM, nC = hs / TC;
     const long long nblk = ((nM + 7) / 8) * 8 * nC;
     if (nblk > 0x7fffffffLL) return -6;
-    if (g_bwd_pipe) hipLaunchKernelGGL(gru_step_bwd_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, static_cast<hipStream_t>(stream), a);
-    else hipLaunchKernelGGL(gru_step_bwd_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(gru_step_bwd_kernel, dim3((unsigned)nblk), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     GTOS_CHECK_LAUNCH();
     return 0;
 }
