@@ -43,8 +43,8 @@ SIGNATURES = {
     "gtos_colsum": [c_i, c_i, c_i, c_l, c_p, c_p, c_p],
     "gtos_gru_cell_fwd": [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_l, c_p, c_p, c_f, c_u64, c_l, c_p],
     "gtos_gru_step_fwd": [c_i, c_i, c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_p, c_p, c_p, c_l,
-                          c_f, c_u64, c_l, c_p],
-    "gtos_gru_step_bwd": [c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_l, c_p, c_i, c_l, c_p, c_f, c_u64, c_l, c_p, c_i, c_p, c_p, c_p, c_i, c_p],
+                          c_f, c_u64, c_l, c_i, c_p],
+    "gtos_gru_step_bwd": [c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_l, c_p, c_i, c_l, c_p, c_f, c_u64, c_l, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p],
     "gtos_segment_sum_rows": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_p, c_p, c_l, c_p, c_p, c_p],
     "gtos_segment_sum_stream": [c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_i, c_p, c_l, c_p, c_p],
     "gtos_segment_sum_finish": [c_i, c_p, c_p, c_i, c_p, c_l, c_p],

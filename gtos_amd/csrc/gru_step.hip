@@ -40,6 +40,7 @@ struct StepArgs {
     int64_t ld_fin; const int* fin_idx;            // a finished row m goes to h_fin[(fin_idx ? fin_idx[m] : m) * ld_fin + channel]
     float p_drop; uint64_t seed; int64_t drop_base;
     int rows, hs; const void* zeros;
+    int save_hn;                                   // 0: the hn block of `gates` is not written (backward recomputes it: StepBwdArgs.w_hn)
 };
 
 // 128 activation rows x 64 k
@@ -286,7 +287,8 @@ __global__ __launch_bounds__(256, 2) void gru_step_fwd_kernel(StepArgs a) {
             o[i] = (1.f - gz[i]) * gn[i] + gz[i] * hp[i];
         }
         bf16_t* gp = a.gates + (int64_t)m * 4 * hs + cb;
-        st16(gp, gr); st16(gp + hs, gz); st16(gp + 2 * hs, gn); st16(gp + 3 * hs, hn);
+        st16(gp, gr); st16(gp + hs, gz); st16(gp + 2 * hs, gn);
+        if (a.save_hn) st16(gp + 3 * hs, hn);
         bf16_t* hdst = m < a.n_out ? a.h_out + (int64_t)m * hs + cb
                                    : a.h_fin + (int64_t)(a.fin_idx ? a.fin_idx[m] : m) * a.ld_fin + cb;
         st16(hdst, o);
@@ -447,7 +449,8 @@ __global__ __launch_bounds__(256, 1) void gru_l1_fwd_persistent_kernel(StepArgs 
             }
             if (m < a.rows) {
                 bf16_t* gp = a.gates + (int64_t)m * 4 * HS + cb;
-                st16(gp, gr); st16(gp + HS, gz); st16(gp + 2 * HS, gn); st16(gp + 3 * HS, hn);
+                st16(gp, gr); st16(gp + HS, gz); st16(gp + 2 * HS, gn);
+                if (a.save_hn) st16(gp + 3 * HS, hn);
                 bf16_t* hdst = m < a.n_out ? a.h_out + (int64_t)m * HS + cb
                                            : a.h_fin + (int64_t)(a.fin_idx ? a.fin_idx[m] : m) * a.ld_fin + cb;
                 st16(hdst, o);
@@ -477,7 +480,8 @@ struct StepBwdArgs {
     int zero_row;                                  //   sum_idx value that stands for "all zero" (a leaf): nothing is fetched for it
     float p_drop; uint64_t seed; int64_t drop_base;
     int rows, hs; const void* zeros;
-};
+    const bf16_t* w_hn; const float* b_hn;         // optional: rows [2hs, 3hs) of W_hh (K-contiguous, ld hs) and of b_hh: hn = h_prev W_hn^T + b_hn is
+};                                                 //   RECOMPUTED here instead of read from the gates buffer (the forward did not store it)
 
 #define GTOS_DPP(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, true))
 __device__ __forceinline__ float row16_sum(float v) {   // sum over the 16 lanes of a DPP row (lane & 15)
@@ -499,8 +503,14 @@ __device__ __forceinline__ void dma_wt(const bf16_t* __restrict__ w, int64_t ld,
     }
 }
 
+// Round 4, hn recompute (a.w_hn != NULL): the forward leaves the hn block of the gates unwritten -- on this chip a saved byte costs a
+// write at 4.4 TB/s plus a read at 6.2, and hn is 1/4 of the 2 KB a row saves -- and this kernel rebuilds it before everything else:
+// hn[128 rows x 64 channels] = h_prev[128 x hs] W_hn[64 x hs]^T + b_hn on the MFMA (hs/64 more k tiles in front of the 3hs/64 of the
+// state-gradient product), rounded to bf16 exactly like the forward rounded the value it used (same operands, same k order: identical),
+// parked in LDS (a lane reads back only what it wrote), so the register budget and the three workgroups per CU stay.
 __global__ __launch_bounds__(256, 3) void gru_step_bwd_kernel(StepBwdArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[A_BYTES + TC * ROWB];
+    __shared__ __attribute__((aligned(16))) char hn_lds[256 * 2 * 32];            // per lane 2 row blocks x 16 channels bf16 (16 KB)
     __shared__ float btab[4 * TC];
     char* As = lds;
     char* Bs = lds + A_BYTES;
@@ -518,6 +528,38 @@ __global__ __launch_bounds__(256, 3) void gru_step_bwd_kernel(StepBwdArgs a) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    if (a.w_hn) {
+        const RowSrc hsrc = row_src(a.hprev, hs, a.rows, m0, wave, lane, a.hprev_idx);
+        for (int kk = 0; kk < hs; kk += BK) {
+            dma_rows_at(hsrc, Z, kk, hs, As, wave);
+            dma_wt(a.w_hn, hs, c0, kk, Bs, wave, lane);
+            __syncthreads();
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8_t fa[2], fb[4];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) fa[mt] = *reinterpret_cast<const bf16x8_t*>(As + lds_off(wave * 32 + mt * 16 + fr, ks * 4 + fq));
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) fb[nt] = *reinterpret_cast<const bf16x8_t*>(Bs + lds_off(nt * 16 + fr, ks * 4 + fq));
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+        float bn[16];
+        ldf16(a.b_hn + c0 + fq * 16, bn);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { v[i] = acc[mt][i >> 2][i & 3] + bn[i]; acc[mt][i >> 2][i & 3] = 0.f; }
+            st16(reinterpret_cast<bf16_t*>(hn_lds + (threadIdx.x * 2 + mt) * 32), v);          // (st16 rounds to bf16: the forward's rounding)
+        }
+    }
 
     if (a.d4_prev && a.sum_idx) {
         // trie: operand rows through the children-sum indirection; the per-lane source addresses are computed once
@@ -578,7 +620,9 @@ __global__ __launch_bounds__(256, 3) void gru_step_bwd_kernel(StepBwdArgs a) {
         const int m = valid ? m_raw : a.rows - 1;
         float gr[16], gz[16], gn[16], hn[16], hp[16], g[16];
         const bf16_t* gp = a.gates + (int64_t)m * 4 * hs + cb;
-        ld16(gp, gr); ld16(gp + hs, gz); ld16(gp + 2 * hs, gn); ld16(gp + 3 * hs, hn);
+        ld16(gp, gr); ld16(gp + hs, gz); ld16(gp + 2 * hs, gn);
+        if (a.w_hn) ld16(reinterpret_cast<const bf16_t*>(hn_lds + (threadIdx.x * 2 + mt) * 32), hn);
+        else ld16(gp + 3 * hs, hn);
         ld16(a.hprev + (int64_t)(a.hprev_idx ? a.hprev_idx[m] : m) * hs + cb, hp);
         float* dhp = static_cast<float*>(a.dh) + (int64_t)m * a.ld_dh + cb;
         bf16_t* dhb = static_cast<bf16_t*>(a.dh) + (int64_t)m * a.ld_dh + cb;
@@ -654,7 +698,7 @@ extern "C" int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, i
                                  const void* xg, const void* gf, const int* gf_idx, const void* gb, const int* gb_idx,
                                  const void* h_in, const int* h_idx, const void* w_hh, const float* b_hh,
                                  void* h_out, int n_out, void* h_fin, int64_t ld_fin, const int* fin_idx, void* gates, void* y, int64_t ldy,
-                                 float p_drop, uint64_t seed, int64_t drop_base, void* stream) {
+                                 float p_drop, uint64_t seed, int64_t drop_base, int save_hn, void* stream) {
     if (rows <= 0) return 0;
     if (hs <= 0 || hs % TC) return -22;
     if (!h_in || !w_hh || !b_hh || !gates) return -23;
@@ -675,7 +719,7 @@ extern "C" int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, i
     a.h_in = (const bf16_t*)h_in; a.h_idx = h_idx; a.w_hh = (const bf16_t*)w_hh; a.b_hh = b_hh;
     a.h_out = (bf16_t*)h_out; a.n_out = n_out; a.h_fin = (bf16_t*)h_fin; a.gates = (bf16_t*)gates; a.y = (bf16_t*)y; a.ldy = ldy;
     a.ld_fin = ld_fin; a.fin_idx = fin_idx;
-    a.p_drop = p_drop; a.seed = seed; a.drop_base = drop_base; a.rows = rows; a.hs = hs;
+    a.p_drop = p_drop; a.seed = seed; a.drop_base = drop_base; a.rows = rows; a.hs = hs; a.save_hn = save_hn;
     a.zeros = gtos_zero_block();
     if (!a.zeros) return -5;
     const long long nM = (rows + TM - 1) / TM, nC = hs / TC;
@@ -707,10 +751,12 @@ extern "C" int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, i
 extern "C" int gtos_gru_step_bwd(int rows, int hs, const void* d4_prev, int rows_prev, const void* w_hh_t,
                                  const void* gates, const void* hprev, const int* hprev_idx, const void* dy, int64_t ldy, void* dh, int dh_dtype,
                                  int64_t ld_dh, void* d4, float p_drop, uint64_t seed, int64_t drop_base, float* bias_partials,
-                                 int n_partials, void* hprev_out, const int* sum_idx, const void* dh_src, int zero_row, void* stream) {
+                                 int n_partials, void* hprev_out, const int* sum_idx, const void* dh_src, int zero_row,
+                                 const void* w_hn, const float* b_hn, void* stream) {
     if (rows <= 0) return 0;
     if (hs <= 0 || hs % TC) return -22;
-    if (!gates || !hprev || !dh || !d4 || (d4_prev && !w_hh_t)) return -23;
+    if (!gates || !hprev || !dh || !d4 || (d4_prev && !w_hh_t) || (w_hn && !b_hn)) return -23;
+    if ((uintptr_t)w_hn % 16 || (uintptr_t)b_hn % 16) return -25;
     if (bias_partials && n_partials < 1) return -26;
     if (sum_idx && (!dh_src || (uintptr_t)dh_src % 16)) return -23;
     if ((uintptr_t)d4_prev % 16 || (uintptr_t)w_hh_t % 16 || (uintptr_t)gates % 16 || (uintptr_t)hprev % 16 || (uintptr_t)dh % 16 ||
@@ -720,6 +766,7 @@ extern "C" int gtos_gru_step_bwd(int rows, int hs, const void* d4_prev, int rows
     a.gates = (const bf16_t*)gates; a.hprev = (const bf16_t*)hprev; a.hprev_idx = hprev_idx; a.dy = (const bf16_t*)dy; a.ldy = ldy;
     a.dh = dh; a.dh_bf16 = dh_dtype == GTOS_BF16; a.ld_dh = ld_dh; a.d4 = (bf16_t*)d4; a.bias_part = bias_partials; a.n_partials = n_partials;
     a.hp_out = (bf16_t*)hprev_out; a.sum_idx = sum_idx; a.dh_src = dh_src; a.zero_row = sum_idx ? zero_row : -1;
+    a.w_hn = (const bf16_t*)w_hn; a.b_hn = b_hn;
     a.p_drop = p_drop; a.seed = seed; a.drop_base = drop_base; a.rows = rows; a.hs = hs;
     a.zeros = gtos_zero_block();
     if (!a.zeros) return -5;

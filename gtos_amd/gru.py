@@ -40,6 +40,14 @@ FUSE = os.environ.get("GTOS_GRU_FUSE", "x")
 # wave fits beside them.
 SIDE_STREAM = os.environ.get("GTOS_GRU_SIDE", "1") != "0"
 SIDE_MIN_ROWS = 200000          # below this the GEMMs are launch-bound and the stream hand-over costs more than it hides
+# Round 4, the MEASUREMENT behind "recomputing gates does not pay" (rounds 2-3 had rejected it on paper): with GTOS_GRU_RECOMPUTE_HN=1 the
+# fused step kernels do not store hn = W_hn h + b_hn -- the cheapest quarter of the saved gates to rebuild: one [128 x hs] x [64 x hs]^T
+# product more per workgroup, operands the kernel reads anyway -- and the backward step recomputes it on the MFMA (bit-identical: parity
+# tests green under both settings).  C2, same box, alternating: layer-1 forward step 419 / 422 -> 402 / 406 us per launch (-0.3 ms per
+# step), backward step 487 / 483 -> 536 / 539 us (+0.8 ms), training step 61.38 / 61.30 -> 62.12 / 62.18 ms; with the reference's masks
+# (per-row path) 86.2 -> 86.9 ms.  The saved bytes (0.5 KB written + 0.5 KB read per row) are worth less than four more k tiles in a
+# kernel that already sits at the chip's read + write ceiling.  Off by default.
+RECOMPUTE_HN = os.environ.get("GTOS_GRU_RECOMPUTE_HN", "0") == "1"
 
 
 def _step_fwd(A, hs, x, xg, h_in, wi, b_ih, wh, b_hh, h_out, n_out, h_fin, gates, y, y_off_elems, ldy, p, seed, drop_base,
@@ -59,18 +67,20 @@ def _step_fwd_call(A, hs, x, xg, h_in, wi, b_ih, wh, b_hh, h_out, n_out, h_fin, 
          ptr(wi) if x is not None else None, ptr(b_ih) if need_bi else None, ptr(xg),
          ptr(gf), ptr(gf_idx), ptr(gb), ptr(gb_idx), ptr(h_in), ptr(h_idx), ptr(wh), ptr(b_hh),
          ptr(h_out), n_out, ptr(h_fin), hs if h_fin is None else h_fin.stride(0), ptr(fin_idx), ptr(gates), yp, ldy,
-         float(p), seed, drop_base, stream())
+         float(p), seed, drop_base, 0 if RECOMPUTE_HN else 1, stream())
 
 
 def _step_bwd(A, hs, d4_prev, rows_prev, wh_t, gates, hprev, dy_ptr, ldy, dh, d4, p, seed, drop_base, bpart, hprev_idx=None, hp_out=None,
-              sum_idx=None, dh_src=None, zero_row=-1):
-    """``dh``: [rows, hs] or a column block of a wider matrix (row stride passed on); ``hp_out``: [rows, hs] receiving the
+              sum_idx=None, dh_src=None, zero_row=-1, wh=None, b_hh=None):
+    """``wh`` / ``b_hh``: the direction's recurrent weight (compute dtype, [3hs, hs]) and bias -- with RECOMPUTE_HN the kernel rebuilds hn
+    from their n rows.  ``dh``: [rows, hs] or a column block of a wider matrix (row stride passed on); ``hp_out``: [rows, hs] receiving the
     (gathered) entering state rows; ``sum_idx`` / ``dh_src``: per-row source rows of the recurrent operand (in d4_prev) and of the
     incoming state gradient (in dh_src) -- the trie's children-sum indirection."""
     with _Timed("gru_step_bwd_%s" % ("trie" if hprev_idx is not None else "rows"), detail=True, units=A):
         call("gtos_gru_step_bwd", A, hs, ptr(d4_prev), rows_prev if d4_prev is not None else 0, ptr(wh_t), ptr(gates), ptr(hprev),
              ptr(hprev_idx), dy_ptr, ldy, ptr(dh), dt(dh), dh.stride(0), ptr(d4), float(p), seed, drop_base,
-             ptr(bpart), N_BIAS_PARTIALS if bpart is not None else 0, ptr(hp_out), ptr(sum_idx), ptr(dh_src), int(zero_row), stream())
+             ptr(bpart), N_BIAS_PARTIALS if bpart is not None else 0, ptr(hp_out), ptr(sum_idx), ptr(dh_src), int(zero_row),
+             ptr(wh[2 * hs:]) if RECOMPUTE_HN else None, ptr(b_hh[2 * hs:]) if RECOMPUTE_HN else None, stream())
 
 
 def _cell_bwd(A, hs, gates, hprev, dy, dy_off_elems, ldy, dh, dxg, dhg, p, seed, drop_base, bpart):
@@ -189,7 +199,7 @@ class BiGRUFinalFn(torch.autograd.Function):
                         dyp = None if dY is None else dY.data_ptr() + (off * 2 * hs + direction * hs) * dY.element_size()
                         _step_bwd(A, hs, None if prev is None else d4[offs[prev]:], 0 if prev is None else batch_sizes[prev], wh_t,
                                   gates[off:off + A], hprev[off:off + A], dyp, 2 * hs, dh, d4[off:off + A], pl, seed,
-                                  off * 2 * hs + direction * hs, bpart)
+                                  off * 2 * hs + direction * hs, bpart, wh=compute_weight(w_hh, dtp), b_hh=b_hh.detach())
                         prev = t
                     dxg = d4[:, :3 * hs]
                     w_jobs = ((w_hh, d4[:, :2 * hs], hprev, 1, slice(0, 2 * hs)), (w_hh, d4[:, 3 * hs:], hprev, 1, slice(2 * hs, 3 * hs)),
@@ -507,7 +517,8 @@ class TrieBiGRUFn(torch.autograd.Function):
             for t in (range(L - 1, -1, -1) if d == 0 else range(L)):
                 A, off = bs[t], offs[t]
                 _step_bwd(A, hs, None if prev is None else d4[offs[prev]:], 0 if prev is None else bs[prev], wh_t,
-                          gates[off:off + A], hprev[off:off + A], None, hs, dh, d4[off:off + A], 0.0, 0, 0, bpart)
+                          gates[off:off + A], hprev[off:off + A], None, hs, dh, d4[off:off + A], 0.0, 0, 0, bpart,
+                          wh=compute_weight(w_hh, dtp), b_hh=b_hh.detach())
                 prev = t
             with on_side(d4, hprev, bpart):
                 _acc_weight_grad(grads, base + 1, w_hh, d4[:, :2 * hs], hprev, rows=slice(0, 2 * hs))
@@ -582,7 +593,7 @@ class TrieBiGRUFn(torch.autograd.Function):
                         _seg_ranges(mhi - mlo, rng_, dhx, hs, dhx[n + 1 + mlo:])
                     _step_bwd(A, hs, d4x if has_kids else None, n + 1 + nm, wh_t, gates[lo:hi], H, dy.data_ptr() + lo * hs * dy.element_size(),
                               hs, dhx[lo:hi], d4[lo:hi], p_layer, seed_y, lo * hs, bpart, hprev_idx=side.par[lo:hi], hp_out=hp[lo:hi],
-                              sum_idx=side.sum_idx[lo:hi], dh_src=dhx, zero_row=n)
+                              sum_idx=side.sum_idx[lo:hi], dh_src=dhx, zero_row=n, wh=compute_weight(w_hh, dtp), b_hh=b_hh.detach())
                 held = (d4x, dhx, bpart, hp)
             else:                                      # GTOS_GRU_SUMIDX=0: a summed row per node of every level (round-2 form)
                 d4 = torch.empty((n, 4 * hs), dtype=dtp, device=dev)
@@ -600,7 +611,8 @@ class TrieBiGRUFn(torch.autograd.Function):
                         _seg_ranges(A, rng_, d4, 4 * hs, S)
                         _seg_ranges(A, rng_, dhz, hs, dhz[lo:hi])
                     _step_bwd(A, hs, S if has_kids else None, A, wh_t, gates[lo:hi], H, dy.data_ptr() + lo * hs * dy.element_size(), hs,
-                              dhz[lo:hi], d4[lo:hi], p_layer, seed_y, lo * hs, bpart, hprev_idx=side.par[lo:hi], hp_out=hp[lo:hi])
+                              dhz[lo:hi], d4[lo:hi], p_layer, seed_y, lo * hs, bpart, hprev_idx=side.par[lo:hi], hp_out=hp[lo:hi],
+                              wh=compute_weight(w_hh, dtp), b_hh=b_hh.detach())
                 held = (d4, dhz, S, bpart, hp)
             with (on_side(d4, hp, X, bpart) if use_side else contextlib.nullcontext()):
                 _acc_weight_grad(grads, base + 1, w_hh, d4[:, :2 * hs], hp, rows=slice(0, 2 * hs))

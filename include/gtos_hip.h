@@ -195,7 +195,9 @@ int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, int in_dim, 
                       const void* xg, const void* gf, const int* gf_idx, const void* gb, const int* gb_idx,
                       const void* h_in, const int* h_idx, const void* w_hh, const float* b_hh,
                       void* h_out, int n_out, void* h_fin, int64_t ld_fin, const int* fin_idx, void* gates, void* y, int64_t ldy,
-                      float p_drop, uint64_t seed, int64_t drop_base, void* stream);
+                      float p_drop, uint64_t seed, int64_t drop_base, int save_hn, void* stream);
+/* save_hn = 0 (round 4): the hn block of `gates` (columns 3hs..4hs) is left unwritten; gtos_gru_step_bwd then gets w_hn / b_hn = rows
+ * [2hs, 3hs) of W_hh ([hs, hs], K-contiguous) and of b_hh and recomputes hn = h_prev W_hn^T + b_hn on the MFMA, rounded like the forward's. */
 
 /* Fused backward GRU step, bf16 only, hs % 64 == 0 (gru_step.hip).  d4 [rows,4hs] = d r | d z | d n_x | d n_h in ONE
  * buffer (d(xg) = columns 0..3hs, d(hg) = columns 0..2hs and 3hs..4hs).  First adds d(hg) W_hh of the step processed
@@ -213,7 +215,7 @@ int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, int in_dim, 
 int gtos_gru_step_bwd(int rows, int hs, const void* d4_prev, int rows_prev, const void* w_hh_t,
                       const void* gates, const void* hprev, const int* hprev_idx, const void* dy, int64_t ldy, void* dh, int dh_dtype,
                       int64_t ld_dh, void* d4, float p_drop, uint64_t seed, int64_t drop_base, float* bias_partials, int n_partials,
-                      void* hprev_out, const int* sum_idx, const void* dh_src, int zero_row, void* stream);
+                      void* hprev_out, const int* sum_idx, const void* dh_src, int zero_row, const void* w_hn, const float* b_hn, void* stream);
 
 /* Segmented row sums for the trie-evaluated RelationEncoder's backward (generator/encoder.py:93-111 runs every path
  * separately; here the gradient of a shared trie node is the sum over the rows that share it).  bf16 rows, fp32

@@ -187,6 +187,8 @@ class Recorder(object):
         elif name == "gtos_gru_step_bwd":
             (rows, hs, d4_prev, rows_prev, w_hh_t, gates, hprev, hprev_idx, dy, ldy, dh, dh_dtype, ld_dh, d4, p_drop, seed, drop_base,
              bias_partials, n_partials, hprev_out, sum_idx, dh_src, zero_row) = a[:23]
+            self._rows("gtos_gru_step_bwd: w_hn", a[23], hs, hs, hs, 2)
+            self._rows("gtos_gru_step_bwd: b_hn", a[24], 1, hs, hs, 4)
             W = "gtos_gru_step_bwd: "
             es_dh = (4, 2)[dh_dtype]
             self._rows(W + "w_hh_t", w_hh_t if d4_prev is not None else None, hs, 3 * hs, 3 * hs, 2)

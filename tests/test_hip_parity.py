@@ -1477,7 +1477,9 @@ def test_gru_layer1_step_kernel_vs_torch(rows):
     n = torch.tanh(xg[:, 2 * hs:] + r * hn)
     o = (1 - z) * n + z * h.float()
     want = torch.cat([r, z, n, hn], 1)
-    torch.testing.assert_close(gates.float(), want, rtol=2e-2, atol=2e-2)
+    from gtos_amd import gru as _g
+    keep = 4 * hs if not _g.RECOMPUTE_HN else 3 * hs       # (GTOS_GRU_RECOMPUTE_HN=1: the forward leaves the hn block unwritten)
+    torch.testing.assert_close(gates.float()[:, :keep], want[:, :keep], rtol=2e-2, atol=2e-2)
     got_h = torch.cat([h_out[:n_out], h_fin[n_out:]]).float()
     torch.testing.assert_close(got_h, o, rtol=2e-2, atol=2e-2)
     assert float(h_fin[:n_out].float().abs().max()) == 0.0 and float(h_out[n_out:].float().abs().max()) == 0.0
