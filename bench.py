@@ -702,6 +702,10 @@ def main():
     loader_leg = None
     if not a.fresh_batches and not a.no_loader_leg and cd == torch.bfloat16 and not a.dense and all_legs:
         try:
+            # the cache is full of blocks cut for ONE batch's sizes; the loader's batches all differ by a percent.  At C2 that costs
+            # nothing, at C5 (95 GB allocated, 230+ GB cached) the first varying-size steps overflow the device and every step pays a
+            # cache flush (938 ms per step measured, against 225 ms for `--fresh-batches` from a clean start): start the leg clean
+            torch.cuda.empty_cache()
             asm2 = []
             feed2, info2 = make_feed(a, cfg, rank, B_rank, dev, asm2, free_b)
             for _ in range(3):

@@ -9,7 +9,6 @@ exact same function as the reference's ``relation.index_select(0, idx).view(n,n,
 reference's signature (generator.py:119) for callers that bring their own search loop.
 """
 import math
-import os
 
 import torch
 from torch import nn
@@ -22,9 +21,6 @@ from .transformer import Transformer, SinusoidalPositionalEmbedding, SelfAttenti
 from .graph_transformer import GraphTransformer, set_compute_dtype
 from .search import Beam, beam_search
 from .vocab import lists_to_tensor, strings_to_char_tensor
-
-
-CONCEPT_SIDE = os.environ.get("GTOS_CONCEPT_SIDE", "1") != "0"
 
 
 class Generator(nn.Module):
@@ -77,26 +73,9 @@ class Generator(nn.Module):
         if 'relation_graphs' in inp:           # a loader batch whose relation section was left to this device (index_prep="device_all")
             from .data import complete_on_device
             complete_on_device(inp, inp['concept'].device)
-        # The concept encoder (character CNN, highway, embeddings, depth embedding, LayerNorm: ~60 small launches forward, ~120 backward,
-        # each far too small to fill the chip) is independent of the RelationEncoder: in training it runs on the auxiliary stream, so its
-        # forward overlaps the RelationEncoder's and -- autograd runs a node's backward on the stream of its forward -- its backward, the
-        # 1.2 ms tail of a C2 step, runs beside the GRU backward instead of after it (round 4, GTOS_CONCEPT_SIDE=0: on the main stream).
-        side = CONCEPT_SIDE and train and torch.is_grad_enabled() and inp['concept'].is_cuda
-        if side:
-            dev = inp['concept'].device
-            main, aux = torch.cuda.current_stream(dev), ops.side_stream(dev)
-            aux.wait_stream(main)
-            with torch.cuda.stream(aux):
-                concept_repr, concept_mask = self._concepts(inp)
-        else:
-            concept_repr, concept_mask = self._concepts(inp)
+        concept_repr, concept_mask = self._concepts(inp)
         with ops._Timed("relation_encoder_fwd"):
             bank = self.relation_encoder(inp['relation_bank'], inp['relation_length'], trie=inp.get('relation_trie'))   # [R, d]
-        if side:
-            main.wait_stream(aux)
-            concept_repr.record_stream(main)
-            concept_mask.record_stream(main)
-            ops.defer_side_join(dev)           # its weight gradients land in the flat bucket from the auxiliary stream: the bucket's readers join it
         if train and self.grad_sync is not None:
             # everything downstream of these two belongs to gradient segments <= 2 (graph encoder, probe, decoders)
             concept_repr, bank = self.grad_sync.boundary(2, concept_repr, bank)
@@ -132,34 +111,14 @@ class Generator(nn.Module):
                         else ops.relation_gather_mean(bank, inp['relation'], zero_row0=True))
             return self.graph_encoder.get_attn_weights(concept_repr, relation, self_padding_mask=concept_mask)
 
-    def _tokens(self, data):
+    def forward(self, data):
+        concept_repr, concept_mask, probe = self.encode_step(data)
         pos = self.token_position(data['token_in']).to(self.compute_dtype)
         token_repr = self.embed_scale * self.token_encoder(data['token_in'], data['token_char_in']) + pos
         ln = self.token_embed_layer_norm
         token_repr = ops.layer_norm_residual(token_repr, None, ln.weight, ln.bias, 0.0, ln.eps)
         token_repr = F.dropout(token_repr, p=self.dropout, training=self.training)
-        return token_repr, torch.eq(data['token_in'], self.vocabs['token'].padding_idx)
-
-    def forward(self, data):
-        # the token side's input encoder does not depend on the graph side: like the concept encoder (encode_step) it runs on the
-        # auxiliary stream in training, beside the RelationEncoder forward and -- in backward -- beside the GRU backward
-        side = CONCEPT_SIDE and torch.is_grad_enabled() and data['token_in'].is_cuda
-        if side:
-            dev = data['token_in'].device
-            main, aux = torch.cuda.current_stream(dev), ops.side_stream(dev)
-            aux.wait_stream(main)
-            with torch.cuda.stream(aux):
-                token_repr, token_mask = self._tokens(data)
-            tok_ready = torch.cuda.Event()
-            tok_ready.record(aux)
-        concept_repr, concept_mask, probe = self.encode_step(data)
-        if side:
-            main.wait_event(tok_ready)
-            token_repr.record_stream(main)
-            token_mask.record_stream(main)
-            ops.defer_side_join(dev)
-        else:
-            token_repr, token_mask = self._tokens(data)
+        token_mask = torch.eq(data['token_in'], self.vocabs['token'].padding_idx)
         attn_mask = self.self_attn_mask(data['token_in'].size(0))
         concept_repr = concept_repr.contiguous()
         gs = self.grad_sync
