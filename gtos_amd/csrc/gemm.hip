@@ -23,6 +23,7 @@
 //   * XCD-aware tile order (block id % 8 = XCD): an XCD walks the N tiles of an M panel / all tiles of one K split;
 //   * gemm256_nt_kernel: 256x256 macro tile with a two-stage DMA pipeline for deep-K products (see its comment).
 #include "common.h"
+#include "gemm_w4_gen.h"
 #include <stdlib.h>
 
 // 256 bytes of zeros in GLOBAL memory (allocated once per process): target of out-of-range tile loads.  A __device__
@@ -1122,6 +1123,311 @@ int launch_p2(const GemmArgs& a, hipStream_t s) {
     return 0;
 }
 
+// ---- gemm_w4_nt_kernel (round 4, OPT-IN: GTOS_GEMM_W4=1; an experiment that reaches the default kernel's rate, not more): the deep-K
+//      forward shape (the K = L*2d bank-gradient slab: 3.65 TFLOP, 3.2-3.5 ms of every C2 step) on the 256 x 256 tile of
+//      gemm256p_nt_kernel with FOUR waves of 128 x 128 (all 256 accumulation registers of a lane, one wave per SIMD) instead of eight of
+//      128 x 64 -- the shape of the hipBLASLt kernel that reaches 1.33-1.41 PF/s on these products where gemm256p_nt_kernel reaches
+//      1.07-1.19.  Five builds, all bit-checked by tests/test_hip_parity.py::test_gemm_deep_k_one_wave_per_simd:
+//        1. LDS-DMA three 32-k stages ahead, fragments of the next step in a second register set      0.97-1.02 PF/s
+//        2. the same, four stages ahead (the register set as the fifth)                                0.97-1.02
+//        3. global loads into registers two steps ahead, ds_write into two LDS slots                   1.01-1.02
+//        4. 64-k stages = one whole cache line per matrix row and stage (was: half a line twice)       1.00-1.12 (square 8192^3: 0.63 -> 1.05-1.10)
+//        5. A two stages deep in registers, every memory instruction between two MFMAs, one load per
+//           8-MFMA group, non-temporal hint on A                                                       1.05-1.14
+//      with the measuring switches of the kernel (GTOS_GEMM_W4_DBG): MFMAs + barriers alone 1.81-2.06 PF/s; with the LDS traffic
+//      1.59-1.81; with the global loads 1.05-1.19 EVEN WHEN every load hits the L1 (all stages redirected to the lines of stage 0) and
+//      whatever their form (global / buffer / LDS-DMA), depth (1-4 stages) or spacing: a 1 KB wave load costs its wave ~60 cycles in
+//      which it issues nothing else, 16 of them per 128 MFMAs, and with one wave per SIMD nobody else feeds the MFMA pipe meanwhile.
+//      The two-waves-per-SIMD ping-pong of gemm256p_nt_kernel hides about as much as this kernel saves.  Left in the tree as the
+//      measured record of that; profiles/r4w_gemm_w4.txt.
+//      hipcc cannot allocate a 256-register accumulator (it permutes tiles through VGPRs and scratch at the loop header, and the scratch
+//      traffic breaks hand-counted vmcnt waits): the MFMAs name a0..a255 themselves (gemm_w4_gen.h, written by tools/gen_gemm_w4.py;
+//      tools/check_gemm_w4_isa.py checks that the compiler stays out of those registers).
+const bool g_use_w4 = getenv("GTOS_GEMM_W4") && getenv("GTOS_GEMM_W4")[0] == '1';
+const int g_w4_mink = getenv("GTOS_GEMM_W4_MINK") ? atoi(getenv("GTOS_GEMM_W4_MINK")) : 2048;
+
+constexpr int W4_ROW = 128;                                // bytes per staged row: 64 k, one whole cache line per row and stage
+constexpr int W4_A = 256 * W4_ROW;                         // bytes of the A half of a stage (the B half follows)
+constexpr int W4_ST = 2 * W4_A;                            // 64 KB per stage
+
+template <int DBG> __global__ __launch_bounds__(256, 1) void gemm_w4_nt_kernel(GemmArgs a) {
+    // Two LDS slots of one 64-k stage each (stage t in slot t & 1).  A stage row is 128 B = ONE whole cache line per matrix row: with
+    // the 64-byte rows of the 32-k stages of gemm256p_nt_kernel every line is requested twice, in consecutive steps, through a vector
+    // L1 that a step's 64 KB of lines has flushed in between -- measured on this kernel's first builds: MFMAs + barriers alone 1.9-2.06
+    // PF/s, with the LDS traffic 1.54-1.69, with the global loads 0.63-1.02 whatever the prefetch depth (LDS-DMA three or four stages
+    // ahead, or registers two steps ahead).  The stage in flight lives in REGISTERS (16 x 16 B per lane) and reaches the LDS by
+    // ds_write one step after its loads were issued.
+    __shared__ __attribute__((aligned(16))) char st[2 * W4_ST];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int wm = (wave >> 1) * 128, wn = (wave & 1) * 128;
+    const int nN = (a.N + BN2 - 1) / BN2;
+    const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
+    const int m0 = ((sq / nN) * 8 + xcd) * BM2, n0 = (sq % nN) * BN2;
+    if (m0 >= a.M) return;
+    const char* Ab = reinterpret_cast<const char*>(static_cast<const bf16_t*>(a.A) + (int64_t)m0 * a.lda);
+    const char* Bb = reinterpret_cast<const char*>(static_cast<const bf16_t*>(a.B) + (int64_t)n0 * a.ldb);
+    const int amax = a.M - 1 - m0, bmax = a.N - 1 - n0;
+    const uint32_t lda2 = (uint32_t)a.lda * 2u, ldb2 = (uint32_t)a.ldb * 2u;
+    const int nk = a.K / 64;
+    // a wave instruction moves 1 KB = 8 rows x 128 B: lane l -> row l >> 3 of the piece; its 16 B land at lane * 16 of the piece
+    // (physical chunk l & 7) and come from logical chunk (l & 7) ^ (row & 7) of the line.  Wave w owns the 8-row pieces w, w + 4, ...,
+    // w + 28 of each operand's 32.
+    const int drow = lane >> 3;
+    const uint32_t dchunk = (uint32_t)(((lane & 7) ^ drow) << 4);
+    uint32_t goff[16];                                     // pieces 0..7: A, 8..15: B
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        goff[i] = (uint32_t)min((wave + 4 * i) * 8 + drow, amax) * lda2 + dchunk;
+        goff[8 + i] = (uint32_t)min((wave + 4 * i) * 8 + drow, bmax) * ldb2 + dchunk;
+    }
+#define GTOS_LDS_ADDR(p_) ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)(p_))
+    // fragment of 16 rows x 32 k (k half h of the stage): lane (fr, fq) reads logical chunk h * 4 + fq of row fr
+    const uint32_t fsw0 = (uint32_t)(fr * W4_ROW + ((fq ^ (fr & 7)) << 4)), fsw1 = (uint32_t)(fr * W4_ROW + (((4 + fq) ^ (fr & 7)) << 4));
+    const uint32_t lds0 = GTOS_LDS_ADDR(st);
+    const uint32_t wbase = lds0 + (uint32_t)(wave * 1024 + lane * 16);    // + 4096 * i for A piece i, + W4_A + 4096 * i for B piece i
+
+    // the 128 x 128 fp32 wave tile lives in a0..a255, named by the inline assembly of gemm_w4_gen.h (tile (mt, nt) = a[(mt*8+nt)*4 ..]);
+    // the compiler never sees an accumulator value, and must not use an accumulation register of its own in this kernel
+    // (tools/check_gemm_w4_isa.py checks the compiled kernel for that)
+    GTOS_W4_ZERO();
+    bf16x8_t fa[8], fbx[8], fby[8];                        // A fragments: one set, refilled row block by row block; B: two sets
+    // stages in flight, in registers: A two steps deep (set t & 1 holds the lane's 8 pieces of stage t), B one step.  A is the operand
+    // that streams from HBM (in the products this kernel is for, B is a weight matrix that stays in the L2); with one 64 KB stage in
+    // flight per CU the loads set the pace -- all stages redirected to the lines of stage 0 (L1 hits) or of stages 0..7 (L2 hits): 1.8-2.0
+    // PF/s; real addresses: 1.0-1.1.
+    U128 ga0[8], ga1[8], gb[8];
+
+// All memory instructions of the loop are inline assembly, issued where they are written, with the waits written out: hipcc sinks
+// ordinary LDS reads to just before their use and drains lgkmcnt(0) there (four exposed LDS latencies per step in the first build).
+#define GTOS_DSR128(dst_, addr_, imm_) if (DBG != 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst_) : "v"(addr_), "n"(imm_))
+#define GTOS_DSW128(addr_, src_, imm_) if (DBG != 2) asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(addr_), "v"(src_), "n"(imm_) : "memory")
+#define GTOS_GLD128(dst_, off_, base_) if (DBG != 1 && DBG != 2) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst_) : "v"(off_), "s"(base_))
+// A streams through the L2 once per block row: its loads carry the non-temporal hint (worth 0-7 % on the bank-gradient product)
+#define GTOS_GLD128A(dst_, off_, base_) if (DBG != 1 && DBG != 2) asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(dst_) : "v"(off_), "s"(base_))
+#define GTOS_GLD128B(dst_, off_, base_) GTOS_GLD128(dst_, off_, base_)
+// DBG (GTOS_GEMM_W4_DBG, a measuring aid; results are garbage for DBG != 0): 1 = no global loads, 2 = no LDS traffic either (MFMAs +
+// barriers), 4 = every stage loads the k range of stage 0 (L1 hits)
+#define GTOS_W4_KB(s_) (DBG == 4 ? 0 : min((s_), nk - 1) * 128)          /* byte offset of a stage's k range; past the end: dummy re-read */
+#define GTOS_W4_KBA(s_) GTOS_W4_KB(s_)
+#define GTOS_W4_KBB(s_) GTOS_W4_KB(s_)
+#define GTOS_W4_LOAD_A(GA, s_)                                                                                                \
+    {                                                                                                                         \
+        const char* p_ = Ab + GTOS_W4_KBA(s_);                                                                                \
+        GTOS_GLD128A(GA[0], goff[0], p_); GTOS_GLD128A(GA[1], goff[1], p_); GTOS_GLD128A(GA[2], goff[2], p_); GTOS_GLD128A(GA[3], goff[3], p_); \
+        GTOS_GLD128A(GA[4], goff[4], p_); GTOS_GLD128A(GA[5], goff[5], p_); GTOS_GLD128A(GA[6], goff[6], p_); GTOS_GLD128A(GA[7], goff[7], p_); \
+    }
+#define GTOS_W4_LOAD_B(s_)                                                                                                    \
+    {                                                                                                                         \
+        const char* p_ = Bb + GTOS_W4_KBB(s_);                                                                                \
+        GTOS_GLD128B(gb[0], goff[8], p_); GTOS_GLD128B(gb[1], goff[9], p_); GTOS_GLD128B(gb[2], goff[10], p_); GTOS_GLD128B(gb[3], goff[11], p_);   \
+        GTOS_GLD128B(gb[4], goff[12], p_); GTOS_GLD128B(gb[5], goff[13], p_); GTOS_GLD128B(gb[6], goff[14], p_); GTOS_GLD128B(gb[7], goff[15], p_); \
+    }
+#define GTOS_W4_DEP8(F) asm volatile("" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3]), "+v"(F[4]), "+v"(F[5]), "+v"(F[6]), "+v"(F[7]))
+// group mt of the FIRST half step (k half 0 of stage s in fa / fbx): B fragment mt of k half 1 of the same stage into fby; A piece mt
+// and B piece mt of stage s+1 from their registers into the other slot; the load of B piece mt-1 of stage s+2 into the registers
+// written one group earlier; the row block's A fragment of k half 1 over the one just consumed.  Group mt of the SECOND half step
+// (k half 1 of stage s): B fragment mt and A fragment mt of k half 0 of stage s+1, and the load of A piece mt of stage s+3.  One load
+// per group: the four waves of a workgroup run in lock step, and 16 loads per wave inside one half step keep the CU's address unit
+// busy for that whole half step (every wave stalls at its issue), while the other half step sends it nothing.
+// The loads of a step are issued B(s+2) b0..7, then A(s+3) a0..7; at the write of A piece mt the loads that may stay in flight are
+// 7 - mt + B(s+1) + A(s+2) + mt - 1 = 22, at the write of B piece mt 7 - mt + A(s+2) + mt - 1 = 14.
+// Every memory instruction sits between two MFMAs: a wave issues in order, and while it issues memory instructions in a row its SIMD's
+// MFMA pipe, which nobody else feeds in this kernel, runs dry.
+#define GTOS_W4_GROUP0(mt, GA)                                                                                                \
+    {                                                                                                                         \
+        GTOS_W4_MFMA(mt, 0, fa[mt], fbx);                                                                                     \
+        GTOS_DSR128(fby[mt], rb1_, (mt) * 2048);                                                                              \
+        GTOS_W4_MFMA(mt, 1, fa[mt], fbx);                                                                                     \
+        GTOS_VMCNT(22);                                                                                                       \
+        asm volatile("" : "+v"(GA[mt]));                                                                                      \
+        GTOS_DSW128(w_, GA[mt], (mt) * 4096);                                                                                 \
+        GTOS_W4_MFMA(mt, 2, fa[mt], fbx);                                                                                     \
+        GTOS_VMCNT(14);                                                                                                       \
+        asm volatile("" : "+v"(gb[mt]));                                                                                      \
+        GTOS_DSW128(w_, gb[mt], W4_A + (mt) * 4096);                                                                          \
+        GTOS_W4_MFMA(mt, 3, fa[mt], fbx);                                                                                     \
+        if ((mt) > 0) GTOS_GLD128B(gb[(mt) > 0 ? (mt) - 1 : 0], goff[8 + ((mt) > 0 ? (mt) - 1 : 0)], pb_);                    \
+        GTOS_W4_MFMA(mt, 4, fa[mt], fbx);                                                                                     \
+        GTOS_W4_MFMA(mt, 5, fa[mt], fbx);                                                                                     \
+        GTOS_W4_MFMA(mt, 6, fa[mt], fbx);                                                                                     \
+        GTOS_W4_MFMA(mt, 7, fa[mt], fbx);                                                                                     \
+        GTOS_DSR128(fa[mt], ra1_, (mt) * 2048);                                                                               \
+    }
+#define GTOS_W4_GROUP1(mt, GA)                                                                                                \
+    {                                                                                                                         \
+        GTOS_W4_MFMA(mt, 0, fa[mt], fby);                                                                                     \
+        GTOS_DSR128(fbx[mt], nb0_, (mt) * 2048);                                                                              \
+        GTOS_W4_MFMA(mt, 1, fa[mt], fby);                                                                                     \
+        GTOS_GLD128A(GA[mt], goff[mt], pa_);                                                                                  \
+        GTOS_W4_MFMA(mt, 2, fa[mt], fby); GTOS_W4_MFMA(mt, 3, fa[mt], fby); GTOS_W4_MFMA(mt, 4, fa[mt], fby);                 \
+        GTOS_W4_MFMA(mt, 5, fa[mt], fby); GTOS_W4_MFMA(mt, 6, fa[mt], fby); GTOS_W4_MFMA(mt, 7, fa[mt], fby);                 \
+        GTOS_DSR128(fa[mt], na0_, (mt) * 2048);                                                                               \
+    }
+// step s_: k half 0 of stage s_ is in fa / fbx.  First half step: MFMAs on it; k half 1 of stage s_ (slot s_ & 1) into fa / fby; stage
+// s_+1 from the registers (GA = its A set) into slot (s_+1) & 1 (free since the middle of step s_-1); loads of A(s_+3), B(s_+2).
+// Barrier.  Second half step: MFMAs on fa / fby; k half 0 of stage s_+1 into fa / fbx.
+#define GTOS_W4_STEP(s_, GA)                                                                                                  \
+    {                                                                                                                         \
+        const uint32_t cur = lds0 + (uint32_t)(((s_) & 1) * W4_ST), nxt = lds0 + (uint32_t)((((s_) + 1) & 1) * W4_ST);        \
+        const uint32_t ra1_ = cur + (uint32_t)(wm * W4_ROW) + fsw1, rb1_ = cur + (uint32_t)(W4_A + wn * W4_ROW) + fsw1;      \
+        const uint32_t na0_ = nxt + (uint32_t)(wm * W4_ROW) + fsw0, nb0_ = nxt + (uint32_t)(W4_A + wn * W4_ROW) + fsw0;      \
+        const uint32_t w_ = wbase + (uint32_t)((((s_) + 1) & 1) * W4_ST);                                                     \
+        const char* pa_ = Ab + GTOS_W4_KBA((s_) + 3);                                                                         \
+        const char* pb_ = Bb + GTOS_W4_KBB((s_) + 2);                                                                         \
+        GTOS_W4_GROUP0(0, GA);                                                                                                \
+        __builtin_amdgcn_s_waitcnt(0xc47f);                /* lgkmcnt(4): the refill of fa[7], the previous half step's last read */ \
+        GTOS_W4_GROUP0(1, GA);                                                                                                \
+        GTOS_W4_GROUP0(2, GA);                                                                                                \
+        GTOS_W4_GROUP0(3, GA);                                                                                                \
+        GTOS_W4_GROUP0(4, GA);                                                                                                \
+        GTOS_W4_GROUP0(5, GA);                                                                                                \
+        GTOS_W4_GROUP0(6, GA);                                                                                                \
+        GTOS_W4_GROUP0(7, GA);                                                                                                \
+        GTOS_GLD128B(gb[7], goff[15], pb_);                                                                                   \
+        __builtin_amdgcn_s_waitcnt(0xc17f);                /* lgkmcnt(1): all but the refill of fa[7] -- own writes, fby, fa[0..6] */ \
+        GTOS_W4_DEP8(fa);                                                                                                     \
+        GTOS_W4_DEP8(fby);                                                                                                    \
+        __builtin_amdgcn_s_barrier();                      /* stage s_+1 is in its slot for everybody */                       \
+        GTOS_W4_GROUP1(0, GA);                                                                                                  \
+        __builtin_amdgcn_s_waitcnt(0xc27f);                /* lgkmcnt(2): the refill of fa[7] */                               \
+        GTOS_W4_GROUP1(1, GA);                                                                                                  \
+        GTOS_W4_GROUP1(2, GA);                                                                                                  \
+        GTOS_W4_GROUP1(3, GA);                                                                                                  \
+        GTOS_W4_GROUP1(4, GA);                                                                                                  \
+        GTOS_W4_GROUP1(5, GA);                                                                                                  \
+        GTOS_W4_GROUP1(6, GA);                                                                                                  \
+        GTOS_W4_GROUP1(7, GA);                                                                                                  \
+        __builtin_amdgcn_s_waitcnt(0xc17f);                /* lgkmcnt(1) */                                                    \
+        GTOS_W4_DEP8(fa);                                                                                                     \
+        GTOS_W4_DEP8(fbx);                                                                                                    \
+    }
+
+    GTOS_W4_LOAD_A(ga0, 0);
+    GTOS_W4_LOAD_B(0);
+    GTOS_VMCNT(0);
+    GTOS_W4_DEP8(ga0);
+    GTOS_W4_DEP8(gb);
+    GTOS_DSW128(wbase, ga0[0], 0); GTOS_DSW128(wbase, ga0[1], 4096); GTOS_DSW128(wbase, ga0[2], 8192); GTOS_DSW128(wbase, ga0[3], 12288);
+    GTOS_DSW128(wbase, ga0[4], 16384); GTOS_DSW128(wbase, ga0[5], 20480); GTOS_DSW128(wbase, ga0[6], 24576); GTOS_DSW128(wbase, ga0[7], 28672);
+    GTOS_DSW128(wbase, gb[0], W4_A); GTOS_DSW128(wbase, gb[1], W4_A + 4096); GTOS_DSW128(wbase, gb[2], W4_A + 8192); GTOS_DSW128(wbase, gb[3], W4_A + 12288);
+    GTOS_DSW128(wbase, gb[4], W4_A + 16384); GTOS_DSW128(wbase, gb[5], W4_A + 20480); GTOS_DSW128(wbase, gb[6], W4_A + 24576); GTOS_DSW128(wbase, gb[7], W4_A + 28672);
+    // the load queue the first step expects: A(1), B(1), A(2)
+    GTOS_W4_LOAD_A(ga1, 1);
+    GTOS_W4_LOAD_B(1);
+    GTOS_W4_LOAD_A(ga0, 2);
+    __builtin_amdgcn_s_waitcnt(0xc07f);                    // own writes of stage 0 done
+    __builtin_amdgcn_s_barrier();
+    {
+        const uint32_t ra_ = lds0 + (uint32_t)(wm * W4_ROW) + fsw0, rb_ = lds0 + (uint32_t)(W4_A + wn * W4_ROW) + fsw0;
+        GTOS_DSR128(fbx[0], rb_, 0); GTOS_DSR128(fbx[1], rb_, 2048); GTOS_DSR128(fbx[2], rb_, 4096); GTOS_DSR128(fbx[3], rb_, 6144);
+        GTOS_DSR128(fbx[4], rb_, 8192); GTOS_DSR128(fbx[5], rb_, 10240); GTOS_DSR128(fbx[6], rb_, 12288); GTOS_DSR128(fbx[7], rb_, 14336);
+        GTOS_DSR128(fa[0], ra_, 0); GTOS_DSR128(fa[1], ra_, 2048); GTOS_DSR128(fa[2], ra_, 4096); GTOS_DSR128(fa[3], ra_, 6144);
+        GTOS_DSR128(fa[4], ra_, 8192); GTOS_DSR128(fa[5], ra_, 10240); GTOS_DSR128(fa[6], ra_, 12288); GTOS_DSR128(fa[7], ra_, 14336);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    GTOS_W4_DEP8(fa);
+    GTOS_W4_DEP8(fbx);
+    int s = 0;
+    for (; s + 2 <= nk; s += 2) {                          // A(s+1) lives in register set (s+1) & 1
+        GTOS_W4_STEP(s, ga1);
+        GTOS_W4_STEP(s + 1, ga0);
+    }
+    if (s < nk) GTOS_W4_STEP(s, ga1);
+    GTOS_VMCNT(0);                                         // the dummy prefetches of the last steps
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    // the destination registers of those last loads and reads stay allocated until here: an output nobody reads is a dead value to the
+    // compiler, which hands its registers to something else while the load is still in flight (the odd-stage-count tail of the second
+    // build put a B fragment where a prefetch landed)
+    GTOS_W4_DEP8(ga0); GTOS_W4_DEP8(ga1); GTOS_W4_DEP8(gb); GTOS_W4_DEP8(fa); GTOS_W4_DEP8(fbx); GTOS_W4_DEP8(fby);
+    __syncthreads();                                       // every wave is done with the slots: they become the output staging
+#undef GTOS_W4_STEP
+#undef GTOS_W4_GROUP1
+#undef GTOS_W4_GROUP0
+#undef GTOS_W4_DEP8
+#undef GTOS_W4_LOAD_B
+#undef GTOS_W4_LOAD_A
+#undef GTOS_GLD128B
+#undef GTOS_GLD128A
+#undef GTOS_W4_KBB
+#undef GTOS_W4_KBA
+#undef GTOS_W4_KB
+#undef GTOS_GLD128
+#undef GTOS_DSW128
+#undef GTOS_DSR128
+#undef GTOS_LDS_ADDR
+
+    // ---- epilogue (bf16 out): 32 rows x 128 columns of the wave tile at a time through the wave's own stage slot
+    bf16_t* C = static_cast<bf16_t*>(a.C);
+    const float keep_scale = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
+    constexpr int CP = 128 * 2 + 16;
+    char* cs = st + wave * 16384;                          // 32 x 272 B per wave
+    const bool plain = !a.bias && !a.relu && !(a.p_drop > 0.f);
+    // MFMA results are not interlocked against v_accvgpr_read issued from inline assembly: the loop's last MFMAs retire first
+    asm volatile("s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15");
+    auto put = [&](int mt, int nt, float v0, float v1, float v2, float v3) {
+        float v[4] = {v0, v1, v2, v3};
+        if (!plain) {
+            const int m = m0 + wm + mt * 16 + fr, n = n0 + wn + nt * 16 + fq * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (a.bias && n + i < a.N) v[i] += a.bias[n + i];
+                if (a.relu) v[i] = fmaxf(v[i], 0.f);
+                if (a.p_drop > 0.f)
+                    v[i] = drop_keep(a.seed, (uint64_t)m * (uint64_t)a.N + (uint64_t)(n + i), a.p_drop) ? v[i] * keep_scale : 0.f;
+            }
+        }
+        *reinterpret_cast<uint2*>(cs + ((mt & 1) * 16 + fr) * CP + (nt * 16 + fq * 4) * 2) = make_uint2(pack_bf(v[0], v[1]), pack_bf(v[2], v[3]));
+    };
+    auto flush = [&](int q4) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0)
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int row = pass * 4 + (lane >> 4), col = (lane & 15) * 8;
+            const int m = m0 + wm + q4 * 32 + row, n = n0 + wn + col;
+            if (m >= a.M || n >= a.N) continue;
+            uint4 val = *reinterpret_cast<const uint4*>(cs + row * CP + col * 2);
+            bf16_t* cp = C + (int64_t)m * a.ldc + n;
+            if (n + 8 <= a.N) {
+                if (a.accumulate) {
+                    const uint4 old = *reinterpret_cast<const uint4*>(cp);
+                    val = make_uint4(pack_bf(lo_bf(val.x) + lo_bf(old.x), hi_bf(val.x) + hi_bf(old.x)),
+                                     pack_bf(lo_bf(val.y) + lo_bf(old.y), hi_bf(val.y) + hi_bf(old.y)),
+                                     pack_bf(lo_bf(val.z) + lo_bf(old.z), hi_bf(val.z) + hi_bf(old.z)),
+                                     pack_bf(lo_bf(val.w) + lo_bf(old.w), hi_bf(val.w) + hi_bf(old.w)));
+                }
+                *reinterpret_cast<uint4*>(cp) = val;
+            } else {
+                const bf16_t* e = reinterpret_cast<const bf16_t*>(cs + row * CP + col * 2);
+                for (int i = 0; i < 8 && n + i < a.N; ++i) {
+                    float o = bf2f(e[i]);
+                    if (a.accumulate) o += bf2f(cp[i]);
+                    cp[i] = f2bf(o);
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+    };
+    GTOS_W4_TILES_0(put); flush(0);
+    GTOS_W4_TILES_1(put); flush(1);
+    GTOS_W4_TILES_2(put); flush(2);
+    GTOS_W4_TILES_3(put); flush(3);
+}
+
+int launch_w4(const GemmArgs& a, hipStream_t s) {
+    const long long nMt = (a.M + BM2 - 1) / BM2, nNt = (a.N + BN2 - 1) / BN2;
+    const long long nblk = ((nMt + 7) / 8) * 8 * nNt;
+    if (nblk > 0x7fffffffLL) return -6;
+    static const int dbg = getenv("GTOS_GEMM_W4_DBG") ? atoi(getenv("GTOS_GEMM_W4_DBG")) : 0;
+    if (dbg == 1) hipLaunchKernelGGL(gemm_w4_nt_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, s, a);
+    else if (dbg == 2) hipLaunchKernelGGL(gemm_w4_nt_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, s, a);
+    else if (dbg == 4) hipLaunchKernelGGL(gemm_w4_nt_kernel<4>, dim3((unsigned)nblk), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(gemm_w4_nt_kernel<0>, dim3((unsigned)nblk), dim3(256), 0, s, a);
+    GTOS_CHECK_LAUNCH();
+    return 0;
+}
+
 int launch256p(const GemmArgs& a, hipStream_t s) {
     const long long nMt = (a.M + BM2 - 1) / BM2, nNt = (a.N + BN2 - 1) / BN2;
     const long long nblk = ((nMt + 7) / 8) * 8 * nNt;
@@ -1353,6 +1659,9 @@ extern "C" int gtos_gemm(int in_dtype, int out_dtype, int transA, int transB, in
         // big forward-shaped products go to the 256x256 macro tile (enough tiles to give every CU several)
         const long long t256 = ((long long)(M + BM2 - 1) / BM2) * ((N + BN2 - 1) / BN2);
         // K % 32 == 0 and enough macro tiles: the software-pipelined 256x256 kernel
+        if (g_use_w4 && !transA && transB && a.vecA && a.vecB && a.vecC && splitk == 1 && N >= 256 && K % 64 == 0 && K >= g_w4_mink &&
+            lda < (1 << 22) && ldb < (1 << 22) && t256 >= 512)
+            return launch_w4(a, s);
         if (g_use_pipe && !transA && transB && a.vecA && a.vecB && a.vecC && splitk == 1 && N >= 256 && N <= g_max_npipe && K % 32 == 0 &&
             lda < (1 << 22) && ldb < (1 << 22) &&
             ((t256 >= 512 && K >= g_min_kpipe) || (t256 <= g_pipe_small_max && K >= 256 && M >= 256)))

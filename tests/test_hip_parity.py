@@ -163,6 +163,47 @@ def test_gemm_short_k_two_workgroups_per_cu(M, N, K, monkeypatch):
     assert bool((slab[:, :128] == 7).all()) and bool((slab[:, 128 + N:] == 7).all())
 
 
+@pytest.mark.parametrize("M,N,K", [(131072, 512, 2048), (131000, 520, 2112), (140000, 256, 2176), (131073, 768, 4160)])
+def test_gemm_deep_k_one_wave_per_simd(M, N, K):
+    """Forward-shaped products with a DEEP reduction (K >= 2048) take gemm_w4_nt_kernel when GTOS_GEMM_W4=1 (round 4: four waves of
+    128 x 128 on the 256 x 256 tile, 64-k stages through registers, accumulators named by hand): even and odd stage counts (K/64 = 32,
+    33, 34, 65), ragged M / N tails, strided A, the epilogues; against fp32 matmul."""
+    import subprocess
+    import sys
+    if os.environ.get("GTOS_GEMM_W4") != "1":
+        env = dict(os.environ, GTOS_GEMM_W4="1")            # read once when the library loads: a child process with the switch set
+        r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-m", "gpu", "-q", "-p", "no:cacheprovider", "-k",
+                            "test_gemm_deep_k_one_wave_per_simd and %d-%d-%d" % (M, N, K)], env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, timeout=300)
+        assert r.returncode == 0, r.stdout.decode(errors="replace")[-3000:]
+        return
+    from gtos_amd import ops
+    torch.manual_seed(M % 83)
+    wide = (torch.randn(M, K + 64, device=dev()) * 0.5).to(torch.bfloat16)
+    a = wide[:, 64:]
+    b = (torch.randn(N, K, device=dev()) * 0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device=dev())
+    want = a.float() @ b.float().t()
+    tol = dict(rtol=2e-2, atol=0.01 * K ** 0.5)
+    got = ops.gemm(a, b, trans_b=True)
+    torch.testing.assert_close(got.float(), want, **tol)
+    ulp = (got.float() - want).abs() / want.abs().clamp_min(1.0)
+    assert float(ulp.max()) < 1.0 / 64, float(ulp.max())
+    got = ops.gemm(a.contiguous(), b, trans_b=True, bias=bias, relu=True)
+    torch.testing.assert_close(got.float(), torch.relu(want + bias), **tol)
+    base = torch.randn(M, N, device=dev()).to(torch.bfloat16)
+    out = base.clone()
+    ops.gemm(a, b, trans_b=True, out=out, accumulate=True)
+    torch.testing.assert_close(out.float(), want + base.float(), rtol=3e-2, atol=0.02 * K ** 0.5)
+    small = ops.gemm(a[:300], b, trans_b=True, p_drop=0.3, seed=77)
+    big = ops.gemm(a, b, trans_b=True, p_drop=0.3, seed=77)
+    assert torch.equal(small == 0, big[:300] == 0)
+    slab = torch.full((M, N + 256), 7.0, device=dev(), dtype=torch.bfloat16)
+    ops.gemm(a, b, trans_b=True, out=slab[:, 128:128 + N])
+    torch.testing.assert_close(slab[:, 128:128 + N].float(), want, **tol)
+    assert bool((slab[:, :128] == 7).all()) and bool((slab[:, 128 + N:] == 7).all())
+
+
 @pytest.mark.parametrize("M,N,K,sk", [(768, 512, 300040, 43), (256, 256, 100000, 64), (1024, 512, 6464, 12), (512, 264, 70008, 16)])
 def test_gemm_weight_gradient_long_k_splitk(M, N, K, sk):
     """dW = A^T B with K in the hundreds of thousands: transpose-read operand path + split-K partial tiles reduced

@@ -34,6 +34,7 @@ SHAPES = [  # name, ta, tb, M, N, K, out dtype
     ("tn_m1024_Kbig TN", True, False, 1024, 512, 2497000, torch.float32),
     ("tn_m768_Ksml  TN", True, False, 768, 512, 434624, torch.float32),
     ("deepK       NT", False, True, 434624, 1024, 4096, torch.bfloat16),     # same tile count as rel_proj, 8x the k tiles
+    ("deepK_dbank NT", False, True, 434624, 512, 8192, torch.bfloat16),     # the bank-gradient slab product of a C2 step
     ("square8k    NT", False, True, 8192, 8192, 8192, torch.bfloat16),
     # t(K) at the relation-projection shape: intercept = output write + launch, slope = k-loop rate
     ("ksweep32    NT", False, True, 434624, 1024, 32, torch.bfloat16),
