@@ -93,6 +93,9 @@ def parse():
                          "layer 0 once per trie node, layer-1 input gates from per-node tables).  The headline runs 'node' and says so; the "
                          "other mode is measured right after the timed region and reported as `reference_masks` / `node_masks`")
     ap.add_argument("--no-masks-leg", action="store_true", help="skip the leg that measures the other --relation-masks mode")
+    ap.add_argument("--graph-leg", action="store_true",
+                    help="after the timed region (N = 1): the same step replayed from a hipGraph (train.GraphedStep).  Opt-in: on ROCm "
+                         "7.2 the capture of the multi-stream C2 step crashes inside hipStreamEndCapture (C1 captures and replays)")
     ap.add_argument("--no-loader-leg", action="store_true",
                     help="skip the loader-in-the-loop leg that follows the timed region of the default (pre-built batch) run")
     ap.add_argument("--device-relations", action="store_true",
@@ -740,6 +743,41 @@ def main():
             loader_leg = {"error": "%s: %s" % (type(e).__name__, e)}
             if world > 1:
                 raise
+    # ---- the same step replayed from a hipGraph (train.GraphedStep): what the Python-paced launch sequence costs.  One process, the
+    # pre-built batch, the trie evaluation of the RelationEncoder (node masks or no dropout); the capture is not part of the figure.
+    graph_leg = None
+    if (world == 1 and not a.fresh_batches and a.graph_leg and cd == torch.bfloat16 and not a.dense
+            and a.relation_masks == "node"):
+        from gtos_amd.train import GraphedStep
+        gs = None
+        try:
+            ops.PROFILE = None
+            t_c = time.perf_counter()
+            gs = GraphedStep(trainer, batch)
+            capture_s = time.perf_counter() - t_c
+            for _ in range(3):
+                gs()
+            torch.cuda.synchronize()
+            t_g = time.perf_counter()
+            gp = [gs() for _ in range(a.steps)]
+            torch.cuda.synchronize()
+            dt_g = time.perf_counter() - t_g
+            gl = [p_.value() for p_ in gp]
+            graph_leg = {"ms_per_step": round(1e3 * dt_g / a.steps, 3), "steps": a.steps, "value": round(stats["B"] * a.steps / dt_g, 1),
+                         "unit": "graphs/s", "vs_eager_launches": round(dt_g / elapsed, 4), "capture_s": round(capture_s, 2),
+                         "losses_distinct": len(set(round(x, 6) for x in gl if x is not None)),
+                         "note": "one torch.cuda.CUDAGraph replay per step on the pre-built batch; dropout masks new in every replay "
+                                 "(device-side seed epoch, gtos_set_seed_epoch); parameters keep training across the replays"}
+        except Exception as e:                  # noqa: BLE001  (the leg must never cost the headline line)
+            graph_leg = {"error": "%s: %s" % (type(e).__name__, str(e)[:400])}
+        finally:
+            if gs is not None:
+                gs.close()
+            else:
+                try:
+                    ops.set_seed_epoch(None)
+                except Exception:               # noqa: BLE001
+                    pass
     # per-rank view: wall time of the timed region and the compute-stream stall on gradient collectives, gathered on rank 0
     table = torch.zeros((world, 2), device=dev, dtype=torch.float64)
     table[rank, 0], table[rank, 1] = my_elapsed, comm_exposed
@@ -793,7 +831,7 @@ def main():
                           "loader": loader_info,
                           "prewarm_steps": prewarm_steps, "device_memory": memory_info,
                           "loss_first": losses[0], "loss_last": losses[-1]},
-               "roofline": roofline, "components": components, "loader_in_loop": loader_leg,
+               "roofline": roofline, "components": components, "loader_in_loop": loader_leg, "hipgraph_replay": graph_leg,
                ("reference_masks" if a.relation_masks == "node" else "node_masks"): masks_leg,
                "other_scaling": other_scaling, "collectives": rccl_info}
         if world == 1 and not a.no_cpu_baseline:

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgtos_hip.so")
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 c_p, c_i, c_l, c_f, c_u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_uint64
 
@@ -67,6 +67,7 @@ SIGNATURES = {
     "gtos_cast_f32_to_bf16": [c_l, c_p, c_p, c_p],
     "gtos_transpose_batch_bf16": [c_i, c_p, c_p, c_i, c_p, c_p, c_p],
     "gtos_step_control": [c_i, c_p, c_p, c_p, c_i, c_i, c_p, c_p],
+    "gtos_set_seed_epoch": [c_p],
     "gtos_adam_step_ctl": [c_l, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_f, c_f, c_p, c_f, c_p, c_p],
 }
 

@@ -69,6 +69,25 @@ __device__ __forceinline__ float rand01(uint64_t seed, uint64_t idx) {
 }
 __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, float p) { return rand01(seed, idx) >= p; }
 
+// A hipGraph replay freezes every kernel argument, the dropout seeds included.  When a training step is replayed from a graph the host
+// registers one device word (gtos_set_seed_epoch) that the step bumps once per replay, and every dropout kernel folds it into its
+// seed on entry.  Not registered (the default): seeds are used as passed.  One copy of the pointer per translation unit (the library
+// is built without relocatable device code); gtos_set_seed_epoch sets them together.
+static __device__ const unsigned long long* g_seed_epoch = nullptr;
+__device__ __forceinline__ uint64_t live_seed(uint64_t seed) {
+    const unsigned long long* p = g_seed_epoch;
+    return p ? seed + (uint64_t)(*p) * 0x9E3779B97F4A7C15ull : seed;
+}
+#define GTOS_SEED_EPOCH_SETTER(tu)                                                                                   \
+    extern "C" __attribute__((visibility("hidden"))) int gtosi_##tu##_set_seed_epoch(const void* p) {               \
+        return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_seed_epoch), &p, sizeof(p));                                      \
+    }
+extern "C" __attribute__((visibility("hidden"))) int gtosi_gemm_set_seed_epoch(const void* p);
+extern "C" __attribute__((visibility("hidden"))) int gtosi_rel_attn_set_seed_epoch(const void* p);
+extern "C" __attribute__((visibility("hidden"))) int gtosi_rowops_set_seed_epoch(const void* p);
+extern "C" __attribute__((visibility("hidden"))) int gtosi_gru_step_set_seed_epoch(const void* p);
+extern "C" __attribute__((visibility("hidden"))) int gtosi_tokenenc_set_seed_epoch(const void* p);
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -221,6 +221,7 @@ __device__ __forceinline__ void store_tile(char* __restrict__ lds, const U128 (&
 // interleaving hides the load latency, and a 64x64 wave tile needs a third fewer LDS fragment reads per MFMA.
 template <typename T, typename TO, bool TA, bool TB, bool FAST, int NTH, int STAGES>
 __global__ __launch_bounds__(NTH, 4) void gemm_kernel(GemmArgs a) {
+    if (a.p_drop > 0.f) a.seed = live_seed(a.seed);
     constexpr int BK = GemmCfg<T>::BK;
     constexpr int NT = NTH, WAVES_N = TCfg<NTH>::WAVES_N, WTN = TCfg<NTH>::WTN, NTW = TCfg<NTH>::NTW, ITERS = TCfg<NTH>::ITERS;
     constexpr int STAGE = (BM + BN) * ROWB;                       // 32 KB
@@ -592,6 +593,7 @@ constexpr int BM2 = 256, BN2 = 256, STAGE2 = (BM2 + BN2) * ROWB;
 const bool g_use256 = !(getenv("GTOS_GEMM256") && getenv("GTOS_GEMM256")[0] == '0');
 
 __global__ __launch_bounds__(512, 2) void gemm256_nt_kernel(GemmArgs a) {
+    if (a.p_drop > 0.f) a.seed = live_seed(a.seed);
     extern __shared__ __attribute__((aligned(16))) char lds2[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fr = lane & 15, fq = lane >> 4;
@@ -746,6 +748,7 @@ const int g_pipe_small_max = getenv("GTOS_GEMM_PIPE_SMALL") ? atoi(getenv("GTOS_
 #define GTOS_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))
 
 __global__ __launch_bounds__(512) void gemm256p_nt_kernel(GemmArgs a) {
+    if (a.p_drop > 0.f) a.seed = live_seed(a.seed);
     __shared__ __attribute__((aligned(16))) char st0[ST3];
     __shared__ __attribute__((aligned(16))) char st1[ST3];
     __shared__ __attribute__((aligned(16))) char st2[ST3];
@@ -919,6 +922,7 @@ const bool g_use_p2 = getenv("GTOS_GEMM_P2") && getenv("GTOS_GEMM_P2")[0] == '1'
 const int g_p2_maxk = getenv("GTOS_GEMM_P2_MAXK") ? atoi(getenv("GTOS_GEMM_P2_MAXK")) : 1023;
 
 __global__ __launch_bounds__(256, 2) void gemm_p2_nt_kernel(GemmArgs a) {
+    if (a.p_drop > 0.f) a.seed = live_seed(a.seed);
     __shared__ __attribute__((aligned(16))) char a0[P2_AS];
     __shared__ __attribute__((aligned(16))) char a1[P2_AS];
     __shared__ __attribute__((aligned(16))) char a2[P2_AS];
@@ -1151,6 +1155,7 @@ constexpr int W4_A = 256 * W4_ROW;                         // bytes of the A hal
 constexpr int W4_ST = 2 * W4_A;                            // 64 KB per stage
 
 template <int DBG> __global__ __launch_bounds__(256, 1) void gemm_w4_nt_kernel(GemmArgs a) {
+    if (a.p_drop > 0.f) a.seed = live_seed(a.seed);
     // Two LDS slots of one 64-k stage each (stage t in slot t & 1).  A stage row is 128 B = ONE whole cache line per matrix row: with
     // the 64-byte rows of the 32-k stages of gemm256p_nt_kernel every line is requested twice, in consecutive steps, through a vector
     // L1 that a step's 64 KB of lines has flushed in between -- measured on this kernel's first builds: MFMAs + barriers alone 1.9-2.06
@@ -1678,3 +1683,5 @@ extern "C" int gtos_gemm(int in_dtype, int out_dtype, int transA, int transB, in
     if (in_dtype == GTOS_F32 && out_dtype == GTOS_F32)   return launch<float, float>(a, transA, transB, s);
     return -1;
 }
+
+GTOS_SEED_EPOCH_SETTER(gemm)

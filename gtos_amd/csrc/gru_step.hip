@@ -188,6 +188,7 @@ __device__ __forceinline__ void ldf16(const float* p, float (&v)[16]) {
 // MODE 0: input gates read from xg; 1: x W_ih^T computed here (HAS_X); 2: input gates gathered from two bf16 tables
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void gru_step_fwd_kernel(StepArgs a) {
+    if (a.p_drop > 0.f) a.seed = live_seed(a.seed);
     constexpr bool HAS_X = MODE == 1;
     constexpr int NG = HAS_X ? 4 : 3;           // accumulator groups: r, z, (n_x,) n_h
     constexpr int GH = HAS_X ? 3 : 2;           // group of the h-part of n
@@ -509,6 +510,7 @@ __device__ __forceinline__ void dma_wt(const bf16_t* __restrict__ w, int64_t ld,
 // state-gradient product), rounded to bf16 exactly like the forward rounded the value it used (same operands, same k order: identical),
 // parked in LDS (a lane reads back only what it wrote), so the register budget and the three workgroups per CU stay.
 __global__ __launch_bounds__(256, 3) void gru_step_bwd_kernel(StepBwdArgs a) {
+    if (a.p_drop > 0.f) a.seed = live_seed(a.seed);
     __shared__ __attribute__((aligned(16))) char lds[A_BYTES + TC * ROWB];
     __shared__ __attribute__((aligned(16))) char hn_lds[256 * 2 * 32];            // per lane 2 row blocks x 16 channels bf16 (16 KB)
     __shared__ float btab[4 * TC];
@@ -777,3 +779,5 @@ extern "C" int gtos_gru_step_bwd(int rows, int hs, const void* d4_prev, int rows
     GTOS_CHECK_LAUNCH();
     return 0;
 }
+
+GTOS_SEED_EPOCH_SETTER(gru_step)

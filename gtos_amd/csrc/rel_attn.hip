@@ -159,6 +159,7 @@ __device__ __forceinline__ bool key_dead(const AttnArgs& a, const unsigned char*
 // ------------------------------------------------------------------------------------------- forward
 template <typename T, int LH, bool GEN>
 __global__ __launch_bounds__(256, 4) void rel_attn_fwd_kernel(AttnArgs a) {
+    if (a.p_drop > 0.f) a.seed = live_seed(a.seed);
     constexpr int U = Unroll<T>::U;
     __shared__ unsigned char smask[MAXS_LDS];
     __shared__ float red[4][64][10];             // per wave, per lane: m, l, o[8]
@@ -302,6 +303,7 @@ __global__ __launch_bounds__(256, 4) void rel_attn_fwd_kernel(AttnArgs a) {
 // stores pd (post-dropout p) and gs (= scale*dS) for the key-major and bank passes.
 template <typename T, int LH, bool GEN>
 __global__ __launch_bounds__(256) void rel_attn_bwd_q_kernel(AttnArgs a) {
+    if (a.p_drop > 0.f) a.seed = live_seed(a.seed);
     constexpr int U = Unroll<T>::U;
     __shared__ unsigned char smask[MAXS_LDS];
     __shared__ float red[4][64][8];
@@ -757,3 +759,5 @@ extern "C" int gtos_rel_attn_bwd_bank(int dtype, int n, int B, int H, int d,
         return 0;
     });
 }
+
+GTOS_SEED_EPOCH_SETTER(rel_attn)

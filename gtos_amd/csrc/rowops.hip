@@ -19,6 +19,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int d, const TX* 
                                                      float p_drop, uint64_t seed, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float eps, TY* __restrict__ y, bf16_t* __restrict__ y2,
                                                      float* __restrict__ mean, float* __restrict__ rstd) {
+    if (p_drop > 0.f) seed = live_seed(seed);
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -82,6 +83,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int d, const TY* 
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, TX* __restrict__ dx, TR* __restrict__ dr,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    if (p_drop > 0.f) seed = live_seed(seed);
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
     const float ks = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
@@ -237,6 +239,7 @@ template <typename T>
 __global__ void gru_fwd_kernel(int rows, int hs, const T* __restrict__ xg, const T* __restrict__ hg, T* __restrict__ h,
                                T* __restrict__ y, int64_t ldy, T* __restrict__ hprev_save, T* __restrict__ gates,
                                float p_drop, uint64_t seed, int64_t drop_base) {
+    if (p_drop > 0.f) seed = live_seed(seed);
     const int hv = hs / 8;
     const float ks = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < (int64_t)rows * hv; t += (int64_t)gridDim.x * blockDim.x) {
@@ -277,6 +280,7 @@ __global__ void gru_bwd_kernel(int rows, int hs, const T* __restrict__ gates, co
                                const T* __restrict__ dy, int64_t ldy, float* __restrict__ dh,
                                T* __restrict__ dxg, T* __restrict__ dhg, float p_drop, uint64_t seed, int64_t drop_base,
                                float* __restrict__ bias_part) {
+    if (p_drop > 0.f) seed = live_seed(seed);
     // bias_part (optional, [gridDim.x, 4*hs] fp32, owned block-row-wise): running column sums of d(r), d(z), d(n_x),
     // d(n_h) -- the bias gradients of the GRU -- accumulated here instead of re-reading dxg/dhg in 8 colsum passes.
     // Needs 256 % (hs/8) == 0 so that a thread keeps the same 8 channels over its grid-stride rows.
@@ -380,6 +384,7 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(int64_t P, int K, int 
 template <typename T>
 __global__ void embed_rows_fwd_kernel(int64_t n, int dim, int dim_pad, const int64_t* __restrict__ tok, const float* __restrict__ table,
                                       T* __restrict__ out, float p_drop, uint64_t seed) {
+    if (p_drop > 0.f) seed = live_seed(seed);
     const int vpr = dim_pad / 8;
     const float ks = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n * vpr; t += (int64_t)gridDim.x * blockDim.x) {
@@ -405,6 +410,7 @@ template <typename T, bool use_lds>
 __global__ __launch_bounds__(256) void embed_rows_bwd_kernel(int64_t n, int V, int dim, int dim_pad, const int64_t* __restrict__ tok,
                                                              const T* __restrict__ dout, float* __restrict__ dtable, float p_drop,
                                                              uint64_t seed, int64_t rows_per_block, float* __restrict__ partials) {
+    if (p_drop > 0.f) seed = live_seed(seed);
     // small tables (the relation / character vocabularies) are accumulated in a private LDS copy first; large ones take
     // fp32 atomics in global memory directly (many rows: little contention)
     extern __shared__ float tab[];
@@ -1161,4 +1167,15 @@ extern "C" int gtos_transpose_batch_bf16(int n_mat, const int64_t* desc, const i
     return 0;
 }
 
-extern "C" int gtos_abi_version(void) { return 17; }
+extern "C" int gtos_set_seed_epoch(const void* epoch) {
+    int rc = gtosi_gemm_set_seed_epoch(epoch);
+    if (!rc) rc = gtosi_rel_attn_set_seed_epoch(epoch);
+    if (!rc) rc = gtosi_rowops_set_seed_epoch(epoch);
+    if (!rc) rc = gtosi_gru_step_set_seed_epoch(epoch);
+    if (!rc) rc = gtosi_tokenenc_set_seed_epoch(epoch);
+    return rc;
+}
+
+extern "C" int gtos_abi_version(void) { return 18; }
+
+GTOS_SEED_EPOCH_SETTER(rowops)

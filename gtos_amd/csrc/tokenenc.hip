@@ -108,6 +108,7 @@ __global__ void max_relu_bwd_kernel(int64_t n8, int L, int F, const T* __restric
 template <typename T>
 __global__ void token_row_fwd_kernel(int64_t n8, int Cc, int Ct, int Cp, const T* __restrict__ feat, const int64_t* __restrict__ tok,
                                      const float* __restrict__ table, T* __restrict__ out, float p_drop, uint64_t seed) {
+    if (p_drop > 0.f) seed = live_seed(seed);
     const int p8 = Cp / 8;
     const float ks = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
@@ -132,6 +133,7 @@ __global__ void token_row_fwd_kernel(int64_t n8, int Cc, int Ct, int Cp, const T
 template <typename T>
 __global__ void token_row_bwd_kernel(int64_t n8, int Cc, int Ct, int Cp, const T* __restrict__ dout, const int64_t* __restrict__ tok,
                                      T* __restrict__ dfeat, float* __restrict__ dtable, float p_drop, uint64_t seed) {
+    if (p_drop > 0.f) seed = live_seed(seed);
     const int p8 = Cp / 8;
     const float ks = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
@@ -220,3 +222,5 @@ extern "C" int gtos_token_row_bwd(int dtype, int64_t N, int Cc, int Ct, int Cp, 
     else GTOS_TE_LAUNCH(token_row_bwd_kernel, float, n8, Cc, Ct, Cp, (const float*)dout, tok, (float*)dfeat, dtable, p_drop, seed);
     return 0;
 }
+
+GTOS_SEED_EPOCH_SETTER(tokenenc)

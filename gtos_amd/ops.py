@@ -48,6 +48,20 @@ def set_seed(s):
     _seed_state[0] = s & 0xFFFFFFFFFFFFFFFF
 
 
+_SEED_EPOCH = [None]
+
+
+def set_seed_epoch(epoch):
+    """Register (or, with None, clear) the device int64 word every dropout kernel folds into its seed: gtos_set_seed_epoch.  A
+    captured training step (train.GraphedStep) freezes the host-side seeds above; the step increments this word once per replay, so
+    every replay draws new masks (and the forward and the backward of one replay the same ones).  The tensor is kept alive here."""
+    if epoch is not None and not (epoch.is_cuda and epoch.dtype == torch.int64 and epoch.numel() == 1):
+        raise ValueError("the seed epoch is one int64 on the GPU")
+    torch.cuda.synchronize()
+    call("gtos_set_seed_epoch", None if epoch is None else ptr(epoch))
+    _SEED_EPOCH[0] = epoch
+
+
 def _row_major(t):
     """2-D view usable by the GEMM: unit inner stride; returns (tensor, leading dimension)."""
     if t.dim() != 2:

@@ -188,6 +188,74 @@ class Trainer:
         return res.value() if sync else res
 
 
+class GraphedStep:
+    """A training step captured once as a hipGraph and replayed: for the configurations whose step is a thousand small launches (C1:
+    9.7 ms of Python-paced launches around ~3 ms of kernels), when consecutive batches have the SAME shapes -- the captured launch
+    plan, every tensor size and every trie level count belongs to the batch it was captured on.
+
+        gs = GraphedStep(trainer, batch)        # warm-up steps + capture (a few real steps on ``batch``)
+        pending = gs()                          # one replay = one training step on ``batch``; PendingLoss like Trainer.step(sync=False)
+
+    New token / concept contents may be copied INTO the captured batch's tensors between replays; a batch with another relation
+    structure (other trie level sizes, another number of distinct paths) is another launch plan and needs its own capture.
+
+    Dropout: kernel arguments are frozen by the capture, so the library's kernels fold a device-side epoch into their seeds
+    (ops.set_seed_epoch) which the captured step increments first thing; torch's own generator is graph-safe by itself.
+    Limits: one process (world_size 1: the gradient collectives' host-side bookkeeping is not captured); the RelationEncoder's
+    trie evaluation (``mask_sharing="node"`` or no dropout) -- the per-(path, position) evaluation sizes its packed sequence with a
+    host read; a batch with its relation tensors already built (device builders run before, not inside, the capture)."""
+
+    def __init__(self, trainer, batch, warmup=3):
+        if trainer.collective:
+            raise ValueError("GraphedStep: single-process training only")
+        dev = trainer.flat.grad.device
+        self.trainer, self.batch, self._dev = trainer, batch, dev
+        self.epoch = torch.zeros((), dtype=torch.int64, device=dev)
+        ops.set_seed_epoch(self.epoch)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):           # torch's capture protocol: a few eager steps on a side stream first (workspaces,
+            for _ in range(warmup):             # cuBLAS-style lazy state, the allocator's pools): REAL training steps on ``batch``
+                self.epoch.add_(1)
+                self._body()
+                trainer.steps_issued += 1
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.epoch.add_(1)
+            self._out = self._body()
+        torch.cuda.synchronize(dev)
+        self.replays = 0
+
+    def _body(self):
+        t = self.trainer
+        # fork the auxiliary stream into the capture before anything else and join it at the end: the step's kernels make the main
+        # stream wait for it in places where, on small inputs, it was never given work -- outside a capture a no-op, inside one a
+        # dependency on a stream that is not being captured (the replay of such a graph hung on ROCm 7.2)
+        main, side = torch.cuda.current_stream(self._dev), ops.side_stream(self._dev)
+        side.wait_stream(main)
+        loss = t.model(self.batch)
+        loss = loss if loss.dtype == torch.float32 else loss.float()
+        t._control(0, loss.detach())
+        t._control(1, loss.detach())
+        loss.backward()
+        ops.join_side()
+        t.flat.step(None, gscale=1.0, max_norm=1.0, ctl=t._ctl)
+        t.flat.zero_grad()
+        main.wait_stream(side)
+        return torch.cat([loss.detach().reshape(1), t._flag])
+
+    def __call__(self):
+        self.graph.replay()
+        self.replays += 1
+        self.trainer.steps_issued += 1
+        return PendingLoss(self._out.clone())
+
+    def close(self):
+        ops.set_seed_epoch(None)
+
+
 class PendingLoss:
     """Loss and skip flag of a step, still on the device."""
 

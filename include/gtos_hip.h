@@ -308,6 +308,13 @@ int gtos_transpose_batch_bf16(int n_mat, const int64_t* desc, const int* tile_st
  * gtos_adam_step_ctl = gtos_adam_step with the learning rate read from ctl[0] and no update at all when ctl[1] != 0. */
 int gtos_step_control(int phase, const float* loss, double* state, float* flag, int warmup_steps, int embed_dim,
                       float* ctl, void* stream);
+
+/* hipGraph replay of a training step (gtos_amd.train.GraphedStep; no reference counterpart -- the reference launches every step from
+ * Python): a replay freezes every kernel argument, dropout seeds included.  ``epoch`` is a device uint64 the captured step increments
+ * once per replay; while it is registered, every kernel of this library that draws a dropout mask uses
+ * seed + *epoch * 0x9E3779B97F4A7C15 instead of seed (forward and backward of an op read the same value within one replay).
+ * NULL (the default) restores the plain seeds.  Synchronous (hipMemcpyToSymbol): call it outside a capture. */
+int gtos_set_seed_epoch(const void* epoch);
 int gtos_adam_step_ctl(int64_t n, float* p, const float* g, float* m, float* v, const float* ctl, float beta1, float beta2,
                        float eps, float weight_decay, float gscale, const float* sqnorm, float max_norm,
                        void* bf16_mirror, void* stream);
