@@ -59,16 +59,21 @@ def build_vocabs(trees, tmp):
     return out
 
 
-def run_arm(arm, a, vocabs, train_trees, held_trees, dev):
+def run_arm(arm, a, vocabs, train_trees, held_trees, dev, seed=0):
+    """``seed``: 0 = the round-3 run (initial weights 19940117, hash seeds 4242, batch order 7); s > 0 offsets all three."""
+    from gtos_amd.encoder import set_relation_mask_sharing
     gru.TRIE = arm != "row"
-    torch.manual_seed(19940117)
+    torch.manual_seed(19940117 + seed)
     model = Generator(vocabs, 32, 300, 32, 300, [(3, 256)], 128, 128, 100, 256, 2, a.d, 2 * a.d, 8, a.dropout, 1, a.layers, 2, None, dev,
                       depth_size=256).to(dev)
     model.set_compute_dtype(torch.bfloat16)
     if arm == "none":
         model.relation_encoder.dropout = 0.0
+    # round 4: the mask semantics are a property of the module: "node" = masks per trie node (opt-in), "path" = per (path, position),
+    # the reference's and the library default ("row" = the same through the GTOS_GRU_TRIE=0 switch of round 3)
+    set_relation_mask_sharing(model, "node" if arm in ("node", "none") else "path")
     tr = Trainer(model, a.d, warmup_steps=a.warmup, compute_dtype=torch.bfloat16)
-    ops.set_seed(4242)
+    ops.set_seed(4242 + 1000003 * seed)
     held = [{k: (v.to(dev) if hasattr(v, "to") else v) for k, v in b.items()}
             for b in DependencyLoader(vocabs, held_trees, a.batch_size, for_train=False)]
 
@@ -81,7 +86,7 @@ def run_arm(arm, a, vocabs, train_trees, held_trees, dev):
         model.train()
         return tot / len(held_trees)
 
-    loader = DependencyLoader(vocabs, train_trees, a.batch_size, for_train=True, rng=random.Random(7))
+    loader = DependencyLoader(vocabs, train_trees, a.batch_size, for_train=True, rng=random.Random(7 + seed))
     loader.set_unk_rate(a.unk_rate)
 
     def epochs():
@@ -100,7 +105,7 @@ def run_arm(arm, a, vocabs, train_trees, held_trees, dev):
             print("%-5s step %5d  train %.4f  held-out %.4f  (%.0f s)" % (arm, step, rec["train_loss"], rec["held_out_loss"], time.time() - t0),
                   flush=True)
     feed.close()
-    return {"arm": arm, "curve": curve, "seconds": round(time.time() - t0, 1), "discarded": tr.discarded}
+    return {"arm": arm, "seed": seed, "curve": curve, "seconds": round(time.time() - t0, 1), "discarded": tr.discarded}
 
 
 def main():
@@ -117,6 +122,7 @@ def main():
     ap.add_argument("--train-trees", type=int, default=1900,
                     help="size of the training subset (the held-out trees are always the last 269); a few hundred trees put the run in "
                          "the over-fitting regime, where regularisation differences show in the held-out loss")
+    ap.add_argument("--seeds", default="0", help="comma-separated: one run of every arm per seed (initial weights, hash seeds, batch order)")
     ap.add_argument("--out", default="gpurun_out/dropout_ab.json")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -126,16 +132,27 @@ def main():
         vocabs = build_vocabs(train_trees, tmp)
     res = {"config": vars(a), "train_trees": len(train_trees), "held_out_trees": len(held_trees),
            "vocab_sizes": {k: v.size for k, v in vocabs.items()}, "arms": []}
-    for arm in a.arms.split(","):
-        res["arms"].append(run_arm(arm, a, vocabs, train_trees, held_trees, dev))
+    seeds = [int(x) for x in a.seeds.split(",")]
+    for seed in seeds:
+        for arm in a.arms.split(","):
+            res["arms"].append(run_arm(arm, a, vocabs, train_trees, held_trees, dev, seed))
     os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
     with open(a.out, "w") as f:
         json.dump(res, f, indent=1)
     # side-by-side table
-    print("\nstep   " + "   ".join("%-22s" % ("%s train / held-out" % r["arm"]) for r in res["arms"]))
+    print("\nstep   " + "   ".join("%-22s" % ("%s/s%d train / held-out" % (r["arm"], r["seed"])) for r in res["arms"]))
     for i in range(len(res["arms"][0]["curve"])):
         print("%5d  " % res["arms"][0]["curve"][i]["step"] + "   ".join(
             "%8.4f / %8.4f     " % (r["curve"][i]["train_loss"], r["curve"][i]["held_out_loss"]) for r in res["arms"]))
+    if len(seeds) > 1:                                  # per arm: mean and range over the seeds, at every record
+        print("\nover seeds %s: mean [min .. max] of the held-out loss" % seeds)
+        arms = a.arms.split(",")
+        for i in range(len(res["arms"][0]["curve"])):
+            cells = []
+            for arm in arms:
+                v = [r["curve"][i]["held_out_loss"] for r in res["arms"] if r["arm"] == arm]
+                cells.append("%s %.4f [%.4f .. %.4f]" % (arm, sum(v) / len(v), min(v), max(v)))
+            print("%5d  " % res["arms"][0]["curve"][i]["step"] + "    ".join(cells))
 
 
 if __name__ == "__main__":
