@@ -70,6 +70,7 @@ class Generator(nn.Module):
         return c, torch.eq(inp['concept'], self.vocabs['concept'].padding_idx)
 
     def encode_step(self, inp, train=True):
+        ops.refresh_side_policy(inp['concept'].device)      # auxiliary stream yes / no for this step (memory: ops.SIDE_STREAMS)
         if 'relation_graphs' in inp:           # a loader batch whose relation section was left to this device (index_prep="device_all")
             from .data import complete_on_device
             complete_on_device(inp, inp['concept'].device)

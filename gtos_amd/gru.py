@@ -20,7 +20,7 @@ import torch
 
 from . import _lib
 from ._lib import call, dt, ptr, stream
-from .ops import (gemm, compute_weight, next_seed, weight_t, _grad_target, _splitk, side_stream as _side_stream, defer_side_join, _Timed,
+from .ops import (gemm, compute_weight, next_seed, weight_t, _grad_target, _splitk, side_stream as _side_stream, side_ok, defer_side_join, _Timed,
                   embed_bwd_workspace)
 
 
@@ -226,7 +226,7 @@ class BiGRUFinalFn(torch.autograd.Function):
                     if bt.requires_grad and _grad_target(bt) is None:
                         grads[base + slot] = torch.zeros(bt.shape, dtype=torch.float32, device=dev)
                 main = torch.cuda.current_stream(dev)
-                side = _side_stream(dev) if (SIDE_STREAM and fused and N >= SIDE_MIN_ROWS) else main
+                side = _side_stream(dev) if (SIDE_STREAM and side_ok(dev) and fused and N >= SIDE_MIN_ROWS) else main
                 if side is not main:
                     side.wait_stream(main)
                     # locals that die (or are rebound) before the side stream is done with them: tell the allocator
@@ -380,7 +380,7 @@ class TrieBiGRUFn(torch.autograd.Function):
         # ---- layer 0 on the tries (suffix side on the auxiliary stream, see TRIE_L0_OVERLAP)
         l0 = []
         main = torch.cuda.current_stream(dev)
-        aux = _side_stream(dev) if (TRIE_L0_OVERLAP and table.is_cuda and N >= SIDE_MIN_ROWS) else main
+        aux = _side_stream(dev) if (TRIE_L0_OVERLAP and table.is_cuda and side_ok(dev) and N >= SIDE_MIN_ROWS) else main
         seeds = [(next_seed() if p_embed > 0 else 0, next_seed() if p_layer > 0 else 0) for _ in sides]
         if aux is not main:
             aux.wait_stream(main)
@@ -415,7 +415,7 @@ class TrieBiGRUFn(torch.autograd.Function):
         # where the two MFMA-bound products run beside direction 0's (HBM-bound) recurrent steps.  Their buffers come from the
         # main stream's pool (the consumer's), the auxiliary stream only fills them.
         tables = []
-        t_aux = _side_stream(dev) if (TRIE_L1_TABLE_OVERLAP and table.is_cuda and N >= SIDE_MIN_ROWS) else None
+        t_aux = _side_stream(dev) if (TRIE_L1_TABLE_OVERLAP and table.is_cuda and side_ok(dev) and N >= SIDE_MIN_ROWS) else None
         for d in (0, 1):
             wi = compute_weight(weights[8 + d * 4], dtp)
             Gf = torch.empty((sides[0].n_nodes, 3 * hs), dtype=dtp, device=dev)      # [nodes of the prefix trie, 3hs]
@@ -482,7 +482,7 @@ class TrieBiGRUFn(torch.autograd.Function):
         # function (weight gradients, gate-table input gradients) goes to the auxiliary stream and runs beside the steps /
         # segment sums that follow it.
         main = torch.cuda.current_stream(dev)
-        aux = _side_stream(dev) if (TRIE_SIDE and SIDE_STREAM and N >= SIDE_MIN_ROWS) else main
+        aux = _side_stream(dev) if (TRIE_SIDE and SIDE_STREAM and side_ok(dev) and N >= SIDE_MIN_ROWS) else main
         use_side = aux is not main
 
         keep = []      # tensors the auxiliary stream reads: kept alive until main has waited for it (no record_stream: blocks
@@ -555,7 +555,7 @@ class TrieBiGRUFn(torch.autograd.Function):
             dtab = torch.zeros(table.shape, dtype=torch.float32, device=dev)
         # the two tries are independent: the suffix side runs on the auxiliary stream beside the prefix side (small launches per
         # level on both); with TRIE_SIDE the GEMMs go to the auxiliary stream instead and both sides stay on main
-        l0_overlap = TRIE_L0_OVERLAP and not use_side and N >= SIDE_MIN_ROWS     # small banks are launch-bound: no stream hand-overs
+        l0_overlap = TRIE_L0_OVERLAP and side_ok(dev) and not use_side and N >= SIDE_MIN_ROWS     # small banks are launch-bound: no stream hand-overs
         emb_parts = []
         aux0 = _side_stream(dev) if l0_overlap else main
         if l0_overlap:

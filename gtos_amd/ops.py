@@ -116,6 +116,36 @@ BWD_SIDE = os.environ.get("GTOS_BWD_SIDE", "1") != "0"
 BWD_SIDE_MIN_ROWS = 100000
 
 
+# The auxiliary stream has a price in memory: the caching allocator keeps one pool per stream, blocks freed on one stream never serve the
+# other, and the two pools peak at different moments of a step -- measured: C2 31 GB allocated, 94-99 GB reserved with the auxiliary
+# stream, 37 GB without (61.6 vs 62.1 ms per step); C5 93 GB allocated, 230-277 GB reserved with it (of 288 GB: one allocator retry from
+# a stall), 119 GB without (212 vs 214.6 ms).  GTOS_SIDE_STREAMS: "1" / "0" = always / never use it; "auto" (default) = use it while the
+# process's peak allocation stays below GTOS_SIDE_MAX_ALLOC_FRACTION (0.25) of the device memory, decided once per step
+# (refresh_side_policy, called by Generator.encode_step) and never switched back on.
+SIDE_STREAMS = os.environ.get("GTOS_SIDE_STREAMS", "auto")
+SIDE_MAX_ALLOC_FRACTION = float(os.environ.get("GTOS_SIDE_MAX_ALLOC_FRACTION", "0.25"))
+_SIDE_POLICY, _DEVICE_BYTES = {}, {}
+
+
+def side_ok(device):
+    """May this step use the auxiliary stream on ``device``?  (The individual switches -- GTOS_PROJ_SIDE, GTOS_BWD_SIDE, GTOS_GRU_SIDE,
+    GTOS_GRU_L0_OVERLAP -- apply on top.)"""
+    return _SIDE_POLICY.get(device, SIDE_STREAMS != "0")
+
+
+def refresh_side_policy(device):
+    """Once per step, before its first launch: host-side allocator statistics only (no synchronisation)."""
+    if device.type != "cuda":
+        return
+    if SIDE_STREAMS != "auto":
+        _SIDE_POLICY[device] = SIDE_STREAMS != "0"
+    elif _SIDE_POLICY.get(device) is not False:
+        total = _DEVICE_BYTES.get(device)
+        if total is None:
+            total = _DEVICE_BYTES[device] = torch.cuda.get_device_properties(device).total_memory
+        _SIDE_POLICY[device] = torch.cuda.max_memory_allocated(device) <= SIDE_MAX_ALLOC_FRACTION * total
+
+
 def side_stream(device):
     """One auxiliary HIP stream per device for work that is independent of the main chain (see gru.py, FactoredRelation)."""
     s = _SIDE.get(device)
@@ -433,7 +463,7 @@ class LinearFn(torch.autograd.Function):
         # A grouped projection (relation_in_proj of one layer) whose weight gradient lands in the flat bucket hands
         # nothing to autograd until the LAST member of its group: its two GEMMs can run on the side stream, beside the
         # attention-backward kernels of the main chain.  The last member makes the main stream wait for all of them.
-        offload = (BWD_SIDE and group is not None and bias is None and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
+        offload = (BWD_SIDE and side_ok(x2.device) and group is not None and bias is None and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
                    and _grad_target(weight) is not None and dy2.shape[0] >= BWD_SIDE_MIN_ROWS)   # small problems are launch-bound
         if offload:
             dev = dy2.device
@@ -679,7 +709,7 @@ class FactoredRelation:
         per-layer kernels of the main stream.  autograd runs a node's backward on the stream of its forward, so the
         projection's dX / dW GEMMs overlap the main chain in backward as well."""
         self._proj = {}
-        if not (PROJ_SIDE and self.bank.is_cuda and torch.is_grad_enabled()):
+        if not (PROJ_SIDE and self.bank.is_cuda and side_ok(self.bank.device) and torch.is_grad_enabled()):
             return
         dev = self.bank.device
         main, side = torch.cuda.current_stream(dev), side_stream(dev)

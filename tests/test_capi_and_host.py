@@ -223,3 +223,39 @@ def test_reference_module_names_resolve_to_the_product_modules():
         for n, m in saved.items():
             if m is not None:
                 sys.modules[n] = m
+
+
+def test_auxiliary_stream_policy_follows_the_peak_allocation(monkeypatch):
+    """ops.SIDE_STREAMS="auto": the auxiliary stream is used while the process's peak allocation stays below a quarter of the device
+    memory, the decision is taken once per step from host-side allocator statistics, and it never switches back on (C5: 93 GB
+    allocated -> one allocator pool, 120 GB reserved instead of 230-277)."""
+    import types
+
+    import torch
+
+    from gtos_amd import ops
+    dev = torch.device("cuda", 0)
+    peak = [10 << 30]
+    monkeypatch.setattr(torch.cuda, "get_device_properties", lambda d: types.SimpleNamespace(total_memory=288 << 30))
+    monkeypatch.setattr(torch.cuda, "max_memory_allocated", lambda d: peak[0])
+    monkeypatch.setattr(ops, "_SIDE_POLICY", {})
+    monkeypatch.setattr(ops, "_DEVICE_BYTES", {})
+    monkeypatch.setattr(ops, "SIDE_STREAMS", "auto")
+    assert ops.side_ok(dev)                                  # before the first step: yes
+    ops.refresh_side_policy(dev)
+    assert ops.side_ok(dev)
+    peak[0] = 93 << 30
+    assert ops.side_ok(dev)                                  # nothing changes inside a step
+    ops.refresh_side_policy(dev)
+    assert not ops.side_ok(dev)
+    peak[0] = 1 << 30                                        # (bench.py resets the peak statistics before its timed region)
+    ops.refresh_side_policy(dev)
+    assert not ops.side_ok(dev)                              # sticky
+    ops.refresh_side_policy(torch.device("cpu"))             # no-op
+    for forced, want in (("0", False), ("1", True)):
+        monkeypatch.setattr(ops, "_SIDE_POLICY", {})
+        monkeypatch.setattr(ops, "SIDE_STREAMS", forced)
+        assert ops.side_ok(dev) is want
+        peak[0] = 200 << 30
+        ops.refresh_side_policy(dev)
+        assert ops.side_ok(dev) is want
