@@ -63,6 +63,8 @@ class RelationMultiheadAttention(nn.Module):
             rel = relation.take_projection(self)                                           # prefetched on the side stream?
             if rel is None:
                 rel = ops.linear(bank, self.relation_in_proj.weight, group=group)           # [R, 2d]
+                if ops.PROJ_RECOMPUTE:      # what the attention core needs to make this tensor again in its backward
+                    rel._gtos_proj_src = (bank.detach(), ops.compute_weight(self.relation_in_proj.weight, cd))
         else:
             fact = None
             rel = ops.linear(relation.to(cd), self.relation_in_proj.weight)               # [n, n, B, 2d]

@@ -111,6 +111,10 @@ PROJ_SIDE = os.environ.get("GTOS_PROJ_SIDE", "1") != "0"
 # ... as long as all the layers' projections together stay small beside the rest of the step (7 GB at C2).  At C5 (R = 1.84 M:
 # 30 GB of projections alive at once on top of a 150 GB step) the prefetch made the step time scatter between 215 and 330 ms.
 PROJ_SIDE_MAX_BYTES = int(os.environ.get("GTOS_PROJ_SIDE_MAX_GB", "16")) << 30
+# GTOS_PROJ_RECOMPUTE=1 (opt-in): the attention core does not keep a layer's projected bank [R, 2d] for its backward but recomputes it
+# there from the bank and the layer's weight (the same GEMM, the same bits).  C5: 3.8 GB per layer, 26 GB of the 93.6 GB peak, for one
+# more [R,d]x[d,2d] product per layer and step.
+PROJ_RECOMPUTE = os.environ.get("GTOS_PROJ_RECOMPUTE", "0") == "1"
 # Backward of the relation projections on the side stream (see LinearFn.backward): overlaps only backward kernels.
 BWD_SIDE = os.environ.get("GTOS_BWD_SIDE", "1") != "0"
 BWD_SIDE_MIN_ROWS = 100000
@@ -764,14 +768,20 @@ class RelAttnFn(torch.autograd.Function):
                  qsrc.data_ptr() + q_off * es, Cq, kv.data_ptr() + k_off * es, Ckv, kv.data_ptr() + v_off * es, Ckv,
                  ptr(rel), ptr(fact.idx_q) if fact is not None else None, ptr(key_pad), ptr(attn_mask),
                  float(scale), float(p_drop), seed, ptr(o), d, ptr(lse), ptr(w), stream())
-        ctx.save_for_backward(qsrc, kvsrc, rel, o, lse, w, key_pad, attn_mask)
+        # (mode 2, opt-in) the projection is not kept: its source -- the bank and the compute-dtype weight, both alive anyway -- is
+        src = getattr(rel, "_gtos_proj_src", None) if (mode == 2 and PROJ_RECOMPUTE) else None
+        ctx.save_for_backward(qsrc, kvsrc, rel if src is None else None, o, lse, w, key_pad, attn_mask)
         ctx.cfg = (fact, offs, d, H, scale, p_drop, seed, mode)
+        ctx.proj_src = src
         return o, w
 
     @staticmethod
     def backward(ctx, d_o, d_w):
         qsrc, kvsrc, rel, o, lse, w, key_pad, attn_mask = ctx.saved_tensors
         fact, (q_off, k_off, v_off), d, H, scale, p_drop, seed, mode = ctx.cfg
+        if ctx.proj_src is not None:
+            bank_, w_ = ctx.proj_src
+            rel = gemm(bank_, w_, trans_b=True)              # the forward's product again: same kernel, same operands, same bits
         kv = qsrc if kvsrc is None else kvsrc
         T_, B, Cq = qsrc.shape
         S, _, Ckv = kv.shape

@@ -1904,3 +1904,36 @@ def test_batched_relation_projection_weight_gradient_opt_in(monkeypatch):
     for k in res[False][1]:
         a, b = res[True][1][k], res[False][1][k]
         assert _rel_frob(a, b) < (2e-3 if "relation_in_proj" in k else 1e-2), (k, _rel_frob(a, b))     # (split-K order / atomics differ run to run)
+
+
+def test_relation_projection_recomputed_in_backward_gives_the_same_gradients(monkeypatch):
+    """GTOS_PROJ_RECOMPUTE=1 (opt-in memory plan, C5): the attention core drops a layer's projected bank after its forward and makes it
+    again in its backward from the bank and the layer's weight.  Same loss, same gradients (the same GEMM on the same operands), with
+    the projection prefetch out of the way so that every layer takes the recompute route."""
+    from gtos_amd import ops, synth
+    from gtos_amd.config import build_generator
+    from gtos_amd.generator import Generator
+    from gtos_amd.pathtrie import attach_path_trie
+    from gtos_amd.relindex import attach_relation_index
+    m = build_generator(Generator, "C1", dev(), dropout=0.0).to(dev())
+    m.set_compute_dtype(torch.bfloat16)
+    m.train()
+    batch, _ = synth.make_config_batch("C1")
+    attach_relation_index(attach_path_trie(batch))
+    batch = {k: (v.to(dev()) if hasattr(v, "to") else v) for k, v in batch.items()}
+    monkeypatch.setattr(ops, "PROJ_SIDE", False)
+
+    def run(flag):
+        monkeypatch.setattr(ops, "PROJ_RECOMPUTE", flag)
+        m.zero_grad(set_to_none=True)
+        loss = m(dict(batch))
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss.detach()), {n: p.grad.detach().float().clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    l0, g0 = run(False)
+    l1, g1 = run(True)
+    assert l0 == l1 and set(g0) == set(g1) and len(g0) > 50
+    worst = max(float((g0[n] - g1[n]).abs().max() / g0[n].abs().max().clamp_min(1e-6)) for n in g0)
+    print("MEASURED projection recompute: worst relative gradient difference %.2e" % worst)
+    assert worst <= 2e-3, worst            # fp32 atomic orders in the bank-gradient kernel differ run to run; everything else is bit-equal
