@@ -86,12 +86,13 @@ def parse():
                     help="--fresh-batches: the loader workers build relation / bank / index / tries with the C++ host builders (the route of "
                          "rounds 1-3: 0.10 s of host time per C2 batch, 3-4 worker processes per GPU).  Default since round 4: everything on "
                          "the device (= --device-relations --prep-in-worker, ONE worker process), as the loaders themselves default to")
-    ap.add_argument("--relation-masks", default="node", choices=["node", "path"],
+    ap.add_argument("--relation-masks", default="path", choices=["node", "path"],
                     help="training-mode dropout masks of the RelationEncoder: 'path' = drawn per (path, position) like the reference "
-                         "(generator/encoder.py:91-92,105; the LIBRARY default: one GRU row per path and position), 'node' = drawn per node of "
-                         "the prefix / suffix trie and shared by the paths through it (opt-in, gtos_amd.encoder.set_relation_mask_sharing: "
-                         "layer 0 once per trie node, layer-1 input gates from per-node tables).  The headline runs 'node' and says so; the "
-                         "other mode is measured right after the timed region and reported as `reference_masks` / `node_masks`")
+                         "(generator/encoder.py:91-92,105; the library default and, since the end of round 4, this script's: one GRU row "
+                         "per path and position), 'node' = drawn per node of the prefix / suffix trie and shared by the paths through it "
+                         "(opt-in, gtos_amd.encoder.set_relation_mask_sharing: layer 0 once per trie node, layer-1 input gates from "
+                         "per-node tables; the headline of rounds 2-3 and of this round's earlier records).  The other mode is measured "
+                         "right after the timed region and reported as `node_masks` / `reference_masks`")
     ap.add_argument("--no-masks-leg", action="store_true", help="skip the leg that measures the other --relation-masks mode")
     ap.add_argument("--graph-leg", action="store_true",
                     help="after the timed region (N = 1): the same step replayed from a hipGraph (train.GraphedStep).  Opt-in: on ROCm "
@@ -681,7 +682,10 @@ def main():
     if not a.no_masks_leg and cd == torch.bfloat16 and not a.fresh_batches and all_legs:
         other = "path" if a.relation_masks == "node" else "node"
         set_relation_mask_sharing(model, other)
-        for _ in range(3):
+        # the other mode is another set of buffer sizes: the cache is full of blocks cut for the headline's (with three warm-up steps on
+        # top of it the trie mode measured 73.5 ms per step after a per-path headline, 61.7 on its own)
+        torch.cuda.empty_cache()
+        for _ in range(8):
             trainer.step(batch, sync=False)
         sync()
         t_m = time.perf_counter()
@@ -823,7 +827,9 @@ def main():
                           "relation_gru": ("trie evaluation, dropout masks drawn per trie node and shared by the paths through it (OPT-IN, "
                                            "--relation-masks node; the library default draws them per (path, position) like the reference: "
                                            "see reference_masks)" if (gru_mod.TRIE and a.relation_masks == "node") else
-                                           "one row per (path, position), dropout masks per (path, position) like the reference"),
+                                           "the reference's dropout semantics (the library default): masks per (path, position), one GRU row "
+                                           "each; the trie-shared masks of rounds 2-3 (an opt-in, a different regulariser) are measured "
+                                           "in the same run: see node_masks"),
                           "allreduce_exposed_ms_per_step": round(1e3 * max(r[1] for r in per_rank) / a.steps, 3),
                           "per_rank_ms_per_step": [round(1e3 * r[0] / a.steps, 3) for r in per_rank],
                           "per_rank_allreduce_exposed_ms_per_step": [round(1e3 * r[1] / a.steps, 3) for r in per_rank],

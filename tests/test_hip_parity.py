@@ -1446,7 +1446,8 @@ def test_bench_two_ranks_on_one_gpu_functional():
     assert d["collectives"]["ranks_seen_by_allreduce"] == 2 and d["collectives"]["backend"] == "gloo"
     o = d["other_scaling"]
     assert o["scaling"] == "strong" and o["global_batch"] == d["config"]["B_per_gpu"] and o["value"] > 0
-    assert d["reference_masks"]["relation_masks"] == "path" and d["reference_masks"]["ms_per_step"] > 0
+    assert "per (path, position)" in d["config"]["relation_gru"]        # the headline runs the reference's dropout semantics ...
+    assert d["node_masks"]["relation_masks"] == "node" and d["node_masks"]["ms_per_step"] > 0      # ... and measures the opt-in beside it
     assert d["loader_in_loop"]["workers_per_gpu"] == 1 and d["loader_in_loop"]["ms_per_step"] > 0, d["loader_in_loop"]
 
 

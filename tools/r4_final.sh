@@ -9,7 +9,7 @@ timeout 300 python __graft_entry__.py --smoke > $O/smoke.log 2>&1; tail -2 $O/sm
 ( time timeout 600 python bench.py > $O/bench_c2_n1.json 2> $O/bench_c2_n1.err ) 2> $O/bench_c2_n1.time; python - <<P
 import json
 try:
-    d=json.loads(open("$O/bench_c2_n1.json").read().strip().splitlines()[-1]); print("bench", round(d["value"],1), round(d["ms_per_step"],2), d["components"]); print(d["roofline"]["frac"], d["roofline"]["in_step"]["frac"], d["cpu_baseline"]["value"], d["reference_masks"]["ms_per_step"], d["loader_in_loop"]["ms_per_step"], d["config"]["device_memory"])
+    d=json.loads(open("$O/bench_c2_n1.json").read().strip().splitlines()[-1]); print("bench", round(d["value"],1), round(d["ms_per_step"],2), d["components"]); print(d["roofline"]["frac"], d["roofline"]["in_step"]["frac"], d["cpu_baseline"]["value"], (d.get("node_masks") or d.get("reference_masks"))["ms_per_step"], d["loader_in_loop"]["ms_per_step"], d["config"]["device_memory"])
     for r in d["roofline"]["kernels"]: print("   ", r["kernel"][:60], r["avg_us"], r["frac"])
 except Exception as e: print("bench failed", e); print(open("$O/bench_c2_n1.err").read()[-2000:])
 P
@@ -19,7 +19,7 @@ for c in C1 C3 C5; do
   python -c "
 import json
 try:
-    d=json.loads(open('$O/bench_$c.json').read().strip().splitlines()[-1]); print('$c', round(d['value'],1), round(d['ms_per_step'],2), d['roofline']['frac'], d['config']['device_memory'], (d.get('reference_masks') or {}).get('ms_per_step'), (d.get('loader_in_loop') or {}).get('ms_per_step'))
+    d=json.loads(open('$O/bench_$c.json').read().strip().splitlines()[-1]); print('$c', round(d['value'],1), round(d['ms_per_step'],2), d['roofline']['frac'], d['config']['device_memory'], (d.get('node_masks') or d.get('reference_masks') or {}).get('ms_per_step'), (d.get('loader_in_loop') or {}).get('ms_per_step'))
 except Exception as e: print('$c failed', e)"
 done
 timeout 200 python tools/bench_gemm.py --torch --reps 5 > $O/gemm_vs_hipblaslt.txt 2>&1; grep -v amdgpu.ids $O/gemm_vs_hipblaslt.txt | grep -c "TF/s"
