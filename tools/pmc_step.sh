@@ -7,7 +7,7 @@ OUT=gpurun_out/pmcstep
 rm -rf $OUT; mkdir -p $OUT
 for ctr in FETCH_SIZE WRITE_SIZE; do
   GTOS_BENCH_NO_DETAIL=1 timeout 400 rocprofv3 --kernel-trace --pmc $ctr -d $OUT/$ctr -o p -- \
-      python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-masks-leg --no-loader-leg --prewarm-seconds 3 > $OUT/$ctr.log 2>&1
+      python bench.py --relation-masks node --steps 2 --warmup 1 --no-cpu-baseline --no-masks-leg --no-loader-leg --prewarm-seconds 3 > $OUT/$ctr.log 2>&1
 done
 python tools/pmc_step_summary.py $OUT gpurun_out/${ROUND:-r3}_step_pmc.json > gpurun_out/${ROUND:-r3}_step_pmc.txt
 cat gpurun_out/${ROUND:-r3}_step_pmc.txt

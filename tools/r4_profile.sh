@@ -4,7 +4,7 @@
 O=gpurun_out/r4p; mkdir -p $O
 export PYTHONPATH=$PWD
 R=$PWD
-cd /tmp && export TMPDIR=/tmp && GTOS_BENCH_NO_DETAIL=1 timeout 300 rocprofv3 --kernel-trace -d $R/$O/prof -o trace -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-masks-leg --no-loader-leg --prewarm-seconds 5 > $R/$O/bench_line_under_rocprof.json 2> $R/$O/bench_rocprof.err
+cd /tmp && export TMPDIR=/tmp && GTOS_BENCH_NO_DETAIL=1 timeout 300 rocprofv3 --kernel-trace -d $R/$O/prof -o trace -- python $R/bench.py --relation-masks node --steps 4 --warmup 1 --no-cpu-baseline --no-masks-leg --no-loader-leg --prewarm-seconds 5 > $R/$O/bench_line_under_rocprof.json 2> $R/$O/bench_rocprof.err
 cd $R
 DB=$(find $O/prof -name "*.db" | head -1)
 python tools/rocpd_stats.py $DB $O/kernel_stats.csv > /dev/null
