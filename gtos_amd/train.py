@@ -203,7 +203,11 @@ class GraphedStep:
     (ops.set_seed_epoch) which the captured step increments first thing; torch's own generator is graph-safe by itself.
     Limits: one process (world_size 1: the gradient collectives' host-side bookkeeping is not captured); the RelationEncoder's
     trie evaluation (``mask_sharing="node"`` or no dropout) -- the per-(path, position) evaluation sizes its packed sequence with a
-    host read; a batch with its relation tensors already built (device builders run before, not inside, the capture)."""
+    host read; a batch with its relation tensors already built (device builders run before, not inside, the capture).
+    Robustness (ROCm 7.2, torch 2.10): C1 captures and replays correctly (equal to the eager steps at dropout 0).
+    At C2, where the auxiliary stream is forked in three places, ``hipStreamEndCapture`` crashed inside the runtime, and with every
+    use of that stream switched off a replay hung; with one use it worked and bought nothing (the step is not launch-bound).  Use it
+    for launch-bound configurations."""
 
     def __init__(self, trainer, batch, warmup=3):
         if trainer.collective:
@@ -230,9 +234,9 @@ class GraphedStep:
 
     def _body(self):
         t = self.trainer
-        # fork the auxiliary stream into the capture before anything else and join it at the end: the step's kernels make the main
-        # stream wait for it in places where, on small inputs, it was never given work -- outside a capture a no-op, inside one a
-        # dependency on a stream that is not being captured (the replay of such a graph hung on ROCm 7.2)
+        # fork the auxiliary stream into the capture before anything else and join it at the end: the step makes the main stream wait
+        # for it in places where, on small inputs, it was never given work -- outside a capture a no-op, inside one a dependency on a
+        # stream that is not being captured
         main, side = torch.cuda.current_stream(self._dev), ops.side_stream(self._dev)
         side.wait_stream(main)
         loss = t.model(self.batch)
