@@ -34,3 +34,17 @@ def test_cpu_baseline_leg_runs_on_a_tiny_config(monkeypatch):
     rec = bench.cpu_baseline("C1", 2, 1, budget_s=5.0, warmup=1)
     assert rec["kind"] == "port" and rec["unit"] == "graphs/s" and rec["value"] > 0 and rec["cores"] >= 1
     assert rec["encoder_only"]["value"] > 0 and "1 warm-up + 1 timed steps" in rec["sample"] and isinstance(rec["cpu"], str)
+
+
+def test_bench_defaults_are_the_library_defaults(monkeypatch):
+    """`python bench.py` with no flags measures what a user of the library gets: the reference's dropout semantics in the RelationEncoder
+    (masks per (path, position), `encoder.MASK_SHARING`), one GPU, the BASELINE configuration the metric is quoted on, no opt-in legs."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = bench.parse()
+    from gtos_amd import encoder
+    assert a.relation_masks == "path" == encoder.MASK_SHARING
+    assert a.gpus == 1 and a.config == "C2" and not a.graph_leg and not a.fresh_batches
