@@ -23,7 +23,6 @@
 //   * XCD-aware tile order (block id % 8 = XCD): an XCD walks the N tiles of an M panel / all tiles of one K split;
 //   * gemm256_nt_kernel: 256x256 macro tile with a two-stage DMA pipeline for deep-K products (see its comment).
 #include "common.h"
-#include "gemm_w4_gen.h"
 #include <stdlib.h>
 
 // 256 bytes of zeros in GLOBAL memory (allocated once per process): target of out-of-range tile loads.  A __device__
@@ -896,542 +895,11 @@ __global__ __launch_bounds__(512) void gemm256p_nt_kernel(GemmArgs a) {
     }
 }
 
-// ---- gemm_p2_nt_kernel (round 4): the forward shape with a SHORT reduction (K = 128 .. 1023: relation projection, GRU gate tables,
-//      RelationEncoder output projection), where a tile's output write costs as much as its k loop.  Measured picture behind it
-//      (tools/probes/membw_probe.hip): the chip streams reads at 6.0-6.3 TB/s but WRITES at 4.4 TB/s, so [R,1024] bf16 = 0.89 GB of
-//      output is 0.20 ms of HBM time against 0.19 ms of MFMA time at the peak -- the two must overlap, and inside one workgroup they
-//      cannot (the accumulators are the data being stored).  So: TWO independent 4-wave workgroups per CU (one wave of each per SIMD),
-//      each on its own 128 x 256 tile; they drift apart by themselves, and while one drains its tile through the store queue the
-//      other has the matrix pipes.  First version (three 32-k stages, every wave loading its share of A and B): 0.65 ms at the
-//      relation projection, no better than the single-stage kernel -- the A operand streams from HBM (2+ us under load) and two
-//      stages of prefetch cover 0.4 us of MFMA time, so every step waited.  A wave's vmcnt retires loads IN ORDER, so one wave
-//      cannot hold a deep A prefetch and a shallow B one at once; hence the ROLE SPLIT: waves 0-1 load only A into a SIX-slot ring
-//      (five 8 KB stages = 40 KB of HBM reads in flight per workgroup), waves 2-3 load only B (the weight, L2-resident: two 16 KB
-//      slots are enough); all four multiply.  80 KB of LDS per workgroup.  Stages are separate static arrays and every wait is
-//      explicit, as in gemm256p_nt_kernel (hipcc would otherwise drain all LDS-DMA in front of each ds_read).  Step s: loaders wait
-//      for their own pieces of stage s (A: vmcnt(16) = four newer stages stay in flight; B: vmcnt(0)), barrier (stage s complete,
-//      every wave past its reads of stage s-1), A(s+5) / B(s+1) issued into the slots of stage s-1, 12 fragment reads, 32 MFMAs.
-//      Rows past M / N re-read the last valid row (never stored); stages past K re-read the last stage (never multiplied).
-constexpr int P2_BM = 128, P2_BN = 256, P2_AS = P2_BM * ROW3, P2_BS = P2_BN * ROW3;   // 8 KB / 16 KB per stage
-// Measured (profiles/r4c_gemm_p2_*.txt, r4d_gemm_p2_*.txt; same box, back to back): relation projection 0.653 ms (three-stage
-// version, every wave loading A and B) and 0.706 ms (this role-split version) against 0.637-0.644 ms for the single-stage 128x128
-// kernel and 0.65-0.69 ms for torch.matmul; t(K) slope 1.04 us per k against 0.96 (0.36 at the MFMA peak) -- the deep A ring changed
-// nothing, so the k loop of all these kernels is not waiting for HBM latency; in the training step: graph encoder forward -0.3..-0.5 ms,
-// RelationEncoder +0.2, step unchanged (61.0 / 60.8 vs 60.95 ms).  Kept as an opt-in (GTOS_GEMM_P2=1) with its parity test.
-const bool g_use_p2 = getenv("GTOS_GEMM_P2") && getenv("GTOS_GEMM_P2")[0] == '1';
-const int g_p2_maxk = getenv("GTOS_GEMM_P2_MAXK") ? atoi(getenv("GTOS_GEMM_P2_MAXK")) : 1023;
-
-__global__ __launch_bounds__(256, 2) void gemm_p2_nt_kernel(GemmArgs a) {
-    if (a.p_drop > 0.f) a.seed = live_seed(a.seed);
-    __shared__ __attribute__((aligned(16))) char a0[P2_AS];
-    __shared__ __attribute__((aligned(16))) char a1[P2_AS];
-    __shared__ __attribute__((aligned(16))) char a2[P2_AS];
-    __shared__ __attribute__((aligned(16))) char a3[P2_AS];
-    __shared__ __attribute__((aligned(16))) char a4[P2_AS];
-    __shared__ __attribute__((aligned(16))) char a5[P2_AS];
-    __shared__ __attribute__((aligned(16))) char b0[P2_BS];
-    __shared__ __attribute__((aligned(16))) char b1[P2_BS];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int fr = lane & 15, fq = lane >> 4;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 128;
-    const bool isA = wave < 2;                             // loader role (wave-uniform)
-    const int lw = wave & 1;                               // loader index inside its role
-    const int nN = (a.N + P2_BN - 1) / P2_BN;
-    const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
-    const int m0 = ((sq / nN) * 8 + xcd) * P2_BM, n0 = (sq % nN) * P2_BN;       // an XCD walks the N tiles of its M panels: A rows stay in its L2
-    if (m0 >= a.M) return;
-    const char* Ab = reinterpret_cast<const char*>(static_cast<const bf16_t*>(a.A) + (int64_t)m0 * a.lda);
-    const char* Bb = reinterpret_cast<const char*>(static_cast<const bf16_t*>(a.B) + (int64_t)n0 * a.ldb);
-    const char* Lb = isA ? Ab : Bb;                        // this wave's operand
-    const int lmax = isA ? a.M - 1 - m0 : a.N - 1 - n0;
-    const uint32_t ld2 = (uint32_t)(isA ? a.lda : a.ldb) * 2u;
-    const int nk = a.K / 32;
-    // DMA: a wave instruction fills 1 KB = 16 rows x 64 B; lane l -> row l >> 2, physical chunk l & 3.  Loader lw of a role owns the
-    // 16-row blocks lw, lw + 2, ... of its operand's stage: 4 of A's 8, 8 of B's 16.
-    const int drow = lane >> 2;
-    const uint32_t dchunk = (uint32_t)(((lane & 3) ^ ((-(lane >> 4)) & 3)) << 4);
-    uint32_t off[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) off[i] = (uint32_t)min((lw + 2 * i) * 16 + drow, lmax) * ld2 + dchunk;
-    const int foff = fr * ROW3 + ((fq ^ ((-(fr >> 2)) & 3)) << 4);
-
-    f32x4_t acc[4][8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    bf16x8_t fa[4], fb[8];
-
-#define GTOS_DMA1(src, dst)                                                                                                   \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),                                    \
-                                     (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
-#define GTOS_P2_DMA_A(slot, s_)                                                                                               \
-    {                                                                                                                         \
-        const int kb_ = min((s_), nk - 1) * 64;            /* byte offset of the stage's k range; past the end: dummy re-read */ \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) GTOS_DMA1(Lb + kb_ + off[i_], (slot) + (lw + 2 * i_) * 1024);        \
-    }
-#define GTOS_P2_DMA_B(slot, s_)                                                                                               \
-    {                                                                                                                         \
-        const int kb_ = min((s_), nk - 1) * 64;                                                                               \
-        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) GTOS_DMA1(Lb + kb_ + off[i_], (slot) + (lw + 2 * i_) * 1024);        \
-    }
-// sa: A slot of stage s_, da: A slot that takes stage s_+5 (= slot of s_-1); sb / db likewise for B's two slots
-#define GTOS_P2_STEP(sa, da, sb, db, s_)                                                                                      \
-    {                                                                                                                         \
-        if (isA) { GTOS_VMCNT(16); } else { GTOS_VMCNT(0); }   /* own pieces of stage s_ (A: 4 newer stages stay in flight) */ \
-        __builtin_amdgcn_s_barrier();                      /* everybody's; and every wave has read its fragments of s_-1 */   \
-        if (isA) { GTOS_P2_DMA_A(da, (s_) + 5); } else { GTOS_P2_DMA_B(db, (s_) + 1); }                                       \
-        {                                                                                                                     \
-            const uint32_t ab_ = GTOS_LDS_ADDR(sb) + fbase_b, aa_ = GTOS_LDS_ADDR(sa) + fbase_a;                              \
-            GTOS_DSR128(fb[0], ab_, 0); GTOS_DSR128(fb[1], ab_, 1024); GTOS_DSR128(fb[2], ab_, 2048); GTOS_DSR128(fb[3], ab_, 3072);   \
-            GTOS_DSR128(fb[4], ab_, 4096); GTOS_DSR128(fb[5], ab_, 5120); GTOS_DSR128(fb[6], ab_, 6144); GTOS_DSR128(fb[7], ab_, 7168); \
-            GTOS_DSR128(fa[0], aa_, 0); GTOS_DSR128(fa[1], aa_, 1024); GTOS_DSR128(fa[2], aa_, 2048); GTOS_DSR128(fa[3], aa_, 3072);   \
-        }                                                                                                                     \
-        __builtin_amdgcn_s_waitcnt(0xc07f);                /* lgkmcnt(0): fragments in registers */                            \
-        asm volatile("" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]),   \
-                          "+v"(fb[4]), "+v"(fb[5]), "+v"(fb[6]), "+v"(fb[7]));   /* the MFMAs below consume values defined AFTER the wait */ \
-        __builtin_amdgcn_sched_barrier(0);                                                                                    \
-        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                                      \
-            _Pragma("unroll") for (int nt = 0; nt < 8; ++nt)                                                                  \
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);                  \
-        __builtin_amdgcn_sched_barrier(0);                                                                                    \
-    }
-
-    // The fragment reads are inline assembly: hipcc's wait-count pass, which cannot know that a wave only ever issues DMA into ITS
-    // role's slots, put s_waitcnt vmcnt(0) in front of every other step's ds_read (checked in the ISA) and with it drained the deep
-    // A ring.  Reads it does not see get no waits; the waits needed are the explicit ones of GTOS_P2_STEP.
-    const uint32_t fbase_a = (uint32_t)(wm * ROW3 + foff), fbase_b = (uint32_t)(wn * ROW3 + foff);
-#define GTOS_LDS_ADDR(p_) ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)(p_))
-#define GTOS_DSR128(dst_, addr_, imm_) asm volatile("ds_read_b128 %0, %1 offset:" #imm_ : "=v"(dst_) : "v"(addr_))
-
-    if (isA) {
-        GTOS_P2_DMA_A(a0, 0); GTOS_P2_DMA_A(a1, 1); GTOS_P2_DMA_A(a2, 2); GTOS_P2_DMA_A(a3, 3); GTOS_P2_DMA_A(a4, 4);
-    } else {
-        GTOS_P2_DMA_B(b0, 0);
-    }
-    int s = 0;
-    for (; s + 6 <= nk; s += 6) {                          // whole sextuples: one path through the body for the wait-count pass
-        GTOS_P2_STEP(a0, a5, b0, b1, s);
-        GTOS_P2_STEP(a1, a0, b1, b0, s + 1);
-        GTOS_P2_STEP(a2, a1, b0, b1, s + 2);
-        GTOS_P2_STEP(a3, a2, b1, b0, s + 3);
-        GTOS_P2_STEP(a4, a3, b0, b1, s + 4);
-        GTOS_P2_STEP(a5, a4, b1, b0, s + 5);
-    }
-    if (s < nk) {
-        GTOS_P2_STEP(a0, a5, b0, b1, s);
-        if (s + 1 < nk) {
-            GTOS_P2_STEP(a1, a0, b1, b0, s + 1);
-            if (s + 2 < nk) {
-                GTOS_P2_STEP(a2, a1, b0, b1, s + 2);
-                if (s + 3 < nk) {
-                    GTOS_P2_STEP(a3, a2, b1, b0, s + 3);
-                    if (s + 4 < nk) GTOS_P2_STEP(a4, a3, b0, b1, s + 4);
-                }
-            }
-        }
-    }
-    GTOS_VMCNT(0);                                         // the dummy prefetches of the last steps
-    __syncthreads();                                       // every wave is done with the stages: a0..a2 become the output staging
-#undef GTOS_P2_STEP
-#undef GTOS_DSR128
-#undef GTOS_LDS_ADDR
-#undef GTOS_P2_DMA_A
-#undef GTOS_P2_DMA_B
-#undef GTOS_DMA1
-    // ---- epilogue (bf16 out): 16 rows x 128 columns of the wave tile at a time through LDS (wave-private rows), 256-byte row segments out
-    bf16_t* C = static_cast<bf16_t*>(a.C);
-    const float keep_scale = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
-    constexpr int CP = 128 * 2 + 16;                       // bytes per staged row
-    char* cs = wave == 0 ? a0 : (wave == 1 ? a1 : (wave == 2 ? a2 : a3));      // 16 x 272 B of a free 8 KB stage slot per wave
-    const bool plain = !a.bias && !a.relu && !(a.p_drop > 0.f);
-    if (plain && !a.accumulate && m0 + P2_BM <= a.M && n0 + P2_BN <= a.N) {
-        // interior tile of a plain product (the relation projections, the gate tables): no per-element conditions, addresses once
-        char* wr = cs + fr * CP + fq * 8;
-        const char* rd = cs + (lane >> 4) * CP + (lane & 15) * 16;
-        bf16_t* cp0 = C + (int64_t)(m0 + wm + (lane >> 4)) * a.ldc + n0 + wn + (lane & 15) * 8;
-        const int64_t ld4 = 4 * a.ldc;
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-#pragma unroll
-            for (int nt = 0; nt < 8; ++nt) {
-                const f32x4_t v = acc[mt][nt];
-                *reinterpret_cast<uint2*>(wr + nt * 32) = make_uint2(pack_bf(v[0], v[1]), pack_bf(v[2], v[3]));
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0)
-            const U128 v0 = *reinterpret_cast<const U128*>(rd), v1 = *reinterpret_cast<const U128*>(rd + 4 * CP);
-            const U128 v2 = *reinterpret_cast<const U128*>(rd + 8 * CP), v3 = *reinterpret_cast<const U128*>(rd + 12 * CP);
-            __builtin_amdgcn_s_waitcnt(0xc07f);            // read back before the next row block overwrites the staging rows
-            *reinterpret_cast<U128*>(cp0 + (mt * 4 + 0) * ld4) = v0;
-            *reinterpret_cast<U128*>(cp0 + (mt * 4 + 1) * ld4) = v1;
-            *reinterpret_cast<U128*>(cp0 + (mt * 4 + 2) * ld4) = v2;
-            *reinterpret_cast<U128*>(cp0 + (mt * 4 + 3) * ld4) = v3;
-        }
-        return;
-    }
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-#pragma unroll
-        for (int nt = 0; nt < 8; ++nt) {
-            float v[4] = {acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]};
-            if (!plain) {
-                const int m = m0 + wm + mt * 16 + fr, n = n0 + wn + nt * 16 + fq * 4;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (a.bias && n + i < a.N) v[i] += a.bias[n + i];
-                    if (a.relu) v[i] = fmaxf(v[i], 0.f);
-                    if (a.p_drop > 0.f)
-                        v[i] = drop_keep(a.seed, (uint64_t)m * (uint64_t)a.N + (uint64_t)(n + i), a.p_drop) ? v[i] * keep_scale : 0.f;
-                }
-            }
-            *reinterpret_cast<uint2*>(cs + fr * CP + (nt * 16 + fq * 4) * 2) = make_uint2(pack_bf(v[0], v[1]), pack_bf(v[2], v[3]));
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0)
-#pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-            const int row = pass * 4 + (lane >> 4), col = (lane & 15) * 8;
-            const int m = m0 + wm + mt * 16 + row, n = n0 + wn + col;
-            if (m >= a.M || n >= a.N) continue;
-            uint4 val = *reinterpret_cast<const uint4*>(cs + row * CP + col * 2);
-            bf16_t* cp = C + (int64_t)m * a.ldc + n;
-            if (n + 8 <= a.N) {
-                if (a.accumulate) {
-                    const uint4 old = *reinterpret_cast<const uint4*>(cp);
-                    val = make_uint4(pack_bf(lo_bf(val.x) + lo_bf(old.x), hi_bf(val.x) + hi_bf(old.x)),
-                                     pack_bf(lo_bf(val.y) + lo_bf(old.y), hi_bf(val.y) + hi_bf(old.y)),
-                                     pack_bf(lo_bf(val.z) + lo_bf(old.z), hi_bf(val.z) + hi_bf(old.z)),
-                                     pack_bf(lo_bf(val.w) + lo_bf(old.w), hi_bf(val.w) + hi_bf(old.w)));
-                }
-                *reinterpret_cast<uint4*>(cp) = val;
-            } else {
-                const bf16_t* e = reinterpret_cast<const bf16_t*>(cs + row * CP + col * 2);
-                for (int i = 0; i < 8 && n + i < a.N; ++i) {
-                    float o = bf2f(e[i]);
-                    if (a.accumulate) o += bf2f(cp[i]);
-                    cp[i] = f2bf(o);
-                }
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);                // the reads are done before the next row block overwrites the staging rows
-    }
-}
-
-int launch_p2(const GemmArgs& a, hipStream_t s) {
-    const long long nMt = (a.M + P2_BM - 1) / P2_BM, nNt = (a.N + P2_BN - 1) / P2_BN;
-    const long long nblk = ((nMt + 7) / 8) * 8 * nNt;
-    if (nblk > 0x7fffffffLL) return -6;
-    hipLaunchKernelGGL(gemm_p2_nt_kernel, dim3((unsigned)nblk), dim3(256), 0, s, a);
-    GTOS_CHECK_LAUNCH();
-    return 0;
-}
-
-// ---- gemm_w4_nt_kernel (round 4, OPT-IN: GTOS_GEMM_W4=1; an experiment that reaches the default kernel's rate, not more): the deep-K
-//      forward shape (the K = L*2d bank-gradient slab: 3.65 TFLOP, 3.2-3.5 ms of every C2 step) on the 256 x 256 tile of
-//      gemm256p_nt_kernel with FOUR waves of 128 x 128 (all 256 accumulation registers of a lane, one wave per SIMD) instead of eight of
-//      128 x 64 -- the shape of the hipBLASLt kernel that reaches 1.33-1.41 PF/s on these products where gemm256p_nt_kernel reaches
-//      1.07-1.19.  Five builds, all bit-checked by tests/test_hip_parity.py::test_gemm_deep_k_one_wave_per_simd:
-//        1. LDS-DMA three 32-k stages ahead, fragments of the next step in a second register set      0.97-1.02 PF/s
-//        2. the same, four stages ahead (the register set as the fifth)                                0.97-1.02
-//        3. global loads into registers two steps ahead, ds_write into two LDS slots                   1.01-1.02
-//        4. 64-k stages = one whole cache line per matrix row and stage (was: half a line twice)       1.00-1.12 (square 8192^3: 0.63 -> 1.05-1.10)
-//        5. A two stages deep in registers, every memory instruction between two MFMAs, one load per
-//           8-MFMA group, non-temporal hint on A                                                       1.05-1.14
-//      with the measuring switches of the kernel (GTOS_GEMM_W4_DBG): MFMAs + barriers alone 1.81-2.06 PF/s; with the LDS traffic
-//      1.59-1.81; with the global loads 1.05-1.19 EVEN WHEN every load hits the L1 (all stages redirected to the lines of stage 0) and
-//      whatever their form (global / buffer / LDS-DMA), depth (1-4 stages) or spacing: a 1 KB wave load costs its wave ~60 cycles in
-//      which it issues nothing else, 16 of them per 128 MFMAs, and with one wave per SIMD nobody else feeds the MFMA pipe meanwhile.
-//      The two-waves-per-SIMD ping-pong of gemm256p_nt_kernel hides about as much as this kernel saves.  Left in the tree as the
-//      measured record of that; profiles/r4w_gemm_w4.txt.
-//      hipcc cannot allocate a 256-register accumulator (it permutes tiles through VGPRs and scratch at the loop header, and the scratch
-//      traffic breaks hand-counted vmcnt waits): the MFMAs name a0..a255 themselves (gemm_w4_gen.h, written by tools/gen_gemm_w4.py;
-//      tools/check_gemm_w4_isa.py checks that the compiler stays out of those registers).
-const bool g_use_w4 = getenv("GTOS_GEMM_W4") && getenv("GTOS_GEMM_W4")[0] == '1';
-const int g_w4_mink = getenv("GTOS_GEMM_W4_MINK") ? atoi(getenv("GTOS_GEMM_W4_MINK")) : 2048;
-
-constexpr int W4_ROW = 128;                                // bytes per staged row: 64 k, one whole cache line per row and stage
-constexpr int W4_A = 256 * W4_ROW;                         // bytes of the A half of a stage (the B half follows)
-constexpr int W4_ST = 2 * W4_A;                            // 64 KB per stage
-
-template <int DBG> __global__ __launch_bounds__(256, 1) void gemm_w4_nt_kernel(GemmArgs a) {
-    if (a.p_drop > 0.f) a.seed = live_seed(a.seed);
-    // Two LDS slots of one 64-k stage each (stage t in slot t & 1).  A stage row is 128 B = ONE whole cache line per matrix row: with
-    // the 64-byte rows of the 32-k stages of gemm256p_nt_kernel every line is requested twice, in consecutive steps, through a vector
-    // L1 that a step's 64 KB of lines has flushed in between -- measured on this kernel's first builds: MFMAs + barriers alone 1.9-2.06
-    // PF/s, with the LDS traffic 1.54-1.69, with the global loads 0.63-1.02 whatever the prefetch depth (LDS-DMA three or four stages
-    // ahead, or registers two steps ahead).  The stage in flight lives in REGISTERS (16 x 16 B per lane) and reaches the LDS by
-    // ds_write one step after its loads were issued.
-    __shared__ __attribute__((aligned(16))) char st[2 * W4_ST];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int fr = lane & 15, fq = lane >> 4;
-    const int wm = (wave >> 1) * 128, wn = (wave & 1) * 128;
-    const int nN = (a.N + BN2 - 1) / BN2;
-    const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
-    const int m0 = ((sq / nN) * 8 + xcd) * BM2, n0 = (sq % nN) * BN2;
-    if (m0 >= a.M) return;
-    const char* Ab = reinterpret_cast<const char*>(static_cast<const bf16_t*>(a.A) + (int64_t)m0 * a.lda);
-    const char* Bb = reinterpret_cast<const char*>(static_cast<const bf16_t*>(a.B) + (int64_t)n0 * a.ldb);
-    const int amax = a.M - 1 - m0, bmax = a.N - 1 - n0;
-    const uint32_t lda2 = (uint32_t)a.lda * 2u, ldb2 = (uint32_t)a.ldb * 2u;
-    const int nk = a.K / 64;
-    // a wave instruction moves 1 KB = 8 rows x 128 B: lane l -> row l >> 3 of the piece; its 16 B land at lane * 16 of the piece
-    // (physical chunk l & 7) and come from logical chunk (l & 7) ^ (row & 7) of the line.  Wave w owns the 8-row pieces w, w + 4, ...,
-    // w + 28 of each operand's 32.
-    const int drow = lane >> 3;
-    const uint32_t dchunk = (uint32_t)(((lane & 7) ^ drow) << 4);
-    uint32_t goff[16];                                     // pieces 0..7: A, 8..15: B
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        goff[i] = (uint32_t)min((wave + 4 * i) * 8 + drow, amax) * lda2 + dchunk;
-        goff[8 + i] = (uint32_t)min((wave + 4 * i) * 8 + drow, bmax) * ldb2 + dchunk;
-    }
-#define GTOS_LDS_ADDR(p_) ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)(p_))
-    // fragment of 16 rows x 32 k (k half h of the stage): lane (fr, fq) reads logical chunk h * 4 + fq of row fr
-    const uint32_t fsw0 = (uint32_t)(fr * W4_ROW + ((fq ^ (fr & 7)) << 4)), fsw1 = (uint32_t)(fr * W4_ROW + (((4 + fq) ^ (fr & 7)) << 4));
-    const uint32_t lds0 = GTOS_LDS_ADDR(st);
-    const uint32_t wbase = lds0 + (uint32_t)(wave * 1024 + lane * 16);    // + 4096 * i for A piece i, + W4_A + 4096 * i for B piece i
-
-    // the 128 x 128 fp32 wave tile lives in a0..a255, named by the inline assembly of gemm_w4_gen.h (tile (mt, nt) = a[(mt*8+nt)*4 ..]);
-    // the compiler never sees an accumulator value, and must not use an accumulation register of its own in this kernel
-    // (tools/check_gemm_w4_isa.py checks the compiled kernel for that)
-    GTOS_W4_ZERO();
-    bf16x8_t fa[8], fbx[8], fby[8];                        // A fragments: one set, refilled row block by row block; B: two sets
-    // stages in flight, in registers: A two steps deep (set t & 1 holds the lane's 8 pieces of stage t), B one step.  A is the operand
-    // that streams from HBM (in the products this kernel is for, B is a weight matrix that stays in the L2); with one 64 KB stage in
-    // flight per CU the loads set the pace -- all stages redirected to the lines of stage 0 (L1 hits) or of stages 0..7 (L2 hits): 1.8-2.0
-    // PF/s; real addresses: 1.0-1.1.
-    U128 ga0[8], ga1[8], gb[8];
-
-// All memory instructions of the loop are inline assembly, issued where they are written, with the waits written out: hipcc sinks
-// ordinary LDS reads to just before their use and drains lgkmcnt(0) there (four exposed LDS latencies per step in the first build).
-#define GTOS_DSR128(dst_, addr_, imm_) if (DBG != 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst_) : "v"(addr_), "n"(imm_))
-#define GTOS_DSW128(addr_, src_, imm_) if (DBG != 2) asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(addr_), "v"(src_), "n"(imm_) : "memory")
-#define GTOS_GLD128(dst_, off_, base_) if (DBG != 1 && DBG != 2) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst_) : "v"(off_), "s"(base_))
-// A streams through the L2 once per block row: its loads carry the non-temporal hint (worth 0-7 % on the bank-gradient product)
-#define GTOS_GLD128A(dst_, off_, base_) if (DBG != 1 && DBG != 2) asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(dst_) : "v"(off_), "s"(base_))
-#define GTOS_GLD128B(dst_, off_, base_) GTOS_GLD128(dst_, off_, base_)
-// DBG (GTOS_GEMM_W4_DBG, a measuring aid; results are garbage for DBG != 0): 1 = no global loads, 2 = no LDS traffic either (MFMAs +
-// barriers), 4 = every stage loads the k range of stage 0 (L1 hits)
-#define GTOS_W4_KB(s_) (DBG == 4 ? 0 : min((s_), nk - 1) * 128)          /* byte offset of a stage's k range; past the end: dummy re-read */
-#define GTOS_W4_KBA(s_) GTOS_W4_KB(s_)
-#define GTOS_W4_KBB(s_) GTOS_W4_KB(s_)
-#define GTOS_W4_LOAD_A(GA, s_)                                                                                                \
-    {                                                                                                                         \
-        const char* p_ = Ab + GTOS_W4_KBA(s_);                                                                                \
-        GTOS_GLD128A(GA[0], goff[0], p_); GTOS_GLD128A(GA[1], goff[1], p_); GTOS_GLD128A(GA[2], goff[2], p_); GTOS_GLD128A(GA[3], goff[3], p_); \
-        GTOS_GLD128A(GA[4], goff[4], p_); GTOS_GLD128A(GA[5], goff[5], p_); GTOS_GLD128A(GA[6], goff[6], p_); GTOS_GLD128A(GA[7], goff[7], p_); \
-    }
-#define GTOS_W4_LOAD_B(s_)                                                                                                    \
-    {                                                                                                                         \
-        const char* p_ = Bb + GTOS_W4_KBB(s_);                                                                                \
-        GTOS_GLD128B(gb[0], goff[8], p_); GTOS_GLD128B(gb[1], goff[9], p_); GTOS_GLD128B(gb[2], goff[10], p_); GTOS_GLD128B(gb[3], goff[11], p_);   \
-        GTOS_GLD128B(gb[4], goff[12], p_); GTOS_GLD128B(gb[5], goff[13], p_); GTOS_GLD128B(gb[6], goff[14], p_); GTOS_GLD128B(gb[7], goff[15], p_); \
-    }
-#define GTOS_W4_DEP8(F) asm volatile("" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3]), "+v"(F[4]), "+v"(F[5]), "+v"(F[6]), "+v"(F[7]))
-// group mt of the FIRST half step (k half 0 of stage s in fa / fbx): B fragment mt of k half 1 of the same stage into fby; A piece mt
-// and B piece mt of stage s+1 from their registers into the other slot; the load of B piece mt-1 of stage s+2 into the registers
-// written one group earlier; the row block's A fragment of k half 1 over the one just consumed.  Group mt of the SECOND half step
-// (k half 1 of stage s): B fragment mt and A fragment mt of k half 0 of stage s+1, and the load of A piece mt of stage s+3.  One load
-// per group: the four waves of a workgroup run in lock step, and 16 loads per wave inside one half step keep the CU's address unit
-// busy for that whole half step (every wave stalls at its issue), while the other half step sends it nothing.
-// The loads of a step are issued B(s+2) b0..7, then A(s+3) a0..7; at the write of A piece mt the loads that may stay in flight are
-// 7 - mt + B(s+1) + A(s+2) + mt - 1 = 22, at the write of B piece mt 7 - mt + A(s+2) + mt - 1 = 14.
-// Every memory instruction sits between two MFMAs: a wave issues in order, and while it issues memory instructions in a row its SIMD's
-// MFMA pipe, which nobody else feeds in this kernel, runs dry.
-#define GTOS_W4_GROUP0(mt, GA)                                                                                                \
-    {                                                                                                                         \
-        GTOS_W4_MFMA(mt, 0, fa[mt], fbx);                                                                                     \
-        GTOS_DSR128(fby[mt], rb1_, (mt) * 2048);                                                                              \
-        GTOS_W4_MFMA(mt, 1, fa[mt], fbx);                                                                                     \
-        GTOS_VMCNT(22);                                                                                                       \
-        asm volatile("" : "+v"(GA[mt]));                                                                                      \
-        GTOS_DSW128(w_, GA[mt], (mt) * 4096);                                                                                 \
-        GTOS_W4_MFMA(mt, 2, fa[mt], fbx);                                                                                     \
-        GTOS_VMCNT(14);                                                                                                       \
-        asm volatile("" : "+v"(gb[mt]));                                                                                      \
-        GTOS_DSW128(w_, gb[mt], W4_A + (mt) * 4096);                                                                          \
-        GTOS_W4_MFMA(mt, 3, fa[mt], fbx);                                                                                     \
-        if ((mt) > 0) GTOS_GLD128B(gb[(mt) > 0 ? (mt) - 1 : 0], goff[8 + ((mt) > 0 ? (mt) - 1 : 0)], pb_);                    \
-        GTOS_W4_MFMA(mt, 4, fa[mt], fbx);                                                                                     \
-        GTOS_W4_MFMA(mt, 5, fa[mt], fbx);                                                                                     \
-        GTOS_W4_MFMA(mt, 6, fa[mt], fbx);                                                                                     \
-        GTOS_W4_MFMA(mt, 7, fa[mt], fbx);                                                                                     \
-        GTOS_DSR128(fa[mt], ra1_, (mt) * 2048);                                                                               \
-    }
-#define GTOS_W4_GROUP1(mt, GA)                                                                                                \
-    {                                                                                                                         \
-        GTOS_W4_MFMA(mt, 0, fa[mt], fby);                                                                                     \
-        GTOS_DSR128(fbx[mt], nb0_, (mt) * 2048);                                                                              \
-        GTOS_W4_MFMA(mt, 1, fa[mt], fby);                                                                                     \
-        GTOS_GLD128A(GA[mt], goff[mt], pa_);                                                                                  \
-        GTOS_W4_MFMA(mt, 2, fa[mt], fby); GTOS_W4_MFMA(mt, 3, fa[mt], fby); GTOS_W4_MFMA(mt, 4, fa[mt], fby);                 \
-        GTOS_W4_MFMA(mt, 5, fa[mt], fby); GTOS_W4_MFMA(mt, 6, fa[mt], fby); GTOS_W4_MFMA(mt, 7, fa[mt], fby);                 \
-        GTOS_DSR128(fa[mt], na0_, (mt) * 2048);                                                                               \
-    }
-// step s_: k half 0 of stage s_ is in fa / fbx.  First half step: MFMAs on it; k half 1 of stage s_ (slot s_ & 1) into fa / fby; stage
-// s_+1 from the registers (GA = its A set) into slot (s_+1) & 1 (free since the middle of step s_-1); loads of A(s_+3), B(s_+2).
-// Barrier.  Second half step: MFMAs on fa / fby; k half 0 of stage s_+1 into fa / fbx.
-#define GTOS_W4_STEP(s_, GA)                                                                                                  \
-    {                                                                                                                         \
-        const uint32_t cur = lds0 + (uint32_t)(((s_) & 1) * W4_ST), nxt = lds0 + (uint32_t)((((s_) + 1) & 1) * W4_ST);        \
-        const uint32_t ra1_ = cur + (uint32_t)(wm * W4_ROW) + fsw1, rb1_ = cur + (uint32_t)(W4_A + wn * W4_ROW) + fsw1;      \
-        const uint32_t na0_ = nxt + (uint32_t)(wm * W4_ROW) + fsw0, nb0_ = nxt + (uint32_t)(W4_A + wn * W4_ROW) + fsw0;      \
-        const uint32_t w_ = wbase + (uint32_t)((((s_) + 1) & 1) * W4_ST);                                                     \
-        const char* pa_ = Ab + GTOS_W4_KBA((s_) + 3);                                                                         \
-        const char* pb_ = Bb + GTOS_W4_KBB((s_) + 2);                                                                         \
-        GTOS_W4_GROUP0(0, GA);                                                                                                \
-        __builtin_amdgcn_s_waitcnt(0xc47f);                /* lgkmcnt(4): the refill of fa[7], the previous half step's last read */ \
-        GTOS_W4_GROUP0(1, GA);                                                                                                \
-        GTOS_W4_GROUP0(2, GA);                                                                                                \
-        GTOS_W4_GROUP0(3, GA);                                                                                                \
-        GTOS_W4_GROUP0(4, GA);                                                                                                \
-        GTOS_W4_GROUP0(5, GA);                                                                                                \
-        GTOS_W4_GROUP0(6, GA);                                                                                                \
-        GTOS_W4_GROUP0(7, GA);                                                                                                \
-        GTOS_GLD128B(gb[7], goff[15], pb_);                                                                                   \
-        __builtin_amdgcn_s_waitcnt(0xc17f);                /* lgkmcnt(1): all but the refill of fa[7] -- own writes, fby, fa[0..6] */ \
-        GTOS_W4_DEP8(fa);                                                                                                     \
-        GTOS_W4_DEP8(fby);                                                                                                    \
-        __builtin_amdgcn_s_barrier();                      /* stage s_+1 is in its slot for everybody */                       \
-        GTOS_W4_GROUP1(0, GA);                                                                                                  \
-        __builtin_amdgcn_s_waitcnt(0xc27f);                /* lgkmcnt(2): the refill of fa[7] */                               \
-        GTOS_W4_GROUP1(1, GA);                                                                                                  \
-        GTOS_W4_GROUP1(2, GA);                                                                                                  \
-        GTOS_W4_GROUP1(3, GA);                                                                                                  \
-        GTOS_W4_GROUP1(4, GA);                                                                                                  \
-        GTOS_W4_GROUP1(5, GA);                                                                                                  \
-        GTOS_W4_GROUP1(6, GA);                                                                                                  \
-        GTOS_W4_GROUP1(7, GA);                                                                                                  \
-        __builtin_amdgcn_s_waitcnt(0xc17f);                /* lgkmcnt(1) */                                                    \
-        GTOS_W4_DEP8(fa);                                                                                                     \
-        GTOS_W4_DEP8(fbx);                                                                                                    \
-    }
-
-    GTOS_W4_LOAD_A(ga0, 0);
-    GTOS_W4_LOAD_B(0);
-    GTOS_VMCNT(0);
-    GTOS_W4_DEP8(ga0);
-    GTOS_W4_DEP8(gb);
-    GTOS_DSW128(wbase, ga0[0], 0); GTOS_DSW128(wbase, ga0[1], 4096); GTOS_DSW128(wbase, ga0[2], 8192); GTOS_DSW128(wbase, ga0[3], 12288);
-    GTOS_DSW128(wbase, ga0[4], 16384); GTOS_DSW128(wbase, ga0[5], 20480); GTOS_DSW128(wbase, ga0[6], 24576); GTOS_DSW128(wbase, ga0[7], 28672);
-    GTOS_DSW128(wbase, gb[0], W4_A); GTOS_DSW128(wbase, gb[1], W4_A + 4096); GTOS_DSW128(wbase, gb[2], W4_A + 8192); GTOS_DSW128(wbase, gb[3], W4_A + 12288);
-    GTOS_DSW128(wbase, gb[4], W4_A + 16384); GTOS_DSW128(wbase, gb[5], W4_A + 20480); GTOS_DSW128(wbase, gb[6], W4_A + 24576); GTOS_DSW128(wbase, gb[7], W4_A + 28672);
-    // the load queue the first step expects: A(1), B(1), A(2)
-    GTOS_W4_LOAD_A(ga1, 1);
-    GTOS_W4_LOAD_B(1);
-    GTOS_W4_LOAD_A(ga0, 2);
-    __builtin_amdgcn_s_waitcnt(0xc07f);                    // own writes of stage 0 done
-    __builtin_amdgcn_s_barrier();
-    {
-        const uint32_t ra_ = lds0 + (uint32_t)(wm * W4_ROW) + fsw0, rb_ = lds0 + (uint32_t)(W4_A + wn * W4_ROW) + fsw0;
-        GTOS_DSR128(fbx[0], rb_, 0); GTOS_DSR128(fbx[1], rb_, 2048); GTOS_DSR128(fbx[2], rb_, 4096); GTOS_DSR128(fbx[3], rb_, 6144);
-        GTOS_DSR128(fbx[4], rb_, 8192); GTOS_DSR128(fbx[5], rb_, 10240); GTOS_DSR128(fbx[6], rb_, 12288); GTOS_DSR128(fbx[7], rb_, 14336);
-        GTOS_DSR128(fa[0], ra_, 0); GTOS_DSR128(fa[1], ra_, 2048); GTOS_DSR128(fa[2], ra_, 4096); GTOS_DSR128(fa[3], ra_, 6144);
-        GTOS_DSR128(fa[4], ra_, 8192); GTOS_DSR128(fa[5], ra_, 10240); GTOS_DSR128(fa[6], ra_, 12288); GTOS_DSR128(fa[7], ra_, 14336);
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    GTOS_W4_DEP8(fa);
-    GTOS_W4_DEP8(fbx);
-    int s = 0;
-    for (; s + 2 <= nk; s += 2) {                          // A(s+1) lives in register set (s+1) & 1
-        GTOS_W4_STEP(s, ga1);
-        GTOS_W4_STEP(s + 1, ga0);
-    }
-    if (s < nk) GTOS_W4_STEP(s, ga1);
-    GTOS_VMCNT(0);                                         // the dummy prefetches of the last steps
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    // the destination registers of those last loads and reads stay allocated until here: an output nobody reads is a dead value to the
-    // compiler, which hands its registers to something else while the load is still in flight (the odd-stage-count tail of the second
-    // build put a B fragment where a prefetch landed)
-    GTOS_W4_DEP8(ga0); GTOS_W4_DEP8(ga1); GTOS_W4_DEP8(gb); GTOS_W4_DEP8(fa); GTOS_W4_DEP8(fbx); GTOS_W4_DEP8(fby);
-    __syncthreads();                                       // every wave is done with the slots: they become the output staging
-#undef GTOS_W4_STEP
-#undef GTOS_W4_GROUP1
-#undef GTOS_W4_GROUP0
-#undef GTOS_W4_DEP8
-#undef GTOS_W4_LOAD_B
-#undef GTOS_W4_LOAD_A
-#undef GTOS_GLD128B
-#undef GTOS_GLD128A
-#undef GTOS_W4_KBB
-#undef GTOS_W4_KBA
-#undef GTOS_W4_KB
-#undef GTOS_GLD128
-#undef GTOS_DSW128
-#undef GTOS_DSR128
-#undef GTOS_LDS_ADDR
-
-    // ---- epilogue (bf16 out): 32 rows x 128 columns of the wave tile at a time through the wave's own stage slot
-    bf16_t* C = static_cast<bf16_t*>(a.C);
-    const float keep_scale = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
-    constexpr int CP = 128 * 2 + 16;
-    char* cs = st + wave * 16384;                          // 32 x 272 B per wave
-    const bool plain = !a.bias && !a.relu && !(a.p_drop > 0.f);
-    // MFMA results are not interlocked against v_accvgpr_read issued from inline assembly: the loop's last MFMAs retire first
-    asm volatile("s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15");
-    auto put = [&](int mt, int nt, float v0, float v1, float v2, float v3) {
-        float v[4] = {v0, v1, v2, v3};
-        if (!plain) {
-            const int m = m0 + wm + mt * 16 + fr, n = n0 + wn + nt * 16 + fq * 4;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (a.bias && n + i < a.N) v[i] += a.bias[n + i];
-                if (a.relu) v[i] = fmaxf(v[i], 0.f);
-                if (a.p_drop > 0.f)
-                    v[i] = drop_keep(a.seed, (uint64_t)m * (uint64_t)a.N + (uint64_t)(n + i), a.p_drop) ? v[i] * keep_scale : 0.f;
-            }
-        }
-        *reinterpret_cast<uint2*>(cs + ((mt & 1) * 16 + fr) * CP + (nt * 16 + fq * 4) * 2) = make_uint2(pack_bf(v[0], v[1]), pack_bf(v[2], v[3]));
-    };
-    auto flush = [&](int q4) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0)
-#pragma unroll
-        for (int pass = 0; pass < 8; ++pass) {
-            const int row = pass * 4 + (lane >> 4), col = (lane & 15) * 8;
-            const int m = m0 + wm + q4 * 32 + row, n = n0 + wn + col;
-            if (m >= a.M || n >= a.N) continue;
-            uint4 val = *reinterpret_cast<const uint4*>(cs + row * CP + col * 2);
-            bf16_t* cp = C + (int64_t)m * a.ldc + n;
-            if (n + 8 <= a.N) {
-                if (a.accumulate) {
-                    const uint4 old = *reinterpret_cast<const uint4*>(cp);
-                    val = make_uint4(pack_bf(lo_bf(val.x) + lo_bf(old.x), hi_bf(val.x) + hi_bf(old.x)),
-                                     pack_bf(lo_bf(val.y) + lo_bf(old.y), hi_bf(val.y) + hi_bf(old.y)),
-                                     pack_bf(lo_bf(val.z) + lo_bf(old.z), hi_bf(val.z) + hi_bf(old.z)),
-                                     pack_bf(lo_bf(val.w) + lo_bf(old.w), hi_bf(val.w) + hi_bf(old.w)));
-                }
-                *reinterpret_cast<uint4*>(cp) = val;
-            } else {
-                const bf16_t* e = reinterpret_cast<const bf16_t*>(cs + row * CP + col * 2);
-                for (int i = 0; i < 8 && n + i < a.N; ++i) {
-                    float o = bf2f(e[i]);
-                    if (a.accumulate) o += bf2f(cp[i]);
-                    cp[i] = f2bf(o);
-                }
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-    };
-    GTOS_W4_TILES_0(put); flush(0);
-    GTOS_W4_TILES_1(put); flush(1);
-    GTOS_W4_TILES_2(put); flush(2);
-    GTOS_W4_TILES_3(put); flush(3);
-}
-
-int launch_w4(const GemmArgs& a, hipStream_t s) {
-    const long long nMt = (a.M + BM2 - 1) / BM2, nNt = (a.N + BN2 - 1) / BN2;
-    const long long nblk = ((nMt + 7) / 8) * 8 * nNt;
-    if (nblk > 0x7fffffffLL) return -6;
-    static const int dbg = getenv("GTOS_GEMM_W4_DBG") ? atoi(getenv("GTOS_GEMM_W4_DBG")) : 0;
-    if (dbg == 1) hipLaunchKernelGGL(gemm_w4_nt_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, s, a);
-    else if (dbg == 2) hipLaunchKernelGGL(gemm_w4_nt_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, s, a);
-    else if (dbg == 4) hipLaunchKernelGGL(gemm_w4_nt_kernel<4>, dim3((unsigned)nblk), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(gemm_w4_nt_kernel<0>, dim3((unsigned)nblk), dim3(256), 0, s, a);
-    GTOS_CHECK_LAUNCH();
-    return 0;
-}
+// (Round 4's two opt-in experiments lived here: gemm_p2_nt_kernel -- two role-split 4-wave workgroups per CU on 128x256 tiles for
+//  K <= 1023 -- and gemm_w4_nt_kernel -- one wave per SIMD with a 256-register accumulator named by hand.  Both were bit-checked on the
+//  GPU and measured at or below the default kernels (profiles/r4c_gemm_p2_*.txt, r4d_*, r4w_gemm_w4.txt; DESIGN.md section 0 keeps the
+//  findings: a 1 KB LDS-DMA piece costs its wave ~60 issue cycles whether it hits or not, whole 128-byte rows per stage matter).  They
+//  are not part of the library any more; the last commit that carries them is 4bd4edb.)
 
 int launch256p(const GemmArgs& a, hipStream_t s) {
     const long long nMt = (a.M + BM2 - 1) / BM2, nNt = (a.N + BN2 - 1) / BN2;
@@ -1450,7 +918,19 @@ int launch256p(const GemmArgs& a, hipStream_t s) {
 //      from ds_read_b64_tr_b16 as in gemm_kernel's transpose path: 32-byte granules XOR-swizzled with (k & 3), applied
 //      on the DMA's source address.  Rows k >= kend read a block of zeros; columns past M / N re-read the last 8 valid
 //      ones (never stored); stages past the end of the split re-read its last stage (never multiplied).
-__global__ __launch_bounds__(512) void gemm256p_tn_kernel(GemmArgs a) {
+//      GROUPED (round 5): the tiles of ONE launch come from a table over TWO B operands -- the GRU weight gradients of a layer and
+//      direction, d4^T [x | h_prev] with d4 = [d r | d z | d n_x | d n_h]: dW_ih = d4[:, 0:3hs]^T x and dW_hh = d4[:, {0:2hs, 3hs:4hs}]^T
+//      h_prev used to be three products (three passes over d4, two over h_prev); here every (A column block, B column block) pair that
+//      holds a needed element is one tile, all tiles of a K split run on one XCD, and d4, x and h_prev are each fetched from HBM once.
+//      Partial tiles go to ws[split][tile][256][256]; gru_dw_reduce_kernel adds the needed elements into the two gradients.
+struct TnGroup {
+    const bf16_t* B1; int64_t ldb1; int N1;        // second B operand [K, N1]; GemmArgs.B / ldb / N describe the first
+    int tiles;
+    int tmn[64];                                   // tile t: A column block (bits 0-7), B operand (8-15), its column block (16-23), x 256
+};
+
+template <bool GROUPED>
+__global__ __launch_bounds__(512) void gemm256p_tn_kernel(GemmArgs a, TnGroup g) {
     __shared__ __attribute__((aligned(16))) char st0[ST3];
     __shared__ __attribute__((aligned(16))) char st1[ST3];
     __shared__ __attribute__((aligned(16))) char st2[ST3];
@@ -1458,11 +938,24 @@ __global__ __launch_bounds__(512) void gemm256p_tn_kernel(GemmArgs a) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fr = lane & 15, fq = lane >> 4;
     const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
-    const int nN = (a.N + BN2 - 1) / BN2, nM = (a.M + BM2 - 1) / BM2, tiles = nM * nN;
+    const int nN = (a.N + BN2 - 1) / BN2, nM = (a.M + BM2 - 1) / BM2, tiles = GROUPED ? g.tiles : nM * nN;
     const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
     const int bz = (sq / tiles) * 8 + xcd, t_ = sq % tiles;        // all tiles of one K split on one XCD
     if (bz >= a.splitk) return;
-    const int m0 = (t_ / nN) * BM2, n0 = (t_ % nN) * BN2;
+    int m0, n0, Nv;
+    const bf16_t* Bp;
+    int64_t ldb, wld;
+    float* wst;                                                    // this split's partial tile: element (m, n) at wst[(m - m0) * wld + n - n0]
+    if constexpr (GROUPED) {
+        const int e = g.tmn[t_], src = (e >> 8) & 255;
+        m0 = (e & 255) * BM2; n0 = ((e >> 16) & 255) * BN2;
+        Bp = src ? g.B1 : static_cast<const bf16_t*>(a.B); ldb = src ? g.ldb1 : a.ldb; Nv = src ? g.N1 : a.N;
+        wst = a.ws + ((int64_t)bz * tiles + t_) * (BM2 * BN2); wld = BN2;
+    } else {
+        m0 = (t_ / nN) * BM2; n0 = (t_ % nN) * BN2;
+        Bp = static_cast<const bf16_t*>(a.B); ldb = a.ldb; Nv = a.N;
+        wst = a.ws + ((int64_t)bz * a.M + m0) * a.N + n0; wld = a.N;
+    }
     const int ktiles = (a.K + 63) / 64, tps = (ktiles + a.splitk - 1) / a.splitk;   // the split boundaries of gemm_kernel
     const int kbeg = bz * tps * 64, kend = min(a.K, kbeg + tps * 64);
     if (kbeg >= kend) return;
@@ -1473,12 +966,12 @@ __global__ __launch_bounds__(512) void gemm256p_tn_kernel(GemmArgs a) {
     const int kr = lane >> 5, pp = lane & 31;
     const int kl0 = 2 * wave + kr, kq_d = kl0 & 3;
     const int lp = ((((pp >> 1) ^ kq_d)) << 1) | (pp & 1);        // logical piece (8 columns) stored at this physical slot
-    const int acol = min(m0 + lp * 8, a.M - 8), bcol = min(n0 + lp * 8, a.N - 8);
+    const int acol = min(m0 + lp * 8, a.M - 8), bcol = min(n0 + lp * 8, Nv - 8);
     // running per-lane source pointers of the NEXT stage to fetch (k-row kcur and kcur + 16 of each operand); rows at or
     // past kend -- also every row of the dummy stages after the split's last one -- read the block of zeros instead
     const char* pa = reinterpret_cast<const char*>(static_cast<const bf16_t*>(a.A) + (int64_t)(kbeg + kl0) * a.lda + acol);
-    const char* pb = reinterpret_cast<const char*>(static_cast<const bf16_t*>(a.B) + (int64_t)(kbeg + kl0) * a.ldb + bcol);
-    const int64_t a16 = 32 * a.lda, b16 = 32 * a.ldb;      // bytes: 16 k-rows
+    const char* pb = reinterpret_cast<const char*>(Bp + (int64_t)(kbeg + kl0) * ldb + bcol);
+    const int64_t a16 = 32 * a.lda, b16 = 32 * ldb;        // bytes: 16 k-rows
     int kcur = kbeg + kl0;
     // fragment reads (tr_fragment of gemm_kernel with 512-byte k-rows): lane addresses k-row fq*8 + (fr >> 2) (+4), the
     // 32-byte granule (column / 16) ^ (fr >> 2), piece fr & 3; column offsets are multiples of 64 elements + t*16
@@ -1553,7 +1046,7 @@ __global__ __launch_bounds__(512) void gemm256p_tn_kernel(GemmArgs a) {
 #undef GTOS_DMA4
 #undef GTOS_DMA1
 
-    // ---- this split's partial tile -> workspace (N % 4 == 0: plain 16-byte stores), reduced by splitk_reduce_kernel
+    // ---- this split's partial tile -> workspace (N % 4 == 0: plain 16-byte stores), reduced by splitk_reduce_kernel / gru_dw_reduce_kernel
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {
         const int m = m0 + wm + mt * 16 + fr;
@@ -1561,18 +1054,46 @@ __global__ __launch_bounds__(512) void gemm256p_tn_kernel(GemmArgs a) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const int n = n0 + wn + nt * 16 + fq * 4;
-            if (n >= a.N) continue;
-            *reinterpret_cast<float4*>(a.ws + ((int64_t)bz * a.M + m) * a.N + n) =
+            if (n >= Nv) continue;
+            *reinterpret_cast<float4*>(wst + (int64_t)(m - m0) * wld + (n - n0)) =
                 make_float4(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]);
         }
     }
+}
+
+// dW_ih[(g, c), j] += sum over splits of the partial element (A column i = g * hs + c, x column j) for g in {r, z, n_x};
+// dW_hh[(g', c), j] += ... (A column i, h_prev column j) for g in {r, z, n_h} (n_h = gate block 3 of d4 -> row block 2 of W_hh)
+struct GruDwOut { float* dwih; int64_t ld_ih; float* dwhh; int64_t ld_hh; int hs, in_dim; };
+__global__ void gru_dw_reduce_kernel(const float* __restrict__ ws, int splits, TnGroup g, GruDwOut o) {
+    const int t_ = blockIdx.x >> 6, q = (blockIdx.x & 63) * 256 + threadIdx.x;        // 64 blocks x 256 threads x float4 = one 256 x 256 tile
+    const int e = g.tmn[t_], src = (e >> 8) & 255;
+    const int r = q >> 6, c = (q & 63) * 4;
+    const int i = (e & 255) * BM2 + r, j = ((e >> 16) & 255) * BN2 + c;
+    if (i >= 4 * o.hs) return;
+    const int gate = i / o.hs, ch = i - gate * o.hs;
+    float* dst;
+    if (src == 0) {
+        if (gate == 3 || j >= o.in_dim) return;
+        dst = o.dwih + (int64_t)(gate * o.hs + ch) * o.ld_ih + j;
+    } else {
+        if (gate == 2 || j >= o.hs) return;
+        dst = o.dwhh + (int64_t)((gate == 3 ? 2 : gate) * o.hs + ch) * o.ld_hh + j;
+    }
+    const float* p = ws + (int64_t)t_ * (BM2 * BN2) + r * BN2 + c;
+    const int64_t plane = (int64_t)g.tiles * (BM2 * BN2);
+    float4 acc = *reinterpret_cast<const float4*>(p);
+    for (int s = 1; s < splits; ++s) {
+        const float4 v = *reinterpret_cast<const float4*>(p + s * plane);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    dst[0] += acc.x; dst[1] += acc.y; dst[2] += acc.z; dst[3] += acc.w;
 }
 
 int launch256p_tn(const GemmArgs& a, hipStream_t s) {
     const long long tiles = ((long long)(a.M + BM2 - 1) / BM2) * ((a.N + BN2 - 1) / BN2);
     const long long nblk = tiles * 8 * ((a.splitk + 7) / 8);
     if (nblk > 0x7fffffffLL) return -6;
-    hipLaunchKernelGGL(gemm256p_tn_kernel, dim3((unsigned)nblk), dim3(512), 0, s, a);
+    hipLaunchKernelGGL(gemm256p_tn_kernel<false>, dim3((unsigned)nblk), dim3(512), 0, s, a, TnGroup{});
     GTOS_CHECK_LAUNCH();
     return 0;
 }
@@ -1664,17 +1185,10 @@ extern "C" int gtos_gemm(int in_dtype, int out_dtype, int transA, int transB, in
         // big forward-shaped products go to the 256x256 macro tile (enough tiles to give every CU several)
         const long long t256 = ((long long)(M + BM2 - 1) / BM2) * ((N + BN2 - 1) / BN2);
         // K % 32 == 0 and enough macro tiles: the software-pipelined 256x256 kernel
-        if (g_use_w4 && !transA && transB && a.vecA && a.vecB && a.vecC && splitk == 1 && N >= 256 && K % 64 == 0 && K >= g_w4_mink &&
-            lda < (1 << 22) && ldb < (1 << 22) && t256 >= 512)
-            return launch_w4(a, s);
         if (g_use_pipe && !transA && transB && a.vecA && a.vecB && a.vecC && splitk == 1 && N >= 256 && N <= g_max_npipe && K % 32 == 0 &&
             lda < (1 << 22) && ldb < (1 << 22) &&
             ((t256 >= 512 && K >= g_min_kpipe) || (t256 <= g_pipe_small_max && K >= 256 && M >= 256)))
             return launch256p(a, s);
-        // short reduction, many tiles: two pipelined workgroups per CU, one's output write beside the other's k loop
-        if (g_use_p2 && !transA && transB && a.vecA && a.vecB && a.vecC && splitk == 1 && N >= 256 && K % 32 == 0 && K >= 128 && K <= g_p2_maxk &&
-            lda < (1 << 22) && ldb < (1 << 22) && ((long long)(M + P2_BM - 1) / P2_BM) * ((N + P2_BN - 1) / P2_BN) >= 1024)
-            return launch_p2(a, s);
         if (g_use256 && !transA && transB && a.vecA && a.vecB && a.vecC && splitk == 1 && t256 >= 1024 && N >= 256 && K >= g_min_k256)
             return launch256(a, s);
         return launch<bf16_t, bf16_t>(a, transA, transB, s);
@@ -1682,6 +1196,57 @@ extern "C" int gtos_gemm(int in_dtype, int out_dtype, int transA, int transB, in
     if (in_dtype == GTOS_BF16 && out_dtype == GTOS_F32)  return launch<bf16_t, float>(a, transA, transB, s);
     if (in_dtype == GTOS_F32 && out_dtype == GTOS_F32)   return launch<float, float>(a, transA, transB, s);
     return -1;
+}
+
+
+extern "C" int gtos_gru_weight_grads(int rows, int hs, int in_dim, int in_valid, const void* d4, const void* x, int64_t ldx, const void* hprev, int64_t ldh,
+                                     float* dwih, int64_t ld_dwih, float* dwhh, int64_t ld_dwhh, void* workspace, int64_t workspace_bytes,
+                                     void* stream) {
+    if (rows <= 0) return 0;
+    if (hs <= 0 || hs % 64 || in_dim < 8 || in_dim % 8 || ldx < in_dim || ldx % 8 || ldh < hs || ldh % 8 || in_valid < 1 || in_valid > in_dim ||
+        in_valid % 4) return -22;
+    if (!d4 || !x || !hprev || !dwih || !dwhh || !workspace) return -23;
+    if ((uintptr_t)d4 % 16 || (uintptr_t)x % 16 || (uintptr_t)hprev % 16 || (uintptr_t)dwih % 4 || (uintptr_t)dwhh % 4 || (uintptr_t)workspace % 16 ||
+        ld_dwih < in_valid || ld_dwhh < hs) return -25;
+    GemmArgs a{};
+    a.A = d4; a.lda = 4 * (int64_t)hs; a.M = 4 * hs; a.B = x; a.ldb = ldx; a.N = in_dim; a.K = rows; a.vecA = a.vecB = 1;
+    a.accumulate = 1; a.zeros = zero_block();
+    if (!a.zeros) return -5;
+    TnGroup g{};
+    g.B1 = static_cast<const bf16_t*>(hprev); g.ldb1 = ldh; g.N1 = hs;
+    int nt = 0;
+    for (int mb = 0; mb * BM2 < 4 * hs; ++mb) {
+        const int lo = mb * BM2, hi = (lo + BM2 < 4 * hs ? lo + BM2 : 4 * hs) - 1;
+        const int g_lo = lo / hs, g_hi = hi / hs;
+        const bool needs_x = g_lo <= 2, needs_h = !(g_lo == 2 && g_hi == 2);
+        for (int src = 0; src < 2; ++src) {
+            if (!(src ? needs_h : needs_x)) continue;
+            const int ncols = src ? hs : in_dim;
+            for (int nb = 0; nb * BN2 < ncols; ++nb) {
+                if (nt >= 64) return -28;
+                g.tmn[nt++] = mb | (src << 8) | (nb << 16);
+            }
+        }
+    }
+    g.tiles = nt;
+    // whole splits per XCD (its 32 CUs hold one 128 KB-LDS workgroup each), at least four 64-row k tiles per split
+    const int ktiles = (rows + 63) / 64;
+    const long long tile_bytes = (long long)BM2 * BN2 * 4;
+    long long sk = 8LL * (32 / nt > 0 ? 32 / nt : 1);
+    if (sk > ktiles / 4) sk = ktiles / 4;
+    if (sk * nt * tile_bytes > workspace_bytes) sk = workspace_bytes / (nt * tile_bytes);
+    if (sk < 1) { if (nt * tile_bytes > workspace_bytes) return -4; sk = 1; }
+    const int tps = (int)((ktiles + sk - 1) / sk);
+    a.splitk = (ktiles + tps - 1) / tps;                                   // no empty split
+    a.ws = static_cast<float*>(workspace);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long nblk = (long long)nt * 8 * ((a.splitk + 7) / 8);
+    hipLaunchKernelGGL(gemm256p_tn_kernel<true>, dim3((unsigned)nblk), dim3(512), 0, s, a, g);
+    GTOS_CHECK_LAUNCH();
+    GruDwOut o{dwih, ld_dwih, dwhh, ld_dwhh, hs, in_valid};            // columns in_valid .. in_dim of x are the zero padding of its rows
+    hipLaunchKernelGGL(gru_dw_reduce_kernel, dim3((unsigned)(nt * 64)), dim3(256), 0, s, a.ws, a.splitk, g, o);
+    GTOS_CHECK_LAUNCH();
+    return 0;
 }
 
 GTOS_SEED_EPOCH_SETTER(gemm)

@@ -482,7 +482,16 @@ struct StepBwdArgs {
     float p_drop; uint64_t seed; int64_t drop_base;
     int rows, hs; const void* zeros;
     const bf16_t* w_hn; const float* b_hn;         // optional: rows [2hs, 3hs) of W_hh (K-contiguous, ld hs) and of b_hh: hn = h_prev W_hn^T + b_hn is
-};                                                 //   RECOMPUTED here instead of read from the gates buffer (the forward did not store it)
+                                                   //   RECOMPUTED here instead of read from the gates buffer (the forward did not store it)
+    // Role B (round 5): workgroups of the SAME launch that turn the d4 rows of the step processed just before into that step's INPUT
+    // gradient, dinp[rows_prev, n_in] = d4_prev[:, 0:3hs] (d r | d z | d n_x) x W_ih -- the product nn.GRU's autograd runs as one
+    // [N,3hs] x [3hs,in] GEMM per direction after BPTT.  They read the rows the recurrent product of role A reads, at the same time and
+    // on the same XCD (one fetch from HBM into its L2 instead of two, a step apart), and their MFMA work runs beside the HBM-bound cell
+    // workgroups instead of in front of the next layer.  wi_t = W_ih^T [n_in, 3hs] (K-contiguous).  p_in > 0: dinp is masked with the
+    // dropout the forward applied to this layer's INPUT (counter in_drop_base + m * n_in + column): the label-embedding rows.
+    const bf16_t* wi_t; bf16_t* dinp; int64_t ld_dinp; int n_in; int dinp_acc;     // dinp_acc: dinp += (the other direction wrote it first)
+    float p_in; uint64_t seed_in; int64_t in_drop_base;
+};
 
 #define GTOS_DPP(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, true))
 __device__ __forceinline__ float row16_sum(float v) {   // sum over the 16 lanes of a DPP row (lane & 15)
@@ -509,18 +518,96 @@ __device__ __forceinline__ void dma_wt(const bf16_t* __restrict__ w, int64_t ld,
 // hn[128 rows x 64 channels] = h_prev[128 x hs] W_hn[64 x hs]^T + b_hn on the MFMA (hs/64 more k tiles in front of the 3hs/64 of the
 // state-gradient product), rounded to bf16 exactly like the forward rounded the value it used (same operands, same k order: identical),
 // parked in LDS (a lane reads back only what it wrote), so the register budget and the three workgroups per CU stay.
+// Role B of the backward step launch (StepBwdArgs.dinp): one 128-row x 128-column tile of the previous step's input gradient,
+// dinp[m0.., n0..] = d4_prev[m0.., 0:3hs] x wi_t[n0.., 0:3hs]^T.  Same single-stage k loop as the recurrent product of role A (the two
+// 64-row weight blocks in the permuted order of dma_wt, so a lane ends up with 16 consecutive columns of each half).
+__device__ __forceinline__ void dinp_tile(const StepBwdArgs& a, int m0, int n0, char* As, char* Bs, int wave, int lane) {
+    if (m0 >= a.rows_prev) return;
+    const int fr = lane & 15, fq = lane >> 4, hs = a.hs;
+    const U128* Z = static_cast<const U128*>(a.zeros);
+    const bool two = n0 + TC < a.n_in;                               // n_in % 64 == 0: the last tile may be half a tile wide
+    f32x4_t acc[2][8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int kk = 0; kk < 3 * hs; kk += BK) {
+        dma_rows(a.d4_prev, Z, 4 * (int64_t)hs, a.rows_prev, m0, kk, kk + BK, As, wave, lane);
+        dma_wt(a.wi_t, 3 * (int64_t)hs, n0, kk, Bs, wave, lane);
+        if (two) dma_wt(a.wi_t, 3 * (int64_t)hs, n0 + TC, kk, Bs + TC * ROWB, wave, lane);
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_t fa[2], fb[4];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) fa[mt] = *reinterpret_cast<const bf16x8_t*>(As + lds_off(wave * 32 + mt * 16 + fr, ks * 4 + fq));
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) fb[nt] = *reinterpret_cast<const bf16x8_t*>(Bs + lds_off(nt * 16 + fr, ks * 4 + fq));
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
+            if (two) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) fb[nt] = *reinterpret_cast<const bf16x8_t*>(Bs + TC * ROWB + lds_off(nt * 16 + fr, ks * 4 + fq));
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        acc[mt][4 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][4 + nt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    const float ks_in = a.p_in > 0.f ? 1.f / (1.f - a.p_in) : 1.f;
+    const uint64_t seed_in = a.p_in > 0.f ? live_seed(a.seed_in) : 0;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int m = m0 + wave * 32 + mt * 16 + fr;
+        if (m >= a.rows_prev) continue;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h == 1 && !two) continue;
+            const int nb = n0 + h * TC + fq * 16;
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = acc[mt][h * 4 + (i >> 2)][i & 3];
+            if (a.p_in > 0.f) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    v[i] = drop_keep(seed_in, (uint64_t)(a.in_drop_base + (int64_t)m * a.n_in + nb + i), a.p_in) ? v[i] * ks_in : 0.f;
+            }
+            bf16_t* dp = a.dinp + (int64_t)m * a.ld_dinp + nb;
+            if (a.dinp_acc) {
+                float old[16];
+                ld16(dp, old);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] += old[i];
+            }
+            st16(dp, v);
+        }
+    }
+}
+
+// HN: the hn recompute of round 4 (a.w_hn != NULL, opt-in) -- its 16 KB LDS park for the rebuilt values exists in that instantiation only
+template <bool HN>
 __global__ __launch_bounds__(256, 3) void gru_step_bwd_kernel(StepBwdArgs a) {
     if (a.p_drop > 0.f) a.seed = live_seed(a.seed);
-    __shared__ __attribute__((aligned(16))) char lds[A_BYTES + TC * ROWB];
-    __shared__ __attribute__((aligned(16))) char hn_lds[256 * 2 * 32];            // per lane 2 row blocks x 16 channels bf16 (16 KB)
+    __shared__ __attribute__((aligned(16))) char lds[A_BYTES + 2 * TC * ROWB];
+    __shared__ __attribute__((aligned(16))) char hn_lds[HN ? 256 * 2 * 32 : 16];  // per lane 2 row blocks x 16 channels bf16 (16 KB)
     __shared__ float btab[4 * TC];
     char* As = lds;
     char* Bs = lds + A_BYTES;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fr = lane & 15, fq = lane >> 4;
     const int hs = a.hs, nC = hs / TC;
+    const int nB = a.dinp ? (a.n_in + 2 * TC - 1) / (2 * TC) : 0, per = nC + nB;
     const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
-    const int m0 = ((sq / nC) * 8 + xcd) * TM, c0 = (sq % nC) * TC;
+    // the workgroups of a 128-row panel -- nC cell tiles (role A), then nB input-gradient tiles (role B) -- run back to back on one XCD
+    const int m0 = ((sq / per) * 8 + xcd) * TM, role = sq % per;
+    if (role >= nC) { dinp_tile(a, m0, (role - nC) * 2 * TC, As, Bs, wave, lane); return; }
+    const int c0 = role * TC;
     if (m0 >= a.rows) return;
     const U128* Z = static_cast<const U128*>(a.zeros);
     if (a.bias_part) { btab[threadIdx.x] = 0.f; }
@@ -531,7 +618,7 @@ __global__ __launch_bounds__(256, 3) void gru_step_bwd_kernel(StepBwdArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    if (a.w_hn) {
+    if (HN && a.w_hn) {
         const RowSrc hsrc = row_src(a.hprev, hs, a.rows, m0, wave, lane, a.hprev_idx);
         for (int kk = 0; kk < hs; kk += BK) {
             dma_rows_at(hsrc, Z, kk, hs, As, wave);
@@ -623,7 +710,7 @@ __global__ __launch_bounds__(256, 3) void gru_step_bwd_kernel(StepBwdArgs a) {
         float gr[16], gz[16], gn[16], hn[16], hp[16], g[16];
         const bf16_t* gp = a.gates + (int64_t)m * 4 * hs + cb;
         ld16(gp, gr); ld16(gp + hs, gz); ld16(gp + 2 * hs, gn);
-        if (a.w_hn) ld16(reinterpret_cast<const bf16_t*>(hn_lds + (threadIdx.x * 2 + mt) * 32), hn);
+        if (HN && a.w_hn) ld16(reinterpret_cast<const bf16_t*>(hn_lds + (threadIdx.x * 2 + mt) * 32), hn);
         else ld16(gp + 3 * hs, hn);
         ld16(a.hprev + (int64_t)(a.hprev_idx ? a.hprev_idx[m] : m) * hs + cb, hp);
         float* dhp = static_cast<float*>(a.dh) + (int64_t)m * a.ld_dh + cb;
@@ -750,34 +837,56 @@ extern "C" int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, i
     return 0;
 }
 
-extern "C" int gtos_gru_step_bwd(int rows, int hs, const void* d4_prev, int rows_prev, const void* w_hh_t,
-                                 const void* gates, const void* hprev, const int* hprev_idx, const void* dy, int64_t ldy, void* dh, int dh_dtype,
-                                 int64_t ld_dh, void* d4, float p_drop, uint64_t seed, int64_t drop_base, float* bias_partials,
-                                 int n_partials, void* hprev_out, const int* sum_idx, const void* dh_src, int zero_row,
-                                 const void* w_hn, const float* b_hn, void* stream) {
-    if (rows <= 0) return 0;
+extern "C" int gtos_gru_step_bwd_fused(int rows, int hs, const void* d4_prev, int rows_prev, const void* w_hh_t,
+                                       const void* gates, const void* hprev, const int* hprev_idx, const void* dy, int64_t ldy,
+                                       void* dh, int dh_dtype, int64_t ld_dh, void* d4, float p_drop, uint64_t seed, int64_t drop_base,
+                                       float* bias_partials, int n_partials, void* hprev_out, const int* sum_idx, const void* dh_src,
+                                       int zero_row, const void* w_hn, const float* b_hn,
+                                       const void* w_ih_t, void* dinp, int64_t ld_dinp, int n_in, int dinp_accumulate, float p_in,
+                                       uint64_t seed_in, int64_t in_drop_base, void* stream) {
+    const bool role_b = dinp != nullptr && d4_prev != nullptr && rows_prev > 0;
+    if (rows <= 0 && !role_b) return 0;
     if (hs <= 0 || hs % TC) return -22;
-    if (!gates || !hprev || !dh || !d4 || (d4_prev && !w_hh_t) || (w_hn && !b_hn)) return -23;
+    if (rows > 0) {
+        if (!gates || !hprev || !dh || !d4 || (d4_prev && !w_hh_t) || (w_hn && !b_hn)) return -23;
+        if (sum_idx && (!dh_src || (uintptr_t)dh_src % 16)) return -23;
+    }
+    if (dinp && (!d4_prev || !w_ih_t || sum_idx)) return -23;                 // role B reads the previous step's rows in place
+    if (dinp && (n_in <= 0 || n_in % TC || ld_dinp < n_in || ld_dinp % 8 || (uintptr_t)dinp % 16 || (uintptr_t)w_ih_t % 16)) return -27;
     if ((uintptr_t)w_hn % 16 || (uintptr_t)b_hn % 16) return -25;
     if (bias_partials && n_partials < 1) return -26;
-    if (sum_idx && (!dh_src || (uintptr_t)dh_src % 16)) return -23;
     if ((uintptr_t)d4_prev % 16 || (uintptr_t)w_hh_t % 16 || (uintptr_t)gates % 16 || (uintptr_t)hprev % 16 || (uintptr_t)dh % 16 ||
-        (uintptr_t)d4 % 16 || (dy && ((uintptr_t)dy % 16 || ldy % 8)) || ld_dh < hs || ld_dh % 8 || (uintptr_t)hprev_out % 16) return -25;
+        (uintptr_t)d4 % 16 || (dy && ((uintptr_t)dy % 16 || ldy % 8)) || (rows > 0 && (ld_dh < hs || ld_dh % 8)) ||
+        (uintptr_t)hprev_out % 16) return -25;
     StepBwdArgs a;
     a.d4_prev = (const bf16_t*)d4_prev; a.rows_prev = d4_prev ? rows_prev : 0; a.wh_t = (const bf16_t*)w_hh_t;
     a.gates = (const bf16_t*)gates; a.hprev = (const bf16_t*)hprev; a.hprev_idx = hprev_idx; a.dy = (const bf16_t*)dy; a.ldy = ldy;
     a.dh = dh; a.dh_bf16 = dh_dtype == GTOS_BF16; a.ld_dh = ld_dh; a.d4 = (bf16_t*)d4; a.bias_part = bias_partials; a.n_partials = n_partials;
     a.hp_out = (bf16_t*)hprev_out; a.sum_idx = sum_idx; a.dh_src = dh_src; a.zero_row = sum_idx ? zero_row : -1;
     a.w_hn = (const bf16_t*)w_hn; a.b_hn = b_hn;
-    a.p_drop = p_drop; a.seed = seed; a.drop_base = drop_base; a.rows = rows; a.hs = hs;
+    a.wi_t = (const bf16_t*)w_ih_t; a.dinp = role_b ? (bf16_t*)dinp : nullptr; a.ld_dinp = ld_dinp; a.n_in = n_in; a.dinp_acc = dinp_accumulate;
+    a.p_in = p_in; a.seed_in = seed_in; a.in_drop_base = in_drop_base;
+    a.p_drop = p_drop; a.seed = seed; a.drop_base = drop_base; a.rows = rows > 0 ? rows : 0; a.hs = hs;
     a.zeros = gtos_zero_block();
     if (!a.zeros) return -5;
-    const long long nM = (rows + TM - 1) / TM, nC = hs / TC;
-    const long long nblk = ((nM + 7) / 8) * 8 * nC;
+    const long long cover = role_b && rows_prev > a.rows ? rows_prev : a.rows;
+    const long long nM = (cover + TM - 1) / TM, per = hs / TC + (role_b ? (n_in + 2 * TC - 1) / (2 * TC) : 0);
+    const long long nblk = ((nM + 7) / 8) * 8 * per;
     if (nblk > 0x7fffffffLL) return -6;
-    hipLaunchKernelGGL(gru_step_bwd_kernel, dim3((unsigned)nblk), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    if (w_hn) hipLaunchKernelGGL(gru_step_bwd_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    else      hipLaunchKernelGGL(gru_step_bwd_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     GTOS_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int gtos_gru_step_bwd(int rows, int hs, const void* d4_prev, int rows_prev, const void* w_hh_t,
+                                 const void* gates, const void* hprev, const int* hprev_idx, const void* dy, int64_t ldy, void* dh, int dh_dtype,
+                                 int64_t ld_dh, void* d4, float p_drop, uint64_t seed, int64_t drop_base, float* bias_partials,
+                                 int n_partials, void* hprev_out, const int* sum_idx, const void* dh_src, int zero_row,
+                                 const void* w_hn, const float* b_hn, void* stream) {
+    return gtos_gru_step_bwd_fused(rows, hs, d4_prev, rows_prev, w_hh_t, gates, hprev, hprev_idx, dy, ldy, dh, dh_dtype, ld_dh, d4,
+                                   p_drop, seed, drop_base, bias_partials, n_partials, hprev_out, sum_idx, dh_src, zero_row, w_hn, b_hn,
+                                   nullptr, nullptr, 0, 0, 0, 0.f, 0, 0, stream);
 }
 
 GTOS_SEED_EPOCH_SETTER(gru_step)

@@ -401,6 +401,51 @@ __global__ void embed_rows_fwd_kernel(int64_t n, int dim, int dim_pad, const int
     }
 }
 
+// The RelationEncoder's packed input in ONE pass, with no host read (round 5).  The reference sorts the paths by length, packs them
+// time-major and embeds the packed tokens (generator/encoder.py:93-100); here the sorted order and the step sizes come WITH the batch
+// (the loader knows the lengths: gtos_amd.pathtrie.PathTrie.seq_order32 / batch_sizes), and packed row n = (step t, sorted path m) with
+// offs[t] <= n < offs[t+1], m = n - offs[t] takes token bank[t, order[m]]:
+//   x[n, 0:dim_pad]  = dropout(table[token]) zero-padded   (counter n * dim_pad + column, as gtos_embed_rows_fwd)
+//   onehot[n, 0:vp]  = e_token (optional, bf16): the left operand that turns the embedding's index_add backward into an MFMA product
+//   tokens[n]        = token (optional)
+template <typename T>
+__global__ __launch_bounds__(256) void embed_packed_paths_kernel(int L, int R, int64_t n_rows, const int64_t* __restrict__ bank,
+                                                                 const int* __restrict__ order, const int* __restrict__ offs,
+                                                                 const float* __restrict__ table, int dim, int dim_pad, T* __restrict__ x,
+                                                                 float p_drop, uint64_t seed, bf16_t* __restrict__ onehot, int vp,
+                                                                 int64_t* __restrict__ tokens) {
+    if (p_drop > 0.f) seed = live_seed(seed);
+    __shared__ int so[66];
+    for (int i = threadIdx.x; i <= L; i += 256) so[i] = offs[i];
+    __syncthreads();
+    const int vpr = dim_pad / 8, ovr = vp / 8;
+    const float ks = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_rows * vpr; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = t / vpr; const int cv = (int)(t % vpr), c = cv * 8;
+        int lo = 0, hi = L;                                  // the step whose range holds `row`
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (so[mid] <= row) lo = mid; else hi = mid; }
+        const int64_t tk = bank[(int64_t)lo * R + order[row - so[lo]]];
+        const float* src = table + tk * dim;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float xv = (c + e < dim) ? src[c + e] : 0.f;
+            if (p_drop > 0.f) xv = drop_keep(seed, (uint64_t)row * dim_pad + c + e, p_drop) ? xv * ks : 0.f;
+            v[e] = xv;
+        }
+        Vec8<T>::store(x + row * dim_pad + c, v);
+        if (onehot) {
+            for (int oc = cv; oc < ovr; oc += vpr) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (oc * 8 + e == tk) ? 1.f : 0.f;
+                Vec8<bf16_t>::store(onehot + row * vp + oc * 8, o);
+            }
+        }
+        if (tokens && cv == 0) tokens[row] = tk;
+    }
+}
+
 // dtable[tok[n], :] += dropmask * dout[n, 0:dim].  The table is small (relation vocabulary ~ 90 x 100): each block
 // accumulates a private copy in LDS (ds_add_f32) over its slice of rows and flushes it with global atomics.
 // LDS layout [e][token][chunk] (channel = chunk * 8 + e): a lane owns the 8 channels of one 16-byte chunk and issues one
@@ -1000,6 +1045,25 @@ extern "C" int gtos_embed_rows_fwd(int dtype, int64_t n, int dim, int dim_pad, c
     return 0;
 }
 
+extern "C" int gtos_embed_packed_paths(int dtype, int L, int R, int64_t n_rows, const int64_t* bank, const int* order, const int* offs,
+                                       const float* table, int dim, int dim_pad, void* x, float p_drop, uint64_t seed, void* onehot, int vp,
+                                       int64_t* tokens, void* stream) {
+    if (dim_pad % 8 || dim_pad < dim || L < 1 || L > 64 || R < 1) return -24;
+    if (onehot && (vp < 8 || vp % 8 || (uintptr_t)onehot % 16)) return -24;
+    if (!bank || !order || !offs || !table || !x || (uintptr_t)x % 16) return -23;
+    if (n_rows <= 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    dim3 grid(grid_for(n_rows * (dim_pad / 8), 256)), block(256);
+    if (dtype == GTOS_BF16)
+        hipLaunchKernelGGL(embed_packed_paths_kernel<bf16_t>, grid, block, 0, s, L, R, n_rows, bank, order, offs, table, dim, dim_pad, (bf16_t*)x,
+                           p_drop, seed, (bf16_t*)onehot, vp, tokens);
+    else
+        hipLaunchKernelGGL(embed_packed_paths_kernel<float>, grid, block, 0, s, L, R, n_rows, bank, order, offs, table, dim, dim_pad, (float*)x,
+                           p_drop, seed, (bf16_t*)onehot, vp, tokens);
+    GTOS_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int gtos_embed_rows_bwd(int dtype, int64_t n, int V, int dim, int dim_pad, const int64_t* tok, const void* dout,
                                    float* dtable, float p_drop, uint64_t seed, float* workspace, int64_t workspace_bytes, void* stream) {
     if (dim_pad % 8 || dim_pad < dim) return -24;
@@ -1176,6 +1240,6 @@ extern "C" int gtos_set_seed_epoch(const void* epoch) {
     return rc;
 }
 
-extern "C" int gtos_abi_version(void) { return 18; }
+extern "C" int gtos_abi_version(void) { return 19; }
 
 GTOS_SEED_EPOCH_SETTER(rowops)

@@ -11,7 +11,7 @@ import torch.nn.functional as F
 
 from . import ops
 from . import gru as _gru
-from .gru import bigru_final, trie_bigru_final
+from .gru import bigru_final, trie_bigru_final, packed_path_gru, PackPlan
 from .pathtrie import build_path_trie
 from .transformer import Embedding
 
@@ -30,6 +30,9 @@ TRIE_DEVICE = {"1": "torch", "torch": "torch", "hip": "hip"}.get(os.environ.get(
 # different regulariser (same function at p = 0 and in eval mode, where the trie evaluation is always used): opt-in.
 # Default "path" = the reference's function; GTOS_RELENC_MASKS=node or ``set_relation_mask_sharing(model, "node")``.
 MASK_SHARING = os.environ.get("GTOS_RELENC_MASKS", "path")
+# Round 5: the per-(path, position) evaluation on gtos_amd.gru.PackedPathGRUFn (bf16, two layers); GTOS_RELENC_PACKED=0 = round 4's
+# BiGRUFinalFn behind sort / cat / index_select (kept: the fp32 parity path is that function).
+PACKED = os.environ.get("GTOS_RELENC_PACKED", "1") != "0"
 assert MASK_SHARING in ("path", "node"), MASK_SHARING
 
 
@@ -113,6 +116,16 @@ class RelationEncoder(nn.Module):
             p_e = self.dropout if self.training else 0.0
             # final states [R, 2h], already in bank order (the step kernels scatter them through trie.seq_order)
             fin = trie_bigru_final(trie, self.rel_embed.weight, rel_dim + pad, p_e, self.hidden_size, p_e, self._weights(pad))
+            return ops.linear(fin, self.out_proj.weight, self.out_proj.bias)
+        if PACKED and src_tokens.is_cuda and self.compute_dtype == torch.bfloat16 and self.num_layers == 2 and self.hidden_size % 64 == 0 \
+                and src_tokens.size(0) <= 64:
+            # One row per (path, position) -- the reference's training-mode function -- on the fused kernels (gtos_amd.gru.PackedPathGRUFn).
+            # With the batch's trie the sorted order and the step sizes are already known (the loader built them with the bank): no sort,
+            # no host read, no packing copies; a bare bank costs one sort and one read of the step sizes.
+            plan = PackPlan.of_trie(trie) if (trie is not None and trie.matches(src_tokens, src_lengths)) \
+                else PackPlan.of_lengths(src_lengths, src_tokens.size(0))
+            p = self.dropout if self.training else 0.0
+            fin = packed_path_gru(src_tokens, plan, self.rel_embed.weight, rel_dim + (-rel_dim) % 64, p, self.hidden_size, p, self._weights(0))
             return ops.linear(fin, self.out_proj.weight, self.out_proj.bias)
         seq_len, bsz = src_tokens.size()
         sorted_len, indices = torch.sort(src_lengths, descending=True, stable=True)

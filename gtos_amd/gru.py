@@ -21,7 +21,7 @@ import torch
 from . import _lib
 from ._lib import call, dt, ptr, stream
 from .ops import (gemm, compute_weight, next_seed, weight_t, _grad_target, _splitk, side_stream as _side_stream, side_ok, defer_side_join, _Timed,
-                  embed_bwd_workspace)
+                  embed_bwd_workspace, _workspace, WORKSPACE_BYTES)
 
 
 def _cell_fwd(A, hs, xg, hg, h, y, y_off_elems, ldy, hprev, gates, p, seed, drop_base):
@@ -268,6 +268,241 @@ class BiGRUFinalFn(torch.autograd.Function):
             else:
                 torch.cuda.current_stream(dev).wait_stream(_side_stream(dev))
         return (dY if ctx.needs_input_grad[0] else None, None, None, None, None) + tuple(grads)
+
+
+# =====================================================================================================================
+# The reference's TRAINING-mode function at production size (round 5): masks per (path, position, channel), hence one GRU row per
+# (path, position) in both layers -- evaluated with no host read (the sorted order and the step sizes come with the batch), the
+# layers' input gradients inside the backward step launches (gtos_gru_step_bwd_fused role B), one grouped product per layer and
+# direction for both weight gradients (gtos_gru_weight_grads) and the label-embedding gradient as a one-hot product.
+class PackPlan(object):
+    """Packed time-major layout of a bank's paths sorted by decreasing length (generator/encoder.py:93-98 builds the same thing with
+    sort + pack_padded_sequence): step t holds rows offs[t] .. offs[t] + batch_sizes[t], row m of a step is sorted path m, which is bank
+    column order[m].  batch_sizes are host integers (launch geometry); order / offs live on the device."""
+
+    def __init__(self, batch_sizes, order32, order64=None):
+        self.batch_sizes = [int(a) for a in batch_sizes if a > 0]
+        self.offs = [0]
+        for a in self.batch_sizes:
+            self.offs.append(self.offs[-1] + a)
+        self.L, self.N = len(self.batch_sizes), self.offs[-1]
+        self.order32 = order32
+        self.order64 = order64 if order64 is not None else order32.to(torch.int64)
+        self.offs_dev = torch.tensor(self.offs, dtype=torch.int32).to(order32.device, non_blocking=True)
+
+    @staticmethod
+    def of_trie(trie):
+        """The plan a batch's PathTrie carries (built by the loader with the bank); cached on the trie."""
+        plan = getattr(trie, "_pack_plan", None)
+        if plan is None or plan.order32.device != trie.seq_order32.device:
+            plan = trie._pack_plan = PackPlan(trie.batch_sizes, trie.seq_order32, trie.seq_order)
+        return plan
+
+    @staticmethod
+    def of_lengths(lengths, max_len):
+        """From the lengths alone (a caller feeding the reference's own batch): one sort and ONE host read of the step sizes."""
+        sorted_len, order = torch.sort(lengths, descending=True, stable=True)
+        bs = (sorted_len.unsqueeze(0) > torch.arange(max_len, device=lengths.device).unsqueeze(1)).sum(1).tolist()
+        return PackPlan(bs, order.to(torch.int32), order)
+
+
+def _step_bwd_fused(A, hs, d4_prev, rows_prev, wh_t, gates, hprev, dy_ptr, ldy, dh, d4, p, seed, drop_base, bpart,
+                    wi_t=None, dinp=None, n_in=0, dinp_acc=False, p_in=0.0, seed_in=0, in_drop_base=0):
+    """gtos_gru_step_bwd_fused: the backward step of ``A`` rows (A == 0: none) plus, with ``dinp``, the input gradient of the
+    ``rows_prev`` rows of the step processed just before (role B workgroups of the same launch)."""
+    with _Timed("gru_step_bwd_rows", detail=True, units=max(A, 0)):
+        call("gtos_gru_step_bwd_fused", A, hs, ptr(d4_prev), rows_prev if d4_prev is not None else 0, ptr(wh_t), ptr(gates), ptr(hprev), None,
+             dy_ptr, ldy, ptr(dh), 0 if dh is None else dt(dh), hs if dh is None else dh.stride(0), ptr(d4), float(p), seed, drop_base,
+             ptr(bpart), N_BIAS_PARTIALS if bpart is not None else 0, None, None, None, -1, None, None,
+             ptr(wi_t), ptr(dinp), 0 if dinp is None else dinp.stride(0), n_in, int(dinp_acc), float(p_in), seed_in, in_drop_base, stream())
+
+
+# A/B switches of the round-5 path (each measured on the same box: profiles/r5_*):
+FUSE_DINP = os.environ.get("GTOS_GRU_FUSE_DINP", "1") != "0"      # layer input gradients inside the backward step launches (0: one GEMM per direction)
+MERGE_DW = os.environ.get("GTOS_GRU_MERGE_DW", "1") != "0"        # both weight gradients of a (layer, direction) as one grouped product (0: three GEMMs)
+
+
+class PackedPathGRUFn(torch.autograd.Function):
+    """(bank [L,R] int64, PackPlan, label-embedding table [V,dim], weights of a 2-layer bidirectional GRU) -> [R, 2*hs] final states of
+    the top layer in BANK order.  bf16, hs % 64 == 0, dim_pad % 64 == 0; weights as in BiGRUFinalFn (nn.GRU's own tensors: layer 0's
+    w_ih is [3hs, dim], padded to dim_pad columns in here, so every gradient lands in its parameter's own ``.grad``).  Dropout p_embed on
+    the embedded labels, p_layer between the layers, both per (path, position, channel)."""
+
+    @staticmethod
+    def forward(ctx, bank, plan, table, dim_pad, p_embed, hs, p_layer, *weights):
+        dev, dtp = table.device, torch.bfloat16
+        bs, offs, L, N = plan.batch_sizes, plan.offs, plan.L, plan.N
+        R = bank.shape[1]
+        V, dim = table.shape
+        tab = table.detach()
+        want_table = table.requires_grad
+        Vp = (V + 7) // 8 * 8
+        X = torch.empty((N, dim_pad), dtype=dtp, device=dev)
+        onehot = torch.empty((N, Vp), dtype=dtp, device=dev) if (want_table and V <= 256) else None
+        tokens = torch.empty((N,), dtype=torch.int64, device=dev) if (want_table and V > 256) else None
+        seed_e = next_seed() if p_embed > 0 else 0            # the seeds in the order BiGRUFinalFn's caller draws them: embedding, layer 0
+        call("gtos_embed_packed_paths", dt(X), L, R, N, ptr(bank), ptr(plan.order32), ptr(plan.offs_dev), ptr(tab), dim, dim_pad, ptr(X),
+             float(p_embed), seed_e, ptr(onehot), Vp, ptr(tokens), stream())
+        fin = (torch.empty if bs[0] == R else torch.zeros)((R, 2 * hs), dtype=dtp, device=dev)      # (an empty path keeps a zero vector)
+        park = torch.empty((bs[0], hs), dtype=dtp, device=dev)           # where layer 0's finished rows land (nobody reads them)
+        inp, saved = X, []
+        for l in range(2):
+            last = l == 1
+            Y = None if last else torch.empty((N, 2 * hs), dtype=dtp, device=dev)
+            seed = next_seed() if (p_layer > 0 and not last) else 0
+            pl = p_layer if not last else 0.0
+            layer_saved = []
+            for direction in (0, 1):
+                w_ih, w_hh, b_ih, b_hh = weights[l * 8 + direction * 4: l * 8 + direction * 4 + 4]
+                wi, wh = compute_weight(w_ih, dtp), compute_weight(w_hh, dtp)
+                if wi.shape[1] != inp.shape[1]:             # layer 0: the label width (100) padded to the k tile
+                    wi = torch.nn.functional.pad(wi.detach(), (0, inp.shape[1] - wi.shape[1]))
+                    wi_t = wi.t().contiguous()
+                else:
+                    wi_t = weight_t(w_ih, wi)
+                gates = torch.empty((N, 4 * hs), dtype=dtp, device=dev)
+                hprev = torch.empty((N, hs), dtype=dtp, device=dev)
+                bi, bh = b_ih.detach(), b_hh.detach()
+                if direction == 0:
+                    hprev[:bs[0]].zero_()
+                else:                                   # rows that become active at step t start from h = 0
+                    for t in range(L):
+                        lo = bs[t + 1] if t + 1 < L else 0
+                        if bs[t] > lo:
+                            hprev[offs[t] + lo: offs[t] + bs[t]].zero_()
+                h_fin = fin[:, direction * hs:(direction + 1) * hs] if last else park
+                for t in (range(L) if direction == 0 else range(L - 1, -1, -1)):
+                    A, off = bs[t], offs[t]
+                    nxt = t + 1 if direction == 0 else t - 1
+                    if 0 <= nxt < L:
+                        h_out, n_out = hprev[offs[nxt]:], min(A, bs[nxt])
+                    else:
+                        h_out, n_out = None, 0
+                    _step_fwd(A, hs, inp[off:off + A], None, hprev[off:off + A], wi, bi, wh, bh, h_out, n_out, h_fin, gates[off:off + A],
+                              Y, off * 2 * hs + direction * hs, 2 * hs, pl, seed, off * 2 * hs + direction * hs,
+                              fin_idx=plan.order32 if last else None)
+                layer_saved.append((wi_t, weight_t(w_hh, wh), gates, hprev))
+            saved.append((inp, seed, pl, layer_saved))
+            inp = Y
+        ctx.cfg = (plan, table, dim_pad, p_embed, seed_e, hs, weights, saved, onehot, tokens)
+        return fin
+
+    @staticmethod
+    def backward(ctx, d_out):
+        with _Timed("relation_gru_bwd"):
+            return PackedPathGRUFn._backward(ctx, d_out)
+
+    @staticmethod
+    def _backward(ctx, d_out):
+        plan, table, dim_pad, p_embed, seed_e, hs, weights, saved, onehot, tokens = ctx.cfg
+        bs, offs, L, N = plan.batch_sizes, plan.offs, plan.L, plan.N
+        dev, dtp = d_out.device, torch.bfloat16
+        # bank order -> packed order, one gather; the two column blocks are the running state gradients of the two directions
+        dfin = d_out.to(dtp).index_select(0, plan.order64)
+        grads = [None] * len(weights)
+        for base in (8, 12, 0, 4):                    # gradient tensors that are not views of the flat bucket: created on the main stream
+            for slot in range(4):
+                wt_ = weights[base + slot]
+                if wt_.requires_grad and _grad_target(wt_) is None:
+                    grads[base + slot] = torch.zeros(wt_.shape, dtype=torch.float32, device=dev)
+        want_table = table.requires_grad
+        main = torch.cuda.current_stream(dev)
+        used_side = False
+        dY = None                                     # d(loss) / d(layer 0 output, after its dropout), [N, 2hs]
+        dX = None
+        for l in (1, 0):
+            inp, seed, pl, layer_saved = saved[l]
+            n_in = inp.shape[1]
+            want_dinp = l == 1 or want_table
+            d_in = torch.empty((N, n_in), dtype=dtp, device=dev) if want_dinp else None
+            for direction in (0, 1):
+                wi_t, wh_t, gates, hprev = layer_saved[direction]
+                base = l * 8 + direction * 4
+                w_ih, w_hh, b_ih, b_hh = weights[base:base + 4]
+                want_bias = b_ih.requires_grad or b_hh.requires_grad
+                dh = dfin[:, direction * hs:(direction + 1) * hs] if l == 1 else torch.zeros((bs[0], hs), dtype=dtp, device=dev)
+                d4 = torch.empty((N, 4 * hs), dtype=dtp, device=dev)
+                bpart = torch.zeros((N_BIAS_PARTIALS, 4 * hs), dtype=torch.float32, device=dev) if want_bias else None
+                rb = dict(wi_t=wi_t, n_in=n_in, dinp_acc=direction == 1, p_in=p_embed if l == 0 else 0.0,
+                          seed_in=seed_e if l == 0 else 0) if (want_dinp and FUSE_DINP) else None
+                prev = None
+                for t in (range(L - 1, -1, -1) if direction == 0 else range(L)):
+                    A, off = bs[t], offs[t]
+                    dyp = None if dY is None else dY.data_ptr() + (off * 2 * hs + direction * hs) * dY.element_size()
+                    kw = {} if (rb is None or prev is None) else dict(rb, dinp=d_in[offs[prev]:], in_drop_base=offs[prev] * n_in)
+                    _step_bwd_fused(A, hs, None if prev is None else d4[offs[prev]:], 0 if prev is None else bs[prev], wh_t,
+                                    gates[off:off + A], hprev[off:off + A], dyp, 2 * hs, dh, d4[off:off + A], pl, seed,
+                                    off * 2 * hs + direction * hs, bpart, **kw)
+                    prev = t
+                if rb is not None:                    # the input gradient of the step processed last: role B workgroups only
+                    _step_bwd_fused(0, hs, d4[offs[prev]:], bs[prev], wh_t, None, None, None, 2 * hs, None, None, 0.0, 0, 0, None,
+                                    **dict(rb, dinp=d_in[offs[prev]:], in_drop_base=offs[prev] * n_in))
+                elif want_dinp:
+                    pe = p_embed if l == 0 else 0.0
+                    if direction == 0:
+                        gemm(d4[:, :3 * hs], wi_t, trans_b=True, out=d_in, p_drop=pe, seed=seed_e if l == 0 else 0)
+                    elif pe > 0:                       # (the GEMM epilogue masks its product only, not the accumulated sum)
+                        d_in += gemm(d4[:, :3 * hs], wi_t, trans_b=True, p_drop=pe, seed=seed_e)
+                    else:
+                        gemm(d4[:, :3 * hs], wi_t, trans_b=True, out=d_in, accumulate=True)
+                # parameter gradients over all steps at once, on the side stream beside the next direction's steps
+                side = _side_stream(dev) if (SIDE_STREAM and side_ok(dev) and N >= SIDE_MIN_ROWS) else main
+                if side is not main:
+                    side.wait_stream(main)
+                    for t_ in (d4, bpart, hprev, inp):
+                        if t_ is not None:
+                            t_.record_stream(side)
+                with torch.cuda.stream(side):
+                    tg_ih = _grad_target(w_ih) if w_ih.requires_grad else None
+                    tg_hh = _grad_target(w_hh) if w_hh.requires_grad else None
+                    tg_ih = grads[base] if (tg_ih is None and w_ih.requires_grad) else tg_ih
+                    tg_hh = grads[base + 1] if (tg_hh is None and w_hh.requires_grad) else tg_hh
+                    if MERGE_DW and tg_ih is not None and tg_hh is not None and w_ih.shape[1] % 4 == 0:
+                        with _Timed("gru_dw_grouped", detail=True, units=N):
+                            ws = _workspace(dev)
+                            call("gtos_gru_weight_grads", N, hs, n_in, w_ih.shape[1], ptr(d4), ptr(inp), inp.stride(0), ptr(hprev), hprev.stride(0),
+                                 ptr(tg_ih), tg_ih.stride(0), ptr(tg_hh), tg_hh.stride(0), ptr(ws), ws.numel() * 4, stream())
+                    else:
+                        for (tg, dyv, xin, rows) in ((tg_hh, d4[:, :2 * hs], hprev, slice(0, 2 * hs)), (tg_hh, d4[:, 3 * hs:], hprev, slice(2 * hs, 3 * hs)),
+                                                     (tg_ih, d4[:, :3 * hs], inp, slice(0, 3 * hs))):
+                            if tg is None:
+                                continue
+                            sk = _splitk(rows.stop - rows.start, xin.shape[1], N)
+                            if tg.shape[1] == xin.shape[1]:
+                                gemm(dyv, xin, trans_a=True, out=tg[rows], accumulate=True, splitk=sk)
+                            else:                      # layer 0's input is wider (zero-padded) than its weight
+                                tg[rows] += gemm(dyv, xin, trans_a=True, out_dtype=torch.float32, splitk=sk)[:, :tg.shape[1]]
+                    if want_bias:
+                        _acc_bias_grads(grads, base, b_ih, b_hh, bpart.sum(0), hs)
+                used_side = used_side or side is not main
+            if l == 1:
+                dY = d_in
+            else:
+                dX = d_in
+        dtab = None
+        if want_table:
+            tgt = _grad_target(table)
+            if tgt is None:
+                tgt = dtab = torch.zeros(table.shape, dtype=torch.float32, device=dev)
+            V, dim = table.shape
+            if onehot is not None:
+                # label-embedding gradient = onehot(token)^T dX (dX already carries the forward's dropout mask): one product on the MFMA GEMM
+                part = gemm(onehot, dX, trans_a=True, out_dtype=torch.float32, splitk=_splitk(onehot.shape[1], dim_pad, N))
+                tgt += part[:V, :dim]
+            else:
+                ws = embed_bwd_workspace(N, V, dim_pad, dev)
+                call("gtos_embed_rows_bwd", dt(dX), N, V, dim, dim_pad, ptr(tokens), ptr(dX), ptr(tgt), 0.0, 0, ptr(ws),
+                     0 if ws is None else ws.numel() * 4, stream())
+        if used_side:
+            if dtab is None and all(gr is None for gr in grads):
+                defer_side_join(dev)       # every gradient went into the flat bucket: its readers join the side stream (ops.join_side)
+            else:
+                main.wait_stream(_side_stream(dev))
+        return (None, None, dtab, None, None, None, None) + tuple(grads)
+
+
+def packed_path_gru(bank, plan, table, dim_pad, p_embed, hs, p_layer, weights):
+    return PackedPathGRUFn.apply(bank, plan, table, dim_pad, float(p_embed), hs, float(p_layer), *weights)
 
 
 def bigru_final(x_packed, batch_sizes, hs, num_layers, p_drop, weights):

@@ -217,6 +217,32 @@ int gtos_gru_step_bwd(int rows, int hs, const void* d4_prev, int rows_prev, cons
                       int64_t ld_dh, void* d4, float p_drop, uint64_t seed, int64_t drop_base, float* bias_partials, int n_partials,
                       void* hprev_out, const int* sum_idx, const void* dh_src, int zero_row, const void* w_hn, const float* b_hn, void* stream);
 
+/* gtos_gru_step_bwd with a second role in the same launch (round 5; gtos_gru_step_bwd forwards here with w_ih_t = dinp = NULL).  With dinp,
+ * additional workgroups turn the d4 rows of the step processed just before into THAT step's input gradient,
+ *   dinp[rows_prev, n_in] (=/+=) mask * (d4_prev[:, 0:3hs] x W_ih)        w_ih_t = W_ih^T [n_in, 3hs], n_in % 64 == 0, row stride ld_dinp
+ * -- the product nn.GRU's autograd runs as one [N,3hs] x [3hs,in] GEMM per layer and direction after BPTT
+ * (generator/encoder.py:104 -> torch's GRU backward).  The tiles of a 128-row panel (hs/64 cell tiles, ceil(n_in/128) input-gradient tiles)
+ * run back to back on one XCD, so the previous step's d4 rows are fetched from HBM once for both products.  dinp_accumulate: add to what
+ * the other direction wrote.  p_in > 0: mask dinp with the dropout the forward applied to the layer's INPUT (counter in_drop_base + m * n_in +
+ * column, m = row inside rows_prev): the label-embedding rows of layer 0.  rows == 0 with dinp: only the input gradient (the step
+ * processed last has no successor launch).  sum_idx (the trie indirection) and dinp exclude each other. */
+int gtos_gru_step_bwd_fused(int rows, int hs, const void* d4_prev, int rows_prev, const void* w_hh_t,
+                            const void* gates, const void* hprev, const int* hprev_idx, const void* dy, int64_t ldy, void* dh, int dh_dtype,
+                            int64_t ld_dh, void* d4, float p_drop, uint64_t seed, int64_t drop_base, float* bias_partials, int n_partials,
+                            void* hprev_out, const int* sum_idx, const void* dh_src, int zero_row, const void* w_hn, const float* b_hn,
+                            const void* w_ih_t, void* dinp, int64_t ld_dinp, int n_in, int dinp_accumulate, float p_in, uint64_t seed_in,
+                            int64_t in_drop_base, void* stream);
+
+/* Both weight gradients of one GRU layer and direction over all its packed rows in ONE grouped product (round 5; torch's GRU backward runs
+ * dW_ih = d(xg)^T x and dW_hh = d(hg)^T h_prev as separate GEMMs): with d4 [rows,4hs] = d r | d z | d n_x | d n_h,
+ *   dwih[3hs, in_valid] += d4[:, 0:3hs]^T x[:, 0:in_valid]          x [rows, in_dim] (row stride ldx; columns in_valid.. are zero padding)
+ *   dwhh[3hs, hs]       += d4[:, {0:2hs, 3hs:4hs}]^T hprev           hprev [rows, hs] (row stride ldh)
+ * as 256x256 tiles of d4^T [x | hprev] (only the tiles holding a needed element) on the split-K ping-pong kernel; d4, x and hprev are
+ * each read from HBM once.  fp32 accumulation; partial tiles go through `workspace` (>= tiles * 256 KB; more = more K splits) and are added
+ * in a fixed order (deterministic).  bf16, hs % 64 == 0, in_dim % 8 == 0, in_valid % 4 == 0. */
+int gtos_gru_weight_grads(int rows, int hs, int in_dim, int in_valid, const void* d4, const void* x, int64_t ldx, const void* hprev, int64_t ldh,
+                          float* dwih, int64_t ld_dwih, float* dwhh, int64_t ld_dwhh, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Segmented row sums for the trie-evaluated RelationEncoder's backward (generator/encoder.py:93-111 runs every path
  * separately; here the gradient of a shared trie node is the sum over the rows that share it).  bf16 rows, fp32
  * accumulation, bf16 result.  _rows: chunk c adds the rows rows[chunk_start[c] .. +chunk_cnt[c]) of src into node
@@ -262,6 +288,16 @@ int gtos_embed_rows_fwd(int dtype, int64_t n, int dim, int dim_pad, const int64_
                         float p_drop, uint64_t seed, void* stream);
 int gtos_embed_rows_bwd(int dtype, int64_t n, int V, int dim, int dim_pad, const int64_t* tok, const void* dout,
                         float* dtable, float p_drop, uint64_t seed, float* workspace, int64_t workspace_bytes, void* stream);
+
+/* The RelationEncoder's packed, embedded input in one pass and without a host read (round 5): the reference sorts the paths by length,
+ * packs them time-major and embeds the packed tokens (generator/encoder.py:93-100).  Here the sorted order and the step offsets arrive
+ * with the batch: packed row n = (step t, sorted path m), offs[t] <= n < offs[t+1] (offs: device int32 [L+1], L <= 64), m = n - offs[t],
+ * token = bank[t, order[m]] (bank int64 [L,R], order int32: sorted position -> bank column).  x[n, 0:dim_pad] = dropout(table[token])
+ * zero-padded, counter n * dim_pad + column (as gtos_embed_rows_fwd); onehot (optional, bf16 [n_rows, vp], vp % 8 == 0, vp >= V):
+ * row n = e_token, the operand that turns the embedding's index_add backward into a product; tokens (optional, int64 [n_rows]). */
+int gtos_embed_packed_paths(int dtype, int L, int R, int64_t n_rows, const int64_t* bank, const int* order, const int* offs,
+                            const float* table, int dim, int dim_pad, void* x, float p_drop, uint64_t seed, void* onehot, int vp,
+                            int64_t* tokens, void* stream);
 
 /* Elementwise pieces of TokenEncoder / CNNEncoder / Highway (generator/encoder.py:123-201), each one kernel per direction in place
  * of a dozen small ATen kernels; `dtype` rows are contiguous.

@@ -184,12 +184,22 @@ class Recorder(object):
                     self._rows(W + "h_fin", h_fin, rows, hs, ld_fin, 2)
             self._rows(W + "gates", gates, rows, 4 * hs, 4 * hs, 2)
             self._rows(W + "y", y, rows, hs, ldy, 2)
-        elif name == "gtos_gru_step_bwd":
+        elif name in ("gtos_gru_step_bwd", "gtos_gru_step_bwd_fused"):
             (rows, hs, d4_prev, rows_prev, w_hh_t, gates, hprev, hprev_idx, dy, ldy, dh, dh_dtype, ld_dh, d4, p_drop, seed, drop_base,
              bias_partials, n_partials, hprev_out, sum_idx, dh_src, zero_row) = a[:23]
-            self._rows("gtos_gru_step_bwd: w_hn", a[23], hs, hs, hs, 2)
-            self._rows("gtos_gru_step_bwd: b_hn", a[24], 1, hs, hs, 4)
-            W = "gtos_gru_step_bwd: "
+            W = name + ": "
+            self._rows(W + "w_hn", a[23], hs, hs, hs, 2)
+            self._rows(W + "b_hn", a[24], 1, hs, hs, 4)
+            if name == "gtos_gru_step_bwd_fused":
+                w_ih_t, dinp, ld_dinp, n_in, acc, p_in, seed_in, in_drop_base = a[25:33]
+                if dinp is not None:
+                    assert d4_prev is not None and sum_idx is None and n_in % 64 == 0 and rows_prev > 0, W + "role B arguments"
+                    self._rows(W + "w_ih_t", w_ih_t, n_in, 3 * hs, 3 * hs, 2)
+                    self._rows(W + "dinp", dinp, rows_prev, n_in, ld_dinp, 2)
+                    self._rows(W + "d4_prev (role B)", d4_prev, rows_prev, 4 * hs, 4 * hs, 2)
+                if rows <= 0:
+                    self.extent_checks += 1
+                    return
             es_dh = (4, 2)[dh_dtype]
             self._rows(W + "w_hh_t", w_hh_t if d4_prev is not None else None, hs, 3 * hs, 3 * hs, 2)
             self._rows(W + "gates", gates, rows, 4 * hs, 4 * hs, 2)
@@ -256,6 +266,33 @@ class Recorder(object):
                 slots = arr(chunk_slot, nchunks)
                 if heavy is not None and int(slots.max()) >= 0:
                     self._rows(W + "heavy", heavy, int(slots.max()) + 1, 2 * d, 2 * d, 4)
+        elif name == "gtos_gru_weight_grads":
+            rows, hs, in_dim, in_valid, d4, x, ldx, hprev, ldh, dwih, ld_ih, dwhh, ld_hh, wsp, ws_bytes = a[:15]
+            assert hs % 64 == 0 and in_dim % 8 == 0 and 0 < in_valid <= in_dim and in_valid % 4 == 0, name + ": shape"
+            self._rows(name + ": d4", d4, rows, 4 * hs, 4 * hs, 2)
+            self._rows(name + ": x", x, rows, in_dim, ldx, 2)
+            self._rows(name + ": hprev", hprev, rows, hs, ldh, 2)
+            self._rows(name + ": dwih", dwih, 3 * hs, in_valid, ld_ih, 4)
+            self._rows(name + ": dwhh", dwhh, 3 * hs, hs, ld_hh, 4)
+            self._rows(name + ": workspace", wsp, 1, ws_bytes, ws_bytes, 1)
+        elif name == "gtos_embed_packed_paths":
+            import ctypes
+            import numpy as np
+            dtc, L, R, n_rows, bank, order, offs, table, dim, dim_pad, x, p_drop, seed, onehot, vp, tokens = a[:16]
+            self._rows(name + ": bank", bank, L, R, R, 8)
+            self._rows(name + ": offs", offs, 1, L + 1, L + 1, 4)
+            o = np.ctypeslib.as_array((ctypes.c_int32 * (L + 1)).from_address(offs))
+            assert int(o[0]) == 0 and int(o[L]) == n_rows and bool((np.diff(o) >= 0).all()), name + ": step offsets"
+            widest = int(np.diff(o).max())
+            self._rows(name + ": order", order, 1, widest, widest, 4)
+            od = np.ctypeslib.as_array((ctypes.c_int32 * widest).from_address(order))
+            assert int(od.min()) >= 0 and int(od.max()) < R, name + ": sorted order outside the bank's columns"
+            bk = np.ctypeslib.as_array((ctypes.c_int64 * (L * R)).from_address(bank))
+            self._rows(name + ": table", table, int(bk.max()) + 1, dim, dim, 4)
+            assert int(bk.min()) >= 0 and (onehot is None or int(bk.max()) < vp), name + ": label ids"
+            self._rows(name + ": x", x, n_rows, dim_pad, dim_pad, es(dtc))
+            self._rows(name + ": onehot", onehot, n_rows, vp, vp, 2)
+            self._rows(name + ": tokens", tokens, 1, n_rows, n_rows, 8)
         elif name == "gtos_embed_rows_fwd":
             dtc, n, dim, dim_pad, tok, table, out = a[:7]
             self._gather(name + ": table", table, tok, 0, n, dim, dim, 4, itype=8)

@@ -51,11 +51,14 @@ def test_training_step_launch_plan_c1_bf16_trie_factored():
     # launches of the three steps lay inside its tensor's storage, every gathered row index inside its table (real index arrays)
     assert rec.extent_checks > 1200 and rec.unknown_ptrs == 0
     L = synth.CONFIGS["C1"]["layers"]
-    # the production path of DESIGN.md: factored attention (one bank-gradient launch per graph layer), trie-evaluated GRU (level
-    # steps, never the per-row cell kernels), fused copy / NLL, device-side step control and ONE fused optimizer sweep per segment
+    # the production path of DESIGN.md: factored attention (one bank-gradient launch per graph layer), the RelationEncoder with the
+    # reference's dropout semantics on the packed-path kernels (round 5: one embedding launch off the batch's own sort order, fused steps
+    # -- never the per-row cell kernels --, the layers' input gradients inside the backward step launches, ONE grouped weight-gradient
+    # product per layer and direction), fused copy / NLL, device-side step control and ONE fused optimizer sweep per segment
     assert hist["gtos_rel_attn_bwd_bank"] == L
     assert hist["gtos_rel_attn_fwd"] == hist["gtos_rel_attn_bwd"] >= L
-    assert hist.get("gtos_gru_step_fwd", 0) > 0 and hist.get("gtos_gru_step_bwd", 0) > 0
+    assert hist.get("gtos_gru_step_fwd", 0) > 0 and hist.get("gtos_gru_step_bwd_fused", 0) == hist["gtos_gru_step_fwd"] + 4
+    assert hist["gtos_gru_weight_grads"] == 4 and hist["gtos_embed_packed_paths"] == 1 and "gtos_gru_step_bwd" not in hist
     assert "gtos_gru_cell_fwd" not in hist and "gtos_relation_gather_mean" not in hist
     assert hist["gtos_copy_nll_fwd"] == hist["gtos_copy_nll_bwd"] == 1
     assert hist["gtos_step_control"] == 2 and "gtos_adam_step" not in hist and hist["gtos_adam_step_ctl"] >= 1   # (flag phase + apply phase)

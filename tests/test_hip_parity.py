@@ -116,94 +116,6 @@ def test_gemm_pipelined_256_tile(M, N, K):
     assert torch.equal(small == 0, big[:300] == 0)
 
 
-@pytest.mark.parametrize("M,N,K", [(140037, 1024, 512), (131072, 768, 256), (270003, 520, 128), (263000, 264, 736), (132000, 512, 992), (434624, 1024, 512)])
-def test_gemm_short_k_two_workgroups_per_cu(M, N, K, monkeypatch):
-    """Forward-shaped products with a SHORT reduction (K % 32 == 0, 128 <= K < 1024) and >= 1024 tiles of 128 x 256 take
-    gemm_p2_nt_kernel (round 4: two pipelined 4-wave workgroups per CU, three 32-k LDS stages each): every remainder of the 3-step
-    unrolled loop (K/32 = 16, 8, 4, 23, 31), ragged M / N tails, strided A, fused bias + ReLU, bf16 accumulate, the dropout mask of
-    the other kernels; against fp32 matmul of the same bf16 operands.  The same shapes again with GTOS_GEMM_P2=0 semantics are covered by
-    test_gemm / test_gemm_256_macro_tile (the dispatcher's other branches)."""
-    import subprocess
-    import sys
-    if os.environ.get("GTOS_GEMM_P2") != "1":
-        # the kernel is an opt-in read once when the library loads: run this case in a child process with the switch set
-        env = dict(os.environ, GTOS_GEMM_P2="1")
-        r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-m", "gpu", "-q", "-p", "no:cacheprovider", "-k",
-                            "test_gemm_short_k_two_workgroups_per_cu and %d-%d-%d" % (M, N, K)], env=env, stdout=subprocess.PIPE,
-                           stderr=subprocess.STDOUT, timeout=300)
-        assert r.returncode == 0, r.stdout.decode(errors="replace")[-3000:]
-        return
-    from gtos_amd import ops
-    torch.manual_seed(M % 83)
-    wide = (torch.randn(M, K + 64, device=dev()) * 0.5).to(torch.bfloat16)
-    a = wide[:, 64:]                                        # row stride K + 64
-    b = (torch.randn(N, K, device=dev()) * 0.5).to(torch.bfloat16)
-    bias = torch.randn(N, device=dev())
-    want = a.float() @ b.float().t()
-    tol = dict(rtol=2e-2, atol=0.01 * K ** 0.5)
-    got = ops.gemm(a, b, trans_b=True)
-    torch.testing.assert_close(got.float(), want, **tol)
-    # exactness of the data path: bf16 products accumulated in fp32 and rounded once -- the result equals the rounded fp32 matmul
-    # up to accumulation order, i.e. within one bf16 ulp almost everywhere
-    ulp = (got.float() - want).abs() / want.abs().clamp_min(1.0)
-    assert float(ulp.max()) < 1.0 / 64, float(ulp.max())
-    got = ops.gemm(a.contiguous(), b, trans_b=True, bias=bias, relu=True)
-    torch.testing.assert_close(got.float(), torch.relu(want + bias), **tol)
-    base = torch.randn(M, N, device=dev()).to(torch.bfloat16)
-    out = base.clone()
-    ops.gemm(a, b, trans_b=True, out=out, accumulate=True)
-    torch.testing.assert_close(out.float(), want + base.float(), rtol=3e-2, atol=0.02 * K ** 0.5)
-    small = ops.gemm(a[:300], b, trans_b=True, p_drop=0.3, seed=77)        # (few tiles: the 128x128 kernel)
-    big = ops.gemm(a, b, trans_b=True, p_drop=0.3, seed=77)
-    assert torch.equal(small == 0, big[:300] == 0)
-    # a column-block output (leading dimension wider than N): rows land where they belong, nothing beyond the block is touched
-    slab = torch.full((M, N + 256), 7.0, device=dev(), dtype=torch.bfloat16)
-    ops.gemm(a, b, trans_b=True, out=slab[:, 128:128 + N])
-    torch.testing.assert_close(slab[:, 128:128 + N].float(), want, **tol)
-    assert bool((slab[:, :128] == 7).all()) and bool((slab[:, 128 + N:] == 7).all())
-
-
-@pytest.mark.parametrize("M,N,K", [(131072, 512, 2048), (131000, 520, 2112), (140000, 256, 2176), (131073, 768, 4160)])
-def test_gemm_deep_k_one_wave_per_simd(M, N, K):
-    """Forward-shaped products with a DEEP reduction (K >= 2048) take gemm_w4_nt_kernel when GTOS_GEMM_W4=1 (round 4: four waves of
-    128 x 128 on the 256 x 256 tile, 64-k stages through registers, accumulators named by hand): even and odd stage counts (K/64 = 32,
-    33, 34, 65), ragged M / N tails, strided A, the epilogues; against fp32 matmul."""
-    import subprocess
-    import sys
-    if os.environ.get("GTOS_GEMM_W4") != "1":
-        env = dict(os.environ, GTOS_GEMM_W4="1")            # read once when the library loads: a child process with the switch set
-        r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-m", "gpu", "-q", "-p", "no:cacheprovider", "-k",
-                            "test_gemm_deep_k_one_wave_per_simd and %d-%d-%d" % (M, N, K)], env=env, stdout=subprocess.PIPE,
-                           stderr=subprocess.STDOUT, timeout=300)
-        assert r.returncode == 0, r.stdout.decode(errors="replace")[-3000:]
-        return
-    from gtos_amd import ops
-    torch.manual_seed(M % 83)
-    wide = (torch.randn(M, K + 64, device=dev()) * 0.5).to(torch.bfloat16)
-    a = wide[:, 64:]
-    b = (torch.randn(N, K, device=dev()) * 0.5).to(torch.bfloat16)
-    bias = torch.randn(N, device=dev())
-    want = a.float() @ b.float().t()
-    tol = dict(rtol=2e-2, atol=0.01 * K ** 0.5)
-    got = ops.gemm(a, b, trans_b=True)
-    torch.testing.assert_close(got.float(), want, **tol)
-    ulp = (got.float() - want).abs() / want.abs().clamp_min(1.0)
-    assert float(ulp.max()) < 1.0 / 64, float(ulp.max())
-    got = ops.gemm(a.contiguous(), b, trans_b=True, bias=bias, relu=True)
-    torch.testing.assert_close(got.float(), torch.relu(want + bias), **tol)
-    base = torch.randn(M, N, device=dev()).to(torch.bfloat16)
-    out = base.clone()
-    ops.gemm(a, b, trans_b=True, out=out, accumulate=True)
-    torch.testing.assert_close(out.float(), want + base.float(), rtol=3e-2, atol=0.02 * K ** 0.5)
-    small = ops.gemm(a[:300], b, trans_b=True, p_drop=0.3, seed=77)
-    big = ops.gemm(a, b, trans_b=True, p_drop=0.3, seed=77)
-    assert torch.equal(small == 0, big[:300] == 0)
-    slab = torch.full((M, N + 256), 7.0, device=dev(), dtype=torch.bfloat16)
-    ops.gemm(a, b, trans_b=True, out=slab[:, 128:128 + N])
-    torch.testing.assert_close(slab[:, 128:128 + N].float(), want, **tol)
-    assert bool((slab[:, :128] == 7).all()) and bool((slab[:, 128 + N:] == 7).all())
-
-
 @pytest.mark.parametrize("M,N,K,sk", [(768, 512, 300040, 43), (256, 256, 100000, 64), (1024, 512, 6464, 12), (512, 264, 70008, 16)])
 def test_gemm_weight_gradient_long_k_splitk(M, N, K, sk):
     """dW = A^T B with K in the hundreds of thousands: transpose-read operand path + split-K partial tiles reduced
@@ -433,14 +345,17 @@ def _rel_frob(a, b):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fuse", ["x", "h", "off"])
+@pytest.mark.parametrize("fuse", ["packed", "x", "h", "off"])
 def test_relation_encoder_bf16_fused_step_vs_golden(fuse, monkeypatch):
-    """bf16 GRU: the fused MFMA step kernel (gtos_gru_step_fwd, input product fused or not) and the GEMM + cell path
-    against the reference vectors; bf16 bar = 2e-3 abs on outputs (north_star 1e-2; measured 8.1e-4), 3e-2 relative Frobenius on gradients."""
-    from gtos_amd import gru
+    """bf16 GRU: the packed-path evaluation (round 5's default: gtos_amd.gru.PackedPathGRUFn), round 4's BiGRUFinalFn on the fused MFMA
+    step kernel (gtos_gru_step_fwd, input product fused or not) and its GEMM + cell path against the reference vectors; bf16 bar = 2e-3
+    abs on outputs (north_star 1e-2; measured 8.1e-4), 3e-2 relative Frobenius on gradients."""
+    from gtos_amd import encoder, gru
     from gtos_amd.encoder import RelationEncoder
     from oracle.gtos_oracle import VocabSpec
-    monkeypatch.setattr(gru, "FUSE", fuse)
+    monkeypatch.setattr(encoder, "PACKED", fuse == "packed")
+    if fuse != "packed":
+        monkeypatch.setattr(gru, "FUSE", fuse)
     g = load_golden("relenc_wide")
     V, rel_dim, d, hid, R, Lmax = [int(v) for v in g["cfg"]]
     m = RelationEncoder(VocabSpec(V, 0), rel_dim, d, hid, 2, 0.0).to(dev())
@@ -1748,25 +1663,29 @@ def _relenc_case(seed=3, R=150, L=6, V=40, hid=64):
     return bank, length
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_relation_encoder_training_mode_reference_masks_vs_oracle(dtype):
+@pytest.mark.parametrize("dtype,with_trie,hid", [(torch.float32, False, 64), (torch.bfloat16, False, 64), (torch.bfloat16, True, 64),
+                                                  (torch.bfloat16, True, 256)])
+def test_relation_encoder_training_mode_reference_masks_vs_oracle(dtype, with_trie, hid):
     """The RelationEncoder's TRAINING-mode function with the reference's dropout semantics (masks per (path, position, channel) on the
     label embeddings and between the GRU layers, generator/encoder.py:91-92,105) -- the library default, ``mask_sharing="path"``: the HIP
     path under its counter-based masks against the pinned oracle given EXACTLY those masks (oracle.MASK_HOOK), outputs and every
-    parameter gradient.  p = 0.3; fp32 1e-3, bf16 1e-2 of the output scale."""
+    parameter gradient.  p = 0.3; fp32 1e-3, bf16 1e-2 of the output scale.  bf16 is the production evaluation (PackedPathGRUFn:
+    labels padded to the 64-wide k tile, the sort order and step sizes taken from the batch's trie when it has one, input gradients
+    inside the backward step launches, grouped weight gradients, one-hot embedding gradient); hid = 256 is the C2 width."""
     from gtos_amd import ops
     from gtos_amd.encoder import RelationEncoder
+    from gtos_amd.pathtrie import build_path_trie
     from oracle import gtos_oracle as O
     bank, length = _relenc_case()
     L, R = bank.shape
-    V, rel_dim, d, hid, p = 40, 100, 64, 64, 0.3
-    dim_pad = rel_dim + (-rel_dim) % 8
+    V, rel_dim, d, p = 40, 100, 64, 0.3
+    dim_pad = rel_dim + ((-rel_dim) % 8 if dtype == torch.float32 else (-rel_dim) % 64)
     torch.manual_seed(5)
     ref = O.RelationEncoder(O.VocabSpec(V, 0), rel_dim, d, hid, 2, p)
     with torch.no_grad():
         for n_, q in ref.named_parameters():
             if n_.startswith("rnn.weight"):
-                q.mul_(2.0)
+                q.mul_(2.0 if hid == 64 else 1.0)
     m = RelationEncoder(O.VocabSpec(V, 0), rel_dim, d, hid, 2, p).to(dev())
     m.load_state_dict(ref.state_dict())
     m.compute_dtype = dtype
@@ -1776,10 +1695,15 @@ def test_relation_encoder_training_mode_reference_masks_vs_oracle(dtype):
     ops.set_seed(99)
     s_e, s_y = ops.next_seed(), ops.next_seed()
     ops.set_seed(99)
-    # packed row of (position t, path r): the module sorts by length (stable, descending) and packs time-major
-    sl, order = torch.sort(length, descending=True, stable=True)
+    # packed row of (position t, path r): paths sorted by length (descending; the module's own stable sort, or the order the batch's
+    # trie carries), packed time-major
+    trie = build_path_trie(bank, length) if with_trie else None
+    if with_trie:
+        order, bs = trie.seq_order.long(), list(trie.batch_sizes)
+    else:
+        sl, order = torch.sort(length, descending=True, stable=True)
+        bs = [int((sl > t).sum()) for t in range(L)]
     rank = torch.empty(R, dtype=torch.long); rank[order] = torch.arange(R)
-    bs = [int((sl > t).sum()) for t in range(L)]
     offs = np.concatenate([[0], np.cumsum(bs)])
     row = torch.from_numpy(offs[:L]).view(L, 1) + rank.view(1, R)                     # [L,R] (meaningless past a path's end: masked by lengths)
 
@@ -1798,9 +1722,11 @@ def test_relation_encoder_training_mode_reference_masks_vs_oracle(dtype):
         (want * wout).sum().backward()
     finally:
         O.MASK_HOOK = None
-    out = m(bank.to(dev()), length.to(dev()))
+    out = m(bank.to(dev()), length.to(dev()), trie=trie.to(dev()) if with_trie else None)
     (out.float() * wout.to(dev())).sum().backward()
-    measured("relation_encoder TRAIN p=0.3 reference masks %s vs oracle" % dtype, out, want)
+    ops.join_side()
+    torch.cuda.synchronize()
+    measured("relation_encoder TRAIN p=0.3 reference masks %s hid=%d trie=%s vs oracle" % (dtype, hid, with_trie), out, want)
     scale = float(want.abs().max())
     tol = 1e-3 if dtype == torch.float32 else 1e-2
     assert float((out.float().cpu() - want).abs().max()) < tol * max(scale, 0.1), (float((out.float().cpu() - want).abs().max()), scale)
@@ -1938,3 +1864,169 @@ def test_relation_projection_recomputed_in_backward_gives_the_same_gradients(mon
     worst = max(float((g0[n] - g1[n]).abs().max() / g0[n].abs().max().clamp_min(1e-6)) for n in g0)
     print("MEASURED projection recompute: worst relative gradient difference %.2e" % worst)
     assert worst <= 2e-3, worst            # fp32 atomic orders in the bank-gradient kernel differ run to run; everything else is bit-equal
+
+
+# ------------------------------------------------------------------------------------------------ packed-path GRU (round 5)
+@pytest.mark.parametrize("case", ["amr", "random", "single", "all_len1", "duplicates"])
+@pytest.mark.parametrize("hid", [64, 256])
+def test_packed_path_gru_equals_per_row_gru_and_oracle(case, hid, monkeypatch):
+    """RelationEncoder in bf16 at dropout 0: round 5's packed-path evaluation (PackedPathGRUFn -- embedding straight off the bank through
+    the sort order, fused steps, the layers' input gradients as role-B workgroups of the backward step launches, grouped weight-gradient
+    products, one-hot embedding gradient; with the batch's trie as the source of the order, and with a bare bank) against round 4's
+    BiGRUFinalFn behind sort / cat / index_select and against the pinned fp32 oracle: forward and every parameter gradient."""
+    from gtos_amd import encoder, gru, ops, synth
+    from gtos_amd.pathtrie import build_path_trie
+    if case == "amr":
+        batch, _ = synth.make_batch(3, 6, 40, 8)
+        bank, length = batch["relation_bank"], batch["relation_length"]
+    elif case == "random":
+        g = torch.Generator().manual_seed(9)
+        length = torch.randint(1, 9, (700,), generator=g)
+        bank = torch.randint(1, 90, (8, 700), generator=g)
+        for r in range(700):
+            bank[int(length[r]):, r] = 0
+    elif case == "all_len1":
+        bank, length = torch.arange(1, 18).view(1, 17), torch.ones(17, dtype=torch.int64)
+    elif case == "duplicates":
+        base = torch.tensor([[5, 5, 9, 9, 9, 3], [6, 6, 2, 2, 2, 0], [7, 7, 0, 0, 0, 0]])
+        bank, length = base, torch.tensor([3, 3, 2, 2, 2, 1])
+    else:
+        bank, length = torch.tensor([[7]]), torch.tensor([1])
+    ref, m = _relenc_pair(bank, length, hid=hid)
+    if hid == 256:
+        with torch.no_grad():                 # (_relenc_pair triples the default init: at 256 channels that saturates every cell)
+            rp = dict(ref.named_parameters())
+            for k_, q_ in m.named_parameters():
+                rp[k_].div_(3.0)
+                q_.copy_(rp[k_])
+    wout = torch.randn(bank.shape[1], 64, generator=torch.Generator().manual_seed(1))
+    out_r = ref(bank, length)
+    (out_r * wout).sum().backward()
+    m.compute_dtype = torch.bfloat16
+    monkeypatch.setattr(gru, "TRIE", False)                 # (at dropout 0 the trie evaluation would take over)
+    res = {}
+    for name in ("packed+trie", "packed", "per-row"):
+        monkeypatch.setattr(encoder, "PACKED", name != "per-row")
+        m.zero_grad()
+        trie = build_path_trie(bank, length).to(dev()) if name == "packed+trie" else None
+        out = m(bank.to(dev()), length.to(dev()), trie=trie)
+        (out.float() * wout.to(dev())).sum().backward()
+        ops.join_side()
+        torch.cuda.synchronize()
+        res[name] = (out.detach().float().cpu(), _grads_of(m))
+    for name in ("packed+trie", "packed"):
+        measured("packed-path GRU (%s, %s, hid %d) vs oracle" % (name, case, hid), res[name][0], out_r.detach())
+        torch.testing.assert_close(res[name][0], res["per-row"][0], rtol=2e-2, atol=2e-2)
+        torch.testing.assert_close(res[name][0], out_r.detach(), rtol=2e-2, atol=2e-2)
+        for k, q in ref.named_parameters():
+            e_old, e_new = _rel_frob(res["per-row"][1][k], q.grad), _rel_frob(res[name][1][k], q.grad)
+            assert e_new < max(3e-2, 1.5 * e_old), (name, k, e_new, e_old)
+    # the order is the only thing the trie contributes: the two packed runs are the same function
+    torch.testing.assert_close(res["packed+trie"][0], res["packed"][0], rtol=0, atol=2e-2)
+
+
+@pytest.mark.parametrize("rows,hs,in_dim,in_valid,ldx", [(1000, 64, 128, 100, 128), (300, 128, 64, 64, 64), (5000, 256, 128, 100, 128),
+                                                         (70001, 256, 512, 512, 512), (200003, 256, 512, 512, 640), (64, 64, 64, 8, 64)])
+def test_gru_grouped_weight_gradients_vs_torch(rows, hs, in_dim, in_valid, ldx):
+    """gtos_gru_weight_grads: dW_ih += d4[:, 0:3hs]^T x, dW_hh += d4[:, {0:2hs, 3hs:4hs}]^T h_prev as ONE grouped product over
+    d4^T [x | h_prev] (256 x 256 tiles of the needed blocks only, split-K partial tiles reduced in a fixed order) against fp32 matmuls
+    of the same bf16 operands; accumulates into what the targets held; deterministic."""
+    from gtos_amd import ops
+    from gtos_amd._lib import call, ptr, stream
+    torch.manual_seed(rows % 97)
+    d4 = (torch.randn(rows, 4 * hs, device=dev()) * 0.5).to(torch.bfloat16)
+    xw = (torch.randn(rows, ldx, device=dev()) * 0.5).to(torch.bfloat16)
+    x = xw[:, :in_dim]
+    hp = (torch.randn(rows, hs, device=dev()) * 0.5).to(torch.bfloat16)
+    base_ih, base_hh = torch.randn(3 * hs, in_valid, device=dev()), torch.randn(3 * hs, hs, device=dev())
+    want_ih = base_ih + d4[:, :3 * hs].float().t() @ x[:, :in_valid].float()
+    want_hh = base_hh + torch.cat([d4[:, :2 * hs], d4[:, 3 * hs:]], 1).float().t() @ hp.float()
+    outs = []
+    for _ in range(2):
+        g_ih, g_hh = base_ih.clone(), base_hh.clone()
+        ws = ops._workspace(dev())
+        call("gtos_gru_weight_grads", rows, hs, in_dim, in_valid, ptr(d4), ptr(x), ldx, ptr(hp), hs, ptr(g_ih), in_valid, ptr(g_hh), hs,
+             ptr(ws), ws.numel() * 4, stream())
+        torch.cuda.synchronize()
+        outs.append((g_ih, g_hh))
+    tol = dict(rtol=2e-3, atol=2e-3 * rows ** 0.5)
+    torch.testing.assert_close(outs[0][0], want_ih, **tol)
+    torch.testing.assert_close(outs[0][1], want_hh, **tol)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("rows,rows_prev,hs,n_in", [(300, 200, 64, 128), (200, 300, 64, 64), (1000, 1000, 256, 512), (0, 777, 256, 512),
+                                                    (40000, 50001, 256, 128)])
+def test_gru_backward_step_input_gradient_role_vs_torch(rows, rows_prev, hs, n_in):
+    """gtos_gru_step_bwd_fused: with ``dinp`` the launch also computes dinp = d4_prev[:, 0:3hs] x W_ih for the step processed just before
+    (role B workgroups), written, accumulated, and masked with the layer-input dropout; the cell part (role A) is bit-identical to the
+    launch without role B; rows == 0 runs role B alone."""
+    from gtos_amd.gru import _step_bwd_fused, N_BIAS_PARTIALS
+    torch.manual_seed(rows + rows_prev)
+    bf = torch.bfloat16
+    d4_prev = (torch.randn(rows_prev, 4 * hs, device=dev()) * 0.3).to(bf)
+    w_ih = (torch.randn(3 * hs, n_in, device=dev()) * 0.1).to(bf)
+    wi_t = w_ih.t().contiguous()
+    wh_t = (torch.randn(hs, 3 * hs, device=dev()) * 0.1).to(bf)
+    want = d4_prev[:, :3 * hs].float() @ w_ih.float()
+    gates = torch.rand(max(rows, 1), 4 * hs, device=dev()).to(bf)
+    hprev = torch.randn(max(rows, 1), hs, device=dev()).to(bf)
+    res = {}
+    for fused in (False, True):
+        dh = torch.randn(max(rows, 1), hs, generator=torch.Generator(device=dev()).manual_seed(3), device=dev()).to(bf)
+        d4 = torch.zeros(max(rows, 1), 4 * hs, device=dev(), dtype=bf)
+        bpart = torch.zeros(N_BIAS_PARTIALS, 4 * hs, device=dev())
+        wide = torch.full((rows_prev, n_in + 64), 7.0, device=dev(), dtype=bf)
+        dinp = wide[:, :n_in]                                                                      # a column block: row stride n_in + 64
+        kw = dict(wi_t=wi_t, dinp=dinp, n_in=n_in) if fused else {}
+        if rows > 0 or fused:
+            _step_bwd_fused(rows, hs, d4_prev, rows_prev, wh_t, gates if rows else None, hprev if rows else None, None, hs,
+                            dh if rows else None, d4 if rows else None, 0.0, 0, 0, bpart if rows else None, **kw)
+        torch.cuda.synchronize()
+        res[fused] = (dh.clone(), d4.clone(), bpart.clone(), dinp, wide)
+    for a_, b_ in zip(res[False][:3], res[True][:3]):
+        assert torch.equal(a_, b_)
+    dinp = res[True][3]
+    torch.testing.assert_close(dinp.float(), want, rtol=2e-2, atol=0.02 * (3 * hs) ** 0.5 * 0.03)
+    assert bool((res[True][4][:, n_in:] == 7).all())                     # nothing beyond the block is touched
+    # accumulate on top, then the masked form: dinp = mask * product, counter in_drop_base + m * n_in + column
+    before = dinp.clone()
+    _step_bwd_fused(0, hs, d4_prev, rows_prev, wh_t, None, None, None, hs, None, None, 0.0, 0, 0, None, wi_t=wi_t, dinp=dinp, n_in=n_in, dinp_acc=True)
+    torch.testing.assert_close(dinp.float(), before.float() + want, rtol=3e-2, atol=0.02)
+    masked = torch.empty(rows_prev, n_in, device=dev(), dtype=bf)
+    _step_bwd_fused(0, hs, d4_prev, rows_prev, wh_t, None, None, None, hs, None, None, 0.0, 0, 0, None, wi_t=wi_t, dinp=masked, n_in=n_in,
+                    p_in=0.25, seed_in=4242, in_drop_base=5 * n_in)
+    torch.cuda.synchronize()
+    idx = (torch.arange(rows_prev).view(-1, 1) + 5) * n_in + torch.arange(n_in).view(1, -1)
+    keep = _hash_keep(4242, idx.numpy(), 0.25).to(dev())
+    torch.testing.assert_close(masked.float(), torch.where(keep, want / 0.75, torch.zeros_like(want)), rtol=2e-2, atol=0.02)
+
+
+@pytest.mark.parametrize("p", [0.0, 0.3])
+def test_embed_packed_paths_equals_sort_pack_embed(p):
+    """gtos_embed_packed_paths (the RelationEncoder's packed input straight off the bank through the sort order, no host read) == the
+    reference's sort -> pack -> embed -> dropout sequence as round 4 ran it (torch.sort / cat + gtos_embed_rows_fwd): bit-identical
+    rows under the same seed, plus the one-hot operand and the packed tokens."""
+    from gtos_amd import ops
+    from gtos_amd._lib import call, dt, ptr, stream
+    from gtos_amd.gru import PackPlan
+    bank, length = _relenc_case(R=1500, L=7, V=86)
+    L, R = bank.shape
+    table = torch.randn(86, 100, device=dev())
+    plan = PackPlan.of_lengths(length.to(dev()), L)
+    sl, order = torch.sort(length, descending=True, stable=True)
+    toks = bank.index_select(1, order)
+    packed = torch.cat([toks[t, :a] for t, a in enumerate(plan.batch_sizes)]).to(dev())
+    assert plan.N == packed.numel() == int(length.sum())
+    for dtype in (torch.bfloat16, torch.float32):
+        ops.set_seed(11)
+        want = ops.embed_rows(packed, table, 128, p, dtype)
+        X = torch.empty(plan.N, 128, device=dev(), dtype=dtype)
+        onehot = torch.empty(plan.N, 88, device=dev(), dtype=torch.bfloat16)
+        tokens = torch.empty(plan.N, device=dev(), dtype=torch.int64)
+        ops.set_seed(11)
+        call("gtos_embed_packed_paths", dt(X), L, R, plan.N, ptr(bank.to(dev())), ptr(plan.order32), ptr(plan.offs_dev), ptr(table), 100, 128, ptr(X),
+             float(p), ops.next_seed() if p > 0 else 0, ptr(onehot), 88, ptr(tokens), stream())
+        torch.cuda.synchronize()
+        assert torch.equal(X, want) and torch.equal(tokens, packed)
+        assert torch.equal(onehot.float(), torch.nn.functional.one_hot(packed, 88).float())
