@@ -222,7 +222,11 @@ def build_roofline(a, cfg, stats, model, trainer, batch, prof, dev, cd, detail=T
     stage_a = P * 2 * d * s_el + 4 * n * B * d * s_el + n * B
     fact_bytes = R * 2 * d * s_el + P * 4 + 4 * n * B * d * s_el + n * B
     pmc = {}
-    pmc_file = next((f for f in (os.path.join(ROOT, "profiles", "r%d_rel_attn_pmc.json" % r) for r in (3, 2)) if os.path.exists(f)), None)
+    import glob
+    import re
+    pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rel_attn_pmc.json")),
+                       key=lambda f: int(re.match(r"r(\d+)", os.path.basename(f)).group(1)))
+    pmc_file = pmc_files[-1] if pmc_files else None          # the newest round's counter profile of the attention kernels
     if a.config == "C2" and a.dtype == "bf16" and pmc_file:
         pmc = json.load(open(pmc_file))
     key = "rel_attn_fwd_mode1" if a.dense else "rel_attn_fwd_mode2"
@@ -303,15 +307,39 @@ def build_roofline(a, cfg, stats, model, trainer, batch, prof, dev, cd, detail=T
                 bytes_per_launch=2 * R_multi * 2 * d * s_el + P_multi * H * 4 + P_multi * 4 + 2 * n * B * d * s_el,
                 note="%d multi-pair types: 2d*s bank row read + gradient row written each; their %d pairs: gs [H] fp32 + pair id; q,k rows "
                      "once (they are served by L2)" % (R_multi, P_multi))
-        hbm_row("gru_step_fwd_tables", "gru_l1_fwd_persistent_kernel (GRU layer 1 step, gate tables gathered, W_hh slice resident in LDS)",
+        # ---- RelationEncoder, by the evaluation this run used (the spans are named per mode and per layer)
+        # the reference's dropout semantics (library default): one GRU row per (path, position) in both layers (gtos_amd.gru.PackedPathGRUFn);
+        # these spans carry their launches' algorithmic bytes as units (gtos_amd/gru.py: _step_fwd / _step_bwd_fused)
+        dp_ = (-100) % 64 + 100
+        hbm_row("gru_step_fwd_packed_l0", "gru_step_fwd_ring_kernel, GRU layer 0 (input product fused: label rows x W_ih inside)", bytes_per_unit=1,
+                note="per active row: label-embedding row %d*2 B + entering state h read; gates 4h + new state h + dropped copy h written (h = %d bf16)" % (dp_, hs))
+        hbm_row("gru_step_fwd_packed_l1", "gru_step_fwd_ring_kernel, GRU layer 1 (input product fused: layer-0 output rows x W_ih inside)", bytes_per_unit=1,
+                note="per active row: layer-0 output row 2h + entering state h read; gates 4h + new state h written")
+        hbm_row("gru_step_bwd_packed_l1", "gru_step_bwd_kernel<false>, GRU layer 1: cell tiles + the previous step's input-gradient tiles in one launch",
+                bytes_per_unit=1,
+                note="per active row: gates 4h + entering state h read, state gradient h read + written, d4 4h written; the previous step's d4 rows "
+                     "once (4h where both roles read them); that step's input gradient 2h written (direction 1: read + written)")
+        hbm_row("gru_step_bwd_packed_l0", "gru_step_bwd_kernel<false>, GRU layer 0: cell tiles + the previous step's (masked) label-row gradient tiles",
+                bytes_per_unit=1,
+                note="as layer 1 plus the output gradient row h read per active row; input gradient %d columns" % dp_)
+        for l_ in (1, 0):
+            ms, cnt, units, tot = span(dp, "gru_dw_grouped_l%d" % l_)
+            if ms:
+                rows.append({"kernel": "gemm256p_tn_kernel<grouped>, GRU layer %d: dW_ih and dW_hh of a direction as one product d4^T [x | h_prev]" % l_,
+                             "bound": "mfma", "launches_per_step": cnt // 2, "avg_us": round(ms * 1e3, 1), "flops_per_launch": int(units / cnt),
+                             "achieved": round(units / tot / 1e9, 1), "unit": "TFLOP/s", "peak": MFMA_PEAK_TFS,
+                             "frac": round(units / tot / 1e9 / MFMA_PEAK_TFS, 4), "ms_per_step": round(tot / 2, 2),
+                             "note": "useful flops 2 N 3h (in + h); runs on the auxiliary stream beside the other direction's HBM-bound steps"})
+        # trie-shared masks (--relation-masks node, opt-in): layer 0 per trie node, layer 1 on per-node gate tables
+        hbm_row("gru_step_fwd_tables", "gru_l1_fwd_persistent_kernel (trie evaluation: GRU layer 1 step, gate tables gathered, W_hh slice resident in LDS)",
                 bytes_per_unit=(4 + 1 + 1 + 6) * hs * 2 + 8,
                 note="per active row: gates 4h + new state h written, state h read, two 3h table rows gathered, 2 node ids")
-        hbm_row("gru_step_fwd_x", "gru_step_fwd_kernel<1> (GRU layer 0 on the tries, input product fused)",
+        hbm_row("gru_step_fwd_x", "gru_step_fwd_kernel<1> (trie evaluation: GRU layer 0 on the tries, input product fused)",
                 bytes_per_unit=(4 + 1 + 1 + 1) * hs * 2 + 104 * 2 + 4,
                 note="per trie node: gates 4h + state h + dropped copy h written, parent state h gathered, embedding row read")
-        hbm_row("gru_step_bwd_rows", "gru_step_bwd_kernel (GRU layer 1)", bytes_per_unit=(4 + 1 + 3 + 2 + 4) * hs * 2,
+        hbm_row("gru_step_bwd_rows", "gru_step_bwd_kernel (trie evaluation: GRU layer 1)", bytes_per_unit=(4 + 1 + 3 + 2 + 4) * hs * 2,
                 note="per active row: gates 4h + h_prev h read, later step's d(hg) 3h read (MFMA operand), dh read+written, d4 4h written")
-        hbm_row("segment_sum_rows", "seg_sum_stream_kernel (gate-table gradients: rows -> trie nodes)",
+        hbm_row("segment_sum_rows", "seg_sum_stream_kernel (trie evaluation: gate-table gradients, rows -> trie nodes)",
                 bytes_per_unit=3 * hs * 2 + 4, note="per row: d(xg) 3h read + row id; + nodes x 3h written (not counted)")
         grows = []
         for key_, evs in gp.items():
@@ -842,6 +870,21 @@ def main():
                "other_scaling": other_scaling, "collectives": rccl_info}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.config, a.cpu_graphs, a.cpu_steps, a.cpu_budget, a.cpu_warmup)
+            # SURVEY 8d's protocol (8 graphs, 2 warm-up + >= 5 timed steps: five minutes of host time) is a run of its own
+            # (--cpu-graphs 8 --cpu-steps 5 --cpu-warmup 2 --cpu-budget 600); the newest committed record of it is quoted beside the bounded leg
+            import glob
+            import re
+            recs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_%s_n1_cpu_protocol.json" % a.config.lower())),
+                          key=lambda f: int(re.match(r"r(\d+)", os.path.basename(f)).group(1)))
+            if recs and a.cpu_graphs < 8:
+                try:
+                    pr = json.loads(open(recs[-1]).read().strip().splitlines()[-1])["cpu_baseline"]
+                    out["cpu_baseline"]["protocol_8d"] = {"value": pr["value"], "unit": pr["unit"], "cores": pr["cores"], "cpu": pr.get("cpu"),
+                                                          "sample": pr["sample"], "source": "profiles/" + os.path.basename(recs[-1]),
+                                                          "note": "the 8-graph working set is larger than the bounded leg's: its graphs/s is the lower, "
+                                                                  "stricter figure (the bounded leg flatters the CPU)"}
+                except Exception as exc:              # a malformed record must not take the bench line down
+                    log("cpu protocol record unreadable:", exc)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()                     # rank 0 may still be measuring its dense-signature leg

@@ -23,6 +23,8 @@
 
 __attribute__((visibility("hidden"))) const void* gtos_zero_block();      // gemm.hip: 256 zero bytes in global memory
 
+#define GTOS_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))
+
 namespace {
 
 constexpr int ROWB = 128, BK = 64, TM = 128, TC = 64, WROWS = 3 * TC;
@@ -302,6 +304,209 @@ __global__ __launch_bounds__(256, 2) void gru_step_fwd_kernel(StepArgs a) {
             st16(a.y + (int64_t)m * a.ldy + cb, o);
         }
     }
+}
+
+
+// The cell of a 128-row x 64-channel tile on the accumulators of the gate products (shared by the step kernels below): lane (fr, fq)
+// holds rows m0 + wave*32 + mt*16 + fr, channels cb .. cb+15 (index nt*4 + e) of accumulator groups r, z, (n_x,) n_h.
+template <int MODE>
+__device__ __forceinline__ void step_cell(const StepArgs& a, f32x4_t (&acc)[2][(MODE == 1 ? 4 : 3) * 4], int m0, int c0, int wave, int fr, int fq) {
+    constexpr bool HAS_X = MODE == 1;
+    constexpr int GH = HAS_X ? 3 : 2;
+    // ---- cell: lane (fr, fq) holds rows m0 + wave*32 + mt*16 + fr, channels cb .. cb+15 (index nt*4 + e)
+    const int cb = c0 + fq * 16, hs = a.hs;
+    float bhr[16], bhz[16], bhn[16];
+    ldf16(a.b_hh + cb, bhr); ldf16(a.b_hh + hs + cb, bhz); ldf16(a.b_hh + 2 * hs + cb, bhn);
+    if constexpr (MODE != 0) {                   // b_ih of r and z joins b_hh; the n part is added to the input-side term below
+        float t[16];
+        ldf16(a.b_ih + cb, t);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bhr[i] += t[i];
+        ldf16(a.b_ih + hs + cb, t);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bhz[i] += t[i];
+    }
+    const float ks = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int m = m0 + wave * 32 + mt * 16 + fr;
+        if (m >= a.rows) continue;
+        float xr[16], xz[16], xn[16], hp[16];
+        if constexpr (HAS_X) {
+            ldf16(a.b_ih + 2 * hs + cb, xn);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { xr[i] = 0.f; xz[i] = 0.f; xn[i] += acc[mt][8 + (i >> 2)][i & 3]; }
+        } else if constexpr (MODE == 2) {
+            const bf16_t* fp = a.gf + (int64_t)a.gf_idx[m] * 3 * hs + cb;
+            const bf16_t* bp = a.gb + (int64_t)a.gb_idx[m] * 3 * hs + cb;
+            float t[16];
+            ld16(fp, xr); ld16(bp, t);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) xr[i] += t[i];
+            ld16(fp + hs, xz); ld16(bp + hs, t);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) xz[i] += t[i];
+            ld16(fp + 2 * hs, xn); ld16(bp + 2 * hs, t);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) xn[i] += t[i];
+            ldf16(a.b_ih + 2 * hs + cb, t);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) xn[i] += t[i];
+        } else {
+            const bf16_t* xp = a.xg + (int64_t)m * 3 * hs + cb;
+            ld16(xp, xr); ld16(xp + hs, xz); ld16(xp + 2 * hs, xn);
+        }
+        ld16(a.h_in + (int64_t)(a.h_idx ? a.h_idx[m] : m) * hs + cb, hp);
+        float gr[16], gz[16], gn[16], hn[16], o[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            gr[i] = 1.f / (1.f + __expf(-(xr[i] + acc[mt][(i >> 2)][i & 3] + bhr[i])));
+            gz[i] = 1.f / (1.f + __expf(-(xz[i] + acc[mt][4 + (i >> 2)][i & 3] + bhz[i])));
+            hn[i] = acc[mt][GH * 4 + (i >> 2)][i & 3] + bhn[i];
+            // the saved hn is what backward multiplies by: round it first so that forward and backward agree
+            hn[i] = bf2f(f2bf(hn[i]));
+            gn[i] = tanhf(xn[i] + gr[i] * hn[i]);
+            o[i] = (1.f - gz[i]) * gn[i] + gz[i] * hp[i];
+        }
+        bf16_t* gp = a.gates + (int64_t)m * 4 * hs + cb;
+        st16(gp, gr); st16(gp + hs, gz); st16(gp + 2 * hs, gn);
+        if (a.save_hn) st16(gp + 3 * hs, hn);
+        bf16_t* hdst = m < a.n_out ? a.h_out + (int64_t)m * hs + cb
+                                   : a.h_fin + (int64_t)(a.fin_idx ? a.fin_idx[m] : m) * a.ld_fin + cb;
+        st16(hdst, o);
+        if (a.y) {
+            if (a.p_drop > 0.f) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    o[i] = drop_keep(a.seed, (uint64_t)(a.drop_base + (int64_t)m * a.ldy + cb + i), a.p_drop) ? o[i] * ks : 0.f;
+            }
+            st16(a.y + (int64_t)m * a.ldy + cb, o);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 5: the fused forward step (MODE 1: input product inside) with a THREE-slot ring of 32-k stages instead of one 64-k stage.
+// gru_step_fwd_kernel<1> walks load -> barrier -> MFMA -> barrier per k tile with nothing in flight while it multiplies: at 250
+// registers two workgroups share a CU, so at most one other wave per SIMD covers a round trip to L2 / HBM, and the per-(path, position)
+// evaluation of the reference's dropout semantics spends 18 ms per C2 step in it at a quarter of either roofline.
+// Here a wave keeps its pieces of TWO stages in flight while it multiplies a third:
+//   * stage = 128 activation rows + 192 weight rows x 32 k = 20 KB in 64-byte rows (chunk c of row r at c ^ ((-(r >> 2)) & 3), as
+//     gemm256p_nt_kernel), 20 LDS-DMA pieces = 5 per wave; three slots in SEPARATE static arrays (hipcc's wait-count pass tracks
+//     LDS-DMA per LDS object); the waits are explicit (vmcnt(5): the newest stage stays in flight);
+//   * the k axis is [x | h]: stages 0 .. in_dim/32 read x rows and W_ih (n -> accumulator group 2), the rest h_in rows and W_hh
+//     (n -> group 3); stage s+2 is issued right after the barrier that proves slot (s+2) % 3 = (s-1) % 3 free: ONE barrier per stage;
+//   * same tile, same lane -> channel map and the same cell (step_cell<1>) as gru_step_fwd_kernel<1>: bit-identical results.
+// Needs in_dim % 32 == 0 (the packed path pads the label width to 64).
+constexpr int RROW = 64, RA = TM * RROW, RST = (TM + WROWS) * RROW;          // 8 KB + 12 KB per stage
+
+__global__ __launch_bounds__(256, 2) void gru_step_fwd_ring_kernel(StepArgs a) {
+    if (a.p_drop > 0.f) a.seed = live_seed(a.seed);
+    __shared__ __attribute__((aligned(16))) char sl0[RST];
+    __shared__ __attribute__((aligned(16))) char sl1[RST];
+    __shared__ __attribute__((aligned(16))) char sl2[RST];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int hs = a.hs, nC = hs / TC;
+    const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
+    const int m0 = ((sq / nC) * 8 + xcd) * TM, c0 = (sq % nC) * TC;
+    if (m0 >= a.rows) return;
+    const int nkx = a.in_dim / 32, nk = nkx + hs / 32;
+    // DMA: a wave instruction fills 1 KB = 16 rows x 64 B; lane l -> row l >> 2, physical chunk l & 3 (logical chunk below)
+    const int drow = lane >> 2;
+    const uint32_t dchunk = (uint32_t)(((lane & 3) ^ ((-(lane >> 4)) & 3)) << 4);
+    // wave w owns pieces w, w + 4 of the activation rows and w, w + 4, w + 8 of the weight rows; rows past the end re-read the last valid
+    // row (their results are never stored)
+    uint32_t axo[2], aho[2], bxo[3], bho[3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = min(m0 + (wave + 4 * i) * 16 + drow, a.rows - 1) - m0;
+        axo[i] = (uint32_t)r * (uint32_t)(a.ldx * 2) + dchunk;
+        aho[i] = (uint32_t)r * (uint32_t)(hs * 2) + dchunk;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int rl = (wave + 4 * i) * 16 + drow;                             // LDS weight row -> (gate, channel) as in dma_weights
+        const int g = rl >> 6, nt = (rl >> 4) & 3, q = (rl >> 2) & 3, e = rl & 3;
+        const int wrow = g * hs + c0 + q * 16 + nt * 4 + e;
+        bxo[i] = (uint32_t)wrow * (uint32_t)(a.in_dim * 2) + dchunk;
+        bho[i] = (uint32_t)wrow * (uint32_t)(hs * 2) + dchunk;
+    }
+    const char* Xb = reinterpret_cast<const char*>(a.x + (int64_t)m0 * a.ldx);
+    const char* Hb = reinterpret_cast<const char*>(a.h_in + (int64_t)m0 * hs);
+    const char* Wi = reinterpret_cast<const char*>(a.w_ih);
+    const char* Wh = reinterpret_cast<const char*>(a.w_hh);
+    const int foff = fr * RROW + ((fq ^ ((-(fr >> 2)) & 3)) << 4);           // fragment reads: row (.. + fr), logical chunk fq
+
+    f32x4_t acc[2][16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    bf16x8_t fa[2], fb[12];
+
+#define GTOS_DMA1(src, dst)                                                                                                   \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),                                    \
+                                     (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+// this wave's five pieces of stage s_ (past the end: the last stage again, never multiplied) into `slot`
+#define GTOS_RING_DMA(slot, s_)                                                                                               \
+    {                                                                                                                         \
+        const int st_ = min((s_), nk - 1);                                                                                    \
+        const bool px_ = st_ < nkx;                                                                                           \
+        const char* ab_ = px_ ? Xb + st_ * 64 : Hb + (st_ - nkx) * 64;                                                        \
+        const char* bb_ = px_ ? Wi + st_ * 64 : Wh + (st_ - nkx) * 64;                                                        \
+        GTOS_DMA1(ab_ + (px_ ? axo[0] : aho[0]), (slot) + wave * 1024);                                                       \
+        GTOS_DMA1(ab_ + (px_ ? axo[1] : aho[1]), (slot) + (wave + 4) * 1024);                                                 \
+        GTOS_DMA1(bb_ + (px_ ? bxo[0] : bho[0]), (slot) + RA + wave * 1024);                                                  \
+        GTOS_DMA1(bb_ + (px_ ? bxo[1] : bho[1]), (slot) + RA + (wave + 4) * 1024);                                            \
+        GTOS_DMA1(bb_ + (px_ ? bxo[2] : bho[2]), (slot) + RA + (wave + 8) * 1024);                                            \
+    }
+// one stage: own pieces of stage s_ landed (vmcnt(5): the pieces of stage s_+1 stay in flight), barrier (everybody's landed, and
+// everybody is past its reads of stage s_-1), stage s_+2 into the slot of stage s_-1, 14 fragment reads, 24 MFMAs
+#define GTOS_RING_STEP(slot_s, slot_d, s_)                                                                                    \
+    {                                                                                                                         \
+        GTOS_VMCNT(5);                                                                                                        \
+        __builtin_amdgcn_s_barrier();                                                                                         \
+        GTOS_RING_DMA(slot_d, (s_) + 2);                                                                                      \
+        _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                                      \
+            fa[mt] = *reinterpret_cast<const bf16x8_t*>((slot_s) + (wave * 32 + mt * 16) * RROW + foff);                      \
+        _Pragma("unroll") for (int t = 0; t < 12; ++t)                                                                        \
+            fb[t] = *reinterpret_cast<const bf16x8_t*>((slot_s) + RA + (t * 16) * RROW + foff);                               \
+        __builtin_amdgcn_s_waitcnt(0xc07f);                /* lgkmcnt(0) */                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                                    \
+        _Pragma("unroll") for (int g = 0; g < 2; ++g)                                                                         \
+            _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                                  \
+                _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                              \
+                    acc[mt][g * 4 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[g * 4 + nt], fa[mt], acc[mt][g * 4 + nt], 0, 0, 0); \
+        if ((s_) < nkx) {                                                                                                     \
+            _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                                  \
+                _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                              \
+                    acc[mt][8 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[8 + nt], fa[mt], acc[mt][8 + nt], 0, 0, 0);  \
+        } else {                                                                                                              \
+            _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                                  \
+                _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                              \
+                    acc[mt][12 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[8 + nt], fa[mt], acc[mt][12 + nt], 0, 0, 0); \
+        }                                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    }
+
+    GTOS_RING_DMA(sl0, 0);
+    GTOS_RING_DMA(sl1, 1);
+    int s = 0;
+    for (; s + 3 <= nk; s += 3) {                          // whole triples: one path through the body for the wait-count pass
+        GTOS_RING_STEP(sl0, sl2, s);
+        GTOS_RING_STEP(sl1, sl0, s + 1);
+        GTOS_RING_STEP(sl2, sl1, s + 2);
+    }
+    if (s < nk) {
+        GTOS_RING_STEP(sl0, sl2, s);
+        if (s + 1 < nk) GTOS_RING_STEP(sl1, sl0, s + 1);
+    }
+    GTOS_VMCNT(0);                                         // the dummy prefetches of the last two stages
+#undef GTOS_RING_STEP
+#undef GTOS_RING_DMA
+#undef GTOS_DMA1
+    step_cell<1>(a, acc, m0, c0, wave, fr, fq);
 }
 
 
@@ -830,7 +1035,11 @@ extern "C" int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, i
         GTOS_CHECK_LAUNCH();
         return 0;
     }
-    if (mode == 1) hipLaunchKernelGGL(gru_step_fwd_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, s, a);
+    // GTOS_GRU_FWD_RING (round 5; 0 = the single-stage kernel): the three-slot ring of 32-k stages for the fused input product
+    static const bool use_ring = !(getenv("GTOS_GRU_FWD_RING") && getenv("GTOS_GRU_FWD_RING")[0] == '0');
+    if (mode == 1 && use_ring && in_dim % 32 == 0 && !h_idx && ldx < (1 << 20) && (int64_t)3 * hs * (in_dim > hs ? in_dim : hs) * 2 < (1LL << 31))
+        hipLaunchKernelGGL(gru_step_fwd_ring_kernel, dim3((unsigned)nblk), dim3(256), 0, s, a);
+    else if (mode == 1) hipLaunchKernelGGL(gru_step_fwd_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, s, a);
     else if (mode == 2) hipLaunchKernelGGL(gru_step_fwd_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(gru_step_fwd_kernel<0>, dim3((unsigned)nblk), dim3(256), 0, s, a);
     GTOS_CHECK_LAUNCH();

@@ -33,7 +33,10 @@ def resolve_index_prep(index_prep):
         return index_prep
     env = os.environ.get("GTOS_INDEX_PREP", "")
     if env:
-        return {"host": True, "device": "device", "device_all": "device_all", "off": False}[env]
+        known = {"host": True, "device": "device", "device_all": "device_all", "off": False}
+        if env not in known:
+            raise ValueError("GTOS_INDEX_PREP=%r: expected one of %s" % (env, ", ".join(sorted(known))))
+        return known[env]
     try:
         if torch.cuda.is_available():
             from . import _lib
@@ -52,6 +55,8 @@ def complete_on_device(batch, device=None, tries="hip"):
         return batch
     train = batch['relation_graphs'].path_mode != relbatch.PATH_ALL
     attach_device_relations(batch, device)
+    if not batch['relation'].is_cuda:      # completed by the host builder (the consumer is not a GPU): reference-shaped, nothing device-side to add
+        return batch
     if train:
         attach_device_relation_index(batch)
     return attach_device_tries(batch, tries)
@@ -110,8 +115,11 @@ class RelationGraphs(object):
     all-pairs work is left to the consumer's device (``index_prep="device_all"``).  Host data; ``.to()`` returns self so that
     ``{k: v.to(device) for k, v in batch.items()}`` passes it through."""
 
-    def __init__(self, csr, special_ids, path_mode, seed, max_len=8):
+    def __init__(self, csr, special_ids, path_mode, seed, max_len=8, graphs=None):
         self.csr, self.special_ids, self.path_mode, self.seed, self.max_len = csr, tuple(int(v) for v in special_ids), path_mode, int(seed), max_len
+        # the graphs themselves ((n_nodes, root, edges[E,3]) each, a few KB): what the C++ host builder takes when the consumer turns out NOT
+        # to be a GPU (a CPU / fp32 parity model fed from a loader that resolved index_prep="auto" on a GPU box)
+        self.graphs = graphs
 
     def to(self, *a, **k):
         return self
@@ -123,8 +131,18 @@ def attach_device_relations(batch, device=None):
     rg = batch.get('relation_graphs')
     if rg is None or 'relation' in batch:
         return batch
-    from .relbatch_hip import HipBackend, build_relation_batch_all_staged, build_relation_batch_staged
     dev = batch['concept'].device if device is None else torch.device(device)
+    if dev.type != "cuda":
+        # the HIP stage kernels take device pointers: a consumer on the host gets the C++ host builder's tensors (the same arrays, element
+        # for element: tests/test_zzz_hip_relbatch.py) -- complete, reference-shaped, with the host-side index preparation
+        if rg.graphs is None:
+            raise ValueError("a batch that ships 'relation_graphs' can only be completed on a GPU (or needs RelationGraphs.graphs for the host builder)")
+        full = relbatch.build_relation_batch(rg.graphs, rg.special_ids, path_mode=rg.path_mode, seed=rg.seed, max_len=rg.max_len)
+        for k in ('relation', 'relation_bank', 'relation_length'):
+            batch[k] = full[k].to(dev)
+        del batch['relation_graphs']
+        return batch
+    from .relbatch_hip import HipBackend, build_relation_batch_all_staged, build_relation_batch_staged
     if rg.path_mode == relbatch.PATH_ALL:        # an eval batch: every shortest path, relation [n,n,B,K]
         rel = build_relation_batch_all_staged(None, rg.special_ids, HipBackend.shared(), max_len=rg.max_len, device=dev, csr=rg.csr)
     else:
@@ -169,7 +187,7 @@ def batchify_dependency(trees, vocabs, n_threads=0, unk_rate=0., rng=None, repla
         from .relbatch_hip import graphs_csr
         csr = graphs_csr(graphs)
         orders = [csr['order'][int(csr['node_off'][b]):int(csr['node_off'][b + 1])].tolist() for b in range(len(trees))]
-        rel = {'relation_graphs': RelationGraphs(csr, relation_special_ids(rv), relbatch.PATH_FIRST, 0)}
+        rel = {'relation_graphs': RelationGraphs(csr, relation_special_ids(rv), relbatch.PATH_FIRST, 0, graphs=graphs)}
     else:
         full = relbatch.build_relation_batch(graphs, relation_special_ids(rv), path_mode=relbatch.PATH_FIRST, n_threads=n_threads)
         orders = [full['order'][b, :len(t[2])].tolist() for b, t in enumerate(trees)]
@@ -339,7 +357,7 @@ def batchify_amr(items, vocabs, train=True, seed=0, n_threads=0, unk_rate=0., rn
         for b, x in enumerate(items):
             lo, hi = int(csr['node_off'][b]), int(csr['node_off'][b + 1])
             assert csr['order'][lo:hi].tolist() == list(range(len(x['concept']))), "items must list their concepts in BFS order"
-        rel = {'relation_graphs': RelationGraphs(csr, relation_special_ids(rv), relbatch.PATH_UNIFORM if train else relbatch.PATH_ALL, seed)}
+        rel = {'relation_graphs': RelationGraphs(csr, relation_special_ids(rv), relbatch.PATH_UNIFORM if train else relbatch.PATH_ALL, seed, graphs=graphs)}
     else:
         rel = relbatch.build_relation_batch(graphs, relation_special_ids(rv),
                                             path_mode=relbatch.PATH_UNIFORM if train else relbatch.PATH_ALL, seed=seed,

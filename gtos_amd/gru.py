@@ -51,12 +51,16 @@ RECOMPUTE_HN = os.environ.get("GTOS_GRU_RECOMPUTE_HN", "0") == "1"
 
 
 def _step_fwd(A, hs, x, xg, h_in, wi, b_ih, wh, b_hh, h_out, n_out, h_fin, gates, y, y_off_elems, ldy, p, seed, drop_base,
-              h_idx=None, gf=None, gf_idx=None, gb=None, gb_idx=None, fin_idx=None):
+              h_idx=None, gf=None, gf_idx=None, gb=None, gb_idx=None, fin_idx=None, tag=None):
     """``h_fin``: [*, hs] or a column block of a wider matrix (its row stride is passed on); ``fin_idx``: int32 row map of the
     finished rows (packed row m -> row fin_idx[m] of h_fin)."""
     yp = None if y is None else y.data_ptr() + y_off_elems * y.element_size()
     need_bi = x is not None or gf is not None
-    with _Timed("gru_step_fwd_%s" % ("x" if x is not None else ("tables" if gf is not None else "xg")), detail=True, units=A):
+    # ``tag`` (bench.py's per-kernel rows): the span is recorded under that name with its ALGORITHMIC bytes as units -- per active row the
+    # input row, the entering state, the four saved gate blocks, the new state and, for a layer with a successor, its dropped copy
+    name = tag or "gru_step_fwd_%s" % ("x" if x is not None else ("tables" if gf is not None else "xg"))
+    units = A if tag is None else A * 2 * (x.shape[1] + hs + 4 * hs + hs + (hs if y is not None else 0))
+    with _Timed(name, detail=True, units=units):
         _step_fwd_call(A, hs, x, xg, h_in, wi, b_ih, wh, b_hh, h_out, n_out, h_fin, gates, yp, ldy, p, seed, drop_base,
                        h_idx, gf, gf_idx, gb, gb_idx, need_bi, fin_idx)
 
@@ -307,10 +311,17 @@ class PackPlan(object):
 
 
 def _step_bwd_fused(A, hs, d4_prev, rows_prev, wh_t, gates, hprev, dy_ptr, ldy, dh, d4, p, seed, drop_base, bpart,
-                    wi_t=None, dinp=None, n_in=0, dinp_acc=False, p_in=0.0, seed_in=0, in_drop_base=0):
+                    wi_t=None, dinp=None, n_in=0, dinp_acc=False, p_in=0.0, seed_in=0, in_drop_base=0, tag="gru_step_bwd_packed"):
     """gtos_gru_step_bwd_fused: the backward step of ``A`` rows (A == 0: none) plus, with ``dinp``, the input gradient of the
-    ``rows_prev`` rows of the step processed just before (role B workgroups of the same launch)."""
-    with _Timed("gru_step_bwd_rows", detail=True, units=max(A, 0)):
+    ``rows_prev`` rows of the step processed just before (role B workgroups of the same launch).  The span's units are the launch's
+    ALGORITHMIC bytes: per active row gates 4h + entering state h read, state gradient h read + written, d4 4h written, dy h read when
+    there is one; of the previous step's d4 the blocks its consumers need, each once (3h for the recurrent product alone, all 4h where
+    the input-gradient tiles read the same rows); dinp written (and read first when it accumulates)."""
+    rp = rows_prev if d4_prev is not None else 0
+    both = min(A, rp) if dinp is not None else 0
+    nbytes = 2 * (A * (4 * hs + hs + 2 * hs + 4 * hs + (hs if dy_ptr else 0)) + both * 4 * hs
+                  + ((rp - both) * 3 * hs if dinp is not None else min(A, rp) * 3 * hs) + (rp * n_in * (2 if dinp_acc else 1) if dinp is not None else 0))
+    with _Timed(tag, detail=True, units=nbytes):
         call("gtos_gru_step_bwd_fused", A, hs, ptr(d4_prev), rows_prev if d4_prev is not None else 0, ptr(wh_t), ptr(gates), ptr(hprev), None,
              dy_ptr, ldy, ptr(dh), 0 if dh is None else dt(dh), hs if dh is None else dh.stride(0), ptr(d4), float(p), seed, drop_base,
              ptr(bpart), N_BIAS_PARTIALS if bpart is not None else 0, None, None, None, -1, None, None,
@@ -380,7 +391,7 @@ class PackedPathGRUFn(torch.autograd.Function):
                         h_out, n_out = None, 0
                     _step_fwd(A, hs, inp[off:off + A], None, hprev[off:off + A], wi, bi, wh, bh, h_out, n_out, h_fin, gates[off:off + A],
                               Y, off * 2 * hs + direction * hs, 2 * hs, pl, seed, off * 2 * hs + direction * hs,
-                              fin_idx=plan.order32 if last else None)
+                              fin_idx=plan.order32 if last else None, tag="gru_step_fwd_packed_l%d" % l)
                 layer_saved.append((wi_t, weight_t(w_hh, wh), gates, hprev))
             saved.append((inp, seed, pl, layer_saved))
             inp = Y
@@ -407,7 +418,7 @@ class PackedPathGRUFn(torch.autograd.Function):
                     grads[base + slot] = torch.zeros(wt_.shape, dtype=torch.float32, device=dev)
         want_table = table.requires_grad
         main = torch.cuda.current_stream(dev)
-        used_side = False
+        used_side, held = False, None
         dY = None                                     # d(loss) / d(layer 0 output, after its dropout), [N, 2hs]
         dX = None
         for l in (1, 0):
@@ -425,6 +436,7 @@ class PackedPathGRUFn(torch.autograd.Function):
                 bpart = torch.zeros((N_BIAS_PARTIALS, 4 * hs), dtype=torch.float32, device=dev) if want_bias else None
                 rb = dict(wi_t=wi_t, n_in=n_in, dinp_acc=direction == 1, p_in=p_embed if l == 0 else 0.0,
                           seed_in=seed_e if l == 0 else 0) if (want_dinp and FUSE_DINP) else None
+                tag = "gru_step_bwd_packed_l%d" % l
                 prev = None
                 for t in (range(L - 1, -1, -1) if direction == 0 else range(L)):
                     A, off = bs[t], offs[t]
@@ -432,10 +444,10 @@ class PackedPathGRUFn(torch.autograd.Function):
                     kw = {} if (rb is None or prev is None) else dict(rb, dinp=d_in[offs[prev]:], in_drop_base=offs[prev] * n_in)
                     _step_bwd_fused(A, hs, None if prev is None else d4[offs[prev]:], 0 if prev is None else bs[prev], wh_t,
                                     gates[off:off + A], hprev[off:off + A], dyp, 2 * hs, dh, d4[off:off + A], pl, seed,
-                                    off * 2 * hs + direction * hs, bpart, **kw)
+                                    off * 2 * hs + direction * hs, bpart, tag=tag, **kw)
                     prev = t
                 if rb is not None:                    # the input gradient of the step processed last: role B workgroups only
-                    _step_bwd_fused(0, hs, d4[offs[prev]:], bs[prev], wh_t, None, None, None, 2 * hs, None, None, 0.0, 0, 0, None,
+                    _step_bwd_fused(0, hs, d4[offs[prev]:], bs[prev], wh_t, None, None, None, 2 * hs, None, None, 0.0, 0, 0, None, tag=tag,
                                     **dict(rb, dinp=d_in[offs[prev]:], in_drop_base=offs[prev] * n_in))
                 elif want_dinp:
                     pe = p_embed if l == 0 else 0.0
@@ -445,20 +457,26 @@ class PackedPathGRUFn(torch.autograd.Function):
                         d_in += gemm(d4[:, :3 * hs], wi_t, trans_b=True, p_drop=pe, seed=seed_e)
                     else:
                         gemm(d4[:, :3 * hs], wi_t, trans_b=True, out=d_in, accumulate=True)
-                # parameter gradients over all steps at once, on the side stream beside the next direction's steps
+                # Parameter gradients over all steps at once, on the auxiliary stream beside the NEXT direction's steps.  No record_stream:
+                # a block freed on one stream while another still reads it can only be recycled once the device has passed the free, and
+                # with no host read left in a step the host runs steps ahead of the device -- every such block (5 GB of d4 per direction at
+                # C2) then sits in limbo while the allocator mallocs new ones (237 GB reserved for 44 GB allocated, measured).  Instead the
+                # operands of a direction's products stay referenced (``held``) until the main stream has waited for the auxiliary one,
+                # one direction later.
                 side = _side_stream(dev) if (SIDE_STREAM and side_ok(dev) and N >= SIDE_MIN_ROWS) else main
+                if held is not None:
+                    main.wait_stream(_side_stream(dev))          # the previous direction's products ran beside the steps just queued
+                    held = None
                 if side is not main:
                     side.wait_stream(main)
-                    for t_ in (d4, bpart, hprev, inp):
-                        if t_ is not None:
-                            t_.record_stream(side)
+                    held = (d4, bpart, hprev, inp)
                 with torch.cuda.stream(side):
                     tg_ih = _grad_target(w_ih) if w_ih.requires_grad else None
                     tg_hh = _grad_target(w_hh) if w_hh.requires_grad else None
                     tg_ih = grads[base] if (tg_ih is None and w_ih.requires_grad) else tg_ih
                     tg_hh = grads[base + 1] if (tg_hh is None and w_hh.requires_grad) else tg_hh
                     if MERGE_DW and tg_ih is not None and tg_hh is not None and w_ih.shape[1] % 4 == 0:
-                        with _Timed("gru_dw_grouped", detail=True, units=N):
+                        with _Timed("gru_dw_grouped_l%d" % l, detail=True, units=2 * N * 3 * hs * (w_ih.shape[1] + hs)):      # (units: useful flops)
                             ws = _workspace(dev)
                             call("gtos_gru_weight_grads", N, hs, n_in, w_ih.shape[1], ptr(d4), ptr(inp), inp.stride(0), ptr(hprev), hprev.stride(0),
                                  ptr(tg_ih), tg_ih.stride(0), ptr(tg_hh), tg_hh.stride(0), ptr(ws), ws.numel() * 4, stream())
@@ -495,7 +513,9 @@ class PackedPathGRUFn(torch.autograd.Function):
                      0 if ws is None else ws.numel() * 4, stream())
         if used_side:
             if dtab is None and all(gr is None for gr in grads):
-                defer_side_join(dev)       # every gradient went into the flat bucket: its readers join the side stream (ops.join_side)
+                # every gradient went into the flat bucket: its readers join the side stream (ops.join_side), which also releases the
+                # last direction's operands
+                defer_side_join(dev, list(t_ for t_ in (held or ()) if t_ is not None))
             else:
                 main.wait_stream(_side_stream(dev))
         return (None, None, dtab, None, None, None, None) + tuple(grads)

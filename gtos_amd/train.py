@@ -14,6 +14,7 @@ Counterpart of the hot loop of /root/reference/generator/train.py:136-154: forwa
   * dropout streams are decorrelated across ranks by seeding the hash stream with base + rank after the (identical)
     weight initialisation, like train.py:113-116.
 """
+import os
 import time
 
 import torch
@@ -26,6 +27,8 @@ from .flat import FlatParams
 # segment 0 finishes first in backward.  The LAST segment is reduced after backward() returned (it holds everything whose
 # gradient is only known to be complete then: the input encoders, the relation GRU's side-stream weight gradients).
 GENERATOR_SEGMENTS = ("decoder.", "snt_encoder.", ("graph_encoder.", "probe_generator."))
+# steps the host may queue ahead of the device (0: unbounded, as up to round 4); see Trainer.step
+MAX_STEPS_AHEAD = int(os.environ.get("GTOS_MAX_STEPS_AHEAD", "2"))
 
 
 def generator_segment_of(name):
@@ -75,6 +78,7 @@ class Trainer:
         self._works = []
         self.comm_exposed_s = 0.0       # host time spent waiting for collectives after backward (gloo blocks here)
         self._comm_events = []          # (start, end) HIP events around the waits on the compute stream: the GPU-side exposed time
+        self._done_events = [] if (dev.type == "cuda" and MAX_STEPS_AHEAD > 0) else None    # end-of-step events of the steps in flight
         if self.overlap and hasattr(model, "grad_sync"):
             model.grad_sync = self      # Generator.forward places the SegmentBoundaryFn markers
         if world_size > 1:
@@ -173,6 +177,14 @@ class Trainer:
         """One training step.  ``sync=True`` returns the loss value (float), or None when the batch was discarded -- one host
         read AFTER every launch of the step has been queued.  ``sync=False`` returns a PendingLoss (``.value()`` reads it
         later): the host runs ahead into the next step, which is what the launch-bound small configurations need."""
+        if self._done_events is not None:
+            # Bounded run-ahead.  Nothing in a step reads the device any more, so the host could queue many steps ahead of it -- and the
+            # caching allocator can only recycle a block that was freed on one stream while another still used it once the DEVICE has
+            # passed that point: an unbounded run-ahead keeps several steps' worth of such blocks in limbo and mallocs new ones (C2:
+            # 237 GB reserved for 44 GB allocated).  Waiting here for the end of step k - MAX_STEPS_AHEAD costs nothing while the device
+            # is the bottleneck and never triggers when the host is (the event has long completed).
+            while len(self._done_events) >= MAX_STEPS_AHEAD:
+                self._done_events.pop(0).synchronize()
         loss = self.model(batch)
         loss = loss if loss.dtype == torch.float32 else loss.float()
         self._control(0, loss.detach())
@@ -185,6 +197,10 @@ class Trainer:
         self.flat.step(None, gscale=1.0 / self.world_size, max_norm=1.0, ctl=self._ctl)
         self.flat.zero_grad()
         res = PendingLoss(torch.cat([loss.detach().reshape(1), self._flag]))
+        if self._done_events is not None:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._done_events.append(ev)
         return res.value() if sync else res
 
 
