@@ -43,6 +43,7 @@ struct StepArgs {
     float p_drop; uint64_t seed; int64_t drop_base;
     int rows, hs; const void* zeros;
     int save_hn;                                   // 0: the hn block of `gates` is not written (backward recomputes it: StepBwdArgs.w_hn)
+    int dbg;                                       // measuring switches of the ring kernel (GTOS_GRU_DBG; 0 in production): 1 = no k loop, 2 = no cell
 };
 
 // 128 activation rows x 64 k
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(256, 2) void gru_step_fwd_ring_kernel(StepArgs a) {
     const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
     const int m0 = ((sq / nC) * 8 + xcd) * TM, c0 = (sq % nC) * TC;
     if (m0 >= a.rows) return;
-    const int nkx = a.in_dim / 32, nk = nkx + hs / 32;
+    const int nkx = a.in_dim / 32, nk = a.dbg == 1 ? 0 : nkx + hs / 32;
     // DMA: a wave instruction fills 1 KB = 16 rows x 64 B; lane l -> row l >> 2, physical chunk l & 3 (logical chunk below)
     const int drow = lane >> 2;
     const uint32_t dchunk = (uint32_t)(((lane & 3) ^ ((-(lane >> 4)) & 3)) << 4);
@@ -490,8 +491,10 @@ __global__ __launch_bounds__(256, 2) void gru_step_fwd_ring_kernel(StepArgs a) {
         __builtin_amdgcn_sched_barrier(0);                                                                                    \
     }
 
-    GTOS_RING_DMA(sl0, 0);
-    GTOS_RING_DMA(sl1, 1);
+    if (nk > 0) {
+        GTOS_RING_DMA(sl0, 0);
+        GTOS_RING_DMA(sl1, 1);
+    }
     int s = 0;
     for (; s + 3 <= nk; s += 3) {                          // whole triples: one path through the body for the wait-count pass
         GTOS_RING_STEP(sl0, sl2, s);
@@ -506,6 +509,15 @@ __global__ __launch_bounds__(256, 2) void gru_step_fwd_ring_kernel(StepArgs a) {
 #undef GTOS_RING_STEP
 #undef GTOS_RING_DMA
 #undef GTOS_DMA1
+    if (a.dbg == 2) {                                      // k loop alone: one store per lane keeps the accumulators alive
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (t == 123.456f) a.gates[threadIdx.x] = f2bf(t);
+        return;
+    }
     step_cell<1>(a, acc, m0, c0, wave, fr, fq);
 }
 
@@ -1014,6 +1026,8 @@ extern "C" int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, i
     a.h_out = (bf16_t*)h_out; a.n_out = n_out; a.h_fin = (bf16_t*)h_fin; a.gates = (bf16_t*)gates; a.y = (bf16_t*)y; a.ldy = ldy;
     a.ld_fin = ld_fin; a.fin_idx = fin_idx;
     a.p_drop = p_drop; a.seed = seed; a.drop_base = drop_base; a.rows = rows; a.hs = hs; a.save_hn = save_hn;
+    static const int dbg = getenv("GTOS_GRU_DBG") ? atoi(getenv("GTOS_GRU_DBG")) : 0;
+    a.dbg = dbg;
     a.zeros = gtos_zero_block();
     if (!a.zeros) return -5;
     const long long nM = (rows + TM - 1) / TM, nC = hs / TC;

@@ -33,6 +33,7 @@
 // LR = nhs*LH <= 64 lanes, and the heads are processed in ceil(H/nhs) independent SLICES (blockIdx.y) -- attention heads
 // never mix, so a slice is the same kernel on its own channels.  Same arithmetic, same dropout counters.
 #include "common.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -151,6 +152,17 @@ __device__ __forceinline__ const unsigned char* stage_mask(const AttnArgs& a, in
     __syncthreads();
     return use ? sm : nullptr;
 }
+// Factored operand: the type ids of a workgroup's row (S of them, 404 bytes at C2) staged in LDS by one coalesced read (round 5).  A bank
+// row's address needs its id first; read from global memory, that id load shared the wave's in-order vmcnt with the row loads of the
+// set in flight, so waiting for the ids of the NEXT set meant waiting for the rows of THIS one: one set of rows in flight instead of two,
+// and the factored forward took the dense kernel's time on two thirds of its bytes (0.46 of HBM peak on its algorithmic
+// bytes against 0.68).  From LDS the ids arrive on lgkmcnt, independent of the row loads.  No barrier here: the callers' next barrier
+// (stage_mask's, or their own) publishes the table.
+__device__ __forceinline__ const int* stage_ids(const int* __restrict__ src, int n, int* sid) {
+    if (!src || n > MAXS_LDS) return nullptr;
+    for (int j = threadIdx.x; j < n; j += 256) sid[j] = src[j];
+    return sid;
+}
 __device__ __forceinline__ bool key_dead(const AttnArgs& a, const unsigned char* sm, int i, int j, int b) {
     if (sm) return sm[j] != 0;
     return (a.key_pad || a.attn_mask) ? is_masked(a, i, j, b) : false;
@@ -162,10 +174,12 @@ __global__ __launch_bounds__(256, 4) void rel_attn_fwd_kernel(AttnArgs a) {
     if (a.p_drop > 0.f) a.seed = live_seed(a.seed);
     constexpr int U = Unroll<T>::U;
     __shared__ unsigned char smask[MAXS_LDS];
+    __shared__ int sid[MAXS_LDS];                // factored operand: the type ids of this (query, graph) row (see stage_ids)
     __shared__ float red[4][64][10];             // per wave, per lane: m, l, o[8]
     __shared__ float fin[64][2];                 // merged m and 1/l per lane (for the weights pass)
     int i, b;
     if (!map_block(a.T, a.B, i, b)) return;      // whole block
+    const int* sidp = stage_ids(a.mode == 2 ? a.idx_q + ((int64_t)i * a.B + b) * a.S : nullptr, a.S, sid);
     const unsigned char* sm = stage_mask(a, i, b, smask);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const LaneMap lm = lane_map<LH, GEN>(a.d, a.H, a.hd, a.nhs, a.lr, lane);
@@ -176,7 +190,7 @@ __global__ __launch_bounds__(256, 4) void rel_attn_fwd_kernel(AttnArgs a) {
     const T* kb = static_cast<const T*>(a.k) + (int64_t)b * a.ldk + c;
     const T* vb = static_cast<const T*>(a.v) + (int64_t)b * a.ldv + c;
     const T* rel = static_cast<const T*>(a.rel);
-    const int* iq = a.mode == 2 ? a.idx_q + ((int64_t)i * a.B + b) * a.S : nullptr;
+    const int* iq = a.mode == 2 ? (sidp ? sidp : a.idx_q + ((int64_t)i * a.B + b) * a.S) : nullptr;
     const float keep_scale = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
     const int joff = wv * G + g;                 // this lane group's key inside a slot
 
@@ -306,10 +320,12 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_q_kernel(AttnArgs a) {
     if (a.p_drop > 0.f) a.seed = live_seed(a.seed);
     constexpr int U = Unroll<T>::U;
     __shared__ unsigned char smask[MAXS_LDS];
+    __shared__ int sid[MAXS_LDS];
     __shared__ float red[4][64][8];
     __shared__ float redw[4][64];
     int i, b;
     if (!map_block(a.T, a.B, i, b)) return;
+    const int* sidp = stage_ids(a.mode == 2 ? a.idx_q + ((int64_t)i * a.B + b) * a.S : nullptr, a.S, sid);
     const unsigned char* sm = stage_mask(a, i, b, smask);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const LaneMap lm = lane_map<LH, GEN>(a.d, a.H, a.hd, a.nhs, a.lr, lane);
@@ -320,7 +336,7 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_q_kernel(AttnArgs a) {
     const T* kb = static_cast<const T*>(a.k) + (int64_t)b * a.ldk + c;
     const T* vb = static_cast<const T*>(a.v) + (int64_t)b * a.ldv + c;
     const T* rel = static_cast<const T*>(a.rel);
-    const int* iq = a.mode == 2 ? a.idx_q + row * a.S : nullptr;
+    const int* iq = a.mode == 2 ? (sidp ? sidp : a.idx_q + row * a.S) : nullptr;
     const float keep_scale = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
 
     float qf[8], dof[8], of[8];
@@ -442,8 +458,11 @@ template <typename T, int LH, bool GEN>
 __global__ __launch_bounds__(256) void rel_attn_bwd_kv_kernel(AttnArgs a) {
     constexpr int U = Unroll<T>::U;
     __shared__ float red[4][64][16];
+    __shared__ int sid[MAXS_LDS];
     int j, b;
     if (!map_block(a.S, a.B, j, b)) return;
+    const int* sidp = stage_ids(a.mode == 2 ? a.idx_k + ((int64_t)j * a.B + b) * a.T : nullptr, a.T, sid);
+    if (sidp) __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const LaneMap lm = lane_map<LH, GEN>(a.d, a.H, a.hd, a.nhs, a.lr, lane);
     const int d = a.d, LR = lm.LR, G = 64 / LR, g = lm.g, c = lm.c, h = lm.h;
@@ -453,7 +472,7 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_kv_kernel(AttnArgs a) {
     const T* qb = static_cast<const T*>(a.q) + (int64_t)b * a.ldq + c;
     const T* dob = static_cast<const T*>(a.d_o) + (int64_t)b * a.lddo + c;
     const T* rel = static_cast<const T*>(a.rel);
-    const int* ik = a.mode == 2 ? a.idx_k + row * a.T : nullptr;
+    const int* ik = a.mode == 2 ? (sidp ? sidp : a.idx_k + row * a.T) : nullptr;
     float dk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
     for (int ib = 0; ib < a.T; ib += KS * U) {
@@ -519,7 +538,9 @@ struct BankArgs {
     int hd, nhs, lr;
 };
 
-template <typename T, int LH, bool GEN>
+// NP: pairs per lane group in flight.  Most chunks hold one or two pairs, so four in flight mostly carried empty slots in 132 registers (3
+// waves per SIMD); two fit 98 (4 waves per SIMD): more chunks' dependent load chains in flight per CU (round 5; GTOS_BANK_NP=4 restores four).
+template <typename T, int LH, bool GEN, int NP>
 __global__ __launch_bounds__(256) void rel_attn_bwd_bank_kernel(BankArgs a) {
     const int lane = threadIdx.x & 63;
     const LaneMap lm = lane_map<LH, GEN>(a.d, a.H, a.hd, a.nhs, a.lr, lane);
@@ -570,11 +591,11 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_bank_kernel(BankArgs a) {
         for (int sb = 0; sb < cnt; sb += 64) {
             const int nb = min(64, cnt - sb);
             const int my_pid = sb == 0 ? l1.my_pid : (lane < nb ? a.pair_sorted[m1.start + sb + lane] : 0);
-            for (int p0 = 0; p0 < nb; p0 += 4 * G) {            // four pairs per group in flight
-                Raw8<T> rk[4], rq[4];
-                float gsc[4];
+            for (int p0 = 0; p0 < nb; p0 += NP * G) {           // NP pairs per group in flight
+                Raw8<T> rk[NP], rq[NP];
+                float gsc[NP];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < NP; ++u) {
                     const int p = p0 + u * G + g;
                     const int pid = __shfl(my_pid, p < nb ? p : 0);
                     rk[u].zero(); rq[u].zero(); gsc[u] = 0.f;
@@ -586,7 +607,7 @@ __global__ __launch_bounds__(256) void rel_attn_bwd_bank_kernel(BankArgs a) {
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < NP; ++u) {
                     float kf[8], qf[8];
                     rk[u].get(kf); rq[u].get(qf);
                     gsum += gsc[u];
@@ -743,17 +764,19 @@ extern "C" int gtos_rel_attn_bwd_bank(int dtype, int n, int B, int H, int d,
     a.xcd_off = xcd_off;
     a.hd = d / H; a.nhs = geo.nhs; a.lr = geo.lr;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    static const bool np4 = getenv("GTOS_BANK_NP") && getenv("GTOS_BANK_NP")[0] == '4';
     int grid = (nchunks + 3) / 4; if (grid > 4096) grid = 4096;
     if (xcd_off) grid = (grid + 7) / 8 * 8;
     const dim3 g2(grid, geo.slices);
     return dispatch_lh(geo.LH, [&](auto lh) {
         constexpr int LH = decltype(lh)::value;
         if (geo.generic) {
-            if (dtype == GTOS_BF16) hipLaunchKernelGGL((rel_attn_bwd_bank_kernel<bf16_t, LH, true>), g2, dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((rel_attn_bwd_bank_kernel<float, LH, true>), g2, dim3(256), 0, s, a);
+            if (dtype == GTOS_BF16) hipLaunchKernelGGL((rel_attn_bwd_bank_kernel<bf16_t, LH, true, 4>), g2, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((rel_attn_bwd_bank_kernel<float, LH, true, 4>), g2, dim3(256), 0, s, a);
         } else {
-            if (dtype == GTOS_BF16) hipLaunchKernelGGL((rel_attn_bwd_bank_kernel<bf16_t, LH, false>), g2, dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((rel_attn_bwd_bank_kernel<float, LH, false>), g2, dim3(256), 0, s, a);
+            if (dtype == GTOS_BF16 && np4) hipLaunchKernelGGL((rel_attn_bwd_bank_kernel<bf16_t, LH, false, 4>), g2, dim3(256), 0, s, a);
+            else if (dtype == GTOS_BF16) hipLaunchKernelGGL((rel_attn_bwd_bank_kernel<bf16_t, LH, false, 2>), g2, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((rel_attn_bwd_bank_kernel<float, LH, false, 4>), g2, dim3(256), 0, s, a);
         }
         GTOS_CHECK_LAUNCH();
         return 0;

@@ -96,6 +96,7 @@ class Generator(nn.Module):
             relation = ops.relation_gather_mean(bank.detach(), inp['relation'], zero_row0=inp['relation'].dim() == 4)
         with ops._Timed("graph_encoder_fwd"):
             concept_repr = self.graph_encoder(concept_repr, relation, self_padding_mask=concept_mask)
+        ops.note_memory(inp['concept'].device)               # a high-water point of the step (ops.refresh_side_policy)
         # (bf16 mode: the encoder returns its fp32 residual stream carrying the bf16 twin; everything downstream is a GEMM operand)
         concept_repr = ops.split_stream(concept_repr, self.compute_dtype)[1]
         probe = torch.tanh(ops.linear(concept_repr[:1], self.probe_generator.weight, self.probe_generator.bias))
@@ -131,8 +132,10 @@ class Generator(nn.Module):
         probe = probe.expand_as(token_repr)
         if gs is not None:          # downstream: the decoder only
             probe, concept_repr, token_repr = gs.boundary(0, probe, concept_repr, token_repr)
-        return self.decoder(probe, concept_repr, token_repr, concept_mask, token_mask, attn_mask,
-                            data['cp_seq'], target=data['token_out'])
+        out = self.decoder(probe, concept_repr, token_repr, concept_mask, token_mask, attn_mask,
+                           data['cp_seq'], target=data['token_out'])
+        ops.note_memory(token_repr.device)                   # end of the forward pass: everything saved for backward is alive
+        return out
 
     # ------------------------------------------------------------------------------------------------ inference
     def work(self, data, beam_size, max_time_step, min_time_step=1):

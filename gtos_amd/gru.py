@@ -21,7 +21,7 @@ import torch
 from . import _lib
 from ._lib import call, dt, ptr, stream
 from .ops import (gemm, compute_weight, next_seed, weight_t, _grad_target, _splitk, side_stream as _side_stream, side_ok, defer_side_join, _Timed,
-                  embed_bwd_workspace, _workspace, WORKSPACE_BYTES)
+                  embed_bwd_workspace, _workspace, WORKSPACE_BYTES, note_memory)
 
 
 def _cell_fwd(A, hs, xg, hg, h, y, y_off_elems, ldy, hprev, gates, p, seed, drop_base):
@@ -433,6 +433,7 @@ class PackedPathGRUFn(torch.autograd.Function):
                 want_bias = b_ih.requires_grad or b_hh.requires_grad
                 dh = dfin[:, direction * hs:(direction + 1) * hs] if l == 1 else torch.zeros((bs[0], hs), dtype=dtp, device=dev)
                 d4 = torch.empty((N, 4 * hs), dtype=dtp, device=dev)
+                note_memory(dev)
                 bpart = torch.zeros((N_BIAS_PARTIALS, 4 * hs), dtype=torch.float32, device=dev) if want_bias else None
                 rb = dict(wi_t=wi_t, n_in=n_in, dinp_acc=direction == 1, p_in=p_embed if l == 0 else 0.0,
                           seed_in=seed_e if l == 0 else 0) if (want_dinp and FUSE_DINP) else None

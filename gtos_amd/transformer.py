@@ -132,20 +132,24 @@ class TransformerLayer(nn.Module):
         inference core); self_cache [t,N,2d] or None; ext_kv [S,N,2d]: cached projection of the graph states.
         Same arithmetic as forward(x, kv=whole prefix, ...) of generator/transformer.py:25-44, without re-projecting
         the prefix.  Returns (x_out, grown cache)."""
-        x = x.to(self.self_attn.compute_dtype)
-        row = self.self_attn.project_kv(new_kv_src)
+        cd = self.self_attn.compute_dtype
+        # the same residual stream as forward(): fp32 also in bf16 mode (ops.FP32_STREAM), with its bf16 twin as the GEMM operand, so that
+        # teacher-forced forward and incremental decoding of one model round alike (the layer output carries the stream to the next layer)
+        xs, x = ops.split_stream(x, cd)
+        row = self.self_attn.project_kv(ops.split_stream(new_kv_src, cd)[1])
         cache = row if self_cache is None else torch.cat([self_cache, row], 0)
         a, _ = self.self_attn.attend_cached(x, cache)
         ln = self.attn_layer_norm
-        x = ops.layer_norm_residual(x, a, ln.weight, ln.bias, 0.0, ln.eps)
+        xs, x = ops.layer_norm_stream(xs, a, ln.weight, ln.bias, 0.0, ln.eps, cd)
         if self.with_external:
             a, _ = self.external_attn.attend_cached(x, ext_kv, key_padding_mask=ext_mask)
             ln = self.external_layer_norm
-            x = ops.layer_norm_residual(x, a, ln.weight, ln.bias, 0.0, ln.eps)
+            xs, x = ops.layer_norm_stream(xs, a, ln.weight, ln.bias, 0.0, ln.eps, cd)
         h = ops.linear(x, self.fc1.weight, self.fc1.bias, relu=True)
         f = ops.linear(h, self.fc2.weight, self.fc2.bias)
         ln = self.ff_layer_norm
-        return ops.layer_norm_residual(x, f, ln.weight, ln.bias, 0.0, ln.eps), cache
+        xs, x = ops.layer_norm_stream(xs, f, ln.weight, ln.bias, 0.0, ln.eps, cd)
+        return ops.join_stream(xs, x), cache
 
 
 class Transformer(nn.Module):

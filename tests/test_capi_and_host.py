@@ -226,36 +226,49 @@ def test_reference_module_names_resolve_to_the_product_modules():
 
 
 def test_auxiliary_stream_policy_follows_the_peak_allocation(monkeypatch):
-    """ops.SIDE_STREAMS="auto": the auxiliary stream is used while the process's peak allocation stays below a quarter of the device
-    memory, the decision is taken once per step from host-side allocator statistics, and it never switches back on (C5: 93 GB
-    allocated -> one allocator pool, 120 GB reserved instead of 230-277)."""
+    """ops.SIDE_STREAMS="auto": the auxiliary stream is used while a step's sampled peak allocation (ops.note_memory at the step's
+    high-water points) stays below a quarter of the device memory; the decision is taken once per step from host-side allocator
+    counters, FROM THE PREVIOUS STEP (not from torch's process-lifetime peak, which one large evaluation batch would poison and a user
+    may reset), and it comes back with hysteresis once the steps are small again (C5: 93 GB allocated -> one allocator pool, 120 GB
+    reserved instead of 230-277)."""
     import types
 
     import torch
 
     from gtos_amd import ops
     dev = torch.device("cuda", 0)
-    peak = [10 << 30]
+    cur = [10 << 30]
     monkeypatch.setattr(torch.cuda, "get_device_properties", lambda d: types.SimpleNamespace(total_memory=288 << 30))
-    monkeypatch.setattr(torch.cuda, "max_memory_allocated", lambda d: peak[0])
+    monkeypatch.setattr(torch.cuda, "memory_allocated", lambda d: cur[0])
+    monkeypatch.setattr(torch.cuda, "max_memory_allocated", lambda d: 250 << 30)      # (nobody reads the process-wide peak any more)
     monkeypatch.setattr(ops, "_SIDE_POLICY", {})
     monkeypatch.setattr(ops, "_DEVICE_BYTES", {})
+    monkeypatch.setattr(ops, "_STEP_PEAK", {})
     monkeypatch.setattr(ops, "SIDE_STREAMS", "auto")
     assert ops.side_ok(dev)                                  # before the first step: yes
     ops.refresh_side_policy(dev)
     assert ops.side_ok(dev)
-    peak[0] = 93 << 30
+    cur[0] = 93 << 30
+    ops.note_memory(dev)                                     # a high-water point inside the step ...
+    cur[0] = 5 << 30
+    ops.note_memory(dev)                                     # ... a later, lower sample does not lower it
     assert ops.side_ok(dev)                                  # nothing changes inside a step
     ops.refresh_side_policy(dev)
-    assert not ops.side_ok(dev)
-    peak[0] = 1 << 30                                        # (bench.py resets the peak statistics before its timed region)
+    assert not ops.side_ok(dev)                              # the NEXT step runs without the stream
+    cur[0] = 65 << 30                                        # below the bound (72 GB) but inside the hysteresis band (> 57.6 GB): stays off
+    ops.note_memory(dev)
     ops.refresh_side_policy(dev)
-    assert not ops.side_ok(dev)                              # sticky
+    assert not ops.side_ok(dev)
+    cur[0] = 40 << 30                                        # small steps again: the stream comes back
+    ops.note_memory(dev)
+    ops.refresh_side_policy(dev)
+    assert ops.side_ok(dev)
     ops.refresh_side_policy(torch.device("cpu"))             # no-op
     for forced, want in (("0", False), ("1", True)):
         monkeypatch.setattr(ops, "_SIDE_POLICY", {})
         monkeypatch.setattr(ops, "SIDE_STREAMS", forced)
         assert ops.side_ok(dev) is want
-        peak[0] = 200 << 30
+        cur[0] = 200 << 30
+        ops.note_memory(dev)
         ops.refresh_side_policy(dev)
         assert ops.side_ok(dev) is want
