@@ -331,6 +331,9 @@ def _step_bwd_fused(A, hs, d4_prev, rows_prev, wh_t, gates, hprev, dy_ptr, ldy, 
 # A/B switches of the round-5 path (each measured on the same box: profiles/r5_*):
 FUSE_DINP = os.environ.get("GTOS_GRU_FUSE_DINP", "1") != "0"      # layer input gradients inside the backward step launches (0: one GEMM per direction)
 MERGE_DW = os.environ.get("GTOS_GRU_MERGE_DW", "1") != "0"        # both weight gradients of a (layer, direction) as one grouped product (0: three GEMMs)
+# forward: direction 1 on the auxiliary stream beside direction 0.  MEASURED, no gain (same box, alternating: 86.66 / 84.89 ms with, 84.65 / 84.50
+# without; profiles/r5_ab_switches.txt): off.  See the comment in PackedPathGRUFn.forward for what it was meant to overlap and why it cannot.
+FWD_OVERLAP = os.environ.get("GTOS_GRU_FWD_OVERLAP", "0") == "1"
 
 
 class PackedPathGRUFn(torch.autograd.Function):
@@ -355,14 +358,25 @@ class PackedPathGRUFn(torch.autograd.Function):
         call("gtos_embed_packed_paths", dt(X), L, R, N, ptr(bank), ptr(plan.order32), ptr(plan.offs_dev), ptr(tab), dim, dim_pad, ptr(X),
              float(p_embed), seed_e, ptr(onehot), Vp, ptr(tokens), stream())
         fin = (torch.empty if bs[0] == R else torch.zeros)((R, 2 * hs), dtype=dtp, device=dev)      # (an empty path keeps a zero vector)
-        park = torch.empty((bs[0], hs), dtype=dtp, device=dev)           # where layer 0's finished rows land (nobody reads them)
+        park = [torch.empty((bs[0], hs), dtype=dtp, device=dev) for _ in (0, 1)]   # where layer 0's finished rows land (nobody reads them)
         inp, saved = X, []
+        # The two directions of a layer are independent; FWD_OVERLAP=1 (opt-in) runs direction 1 on the auxiliary stream beside direction 0.
+        # What it was for: a step workgroup is a k loop followed by a cell that streams 2.5-3 KB per row out, and a launch measured alone
+        # costs the SUM of the two parts (gru_step_fwd_ring_kernel's measuring switches, L1 at 434 k rows: 593 us of k loop alone + 437 us of
+        # cell alone = 978 us together), not their maximum -- so workgroups of two launches, out of phase on a CU, might have overlapped one's
+        # stores with the other's products.  They do not (no gain, measured): the k loop is bound by operand delivery into LDS (6.5 GB of
+        # LDS-DMA per launch at the ~10.7 TB/s the chip sustains = the 593 us) and the cell by its stores, and both go through the CUs' one
+        # vector-memory pipe -- the phases add up however they are interleaved.  What shortens a launch is fewer bytes through that pipe.
+        main = torch.cuda.current_stream(dev)
+        aux = _side_stream(dev) if (FWD_OVERLAP and table.is_cuda and side_ok(dev) and N >= SIDE_MIN_ROWS) else main
         for l in range(2):
             last = l == 1
             Y = None if last else torch.empty((N, 2 * hs), dtype=dtp, device=dev)
             seed = next_seed() if (p_layer > 0 and not last) else 0
             pl = p_layer if not last else 0.0
             layer_saved = []
+            bufs = [(torch.empty((N, 4 * hs), dtype=dtp, device=dev), torch.empty((N, hs), dtype=dtp, device=dev)) for _ in (0, 1)]
+            wts = []
             for direction in (0, 1):
                 w_ih, w_hh, b_ih, b_hh = weights[l * 8 + direction * 4: l * 8 + direction * 4 + 4]
                 wi, wh = compute_weight(w_ih, dtp), compute_weight(w_hh, dtp)
@@ -371,9 +385,13 @@ class PackedPathGRUFn(torch.autograd.Function):
                     wi_t = wi.t().contiguous()
                 else:
                     wi_t = weight_t(w_ih, wi)
-                gates = torch.empty((N, 4 * hs), dtype=dtp, device=dev)
-                hprev = torch.empty((N, hs), dtype=dtp, device=dev)
-                bi, bh = b_ih.detach(), b_hh.detach()
+                wts.append((wi, wh, wi_t, weight_t(w_hh, wh), b_ih.detach(), b_hh.detach()))
+            if aux is not main:
+                aux.wait_stream(main)
+            for direction in (0, 1):
+              with torch.cuda.stream(aux if direction == 1 else main):
+                wi, wh, wi_t, wh_t, bi, bh = wts[direction]
+                gates, hprev = bufs[direction]
                 if direction == 0:
                     hprev[:bs[0]].zero_()
                 else:                                   # rows that become active at step t start from h = 0
@@ -381,7 +399,7 @@ class PackedPathGRUFn(torch.autograd.Function):
                         lo = bs[t + 1] if t + 1 < L else 0
                         if bs[t] > lo:
                             hprev[offs[t] + lo: offs[t] + bs[t]].zero_()
-                h_fin = fin[:, direction * hs:(direction + 1) * hs] if last else park
+                h_fin = fin[:, direction * hs:(direction + 1) * hs] if last else park[direction]
                 for t in (range(L) if direction == 0 else range(L - 1, -1, -1)):
                     A, off = bs[t], offs[t]
                     nxt = t + 1 if direction == 0 else t - 1
@@ -392,7 +410,9 @@ class PackedPathGRUFn(torch.autograd.Function):
                     _step_fwd(A, hs, inp[off:off + A], None, hprev[off:off + A], wi, bi, wh, bh, h_out, n_out, h_fin, gates[off:off + A],
                               Y, off * 2 * hs + direction * hs, 2 * hs, pl, seed, off * 2 * hs + direction * hs,
                               fin_idx=plan.order32 if last else None, tag="gru_step_fwd_packed_l%d" % l)
-                layer_saved.append((wi_t, weight_t(w_hh, wh), gates, hprev))
+                layer_saved.append((wi_t, wh_t, gates, hprev))
+            if aux is not main:
+                main.wait_stream(aux)
             saved.append((inp, seed, pl, layer_saved))
             inp = Y
         ctx.cfg = (plan, table, dim_pad, p_embed, seed_e, hs, weights, saved, onehot, tokens)
