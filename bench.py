@@ -778,8 +778,7 @@ def main():
     # ---- the same step replayed from a hipGraph (train.GraphedStep): what the Python-paced launch sequence costs.  One process, the
     # pre-built batch, the trie evaluation of the RelationEncoder (node masks or no dropout); the capture is not part of the figure.
     graph_leg = None
-    if (world == 1 and not a.fresh_batches and a.graph_leg and cd == torch.bfloat16 and not a.dense
-            and a.relation_masks == "node"):
+    if world == 1 and not a.fresh_batches and a.graph_leg and cd == torch.bfloat16 and not a.dense:
         from gtos_amd.train import GraphedStep
         gs = None
         try:

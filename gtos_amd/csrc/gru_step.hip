@@ -43,7 +43,6 @@ struct StepArgs {
     float p_drop; uint64_t seed; int64_t drop_base;
     int rows, hs; const void* zeros;
     int save_hn;                                   // 0: the hn block of `gates` is not written (backward recomputes it: StepBwdArgs.w_hn)
-    int dbg;                                       // measuring switches of the ring kernel (GTOS_GRU_DBG; 0 in production): 1 = no k loop, 2 = no cell
 };
 
 // 128 activation rows x 64 k
@@ -188,6 +187,15 @@ __device__ __forceinline__ void ldf16(const float* p, float (&v)[16]) {
     }
 }
 
+// tanh for the bf16 step kernels: 1 - 2 / (exp(2x) + 1) on v_exp_f32 / v_rcp_f32 (~6 instructions; exact limits -1 / +1, no NaN for finite
+// x).  tanhf() is ~40 instructions with range checks per element and made the cell of the fused forward step VALU-bound: ~2,700 VALU
+// instructions per wave after the last MFMA, half of them tanhf -- the "cell alone" time of the measuring switches, 437-524 us per 434 k-row
+// launch, was arithmetic, not stores.  Absolute error ~1e-7, far below the bf16 rounding of the value it feeds (n is stored as bf16).
+__device__ __forceinline__ float fast_tanh(float x) {
+    const float e = __expf(2.f * x);
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
+}
+
 // MODE 0: input gates read from xg; 1: x W_ih^T computed here (HAS_X); 2: input gates gathered from two bf16 tables
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void gru_step_fwd_kernel(StepArgs a) {
@@ -287,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void gru_step_fwd_kernel(StepArgs a) {
             hn[i] = acc[mt][GH * 4 + (i >> 2)][i & 3] + bhn[i];
             // the saved hn is what backward multiplies by: round it first so that forward and backward agree
             hn[i] = bf2f(f2bf(hn[i]));
-            gn[i] = tanhf(xn[i] + gr[i] * hn[i]);
+            gn[i] = fast_tanh(xn[i] + gr[i] * hn[i]);
             o[i] = (1.f - gz[i]) * gn[i] + gz[i] * hp[i];
         }
         bf16_t* gp = a.gates + (int64_t)m * 4 * hs + cb;
@@ -366,7 +374,7 @@ __device__ __forceinline__ void step_cell(const StepArgs& a, f32x4_t (&acc)[2][(
             hn[i] = acc[mt][GH * 4 + (i >> 2)][i & 3] + bhn[i];
             // the saved hn is what backward multiplies by: round it first so that forward and backward agree
             hn[i] = bf2f(f2bf(hn[i]));
-            gn[i] = tanhf(xn[i] + gr[i] * hn[i]);
+            gn[i] = fast_tanh(xn[i] + gr[i] * hn[i]);
             o[i] = (1.f - gz[i]) * gn[i] + gz[i] * hp[i];
         }
         bf16_t* gp = a.gates + (int64_t)m * 4 * hs + cb;
@@ -399,35 +407,45 @@ __device__ __forceinline__ void step_cell(const StepArgs& a, f32x4_t (&acc)[2][(
 //     (n -> group 3); stage s+2 is issued right after the barrier that proves slot (s+2) % 3 = (s-1) % 3 free: ONE barrier per stage;
 //   * same tile, same lane -> channel map and the same cell (step_cell<1>) as gru_step_fwd_kernel<1>: bit-identical results.
 // Needs in_dim % 32 == 0 (the packed path pads the label width to 64).
-constexpr int RROW = 64, RA = TM * RROW, RST = (TM + WROWS) * RROW;          // 8 KB + 12 KB per stage
+constexpr int RROW = 64;                                                      // bytes per LDS row: 32 k
 
-__global__ __launch_bounds__(256, 2) void gru_step_fwd_ring_kernel(StepArgs a) {
+// NW waves of 32 rows each: 4 (128-row panels, two workgroups per CU) or 8 (256-row panels, one workgroup per CU: the 192 weight rows of a
+// stage serve twice the activation rows, 28 KB of LDS-DMA per stage and 256 rows instead of 2 x 20 KB -- the k loop is bound by exactly
+// that traffic).  DBG: measuring switches (GTOS_GRU_DBG): 0 production, 1 no k loop, 2 no cell.
+template <int DBG, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void gru_step_fwd_ring_kernel(StepArgs a) {
+    constexpr int TMW = 32 * NW, RAW = TMW * RROW, RSTW = (TMW + WROWS) * RROW;
     if (a.p_drop > 0.f) a.seed = live_seed(a.seed);
-    __shared__ __attribute__((aligned(16))) char sl0[RST];
-    __shared__ __attribute__((aligned(16))) char sl1[RST];
-    __shared__ __attribute__((aligned(16))) char sl2[RST];
+    __shared__ __attribute__((aligned(16))) char sl0[RSTW];
+    __shared__ __attribute__((aligned(16))) char sl1[RSTW];
+    __shared__ __attribute__((aligned(16))) char sl2[RSTW];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fr = lane & 15, fq = lane >> 4;
     const int hs = a.hs, nC = hs / TC;
     const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
-    const int m0 = ((sq / nC) * 8 + xcd) * TM, c0 = (sq % nC) * TC;
+    const int m0 = ((sq / nC) * 8 + xcd) * TMW, c0 = (sq % nC) * TC;
     if (m0 >= a.rows) return;
-    const int nkx = a.in_dim / 32, nk = a.dbg == 1 ? 0 : nkx + hs / 32;
+    const int nkx = a.in_dim / 32, nk = DBG == 1 ? 0 : nkx + hs / 32;
     // DMA: a wave instruction fills 1 KB = 16 rows x 64 B; lane l -> row l >> 2, physical chunk l & 3 (logical chunk below)
     const int drow = lane >> 2;
     const uint32_t dchunk = (uint32_t)(((lane & 3) ^ ((-(lane >> 4)) & 3)) << 4);
-    // wave w owns pieces w, w + 4 of the activation rows and w, w + 4, w + 8 of the weight rows; rows past the end re-read the last valid
-    // row (their results are never stored)
-    uint32_t axo[2], aho[2], bxo[3], bho[3];
+    // wave w owns pieces w, w + NW of the activation rows and w, w + NW, .. of the weight rows -- 3 each with four waves, 2 each with
+    // eight, where waves 4-7 (whose second piece would be 12..15: there are 12) fetch their first piece twice: every wave issues the same
+    // number of DMAs per stage, so one wait count serves all (a conditional DMA made hipcc drain vmcnt(0) in front of the fragment
+    // reads).  Rows past the end re-read the last valid row (their results are never stored).
+    constexpr int NBP = (12 + NW - 1) / NW;
+    uint32_t axo[2], aho[2], bxo[NBP], bho[NBP], bdst[NBP];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int r = min(m0 + (wave + 4 * i) * 16 + drow, a.rows - 1) - m0;
+        const int r = min(m0 + (wave + NW * i) * 16 + drow, a.rows - 1) - m0;
         axo[i] = (uint32_t)r * (uint32_t)(a.ldx * 2) + dchunk;
         aho[i] = (uint32_t)r * (uint32_t)(hs * 2) + dchunk;
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int rl = (wave + 4 * i) * 16 + drow;                             // LDS weight row -> (gate, channel) as in dma_weights
+    for (int i = 0; i < NBP; ++i) {
+        const int piece = wave + NW * i < 12 ? wave + NW * i : wave;
+        bdst[i] = (uint32_t)piece * 1024u;
+        const int rl = piece * 16 + drow;                                      // LDS weight row -> (gate, channel) as in dma_weights
         const int g = rl >> 6, nt = (rl >> 4) & 3, q = (rl >> 2) & 3, e = rl & 3;
         const int wrow = g * hs + c0 + q * 16 + nt * 4 + e;
         bxo[i] = (uint32_t)wrow * (uint32_t)(a.in_dim * 2) + dchunk;
@@ -449,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void gru_step_fwd_ring_kernel(StepArgs a) {
 #define GTOS_DMA1(src, dst)                                                                                                   \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),                                    \
                                      (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
-// this wave's five pieces of stage s_ (past the end: the last stage again, never multiplied) into `slot`
+// this wave's pieces of stage s_ (past the end: the last stage again, never multiplied) into `slot`
 #define GTOS_RING_DMA(slot, s_)                                                                                               \
     {                                                                                                                         \
         const int st_ = min((s_), nk - 1);                                                                                    \
@@ -457,22 +475,22 @@ __global__ __launch_bounds__(256, 2) void gru_step_fwd_ring_kernel(StepArgs a) {
         const char* ab_ = px_ ? Xb + st_ * 64 : Hb + (st_ - nkx) * 64;                                                        \
         const char* bb_ = px_ ? Wi + st_ * 64 : Wh + (st_ - nkx) * 64;                                                        \
         GTOS_DMA1(ab_ + (px_ ? axo[0] : aho[0]), (slot) + wave * 1024);                                                       \
-        GTOS_DMA1(ab_ + (px_ ? axo[1] : aho[1]), (slot) + (wave + 4) * 1024);                                                 \
-        GTOS_DMA1(bb_ + (px_ ? bxo[0] : bho[0]), (slot) + RA + wave * 1024);                                                  \
-        GTOS_DMA1(bb_ + (px_ ? bxo[1] : bho[1]), (slot) + RA + (wave + 4) * 1024);                                            \
-        GTOS_DMA1(bb_ + (px_ ? bxo[2] : bho[2]), (slot) + RA + (wave + 8) * 1024);                                            \
+        GTOS_DMA1(ab_ + (px_ ? axo[1] : aho[1]), (slot) + (wave + NW) * 1024);                                                \
+        GTOS_DMA1(bb_ + (px_ ? bxo[0] : bho[0]), (slot) + RAW + bdst[0]);                                                     \
+        GTOS_DMA1(bb_ + (px_ ? bxo[1] : bho[1]), (slot) + RAW + bdst[1]);                                                     \
+        if constexpr (NBP > 2) GTOS_DMA1(bb_ + (px_ ? bxo[2] : bho[2]), (slot) + RAW + bdst[2]);                              \
     }
-// one stage: own pieces of stage s_ landed (vmcnt(5): the pieces of stage s_+1 stay in flight), barrier (everybody's landed, and
+// one stage: own pieces of stage s_ landed (vmcnt(pieces per stage): those of stage s_+1 stay in flight), barrier (everybody's landed, and
 // everybody is past its reads of stage s_-1), stage s_+2 into the slot of stage s_-1, 14 fragment reads, 24 MFMAs
 #define GTOS_RING_STEP(slot_s, slot_d, s_)                                                                                    \
     {                                                                                                                         \
-        GTOS_VMCNT(5);                                                                                                        \
+        GTOS_VMCNT(2 + NBP);                                                                                                  \
         __builtin_amdgcn_s_barrier();                                                                                         \
         GTOS_RING_DMA(slot_d, (s_) + 2);                                                                                      \
         _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                                      \
             fa[mt] = *reinterpret_cast<const bf16x8_t*>((slot_s) + (wave * 32 + mt * 16) * RROW + foff);                      \
         _Pragma("unroll") for (int t = 0; t < 12; ++t)                                                                        \
-            fb[t] = *reinterpret_cast<const bf16x8_t*>((slot_s) + RA + (t * 16) * RROW + foff);                               \
+            fb[t] = *reinterpret_cast<const bf16x8_t*>((slot_s) + RAW + (t * 16) * RROW + foff);                               \
         __builtin_amdgcn_s_waitcnt(0xc07f);                /* lgkmcnt(0) */                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                                    \
         _Pragma("unroll") for (int g = 0; g < 2; ++g)                                                                         \
@@ -509,7 +527,7 @@ __global__ __launch_bounds__(256, 2) void gru_step_fwd_ring_kernel(StepArgs a) {
 #undef GTOS_RING_STEP
 #undef GTOS_RING_DMA
 #undef GTOS_DMA1
-    if (a.dbg == 2) {                                      // k loop alone: one store per lane keeps the accumulators alive
+    if constexpr (DBG == 2) {                              // k loop alone: one store per lane keeps the accumulators alive
         float t = 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -662,7 +680,7 @@ __global__ __launch_bounds__(256, 1) void gru_l1_fwd_persistent_kernel(StepArgs 
                 gr[i] = 1.f / (1.f + __expf(-(xr[i] + acc[mt][(i >> 2)][i & 3] + bhr[i])));
                 gz[i] = 1.f / (1.f + __expf(-(xz[i] + acc[mt][4 + (i >> 2)][i & 3] + bhz[i])));
                 hn[i] = bf2f(f2bf(acc[mt][8 + (i >> 2)][i & 3] + bhn[i]));   // rounded like the saved value backward uses
-                gn[i] = tanhf(xn[i] + gr[i] * hn[i]);
+                gn[i] = fast_tanh(xn[i] + gr[i] * hn[i]);
                 o[i] = (1.f - gz[i]) * gn[i] + gz[i] * hp[i];
             }
             if (m < a.rows) {
@@ -1027,7 +1045,6 @@ extern "C" int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, i
     a.ld_fin = ld_fin; a.fin_idx = fin_idx;
     a.p_drop = p_drop; a.seed = seed; a.drop_base = drop_base; a.rows = rows; a.hs = hs; a.save_hn = save_hn;
     static const int dbg = getenv("GTOS_GRU_DBG") ? atoi(getenv("GTOS_GRU_DBG")) : 0;
-    a.dbg = dbg;
     a.zeros = gtos_zero_block();
     if (!a.zeros) return -5;
     const long long nM = (rows + TM - 1) / TM, nC = hs / TC;
@@ -1049,10 +1066,22 @@ extern "C" int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, i
         GTOS_CHECK_LAUNCH();
         return 0;
     }
-    // GTOS_GRU_FWD_RING (round 5; 0 = the single-stage kernel): the three-slot ring of 32-k stages for the fused input product
+    // GTOS_GRU_FWD_RING (round 5; 0 = the single-stage kernel): the three-slot ring of 32-k stages for the fused input product;
+    // GTOS_GRU_FWD_NW = 4 / 8 waves per workgroup (128- / 256-row panels)
     static const bool use_ring = !(getenv("GTOS_GRU_FWD_RING") && getenv("GTOS_GRU_FWD_RING")[0] == '0');
+    static const int ring_nw = getenv("GTOS_GRU_FWD_NW") ? atoi(getenv("GTOS_GRU_FWD_NW")) : 8;
     if (mode == 1 && use_ring && in_dim % 32 == 0 && !h_idx && ldx < (1 << 20) && (int64_t)3 * hs * (in_dim > hs ? in_dim : hs) * 2 < (1LL << 31))
-        hipLaunchKernelGGL(gru_step_fwd_ring_kernel, dim3((unsigned)nblk), dim3(256), 0, s, a);
+    {
+        if (ring_nw == 8 && rows >= 8192) {                    // (small launches: more, smaller workgroups fill the chip better)
+            const long long nM8 = (rows + 255) / 256, nblk8 = ((nM8 + 7) / 8) * 8 * nC;
+            if (dbg == 1) hipLaunchKernelGGL((gru_step_fwd_ring_kernel<1, 8>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
+            else if (dbg == 2) hipLaunchKernelGGL((gru_step_fwd_ring_kernel<2, 8>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
+            else hipLaunchKernelGGL((gru_step_fwd_ring_kernel<0, 8>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
+        }
+        else if (dbg == 1) hipLaunchKernelGGL((gru_step_fwd_ring_kernel<1, 4>), dim3((unsigned)nblk), dim3(256), 0, s, a);
+        else if (dbg == 2) hipLaunchKernelGGL((gru_step_fwd_ring_kernel<2, 4>), dim3((unsigned)nblk), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((gru_step_fwd_ring_kernel<0, 4>), dim3((unsigned)nblk), dim3(256), 0, s, a);
+    }
     else if (mode == 1) hipLaunchKernelGGL(gru_step_fwd_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, s, a);
     else if (mode == 2) hipLaunchKernelGGL(gru_step_fwd_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(gru_step_fwd_kernel<0>, dim3((unsigned)nblk), dim3(256), 0, s, a);

@@ -217,9 +217,10 @@ class GraphedStep:
 
     Dropout: kernel arguments are frozen by the capture, so the library's kernels fold a device-side epoch into their seeds
     (ops.set_seed_epoch) which the captured step increments first thing; torch's own generator is graph-safe by itself.
-    Limits: one process (world_size 1: the gradient collectives' host-side bookkeeping is not captured); the RelationEncoder's
-    trie evaluation (``mask_sharing="node"`` or no dropout) -- the per-(path, position) evaluation sizes its packed sequence with a
-    host read; a batch with its relation tensors already built (device builders run before, not inside, the capture).
+    Limits: one process (world_size 1: the gradient collectives' host-side bookkeeping is not captured); a batch that carries its path
+    trie (``batch['relation_trie']``: the RelationEncoder then takes the sort order and the step sizes from it -- since round 5 also with
+    the reference's dropout semantics, whose packed sequence used to be sized by a host read; a bare bank still costs that read and cannot
+    be captured) and its relation tensors already built (device builders run before, not inside, the capture).
     Robustness (ROCm 7.2, torch 2.10): C1 captures and replays correctly (equal to the eager steps at dropout 0).
     At C2, where the auxiliary stream is forked in three places, ``hipStreamEndCapture`` crashed inside the runtime, and with every
     use of that stream switched off a replay hung; with one use it worked and bought nothing (the step is not launch-bound).  Use it

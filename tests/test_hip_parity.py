@@ -2039,7 +2039,7 @@ import sys, torch
 from gtos_amd import gru, ops
 torch.manual_seed(7)
 dev = torch.device("cuda:0")
-R, L, hs, ind = 1203, 5, 256, int(sys.argv[2])
+R, L, hs, ind = 20011, 5, 256, int(sys.argv[2])
 lengths = torch.randint(1, L + 1, (R,)); lengths[0] = L
 sl, _ = torch.sort(lengths, descending=True, stable=True)
 bs = [int((sl > t).sum()) for t in range(L)]
@@ -2058,17 +2058,18 @@ torch.save(out.cpu(), sys.argv[1])
 
 @pytest.mark.parametrize("ind", [128, 512])
 def test_gru_forward_ring_kernel_bit_identical_to_single_stage(ind, tmp_path):
-    """gru_step_fwd_ring_kernel (round 5: three-slot ring of 32-k stages, explicit waits) against gru_step_fwd_kernel<1> (one 64-k stage):
-    same tile, same k order, same cell -> the SAME bits, through two GRU layers with inter-layer dropout, ragged lengths, a partial last
-    row panel.  The switch is read once per process: two child processes."""
+    """gru_step_fwd_ring_kernel (round 5: three-slot ring of 32-k stages, explicit waits; 256-row panels on eight waves -- launches of at
+    least 8192 rows -- and 128-row panels on four) against gru_step_fwd_kernel<1> (one 64-k stage): same lane -> channel map, same k
+    order, same cell -> the SAME bits, through two GRU layers with inter-layer dropout, ragged lengths (steps of 20,011 .. ~4,000 rows:
+    both panel sizes run), a partial last row panel.  The switches are read once per process: three child processes."""
     import subprocess
     import sys
     outs = []
-    for ring in ("1", "0"):
-        f = str(tmp_path / ("ring%s.pt" % ring))
-        env = dict(os.environ, GTOS_GRU_FWD_RING=ring, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    for ring, nw in (("1", "8"), ("1", "4"), ("0", "4")):
+        f = str(tmp_path / ("ring%s_%s.pt" % (ring, nw)))
+        env = dict(os.environ, GTOS_GRU_FWD_RING=ring, GTOS_GRU_FWD_NW=nw, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         r = subprocess.run([sys.executable, "-c", _RING_CHILD, f, str(ind)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
         assert r.returncode == 0, r.stdout.decode(errors="replace")[-3000:]
         outs.append(torch.load(f))
     assert torch.isfinite(outs[0].float()).all() and float(outs[0].float().abs().max()) > 0.05
-    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])

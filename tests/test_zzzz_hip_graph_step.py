@@ -51,14 +51,29 @@ def test_seed_epoch_changes_the_masks_and_keeps_forward_and_backward_consistent(
         ops.set_seed_epoch(torch.zeros((), dtype=torch.int32, device=dev()))
 
 
-# The capture tests are opt-in (GTOS_TEST_HIPGRAPH=1).  On this stack (ROCm 7.2, torch 2.10) stream capture of the step is not robust: C1
-# (a single stream at that size) captures and replays correctly, C2 with the auxiliary stream forked three ways segfaults inside
-# hipStreamEndCapture and one single-stream C2 variant hung at replay -- a hung GPU would take the rest
-# of a `-m gpu` run with it.  The seed-epoch test above involves no capture and always runs.
-graphs = pytest.mark.skipif(os.environ.get("GTOS_TEST_HIPGRAPH") != "1", reason="hipGraph capture tests are opt-in: GTOS_TEST_HIPGRAPH=1")
+# The capture tests run by default since round 5 (C1, the library's default RelationEncoder semantics, ONE stream: the configuration that
+# has captured and replayed correctly in every run of rounds 4 and 5), each in a CHILD process with a hard timeout: on this stack (ROCm
+# 7.2, torch 2.10) the capture of the multi-stream C2 step segfaulted inside hipStreamEndCapture and one single-stream C2 variant hung at
+# replay, and a wedged process must cost its own test, not the rest of the `-m gpu` run.  GTOS_TEST_HIPGRAPH=0 skips
+# them; inside the child GTOS_TEST_HIPGRAPH=child runs the body.
+_MODE = os.environ.get("GTOS_TEST_HIPGRAPH", "1")
+graphs = pytest.mark.skipif(_MODE == "0", reason="hipGraph capture tests switched off: GTOS_TEST_HIPGRAPH=0")
 
 
-def _trainer(dropout, seed=0):
+def _in_child(name):
+    """Parent: run test ``name`` of this file in a child process (timeout 240 s) and assert it passed; returns True.  Child: returns False."""
+    if _MODE == "child":
+        return False
+    import subprocess
+    import sys
+    env = dict(os.environ, GTOS_TEST_HIPGRAPH="child")
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__ + "::" + name, "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")[-3000:]
+    return True
+
+
+def _trainer(dropout, seed=0, masks="path"):
     from gtos_amd import ops, synth
     from gtos_amd.config import build_generator
     from gtos_amd.encoder import set_relation_mask_sharing
@@ -68,8 +83,8 @@ def _trainer(dropout, seed=0):
     from gtos_amd.train import Trainer
     m = build_generator(Generator, "C1", dev(), dropout=dropout).to(dev())
     m.set_compute_dtype(torch.bfloat16)
-    set_relation_mask_sharing(m, "node")
-    m.train()
+    set_relation_mask_sharing(m, masks)          # "path" = the library default (the reference's dropout semantics): since round 5 its
+    m.train()                                    # RelationEncoder has no host read (the batch's trie carries the sort order and step sizes)
     batch, _ = synth.make_config_batch("C1", rank=0, B=8)
     attach_relation_index(attach_path_trie(batch))
     batch = {k: (v.to(dev()) if hasattr(v, "to") else v) for k, v in batch.items()}
@@ -81,6 +96,8 @@ def _trainer(dropout, seed=0):
 @graphs
 def test_graphed_step_without_dropout_trains_like_the_eager_step():
     """dropout 0: 3 warm-up steps + 5 replays == 8 eager steps, loss by loss (same kernels, same order, same batch)."""
+    if _in_child("test_graphed_step_without_dropout_trains_like_the_eager_step"):
+        return
     from gtos_amd.train import GraphedStep
     tr_e, batch = _trainer(0.0)
     eager = [tr_e.step(batch) for _ in range(8)]
@@ -98,6 +115,8 @@ def test_graphed_step_without_dropout_trains_like_the_eager_step():
 
 @graphs
 def test_graphed_step_draws_new_dropout_masks_in_every_replay():
+    if _in_child("test_graphed_step_draws_new_dropout_masks_in_every_replay"):
+        return
     from gtos_amd.train import GraphedStep
     tr, batch = _trainer(0.2)
     gs = GraphedStep(tr, batch, warmup=3)
