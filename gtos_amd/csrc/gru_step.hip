@@ -482,16 +482,28 @@ __global__ __launch_bounds__(64 * NW, 2) void gru_step_fwd_ring_kernel(StepArgs 
     }
 // one stage: own pieces of stage s_ landed (vmcnt(pieces per stage): those of stage s_+1 stay in flight), barrier (everybody's landed, and
 // everybody is past its reads of stage s_-1), stage s_+2 into the slot of stage s_-1, 14 fragment reads, 24 MFMAs
+// Eight waves (two per SIMD) run it as a PING-PONG like gemm256p_nt_kernel: a step is a LOAD segment (DMA issue, the 14 fragment reads --
+// 14 KB per wave out of LDS --, the wait for the wave's own pieces of stage s_+1) and a COMPUTE segment (24 MFMAs), each closed by a
+// barrier, and waves 4-7 run one segment behind waves 0-3: on every SIMD one wave reads LDS while its partner multiplies.  With all
+// waves in the same phase (the four-wave form, or eight in lock step) a stage costs LDS time PLUS matrix time: 112 KB of fragment reads
+// and 2 x 408 cycles of MFMA per SIMD measured ~1900 cycles per stage, the k loop alone 581 us per 434 k-row launch whatever the DMA volume.
 #define GTOS_RING_STEP(slot_s, slot_d, s_)                                                                                    \
     {                                                                                                                         \
-        GTOS_VMCNT(2 + NBP);                                                                                                  \
-        __builtin_amdgcn_s_barrier();                                                                                         \
+        if constexpr (NW == 4) {                                                                                              \
+            GTOS_VMCNT(2 + NBP);                                                                                              \
+            __builtin_amdgcn_s_barrier();                                                                                     \
+        }                                                                                                                     \
         GTOS_RING_DMA(slot_d, (s_) + 2);                                                                                      \
         _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                                      \
             fa[mt] = *reinterpret_cast<const bf16x8_t*>((slot_s) + (wave * 32 + mt * 16) * RROW + foff);                      \
         _Pragma("unroll") for (int t = 0; t < 12; ++t)                                                                        \
             fb[t] = *reinterpret_cast<const bf16x8_t*>((slot_s) + RAW + (t * 16) * RROW + foff);                               \
-        __builtin_amdgcn_s_waitcnt(0xc07f);                /* lgkmcnt(0) */                                                   \
+        if constexpr (NW == 4) {                                                                                              \
+            __builtin_amdgcn_s_waitcnt(0xc07f);            /* lgkmcnt(0) */                                                   \
+        } else {                                           /* fragments here AND own pieces of stage s_+1 landed, then everybody's */ \
+            __builtin_amdgcn_s_waitcnt(0x0070 | ((2 + NBP) & 15));                                                            \
+            __builtin_amdgcn_s_barrier();                                                                                     \
+        }                                                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                                    \
         _Pragma("unroll") for (int g = 0; g < 2; ++g)                                                                         \
             _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                                  \
@@ -507,11 +519,17 @@ __global__ __launch_bounds__(64 * NW, 2) void gru_step_fwd_ring_kernel(StepArgs 
                     acc[mt][12 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[8 + nt], fa[mt], acc[mt][12 + nt], 0, 0, 0); \
         }                                                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                                    \
+        if constexpr (NW == 8) __builtin_amdgcn_s_barrier();                                                                  \
     }
 
     if (nk > 0) {
         GTOS_RING_DMA(sl0, 0);
         GTOS_RING_DMA(sl1, 1);
+        if constexpr (NW == 8) {
+            GTOS_VMCNT(2 + NBP);                           // own pieces of stage 0
+            __builtin_amdgcn_s_barrier();                  // everybody's
+            if (wave >= 4) __builtin_amdgcn_s_barrier();   // the second wave of every SIMD starts one segment late
+        }
     }
     int s = 0;
     for (; s + 3 <= nk; s += 3) {                          // whole triples: one path through the body for the wait-count pass
@@ -523,6 +541,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gru_step_fwd_ring_kernel(StepArgs 
         GTOS_RING_STEP(sl0, sl2, s);
         if (s + 1 < nk) GTOS_RING_STEP(sl1, sl0, s + 1);
     }
+    if constexpr (NW == 8) { if (nk > 0 && wave < 4) __builtin_amdgcn_s_barrier(); }     // same number of barriers for both halves
     GTOS_VMCNT(0);                                         // the dummy prefetches of the last two stages
 #undef GTOS_RING_STEP
 #undef GTOS_RING_DMA

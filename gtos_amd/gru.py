@@ -441,13 +441,18 @@ class PackedPathGRUFn(torch.autograd.Function):
         used_side, held = False, None
         dY = None                                     # d(loss) / d(layer 0 output, after its dropout), [N, 2hs]
         dX = None
+        saved = [list(e) for e in saved]              # (released piece by piece below: at C5 a direction's gates alone are 22 GB)
+        ctx.cfg = None
         for l in (1, 0):
             inp, seed, pl, layer_saved = saved[l]
+            saved[l] = None
+            layer_saved = list(layer_saved)
             n_in = inp.shape[1]
             want_dinp = l == 1 or want_table
             d_in = torch.empty((N, n_in), dtype=dtp, device=dev) if want_dinp else None
             for direction in (0, 1):
                 wi_t, wh_t, gates, hprev = layer_saved[direction]
+                layer_saved[direction] = None
                 base = l * 8 + direction * 4
                 w_ih, w_hh, b_ih, b_hh = weights[base:base + 4]
                 want_bias = b_ih.requires_grad or b_hh.requires_grad
@@ -478,6 +483,7 @@ class PackedPathGRUFn(torch.autograd.Function):
                         d_in += gemm(d4[:, :3 * hs], wi_t, trans_b=True, p_drop=pe, seed=seed_e)
                     else:
                         gemm(d4[:, :3 * hs], wi_t, trans_b=True, out=d_in, accumulate=True)
+                del gates                              # the steps were their last reader
                 # Parameter gradients over all steps at once, on the auxiliary stream beside the NEXT direction's steps.  No record_stream:
                 # a block freed on one stream while another still reads it can only be recycled once the device has passed the free, and
                 # with no host read left in a step the host runs steps ahead of the device -- every such block (5 GB of d4 per direction at
@@ -514,10 +520,12 @@ class PackedPathGRUFn(torch.autograd.Function):
                     if want_bias:
                         _acc_bias_grads(grads, base, b_ih, b_hh, bpart.sum(0), hs)
                 used_side = used_side or side is not main
+                del d4, hprev, bpart                   # (``held`` keeps what the auxiliary stream still reads)
+            del inp
             if l == 1:
                 dY = d_in
             else:
-                dX = d_in
+                dX, dY = d_in, None
         dtab = None
         if want_table:
             tgt = _grad_target(table)

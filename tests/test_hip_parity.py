@@ -779,9 +779,17 @@ def _oracle_slice(cfg_name, B):
 # (the fp32 run of the same code agrees with the oracle to 4e-4).
 # Measured in round 4 (fp32 residual stream; profiles/r4c_bf16_grad_table.tsv): global 2.67e-2 / 1.87e-2 / 2.04e-2 and worst tensor
 # 0.169 / 0.227 / 0.184 (a relation_in_proj.weight each time, or the character embedding) on C2 B=3 / C5 B=1 / C3 B=3: the bars
-# keep 1.5x / 1.3x of headroom over the largest value.
+# keep 1.5x / 1.1x of headroom over the largest value.
+# Round 5, by tensor size (the same table): the tensors at 0.17-0.23 have gradient norms of 1e-5 .. 3e-5 against 0.5-1.3 for the largest
+# ones -- five orders below what moves the model -- and the largest tensors are where they should be: decoder projections 0.5-0.7 %,
+# concept_encoder.out_proj 2.6-3.8 %, the graph layers' fc1.weight (norm 0.15) 7.6 % at worst.  Hence two tiers: every tensor that
+# carries at least 5 % of the largest tensor's norm within BF16_GRAD_REL_MAJOR = 0.1 (VERDICT round 4's figure; measured 0.076), the
+# small ones (down to 1e-4 of the largest norm) within BF16_GRAD_REL = 0.25 (measured 0.227).  What the small tensors' error is NOT: a
+# storage choice that fp32 rows would fix -- the fc1 / character-CNN tensors at 8-18 % go through no bank-gradient row at all; the bf16
+# FUNCTION (activations rounded layer by layer, attention patterns shifted by 1e-3) has a different gradient than the fp32 one there.
 BF16_GRAD_GLOBAL = 4e-2
-BF16_GRAD_REL = 0.3
+BF16_GRAD_REL = 0.25
+BF16_GRAD_REL_MAJOR = 0.1
 
 
 def _product_on(cfg_name, sd, dtype):
@@ -831,8 +839,13 @@ def _check_slice(cfg_name, B, dtype):
                 fo.write("%s B=%d\tGLOBAL\t%.4g\t%.4g\n" % (cfg_name, B, glob, den ** 0.5))
         assert glob < BF16_GRAD_GLOBAL, glob
         gmax = max(nrm for _, _, nrm in table)
+        major = [(k, e, nrm) for k, e, nrm in table if nrm >= 0.05 * gmax]
+        print("largest tensors (norm >= 5 %% of the largest, %d of them): worst %s" % (
+            len(major), ", ".join("%s %.3g" % (k, e) for k, e, _ in sorted(major, key=lambda r: -r[1])[:3])))
         for k, e, nrm in table:
-            if nrm > 1e-4 * gmax:                     # gradients that are numerically zero carry no relative information
+            if nrm >= 0.05 * gmax:
+                assert e < BF16_GRAD_REL_MAJOR, (k, e, nrm)
+            elif nrm > 1e-4 * gmax:                   # gradients that are numerically zero carry no relative information
                 assert e < BF16_GRAD_REL, (k, e, nrm)
 
 
