@@ -855,8 +855,9 @@ def main():
                                            "--relation-masks node; the library default draws them per (path, position) like the reference: "
                                            "see reference_masks)" if (gru_mod.TRIE and a.relation_masks == "node") else
                                            "the reference's dropout semantics (the library default): masks per (path, position), one GRU row "
-                                           "each; the trie-shared masks of rounds 2-3 (an opt-in, a different regulariser) are measured "
-                                           "in the same run: see node_masks"),
+                                           "each, on the packed-path kernels (gtos_amd.gru.PackedPathGRUFn: no host read, input gradients inside "
+                                           "the backward step launches, grouped weight gradients); the trie-shared masks of rounds 2-3 (an opt-in, "
+                                           "a different regulariser) are measured in the same run: see node_masks"),
                           "allreduce_exposed_ms_per_step": round(1e3 * max(r[1] for r in per_rank) / a.steps, 3),
                           "per_rank_ms_per_step": [round(1e3 * r[0] / a.steps, 3) for r in per_rank],
                           "per_rank_allreduce_exposed_ms_per_step": [round(1e3 * r[1] / a.steps, 3) for r in per_rank],

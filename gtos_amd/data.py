@@ -55,8 +55,9 @@ def complete_on_device(batch, device=None, tries="hip"):
         return batch
     train = batch['relation_graphs'].path_mode != relbatch.PATH_ALL
     attach_device_relations(batch, device)
-    if not batch['relation'].is_cuda:      # completed by the host builder (the consumer is not a GPU): reference-shaped, nothing device-side to add
-        return batch
+    from .relbatch_hip import HipBackend
+    if not batch['relation'].is_cuda and getattr(HipBackend.shared(), "needs_device", False):
+        return batch                       # completed by the host builder (the consumer is not a GPU): reference-shaped, nothing device-side to add
     if train:
         attach_device_relation_index(batch)
     return attach_device_tries(batch, tries)
@@ -132,17 +133,19 @@ def attach_device_relations(batch, device=None):
     if rg is None or 'relation' in batch:
         return batch
     dev = batch['concept'].device if device is None else torch.device(device)
-    if dev.type != "cuda":
+    from .relbatch_hip import HipBackend, build_relation_batch_all_staged, build_relation_batch_staged
+    if dev.type != "cuda" and getattr(HipBackend.shared(), "needs_device", False):
         # the HIP stage kernels take device pointers: a consumer on the host gets the C++ host builder's tensors (the same arrays, element
-        # for element: tests/test_zzz_hip_relbatch.py) -- complete, reference-shaped, with the host-side index preparation
+        # for element: tests/test_zzz_hip_relbatch.py) -- complete, reference-shaped.  (The tests' emulation backends run the stage code
+        # on host memory and do not set ``needs_device``.)
         if rg.graphs is None:
             raise ValueError("a batch that ships 'relation_graphs' can only be completed on a GPU (or needs RelationGraphs.graphs for the host builder)")
         full = relbatch.build_relation_batch(rg.graphs, rg.special_ids, path_mode=rg.path_mode, seed=rg.seed, max_len=rg.max_len)
         for k in ('relation', 'relation_bank', 'relation_length'):
             batch[k] = full[k].to(dev)
+        batch['relation_rows'] = HostInt(int(full['relation_length'].sum()))
         del batch['relation_graphs']
         return batch
-    from .relbatch_hip import HipBackend, build_relation_batch_all_staged, build_relation_batch_staged
     if rg.path_mode == relbatch.PATH_ALL:        # an eval batch: every shortest path, relation [n,n,B,K]
         rel = build_relation_batch_all_staged(None, rg.special_ids, HipBackend.shared(), max_len=rg.max_len, device=dev, csr=rg.csr)
     else:

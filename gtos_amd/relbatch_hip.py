@@ -71,6 +71,7 @@ def graphs_csr(graphs):
 class HipBackend(object):
     """gtos_relbatch_dev_phase_a / _b of libgtos_hip.so on the current stream."""
     _shared = None
+    needs_device = True            # its buffers must live on the GPU (data.attach_device_relations falls back to the host builder otherwise)
 
     def __init__(self):
         from ._lib import load, stream

@@ -268,3 +268,29 @@ def test_flattened_graphs_refuse_invalid_node_counts_before_writing():
         graphs_csr([])
     c = graphs_csr([good, (1, 0, np.zeros((0, 3), np.int32))])          # a single node: no adjacency at all
     assert c["S"] == 4 and c["P"] == 10 and c["adj_base"].tolist() == [0, 4, 4]
+
+
+def test_device_all_batch_completed_on_the_host_when_the_consumer_is_not_a_gpu():
+    """the loaders' index_prep="auto" resolves to "device_all" wherever a GPU is visible, so a CPU / fp32 parity model fed
+    from such a loader meets a batch that carries ``relation_graphs`` instead of relation / bank / length.  complete_on_device() on a
+    non-GPU target must not hand host pointers to the HIP stage kernels: it falls back to the C++ host builder (the real HipBackend says
+    ``needs_device``; no emulation here) and yields the reference-shaped batch the host loader ships."""
+    import random
+    from gtos_amd import data, relbatch_hip
+    assert relbatch_hip.HipBackend.needs_device
+    vocabs = synth.synth_vocabs()
+    items, graphs = synth.make_amr_items("C1", 16, first_graph=0, vocabs=vocabs)
+    unit = data.AMRLoader.size_of(items[0])
+
+    def loader(prep):
+        return data.AMRLoader(vocabs, items, batch_size=8 * unit - unit // 2, for_train=True, rng=random.Random(5), n_threads=1, graphs=graphs,
+                              index_prep=prep)
+    host_ld, dev_ld = loader(True), loader("device_all")
+    for jh, jd in zip(list(host_ld.jobs())[:2], list(dev_ld.jobs())[:2]):
+        want, got = host_ld.run_job(jh), dev_ld.run_job(jd)
+        assert 'relation_graphs' in got and 'relation' not in got
+        got = data.complete_on_device(got, torch.device("cpu"))
+        assert 'relation_graphs' not in got
+        for k in ("relation", "relation_bank", "relation_length", "concept", "token_in"):
+            assert torch.equal(want[k], got[k]) and not got[k].is_cuda, k
+        assert int(got['relation_rows']) == int(want['relation_length'].sum())
