@@ -2086,3 +2086,34 @@ def test_gru_forward_ring_kernel_bit_identical_to_single_stage(ind, tmp_path):
         outs.append(torch.load(f))
     assert torch.isfinite(outs[0].float()).all() and float(outs[0].float().abs().max()) > 0.05
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_packed_path_gru_two_stream_forward_is_the_same_function(monkeypatch):
+    """GTOS_GRU_FWD_OVERLAP=1 (opt-in, measured: no gain): the packed path's forward with direction 1 on the auxiliary stream beside
+    direction 0 -- every buffer allocated on the main stream, the auxiliary stream joined before the next layer -- gives bit-identical
+    outputs and gradients (same kernels, same operands, another interleaving)."""
+    from gtos_amd import encoder, gru, ops
+    g = torch.Generator().manual_seed(9)
+    length = torch.randint(1, 9, (3000,), generator=g)
+    bank = torch.randint(1, 90, (8, 3000), generator=g)
+    for r in range(3000):
+        bank[int(length[r]):, r] = 0
+    ref, m = _relenc_pair(bank, length, hid=64)
+    m.compute_dtype = torch.bfloat16
+    m.dropout = 0.25
+    m.train()
+    wout = torch.randn(bank.shape[1], 64, generator=torch.Generator().manual_seed(1)).to(dev())
+    monkeypatch.setattr(gru, "SIDE_MIN_ROWS", 0)            # (small bank: let the stream logic engage)
+    res = []
+    for overlap in (False, True):
+        monkeypatch.setattr(gru, "FWD_OVERLAP", overlap)
+        ops.set_seed(77)
+        m.zero_grad()
+        out = m(bank.to(dev()), length.to(dev()))
+        (out.float() * wout).sum().backward()
+        ops.join_side()
+        torch.cuda.synchronize()
+        res.append((out.detach().clone(), _grads_of(m)))
+    assert torch.equal(res[0][0], res[1][0])
+    for k in res[0][1]:
+        torch.testing.assert_close(res[0][1][k], res[1][1][k], rtol=1e-5, atol=1e-6, msg=lambda s_, k=k: "%s: %s" % (k, s_))
