@@ -735,7 +735,8 @@ def main():
     # each on a NEW batch from the default loader route (relation section on the device, ONE worker process per GPU).  The headline
     # above is the pre-built batch SURVEY 8d prescribes; this leg says what feeding costs on top of it.
     loader_leg = None
-    if not a.fresh_batches and not a.no_loader_leg and cd == torch.bfloat16 and not a.dense and all_legs:
+    # (round 5: this leg runs at every N -- one loader worker process per rank, N of them on the host -- the other secondary legs at N = 1)
+    if not a.fresh_batches and not a.no_loader_leg and cd == torch.bfloat16 and not a.dense:
         try:
             # the cache is full of blocks cut for ONE batch's sizes; the loader's batches all differ by a percent.  At C2 that costs
             # nothing, at C5 (95 GB allocated, 230+ GB cached) the first varying-size steps overflow the device and every step pays a
