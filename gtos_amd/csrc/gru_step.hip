@@ -396,22 +396,27 @@ __device__ __forceinline__ void step_cell(const StepArgs& a, f32x4_t (&acc)[2][(
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Round 5: the fused forward step (MODE 1: input product inside) with a THREE-slot ring of 32-k stages instead of one 64-k stage.
-// gru_step_fwd_kernel<1> walks load -> barrier -> MFMA -> barrier per k tile with nothing in flight while it multiplies: at 250
-// registers two workgroups share a CU, so at most one other wave per SIMD covers a round trip to L2 / HBM, and the per-(path, position)
-// evaluation of the reference's dropout semantics spends 18 ms per C2 step in it at a quarter of either roofline.
-// Here a wave keeps its pieces of TWO stages in flight while it multiplies a third:
-//   * stage = 128 activation rows + 192 weight rows x 32 k = 20 KB in 64-byte rows (chunk c of row r at c ^ ((-(r >> 2)) & 3), as
-//     gemm256p_nt_kernel), 20 LDS-DMA pieces = 5 per wave; three slots in SEPARATE static arrays (hipcc's wait-count pass tracks
-//     LDS-DMA per LDS object); the waits are explicit (vmcnt(5): the newest stage stays in flight);
+// gru_step_fwd_kernel<1> walks load -> barrier -> MFMA -> barrier per k tile with nothing in flight while it multiplies; the
+// per-(path, position) evaluation of the reference's dropout semantics spent 18 ms per C2 step in it at a quarter of either roofline
+// (VERDICT round 4).  Here a wave keeps its pieces of TWO stages in flight while it multiplies a third:
+//   * stage = TMW activation rows + 192 weight rows x 32 k in 64-byte rows (chunk c of row r at c ^ ((-(r >> 2)) & 3), as
+//     gemm256p_nt_kernel): 20 KB = 20 LDS-DMA pieces for a 128-row panel (5 per wave), 28 KB for a 256-row panel (4 per wave, see
+//     below); three slots in SEPARATE static arrays (hipcc's wait-count pass tracks LDS-DMA per LDS object); the waits are explicit
+//     (vmcnt(pieces per stage): the newest stage stays in flight);
 //   * the k axis is [x | h]: stages 0 .. in_dim/32 read x rows and W_ih (n -> accumulator group 2), the rest h_in rows and W_hh
-//     (n -> group 3); stage s+2 is issued right after the barrier that proves slot (s+2) % 3 = (s-1) % 3 free: ONE barrier per stage;
-//   * same tile, same lane -> channel map and the same cell (step_cell<1>) as gru_step_fwd_kernel<1>: bit-identical results.
+//     (n -> group 3); stage s+2 goes into the slot of stage s-1, which every wave has finished reading by then;
+//   * same lane -> channel map, same k order and the same cell (step_cell<1>) as gru_step_fwd_kernel<1>: bit-identical results
+//     (tests/test_hip_parity.py::test_gru_forward_ring_kernel_bit_identical_to_single_stage, all three kernels).
 // Needs in_dim % 32 == 0 (the packed path pads the label width to 64).
+// MEASURED (profiles/r5_ab_switches.txt; 434,624 rows per launch): the ring alone changed nothing (883 vs 895 us for layer 1), nor did 30 %
+// less LDS-DMA per row (256-row panels: k loop alone 581 vs 595 us) or the ping-pong below (558 vs 581 us); the launch is the SUM of its k
+// loop alone (324-356 / 558-595 us for layer 0 / 1) and its cell alone (461 / 381 us), see DESIGN.md section 5.  Kept because the pieces
+// are each slightly ahead in the step (forward 19.5 -> 18.6 ms together with the cheap tanh) and because the switches say where the time is.
 constexpr int RROW = 64;                                                      // bytes per LDS row: 32 k
 
-// NW waves of 32 rows each: 4 (128-row panels, two workgroups per CU) or 8 (256-row panels, one workgroup per CU: the 192 weight rows of a
-// stage serve twice the activation rows, 28 KB of LDS-DMA per stage and 256 rows instead of 2 x 20 KB -- the k loop is bound by exactly
-// that traffic).  DBG: measuring switches (GTOS_GRU_DBG): 0 production, 1 no k loop, 2 no cell.
+// NW waves of 32 rows each: 4 (128-row panels, two workgroups per CU, one barrier per stage) or 8 (256-row panels, one workgroup per CU,
+// ping-pong: the 192 weight rows of a stage serve twice the activation rows).  DBG: measuring switches (GTOS_GRU_DBG) as separate
+// instantiations: 0 production, 1 no k loop, 2 no cell.
 template <int DBG, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void gru_step_fwd_ring_kernel(StepArgs a) {
     constexpr int TMW = 32 * NW, RAW = TMW * RROW, RSTW = (TMW + WROWS) * RROW;
