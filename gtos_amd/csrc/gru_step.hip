@@ -43,6 +43,7 @@ struct StepArgs {
     float p_drop; uint64_t seed; int64_t drop_base;
     int rows, hs; const void* zeros;
     int save_hn;                                   // 0: the hn block of `gates` is not written (backward recomputes it: StepBwdArgs.w_hn)
+    int dbg_delay;                                 // measuring switches 5 / 6 of the ring kernel: start delay of some first-generation workgroups, 10 ns ticks
 };
 
 // 128 activation rows x 64 k
@@ -416,7 +417,8 @@ constexpr int RROW = 64;                                                      //
 
 // NW waves of 32 rows each: 4 (128-row panels, two workgroups per CU, one barrier per stage) or 8 (256-row panels, one workgroup per CU,
 // ping-pong: the 192 weight rows of a stage serve twice the activation rows).  DBG: measuring switches (GTOS_GRU_DBG) as separate
-// instantiations: 0 production, 1 no k loop, 2 no cell.
+// instantiations: 0 production, 1 no k loop, 2 no cell; eight waves only: 3 = the k loop's DMA alone (no fragment reads, no MFMAs),
+// 4 = its fragment reads and MFMAs alone (no DMA: the slots hold whatever they hold).
 template <int DBG, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void gru_step_fwd_ring_kernel(StepArgs a) {
     constexpr int TMW = 32 * NW, RAW = TMW * RROW, RSTW = (TMW + WROWS) * RROW;
@@ -430,6 +432,13 @@ __global__ __launch_bounds__(64 * NW, 2) void gru_step_fwd_ring_kernel(StepArgs 
     const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
     const int m0 = ((sq / nC) * 8 + xcd) * TMW, c0 = (sq % nC) * TC;
     if (m0 >= a.rows) return;
+    if constexpr (DBG == 5 || DBG == 6) {                  // phase offset between the workgroups that share a CU (two per CU with four waves)
+        const bool late = DBG == 5 ? (blockIdx.x >= 256 && blockIdx.x < 512) : (blockIdx.x < 512 && ((blockIdx.x >> 3) & 1));
+        if (late) {
+            const uint64_t t0 = wall_clock64();
+            while (wall_clock64() - t0 < (uint64_t)a.dbg_delay) __builtin_amdgcn_s_sleep(64);
+        }
+    }
     const int nkx = a.in_dim / 32, nk = DBG == 1 ? 0 : nkx + hs / 32;
     // DMA: a wave instruction fills 1 KB = 16 rows x 64 B; lane l -> row l >> 2, physical chunk l & 3 (logical chunk below)
     const int drow = lane >> 2;
@@ -474,7 +483,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gru_step_fwd_ring_kernel(StepArgs 
                                      (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
 // this wave's pieces of stage s_ (past the end: the last stage again, never multiplied) into `slot`
 #define GTOS_RING_DMA(slot, s_)                                                                                               \
-    {                                                                                                                         \
+    if constexpr (DBG != 4) {                                                                                                 \
         const int st_ = min((s_), nk - 1);                                                                                    \
         const bool px_ = st_ < nkx;                                                                                           \
         const char* ab_ = px_ ? Xb + st_ * 64 : Hb + (st_ - nkx) * 64;                                                        \
@@ -499,10 +508,12 @@ __global__ __launch_bounds__(64 * NW, 2) void gru_step_fwd_ring_kernel(StepArgs 
             __builtin_amdgcn_s_barrier();                                                                                     \
         }                                                                                                                     \
         GTOS_RING_DMA(slot_d, (s_) + 2);                                                                                      \
-        _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                                      \
-            fa[mt] = *reinterpret_cast<const bf16x8_t*>((slot_s) + (wave * 32 + mt * 16) * RROW + foff);                      \
-        _Pragma("unroll") for (int t = 0; t < 12; ++t)                                                                        \
-            fb[t] = *reinterpret_cast<const bf16x8_t*>((slot_s) + RAW + (t * 16) * RROW + foff);                               \
+        if constexpr (DBG != 3) {                                                                                             \
+            _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                                  \
+                fa[mt] = *reinterpret_cast<const bf16x8_t*>((slot_s) + (wave * 32 + mt * 16) * RROW + foff);                  \
+            _Pragma("unroll") for (int t = 0; t < 12; ++t)                                                                    \
+                fb[t] = *reinterpret_cast<const bf16x8_t*>((slot_s) + RAW + (t * 16) * RROW + foff);                           \
+        }                                                                                                                     \
         if constexpr (NW == 4) {                                                                                              \
             __builtin_amdgcn_s_waitcnt(0xc07f);            /* lgkmcnt(0) */                                                   \
         } else {                                           /* fragments here AND own pieces of stage s_+1 landed, then everybody's */ \
@@ -510,11 +521,13 @@ __global__ __launch_bounds__(64 * NW, 2) void gru_step_fwd_ring_kernel(StepArgs 
             __builtin_amdgcn_s_barrier();                                                                                     \
         }                                                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                                    \
+        if constexpr (DBG != 3)                                                                                               \
         _Pragma("unroll") for (int g = 0; g < 2; ++g)                                                                         \
             _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                                  \
                 _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                              \
                     acc[mt][g * 4 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[g * 4 + nt], fa[mt], acc[mt][g * 4 + nt], 0, 0, 0); \
-        if ((s_) < nkx) {                                                                                                     \
+        if constexpr (DBG == 3) {                                                                                             \
+        } else if ((s_) < nkx) {                                                                                              \
             _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                                  \
                 _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                              \
                     acc[mt][8 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[8 + nt], fa[mt], acc[mt][8 + nt], 0, 0, 0);  \
@@ -551,7 +564,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gru_step_fwd_ring_kernel(StepArgs 
 #undef GTOS_RING_STEP
 #undef GTOS_RING_DMA
 #undef GTOS_DMA1
-    if constexpr (DBG == 2) {                              // k loop alone: one store per lane keeps the accumulators alive
+    if constexpr (DBG >= 2 && DBG <= 4) {                  // k loop alone (3: its DMA only, 4: its LDS reads + MFMAs only): one store per lane keeps the accumulators alive
         float t = 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -1067,8 +1080,14 @@ extern "C" int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, i
     a.h_in = (const bf16_t*)h_in; a.h_idx = h_idx; a.w_hh = (const bf16_t*)w_hh; a.b_hh = b_hh;
     a.h_out = (bf16_t*)h_out; a.n_out = n_out; a.h_fin = (bf16_t*)h_fin; a.gates = (bf16_t*)gates; a.y = (bf16_t*)y; a.ldy = ldy;
     a.ld_fin = ld_fin; a.fin_idx = fin_idx;
-    a.p_drop = p_drop; a.seed = seed; a.drop_base = drop_base; a.rows = rows; a.hs = hs; a.save_hn = save_hn;
-    static const int dbg = getenv("GTOS_GRU_DBG") ? atoi(getenv("GTOS_GRU_DBG")) : 0;
+    a.p_drop = p_drop; a.seed = seed; a.drop_base = drop_base; a.rows = rows; a.hs = hs;
+    static const int env_dbg = getenv("GTOS_GRU_DBG") ? atoi(getenv("GTOS_GRU_DBG")) : 0;
+    // tools/bench_gru_step.py passes measuring switches per launch above the flag: bits 8-15 the switch, 16-19 the wave count, 20+ a delay in us
+    const int dbg = ((save_hn >> 8) & 0xff) ? ((save_hn >> 8) & 0xff) : env_dbg;
+    const int nw_launch = (save_hn >> 16) & 0xf;
+    a.dbg_delay = (save_hn >> 20) * 100;
+    save_hn &= 0xff;
+    a.save_hn = save_hn;
     a.zeros = gtos_zero_block();
     if (!a.zeros) return -5;
     const long long nM = (rows + TM - 1) / TM, nC = hs / TC;
@@ -1096,14 +1115,19 @@ extern "C" int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, i
     static const int ring_nw = getenv("GTOS_GRU_FWD_NW") ? atoi(getenv("GTOS_GRU_FWD_NW")) : 8;
     if (mode == 1 && use_ring && in_dim % 32 == 0 && !h_idx && ldx < (1 << 20) && (int64_t)3 * hs * (in_dim > hs ? in_dim : hs) * 2 < (1LL << 31))
     {
-        if (ring_nw == 8 && rows >= 8192) {                    // (small launches: more, smaller workgroups fill the chip better)
+        const int nw_env = ring_nw ? ring_nw : (in_dim <= 128 ? 4 : 8);                 // 0: by the input width
+        if ((nw_launch ? nw_launch : nw_env) == 8 && rows >= 8192) {                    // (small launches: more, smaller workgroups fill the chip better)
             const long long nM8 = (rows + 255) / 256, nblk8 = ((nM8 + 7) / 8) * 8 * nC;
             if (dbg == 1) hipLaunchKernelGGL((gru_step_fwd_ring_kernel<1, 8>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
             else if (dbg == 2) hipLaunchKernelGGL((gru_step_fwd_ring_kernel<2, 8>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
+            else if (dbg == 3) hipLaunchKernelGGL((gru_step_fwd_ring_kernel<3, 8>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
+            else if (dbg == 4) hipLaunchKernelGGL((gru_step_fwd_ring_kernel<4, 8>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
             else hipLaunchKernelGGL((gru_step_fwd_ring_kernel<0, 8>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
         }
         else if (dbg == 1) hipLaunchKernelGGL((gru_step_fwd_ring_kernel<1, 4>), dim3((unsigned)nblk), dim3(256), 0, s, a);
         else if (dbg == 2) hipLaunchKernelGGL((gru_step_fwd_ring_kernel<2, 4>), dim3((unsigned)nblk), dim3(256), 0, s, a);
+        else if (dbg == 5) hipLaunchKernelGGL((gru_step_fwd_ring_kernel<5, 4>), dim3((unsigned)nblk), dim3(256), 0, s, a);
+        else if (dbg == 6) hipLaunchKernelGGL((gru_step_fwd_ring_kernel<6, 4>), dim3((unsigned)nblk), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((gru_step_fwd_ring_kernel<0, 4>), dim3((unsigned)nblk), dim3(256), 0, s, a);
     }
     else if (mode == 1) hipLaunchKernelGGL(gru_step_fwd_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, s, a);

@@ -25,12 +25,81 @@ def timed(fn, reps):
     return ts[len(ts) // 2] * 1e3
 
 
+def concurrent(a):
+    dev, bf = torch.device("cuda:0"), torch.bfloat16
+    A, hs = a.rows, 256
+    torch.manual_seed(0)
+    r = lambda *s: (torch.randn(*s, device=dev) * 0.3).to(bf)                     # noqa: E731
+    for layer, ind in ((0, 128), (1, 512)):
+        bufs = []
+        for _ in range(2):                                                        # two independent problem instances
+            bufs.append(dict(x=r(A, ind), h_in=r(A, hs), wi=r(3 * hs, ind), wh=r(3 * hs, hs), bi=torch.zeros(3 * hs, device=dev),
+                             bh=torch.zeros(3 * hs, device=dev), h_out=torch.empty(A, hs, device=dev, dtype=bf),
+                             gates=torch.empty(A, 4 * hs, device=dev, dtype=bf)))
+        s2 = torch.cuda.Stream()
+
+        def launch(b, dbg):
+            call("gtos_gru_step_fwd", A, hs, ptr(b["x"]), ind, ind, ptr(b["wi"]), ptr(b["bi"]), None, None, None, None, None, ptr(b["h_in"]), None,
+                 ptr(b["wh"]), ptr(b["bh"]), ptr(b["h_out"]), A, None, hs, None, ptr(b["gates"]), None, 2 * hs, 0.0, 0, 0, 1 | (dbg << 8), stream())
+
+        def serial(d0, d1):
+            launch(bufs[0], d0); launch(bufs[1], d1)
+
+        def side_by_side(d0, d1):
+            s2.wait_stream(torch.cuda.current_stream())
+            launch(bufs[0], d0)
+            with torch.cuda.stream(s2):
+                launch(bufs[1], d1)
+            torch.cuda.current_stream().wait_stream(s2)
+        for name, d0, d1 in (("k loop alone + cell alone", 2, 1), ("DMA alone + cell alone", 3, 1), ("reads+MFMA alone + cell alone", 4, 1),
+                             ("DMA alone + reads+MFMA alone", 3, 4), ("cell alone + cell alone", 1, 1), ("k loop alone + k loop alone", 2, 2)):
+            t_ser = timed(lambda: serial(d0, d1), a.reps)
+            t_par = timed(lambda: side_by_side(d0, d1), a.reps)
+            print("L%d %-34s one after the other %7.1f us   side by side on two streams %7.1f us   (%.2f)" % (layer, name, t_ser, t_par, t_par / t_ser), flush=True)
+
+
+def phase(a):
+    dev, bf = torch.device("cuda:0"), torch.bfloat16
+    A, hs = a.rows, 256
+    torch.manual_seed(0)
+    r = lambda *s: (torch.randn(*s, device=dev) * 0.3).to(bf)                     # noqa: E731
+    for layer, ind in ((0, 128), (1, 512)):
+        b = dict(x=r(A, ind), h_in=r(A, hs), wi=r(3 * hs, ind), wh=r(3 * hs, hs), bi=torch.zeros(3 * hs, device=dev),
+                 bh=torch.zeros(3 * hs, device=dev), h_out=torch.empty(A, hs, device=dev, dtype=bf),
+                 gates=torch.empty(A, 4 * hs, device=dev, dtype=bf))
+
+        def launch(dbg, nw, delay_us):
+            call("gtos_gru_step_fwd", A, hs, ptr(b["x"]), ind, ind, ptr(b["wi"]), ptr(b["bi"]), None, None, None, None, None, ptr(b["h_in"]), None,
+                 ptr(b["wh"]), ptr(b["bh"]), ptr(b["h_out"]), A, None, hs, None, ptr(b["gates"]), None, 2 * hs, 0.0, 0, 0,
+                 1 | (dbg << 8) | (nw << 16) | (delay_us << 20), stream())
+        launch(0, 4, 0)
+        ref = b["h_out"].clone()
+        print("L%d  eight waves %7.1f us   four waves %7.1f us   (k loop alone %7.1f, cell alone %7.1f)" % (
+            layer, timed(lambda: launch(0, 8, 0), a.reps), timed(lambda: launch(0, 4, 0), a.reps),
+            timed(lambda: launch(2, 4, 0), a.reps), timed(lambda: launch(1, 4, 0), a.reps)), flush=True)
+        for dbg, what in ((5, "workgroups 256..511 late"), (6, "every other of the first 512 late")):
+            for d in (0, 20, 40, 60, 80, 120, 200):
+                t = timed(lambda: launch(dbg, 4, d), a.reps)
+                same = bool((b["h_out"] == ref).all())
+                print("L%d  %-36s by %3d us: %7.1f us   %s" % (layer, what, d, t, "same result" if same else "RESULT DIFFERS"), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=434624)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--only", default="")
+    ap.add_argument("--concurrent", action="store_true",
+                    help="forward step of layer 1: its k loop alone and its cell alone (the kernel's measuring switches, per launch) one after the other "
+                         "on one stream and SIDE BY SIDE on two streams -- do the two phases use independent resources?")
+    ap.add_argument("--phase", action="store_true",
+                    help="forward step, four waves (two workgroups per CU): some first-generation workgroups start late, so that the two "
+                         "workgroups of a CU are in opposite phases (k loop / cell) -- measuring switches 5 / 6 of the kernel")
     a = ap.parse_args()
+    if a.concurrent:
+        return concurrent(a)
+    if a.phase:
+        return phase(a)
     dev, bf = torch.device("cuda:0"), torch.bfloat16
     A, hs = a.rows, 256
     torch.manual_seed(0)
