@@ -319,9 +319,23 @@ __global__ __launch_bounds__(256, 2) void gru_step_fwd_kernel(StepArgs a) {
 
 // The cell of a 128-row x 64-channel tile on the accumulators of the gate products (shared by the step kernels below): lane (fr, fq)
 // holds rows m0 + wave*32 + mt*16 + fr, channels cb .. cb+15 (index nt*4 + e) of accumulator groups r, z, (n_x,) n_h.
-template <int MODE>
+// LINES (a TIMING experiment only, measuring switches 8 / 9 of gru_step_fwd_dbuf_kernel: the values land in the wrong places): the same
+// loads and stores with the addresses of a lane -> memory map in which 8 consecutive lanes cover one 128-byte row segment (8 rows x 128 B
+// per instruction) instead of 16 rows x four 16-byte pieces at a 32-byte stride.
+template <bool LINES>
+__device__ __forceinline__ void st16x(bf16_t* base, int64_t ld, int64_t m, int col, int row0, int c0, int lane, const float (&v)[16]) {
+    if constexpr (LINES) {
+        bf16_t* p0 = base + (int64_t)(row0 + (lane >> 3)) * ld + c0 + (lane & 7) * 8;
+        *reinterpret_cast<uint4*>(p0) = make_uint4(pack_bf(v[0], v[1]), pack_bf(v[2], v[3]), pack_bf(v[4], v[5]), pack_bf(v[6], v[7]));
+        *reinterpret_cast<uint4*>(p0 + 8 * ld) = make_uint4(pack_bf(v[8], v[9]), pack_bf(v[10], v[11]), pack_bf(v[12], v[13]), pack_bf(v[14], v[15]));
+    } else {
+        st16(base + m * ld + col, v);
+    }
+}
+template <int MODE, bool LINES = false>
 __device__ __forceinline__ void step_cell(const StepArgs& a, f32x4_t (&acc)[2][(MODE == 1 ? 4 : 3) * 4], int m0, int c0, int wave, int fr, int fq) {
     constexpr bool HAS_X = MODE == 1;
+    const int lane_ = fq * 16 + fr;
     constexpr int GH = HAS_X ? 3 : 2;
     // ---- cell: lane (fr, fq) holds rows m0 + wave*32 + mt*16 + fr, channels cb .. cb+15 (index nt*4 + e)
     const int cb = c0 + fq * 16, hs = a.hs;
@@ -366,6 +380,12 @@ __device__ __forceinline__ void step_cell(const StepArgs& a, f32x4_t (&acc)[2][(
             const bf16_t* xp = a.xg + (int64_t)m * 3 * hs + cb;
             ld16(xp, xr); ld16(xp + hs, xz); ld16(xp + 2 * hs, xn);
         }
+        if constexpr (LINES) {
+            const bf16_t* p0 = a.h_in + (int64_t)(m0 + wave * 32 + mt * 16 + (lane_ >> 3)) * hs + c0 + (lane_ & 7) * 8;
+            const uint4 u = *reinterpret_cast<const uint4*>(p0), w = *reinterpret_cast<const uint4*>(p0 + 8 * hs);
+            hp[0] = lo_bf(u.x); hp[1] = hi_bf(u.x); hp[2] = lo_bf(u.y); hp[3] = hi_bf(u.y); hp[4] = lo_bf(u.z); hp[5] = hi_bf(u.z); hp[6] = lo_bf(u.w); hp[7] = hi_bf(u.w);
+            hp[8] = lo_bf(w.x); hp[9] = hi_bf(w.x); hp[10] = lo_bf(w.y); hp[11] = hi_bf(w.y); hp[12] = lo_bf(w.z); hp[13] = hi_bf(w.z); hp[14] = lo_bf(w.w); hp[15] = hi_bf(w.w);
+        } else
         ld16(a.h_in + (int64_t)(a.h_idx ? a.h_idx[m] : m) * hs + cb, hp);
         float gr[16], gz[16], gn[16], hn[16], o[16];
 #pragma unroll
@@ -378,19 +398,28 @@ __device__ __forceinline__ void step_cell(const StepArgs& a, f32x4_t (&acc)[2][(
             gn[i] = fast_tanh(xn[i] + gr[i] * hn[i]);
             o[i] = (1.f - gz[i]) * gn[i] + gz[i] * hp[i];
         }
+        if constexpr (LINES) {
+            const int r0_ = m0 + wave * 32 + mt * 16;
+            st16x<true>(a.gates, 4 * (int64_t)hs, m, cb, r0_, c0, lane_, gr); st16x<true>(a.gates + hs, 4 * (int64_t)hs, m, cb, r0_, c0, lane_, gz);
+            st16x<true>(a.gates + 2 * hs, 4 * (int64_t)hs, m, cb, r0_, c0, lane_, gn);
+            if (a.save_hn) st16x<true>(a.gates + 3 * hs, 4 * (int64_t)hs, m, cb, r0_, c0, lane_, hn);
+            st16x<true>(a.h_out, hs, m, cb, r0_, c0, lane_, o);
+        } else {
         bf16_t* gp = a.gates + (int64_t)m * 4 * hs + cb;
         st16(gp, gr); st16(gp + hs, gz); st16(gp + 2 * hs, gn);
         if (a.save_hn) st16(gp + 3 * hs, hn);
         bf16_t* hdst = m < a.n_out ? a.h_out + (int64_t)m * hs + cb
                                    : a.h_fin + (int64_t)(a.fin_idx ? a.fin_idx[m] : m) * a.ld_fin + cb;
         st16(hdst, o);
+        }
         if (a.y) {
             if (a.p_drop > 0.f) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
                     o[i] = drop_keep(a.seed, (uint64_t)(a.drop_base + (int64_t)m * a.ldy + cb + i), a.p_drop) ? o[i] * ks : 0.f;
             }
-            st16(a.y + (int64_t)m * a.ldy + cb, o);
+            if constexpr (LINES) st16x<true>(a.y, a.ldy, m, cb, m0 + wave * 32 + mt * 16, c0, lane_, o);
+            else st16(a.y + (int64_t)m * a.ldy + cb, o);
         }
     }
 }
@@ -574,6 +603,140 @@ __global__ __launch_bounds__(64 * NW, 2) void gru_step_fwd_ring_kernel(StepArgs 
         return;
     }
     step_cell<1>(a, acc, m0, c0, wave, fr, fq);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 5, last: the same fused forward step with TWO slots of 64-k stages -- whole 128-byte lines per operand row and DMA instruction
+// (8 rows x 128 B) where the three-slot ring above fetches 16 rows x 64 B, i.e. asks for every cache line twice, a stage apart (round 4
+// measured what that costs a GEMM k loop: 8192^3 0.63 -> 1.05 PF/s) -- and the next stage in flight while this one is multiplied, which
+// gru_step_fwd_kernel<1> (128-byte rows, one stage) does not have.  Eight waves, 256 rows x 64 channels per workgroup, 2 x 56 KB of LDS, one
+// workgroup per CU; per stage a wave issues 7 DMAs (4 of activation rows, 3 of weight rows), waits for its own pieces of the stage it is
+// about to read, meets the others at ONE barrier (everybody's pieces landed, everybody past its reads of the previous stage = the other
+// slot is free), starts the next stage into the other slot and runs two 32-k sub-steps of 14 fragment reads + 24 MFMAs.  Same lane ->
+// channel map, k order and cell as the other two kernels: bit-identical.  in_dim % 64 == 0.  DBG as above (0 production, 1 no k loop,
+// 2 no cell, 3 DMA alone, 4 reads + MFMAs alone).
+template <int DBG, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void gru_step_fwd_dbuf_kernel(StepArgs a) {
+    constexpr int TMW = 32 * NW, AW = TMW * ROWB, SLOT = AW + B_BYTES, NBP = 24 / NW;      // eight waves: 32 KB + 24 KB per slot
+    if (a.p_drop > 0.f) a.seed = live_seed(a.seed);
+    __shared__ __attribute__((aligned(16))) char sd0[SLOT];
+    __shared__ __attribute__((aligned(16))) char sd1[SLOT];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int hs = a.hs, nC = hs / TC;
+    const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
+    const int m0 = ((sq / nC) * 8 + xcd) * TMW, c0 = (sq % nC) * TC;
+    if (m0 >= a.rows) return;
+    // DBG 7: MIXED roles in one launch -- workgroups with bit 5 of their per-XCD index set run the k loop's DMA alone, the others the cell
+    // alone (each CU's first two workgroups, or neighbouring CUs with eight waves, get one of each): do the two phases share a resource?
+    const bool dma_role = DBG == 7 && ((sq >> 5) & 1);
+    const int nkx = a.in_dim / BK, nk = (DBG == 1 || DBG == 8 || (DBG == 7 && !dma_role)) ? 0 : nkx + hs / BK;
+    // per-lane source offsets, once: wave w owns 1 KB blocks w, w + 8, .. (8 rows x 128 B each) of both operands
+    uint32_t axo[4], aho[4], bxo[NBP], bho[NBP];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rl = (i * NW + wave) * 8 + (lane >> 3);
+        const int r = min(m0 + rl, a.rows - 1) - m0;                          // rows past the end re-read the last valid row (never stored)
+        const uint32_t c = (uint32_t)(((lane & 7) ^ swz(rl)) << 4);
+        axo[i] = (uint32_t)r * (uint32_t)(a.ldx * 2) + c;
+        aho[i] = (uint32_t)r * (uint32_t)(hs * 2) + c;
+    }
+#pragma unroll
+    for (int i = 0; i < NBP; ++i) {
+        const int rl = (i * NW + wave) * 8 + (lane >> 3);
+        const int g = rl >> 6, nt = (rl >> 4) & 3, q = (rl >> 2) & 3, e = rl & 3;
+        const int wrow = g * hs + c0 + q * 16 + nt * 4 + e;
+        const uint32_t c = (uint32_t)(((lane & 7) ^ swz(rl)) << 4);
+        bxo[i] = (uint32_t)wrow * (uint32_t)(a.in_dim * 2) + c;
+        bho[i] = (uint32_t)wrow * (uint32_t)(hs * 2) + c;
+    }
+    const char* Xb = reinterpret_cast<const char*>(a.x + (int64_t)m0 * a.ldx);
+    const char* Hb = reinterpret_cast<const char*>(a.h_in + (int64_t)m0 * hs);
+    const char* Wi = reinterpret_cast<const char*>(a.w_ih);
+    const char* Wh = reinterpret_cast<const char*>(a.w_hh);
+
+    f32x4_t acc[2][16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+#define GTOS_DMA1(src, dst)                                                                                                   \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),                                    \
+                                     (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+// this wave's 7 pieces of stage s_ (past the end: the last stage again, never multiplied) into `slot`
+#define GTOS_DBUF_DMA(slot, s_)                                                                                               \
+    if constexpr (DBG != 4) {                                                                                                 \
+        const int st_ = min((s_), nk - 1);                                                                                    \
+        const bool px_ = st_ < nkx;                                                                                           \
+        const char* ab_ = px_ ? Xb + st_ * ROWB : Hb + (st_ - nkx) * ROWB;                                                    \
+        const char* bb_ = px_ ? Wi + st_ * ROWB : Wh + (st_ - nkx) * ROWB;                                                    \
+        GTOS_DMA1(ab_ + (px_ ? axo[0] : aho[0]), (slot) + (0 * NW + wave) * 1024);                                             \
+        GTOS_DMA1(ab_ + (px_ ? axo[1] : aho[1]), (slot) + (1 * NW + wave) * 1024);                                             \
+        GTOS_DMA1(ab_ + (px_ ? axo[2] : aho[2]), (slot) + (2 * NW + wave) * 1024);                                             \
+        GTOS_DMA1(ab_ + (px_ ? axo[3] : aho[3]), (slot) + (3 * NW + wave) * 1024);                                             \
+        GTOS_DMA1(bb_ + (px_ ? bxo[0] : bho[0]), (slot) + AW + (0 * NW + wave) * 1024);                                        \
+        GTOS_DMA1(bb_ + (px_ ? bxo[1] : bho[1]), (slot) + AW + (1 * NW + wave) * 1024);                                        \
+        GTOS_DMA1(bb_ + (px_ ? bxo[2] : bho[2]), (slot) + AW + (2 * NW + wave) * 1024);                                        \
+        if constexpr (NBP > 3) {                                                                                              \
+            GTOS_DMA1(bb_ + (px_ ? bxo[3] : bho[3]), (slot) + AW + (3 * NW + wave) * 1024);                                   \
+            GTOS_DMA1(bb_ + (px_ ? bxo[4] : bho[4]), (slot) + AW + (4 * NW + wave) * 1024);                                   \
+            GTOS_DMA1(bb_ + (px_ ? bxo[5] : bho[5]), (slot) + AW + (5 * NW + wave) * 1024);                                   \
+        }                                                                                                                     \
+    }
+#define GTOS_DBUF_STEP(slot_s, slot_d, s_)                                                                                    \
+    {                                                                                                                         \
+        GTOS_VMCNT(0);                                     /* own pieces of stage s_ */                                       \
+        __builtin_amdgcn_s_barrier();                      /* everybody's; and everybody is past its reads of stage s_ - 1 */ \
+        GTOS_DBUF_DMA(slot_d, (s_) + 1);                                                                                      \
+        if constexpr (DBG != 3 && DBG != 7) {                                                                             \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                                \
+                bf16x8_t fa[2], fb[12];                                                                                       \
+                _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                              \
+                    fa[mt] = *reinterpret_cast<const bf16x8_t*>((slot_s) + lds_off(wave * 32 + mt * 16 + fr, ks * 4 + fq));   \
+                _Pragma("unroll") for (int t = 0; t < 12; ++t)                                                                \
+                    fb[t] = *reinterpret_cast<const bf16x8_t*>((slot_s) + AW + lds_off(t * 16 + fr, ks * 4 + fq));            \
+                _Pragma("unroll") for (int g = 0; g < 2; ++g)                                                                 \
+                    _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                          \
+                        _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                      \
+                            acc[mt][g * 4 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[g * 4 + nt], fa[mt], acc[mt][g * 4 + nt], 0, 0, 0); \
+                if ((s_) < nkx) {                                                                                             \
+                    _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                          \
+                        _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                      \
+                            acc[mt][8 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[8 + nt], fa[mt], acc[mt][8 + nt], 0, 0, 0); \
+                } else {                                                                                                      \
+                    _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                          \
+                        _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                      \
+                            acc[mt][12 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[8 + nt], fa[mt], acc[mt][12 + nt], 0, 0, 0); \
+                }                                                                                                             \
+            }                                                                                                                 \
+        }                                                                                                                     \
+    }
+
+    if (nk > 0) GTOS_DBUF_DMA(sd0, 0);
+    int s = 0;
+    for (; s + 2 <= nk; s += 2) {                          // whole pairs: every code location has its slot (the compiler's wait-count pass)
+        GTOS_DBUF_STEP(sd0, sd1, s);
+        GTOS_DBUF_STEP(sd1, sd0, s + 1);
+    }
+    if (s < nk) GTOS_DBUF_STEP(sd0, sd1, s);
+    GTOS_VMCNT(0);                                         // the dummy prefetch of the last stage
+#undef GTOS_DBUF_STEP
+#undef GTOS_DBUF_DMA
+#undef GTOS_DMA1
+    if (DBG == 7 && dma_role) return;
+    if constexpr (DBG >= 2 && DBG <= 4) {                  // measuring switches: one store per lane keeps the accumulators alive
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (t == 123.456f) a.gates[threadIdx.x] = f2bf(t);
+        return;
+    }
+    if constexpr (DBG == 8 || DBG == 9) { if (m0 + TMW <= a.rows) step_cell<1, true>(a, acc, m0, c0, wave, fr, fq); }   // (whole panels only: timing)
+    else step_cell<1>(a, acc, m0, c0, wave, fr, fq);
 }
 
 
@@ -793,20 +956,22 @@ __device__ __forceinline__ void dma_wt(const bf16_t* __restrict__ w, int64_t ld,
 // Role B of the backward step launch (StepBwdArgs.dinp): one 128-row x 128-column tile of the previous step's input gradient,
 // dinp[m0.., n0..] = d4_prev[m0.., 0:3hs] x wi_t[n0.., 0:3hs]^T.  Same single-stage k loop as the recurrent product of role A (the two
 // 64-row weight blocks in the permuted order of dma_wt, so a lane ends up with 16 consecutive columns of each half).
+template <int DBG, int NS>
 __device__ __forceinline__ void dinp_tile(const StepBwdArgs& a, int m0, int n0, char* As, char* Bs, int wave, int lane) {
     if (m0 >= a.rows_prev) return;
     const int fr = lane & 15, fq = lane >> 4, hs = a.hs;
     const U128* Z = static_cast<const U128*>(a.zeros);
-    const bool two = n0 + TC < a.n_in;                               // n_in % 64 == 0: the last tile may be half a tile wide
-    f32x4_t acc[2][8];
+    const int nsub = min(NS, (a.n_in - n0) / TC);                    // n_in % 64 == 0: the last tile may be narrower
+    f32x4_t acc[2][NS * 4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    for (int kk = 0; kk < 3 * hs; kk += BK) {
+        for (int j = 0; j < NS * 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int kk = 0; kk < (DBG == 1 ? 0 : 3 * hs); kk += BK) {
         dma_rows(a.d4_prev, Z, 4 * (int64_t)hs, a.rows_prev, m0, kk, kk + BK, As, wave, lane);
-        dma_wt(a.wi_t, 3 * (int64_t)hs, n0, kk, Bs, wave, lane);
-        if (two) dma_wt(a.wi_t, 3 * (int64_t)hs, n0 + TC, kk, Bs + TC * ROWB, wave, lane);
+#pragma unroll
+        for (int h = 0; h < NS; ++h)
+            if (h < nsub) dma_wt(a.wi_t, 3 * (int64_t)hs, n0 + h * TC, kk, Bs + h * TC * ROWB, wave, lane);
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -814,23 +979,28 @@ __device__ __forceinline__ void dinp_tile(const StepBwdArgs& a, int m0, int n0, 
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) fa[mt] = *reinterpret_cast<const bf16x8_t*>(As + lds_off(wave * 32 + mt * 16 + fr, ks * 4 + fq));
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) fb[nt] = *reinterpret_cast<const bf16x8_t*>(Bs + lds_off(nt * 16 + fr, ks * 4 + fq));
+            for (int h = 0; h < NS; ++h) {
+                if (h < nsub) {
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+                    for (int nt = 0; nt < 4; ++nt) fb[nt] = *reinterpret_cast<const bf16x8_t*>(Bs + h * TC * ROWB + lds_off(nt * 16 + fr, ks * 4 + fq));
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
-            if (two) {
+                    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) fb[nt] = *reinterpret_cast<const bf16x8_t*>(Bs + TC * ROWB + lds_off(nt * 16 + fr, ks * 4 + fq));
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt)
-                        acc[mt][4 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][4 + nt], 0, 0, 0);
+                        for (int nt = 0; nt < 4; ++nt)
+                            acc[mt][h * 4 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][h * 4 + nt], 0, 0, 0);
+                }
             }
         }
         __syncthreads();
+    }
+    if constexpr (DBG == 2) {                              // measuring switch: the product alone
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NS * 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (t == 123.456f) a.dinp[threadIdx.x] = f2bf(t);
+        return;
     }
     const float ks_in = a.p_in > 0.f ? 1.f / (1.f - a.p_in) : 1.f;
     const uint64_t seed_in = a.p_in > 0.f ? live_seed(a.seed_in) : 0;
@@ -839,8 +1009,8 @@ __device__ __forceinline__ void dinp_tile(const StepBwdArgs& a, int m0, int n0, 
         const int m = m0 + wave * 32 + mt * 16 + fr;
         if (m >= a.rows_prev) continue;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            if (h == 1 && !two) continue;
+        for (int h = 0; h < NS; ++h) {
+            if (h >= nsub) continue;
             const int nb = n0 + h * TC + fq * 16;
             float v[16];
 #pragma unroll
@@ -862,11 +1032,21 @@ __device__ __forceinline__ void dinp_tile(const StepBwdArgs& a, int m0, int n0, 
     }
 }
 
-// HN: the hn recompute of round 4 (a.w_hn != NULL, opt-in) -- its 16 KB LDS park for the rebuilt values exists in that instantiation only
-template <bool HN>
+// HN: the hn recompute of round 4 (a.w_hn != NULL, opt-in) -- its 16 KB LDS park for the rebuilt values exists in that instantiation only.
+// NS: 64-column pieces per input-gradient tile (role B): 2 = 128 columns (32 KB of LDS with the row panel).  4 = 256 columns (the previous
+// step's rows fetched half as often) was built and measured in round 5: role B alone 400 vs 409-432 us per 434 k-row launch of layer 1, the
+// whole launch 1128 vs 1046-1059 us at two workgroups per CU (202 registers) and 2314 us at three (124 bytes of scratch per lane): fewer
+// fetched bytes do not shorten these k loops (profiles/r5_ab_switches.txt, call 21).
+// DBG: measuring switches (GTOS_GRU_BWD_DBG, packed-path launches): 1 = no k loops, 2 = the k loops alone.  Call 18, 434,624 rows: layer 1
+// 1040 us = 530 (no k loops) + 528 (k loops alone); layer 0 860 = 524 + 363 -- the launch costs the sum of its two parts here as well.
+// Double-buffered k loops in both roles (two 32 KB slots, the next stage in flight; 64 KB of LDS = two workgroups per CU) were built and
+// measured (call 22, against the single-stage form on the same box): 1098-1126 vs 1072-1082 us (layer 1), 901-928 vs 867 (layer 0),
+// 31.8 vs 30.2 ms of GRU backward in the step -- three single-stage workgroups per CU cover each other's loads better than two pipelined
+// ones.  Not kept.
+template <bool HN, int DBG, int NS = 2>
 __global__ __launch_bounds__(256, 3) void gru_step_bwd_kernel(StepBwdArgs a) {
     if (a.p_drop > 0.f) a.seed = live_seed(a.seed);
-    __shared__ __attribute__((aligned(16))) char lds[A_BYTES + 2 * TC * ROWB];
+    __shared__ __attribute__((aligned(16))) char lds[A_BYTES + NS * TC * ROWB];
     __shared__ __attribute__((aligned(16))) char hn_lds[HN ? 256 * 2 * 32 : 16];  // per lane 2 row blocks x 16 channels bf16 (16 KB)
     __shared__ float btab[4 * TC];
     char* As = lds;
@@ -874,11 +1054,11 @@ __global__ __launch_bounds__(256, 3) void gru_step_bwd_kernel(StepBwdArgs a) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fr = lane & 15, fq = lane >> 4;
     const int hs = a.hs, nC = hs / TC;
-    const int nB = a.dinp ? (a.n_in + 2 * TC - 1) / (2 * TC) : 0, per = nC + nB;
+    const int nB = a.dinp ? (a.n_in + NS * TC - 1) / (NS * TC) : 0, per = nC + nB;
     const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
     // the workgroups of a 128-row panel -- nC cell tiles (role A), then nB input-gradient tiles (role B) -- run back to back on one XCD
     const int m0 = ((sq / per) * 8 + xcd) * TM, role = sq % per;
-    if (role >= nC) { dinp_tile(a, m0, (role - nC) * 2 * TC, As, Bs, wave, lane); return; }
+    if (role >= nC) { dinp_tile<DBG, NS>(a, m0, (role - nC) * NS * TC, As, Bs, wave, lane); return; }
     const int c0 = role * TC;
     if (m0 >= a.rows) return;
     const U128* Z = static_cast<const U128*>(a.zeros);
@@ -945,7 +1125,7 @@ __global__ __launch_bounds__(256, 3) void gru_step_bwd_kernel(StepBwdArgs a) {
             }
             __syncthreads();
         }
-    } else if (a.d4_prev && m0 < a.rows_prev) {
+    } else if (DBG != 1 && a.d4_prev && m0 < a.rows_prev) {
         for (int kk = 0; kk < 3 * hs; kk += BK) {
             const int ak = kk < 2 * hs ? kk : kk + hs;                 // skip the d n_x block of d4
             dma_rows(a.d4_prev, Z, 4 * (int64_t)hs, a.rows_prev, m0, ak, ak + BK, As, wave, lane);
@@ -970,6 +1150,15 @@ __global__ __launch_bounds__(256, 3) void gru_step_bwd_kernel(StepBwdArgs a) {
         __syncthreads();                                               // btab zeroed before anyone adds to it
     }
 
+    if constexpr (DBG == 2) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (t == 123.456f) a.d4[threadIdx.x] = f2bf(t);
+        return;
+    }
     const int cb = c0 + fq * 16;
     const float ks = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
 #pragma unroll
@@ -1116,6 +1305,30 @@ extern "C" int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, i
     if (mode == 1 && use_ring && in_dim % 32 == 0 && !h_idx && ldx < (1 << 20) && (int64_t)3 * hs * (in_dim > hs ? in_dim : hs) * 2 < (1LL << 31))
     {
         const int nw_env = ring_nw ? ring_nw : (in_dim <= 128 ? 4 : 8);                 // 0: by the input width
+        // GTOS_GRU_FWD_DBUF (default 1; 0 = the ring; 4 = four waves, 128-row panels, two workgroups per CU at exactly 2 x 80 KB of LDS:
+        // ahead in isolated launches, 82.2 / 79.9 ms in the step against 80.3 / 80.1 -- not stable): two slots of 64-k stages, 128-byte rows.
+        // (Per launch, tools/bench_gru_step.py: wave-count field 2 = eight waves, 3 = four.)
+        static const bool use_dbuf = !(getenv("GTOS_GRU_FWD_DBUF") && getenv("GTOS_GRU_FWD_DBUF")[0] == '0');
+        static const int dbuf_nw = (getenv("GTOS_GRU_FWD_DBUF") && getenv("GTOS_GRU_FWD_DBUF")[0] == '4') ? 4 : 8;
+        const int db = nw_launch ? (nw_launch == 2 ? 8 : nw_launch == 3 ? 4 : 0) : (use_dbuf ? dbuf_nw : 0);
+        if (db == 8 && in_dim % 64 == 0 && rows >= 8192) {
+            const long long nM8 = (rows + 255) / 256, nblk8 = ((nM8 + 7) / 8) * 8 * nC;
+            if (dbg == 1) hipLaunchKernelGGL((gru_step_fwd_dbuf_kernel<1, 8>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
+            else if (dbg == 2) hipLaunchKernelGGL((gru_step_fwd_dbuf_kernel<2, 8>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
+            else if (dbg == 3) hipLaunchKernelGGL((gru_step_fwd_dbuf_kernel<3, 8>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
+            else if (dbg == 7) hipLaunchKernelGGL((gru_step_fwd_dbuf_kernel<7, 8>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
+            else if (dbg == 8) hipLaunchKernelGGL((gru_step_fwd_dbuf_kernel<8, 8>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
+            else if (dbg == 9) hipLaunchKernelGGL((gru_step_fwd_dbuf_kernel<9, 8>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
+            else hipLaunchKernelGGL((gru_step_fwd_dbuf_kernel<0, 8>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
+        }
+        else if (db == 4 && in_dim % 64 == 0) {
+            if (dbg == 1) hipLaunchKernelGGL((gru_step_fwd_dbuf_kernel<1, 4>), dim3((unsigned)nblk), dim3(256), 0, s, a);
+            else if (dbg == 2) hipLaunchKernelGGL((gru_step_fwd_dbuf_kernel<2, 4>), dim3((unsigned)nblk), dim3(256), 0, s, a);
+            else if (dbg == 3) hipLaunchKernelGGL((gru_step_fwd_dbuf_kernel<3, 4>), dim3((unsigned)nblk), dim3(256), 0, s, a);
+            else if (dbg == 7) hipLaunchKernelGGL((gru_step_fwd_dbuf_kernel<7, 4>), dim3((unsigned)nblk), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((gru_step_fwd_dbuf_kernel<0, 4>), dim3((unsigned)nblk), dim3(256), 0, s, a);
+        }
+        else
         if ((nw_launch ? nw_launch : nw_env) == 8 && rows >= 8192) {                    // (small launches: more, smaller workgroups fill the chip better)
             const long long nM8 = (rows + 255) / 256, nblk8 = ((nM8 + 7) / 8) * 8 * nC;
             if (dbg == 1) hipLaunchKernelGGL((gru_step_fwd_ring_kernel<1, 8>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
@@ -1173,8 +1386,15 @@ extern "C" int gtos_gru_step_bwd_fused(int rows, int hs, const void* d4_prev, in
     const long long nM = (cover + TM - 1) / TM, per = hs / TC + (role_b ? (n_in + 2 * TC - 1) / (2 * TC) : 0);
     const long long nblk = ((nM + 7) / 8) * 8 * per;
     if (nblk > 0x7fffffffLL) return -6;
-    if (w_hn) hipLaunchKernelGGL(gru_step_bwd_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, static_cast<hipStream_t>(stream), a);
-    else      hipLaunchKernelGGL(gru_step_bwd_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    static const int bwd_dbg = getenv("GTOS_GRU_BWD_DBG") ? atoi(getenv("GTOS_GRU_BWD_DBG")) : 0;
+    const int dbg = (w_hn || sum_idx) ? 0 : bwd_dbg;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define GTOS_BWD_LAUNCH(HN_, D_) hipLaunchKernelGGL((gru_step_bwd_kernel<HN_, D_>), dim3((unsigned)nblk), dim3(256), 0, st, a)
+    if (w_hn) GTOS_BWD_LAUNCH(true, 0);
+    else if (dbg == 1) GTOS_BWD_LAUNCH(false, 1);
+    else if (dbg == 2) GTOS_BWD_LAUNCH(false, 2);
+    else GTOS_BWD_LAUNCH(false, 0);
+#undef GTOS_BWD_LAUNCH
     GTOS_CHECK_LAUNCH();
     return 0;
 }

@@ -84,6 +84,38 @@ def phase(a):
                 print("L%d  %-36s by %3d us: %7.1f us   %s" % (layer, what, d, t, "same result" if same else "RESULT DIFFERS"), flush=True)
 
 
+def dbuf(a):
+    dev, bf = torch.device("cuda:0"), torch.bfloat16
+    hs = 256
+    torch.manual_seed(0)
+    r = lambda *s: (torch.randn(*s, device=dev) * 0.3).to(bf)                     # noqa: E731
+    for A in (a.rows, 100003):
+        for layer, ind in ((0, 128), (1, 512)):
+            b = dict(x=r(A, ind), h_in=r(A, hs), wi=r(3 * hs, ind), wh=r(3 * hs, hs), bi=torch.randn(3 * hs, device=dev) * 0.1,
+                     bh=torch.randn(3 * hs, device=dev) * 0.1)
+
+            def launch(dbg, nw, out):
+                call("gtos_gru_step_fwd", A, hs, ptr(b["x"]), ind, ind, ptr(b["wi"]), ptr(b["bi"]), None, None, None, None, None, ptr(b["h_in"]), None,
+                     ptr(b["wh"]), ptr(b["bh"]), ptr(out[0]), A, None, hs, None, ptr(out[1]), None, 2 * hs, 0.0, 0, 0,
+                     1 | (dbg << 8) | (nw << 16), stream())
+            outs = {}
+            for name, nw in (("ring, eight waves", 8), ("two slots of 64-k, 8 waves", 2), ("two slots of 64-k, 4 waves", 3)):
+                out = (torch.zeros(A, hs, device=dev, dtype=bf), torch.zeros(A, 4 * hs, device=dev, dtype=bf))
+                launch(0, nw, out)
+                torch.cuda.synchronize()
+                outs[name] = (out[0].clone(), out[1].clone())       # (the timed launches below overwrite `out`)
+                t = [timed(lambda d=d: launch(d, nw, out), a.reps) for d in (0, 2, 3, 1)]
+                print("rows %7d L%d  %-26s full %7.1f us   k loop alone %7.1f   its DMA alone %7.1f   cell alone %7.1f" % ((A, layer, name) + tuple(t)), end="", flush=True)
+                if nw == 2:                    # the cell's loads and stores with whole 128-byte row segments per 8 consecutive lanes (timing only: wrong places)
+                    print("   LINE-WISE cell accesses (timing only): cell alone %7.1f, full %7.1f" % (timed(lambda: launch(8, nw, out), a.reps), timed(lambda: launch(9, nw, out), a.reps)), end="")
+                if nw != 8:                    # mixed roles: half the workgroups DMA alone, half cell alone -> (DMA alone + cell alone) / 2 if they queue on one resource
+                    print("   mixed roles %7.1f (half the sum %7.1f, half the larger %7.1f)" % (timed(lambda: launch(7, nw, out), a.reps), (t[2] + t[3]) / 2, max(t[2], t[3]) / 2), end="")
+                print(flush=True)
+            (h0, g0), (h1, g1), (h2, g2) = outs.values()
+            print("rows %7d L%d  bit-identical: state %s %s, gates %s %s" % (A, layer, bool((h0 == h1).all()), bool((h0 == h2).all()),
+                                                                            bool((g0 == g1).all()), bool((g0 == g2).all())), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=434624)
@@ -95,7 +127,12 @@ def main():
     ap.add_argument("--phase", action="store_true",
                     help="forward step, four waves (two workgroups per CU): some first-generation workgroups start late, so that the two "
                          "workgroups of a CU are in opposite phases (k loop / cell) -- measuring switches 5 / 6 of the kernel")
+    ap.add_argument("--dbuf", action="store_true",
+                    help="forward step: the three-slot ring of 32-k stages (64-byte rows) against two slots of 64-k stages (whole 128-byte lines "
+                         "per row and DMA instruction), each whole and split by the measuring switches; results compared bit for bit")
     a = ap.parse_args()
+    if a.dbuf:
+        return dbuf(a)
     if a.concurrent:
         return concurrent(a)
     if a.phase:
