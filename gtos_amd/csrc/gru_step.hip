@@ -615,7 +615,11 @@ __global__ __launch_bounds__(64 * NW, 2) void gru_step_fwd_ring_kernel(StepArgs 
 // about to read, meets the others at ONE barrier (everybody's pieces landed, everybody past its reads of the previous stage = the other
 // slot is free), starts the next stage into the other slot and runs two 32-k sub-steps of 14 fragment reads + 24 MFMAs.  Same lane ->
 // channel map, k order and cell as the other two kernels: bit-identical.  in_dim % 64 == 0.  DBG as above (0 production, 1 no k loop,
-// 2 no cell, 3 DMA alone, 4 reads + MFMAs alone).
+// 2 no cell, 3 DMA alone, 4 reads + MFMAs alone); 7 mixed roles, 8 / 9 line-wise cell accesses, 10 DMA alone with two stages in flight.
+// What bounds the k loop (profiles/r5_ab_switches.txt, calls 19-24): its DMA alone takes 434 us per 434 k-row launch of layer 1 with ONE
+// 56 KB stage per CU in flight and 309 us with two (switch 10) -- a round trip per stage, not a bandwidth -- but a third 56 KB slot does not
+// fit the 160 KB of LDS, and four 28 KB stages of 32 k in flight (a five-slot ring, built and measured: DMA alone 436 us, launch 839 vs 792,
+// RelationEncoder forward 19.8 vs 18.2 ms in the step) do not deliver faster than two: half-line rows gain nothing from depth.
 template <int DBG, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void gru_step_fwd_dbuf_kernel(StepArgs a) {
     constexpr int TMW = 32 * NW, AW = TMW * ROWB, SLOT = AW + B_BYTES, NBP = 24 / NW;      // eight waves: 32 KB + 24 KB per slot
@@ -687,10 +691,11 @@ __global__ __launch_bounds__(64 * NW, 2) void gru_step_fwd_dbuf_kernel(StepArgs 
     }
 #define GTOS_DBUF_STEP(slot_s, slot_d, s_)                                                                                    \
     {                                                                                                                         \
-        GTOS_VMCNT(0);                                     /* own pieces of stage s_ */                                       \
+        if constexpr (DBG == 10) { GTOS_VMCNT(4 + NBP); }  /* (DMA alone with TWO stages in flight: nobody reads what lands) */  \
+        else { GTOS_VMCNT(0); }                            /* own pieces of stage s_ */                                       \
         __builtin_amdgcn_s_barrier();                      /* everybody's; and everybody is past its reads of stage s_ - 1 */ \
         GTOS_DBUF_DMA(slot_d, (s_) + 1);                                                                                      \
-        if constexpr (DBG != 3 && DBG != 7) {                                                                             \
+        if constexpr (DBG != 3 && DBG != 7 && DBG != 10) {                                                                             \
             _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                                \
                 bf16x8_t fa[2], fb[12];                                                                                       \
                 _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                              \
@@ -726,7 +731,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gru_step_fwd_dbuf_kernel(StepArgs 
 #undef GTOS_DBUF_DMA
 #undef GTOS_DMA1
     if (DBG == 7 && dma_role) return;
-    if constexpr (DBG >= 2 && DBG <= 4) {                  // measuring switches: one store per lane keeps the accumulators alive
+    if constexpr ((DBG >= 2 && DBG <= 4) || DBG == 10) {   // measuring switches: one store per lane keeps the accumulators alive
         float t = 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -1317,6 +1322,7 @@ extern "C" int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, i
             else if (dbg == 2) hipLaunchKernelGGL((gru_step_fwd_dbuf_kernel<2, 8>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
             else if (dbg == 3) hipLaunchKernelGGL((gru_step_fwd_dbuf_kernel<3, 8>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
             else if (dbg == 7) hipLaunchKernelGGL((gru_step_fwd_dbuf_kernel<7, 8>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
+            else if (dbg == 10) hipLaunchKernelGGL((gru_step_fwd_dbuf_kernel<10, 8>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
             else if (dbg == 8) hipLaunchKernelGGL((gru_step_fwd_dbuf_kernel<8, 8>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
             else if (dbg == 9) hipLaunchKernelGGL((gru_step_fwd_dbuf_kernel<9, 8>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
             else hipLaunchKernelGGL((gru_step_fwd_dbuf_kernel<0, 8>), dim3((unsigned)nblk8), dim3(512), 0, s, a);

@@ -106,14 +106,16 @@ def dbuf(a):
                 outs[name] = (out[0].clone(), out[1].clone())       # (the timed launches below overwrite `out`)
                 t = [timed(lambda d=d: launch(d, nw, out), a.reps) for d in (0, 2, 3, 1)]
                 print("rows %7d L%d  %-26s full %7.1f us   k loop alone %7.1f   its DMA alone %7.1f   cell alone %7.1f" % ((A, layer, name) + tuple(t)), end="", flush=True)
+                if nw == 2:
+                    print("   DMA alone with two stages in flight %7.1f" % timed(lambda: launch(10, nw, out), a.reps), end="")
                 if nw == 2:                    # the cell's loads and stores with whole 128-byte row segments per 8 consecutive lanes (timing only: wrong places)
                     print("   LINE-WISE cell accesses (timing only): cell alone %7.1f, full %7.1f" % (timed(lambda: launch(8, nw, out), a.reps), timed(lambda: launch(9, nw, out), a.reps)), end="")
-                if nw != 8:                    # mixed roles: half the workgroups DMA alone, half cell alone -> (DMA alone + cell alone) / 2 if they queue on one resource
+                if nw in (2, 3):               # mixed roles: half the workgroups DMA alone, half cell alone -> (DMA alone + cell alone) / 2 if they queue on one resource
                     print("   mixed roles %7.1f (half the sum %7.1f, half the larger %7.1f)" % (timed(lambda: launch(7, nw, out), a.reps), (t[2] + t[3]) / 2, max(t[2], t[3]) / 2), end="")
                 print(flush=True)
-            (h0, g0), (h1, g1), (h2, g2) = outs.values()
-            print("rows %7d L%d  bit-identical: state %s %s, gates %s %s" % (A, layer, bool((h0 == h1).all()), bool((h0 == h2).all()),
-                                                                            bool((g0 == g1).all()), bool((g0 == g2).all())), flush=True)
+            vals = list(outs.values())
+            print("rows %7d L%d  bit-identical to the ring: state %s, gates %s" % (A, layer, [bool((vals[0][0] == v[0]).all()) for v in vals[1:]],
+                                                                                  [bool((vals[0][1] == v[1]).all()) for v in vals[1:]]), flush=True)
 
 
 def main():
