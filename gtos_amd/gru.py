@@ -333,6 +333,11 @@ FUSE_DINP = os.environ.get("GTOS_GRU_FUSE_DINP", "1") != "0"      # layer input 
 MERGE_DW = os.environ.get("GTOS_GRU_MERGE_DW", "1") != "0"        # both weight gradients of a (layer, direction) as one grouped product (0: three GEMMs)
 # forward: direction 1 on the auxiliary stream beside direction 0.  MEASURED, no gain (same box, alternating: 86.66 / 84.89 ms with, 84.65 / 84.50
 # without; profiles/r5_ab_switches.txt): off.  See the comment in PackedPathGRUFn.forward for what it was meant to overlap and why it cannot.
+# packed path, backward: d4 written over the saved gates -- "1" always, "0" never, default: when the buffer is at least D4_INPLACE_MIN_BYTES
+# (measured, call 26: C2 -- 5 GB per buffer -- 80.7 vs 80.3 ms per step in place, reserved 64 vs 71 GB; C5 -- 18 GB -- 275.7 vs 276.5-277.2 ms,
+# reserved 145 vs 161-163 GB: worth it where memory is what is short)
+D4_INPLACE = os.environ.get("GTOS_GRU_D4_INPLACE", "auto")
+D4_INPLACE_MIN_BYTES = 8 << 30
 FWD_OVERLAP = os.environ.get("GTOS_GRU_FWD_OVERLAP", "0") == "1"
 
 
@@ -457,7 +462,12 @@ class PackedPathGRUFn(torch.autograd.Function):
                 w_ih, w_hh, b_ih, b_hh = weights[base:base + 4]
                 want_bias = b_ih.requires_grad or b_hh.requires_grad
                 dh = dfin[:, direction * hs:(direction + 1) * hs] if l == 1 else torch.zeros((bs[0], hs), dtype=dtp, device=dev)
-                d4 = torch.empty((N, 4 * hs), dtype=dtp, device=dev)
+                # d4 = [d r | d z | d n_x | d n_h] of every packed row, written by the cell tiles: IN PLACE over the saved gates (same shape; a
+                # lane reads the four gate values of its (row, channels) and writes the four gradients to the same addresses, the rows of other
+                # steps are either still gates -- not yet processed -- or already gradients -- what the next launch's products read): one
+                # [N, 4hs] buffer less while a direction runs (C5: 18 GB; reserved memory 145 instead of 161-163 GB).  See D4_INPLACE above.
+                in_place = D4_INPLACE == "1" or (D4_INPLACE != "0" and gates.numel() * gates.element_size() >= D4_INPLACE_MIN_BYTES)
+                d4 = gates if in_place else torch.empty((N, 4 * hs), dtype=dtp, device=dev)
                 note_memory(dev)
                 bpart = torch.zeros((N_BIAS_PARTIALS, 4 * hs), dtype=torch.float32, device=dev) if want_bias else None
                 rb = dict(wi_t=wi_t, n_in=n_in, dinp_acc=direction == 1, p_in=p_embed if l == 0 else 0.0,

@@ -2091,6 +2091,36 @@ def test_gru_forward_ring_kernel_bit_identical_to_single_stage(ind, tmp_path):
         assert torch.equal(outs[0], o)
 
 
+def test_packed_path_gru_backward_d4_in_place_is_the_same_function(monkeypatch):
+    """GTOS_GRU_D4_INPLACE (automatic for buffers of 8 GB and more: C5): the backward cell tiles write d4 over the saved gates instead of
+    into a buffer of their own -- same launches, same operands, same bits in every gradient (training mode, dropout on)."""
+    from gtos_amd import gru, ops
+    g = torch.Generator().manual_seed(11)
+    length = torch.randint(1, 9, (2500,), generator=g)
+    bank = torch.randint(1, 90, (8, 2500), generator=g)
+    for r in range(2500):
+        bank[int(length[r]):, r] = 0
+    ref, m = _relenc_pair(bank, length, hid=64)
+    m.compute_dtype = torch.bfloat16
+    m.dropout = 0.25
+    m.train()
+    wout = torch.randn(bank.shape[1], 64, generator=torch.Generator().manual_seed(1)).to(dev())
+    res = []
+    for mode in ("0", "1"):
+        monkeypatch.setattr(gru, "D4_INPLACE", mode)
+        ops.set_seed(78)
+        m.zero_grad()
+        out = m(bank.to(dev()), length.to(dev()))
+        (out.float() * wout).sum().backward()
+        ops.join_side()
+        torch.cuda.synchronize()
+        res.append((out.detach().clone(), _grads_of(m)))
+    assert torch.equal(res[0][0], res[1][0])
+    for k in res[0][1]:
+        torch.testing.assert_close(res[0][1][k], res[1][1][k], rtol=1e-5, atol=1e-6, msg=lambda s_, k=k: "%s: %s" % (k, s_))
+    assert float(max(v.abs().max() for v in res[0][1].values())) > 0
+
+
 def test_packed_path_gru_two_stream_forward_is_the_same_function(monkeypatch):
     """GTOS_GRU_FWD_OVERLAP=1 (opt-in, measured: no gain): the packed path's forward with direction 1 on the auxiliary stream beside
     direction 0 -- every buffer allocated on the main stream, the auxiliary stream joined before the next layer -- gives bit-identical
