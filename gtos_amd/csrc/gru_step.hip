@@ -620,6 +620,9 @@ __global__ __launch_bounds__(64 * NW, 2) void gru_step_fwd_ring_kernel(StepArgs 
 // 56 KB stage per CU in flight and 309 us with two (switch 10) -- a round trip per stage, not a bandwidth -- but a third 56 KB slot does not
 // fit the 160 KB of LDS, and four 28 KB stages of 32 k in flight (a five-slot ring, built and measured: DMA alone 436 us, launch 839 vs 792,
 // RelationEncoder forward 19.8 vs 18.2 ms in the step) do not deliver faster than two: half-line rows gain nothing from depth.
+// The cell with line-wise global accesses FOR REAL (every array through a wave-private, swizzled 2 KB LDS area and out as 8 rows x 128
+// contiguous bytes per instruction; the entering state in the same way; bit-identical; call 27): the cell alone 385 -> 255 us as the timing
+// experiment (switches 8 / 9) had said, but the launch only 543 -> 533 / 818 -> 808 us and the step 80.02 / 80.07 -> 79.99 / 79.96 ms.  Removed.
 template <int DBG, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void gru_step_fwd_dbuf_kernel(StepArgs a) {
     constexpr int TMW = 32 * NW, AW = TMW * ROWB, SLOT = AW + B_BYTES, NBP = 24 / NW;      // eight waves: 32 KB + 24 KB per slot
