@@ -749,6 +749,164 @@ __global__ __launch_bounds__(64 * NW, 2) void gru_step_fwd_dbuf_kernel(StepArgs 
 
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The two-slot kernel with MORE IN FLIGHT (the default where it applies).  What bounds gru_step_fwd_dbuf_kernel's k loop is the round trip of
+// the ONE 56 KB stage a CU has in flight (its DMA alone: 434 us per 434 k-row launch of layer 1; with two stages in flight and nobody reading
+// them: 309 us), and a third 56 KB slot does not fit the LDS -- but the two operands of a stage need not have the same number of slots:
+//   A3 (default): THREE slots of activation rows (32 KB each) and two of weight rows (24 KB): 144 KB of LDS; per stage a wave issues its 3
+//       pieces of W(s+1) and THEN its 4 of A(s+2); loads complete in order, so "all but the newest four" (vmcnt(4)) is exactly "W(s) and A(s)
+//       have landed, A(s+1) may still fly" -- while stage s is multiplied, A(s+1), W(s+1) and A(s+2) are under way: 88 KB per CU;
+//   !A3: two slots of activation rows and three of weight rows (136 KB; A(s+1) then W(s+2) per stage, vmcnt(3); 80 KB in flight).
+// Measured (call 31, 434 k rows, layer 1 / layer 0): DMA alone 433 -> 405 (!A3) -> 332 us (A3) / 222 -> 215 -> 183; launch 804 -> 760 -> 730 /
+// 544 -> 541 -> 524 us; in the step RelationEncoder forward 18.2 -> 16.9 -> 16.6 ms, step 80.4 -> 79.2 -> 79.0 ms.
+// Slots are static arrays (hipcc's wait-count pass tracks LDS-DMA per LDS object): the body is unrolled over lcm(2, 3) = 6 stages, so the stage
+// count must be a multiple of 6 (in_dim 128: 2 + 4; in_dim 512: 8 + 4; the host falls back to the two-slot kernel otherwise).  Eight waves,
+// 256 rows x 64 channels, same lane -> channel map, k order and cell: the same bits.  DBG: 0 production, 1 no k loop, 2 no cell, 3 DMA alone.
+template <int DBG, bool A3>
+__global__ __launch_bounds__(512, 2) void gru_step_fwd_a2w3_kernel(StepArgs a) {
+    constexpr int TMW = 256, AW = TMW * ROWB;                                  // 32 KB of activation rows, B_BYTES = 24 KB of weight rows
+    if (a.p_drop > 0.f) a.seed = live_seed(a.seed);
+    __shared__ __attribute__((aligned(16))) char sa0[AW];
+    __shared__ __attribute__((aligned(16))) char sa1[AW];
+    __shared__ __attribute__((aligned(16))) char sw0[B_BYTES];
+    __shared__ __attribute__((aligned(16))) char sw1[B_BYTES];
+    __shared__ __attribute__((aligned(16))) char sw2[A3 ? 16 : B_BYTES];
+    __shared__ __attribute__((aligned(16))) char sa2[A3 ? AW : 16];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int hs = a.hs, nC = hs / TC;
+    const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
+    const int m0 = ((sq / nC) * 8 + xcd) * TMW, c0 = (sq % nC) * TC;
+    if (m0 >= a.rows) return;
+    const int nkx = a.in_dim / BK, nk = DBG == 1 ? 0 : nkx + hs / BK;
+    uint32_t axo[4], aho[4], bxo[3], bho[3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rl = (i * 8 + wave) * 8 + (lane >> 3);
+        const int r = min(m0 + rl, a.rows - 1) - m0;                          // rows past the end re-read the last valid row (never stored)
+        const uint32_t c = (uint32_t)(((lane & 7) ^ swz(rl)) << 4);
+        axo[i] = (uint32_t)r * (uint32_t)(a.ldx * 2) + c;
+        aho[i] = (uint32_t)r * (uint32_t)(hs * 2) + c;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int rl = (i * 8 + wave) * 8 + (lane >> 3);
+        const int g = rl >> 6, nt = (rl >> 4) & 3, q = (rl >> 2) & 3, e = rl & 3;
+        const int wrow = g * hs + c0 + q * 16 + nt * 4 + e;
+        const uint32_t c = (uint32_t)(((lane & 7) ^ swz(rl)) << 4);
+        bxo[i] = (uint32_t)wrow * (uint32_t)(a.in_dim * 2) + c;
+        bho[i] = (uint32_t)wrow * (uint32_t)(hs * 2) + c;
+    }
+    const char* Xb = reinterpret_cast<const char*>(a.x + (int64_t)m0 * a.ldx);
+    const char* Hb = reinterpret_cast<const char*>(a.h_in + (int64_t)m0 * hs);
+    const char* Wi = reinterpret_cast<const char*>(a.w_ih);
+    const char* Wh = reinterpret_cast<const char*>(a.w_hh);
+
+    f32x4_t acc[2][16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+#define GTOS_DMA1(src, dst)                                                                                                   \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),                                    \
+                                     (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+// this wave's 4 pieces of the activation rows / 3 pieces of the weight rows of stage s_ (past the end: the last stage again, never multiplied)
+#define GTOS_A2W3_DMA_A(slot, s_)                                                                                             \
+    {                                                                                                                         \
+        const int st_ = min((s_), nk - 1);                                                                                    \
+        const bool px_ = st_ < nkx;                                                                                           \
+        const char* ab_ = px_ ? Xb + st_ * ROWB : Hb + (st_ - nkx) * ROWB;                                                    \
+        GTOS_DMA1(ab_ + (px_ ? axo[0] : aho[0]), (slot) + (0 * 8 + wave) * 1024);                                             \
+        GTOS_DMA1(ab_ + (px_ ? axo[1] : aho[1]), (slot) + (1 * 8 + wave) * 1024);                                             \
+        GTOS_DMA1(ab_ + (px_ ? axo[2] : aho[2]), (slot) + (2 * 8 + wave) * 1024);                                             \
+        GTOS_DMA1(ab_ + (px_ ? axo[3] : aho[3]), (slot) + (3 * 8 + wave) * 1024);                                             \
+    }
+#define GTOS_A2W3_DMA_W(slot, s_)                                                                                             \
+    {                                                                                                                         \
+        const int st_ = min((s_), nk - 1);                                                                                    \
+        const bool px_ = st_ < nkx;                                                                                           \
+        const char* bb_ = px_ ? Wi + st_ * ROWB : Wh + (st_ - nkx) * ROWB;                                                    \
+        GTOS_DMA1(bb_ + (px_ ? bxo[0] : bho[0]), (slot) + (0 * 8 + wave) * 1024);                                             \
+        GTOS_DMA1(bb_ + (px_ ? bxo[1] : bho[1]), (slot) + (1 * 8 + wave) * 1024);                                             \
+        GTOS_DMA1(bb_ + (px_ ? bxo[2] : bho[2]), (slot) + (2 * 8 + wave) * 1024);                                             \
+    }
+// stage s_: A in sa_, W in sw_; A(s_+1) goes to sa_n (held A(s_-1)), W(s_+2) to sw_n (held W(s_-1))
+#define GTOS_A2W3_STEP(sa_, sw_, sa_n, sw_n, s_)                                                                              \
+    {                                                                                                                         \
+        if constexpr (A3) { GTOS_VMCNT(4); } else { GTOS_VMCNT(3); }   /* own pieces of A(s_) and W(s_); the newest stage issued may still fly */ \
+        __builtin_amdgcn_s_barrier();                      /* everybody's; and everybody is past its reads of stage s_ - 1 */ \
+        if constexpr (A3) {                                                                                                   \
+            GTOS_A2W3_DMA_W(sw_n, (s_) + 1);                                                                                  \
+            GTOS_A2W3_DMA_A(sa_n, (s_) + 2);                                                                                  \
+        } else {                                                                                                              \
+            GTOS_A2W3_DMA_A(sa_n, (s_) + 1);                                                                                  \
+            GTOS_A2W3_DMA_W(sw_n, (s_) + 2);                                                                                  \
+        }                                                                                                                     \
+        if constexpr (DBG != 3) {                                                                                             \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                                \
+                bf16x8_t fa[2], fb[12];                                                                                       \
+                _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                              \
+                    fa[mt] = *reinterpret_cast<const bf16x8_t*>((sa_) + lds_off(wave * 32 + mt * 16 + fr, ks * 4 + fq));      \
+                _Pragma("unroll") for (int t = 0; t < 12; ++t)                                                                \
+                    fb[t] = *reinterpret_cast<const bf16x8_t*>((sw_) + lds_off(t * 16 + fr, ks * 4 + fq));                    \
+                _Pragma("unroll") for (int g = 0; g < 2; ++g)                                                                 \
+                    _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                          \
+                        _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                      \
+                            acc[mt][g * 4 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[g * 4 + nt], fa[mt], acc[mt][g * 4 + nt], 0, 0, 0); \
+                if ((s_) < nkx) {                                                                                             \
+                    _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                          \
+                        _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                      \
+                            acc[mt][8 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[8 + nt], fa[mt], acc[mt][8 + nt], 0, 0, 0); \
+                } else {                                                                                                      \
+                    _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                          \
+                        _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                      \
+                            acc[mt][12 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[8 + nt], fa[mt], acc[mt][12 + nt], 0, 0, 0); \
+                }                                                                                                             \
+            }                                                                                                                 \
+        }                                                                                                                     \
+    }
+
+    if (nk > 0) {                                          // the loop's invariant from the start: the newest pieces are one whole stage of one operand
+        GTOS_A2W3_DMA_A(sa0, 0);
+        GTOS_A2W3_DMA_W(sw0, 0);
+        if constexpr (A3) { GTOS_A2W3_DMA_A(sa1, 1); } else { GTOS_A2W3_DMA_W(sw1, 1); }
+    }
+    for (int s = 0; s + 6 <= nk; s += 6) {                 // (nk % 6 == 0: checked by the host)
+        if constexpr (A3) {                                // A(s) in slot s % 3, W(s) in slot s % 2; A(s+2) -> (s+2) % 3, W(s+1) -> (s+1) % 2
+            GTOS_A2W3_STEP(sa0, sw0, sa2, sw1, s);
+            GTOS_A2W3_STEP(sa1, sw1, sa0, sw0, s + 1);
+            GTOS_A2W3_STEP(sa2, sw0, sa1, sw1, s + 2);
+            GTOS_A2W3_STEP(sa0, sw1, sa2, sw0, s + 3);
+            GTOS_A2W3_STEP(sa1, sw0, sa0, sw1, s + 4);
+            GTOS_A2W3_STEP(sa2, sw1, sa1, sw0, s + 5);
+        } else {                                           // A(s) in slot s % 2, W(s) in slot s % 3; A(s+1) -> (s+1) % 2, W(s+2) -> (s+2) % 3
+            GTOS_A2W3_STEP(sa0, sw0, sa1, sw2, s);
+            GTOS_A2W3_STEP(sa1, sw1, sa0, sw0, s + 1);
+            GTOS_A2W3_STEP(sa0, sw2, sa1, sw1, s + 2);
+            GTOS_A2W3_STEP(sa1, sw0, sa0, sw2, s + 3);
+            GTOS_A2W3_STEP(sa0, sw1, sa1, sw0, s + 4);
+            GTOS_A2W3_STEP(sa1, sw2, sa0, sw1, s + 5);
+        }
+    }
+    GTOS_VMCNT(0);                                         // the dummy prefetches of the last stages
+#undef GTOS_A2W3_STEP
+#undef GTOS_A2W3_DMA_W
+#undef GTOS_A2W3_DMA_A
+#undef GTOS_DMA1
+    if constexpr (DBG >= 2) {                              // measuring switches: one store per lane keeps the accumulators alive
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (t == 123.456f) a.gates[threadIdx.x] = f2bf(t);
+        return;
+    }
+    step_cell<1>(a, acc, m0, c0, wave, fr, fq);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
 // PERSISTENT forward step for the second GRU layer on the path tries (input gates gathered from the two per-node tables,
 // MODE 2 above), hs <= 256.  The step is memory-latency bound in the tile-per-workgroup kernel: every workgroup re-streams
 // its 96 KB W_hh slice and walks load -> barrier -> MFMA four times before it even starts the gathers of its epilogue,
@@ -1319,7 +1477,25 @@ extern "C" int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, i
         static const bool use_dbuf = !(getenv("GTOS_GRU_FWD_DBUF") && getenv("GTOS_GRU_FWD_DBUF")[0] == '0');
         static const int dbuf_nw = (getenv("GTOS_GRU_FWD_DBUF") && getenv("GTOS_GRU_FWD_DBUF")[0] == '4') ? 4 : 8;
         const int db = nw_launch ? (nw_launch == 2 ? 8 : nw_launch == 3 ? 4 : 0) : (use_dbuf ? dbuf_nw : 0);
-        if (db == 8 && in_dim % 64 == 0 && rows >= 8192) {
+        // GTOS_GRU_FWD_A2W3 (default 2): separate slot counts for the two operands of the two-slot kernel's stages -- 2 = THREE slots of activation
+        // rows and two of weight rows (88 KB per CU in flight, 144 KB of LDS), 1 = two and three (80 KB, 136 KB), 0 = two and two (56 KB: the
+        // kernel above).  Needs a stage count that is a multiple of 6; same bits.  Same box, the step: 80.46 / 80.31 (0), 79.10 / 79.33 (1), 78.72 / 79.21 ms (2).
+        static const int a2w3_mode = getenv("GTOS_GRU_FWD_A2W3") ? atoi(getenv("GTOS_GRU_FWD_A2W3")) : 2;
+        const int a2w3 = nw_launch ? (nw_launch == 6 ? 1 : nw_launch == 7 ? 2 : 0) : (use_dbuf ? a2w3_mode : 0);     // 1: A two / W three slots, 2: A three / W two
+        if (a2w3 && in_dim % 64 == 0 && (in_dim / 64 + hs / 64) % 6 == 0 && rows >= 8192) {
+            const long long nM8 = (rows + 255) / 256, nblk8 = ((nM8 + 7) / 8) * 8 * nC;
+            if (a2w3 == 2) {
+                if (dbg == 1) hipLaunchKernelGGL((gru_step_fwd_a2w3_kernel<1, true>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
+                else if (dbg == 2) hipLaunchKernelGGL((gru_step_fwd_a2w3_kernel<2, true>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
+                else if (dbg == 3) hipLaunchKernelGGL((gru_step_fwd_a2w3_kernel<3, true>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
+                else hipLaunchKernelGGL((gru_step_fwd_a2w3_kernel<0, true>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
+            }
+            else if (dbg == 1) hipLaunchKernelGGL((gru_step_fwd_a2w3_kernel<1, false>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
+            else if (dbg == 2) hipLaunchKernelGGL((gru_step_fwd_a2w3_kernel<2, false>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
+            else if (dbg == 3) hipLaunchKernelGGL((gru_step_fwd_a2w3_kernel<3, false>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
+            else hipLaunchKernelGGL((gru_step_fwd_a2w3_kernel<0, false>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
+        }
+        else if (db == 8 && in_dim % 64 == 0 && rows >= 8192) {
             const long long nM8 = (rows + 255) / 256, nblk8 = ((nM8 + 7) / 8) * 8 * nC;
             if (dbg == 1) hipLaunchKernelGGL((gru_step_fwd_dbuf_kernel<1, 8>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
             else if (dbg == 2) hipLaunchKernelGGL((gru_step_fwd_dbuf_kernel<2, 8>), dim3((unsigned)nblk8), dim3(512), 0, s, a);

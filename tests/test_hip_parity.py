@@ -2071,17 +2071,19 @@ torch.save(out.cpu(), sys.argv[1])
 
 @pytest.mark.parametrize("ind", [128, 512])
 def test_gru_forward_ring_kernel_bit_identical_to_single_stage(ind, tmp_path):
-    """The fused forward step's k loops -- gru_step_fwd_dbuf_kernel (the default: two slots of 64-k stages, whole 128-byte lines per DMA row,
+    """The fused forward step's k loops -- gru_step_fwd_a2w3_kernel (the default: three slots of activation rows + two of weight rows per 64-k
+    stage, and its two + three form), gru_step_fwd_dbuf_kernel (two slots of whole stages, whole 128-byte lines per DMA row,
     the next stage in flight; 256-row panels on eight waves for launches of at least 8192 rows, and the four-wave form), gru_step_fwd_ring_kernel
     (three-slot ring of 32-k stages; eight and four waves) -- against gru_step_fwd_kernel<1> (one 64-k stage): same lane -> channel map, same
     k order, same cell -> the SAME bits, through two GRU layers with inter-layer dropout, ragged lengths (steps of 20,011 .. ~4,000 rows: both
-    panel sizes run), a partial last row panel.  The switches are read once per process: five child processes."""
+    panel sizes run), a partial last row panel.  The switches are read once per process: seven child processes."""
     import subprocess
     import sys
     outs = []
-    for dbuf, ring, nw in (("1", "1", "8"), ("4", "1", "8"), ("0", "1", "8"), ("0", "1", "4"), ("0", "0", "4")):
-        f = str(tmp_path / ("dbuf%s_ring%s_%s.pt" % (dbuf, ring, nw)))
-        env = dict(os.environ, GTOS_GRU_FWD_DBUF=dbuf, GTOS_GRU_FWD_RING=ring, GTOS_GRU_FWD_NW=nw,
+    for a2w3, dbuf, ring, nw in (("2", "1", "1", "8"), ("1", "1", "1", "8"), ("0", "1", "1", "8"), ("0", "4", "1", "8"), ("0", "0", "1", "8"),
+                                 ("0", "0", "1", "4"), ("0", "0", "0", "4")):
+        f = str(tmp_path / ("a%s_dbuf%s_ring%s_%s.pt" % (a2w3, dbuf, ring, nw)))
+        env = dict(os.environ, GTOS_GRU_FWD_A2W3=a2w3, GTOS_GRU_FWD_DBUF=dbuf, GTOS_GRU_FWD_RING=ring, GTOS_GRU_FWD_NW=nw,
                    PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         r = subprocess.run([sys.executable, "-c", _RING_CHILD, f, str(ind)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
         assert r.returncode == 0, r.stdout.decode(errors="replace")[-3000:]

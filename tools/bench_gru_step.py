@@ -99,7 +99,7 @@ def dbuf(a):
                      ptr(b["wh"]), ptr(b["bh"]), ptr(out[0]), A, None, hs, None, ptr(out[1]), None, 2 * hs, 0.0, 0, 0,
                      1 | (dbg << 8) | (nw << 16), stream())
             outs = {}
-            for name, nw in (("ring, eight waves", 8), ("two slots of 64-k, 8 waves", 2), ("two slots of 64-k, 4 waves", 3)):
+            for name, nw in (("ring, eight waves", 8), ("two slots of 64-k, 8 waves", 2), ("two slots of 64-k, 4 waves", 3), ("A two slots + W three slots", 6), ("A three slots + W two slots", 7)):
                 out = (torch.zeros(A, hs, device=dev, dtype=bf), torch.zeros(A, 4 * hs, device=dev, dtype=bf))
                 launch(0, nw, out)
                 torch.cuda.synchronize()
