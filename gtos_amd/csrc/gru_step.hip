@@ -24,6 +24,12 @@
 __attribute__((visibility("hidden"))) const void* gtos_zero_block();      // gemm.hip: 256 zero bytes in global memory
 
 #define GTOS_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))
+// vmcnt(n) AND lgkmcnt(0): in front of a barrier after which somebody's LDS-DMA overwrites a slot this wave has been reading.  hipcc sinks the
+// MFMAs of a stage -- and with them the lgkmcnt wait of their fragment reads -- below the next s_barrier; the reads would then still be
+// queued when another wave, past the barrier, starts the DMA into that slot.  (Found by test_gru_backward_step_input_gradient_role_vs_torch
+// on the backward step's pipelined k loop, whose weight rows come back from L1 within the time a queued ds_read waits: 1,200 of 40,000 rows
+// differed from run to run.  The forward kernels' operands take an L2 / HBM round trip and never showed it; they wait the same way now.)
+#define GTOS_VMCNT_LDS(n) __builtin_amdgcn_s_waitcnt(0x0070 | ((n) & 15) | (((n) >> 4) << 14))
 
 namespace {
 
@@ -695,7 +701,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gru_step_fwd_dbuf_kernel(StepArgs 
 #define GTOS_DBUF_STEP(slot_s, slot_d, s_)                                                                                    \
     {                                                                                                                         \
         if constexpr (DBG == 10) { GTOS_VMCNT(4 + NBP); }  /* (DMA alone with TWO stages in flight: nobody reads what lands) */  \
-        else { GTOS_VMCNT(0); }                            /* own pieces of stage s_ */                                       \
+        else { GTOS_VMCNT_LDS(0); }                        /* own pieces of stage s_; own fragment reads of stage s_ - 1 done */ \
         __builtin_amdgcn_s_barrier();                      /* everybody's; and everybody is past its reads of stage s_ - 1 */ \
         GTOS_DBUF_DMA(slot_d, (s_) + 1);                                                                                      \
         if constexpr (DBG != 3 && DBG != 7 && DBG != 10) {                                                                             \
@@ -833,7 +839,7 @@ __global__ __launch_bounds__(512, 2) void gru_step_fwd_a2w3_kernel(StepArgs a) {
 // stage s_: A in sa_, W in sw_; A(s_+1) goes to sa_n (held A(s_-1)), W(s_+2) to sw_n (held W(s_-1))
 #define GTOS_A2W3_STEP(sa_, sw_, sa_n, sw_n, s_)                                                                              \
     {                                                                                                                         \
-        if constexpr (A3) { GTOS_VMCNT(4); } else { GTOS_VMCNT(3); }   /* own pieces of A(s_) and W(s_); the newest stage issued may still fly */ \
+        if constexpr (A3) { GTOS_VMCNT_LDS(4); } else { GTOS_VMCNT_LDS(3); }   /* own pieces of A(s_), W(s_) (the newest stage issued may still fly); own reads of s_ - 1 done */ \
         __builtin_amdgcn_s_barrier();                      /* everybody's; and everybody is past its reads of stage s_ - 1 */ \
         if constexpr (A3) {                                                                                                   \
             GTOS_A2W3_DMA_W(sw_n, (s_) + 1);                                                                                  \
@@ -1122,8 +1128,65 @@ __device__ __forceinline__ void dma_wt(const bf16_t* __restrict__ w, int64_t ld,
 // Role B of the backward step launch (StepBwdArgs.dinp): one 128-row x 128-column tile of the previous step's input gradient,
 // dinp[m0.., n0..] = d4_prev[m0.., 0:3hs] x wi_t[n0.., 0:3hs]^T.  Same single-stage k loop as the recurrent product of role A (the two
 // 64-row weight blocks in the permuted order of dma_wt, so a lane ends up with 16 consecutive columns of each half).
-template <int DBG, int NS>
-__device__ __forceinline__ void dinp_tile(const StepBwdArgs& a, int m0, int n0, char* As, char* Bs, int wave, int lane) {
+// The k loop of both roles of the backward step launch with the ACTIVATION operand one stage ahead (round 5, after the forward step's
+// measurements: these loops wait for round trips, and the longer one is the row panel's): two slots for the 128-row panel of d4_prev (2 x 16
+// KB), ONE for the weight rows (NB x 8 KB) -- 40 / 48 KB per workgroup, so three workgroups per CU stay (the fully double-buffered form
+// needed 64 KB, ran two per CU and was slower: call 22).  Per stage: W(s) is issued, then everybody waits for A(s) (issued a stage ago) and
+// W(s), A(s+1) goes into the other slot, the stage is multiplied, and a second barrier frees the weight slot.  Same stage and k order as the
+// single-stage loop: the same bits.  SKIP: the A operand skips the d n_x block of d4 (the recurrent product).  nsub <= NB weight pieces are
+// valid (uniform per workgroup); the pieces past them are neither fetched nor multiplied.
+// Measured against the single-stage loops (GTOS_GRU_BWD_DBG=3) on one box, call 36: 1065 vs 1080 us (layer 1) and 882 vs 874 us (layer 0) per
+// 434 k-row launch alone, GRU backward 29.9 vs 30.3 ms and the step 78.6 / 78.8 vs 78.8 / 79.2 ms.
+template <int NB, bool SKIP>
+__device__ __forceinline__ void kloop_a2(const bf16_t* __restrict__ A, int64_t lda, int rows_total, int m0, const bf16_t* __restrict__ W,
+                                         int64_t ldw, int n0, int nsub, int hs, const U128* __restrict__ Z, char* a0, char* a1, char* ws,
+                                         f32x4_t (&acc)[2][NB * 4], int wave, int lane) {
+    const int fr = lane & 15, fq = lane >> 4, nst = 3 * hs / BK;
+#define GTOS_KA_A(slot, s_)                                                                                                   \
+    {                                                                                                                         \
+        const int kk_ = min((s_), nst - 1) * BK, ak_ = SKIP ? (kk_ < 2 * hs ? kk_ : kk_ + hs) : kk_;                            \
+        dma_rows(A, Z, lda, rows_total, m0, ak_, ak_ + BK, (slot), wave, lane);                                               \
+    }
+#define GTOS_KA_STEP(cur, nxt, s_)                                                                                            \
+    {                                                                                                                         \
+        _Pragma("unroll") for (int h = 0; h < NB; ++h)                                                                        \
+            if (h < nsub) dma_wt(W, ldw, n0 + h * TC, (s_) * BK, ws + h * TC * ROWB, wave, lane);                             \
+        GTOS_VMCNT_LDS(0);                                                                                                    \
+        __builtin_amdgcn_s_barrier();                      /* A(s_) and W(s_) of every wave have landed */                    \
+        GTOS_KA_A(nxt, (s_) + 1);                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                                    \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                                    \
+            bf16x8_t fa[2], fb[4];                                                                                            \
+            _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                                  \
+                fa[mt] = *reinterpret_cast<const bf16x8_t*>((cur) + lds_off(wave * 32 + mt * 16 + fr, ks * 4 + fq));          \
+            _Pragma("unroll") for (int h = 0; h < NB; ++h) {                                                                  \
+                if (h < nsub) {                                                                                               \
+                    _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                          \
+                        fb[nt] = *reinterpret_cast<const bf16x8_t*>(ws + h * TC * ROWB + lds_off(nt * 16 + fr, ks * 4 + fq)); \
+                    _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                          \
+                        _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                      \
+                            acc[mt][h * 4 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][h * 4 + nt], 0, 0, 0); \
+                }                                                                                                             \
+            }                                                                                                                 \
+        }                                                                                                                     \
+        __builtin_amdgcn_s_waitcnt(0xc07f);                /* lgkmcnt(0): this wave's fragment reads have COMPLETED, not just been issued */ \
+        __builtin_amdgcn_s_barrier();                      /* the weight slot (and this panel slot) are free again */         \
+    }
+    GTOS_KA_A(a0, 0);
+    int s = 0;
+    for (; s + 2 <= nst; s += 2) {
+        GTOS_KA_STEP(a0, a1, s);
+        GTOS_KA_STEP(a1, a0, s + 1);
+    }
+    if (s < nst) GTOS_KA_STEP(a0, a1, s);
+    GTOS_VMCNT(0);                                         // the dummy prefetch of the last stage
+    __builtin_amdgcn_s_barrier();
+#undef GTOS_KA_STEP
+#undef GTOS_KA_A
+}
+
+template <int DBG, int NS, bool PIPE>
+__device__ __forceinline__ void dinp_tile(const StepBwdArgs& a, int m0, int n0, char* As, char* Bs, char* A1, int wave, int lane) {
     if (m0 >= a.rows_prev) return;
     const int fr = lane & 15, fq = lane >> 4, hs = a.hs;
     const U128* Z = static_cast<const U128*>(a.zeros);
@@ -1133,6 +1196,10 @@ __device__ __forceinline__ void dinp_tile(const StepBwdArgs& a, int m0, int n0, 
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < NS * 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if constexpr (PIPE) {
+        if constexpr (DBG != 1)
+            kloop_a2<NS, false>(a.d4_prev, 4 * (int64_t)hs, a.rows_prev, m0, a.wi_t, 3 * (int64_t)hs, n0, nsub, hs, Z, As, A1, Bs, acc, wave, lane);
+    } else
     for (int kk = 0; kk < (DBG == 1 ? 0 : 3 * hs); kk += BK) {
         dma_rows(a.d4_prev, Z, 4 * (int64_t)hs, a.rows_prev, m0, kk, kk + BK, As, wave, lane);
 #pragma unroll
@@ -1203,20 +1270,25 @@ __device__ __forceinline__ void dinp_tile(const StepBwdArgs& a, int m0, int n0, 
 // step's rows fetched half as often) was built and measured in round 5: role B alone 400 vs 409-432 us per 434 k-row launch of layer 1, the
 // whole launch 1128 vs 1046-1059 us at two workgroups per CU (202 registers) and 2314 us at three (124 bytes of scratch per lane): fewer
 // fetched bytes do not shorten these k loops (profiles/r5_ab_switches.txt, call 21).
-// DBG: measuring switches (GTOS_GRU_BWD_DBG, packed-path launches): 1 = no k loops, 2 = the k loops alone.  Call 18, 434,624 rows: layer 1
-// 1040 us = 530 (no k loops) + 528 (k loops alone); layer 0 860 = 524 + 363 -- the launch costs the sum of its two parts here as well.
-// Double-buffered k loops in both roles (two 32 KB slots, the next stage in flight; 64 KB of LDS = two workgroups per CU) were built and
-// measured (call 22, against the single-stage form on the same box): 1098-1126 vs 1072-1082 us (layer 1), 901-928 vs 867 (layer 0),
-// 31.8 vs 30.2 ms of GRU backward in the step -- three single-stage workgroups per CU cover each other's loads better than two pipelined
-// ones.  Not kept.
+// DBG: measuring switches (GTOS_GRU_BWD_DBG, packed-path launches): 1 = no k loops, 2 = the k loops alone, 3 = the production code with the
+// single-stage k loops (what ran until the end of round 5).  Call 18 (single-stage loops), 434,624 rows: layer 1 1040 us = 530 (no k loops) +
+// 528 (k loops alone); layer 0 860 = 524 + 363 -- the launch costs the sum of its two parts here as well.
+// Fully double-buffered k loops (two 32 KB slots per role: 64 KB of LDS = two workgroups per CU) were built and measured (call 22): 1098-1126
+// vs 1072-1082 us (layer 1), 901-928 vs 867 (layer 0), 31.8 vs 30.2 ms of GRU backward in the step -- the third workgroup per CU is worth
+// more than the second weight slot.  What runs now keeps it: kloop_a2 above.
 template <bool HN, int DBG, int NS = 2>
 __global__ __launch_bounds__(256, 3) void gru_step_bwd_kernel(StepBwdArgs a) {
+    constexpr bool PIPE = !HN && DBG != 3;                 // the row panel one stage ahead (kloop_a2); DBG 3: the single-stage loops, for comparison
     if (a.p_drop > 0.f) a.seed = live_seed(a.seed);
-    __shared__ __attribute__((aligned(16))) char lds[A_BYTES + NS * TC * ROWB];
+    // separate LDS objects for the row-panel slots and the weight slot: hipcc's wait-count pass tracks LDS-DMA per object (with the weight rows
+    // behind the panel in one array it drained vmcnt(0) in front of every fragment read of the weights while the next panel was in flight)
+    __shared__ __attribute__((aligned(16))) char lds[A_BYTES];
+    __shared__ __attribute__((aligned(16))) char lds_w[NS * TC * ROWB];
+    __shared__ __attribute__((aligned(16))) char lds_a1[PIPE ? A_BYTES : 16];      // the second slot of the row panel
     __shared__ __attribute__((aligned(16))) char hn_lds[HN ? 256 * 2 * 32 : 16];  // per lane 2 row blocks x 16 channels bf16 (16 KB)
     __shared__ float btab[4 * TC];
     char* As = lds;
-    char* Bs = lds + A_BYTES;
+    char* Bs = lds_w;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fr = lane & 15, fq = lane >> 4;
     const int hs = a.hs, nC = hs / TC;
@@ -1224,7 +1296,7 @@ __global__ __launch_bounds__(256, 3) void gru_step_bwd_kernel(StepBwdArgs a) {
     const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
     // the workgroups of a 128-row panel -- nC cell tiles (role A), then nB input-gradient tiles (role B) -- run back to back on one XCD
     const int m0 = ((sq / per) * 8 + xcd) * TM, role = sq % per;
-    if (role >= nC) { dinp_tile<DBG, NS>(a, m0, (role - nC) * NS * TC, As, Bs, wave, lane); return; }
+    if (role >= nC) { dinp_tile<DBG, NS, PIPE>(a, m0, (role - nC) * NS * TC, As, Bs, lds_a1, wave, lane); return; }
     const int c0 = role * TC;
     if (m0 >= a.rows) return;
     const U128* Z = static_cast<const U128*>(a.zeros);
@@ -1291,6 +1363,8 @@ __global__ __launch_bounds__(256, 3) void gru_step_bwd_kernel(StepBwdArgs a) {
             }
             __syncthreads();
         }
+    } else if (PIPE && DBG != 1 && a.d4_prev && m0 < a.rows_prev) {
+        kloop_a2<1, true>(a.d4_prev, 4 * (int64_t)hs, a.rows_prev, m0, a.wh_t, 3 * (int64_t)hs, c0, 1, hs, Z, As, lds_a1, Bs, acc, wave, lane);
     } else if (DBG != 1 && a.d4_prev && m0 < a.rows_prev) {
         for (int kk = 0; kk < 3 * hs; kk += BK) {
             const int ak = kk < 2 * hs ? kk : kk + hs;                 // skip the d n_x block of d4
@@ -1578,6 +1652,7 @@ extern "C" int gtos_gru_step_bwd_fused(int rows, int hs, const void* d4_prev, in
     if (w_hn) GTOS_BWD_LAUNCH(true, 0);
     else if (dbg == 1) GTOS_BWD_LAUNCH(false, 1);
     else if (dbg == 2) GTOS_BWD_LAUNCH(false, 2);
+    else if (dbg == 3) GTOS_BWD_LAUNCH(false, 3);
     else GTOS_BWD_LAUNCH(false, 0);
 #undef GTOS_BWD_LAUNCH
     GTOS_CHECK_LAUNCH();
