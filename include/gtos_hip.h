@@ -200,8 +200,9 @@ int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, int in_dim, 
  * [2hs, 3hs) of W_hh ([hs, hs], K-contiguous) and of b_hh and recomputes hn = h_prev W_hn^T + b_hn on the MFMA, rounded like the forward's.
  * Only bit 0..7 of save_hn are the flag; bits 8 and up are ZERO for every product call (tools/bench_gru_step.py passes the step kernels'
  * measuring switches there: bits 8-15 the switch, 16-19 the kernel form, 20+ a delay in us -- results are garbage under a switch).
- * Which k loop runs for x != NULL (all give the same bits): gru_step_fwd_dbuf_kernel (two slots of 64-k stages, 256-row panels; rows >= 8192
- * and in_dim % 64 == 0), else gru_step_fwd_ring_kernel (in_dim % 32 == 0), else gru_step_fwd_kernel<1>; GTOS_GRU_FWD_DBUF / _RING / _NW. */
+ * Which k loop runs for x != NULL (all give the same bits): gru_step_fwd_a2w3_kernel (64-k stages, three slots of activation rows + two of
+ * weight rows, 256-row panels; rows >= 8192 and (in_dim + hs) / 64 a multiple of 6), else gru_step_fwd_dbuf_kernel (two slots of whole stages;
+ * in_dim % 64 == 0), else gru_step_fwd_ring_kernel (in_dim % 32 == 0), else gru_step_fwd_kernel<1>; GTOS_GRU_FWD_A2W3 / _DBUF / _RING / _NW. */
 
 /* Fused backward GRU step, bf16 only, hs % 64 == 0 (gru_step.hip).  d4 [rows,4hs] = d r | d z | d n_x | d n_h in ONE
  * buffer (d(xg) = columns 0..3hs, d(hg) = columns 0..2hs and 3hs..4hs).  First adds d(hg) W_hh of the step processed
