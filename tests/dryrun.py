@@ -394,6 +394,13 @@ def DryRun():
     patch(torch.cuda, "current_device", lambda: 0)
     patch(torch.Tensor, "is_cuda", property(lambda self: True))
     patch(torch.Tensor, "record_stream", lambda self, s: None)
+    # no kernel runs, so what a kernel would have written stays what the allocator handed out: zeros instead of whatever the heap held, or the
+    # glue downstream of a kernel (top-k token ids of the beam search into the vocabulary) depends on stale memory -- the beam-search dry run
+    # failed one run in three with an IndexError from an out-of-vocabulary id picked out of garbage
+    real_empty, real_empty_like, real_new_empty = torch.empty, torch.empty_like, torch.Tensor.new_empty
+    patch(torch, "empty", lambda *a, **k: real_empty(*a, **k).zero_())
+    patch(torch, "empty_like", lambda *a, **k: real_empty_like(*a, **k).zero_())
+    patch(torch.Tensor, "new_empty", lambda self, *a, **k: real_new_empty(self, *a, **k).zero_())
     try:
         yield rec
     finally:
