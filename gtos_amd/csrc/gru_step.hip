@@ -1482,6 +1482,283 @@ __global__ __launch_bounds__(256, 3) void gru_step_bwd_kernel(StepBwdArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 6: the backward step launch on 256-row panels, eight waves, BOTH roles in one workgroup.
+//
+// gru_step_bwd_kernel above runs a 128-row panel as hs/64 cell workgroups (role A: recurrent product, K = 3hs, 64 output channels, then
+// the cell) plus n_in/128 input-gradient workgroups (role B: K = 3hs, 128 output columns): eight workgroups at layer 1, each pulling the
+// panel's d4_prev rows (196 KB) and its own weight rows through LDS -- 2.75 MB of LDS-DMA per 128 rows, 9.3 GB per 434 k-row launch, with at
+// most one 16 KB panel stage + one weight stage in flight per workgroup.  The k loops take as long as the cells (528 vs 530 us alone) and the
+// two add up: what the launch waits for is operand delivery through the CUs' vector-memory path.
+// Here ONE workgroup owns 256 rows x (64 state channels + n_in / (hs/64) input columns): it walks the four blocks of d4_prev
+// (d r | d z | d n_x | d n_h) ONCE, 64 k per stage, and feeds both products from the same fragment reads of the row panel --
+//     blocks d r, d z:  role A (W_hh^T rows) and role B (W_ih^T rows);   d n_x: role B only;   d n_h: role A only
+// -- so a panel's rows go through LDS hs/64 times instead of hs/64 + n_in/128 times and every weight row serves 256 rows instead of 128:
+// 3.2 MB of LDS-DMA per 256 rows at layer 1 (-42 %).  The k loop is the forward step's (gru_step_fwd_a2w3_kernel): three slots of panel
+// stages (3 x 32 KB) + two of weight stages, W(s+1) then A(s+2) issued per stage, vmcnt(4) = "A(s), W(s) landed": 80-88 KB in flight per CU.
+// Each accumulator sees the MFMAs of its role's blocks in the old order with the old operands: role A's d4 / dh / bias sums and role B's
+// dinp are the SAME BITS as gru_step_bwd_kernel's (test_gru_backward_step_wide_kernel_bit_identical).
+// NBT: 16-column blocks of role B per workgroup (n_in = (hs/64) * 16 * NBT; 8 at layer 1, 2 at layer 0, 0 = no role B); a lane ends up with
+// 4 * NBT consecutive input columns of a row (weight rows DMA'd in the order lds_row = nt*16 + q*4 + e <-> column = q*4*NBT + nt*4 + e).
+// Every wave issues the same number of DMA instructions per stage whatever the block (the wait counts are immediates): pieces a block does
+// not need read the zero block.  DBG (GTOS_GRU_BWD_DBG): 1 = no k loop, 2 = the k loop alone.
+template <int NBT, int DBG>
+__global__ __launch_bounds__(512, 2) void gru_step_bwd8_kernel(StepBwdArgs a) {
+    constexpr int TMW = 256, AW = TMW * ROWB;                                  // a stage of the row panel: 32 KB
+    constexpr int WP = (TC / 8 + NBT * 2 + 7) / 8;                             // weight pieces (8 rows x 128 B) per wave and stage: 1 / 2 / 2 / 3
+    constexpr int WB = WP * 8 * 1024;                                          // a stage of weight rows: 8 / 16 / 16 / 24 KB
+    constexpr int NBC = NBT * 16;                                              // role B columns of this workgroup
+    if (a.p_drop > 0.f) a.seed = live_seed(a.seed);
+    __shared__ __attribute__((aligned(16))) char sa0[AW];
+    __shared__ __attribute__((aligned(16))) char sa1[AW];
+    __shared__ __attribute__((aligned(16))) char sa2[AW];
+    __shared__ __attribute__((aligned(16))) char sw0[WB];
+    __shared__ __attribute__((aligned(16))) char sw1[WB];
+    __shared__ float btab[4 * TC];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int hs = a.hs, nC = hs / TC, nkb = hs / BK;
+    const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
+    const int m0 = ((sq / nC) * 8 + xcd) * TMW, ct = sq % nC, c0 = ct * TC, n0 = ct * NBC;
+    const bool has_a = m0 < a.rows;                                            // the panel has cell rows
+    const bool has_k = DBG != 1 && a.d4_prev != nullptr && m0 < a.rows_prev;   // ... rows of the step processed just before
+    const bool has_b = NBT > 0 && a.dinp != nullptr && has_k;
+    if (!has_a && !has_b) return;
+    const char* Z = static_cast<const char*>(a.zeros);
+    if (a.bias_part && threadIdx.x < 4 * TC) btab[threadIdx.x] = 0.f;
+
+    f32x4_t acc[2][4 + NBT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4 + NBT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    if (has_k) {
+        const int nst = 4 * nkb;
+        // per-lane sources: this wave's 4 pieces of a panel stage (rows past rows_prev: zeros), its role A weight piece, its role B pieces
+        const char* ap[4];
+        const char* Ab = reinterpret_cast<const char*>(a.d4_prev + (int64_t)m0 * 4 * hs);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rl = (i * 8 + wave) * 8 + (lane >> 3);
+            const uint32_t c = (uint32_t)(((lane & 7) ^ swz(rl)) << 4);
+            ap[i] = (m0 + rl < a.rows_prev) ? Ab + (uint32_t)rl * (uint32_t)(hs * 8) + c : nullptr;
+        }
+        const char* wa;                                                        // role A: piece `wave` of the 8 (64 rows of W_hh^T)
+        {
+            const int rl = wave * 8 + (lane >> 3);
+            const int nt = (rl >> 4) & 3, q = (rl >> 2) & 3, e = rl & 3;
+            const uint32_t c = (uint32_t)(((lane & 7) ^ swz(rl)) << 4);
+            wa = has_a ? reinterpret_cast<const char*>(a.wh_t) + (uint32_t)(c0 + q * 16 + nt * 4 + e) * (uint32_t)(hs * 6) + c : nullptr;
+        }
+        const char* wb[WP > 1 ? WP - 1 : 1];                                   // role B: pieces wave, 8 + wave of the 2 * NBT (NBC rows of W_ih^T)
+#pragma unroll
+        for (int i = 0; i < WP - 1; ++i) {
+            const int pj = i * 8 + wave, rb = pj * 8 + (lane >> 3);
+            const int nt = rb >> 4, q = (rb >> 2) & 3, e = rb & 3;
+            const uint32_t c = (uint32_t)(((lane & 7) ^ swz(rb)) << 4);
+            wb[i] = (has_b && pj < NBT * 2) ? reinterpret_cast<const char*>(a.wi_t) + (uint32_t)(n0 + q * 4 * NBT + nt * 4 + e) * (uint32_t)(hs * 6) + c : nullptr;
+        }
+#define GTOS_DMA1(src, dst)                                                                                                   \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),                                    \
+                                     (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+// stage s_ of the row panel = columns s_ * 64 .. of d4_prev (the four blocks are contiguous); past the last stage: zeros, never multiplied
+#define GTOS_B8_DMA_A(slot, s_)                                                                                               \
+    {                                                                                                                         \
+        const bool in_ = (s_) < nst;                                                                                          \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                                      \
+            GTOS_DMA1((in_ && ap[i_]) ? ap[i_] + (s_) * ROWB : Z, (slot) + (i_ * 8 + wave) * 1024);                           \
+    }
+// weight rows of stage s_: W_hh^T has the k order (r, z, n_h) -- block 2 of d4 is not its operand --, W_ih^T the order (r, z, n_x)
+#define GTOS_B8_DMA_W(slot, s_)                                                                                               \
+    {                                                                                                                         \
+        const int blk_ = (s_) / nkb;                                                                                          \
+        const bool ua_ = (s_) < nst && blk_ != 2 && wa != nullptr;                                                            \
+        GTOS_DMA1(ua_ ? wa + ((s_) - (blk_ == 3 ? nkb : 0)) * ROWB : Z, (slot) + wave * 1024);                                \
+        _Pragma("unroll") for (int i_ = 0; i_ < WP - 1; ++i_)                                                                 \
+            GTOS_DMA1((blk_ < 3 && wb[i_]) ? wb[i_] + (s_) * ROWB : Z, (slot) + ((i_ + 1) * 8 + wave) * 1024);                \
+    }
+// stage s_: A in sa_, W in sw_; W(s_+1) goes to sw_n (held W(s_-1)), A(s_+2) to sa_n (held A(s_-1))
+#define GTOS_B8_STEP(sa_, sw_, sa_n, sw_n, s_)                                                                                \
+    {                                                                                                                         \
+        GTOS_VMCNT_LDS(4);                                 /* own pieces of A(s_), W(s_) landed (A(s_+1) may fly); own reads of s_ - 1 done */ \
+        __builtin_amdgcn_s_barrier();                      /* everybody's; and everybody is past its reads of stage s_ - 1 */ \
+        GTOS_B8_DMA_W(sw_n, (s_) + 1);                                                                                        \
+        GTOS_B8_DMA_A(sa_n, (s_) + 2);                                                                                        \
+        const int blk_s = (s_) / nkb;                                                                                         \
+        const bool do_a = has_a && blk_s != 2, do_b = NBT > 0 && has_b && blk_s != 3;                                         \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                                    \
+            bf16x8_t fa[2];                                                                                                   \
+            _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                                  \
+                fa[mt] = *reinterpret_cast<const bf16x8_t*>((sa_) + lds_off(wave * 32 + mt * 16 + fr, ks * 4 + fq));          \
+            if (do_a) {                                                                                                       \
+                bf16x8_t fb[4];                                                                                               \
+                _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                              \
+                    fb[nt] = *reinterpret_cast<const bf16x8_t*>((sw_) + lds_off(nt * 16 + fr, ks * 4 + fq));                  \
+                _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                              \
+                    _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                          \
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);          \
+            }                                                                                                                 \
+            if (do_b) {                                                                                                       \
+                bf16x8_t fc[NBT > 0 ? NBT : 1];                                                                               \
+                _Pragma("unroll") for (int t = 0; t < NBT; ++t)                                                               \
+                    fc[t] = *reinterpret_cast<const bf16x8_t*>((sw_) + lds_off(TC + t * 16 + fr, ks * 4 + fq));               \
+                _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                              \
+                    _Pragma("unroll") for (int t = 0; t < NBT; ++t)                                                           \
+                        acc[mt][4 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[t], fa[mt], acc[mt][4 + t], 0, 0, 0);     \
+            }                                                                                                                 \
+        }                                                                                                                     \
+    }
+        GTOS_B8_DMA_A(sa0, 0);
+        GTOS_B8_DMA_W(sw0, 0);
+        GTOS_B8_DMA_A(sa1, 1);
+        int s = 0;
+        for (; s + 6 <= nst; s += 6) {                     // A(s) in slot s % 3, W(s) in slot s % 2
+            GTOS_B8_STEP(sa0, sw0, sa2, sw1, s);
+            GTOS_B8_STEP(sa1, sw1, sa0, sw0, s + 1);
+            GTOS_B8_STEP(sa2, sw0, sa1, sw1, s + 2);
+            GTOS_B8_STEP(sa0, sw1, sa2, sw0, s + 3);
+            GTOS_B8_STEP(sa1, sw0, sa0, sw1, s + 4);
+            GTOS_B8_STEP(sa2, sw1, sa1, sw0, s + 5);
+        }
+        if (nst - s >= 2) {                                // nst = 4 * hs / 64: a remainder of 0, 2 or 4 stages (hs = 256: 16 = 12 + 4)
+            GTOS_B8_STEP(sa0, sw0, sa2, sw1, s);
+            GTOS_B8_STEP(sa1, sw1, sa0, sw0, s + 1);
+        }
+        if (nst - s >= 4) {
+            GTOS_B8_STEP(sa2, sw0, sa1, sw1, s + 2);
+            GTOS_B8_STEP(sa0, sw1, sa2, sw0, s + 3);
+        }
+        GTOS_VMCNT(0);                                     // the zero-block prefetches past the last stage
+#undef GTOS_B8_STEP
+#undef GTOS_B8_DMA_W
+#undef GTOS_B8_DMA_A
+#undef GTOS_DMA1
+    }
+    if constexpr (DBG == 2) {                              // measuring switch: the k loop alone
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4 + NBT; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (t == 123.456f) a.d4[threadIdx.x] = f2bf(t);
+        return;
+    }
+    __syncthreads();                                       // btab zeroed before anyone adds to it (no k loop: no barrier so far)
+
+    if constexpr (NBT > 0) {
+        if (has_b) {                                       // role B: the previous step's input gradient, 4 * NBT consecutive columns per lane and row
+            const float ks_in = a.p_in > 0.f ? 1.f / (1.f - a.p_in) : 1.f;
+            const uint64_t seed_in = a.p_in > 0.f ? live_seed(a.seed_in) : 0;
+            const int nb = n0 + fq * 4 * NBT;
+            uint4 oldv[2][NBT / 2];                        // direction 1 adds to what direction 0 wrote: every piece in flight before the first is used
+            if (a.dinp_acc) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int m = min(m0 + wave * 32 + mt * 16 + fr, a.rows_prev - 1);
+#pragma unroll
+                    for (int h = 0; h < NBT / 2; ++h) oldv[mt][h] = *reinterpret_cast<const uint4*>(a.dinp + (int64_t)m * a.ld_dinp + nb + h * 8);
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int m = m0 + wave * 32 + mt * 16 + fr;
+                if (m >= a.rows_prev) continue;
+                bf16_t* dp = a.dinp + (int64_t)m * a.ld_dinp + nb;
+#pragma unroll
+                for (int h = 0; h < NBT / 2; ++h) {        // 8 columns (16 bytes) at a time
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = acc[mt][4 + h * 2 + (i >> 2)][i & 3];
+                    if (a.p_in > 0.f) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i)
+                            v[i] = drop_keep(seed_in, (uint64_t)(a.in_drop_base + (int64_t)m * a.n_in + nb + h * 8 + i), a.p_in) ? v[i] * ks_in : 0.f;
+                    }
+                    if (a.dinp_acc) {
+                        const uint4 o = oldv[mt][h];
+                        v[0] += lo_bf(o.x); v[1] += hi_bf(o.x); v[2] += lo_bf(o.y); v[3] += hi_bf(o.y);
+                        v[4] += lo_bf(o.z); v[5] += hi_bf(o.z); v[6] += lo_bf(o.w); v[7] += hi_bf(o.w);
+                    }
+                    Vec8<bf16_t>::store(dp + h * 8, v);
+                }
+            }
+        }
+    }
+    if (!has_a) return;
+
+    const int cb = c0 + fq * 16;
+    const float ks = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        // rows past the end read the last valid row and contribute zeros: every lane stays active (the bias sums are DPP reductions)
+        const int m_raw = m0 + wave * 32 + mt * 16 + fr;
+        const bool valid = m_raw < a.rows;
+        const int m = valid ? m_raw : a.rows - 1;
+        float gr[16], gz[16], gn[16], hn[16], hp[16], g[16];
+        const bf16_t* gp = a.gates + (int64_t)m * 4 * hs + cb;
+        ld16(gp, gr); ld16(gp + hs, gz); ld16(gp + 2 * hs, gn); ld16(gp + 3 * hs, hn);
+        ld16(a.hprev + (int64_t)m * hs + cb, hp);
+        float* dhp = static_cast<float*>(a.dh) + (int64_t)m * a.ld_dh + cb;
+        bf16_t* dhb = static_cast<bf16_t*>(a.dh) + (int64_t)m * a.ld_dh + cb;
+        if (a.dh_bf16) ld16(dhb, g); else ldf16(dhp, g);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) g[i] += acc[mt][i >> 2][i & 3];
+        if (a.dy) {
+            float dyv[16];
+            ld16(a.dy + (int64_t)m * a.ldy + cb, dyv);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float t2 = dyv[i];
+                if (a.p_drop > 0.f) t2 = drop_keep(a.seed, (uint64_t)(a.drop_base + (int64_t)m * a.ldy + cb + i), a.p_drop) ? t2 * ks : 0.f;
+                g[i] += t2;
+            }
+        }
+        float dr_[16], dz_[16], dn_[16], dhn[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float dn = g[i] * (1.f - gz[i]);
+            const float dz = g[i] * (hp[i] - gn[i]);
+            dn_[i] = dn * (1.f - gn[i] * gn[i]);
+            dhn[i] = dn_[i] * gr[i];
+            dr_[i] = dn_[i] * hn[i] * gr[i] * (1.f - gr[i]);
+            dz_[i] = dz * gz[i] * (1.f - gz[i]);
+            g[i] *= gz[i];                                             // the direct path h_prev -> h
+            if (!valid) { dn_[i] = 0.f; dhn[i] = 0.f; dr_[i] = 0.f; dz_[i] = 0.f; }
+        }
+        if (valid) {
+            if (a.dh_bf16) {
+                st16(dhb, g);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<float4*>(dhp + i * 4) = make_float4(g[i * 4], g[i * 4 + 1], g[i * 4 + 2], g[i * 4 + 3]);
+            }
+            bf16_t* dp = a.d4 + (int64_t)m * 4 * hs + cb;
+            st16(dp, dr_); st16(dp + hs, dz_); st16(dp + 2 * hs, dn_); st16(dp + 3 * hs, dhn);
+            if (a.hp_out) st16(a.hp_out + (int64_t)m * hs + cb, hp);
+        }
+        if (a.bias_part) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float t0 = row16_sum(bf2f(f2bf(dr_[i]))), t1 = row16_sum(bf2f(f2bf(dz_[i])));
+                const float t2 = row16_sum(bf2f(f2bf(dn_[i]))), t3 = row16_sum(bf2f(f2bf(dhn[i])));
+                if (fr == 0) {
+                    atomicAdd(&btab[0 * TC + fq * 16 + i], t0); atomicAdd(&btab[1 * TC + fq * 16 + i], t1);
+                    atomicAdd(&btab[2 * TC + fq * 16 + i], t2); atomicAdd(&btab[3 * TC + fq * 16 + i], t3);
+                }
+            }
+        }
+    }
+    if (a.bias_part) {
+        __syncthreads();
+        if (threadIdx.x < 4 * TC) {
+            const int q = threadIdx.x >> 6, ch = threadIdx.x & 63;
+            atomicAdd(a.bias_part + (int64_t)(blockIdx.x % a.n_partials) * 4 * hs + q * hs + c0 + ch, btab[threadIdx.x]);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, int in_dim, const void* w_ih, const float* b_ih,
@@ -1609,6 +1886,15 @@ extern "C" int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, i
     return 0;
 }
 
+// which backward step kernel runs (read once from the environment; gtos_gru_bwd_config overrides per process -- the tests compare the two)
+static int g_bwd8 = !(getenv("GTOS_GRU_BWD8") && getenv("GTOS_GRU_BWD8")[0] == '0');
+static int g_bwd8_min_rows = getenv("GTOS_GRU_BWD8_MINROWS") ? atoi(getenv("GTOS_GRU_BWD8_MINROWS")) : 8192;
+extern "C" int gtos_gru_bwd_config(int wide, int min_rows) {
+    if (wide >= 0) g_bwd8 = wide != 0;
+    if (min_rows >= 0) g_bwd8_min_rows = min_rows;
+    return 0;
+}
+
 extern "C" int gtos_gru_step_bwd_fused(int rows, int hs, const void* d4_prev, int rows_prev, const void* w_hh_t,
                                        const void* gates, const void* hprev, const int* hprev_idx, const void* dy, int64_t ldy,
                                        void* dh, int dh_dtype, int64_t ld_dh, void* d4, float p_drop, uint64_t seed, int64_t drop_base,
@@ -1648,6 +1934,26 @@ extern "C" int gtos_gru_step_bwd_fused(int rows, int hs, const void* d4_prev, in
     static const int bwd_dbg = getenv("GTOS_GRU_BWD_DBG") ? atoi(getenv("GTOS_GRU_BWD_DBG")) : 0;
     const int dbg = (w_hn || sum_idx) ? 0 : bwd_dbg;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // Round 6: launches with a recurrent product over at least g_bwd8_min_rows rows run on 256-row panels with both roles in one eight-wave
+    // workgroup (gru_step_bwd8_kernel; GTOS_GRU_BWD8=0 / gtos_gru_bwd_config: never).  Same bits as the kernel below.
+    const int nC8 = hs / TC, nbt = role_b ? n_in / (nC8 * 16) : 0;
+    if (g_bwd8 && rows > 0 && d4_prev && rows_prev > 0 && !sum_idx && !w_hn && !hprev_idx && cover >= g_bwd8_min_rows &&
+        (!role_b || (n_in == nC8 * 16 * nbt && (nbt == 2 || nbt == 4 || nbt == 8))) && (int64_t)hs * 6 * (n_in > hs ? n_in : hs) < (1LL << 32)) {
+        const long long nM8 = (cover + 255) / 256, nblk8 = ((nM8 + 7) / 8) * 8 * nC8;
+#define GTOS_BWD8_LAUNCH(NBT_)                                                                                                    \
+        {                                                                                                                         \
+            if (dbg == 1) hipLaunchKernelGGL((gru_step_bwd8_kernel<NBT_, 1>), dim3((unsigned)nblk8), dim3(512), 0, st, a);        \
+            else if (dbg == 2) hipLaunchKernelGGL((gru_step_bwd8_kernel<NBT_, 2>), dim3((unsigned)nblk8), dim3(512), 0, st, a);   \
+            else hipLaunchKernelGGL((gru_step_bwd8_kernel<NBT_, 0>), dim3((unsigned)nblk8), dim3(512), 0, st, a);                 \
+        }
+        if (nbt == 8) GTOS_BWD8_LAUNCH(8)
+        else if (nbt == 4) GTOS_BWD8_LAUNCH(4)
+        else if (nbt == 2) GTOS_BWD8_LAUNCH(2)
+        else GTOS_BWD8_LAUNCH(0)
+#undef GTOS_BWD8_LAUNCH
+        GTOS_CHECK_LAUNCH();
+        return 0;
+    }
 #define GTOS_BWD_LAUNCH(HN_, D_) hipLaunchKernelGGL((gru_step_bwd_kernel<HN_, D_>), dim3((unsigned)nblk), dim3(256), 0, st, a)
     if (w_hn) GTOS_BWD_LAUNCH(true, 0);
     else if (dbg == 1) GTOS_BWD_LAUNCH(false, 1);

@@ -238,6 +238,14 @@ int gtos_gru_step_bwd_fused(int rows, int hs, const void* d4_prev, int rows_prev
                             const void* w_ih_t, void* dinp, int64_t ld_dinp, int n_in, int dinp_accumulate, float p_in, uint64_t seed_in,
                             int64_t in_drop_base, void* stream);
 
+/* Which kernel gtos_gru_step_bwd_fused launches (round 6).  Launches with a recurrent product (d4_prev != NULL, rows > 0) that cover at least
+ * `min_rows` rows (default 8192; GTOS_GRU_BWD8_MINROWS), no trie indirection, no hn recompute and, with dinp, n_in = (hs/64) * 16 * {2, 4, 8}
+ * run on 256-row panels with BOTH roles in one eight-wave workgroup (gru_step_bwd8_kernel: the panel's d4_prev rows go through LDS hs/64
+ * times instead of hs/64 + n_in/128 times, every weight row serves 256 rows; three panel stages + two weight stages in flight).  Same bits as
+ * the 128-row kernel.  wide: 1 / 0 = use it / never (GTOS_GRU_BWD8), -1 = leave; min_rows < 0 = leave.  Returns 0.
+ * A process-wide switch for A/B timing and for the tests that compare the two kernels. */
+int gtos_gru_bwd_config(int wide, int min_rows);
+
 /* Both weight gradients of one GRU layer and direction over all its packed rows in ONE grouped product (round 5; torch's GRU backward runs
  * dW_ih = d(xg)^T x and dW_hh = d(hg)^T h_prev as separate GEMMs): with d4 [rows,4hs] = d r | d z | d n_x | d n_h,
  *   dwih[3hs, in_valid] += d4[:, 0:3hs]^T x[:, 0:in_valid]          x [rows, in_dim] (row stride ldx; columns in_valid.. are zero padding)
