@@ -1759,6 +1759,273 @@ __global__ __launch_bounds__(512, 2) void gru_step_bwd8_kernel(StepBwdArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 6: PERSISTENT backward step -- the weights stay in LDS for the whole launch, the waves are decoupled.
+//
+// Every tile kernel above runs a workgroup in lock step: DMA a stage, wait, barrier, multiply, barrier -- and then its cell, while nothing
+// multiplies.  Measured at 434,624 rows of layer 1 (tools/bench_gru_step.py, round 6): the 128-row kernel 520 us without its k loops + 566 us
+// of k loops alone = 1,070 together; the 256-row / eight-wave kernel of this round's first attempt (half the LDS-DMA bytes, 88 KB in flight):
+// 487 + 597 = 1,107.  Fewer operand bytes and more of them in flight bought nothing: the phases of a workgroup are serial by construction and
+// the k loop's MFMA pipe idles through every wait-barrier-fragment-read sequence (0.9 PF/s alone).
+// Here the two products of a row -- recurrent: d4_prev[{r,z,n_h}] x W_hh^T, input gradient: d4_prev[{r,z,n_x}] x W_ih^T; 768 output columns
+// at layer 1, 384 at layer 0, K = 768 each -- are cut into S column SLICES of 96 columns (NA*16 state channels + NBT*16 input columns:
+// 32 + 64 at layer 1, S = 8; 64 + 32 at layer 0, S = 4), whose 96 x 768 weight elements are exactly 144 KB: one workgroup per CU loads its
+// slice ONCE and keeps it.  After that there is no LDS-DMA, no stage, no barrier: each of the eight waves walks its own 32-row tiles,
+// pulls the d4_prev rows straight into MFMA fragment registers (buffer loads, three k tiles ahead; rows past rows_prev come back as
+// zeros from the bounds check), reads weight fragments from the resident slice, and runs role B's store and role A's cell on its
+// accumulators -- the cell's operand loads of the tile are issued in the middle of its k loop, its stores drain under the next tile's.
+// While one wave of a SIMD waits for memory the other one multiplies.  The S slices of a row panel run on one XCD at the same pace, so a
+// panel's d4_prev rows come from HBM once.
+// Accumulation order per output element is the tile kernels': same k tiles, same order, same operands -- the same bits.
+// Bias-gradient partial sums collect in LDS over the whole launch (one flush per workgroup).
+template <int NA, int NBT>
+struct PwGeom {
+    static constexpr int NKB = 4, NKT = 4 * NKB;                               // hs = 256: four 64-k tiles per block of d4 = [r | z | n_x | n_h]
+    static constexpr int RA = 16 * NA, RB = 16 * NBT;
+    // LDS region of k tile kt: role A rows (blocks r, z, n_h) then role B rows (blocks r, z, n_x), 128 bytes each
+    static constexpr int rows(int kt) { return kt / NKB < 2 ? RA + RB : (kt / NKB == 2 ? RB : RA); }
+    static constexpr int off(int kt) {
+        return (kt / NKB < 2 ? kt * (RA + RB) : kt / NKB == 2 ? 2 * NKB * (RA + RB) + (kt - 2 * NKB) * RB
+                                                              : 2 * NKB * (RA + RB) + NKB * RB + (kt - 3 * NKB) * RA) * ROWB;
+    }
+    static constexpr int BYTES = (2 * NKB * (RA + RB) + NKB * (RA + RB)) * ROWB;
+    static constexpr int LDS_TOTAL = BYTES + 4 * RA * (int)sizeof(float);
+};
+
+// LDS offset of (row, 16-byte chunk) inside a k tile's region: the chunk swizzle depends on the row's position inside its 16-row MFMA block
+// only, so the fragment address of block nt is the lane's base + nt * 2048 -- an immediate (lds_off's swizzle also mixes in the block
+// index: a register per block and k half, and this kernel has none to spare)
+__device__ __forceinline__ int pw_off(int r, int c) { return r * ROWB + ((c ^ ((r >> 1) & 7)) << 4); }
+
+template <int NA, int NBT, bool ACC, bool DY>
+__global__ __launch_bounds__(512, 2) void gru_step_bwd_pw_kernel(StepBwdArgs a, int n_panels, int S, int Wk) {
+    using G = PwGeom<NA, NBT>;
+    constexpr int NKB = G::NKB, NKT = G::NKT, RA = G::RA, CH = 4 * NA, CV = CH / 8, NBV = NBT / 2, DEPTH = 2, NBUF = DEPTH + 1;
+    extern __shared__ __attribute__((aligned(16))) char pw[];
+    float* btab = reinterpret_cast<float*>(pw + G::BYTES);                     // [4 gates][RA channels]
+    if (a.p_drop > 0.f) a.seed = live_seed(a.seed);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int hs = a.hs;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, slice = idx % S, worker = idx / S;
+    if (worker >= Wk) return;
+    const int c0 = slice * RA, n0 = slice * G::RB;
+
+    // ---- the slice's weights -> LDS, once ----
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        const int b = kt / NKB, npc = G::rows(kt) / 8;
+        for (int j = wave; j < npc; j += 8) {
+            const int row = j * 8 + (lane >> 3);                               // region-relative row
+            const bool is_a = b != 2 && row < RA;
+            const int rr = is_a ? row : row - (b < 2 ? RA : 0);                // row inside its role's block
+            const int nt = rr >> 4, q = (rr >> 2) & 3, e = rr & 3;
+            const int c = (lane & 7) ^ ((row >> 1) & 7);            // (pw_off's swizzle)
+            const bf16_t* src = is_a ? a.wh_t + (int64_t)(c0 + q * CH + nt * 4 + e) * 3 * hs + (b == 3 ? kt - NKB : kt) * BK + c * 8
+                                     : a.wi_t + (int64_t)(n0 + q * 4 * NBT + nt * 4 + e) * 3 * hs + kt * BK + c * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(pw + G::off(kt) + j * 1024), 16, 0, 0);
+        }
+    }
+    if (threadIdx.x < 4 * RA) btab[threadIdx.x] = 0.f;
+    GTOS_VMCNT(0);
+    __syncthreads();
+
+    const uint32_t rowb = (uint32_t)hs * 8u;                                   // bytes of a d4 row
+    const uint32_t vo0 = (uint32_t)fr * rowb + (uint32_t)fq * 16u, vo1 = vo0 + 16u * rowb;
+    const int cb = c0 + fq * CH, nb = n0 + fq * 4 * NBT;
+    const float ks_d = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
+    const float ks_in = a.p_in > 0.f ? 1.f / (1.f - a.p_in) : 1.f;
+    const uint64_t seed_in = a.p_in > 0.f ? live_seed(a.seed_in) : 0;
+
+    for (int p = xcd + 8 * worker; p < n_panels; p += 8 * Wk) {
+        const int m_base = p * 256 + wave * 32;                                // this wave's 32 rows
+        const bool has_a = m_base < a.rows, has_b = m_base < a.rows_prev;     // (role B and the recurrent product need rows of the step before)
+        if (!has_a && !has_b) continue;
+        f32x4_t acc[2][NA + NBT];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NA + NBT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        // operand addresses of the cell (rows past the end re-read the last valid row; never stored) and of role B
+        int mrow[2];
+        bool valid[2], bvalid[2];
+        const bf16_t* gp[2];
+        U128 cg[2][4][CV], chp[2][CV], cdh[2][CV], cdy[2][DY ? CV : 1], oldv[2][ACC ? NBV : 1];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int m_raw = m_base + mt * 16 + fr;
+            valid[mt] = m_raw < a.rows;
+            bvalid[mt] = m_raw < a.rows_prev;
+            mrow[mt] = min(m_raw, a.rows - 1);
+            gp[mt] = a.gates + (int64_t)mrow[mt] * 4 * hs + cb;
+        }
+        auto cell_loads = [&](int mt) {
+#pragma unroll
+            for (int v = 0; v < CV; ++v) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) cg[mt][g][v] = *reinterpret_cast<const U128*>(gp[mt] + g * hs + v * 8);
+                chp[mt][v] = *reinterpret_cast<const U128*>(a.hprev + (int64_t)mrow[mt] * hs + cb + v * 8);
+                cdh[mt][v] = *reinterpret_cast<const U128*>(static_cast<const bf16_t*>(a.dh) + (int64_t)mrow[mt] * a.ld_dh + cb + v * 8);
+                if constexpr (DY) cdy[mt][v] = *reinterpret_cast<const U128*>(a.dy + (int64_t)mrow[mt] * a.ldy + cb + v * 8);
+            }
+            if constexpr (ACC) {
+                const int mb = min(m_base + mt * 16 + fr, a.rows_prev - 1);
+#pragma unroll
+                for (int h = 0; h < NBV; ++h) oldv[mt][h] = *reinterpret_cast<const U128*>(a.dinp + (int64_t)mb * a.ld_dinp + nb + h * 8);
+            }
+        };
+        if (has_b) {
+            const int nrow = min(32, a.rows_prev - m_base);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<bf16_t*>(a.d4_prev + (int64_t)m_base * 4 * hs), 0, (int)((uint32_t)nrow * rowb), 0x00020000);
+            U128 af[NBUF][2][2];
+            bf16x8_t fw[NA + NBT];                         // weight fragments of a 32-k step (the SIMD's other wave multiplies while these arrive)
+#define GTOS_PW_LOAD_A(kt_)                                                                                                    \
+            {                                                                                                                  \
+                _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) {                                                          \
+                    af[(kt_) % NBUF][0][ks_] = __builtin_bit_cast(U128, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)vo0 + (kt_) * ROWB + ks_ * 64, 0, 0)); \
+                    af[(kt_) % NBUF][1][ks_] = __builtin_bit_cast(U128, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)vo1 + (kt_) * ROWB + ks_ * 64, 0, 0)); \
+                }                                                                                                              \
+            }
+#pragma unroll
+            for (int kt = 0; kt < DEPTH; ++kt) GTOS_PW_LOAD_A(kt)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 2 * NKT; ++u) {            // a step = one 32-k half of a k tile: 2 * (NA + NBT) MFMAs at most
+                const int kt = u >> 1, ks = u & 1, b = kt / NKB;
+                const char* reg = pw + G::off(kt);
+                // issue first: (once per k tile) the row loads DEPTH tiles ahead, (once) the first row block's cell operands, this step's weight fragments
+                if (ks == 0 && kt + DEPTH < NKT) GTOS_PW_LOAD_A(kt + DEPTH)
+                if (ks == 0 && kt == NKT - DEPTH) cell_loads(0);              // behind the last row loads: they fly through the rest of the k loop
+                if (b != 2) {
+#pragma unroll
+                    for (int nt = 0; nt < NA; ++nt) fw[nt] = *reinterpret_cast<const bf16x8_t*>(reg + pw_off(nt * 16 + fr, ks * 4 + fq));
+                }
+                if (b != 3) {
+#pragma unroll
+                    for (int t = 0; t < NBT; ++t) fw[NA + t] = *reinterpret_cast<const bf16x8_t*>(reg + pw_off((b < 2 ? RA : 0) + t * 16 + fr, ks * 4 + fq));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const bf16x8_t fa0 = __builtin_bit_cast(bf16x8_t, af[kt % NBUF][0][ks]), fa1 = __builtin_bit_cast(bf16x8_t, af[kt % NBUF][1][ks]);
+                if (b != 2) {
+#pragma unroll
+                    for (int nt = 0; nt < NA; ++nt) {
+                        acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nt], fa0, acc[0][nt], 0, 0, 0);
+                        acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nt], fa1, acc[1][nt], 0, 0, 0);
+                    }
+                }
+                if (b != 3) {
+#pragma unroll
+                    for (int t = 0; t < NBT; ++t) {
+                        acc[0][NA + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[NA + t], fa0, acc[0][NA + t], 0, 0, 0);
+                        acc[1][NA + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[NA + t], fa1, acc[1][NA + t], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#undef GTOS_PW_LOAD_A
+            cell_loads(1);                                 // the second row block's: under the input-gradient stores and the first block's cell
+            // role B: the previous step's input gradient, 4 * NBT consecutive columns per lane and row
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int m = m_base + mt * 16 + fr;
+                if (!bvalid[mt]) continue;
+                bf16_t* dp = a.dinp + (int64_t)m * a.ld_dinp + nb;
+#pragma unroll
+                for (int h = 0; h < NBV; ++h) {
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = acc[mt][NA + h * 2 + (i >> 2)][i & 3];
+                    if (a.p_in > 0.f) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i)
+                            v[i] = drop_keep(seed_in, (uint64_t)(a.in_drop_base + (int64_t)m * a.n_in + nb + h * 8 + i), a.p_in) ? v[i] * ks_in : 0.f;
+                    }
+                    if constexpr (ACC) {
+                        const U128 o = oldv[mt][h];
+                        v[0] += lo_bf(o.x); v[1] += hi_bf(o.x); v[2] += lo_bf(o.y); v[3] += hi_bf(o.y);
+                        v[4] += lo_bf(o.z); v[5] += hi_bf(o.z); v[6] += lo_bf(o.w); v[7] += hi_bf(o.w);
+                    }
+                    Vec8<bf16_t>::store(dp + h * 8, v);
+                }
+            }
+        } else {
+            cell_loads(0);
+            cell_loads(1);
+        }
+        if (!has_a) continue;
+
+        // role A: the cell backward of the tile's rows, CH consecutive channels per lane and row, eight at a time
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            bf16_t* dhb = static_cast<bf16_t*>(a.dh) + (int64_t)mrow[mt] * a.ld_dh + cb;
+            bf16_t* dp = a.d4 + (int64_t)mrow[mt] * 4 * hs + cb;
+#pragma unroll
+            for (int v = 0; v < CV; ++v) {
+                float gr[8], gz[8], gn[8], hn[8], hp[8], g[8];
+#define GTOS_PW_UNPACK(dst, src)                                                                                               \
+                {                                                                                                              \
+                    const U128 r_ = (src);                                                                                     \
+                    dst[0] = lo_bf(r_.x); dst[1] = hi_bf(r_.x); dst[2] = lo_bf(r_.y); dst[3] = hi_bf(r_.y);                    \
+                    dst[4] = lo_bf(r_.z); dst[5] = hi_bf(r_.z); dst[6] = lo_bf(r_.w); dst[7] = hi_bf(r_.w);                    \
+                }
+                GTOS_PW_UNPACK(gr, cg[mt][0][v]) GTOS_PW_UNPACK(gz, cg[mt][1][v]) GTOS_PW_UNPACK(gn, cg[mt][2][v]) GTOS_PW_UNPACK(hn, cg[mt][3][v])
+                GTOS_PW_UNPACK(hp, chp[mt][v]) GTOS_PW_UNPACK(g, cdh[mt][v])
+#pragma unroll
+                for (int i = 0; i < 8; ++i) g[i] += acc[mt][v * 2 + (i >> 2)][i & 3];
+                if constexpr (DY) {
+                    float dyv[8];
+                    GTOS_PW_UNPACK(dyv, cdy[mt][v])
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        float t2 = dyv[i];
+                        if (a.p_drop > 0.f)
+                            t2 = drop_keep(a.seed, (uint64_t)(a.drop_base + (int64_t)mrow[mt] * a.ldy + cb + v * 8 + i), a.p_drop) ? t2 * ks_d : 0.f;
+                        g[i] += t2;
+                    }
+                }
+#undef GTOS_PW_UNPACK
+                float dr_[8], dz_[8], dn_[8], dhn[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float dn = g[i] * (1.f - gz[i]);
+                    const float dz = g[i] * (hp[i] - gn[i]);
+                    dn_[i] = dn * (1.f - gn[i] * gn[i]);
+                    dhn[i] = dn_[i] * gr[i];
+                    dr_[i] = dn_[i] * hn[i] * gr[i] * (1.f - gr[i]);
+                    dz_[i] = dz * gz[i] * (1.f - gz[i]);
+                    g[i] *= gz[i];                                         // the direct path h_prev -> h
+                    if (!valid[mt]) { dn_[i] = 0.f; dhn[i] = 0.f; dr_[i] = 0.f; dz_[i] = 0.f; }
+                }
+                if (valid[mt]) {
+                    Vec8<bf16_t>::store(dhb + v * 8, g);
+                    Vec8<bf16_t>::store(dp + v * 8, dr_); Vec8<bf16_t>::store(dp + hs + v * 8, dz_);
+                    Vec8<bf16_t>::store(dp + 2 * hs + v * 8, dn_); Vec8<bf16_t>::store(dp + 3 * hs + v * 8, dhn);
+                }
+                if (a.bias_part) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float t0 = row16_sum(bf2f(f2bf(dr_[i]))), t1 = row16_sum(bf2f(f2bf(dz_[i])));
+                        const float t2 = row16_sum(bf2f(f2bf(dn_[i]))), t3 = row16_sum(bf2f(f2bf(dhn[i])));
+                        if (fr == 0) {
+                            atomicAdd(&btab[0 * RA + fq * CH + v * 8 + i], t0); atomicAdd(&btab[1 * RA + fq * CH + v * 8 + i], t1);
+                            atomicAdd(&btab[2 * RA + fq * CH + v * 8 + i], t2); atomicAdd(&btab[3 * RA + fq * CH + v * 8 + i], t3);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (a.bias_part) {
+        __syncthreads();
+        if (threadIdx.x < 4 * RA) {
+            const int q = threadIdx.x / RA, ch = threadIdx.x % RA;
+            atomicAdd(a.bias_part + (int64_t)(blockIdx.x % a.n_partials) * 4 * hs + q * hs + c0 + ch, btab[threadIdx.x]);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, int in_dim, const void* w_ih, const float* b_ih,
@@ -1886,12 +2153,47 @@ extern "C" int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, i
     return 0;
 }
 
-// which backward step kernel runs (read once from the environment; gtos_gru_bwd_config overrides per process -- the tests compare the two)
-static int g_bwd8 = !(getenv("GTOS_GRU_BWD8") && getenv("GTOS_GRU_BWD8")[0] == '0');
-static int g_bwd8_min_rows = getenv("GTOS_GRU_BWD8_MINROWS") ? atoi(getenv("GTOS_GRU_BWD8_MINROWS")) : 8192;
-extern "C" int gtos_gru_bwd_config(int wide, int min_rows) {
-    if (wide >= 0) g_bwd8 = wide != 0;
-    if (min_rows >= 0) g_bwd8_min_rows = min_rows;
+// which backward step kernel runs (read once from the environment; gtos_gru_bwd_config overrides per process -- the tests compare them):
+// 2 = the persistent kernel where it applies (default), 1 = the 256-row / eight-wave tile kernel, 0 = the 128-row tile kernel only
+static int g_bwd_kernel = getenv("GTOS_GRU_BWD_KERNEL") ? atoi(getenv("GTOS_GRU_BWD_KERNEL")) : 2;
+static const int k_bwd8_min_rows = getenv("GTOS_GRU_BWD8_MINROWS") ? atoi(getenv("GTOS_GRU_BWD8_MINROWS")) : 8192;
+static const int k_bwd_pw_min_rows = getenv("GTOS_GRU_BWD_PW_MINROWS") ? atoi(getenv("GTOS_GRU_BWD_PW_MINROWS")) : 32768;
+static int g_bwd8_min_rows = k_bwd8_min_rows, g_bwd_pw_min_rows = k_bwd_pw_min_rows;
+extern "C" int gtos_gru_bwd_config(int kernel, int min_rows) {
+    if (kernel >= 0) g_bwd_kernel = kernel;
+    if (min_rows >= 0) g_bwd8_min_rows = g_bwd_pw_min_rows = min_rows;
+    if (min_rows == -2) { g_bwd8_min_rows = k_bwd8_min_rows; g_bwd_pw_min_rows = k_bwd_pw_min_rows; }
+    return 0;
+}
+
+template <int NA, int NBT>
+static int launch_bwd_pw(const StepBwdArgs& a, bool acc, bool dy, long long cover, hipStream_t st) {
+    using G = PwGeom<NA, NBT>;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return -7;
+        n_cu = pr.multiProcessorCount;
+    }
+    const int S = a.hs / G::RA, Wk = (n_cu / 8) / S > 0 ? (n_cu / 8) / S : 1;
+    const int n_panels = (int)((cover + 255) / 256);
+#define GTOS_PW_GO(ACC_, DY_)                                                                                                     \
+    {                                                                                                                             \
+        static bool configured = false;                                                                                           \
+        if (!configured) {                                                                                                        \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_bwd_pw_kernel<NA, NBT, ACC_, DY_>),                    \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_TOTAL) != hipSuccess) return -7;           \
+            configured = true;                                                                                                    \
+        }                                                                                                                         \
+        hipLaunchKernelGGL((gru_step_bwd_pw_kernel<NA, NBT, ACC_, DY_>), dim3(8 * S * Wk), dim3(512), G::LDS_TOTAL, st, a, n_panels, S, Wk); \
+    }
+    if (acc && dy) GTOS_PW_GO(true, true)
+    else if (acc) GTOS_PW_GO(true, false)
+    else if (dy) GTOS_PW_GO(false, true)
+    else GTOS_PW_GO(false, false)
+#undef GTOS_PW_GO
+    GTOS_CHECK_LAUNCH();
     return 0;
 }
 
@@ -1935,9 +2237,15 @@ extern "C" int gtos_gru_step_bwd_fused(int rows, int hs, const void* d4_prev, in
     const int dbg = (w_hn || sum_idx) ? 0 : bwd_dbg;
     hipStream_t st = static_cast<hipStream_t>(stream);
     // Round 6: launches with a recurrent product over at least g_bwd8_min_rows rows run on 256-row panels with both roles in one eight-wave
-    // workgroup (gru_step_bwd8_kernel; GTOS_GRU_BWD8=0 / gtos_gru_bwd_config: never).  Same bits as the kernel below.
+    // workgroup (gru_step_bwd8_kernel; GTOS_GRU_BWD_KERNEL=1 / gtos_gru_bwd_config).  Same bits as the kernel below.
     const int nC8 = hs / TC, nbt = role_b ? n_in / (nC8 * 16) : 0;
-    if (g_bwd8 && rows > 0 && d4_prev && rows_prev > 0 && !sum_idx && !w_hn && !hprev_idx && cover >= g_bwd8_min_rows &&
+    // the persistent kernel: hs = 256, both roles, bf16 state gradient, n_in = 512 (8 slices of 32 channels + 64 columns) or 128 (4 of 64 + 32)
+    if (g_bwd_kernel == 2 && hs == 256 && rows > 0 && d4_prev && rows_prev > 0 && role_b && a.dh_bf16 && !sum_idx && !w_hn && !hprev_idx &&
+        !hprev_out && cover >= g_bwd_pw_min_rows && (n_in == 512 || n_in == 128) && (int64_t)cover * hs * 8 < (1LL << 40)) {
+        return n_in == 512 ? launch_bwd_pw<2, 4>(a, dinp_accumulate != 0, dy != nullptr, cover, st)
+                           : launch_bwd_pw<4, 2>(a, dinp_accumulate != 0, dy != nullptr, cover, st);
+    }
+    if (g_bwd_kernel >= 1 && rows > 0 && d4_prev && rows_prev > 0 && !sum_idx && !w_hn && !hprev_idx && cover >= g_bwd8_min_rows &&
         (!role_b || (n_in == nC8 * 16 * nbt && (nbt == 2 || nbt == 4 || nbt == 8))) && (int64_t)hs * 6 * (n_in > hs ? n_in : hs) < (1LL << 32)) {
         const long long nM8 = (cover + 255) / 256, nblk8 = ((nM8 + 7) / 8) * 8 * nC8;
 #define GTOS_BWD8_LAUNCH(NBT_)                                                                                                    \

@@ -25,6 +25,9 @@ CASES = [
     (16000, 15000, 128, 128, True, False),       # ... 64 input columns per workgroup (NBT = 4)
     (10000, 10000, 64, 128, False, True),        # hs = 64: one channel tile, 4 stages (the loop's remainder only)
     (10000, 9000, 192, 192, False, False),       # hs = 192: 12 stages = two whole rounds of the six-stage pattern (n_in = 3 * 64: NBT = 4)
+    (70001, 66000, 256, 512, False, False),      # several panels per persistent worker; direction 0
+    (66000, 70001, 256, 128, True, True),        # ... direction 1 at layer 0
+    (300, 290, 256, 512, False, True),           # a launch smaller than one panel per workgroup
 ]
 
 
@@ -42,8 +45,8 @@ def test_gru_backward_step_wide_kernel_bit_identical(rows, rows_prev, hs, n_in, 
     dinp0 = rnd(rows_prev, n_in + 64) if n_in else None                           # a column block of a wider matrix
     res = []
     try:
-        for wide in (0, 1):
-            call("gtos_gru_bwd_config", wide, 0)
+        for kernel in (0, 1, 2):                          # 128-row tiles, 256-row tiles, persistent (where it applies: hs 256, n_in 128 / 512)
+            call("gtos_gru_bwd_config", kernel, 0)
             dh, d4 = dh0.clone(), torch.zeros(rows, 4 * hs, device=dev(), dtype=bf)
             bpart = torch.zeros(N_BIAS_PARTIALS, 4 * hs, device=dev())
             wide_m = dinp0.clone() if n_in else None
@@ -53,16 +56,18 @@ def test_gru_backward_step_wide_kernel_bit_identical(rows, rows_prev, hs, n_in, 
             torch.cuda.synchronize()
             res.append((dh, d4, wide_m, bpart))
     finally:
-        call("gtos_gru_bwd_config", 1, 8192)
+        call("gtos_gru_bwd_config", 2, -2)
     assert float(res[0][1].float().abs().max()) > 0
-    assert torch.equal(res[0][0], res[1][0]), "dh: %d rows differ" % int((res[0][0] != res[1][0]).any(1).sum())
-    assert torch.equal(res[0][1], res[1][1]), "d4: %d rows differ" % int((res[0][1] != res[1][1]).any(1).sum())
-    if n_in:
-        assert torch.equal(res[0][2], res[1][2]), "dinp: %d rows differ" % int((res[0][2] != res[1][2]).any(1).sum())
-        assert torch.equal(res[1][2][:, n_in:], dinp0[:, n_in:])                   # nothing beyond the block is touched
-        if not acc:
-            assert not torch.equal(res[1][2][:, :n_in], dinp0[:, :n_in])
-    torch.testing.assert_close(res[0][3].sum(0), res[1][3].sum(0), rtol=1e-4, atol=1e-3)
+    for k in (1, 2):
+        name = ("256-row", "persistent")[k - 1]
+        assert torch.equal(res[0][0], res[k][0]), "%s dh: %d rows differ" % (name, int((res[0][0] != res[k][0]).any(1).sum()))
+        assert torch.equal(res[0][1], res[k][1]), "%s d4: %d rows differ" % (name, int((res[0][1] != res[k][1]).any(1).sum()))
+        if n_in:
+            assert torch.equal(res[0][2], res[k][2]), "%s dinp: %d rows differ" % (name, int((res[0][2] != res[k][2]).any(1).sum()))
+            assert torch.equal(res[k][2][:, n_in:], dinp0[:, n_in:])               # nothing beyond the block is touched
+            if not acc:
+                assert not torch.equal(res[k][2][:, :n_in], dinp0[:, :n_in])
+        torch.testing.assert_close(res[0][3].sum(0), res[k][3].sum(0), rtol=1e-4, atol=1e-3)
 
 
 def test_wide_kernel_is_what_production_sized_launches_run():
@@ -77,12 +82,12 @@ def test_wide_kernel_is_what_production_sized_launches_run():
     d4_prev, wh_t, wi_t = rnd(rows, 4 * hs), rnd(hs, 3 * hs), rnd(512, 3 * hs)
     gates, hprev = torch.rand(rows, 4 * hs, device=dev()).to(bf), rnd(rows, hs)
     used = []
-    for wide, min_rows in ((1, 8192), (1, 8193), (0, 0)):
-        call("gtos_gru_bwd_config", wide, min_rows)
+    for kernel, min_rows in ((1, 8192), (1, 8193), (0, 0)):
+        call("gtos_gru_bwd_config", kernel, min_rows)
         dh, d4, dinp = rnd(rows, hs), torch.empty(rows, 4 * hs, device=dev(), dtype=bf), torch.empty(rows, 512, device=dev(), dtype=bf)
         bpart = torch.zeros(N_BIAS_PARTIALS, 4 * hs, device=dev())
         _step_bwd_fused(rows, hs, d4_prev, rows, wh_t, gates, hprev, None, 2 * hs, dh, d4, 0.0, 0, 0, bpart, wi_t=wi_t, dinp=dinp, n_in=512)
         torch.cuda.synchronize()
         used.append(int((bpart.abs().sum(1) > 0).sum()))
-    call("gtos_gru_bwd_config", 1, 8192)
+    call("gtos_gru_bwd_config", 2, -2)
     assert used[0] < used[1] == used[2], used
