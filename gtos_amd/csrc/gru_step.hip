@@ -1797,10 +1797,13 @@ struct PwGeom {
 // index: a register per block and k half, and this kernel has none to spare)
 __device__ __forceinline__ int pw_off(int r, int c) { return r * ROWB + ((c ^ ((r >> 1) & 7)) << 4); }
 
+#ifndef GTOS_PW_DEPTH
+#define GTOS_PW_DEPTH 5
+#endif
 template <int NA, int NBT, bool ACC, bool DY>
 __global__ __launch_bounds__(512, 2) void gru_step_bwd_pw_kernel(StepBwdArgs a, int n_panels, int S, int Wk) {
     using G = PwGeom<NA, NBT>;
-    constexpr int NKB = G::NKB, NKT = G::NKT, RA = G::RA, CH = 4 * NA, CV = CH / 8, NBV = NBT / 2, DEPTH = 2, NBUF = DEPTH + 1;
+    constexpr int NKB = G::NKB, NKT = G::NKT, RA = G::RA, CH = 4 * NA, CV = CH / 8, NBV = NBT / 2, DEPTH = GTOS_PW_DEPTH, NBUF = DEPTH + 1;
     extern __shared__ __attribute__((aligned(16))) char pw[];
     float* btab = reinterpret_cast<float*>(pw + G::BYTES);                     // [4 gates][RA channels]
     if (a.p_drop > 0.f) a.seed = live_seed(a.seed);
@@ -1897,7 +1900,7 @@ __global__ __launch_bounds__(512, 2) void gru_step_bwd_pw_kernel(StepBwdArgs a, 
                 const char* reg = pw + G::off(kt);
                 // issue first: (once per k tile) the row loads DEPTH tiles ahead, (once) the first row block's cell operands, this step's weight fragments
                 if (ks == 0 && kt + DEPTH < NKT) GTOS_PW_LOAD_A(kt + DEPTH)
-                if (ks == 0 && kt == NKT - DEPTH) cell_loads(0);              // behind the last row loads: they fly through the rest of the k loop
+                if (ks == 0 && kt == NKT - (DEPTH < 3 ? DEPTH : 2)) cell_loads(0);      // behind the last row loads: they fly through the rest of the k loop
                 if (b != 2) {
 #pragma unroll
                     for (int nt = 0; nt < NA; ++nt) fw[nt] = *reinterpret_cast<const bf16x8_t*>(reg + pw_off(nt * 16 + fr, ks * 4 + fq));
