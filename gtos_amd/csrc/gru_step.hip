@@ -1237,6 +1237,18 @@ __device__ __forceinline__ void dinp_tile(const StepBwdArgs& a, int m0, int n0, 
     }
     const float ks_in = a.p_in > 0.f ? 1.f / (1.f - a.p_in) : 1.f;
     const uint64_t seed_in = a.p_in > 0.f ? live_seed(a.seed_in) : 0;
+    // direction 1 adds to what direction 0 wrote: all of a lane's pieces in flight before the first is used (round 6; one dependent
+    // round trip per piece before: a launch that accumulates took 1,114 us where one that writes took 1,066)
+    Raw16 oldv[2][NS];
+    if (a.dinp_acc) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int m = min(m0 + wave * 32 + mt * 16 + fr, a.rows_prev - 1);
+#pragma unroll
+            for (int h = 0; h < NS; ++h)
+                if (h < nsub) oldv[mt][h] = ldraw16(a.dinp + (int64_t)m * a.ld_dinp + n0 + h * TC + fq * 16);
+        }
+    }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         const int m = m0 + wave * 32 + mt * 16 + fr;
@@ -1256,7 +1268,7 @@ __device__ __forceinline__ void dinp_tile(const StepBwdArgs& a, int m0, int n0, 
             bf16_t* dp = a.dinp + (int64_t)m * a.ld_dinp + nb;
             if (a.dinp_acc) {
                 float old[16];
-                ld16(dp, old);
+                unpack16(oldv[mt][h], old);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) v[i] += old[i];
             }
@@ -1482,552 +1494,6 @@ __global__ __launch_bounds__(256, 3) void gru_step_bwd_kernel(StepBwdArgs a) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Round 6: the backward step launch on 256-row panels, eight waves, BOTH roles in one workgroup.
-//
-// gru_step_bwd_kernel above runs a 128-row panel as hs/64 cell workgroups (role A: recurrent product, K = 3hs, 64 output channels, then
-// the cell) plus n_in/128 input-gradient workgroups (role B: K = 3hs, 128 output columns): eight workgroups at layer 1, each pulling the
-// panel's d4_prev rows (196 KB) and its own weight rows through LDS -- 2.75 MB of LDS-DMA per 128 rows, 9.3 GB per 434 k-row launch, with at
-// most one 16 KB panel stage + one weight stage in flight per workgroup.  The k loops take as long as the cells (528 vs 530 us alone) and the
-// two add up: what the launch waits for is operand delivery through the CUs' vector-memory path.
-// Here ONE workgroup owns 256 rows x (64 state channels + n_in / (hs/64) input columns): it walks the four blocks of d4_prev
-// (d r | d z | d n_x | d n_h) ONCE, 64 k per stage, and feeds both products from the same fragment reads of the row panel --
-//     blocks d r, d z:  role A (W_hh^T rows) and role B (W_ih^T rows);   d n_x: role B only;   d n_h: role A only
-// -- so a panel's rows go through LDS hs/64 times instead of hs/64 + n_in/128 times and every weight row serves 256 rows instead of 128:
-// 3.2 MB of LDS-DMA per 256 rows at layer 1 (-42 %).  The k loop is the forward step's (gru_step_fwd_a2w3_kernel): three slots of panel
-// stages (3 x 32 KB) + two of weight stages, W(s+1) then A(s+2) issued per stage, vmcnt(4) = "A(s), W(s) landed": 80-88 KB in flight per CU.
-// Each accumulator sees the MFMAs of its role's blocks in the old order with the old operands: role A's d4 / dh / bias sums and role B's
-// dinp are the SAME BITS as gru_step_bwd_kernel's (test_gru_backward_step_wide_kernel_bit_identical).
-// NBT: 16-column blocks of role B per workgroup (n_in = (hs/64) * 16 * NBT; 8 at layer 1, 2 at layer 0, 0 = no role B); a lane ends up with
-// 4 * NBT consecutive input columns of a row (weight rows DMA'd in the order lds_row = nt*16 + q*4 + e <-> column = q*4*NBT + nt*4 + e).
-// Every wave issues the same number of DMA instructions per stage whatever the block (the wait counts are immediates): pieces a block does
-// not need read the zero block.  DBG (GTOS_GRU_BWD_DBG): 1 = no k loop, 2 = the k loop alone.
-template <int NBT, int DBG>
-__global__ __launch_bounds__(512, 2) void gru_step_bwd8_kernel(StepBwdArgs a) {
-    constexpr int TMW = 256, AW = TMW * ROWB;                                  // a stage of the row panel: 32 KB
-    constexpr int WP = (TC / 8 + NBT * 2 + 7) / 8;                             // weight pieces (8 rows x 128 B) per wave and stage: 1 / 2 / 2 / 3
-    constexpr int WB = WP * 8 * 1024;                                          // a stage of weight rows: 8 / 16 / 16 / 24 KB
-    constexpr int NBC = NBT * 16;                                              // role B columns of this workgroup
-    if (a.p_drop > 0.f) a.seed = live_seed(a.seed);
-    __shared__ __attribute__((aligned(16))) char sa0[AW];
-    __shared__ __attribute__((aligned(16))) char sa1[AW];
-    __shared__ __attribute__((aligned(16))) char sa2[AW];
-    __shared__ __attribute__((aligned(16))) char sw0[WB];
-    __shared__ __attribute__((aligned(16))) char sw1[WB];
-    __shared__ float btab[4 * TC];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int fr = lane & 15, fq = lane >> 4;
-    const int hs = a.hs, nC = hs / TC, nkb = hs / BK;
-    const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
-    const int m0 = ((sq / nC) * 8 + xcd) * TMW, ct = sq % nC, c0 = ct * TC, n0 = ct * NBC;
-    const bool has_a = m0 < a.rows;                                            // the panel has cell rows
-    const bool has_k = DBG != 1 && a.d4_prev != nullptr && m0 < a.rows_prev;   // ... rows of the step processed just before
-    const bool has_b = NBT > 0 && a.dinp != nullptr && has_k;
-    if (!has_a && !has_b) return;
-    const char* Z = static_cast<const char*>(a.zeros);
-    if (a.bias_part && threadIdx.x < 4 * TC) btab[threadIdx.x] = 0.f;
-
-    f32x4_t acc[2][4 + NBT];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4 + NBT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    if (has_k) {
-        const int nst = 4 * nkb;
-        // per-lane sources: this wave's 4 pieces of a panel stage (rows past rows_prev: zeros), its role A weight piece, its role B pieces
-        const char* ap[4];
-        const char* Ab = reinterpret_cast<const char*>(a.d4_prev + (int64_t)m0 * 4 * hs);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int rl = (i * 8 + wave) * 8 + (lane >> 3);
-            const uint32_t c = (uint32_t)(((lane & 7) ^ swz(rl)) << 4);
-            ap[i] = (m0 + rl < a.rows_prev) ? Ab + (uint32_t)rl * (uint32_t)(hs * 8) + c : nullptr;
-        }
-        const char* wa;                                                        // role A: piece `wave` of the 8 (64 rows of W_hh^T)
-        {
-            const int rl = wave * 8 + (lane >> 3);
-            const int nt = (rl >> 4) & 3, q = (rl >> 2) & 3, e = rl & 3;
-            const uint32_t c = (uint32_t)(((lane & 7) ^ swz(rl)) << 4);
-            wa = has_a ? reinterpret_cast<const char*>(a.wh_t) + (uint32_t)(c0 + q * 16 + nt * 4 + e) * (uint32_t)(hs * 6) + c : nullptr;
-        }
-        const char* wb[WP > 1 ? WP - 1 : 1];                                   // role B: pieces wave, 8 + wave of the 2 * NBT (NBC rows of W_ih^T)
-#pragma unroll
-        for (int i = 0; i < WP - 1; ++i) {
-            const int pj = i * 8 + wave, rb = pj * 8 + (lane >> 3);
-            const int nt = rb >> 4, q = (rb >> 2) & 3, e = rb & 3;
-            const uint32_t c = (uint32_t)(((lane & 7) ^ swz(rb)) << 4);
-            wb[i] = (has_b && pj < NBT * 2) ? reinterpret_cast<const char*>(a.wi_t) + (uint32_t)(n0 + q * 4 * NBT + nt * 4 + e) * (uint32_t)(hs * 6) + c : nullptr;
-        }
-#define GTOS_DMA1(src, dst)                                                                                                   \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),                                    \
-                                     (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
-// stage s_ of the row panel = columns s_ * 64 .. of d4_prev (the four blocks are contiguous); past the last stage: zeros, never multiplied
-#define GTOS_B8_DMA_A(slot, s_)                                                                                               \
-    {                                                                                                                         \
-        const bool in_ = (s_) < nst;                                                                                          \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                                      \
-            GTOS_DMA1((in_ && ap[i_]) ? ap[i_] + (s_) * ROWB : Z, (slot) + (i_ * 8 + wave) * 1024);                           \
-    }
-// weight rows of stage s_: W_hh^T has the k order (r, z, n_h) -- block 2 of d4 is not its operand --, W_ih^T the order (r, z, n_x)
-#define GTOS_B8_DMA_W(slot, s_)                                                                                               \
-    {                                                                                                                         \
-        const int blk_ = (s_) / nkb;                                                                                          \
-        const bool ua_ = (s_) < nst && blk_ != 2 && wa != nullptr;                                                            \
-        GTOS_DMA1(ua_ ? wa + ((s_) - (blk_ == 3 ? nkb : 0)) * ROWB : Z, (slot) + wave * 1024);                                \
-        _Pragma("unroll") for (int i_ = 0; i_ < WP - 1; ++i_)                                                                 \
-            GTOS_DMA1((blk_ < 3 && wb[i_]) ? wb[i_] + (s_) * ROWB : Z, (slot) + ((i_ + 1) * 8 + wave) * 1024);                \
-    }
-// stage s_: A in sa_, W in sw_; W(s_+1) goes to sw_n (held W(s_-1)), A(s_+2) to sa_n (held A(s_-1))
-#define GTOS_B8_STEP(sa_, sw_, sa_n, sw_n, s_)                                                                                \
-    {                                                                                                                         \
-        GTOS_VMCNT_LDS(4);                                 /* own pieces of A(s_), W(s_) landed (A(s_+1) may fly); own reads of s_ - 1 done */ \
-        __builtin_amdgcn_s_barrier();                      /* everybody's; and everybody is past its reads of stage s_ - 1 */ \
-        GTOS_B8_DMA_W(sw_n, (s_) + 1);                                                                                        \
-        GTOS_B8_DMA_A(sa_n, (s_) + 2);                                                                                        \
-        const int blk_s = (s_) / nkb;                                                                                         \
-        const bool do_a = has_a && blk_s != 2, do_b = NBT > 0 && has_b && blk_s != 3;                                         \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                                    \
-            bf16x8_t fa[2];                                                                                                   \
-            _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                                  \
-                fa[mt] = *reinterpret_cast<const bf16x8_t*>((sa_) + lds_off(wave * 32 + mt * 16 + fr, ks * 4 + fq));          \
-            if (do_a) {                                                                                                       \
-                bf16x8_t fb[4];                                                                                               \
-                _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                              \
-                    fb[nt] = *reinterpret_cast<const bf16x8_t*>((sw_) + lds_off(nt * 16 + fr, ks * 4 + fq));                  \
-                _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                              \
-                    _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                          \
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);          \
-            }                                                                                                                 \
-            if (do_b) {                                                                                                       \
-                bf16x8_t fc[NBT > 0 ? NBT : 1];                                                                               \
-                _Pragma("unroll") for (int t = 0; t < NBT; ++t)                                                               \
-                    fc[t] = *reinterpret_cast<const bf16x8_t*>((sw_) + lds_off(TC + t * 16 + fr, ks * 4 + fq));               \
-                _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                              \
-                    _Pragma("unroll") for (int t = 0; t < NBT; ++t)                                                           \
-                        acc[mt][4 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[t], fa[mt], acc[mt][4 + t], 0, 0, 0);     \
-            }                                                                                                                 \
-        }                                                                                                                     \
-    }
-        GTOS_B8_DMA_A(sa0, 0);
-        GTOS_B8_DMA_W(sw0, 0);
-        GTOS_B8_DMA_A(sa1, 1);
-        int s = 0;
-        for (; s + 6 <= nst; s += 6) {                     // A(s) in slot s % 3, W(s) in slot s % 2
-            GTOS_B8_STEP(sa0, sw0, sa2, sw1, s);
-            GTOS_B8_STEP(sa1, sw1, sa0, sw0, s + 1);
-            GTOS_B8_STEP(sa2, sw0, sa1, sw1, s + 2);
-            GTOS_B8_STEP(sa0, sw1, sa2, sw0, s + 3);
-            GTOS_B8_STEP(sa1, sw0, sa0, sw1, s + 4);
-            GTOS_B8_STEP(sa2, sw1, sa1, sw0, s + 5);
-        }
-        if (nst - s >= 2) {                                // nst = 4 * hs / 64: a remainder of 0, 2 or 4 stages (hs = 256: 16 = 12 + 4)
-            GTOS_B8_STEP(sa0, sw0, sa2, sw1, s);
-            GTOS_B8_STEP(sa1, sw1, sa0, sw0, s + 1);
-        }
-        if (nst - s >= 4) {
-            GTOS_B8_STEP(sa2, sw0, sa1, sw1, s + 2);
-            GTOS_B8_STEP(sa0, sw1, sa2, sw0, s + 3);
-        }
-        GTOS_VMCNT(0);                                     // the zero-block prefetches past the last stage
-#undef GTOS_B8_STEP
-#undef GTOS_B8_DMA_W
-#undef GTOS_B8_DMA_A
-#undef GTOS_DMA1
-    }
-    if constexpr (DBG == 2) {                              // measuring switch: the k loop alone
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4 + NBT; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-        if (t == 123.456f) a.d4[threadIdx.x] = f2bf(t);
-        return;
-    }
-    __syncthreads();                                       // btab zeroed before anyone adds to it (no k loop: no barrier so far)
-
-    if constexpr (NBT > 0) {
-        if (has_b) {                                       // role B: the previous step's input gradient, 4 * NBT consecutive columns per lane and row
-            const float ks_in = a.p_in > 0.f ? 1.f / (1.f - a.p_in) : 1.f;
-            const uint64_t seed_in = a.p_in > 0.f ? live_seed(a.seed_in) : 0;
-            const int nb = n0 + fq * 4 * NBT;
-            uint4 oldv[2][NBT / 2];                        // direction 1 adds to what direction 0 wrote: every piece in flight before the first is used
-            if (a.dinp_acc) {
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const int m = min(m0 + wave * 32 + mt * 16 + fr, a.rows_prev - 1);
-#pragma unroll
-                    for (int h = 0; h < NBT / 2; ++h) oldv[mt][h] = *reinterpret_cast<const uint4*>(a.dinp + (int64_t)m * a.ld_dinp + nb + h * 8);
-                }
-            }
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const int m = m0 + wave * 32 + mt * 16 + fr;
-                if (m >= a.rows_prev) continue;
-                bf16_t* dp = a.dinp + (int64_t)m * a.ld_dinp + nb;
-#pragma unroll
-                for (int h = 0; h < NBT / 2; ++h) {        // 8 columns (16 bytes) at a time
-                    float v[8];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = acc[mt][4 + h * 2 + (i >> 2)][i & 3];
-                    if (a.p_in > 0.f) {
-#pragma unroll
-                        for (int i = 0; i < 8; ++i)
-                            v[i] = drop_keep(seed_in, (uint64_t)(a.in_drop_base + (int64_t)m * a.n_in + nb + h * 8 + i), a.p_in) ? v[i] * ks_in : 0.f;
-                    }
-                    if (a.dinp_acc) {
-                        const uint4 o = oldv[mt][h];
-                        v[0] += lo_bf(o.x); v[1] += hi_bf(o.x); v[2] += lo_bf(o.y); v[3] += hi_bf(o.y);
-                        v[4] += lo_bf(o.z); v[5] += hi_bf(o.z); v[6] += lo_bf(o.w); v[7] += hi_bf(o.w);
-                    }
-                    Vec8<bf16_t>::store(dp + h * 8, v);
-                }
-            }
-        }
-    }
-    if (!has_a) return;
-
-    const int cb = c0 + fq * 16;
-    const float ks = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        // rows past the end read the last valid row and contribute zeros: every lane stays active (the bias sums are DPP reductions)
-        const int m_raw = m0 + wave * 32 + mt * 16 + fr;
-        const bool valid = m_raw < a.rows;
-        const int m = valid ? m_raw : a.rows - 1;
-        float gr[16], gz[16], gn[16], hn[16], hp[16], g[16];
-        const bf16_t* gp = a.gates + (int64_t)m * 4 * hs + cb;
-        ld16(gp, gr); ld16(gp + hs, gz); ld16(gp + 2 * hs, gn); ld16(gp + 3 * hs, hn);
-        ld16(a.hprev + (int64_t)m * hs + cb, hp);
-        float* dhp = static_cast<float*>(a.dh) + (int64_t)m * a.ld_dh + cb;
-        bf16_t* dhb = static_cast<bf16_t*>(a.dh) + (int64_t)m * a.ld_dh + cb;
-        if (a.dh_bf16) ld16(dhb, g); else ldf16(dhp, g);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) g[i] += acc[mt][i >> 2][i & 3];
-        if (a.dy) {
-            float dyv[16];
-            ld16(a.dy + (int64_t)m * a.ldy + cb, dyv);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float t2 = dyv[i];
-                if (a.p_drop > 0.f) t2 = drop_keep(a.seed, (uint64_t)(a.drop_base + (int64_t)m * a.ldy + cb + i), a.p_drop) ? t2 * ks : 0.f;
-                g[i] += t2;
-            }
-        }
-        float dr_[16], dz_[16], dn_[16], dhn[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float dn = g[i] * (1.f - gz[i]);
-            const float dz = g[i] * (hp[i] - gn[i]);
-            dn_[i] = dn * (1.f - gn[i] * gn[i]);
-            dhn[i] = dn_[i] * gr[i];
-            dr_[i] = dn_[i] * hn[i] * gr[i] * (1.f - gr[i]);
-            dz_[i] = dz * gz[i] * (1.f - gz[i]);
-            g[i] *= gz[i];                                             // the direct path h_prev -> h
-            if (!valid) { dn_[i] = 0.f; dhn[i] = 0.f; dr_[i] = 0.f; dz_[i] = 0.f; }
-        }
-        if (valid) {
-            if (a.dh_bf16) {
-                st16(dhb, g);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    *reinterpret_cast<float4*>(dhp + i * 4) = make_float4(g[i * 4], g[i * 4 + 1], g[i * 4 + 2], g[i * 4 + 3]);
-            }
-            bf16_t* dp = a.d4 + (int64_t)m * 4 * hs + cb;
-            st16(dp, dr_); st16(dp + hs, dz_); st16(dp + 2 * hs, dn_); st16(dp + 3 * hs, dhn);
-            if (a.hp_out) st16(a.hp_out + (int64_t)m * hs + cb, hp);
-        }
-        if (a.bias_part) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float t0 = row16_sum(bf2f(f2bf(dr_[i]))), t1 = row16_sum(bf2f(f2bf(dz_[i])));
-                const float t2 = row16_sum(bf2f(f2bf(dn_[i]))), t3 = row16_sum(bf2f(f2bf(dhn[i])));
-                if (fr == 0) {
-                    atomicAdd(&btab[0 * TC + fq * 16 + i], t0); atomicAdd(&btab[1 * TC + fq * 16 + i], t1);
-                    atomicAdd(&btab[2 * TC + fq * 16 + i], t2); atomicAdd(&btab[3 * TC + fq * 16 + i], t3);
-                }
-            }
-        }
-    }
-    if (a.bias_part) {
-        __syncthreads();
-        if (threadIdx.x < 4 * TC) {
-            const int q = threadIdx.x >> 6, ch = threadIdx.x & 63;
-            atomicAdd(a.bias_part + (int64_t)(blockIdx.x % a.n_partials) * 4 * hs + q * hs + c0 + ch, btab[threadIdx.x]);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Round 6: PERSISTENT backward step -- the weights stay in LDS for the whole launch, the waves are decoupled.
-//
-// Every tile kernel above runs a workgroup in lock step: DMA a stage, wait, barrier, multiply, barrier -- and then its cell, while nothing
-// multiplies.  Measured at 434,624 rows of layer 1 (tools/bench_gru_step.py, round 6): the 128-row kernel 520 us without its k loops + 566 us
-// of k loops alone = 1,070 together; the 256-row / eight-wave kernel of this round's first attempt (half the LDS-DMA bytes, 88 KB in flight):
-// 487 + 597 = 1,107.  Fewer operand bytes and more of them in flight bought nothing: the phases of a workgroup are serial by construction and
-// the k loop's MFMA pipe idles through every wait-barrier-fragment-read sequence (0.9 PF/s alone).
-// Here the two products of a row -- recurrent: d4_prev[{r,z,n_h}] x W_hh^T, input gradient: d4_prev[{r,z,n_x}] x W_ih^T; 768 output columns
-// at layer 1, 384 at layer 0, K = 768 each -- are cut into S column SLICES of 96 columns (NA*16 state channels + NBT*16 input columns:
-// 32 + 64 at layer 1, S = 8; 64 + 32 at layer 0, S = 4), whose 96 x 768 weight elements are exactly 144 KB: one workgroup per CU loads its
-// slice ONCE and keeps it.  After that there is no LDS-DMA, no stage, no barrier: each of the eight waves walks its own 32-row tiles,
-// pulls the d4_prev rows straight into MFMA fragment registers (buffer loads, three k tiles ahead; rows past rows_prev come back as
-// zeros from the bounds check), reads weight fragments from the resident slice, and runs role B's store and role A's cell on its
-// accumulators -- the cell's operand loads of the tile are issued in the middle of its k loop, its stores drain under the next tile's.
-// While one wave of a SIMD waits for memory the other one multiplies.  The S slices of a row panel run on one XCD at the same pace, so a
-// panel's d4_prev rows come from HBM once.
-// Accumulation order per output element is the tile kernels': same k tiles, same order, same operands -- the same bits.
-// Bias-gradient partial sums collect in LDS over the whole launch (one flush per workgroup).
-template <int NA, int NBT>
-struct PwGeom {
-    static constexpr int NKB = 4, NKT = 4 * NKB;                               // hs = 256: four 64-k tiles per block of d4 = [r | z | n_x | n_h]
-    static constexpr int RA = 16 * NA, RB = 16 * NBT;
-    // LDS region of k tile kt: role A rows (blocks r, z, n_h) then role B rows (blocks r, z, n_x), 128 bytes each
-    static constexpr int rows(int kt) { return kt / NKB < 2 ? RA + RB : (kt / NKB == 2 ? RB : RA); }
-    static constexpr int off(int kt) {
-        return (kt / NKB < 2 ? kt * (RA + RB) : kt / NKB == 2 ? 2 * NKB * (RA + RB) + (kt - 2 * NKB) * RB
-                                                              : 2 * NKB * (RA + RB) + NKB * RB + (kt - 3 * NKB) * RA) * ROWB;
-    }
-    static constexpr int BYTES = (2 * NKB * (RA + RB) + NKB * (RA + RB)) * ROWB;
-    static constexpr int LDS_TOTAL = BYTES + 4 * RA * (int)sizeof(float);
-};
-
-// LDS offset of (row, 16-byte chunk) inside a k tile's region: the chunk swizzle depends on the row's position inside its 16-row MFMA block
-// only, so the fragment address of block nt is the lane's base + nt * 2048 -- an immediate (lds_off's swizzle also mixes in the block
-// index: a register per block and k half, and this kernel has none to spare)
-__device__ __forceinline__ int pw_off(int r, int c) { return r * ROWB + ((c ^ ((r >> 1) & 7)) << 4); }
-
-#ifndef GTOS_PW_DEPTH
-#define GTOS_PW_DEPTH 5
-#endif
-template <int NA, int NBT, bool ACC, bool DY>
-__global__ __launch_bounds__(512, 2) void gru_step_bwd_pw_kernel(StepBwdArgs a, int n_panels, int S, int Wk) {
-    using G = PwGeom<NA, NBT>;
-    constexpr int NKB = G::NKB, NKT = G::NKT, RA = G::RA, CH = 4 * NA, CV = CH / 8, NBV = NBT / 2, DEPTH = GTOS_PW_DEPTH, NBUF = DEPTH + 1;
-    extern __shared__ __attribute__((aligned(16))) char pw[];
-    float* btab = reinterpret_cast<float*>(pw + G::BYTES);                     // [4 gates][RA channels]
-    if (a.p_drop > 0.f) a.seed = live_seed(a.seed);
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int fr = lane & 15, fq = lane >> 4;
-    const int hs = a.hs;
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, slice = idx % S, worker = idx / S;
-    if (worker >= Wk) return;
-    const int c0 = slice * RA, n0 = slice * G::RB;
-
-    // ---- the slice's weights -> LDS, once ----
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-        const int b = kt / NKB, npc = G::rows(kt) / 8;
-        for (int j = wave; j < npc; j += 8) {
-            const int row = j * 8 + (lane >> 3);                               // region-relative row
-            const bool is_a = b != 2 && row < RA;
-            const int rr = is_a ? row : row - (b < 2 ? RA : 0);                // row inside its role's block
-            const int nt = rr >> 4, q = (rr >> 2) & 3, e = rr & 3;
-            const int c = (lane & 7) ^ ((row >> 1) & 7);            // (pw_off's swizzle)
-            const bf16_t* src = is_a ? a.wh_t + (int64_t)(c0 + q * CH + nt * 4 + e) * 3 * hs + (b == 3 ? kt - NKB : kt) * BK + c * 8
-                                     : a.wi_t + (int64_t)(n0 + q * 4 * NBT + nt * 4 + e) * 3 * hs + kt * BK + c * 8;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(pw + G::off(kt) + j * 1024), 16, 0, 0);
-        }
-    }
-    if (threadIdx.x < 4 * RA) btab[threadIdx.x] = 0.f;
-    GTOS_VMCNT(0);
-    __syncthreads();
-
-    const uint32_t rowb = (uint32_t)hs * 8u;                                   // bytes of a d4 row
-    const uint32_t vo0 = (uint32_t)fr * rowb + (uint32_t)fq * 16u, vo1 = vo0 + 16u * rowb;
-    const int cb = c0 + fq * CH, nb = n0 + fq * 4 * NBT;
-    const float ks_d = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
-    const float ks_in = a.p_in > 0.f ? 1.f / (1.f - a.p_in) : 1.f;
-    const uint64_t seed_in = a.p_in > 0.f ? live_seed(a.seed_in) : 0;
-
-    for (int p = xcd + 8 * worker; p < n_panels; p += 8 * Wk) {
-        const int m_base = p * 256 + wave * 32;                                // this wave's 32 rows
-        const bool has_a = m_base < a.rows, has_b = m_base < a.rows_prev;     // (role B and the recurrent product need rows of the step before)
-        if (!has_a && !has_b) continue;
-        f32x4_t acc[2][NA + NBT];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < NA + NBT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        // operand addresses of the cell (rows past the end re-read the last valid row; never stored) and of role B
-        int mrow[2];
-        bool valid[2], bvalid[2];
-        const bf16_t* gp[2];
-        U128 cg[2][4][CV], chp[2][CV], cdh[2][CV], cdy[2][DY ? CV : 1], oldv[2][ACC ? NBV : 1];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int m_raw = m_base + mt * 16 + fr;
-            valid[mt] = m_raw < a.rows;
-            bvalid[mt] = m_raw < a.rows_prev;
-            mrow[mt] = min(m_raw, a.rows - 1);
-            gp[mt] = a.gates + (int64_t)mrow[mt] * 4 * hs + cb;
-        }
-        auto cell_loads = [&](int mt) {
-#pragma unroll
-            for (int v = 0; v < CV; ++v) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) cg[mt][g][v] = *reinterpret_cast<const U128*>(gp[mt] + g * hs + v * 8);
-                chp[mt][v] = *reinterpret_cast<const U128*>(a.hprev + (int64_t)mrow[mt] * hs + cb + v * 8);
-                cdh[mt][v] = *reinterpret_cast<const U128*>(static_cast<const bf16_t*>(a.dh) + (int64_t)mrow[mt] * a.ld_dh + cb + v * 8);
-                if constexpr (DY) cdy[mt][v] = *reinterpret_cast<const U128*>(a.dy + (int64_t)mrow[mt] * a.ldy + cb + v * 8);
-            }
-            if constexpr (ACC) {
-                const int mb = min(m_base + mt * 16 + fr, a.rows_prev - 1);
-#pragma unroll
-                for (int h = 0; h < NBV; ++h) oldv[mt][h] = *reinterpret_cast<const U128*>(a.dinp + (int64_t)mb * a.ld_dinp + nb + h * 8);
-            }
-        };
-        if (has_b) {
-            const int nrow = min(32, a.rows_prev - m_base);
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<bf16_t*>(a.d4_prev + (int64_t)m_base * 4 * hs), 0, (int)((uint32_t)nrow * rowb), 0x00020000);
-            U128 af[NBUF][2][2];
-            bf16x8_t fw[NA + NBT];                         // weight fragments of a 32-k step (the SIMD's other wave multiplies while these arrive)
-#define GTOS_PW_LOAD_A(kt_)                                                                                                    \
-            {                                                                                                                  \
-                _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) {                                                          \
-                    af[(kt_) % NBUF][0][ks_] = __builtin_bit_cast(U128, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)vo0 + (kt_) * ROWB + ks_ * 64, 0, 0)); \
-                    af[(kt_) % NBUF][1][ks_] = __builtin_bit_cast(U128, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)vo1 + (kt_) * ROWB + ks_ * 64, 0, 0)); \
-                }                                                                                                              \
-            }
-#pragma unroll
-            for (int kt = 0; kt < DEPTH; ++kt) GTOS_PW_LOAD_A(kt)
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < 2 * NKT; ++u) {            // a step = one 32-k half of a k tile: 2 * (NA + NBT) MFMAs at most
-                const int kt = u >> 1, ks = u & 1, b = kt / NKB;
-                const char* reg = pw + G::off(kt);
-                // issue first: (once per k tile) the row loads DEPTH tiles ahead, (once) the first row block's cell operands, this step's weight fragments
-                if (ks == 0 && kt + DEPTH < NKT) GTOS_PW_LOAD_A(kt + DEPTH)
-                if (ks == 0 && kt == NKT - (DEPTH < 3 ? DEPTH : 2)) cell_loads(0);      // behind the last row loads: they fly through the rest of the k loop
-                if (b != 2) {
-#pragma unroll
-                    for (int nt = 0; nt < NA; ++nt) fw[nt] = *reinterpret_cast<const bf16x8_t*>(reg + pw_off(nt * 16 + fr, ks * 4 + fq));
-                }
-                if (b != 3) {
-#pragma unroll
-                    for (int t = 0; t < NBT; ++t) fw[NA + t] = *reinterpret_cast<const bf16x8_t*>(reg + pw_off((b < 2 ? RA : 0) + t * 16 + fr, ks * 4 + fq));
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                const bf16x8_t fa0 = __builtin_bit_cast(bf16x8_t, af[kt % NBUF][0][ks]), fa1 = __builtin_bit_cast(bf16x8_t, af[kt % NBUF][1][ks]);
-                if (b != 2) {
-#pragma unroll
-                    for (int nt = 0; nt < NA; ++nt) {
-                        acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nt], fa0, acc[0][nt], 0, 0, 0);
-                        acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nt], fa1, acc[1][nt], 0, 0, 0);
-                    }
-                }
-                if (b != 3) {
-#pragma unroll
-                    for (int t = 0; t < NBT; ++t) {
-                        acc[0][NA + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[NA + t], fa0, acc[0][NA + t], 0, 0, 0);
-                        acc[1][NA + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[NA + t], fa1, acc[1][NA + t], 0, 0, 0);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#undef GTOS_PW_LOAD_A
-            cell_loads(1);                                 // the second row block's: under the input-gradient stores and the first block's cell
-            // role B: the previous step's input gradient, 4 * NBT consecutive columns per lane and row
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const int m = m_base + mt * 16 + fr;
-                if (!bvalid[mt]) continue;
-                bf16_t* dp = a.dinp + (int64_t)m * a.ld_dinp + nb;
-#pragma unroll
-                for (int h = 0; h < NBV; ++h) {
-                    float v[8];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = acc[mt][NA + h * 2 + (i >> 2)][i & 3];
-                    if (a.p_in > 0.f) {
-#pragma unroll
-                        for (int i = 0; i < 8; ++i)
-                            v[i] = drop_keep(seed_in, (uint64_t)(a.in_drop_base + (int64_t)m * a.n_in + nb + h * 8 + i), a.p_in) ? v[i] * ks_in : 0.f;
-                    }
-                    if constexpr (ACC) {
-                        const U128 o = oldv[mt][h];
-                        v[0] += lo_bf(o.x); v[1] += hi_bf(o.x); v[2] += lo_bf(o.y); v[3] += hi_bf(o.y);
-                        v[4] += lo_bf(o.z); v[5] += hi_bf(o.z); v[6] += lo_bf(o.w); v[7] += hi_bf(o.w);
-                    }
-                    Vec8<bf16_t>::store(dp + h * 8, v);
-                }
-            }
-        } else {
-            cell_loads(0);
-            cell_loads(1);
-        }
-        if (!has_a) continue;
-
-        // role A: the cell backward of the tile's rows, CH consecutive channels per lane and row, eight at a time
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            bf16_t* dhb = static_cast<bf16_t*>(a.dh) + (int64_t)mrow[mt] * a.ld_dh + cb;
-            bf16_t* dp = a.d4 + (int64_t)mrow[mt] * 4 * hs + cb;
-#pragma unroll
-            for (int v = 0; v < CV; ++v) {
-                float gr[8], gz[8], gn[8], hn[8], hp[8], g[8];
-#define GTOS_PW_UNPACK(dst, src)                                                                                               \
-                {                                                                                                              \
-                    const U128 r_ = (src);                                                                                     \
-                    dst[0] = lo_bf(r_.x); dst[1] = hi_bf(r_.x); dst[2] = lo_bf(r_.y); dst[3] = hi_bf(r_.y);                    \
-                    dst[4] = lo_bf(r_.z); dst[5] = hi_bf(r_.z); dst[6] = lo_bf(r_.w); dst[7] = hi_bf(r_.w);                    \
-                }
-                GTOS_PW_UNPACK(gr, cg[mt][0][v]) GTOS_PW_UNPACK(gz, cg[mt][1][v]) GTOS_PW_UNPACK(gn, cg[mt][2][v]) GTOS_PW_UNPACK(hn, cg[mt][3][v])
-                GTOS_PW_UNPACK(hp, chp[mt][v]) GTOS_PW_UNPACK(g, cdh[mt][v])
-#pragma unroll
-                for (int i = 0; i < 8; ++i) g[i] += acc[mt][v * 2 + (i >> 2)][i & 3];
-                if constexpr (DY) {
-                    float dyv[8];
-                    GTOS_PW_UNPACK(dyv, cdy[mt][v])
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        float t2 = dyv[i];
-                        if (a.p_drop > 0.f)
-                            t2 = drop_keep(a.seed, (uint64_t)(a.drop_base + (int64_t)mrow[mt] * a.ldy + cb + v * 8 + i), a.p_drop) ? t2 * ks_d : 0.f;
-                        g[i] += t2;
-                    }
-                }
-#undef GTOS_PW_UNPACK
-                float dr_[8], dz_[8], dn_[8], dhn[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float dn = g[i] * (1.f - gz[i]);
-                    const float dz = g[i] * (hp[i] - gn[i]);
-                    dn_[i] = dn * (1.f - gn[i] * gn[i]);
-                    dhn[i] = dn_[i] * gr[i];
-                    dr_[i] = dn_[i] * hn[i] * gr[i] * (1.f - gr[i]);
-                    dz_[i] = dz * gz[i] * (1.f - gz[i]);
-                    g[i] *= gz[i];                                         // the direct path h_prev -> h
-                    if (!valid[mt]) { dn_[i] = 0.f; dhn[i] = 0.f; dr_[i] = 0.f; dz_[i] = 0.f; }
-                }
-                if (valid[mt]) {
-                    Vec8<bf16_t>::store(dhb + v * 8, g);
-                    Vec8<bf16_t>::store(dp + v * 8, dr_); Vec8<bf16_t>::store(dp + hs + v * 8, dz_);
-                    Vec8<bf16_t>::store(dp + 2 * hs + v * 8, dn_); Vec8<bf16_t>::store(dp + 3 * hs + v * 8, dhn);
-                }
-                if (a.bias_part) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const float t0 = row16_sum(bf2f(f2bf(dr_[i]))), t1 = row16_sum(bf2f(f2bf(dz_[i])));
-                        const float t2 = row16_sum(bf2f(f2bf(dn_[i]))), t3 = row16_sum(bf2f(f2bf(dhn[i])));
-                        if (fr == 0) {
-                            atomicAdd(&btab[0 * RA + fq * CH + v * 8 + i], t0); atomicAdd(&btab[1 * RA + fq * CH + v * 8 + i], t1);
-                            atomicAdd(&btab[2 * RA + fq * CH + v * 8 + i], t2); atomicAdd(&btab[3 * RA + fq * CH + v * 8 + i], t3);
-                        }
-                    }
-                }
-            }
-        }
-    }
-    if (a.bias_part) {
-        __syncthreads();
-        if (threadIdx.x < 4 * RA) {
-            const int q = threadIdx.x / RA, ch = threadIdx.x % RA;
-            atomicAdd(a.bias_part + (int64_t)(blockIdx.x % a.n_partials) * 4 * hs + q * hs + c0 + ch, btab[threadIdx.x]);
-        }
-    }
-}
 
 }  // namespace
 
@@ -2156,50 +1622,6 @@ extern "C" int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, i
     return 0;
 }
 
-// which backward step kernel runs (read once from the environment; gtos_gru_bwd_config overrides per process -- the tests compare them):
-// 2 = the persistent kernel where it applies (default), 1 = the 256-row / eight-wave tile kernel, 0 = the 128-row tile kernel only
-static int g_bwd_kernel = getenv("GTOS_GRU_BWD_KERNEL") ? atoi(getenv("GTOS_GRU_BWD_KERNEL")) : 2;
-static const int k_bwd8_min_rows = getenv("GTOS_GRU_BWD8_MINROWS") ? atoi(getenv("GTOS_GRU_BWD8_MINROWS")) : 8192;
-static const int k_bwd_pw_min_rows = getenv("GTOS_GRU_BWD_PW_MINROWS") ? atoi(getenv("GTOS_GRU_BWD_PW_MINROWS")) : 32768;
-static int g_bwd8_min_rows = k_bwd8_min_rows, g_bwd_pw_min_rows = k_bwd_pw_min_rows;
-extern "C" int gtos_gru_bwd_config(int kernel, int min_rows) {
-    if (kernel >= 0) g_bwd_kernel = kernel;
-    if (min_rows >= 0) g_bwd8_min_rows = g_bwd_pw_min_rows = min_rows;
-    if (min_rows == -2) { g_bwd8_min_rows = k_bwd8_min_rows; g_bwd_pw_min_rows = k_bwd_pw_min_rows; }
-    return 0;
-}
-
-template <int NA, int NBT>
-static int launch_bwd_pw(const StepBwdArgs& a, bool acc, bool dy, long long cover, hipStream_t st) {
-    using G = PwGeom<NA, NBT>;
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t pr;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return -7;
-        n_cu = pr.multiProcessorCount;
-    }
-    const int S = a.hs / G::RA, Wk = (n_cu / 8) / S > 0 ? (n_cu / 8) / S : 1;
-    const int n_panels = (int)((cover + 255) / 256);
-#define GTOS_PW_GO(ACC_, DY_)                                                                                                     \
-    {                                                                                                                             \
-        static bool configured = false;                                                                                           \
-        if (!configured) {                                                                                                        \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_bwd_pw_kernel<NA, NBT, ACC_, DY_>),                    \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_TOTAL) != hipSuccess) return -7;           \
-            configured = true;                                                                                                    \
-        }                                                                                                                         \
-        hipLaunchKernelGGL((gru_step_bwd_pw_kernel<NA, NBT, ACC_, DY_>), dim3(8 * S * Wk), dim3(512), G::LDS_TOTAL, st, a, n_panels, S, Wk); \
-    }
-    if (acc && dy) GTOS_PW_GO(true, true)
-    else if (acc) GTOS_PW_GO(true, false)
-    else if (dy) GTOS_PW_GO(false, true)
-    else GTOS_PW_GO(false, false)
-#undef GTOS_PW_GO
-    GTOS_CHECK_LAUNCH();
-    return 0;
-}
-
 extern "C" int gtos_gru_step_bwd_fused(int rows, int hs, const void* d4_prev, int rows_prev, const void* w_hh_t,
                                        const void* gates, const void* hprev, const int* hprev_idx, const void* dy, int64_t ldy,
                                        void* dh, int dh_dtype, int64_t ld_dh, void* d4, float p_drop, uint64_t seed, int64_t drop_base,
@@ -2239,32 +1661,6 @@ extern "C" int gtos_gru_step_bwd_fused(int rows, int hs, const void* d4_prev, in
     static const int bwd_dbg = getenv("GTOS_GRU_BWD_DBG") ? atoi(getenv("GTOS_GRU_BWD_DBG")) : 0;
     const int dbg = (w_hn || sum_idx) ? 0 : bwd_dbg;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // Round 6: launches with a recurrent product over at least g_bwd8_min_rows rows run on 256-row panels with both roles in one eight-wave
-    // workgroup (gru_step_bwd8_kernel; GTOS_GRU_BWD_KERNEL=1 / gtos_gru_bwd_config).  Same bits as the kernel below.
-    const int nC8 = hs / TC, nbt = role_b ? n_in / (nC8 * 16) : 0;
-    // the persistent kernel: hs = 256, both roles, bf16 state gradient, n_in = 512 (8 slices of 32 channels + 64 columns) or 128 (4 of 64 + 32)
-    if (g_bwd_kernel == 2 && hs == 256 && rows > 0 && d4_prev && rows_prev > 0 && role_b && a.dh_bf16 && !sum_idx && !w_hn && !hprev_idx &&
-        !hprev_out && cover >= g_bwd_pw_min_rows && (n_in == 512 || n_in == 128) && (int64_t)cover * hs * 8 < (1LL << 40)) {
-        return n_in == 512 ? launch_bwd_pw<2, 4>(a, dinp_accumulate != 0, dy != nullptr, cover, st)
-                           : launch_bwd_pw<4, 2>(a, dinp_accumulate != 0, dy != nullptr, cover, st);
-    }
-    if (g_bwd_kernel >= 1 && rows > 0 && d4_prev && rows_prev > 0 && !sum_idx && !w_hn && !hprev_idx && cover >= g_bwd8_min_rows &&
-        (!role_b || (n_in == nC8 * 16 * nbt && (nbt == 2 || nbt == 4 || nbt == 8))) && (int64_t)hs * 6 * (n_in > hs ? n_in : hs) < (1LL << 32)) {
-        const long long nM8 = (cover + 255) / 256, nblk8 = ((nM8 + 7) / 8) * 8 * nC8;
-#define GTOS_BWD8_LAUNCH(NBT_)                                                                                                    \
-        {                                                                                                                         \
-            if (dbg == 1) hipLaunchKernelGGL((gru_step_bwd8_kernel<NBT_, 1>), dim3((unsigned)nblk8), dim3(512), 0, st, a);        \
-            else if (dbg == 2) hipLaunchKernelGGL((gru_step_bwd8_kernel<NBT_, 2>), dim3((unsigned)nblk8), dim3(512), 0, st, a);   \
-            else hipLaunchKernelGGL((gru_step_bwd8_kernel<NBT_, 0>), dim3((unsigned)nblk8), dim3(512), 0, st, a);                 \
-        }
-        if (nbt == 8) GTOS_BWD8_LAUNCH(8)
-        else if (nbt == 4) GTOS_BWD8_LAUNCH(4)
-        else if (nbt == 2) GTOS_BWD8_LAUNCH(2)
-        else GTOS_BWD8_LAUNCH(0)
-#undef GTOS_BWD8_LAUNCH
-        GTOS_CHECK_LAUNCH();
-        return 0;
-    }
 #define GTOS_BWD_LAUNCH(HN_, D_) hipLaunchKernelGGL((gru_step_bwd_kernel<HN_, D_>), dim3((unsigned)nblk), dim3(256), 0, st, a)
     if (w_hn) GTOS_BWD_LAUNCH(true, 0);
     else if (dbg == 1) GTOS_BWD_LAUNCH(false, 1);

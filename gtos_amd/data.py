@@ -56,7 +56,7 @@ def complete_on_device(batch, device=None, tries="hip"):
     train = batch['relation_graphs'].path_mode != relbatch.PATH_ALL
     attach_device_relations(batch, device)
     from .relbatch_hip import HipBackend
-    if not batch['relation'].is_cuda and getattr(HipBackend.shared(), "needs_device", False):
+    if not batch['relation'].is_cuda and HipBackend.backend_needs_device():
         return batch                       # completed by the host builder (the consumer is not a GPU): reference-shaped, nothing device-side to add
     if train:
         attach_device_relation_index(batch)
@@ -134,7 +134,7 @@ def attach_device_relations(batch, device=None):
         return batch
     dev = batch['concept'].device if device is None else torch.device(device)
     from .relbatch_hip import HipBackend, build_relation_batch_all_staged, build_relation_batch_staged
-    if dev.type != "cuda" and getattr(HipBackend.shared(), "needs_device", False):
+    if dev.type != "cuda" and HipBackend.backend_needs_device():
         # the HIP stage kernels take device pointers: a consumer on the host gets the C++ host builder's tensors (the same arrays, element
         # for element: tests/test_zzz_hip_relbatch.py) -- complete, reference-shaped.  (The tests' emulation backends run the stage code
         # on host memory and do not set ``needs_device``.)

@@ -51,9 +51,10 @@ RECOMPUTE_HN = os.environ.get("GTOS_GRU_RECOMPUTE_HN", "0") == "1"
 
 
 def _step_fwd(A, hs, x, xg, h_in, wi, b_ih, wh, b_hh, h_out, n_out, h_fin, gates, y, y_off_elems, ldy, p, seed, drop_base,
-              h_idx=None, gf=None, gf_idx=None, gb=None, gb_idx=None, fin_idx=None, tag=None):
+              h_idx=None, gf=None, gf_idx=None, gb=None, gb_idx=None, fin_idx=None, tag=None, save_hn=None):
     """``h_fin``: [*, hs] or a column block of a wider matrix (its row stride is passed on); ``fin_idx``: int32 row map of the
-    finished rows (packed row m -> row fin_idx[m] of h_fin)."""
+    finished rows (packed row m -> row fin_idx[m] of h_fin).  ``save_hn``: None = by RECOMPUTE_HN (the callers whose backward passes the
+    kernel w_hn / b_hn); True = always store the hn block (the packed path: its backward launches read it)."""
     yp = None if y is None else y.data_ptr() + y_off_elems * y.element_size()
     need_bi = x is not None or gf is not None
     # ``tag`` (bench.py's per-kernel rows): the span is recorded under that name with its ALGORITHMIC bytes as units -- per active row the
@@ -62,16 +63,18 @@ def _step_fwd(A, hs, x, xg, h_in, wi, b_ih, wh, b_hh, h_out, n_out, h_fin, gates
     units = A if tag is None else A * 2 * (x.shape[1] + hs + 4 * hs + hs + (hs if y is not None else 0))
     with _Timed(name, detail=True, units=units):
         _step_fwd_call(A, hs, x, xg, h_in, wi, b_ih, wh, b_hh, h_out, n_out, h_fin, gates, yp, ldy, p, seed, drop_base,
-                       h_idx, gf, gf_idx, gb, gb_idx, need_bi, fin_idx)
+                       h_idx, gf, gf_idx, gb, gb_idx, need_bi, fin_idx, save_hn)
 
 
 def _step_fwd_call(A, hs, x, xg, h_in, wi, b_ih, wh, b_hh, h_out, n_out, h_fin, gates, yp, ldy, p, seed, drop_base,
-                   h_idx, gf, gf_idx, gb, gb_idx, need_bi, fin_idx=None):
+                   h_idx, gf, gf_idx, gb, gb_idx, need_bi, fin_idx=None, save_hn=None):
+    if save_hn is None:
+        save_hn = not RECOMPUTE_HN
     call("gtos_gru_step_fwd", A, hs, ptr(x), 0 if x is None else x.stride(0), 0 if x is None else x.shape[1],
          ptr(wi) if x is not None else None, ptr(b_ih) if need_bi else None, ptr(xg),
          ptr(gf), ptr(gf_idx), ptr(gb), ptr(gb_idx), ptr(h_in), ptr(h_idx), ptr(wh), ptr(b_hh),
          ptr(h_out), n_out, ptr(h_fin), hs if h_fin is None else h_fin.stride(0), ptr(fin_idx), ptr(gates), yp, ldy,
-         float(p), seed, drop_base, 0 if RECOMPUTE_HN else 1, stream())
+         float(p), seed, drop_base, 1 if save_hn else 0, stream())
 
 
 def _step_bwd(A, hs, d4_prev, rows_prev, wh_t, gates, hprev, dy_ptr, ldy, dh, d4, p, seed, drop_base, bpart, hprev_idx=None, hp_out=None,
@@ -352,9 +355,13 @@ class PackedPathGRUFn(torch.autograd.Function):
         dev, dtp = table.device, torch.bfloat16
         bs, offs, L, N = plan.batch_sizes, plan.offs, plan.L, plan.N
         R = bank.shape[1]
+        if L == 0 or R == 0:                               # no active step (every path empty / no path): the final states are zero vectors
+            ctx.cfg = False
+            return torch.zeros((R, 2 * hs), dtype=dtp, device=dev)
         V, dim = table.shape
         tab = table.detach()
-        want_table = table.requires_grad
+        # (a custom Function's forward runs under no_grad: whether anybody will call backward is what needs_input_grad says)
+        want_table = table.requires_grad and ctx.needs_input_grad[2]
         Vp = (V + 7) // 8 * 8
         X = torch.empty((N, dim_pad), dtype=dtp, device=dev)
         onehot = torch.empty((N, Vp), dtype=dtp, device=dev) if (want_table and V <= 256) else None
@@ -414,7 +421,8 @@ class PackedPathGRUFn(torch.autograd.Function):
                         h_out, n_out = None, 0
                     _step_fwd(A, hs, inp[off:off + A], None, hprev[off:off + A], wi, bi, wh, bh, h_out, n_out, h_fin, gates[off:off + A],
                               Y, off * 2 * hs + direction * hs, 2 * hs, pl, seed, off * 2 * hs + direction * hs,
-                              fin_idx=plan.order32 if last else None, tag="gru_step_fwd_packed_l%d" % l)
+                              fin_idx=plan.order32 if last else None, tag="gru_step_fwd_packed_l%d" % l,
+                              save_hn=True)           # (_step_bwd_fused reads the hn block: GTOS_GRU_RECOMPUTE_HN does not apply here)
                 layer_saved.append((wi_t, wh_t, gates, hprev))
             if aux is not main:
                 main.wait_stream(aux)
@@ -430,6 +438,11 @@ class PackedPathGRUFn(torch.autograd.Function):
 
     @staticmethod
     def _backward(ctx, d_out):
+        if ctx.cfg is False:                               # the empty plan: nothing depends on any input
+            return (None,) * len(ctx.needs_input_grad)
+        if ctx.cfg is None:
+            raise RuntimeError("PackedPathGRUFn: backward called a second time -- the saved gates and states are released piece by piece "
+                               "during the first (retain_graph is not supported on this path)")
         plan, table, dim_pad, p_embed, seed_e, hs, weights, saved, onehot, tokens = ctx.cfg
         bs, offs, L, N = plan.batch_sizes, plan.offs, plan.L, plan.N
         dev, dtp = d_out.device, torch.bfloat16
@@ -441,7 +454,7 @@ class PackedPathGRUFn(torch.autograd.Function):
                 wt_ = weights[base + slot]
                 if wt_.requires_grad and _grad_target(wt_) is None:
                     grads[base + slot] = torch.zeros(wt_.shape, dtype=torch.float32, device=dev)
-        want_table = table.requires_grad
+        want_table = onehot is not None or tokens is not None
         main = torch.cuda.current_stream(dev)
         used_side, held = False, None
         dY = None                                     # d(loss) / d(layer 0 output, after its dropout), [N, 2hs]

@@ -84,6 +84,13 @@ class HipBackend(object):
             cls._shared = cls()
         return cls._shared
 
+    @classmethod
+    def backend_needs_device(cls):
+        """Whether the backend in use takes device pointers -- WITHOUT loading libgtos_hip.so: a host-side consumer asks this to decide
+        for the C++ host builder, and must get its answer on a box where the HIP library cannot be loaded.  (The tests' emulation
+        backends are installed as ``_shared`` and do not set ``needs_device``.)"""
+        return bool(getattr(cls._shared if cls._shared is not None else cls, "needs_device", False))
+
     def _workspace(self, total, dev):
         out = ctypes.c_int64(0)
         if self._lib.gtos_relbatch_dev_workspace(total, ctypes.byref(out)):

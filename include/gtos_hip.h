@@ -238,20 +238,6 @@ int gtos_gru_step_bwd_fused(int rows, int hs, const void* d4_prev, int rows_prev
                             const void* w_ih_t, void* dinp, int64_t ld_dinp, int n_in, int dinp_accumulate, float p_in, uint64_t seed_in,
                             int64_t in_drop_base, void* stream);
 
-/* Which kernel gtos_gru_step_bwd_fused launches (round 6; all three give the SAME BITS in dh, d4 and dinp).  kernel:
- *   2 (default; GTOS_GRU_BWD_KERNEL)  gru_step_bwd_pw_kernel where it applies -- hs = 256, a recurrent product (d4_prev != NULL, rows > 0) AND dinp,
- *       n_in = 512 or 128, bf16 dh, no trie indirection / hn recompute / hprev_idx / hprev_out, >= 32768 covered rows (GTOS_GRU_BWD_PW_MINROWS):
- *       PERSISTENT workgroups, one per CU, each keeping a 96-column slice of [W_hh^T | W_ih^T] (144 KB) in LDS for the whole launch; the waves
- *       are decoupled (no stage, no barrier): a wave pulls its 32 rows of d4_prev straight into MFMA fragment registers, multiplies against
- *       the resident slice, stores its part of dinp and runs the cell on its accumulators, while the SIMD's other wave is in another phase;
- *       else as 1;
- *   1  gru_step_bwd8_kernel for launches covering >= 8192 rows (GTOS_GRU_BWD8_MINROWS) with dinp absent or n_in = (hs/64) * 16 * {2, 4, 8}:
- *       256-row tiles, eight waves, both roles fed from one walk over d4_prev (measured slower than 0: kept as the A/B of the round);
- *   0  gru_step_bwd_kernel only (128-row tiles, a workgroup per role and tile; every shape).
- * kernel < 0: leave.  min_rows >= 0: both row thresholds; -2: back to the defaults; -1: leave.  Returns 0.  A process-wide switch for A/B
- * timing and for the tests that compare the kernels bit for bit. */
-int gtos_gru_bwd_config(int kernel, int min_rows);
-
 /* Both weight gradients of one GRU layer and direction over all its packed rows in ONE grouped product (round 5; torch's GRU backward runs
  * dW_ih = d(xg)^T x and dW_hh = d(hg)^T h_prev as separate GEMMs): with d4 [rows,4hs] = d r | d z | d n_x | d n_h,
  *   dwih[3hs, in_valid] += d4[:, 0:3hs]^T x[:, 0:in_valid]          x [rows, in_dim] (row stride ldx; columns in_valid.. are zero padding)

@@ -2152,3 +2152,44 @@ def test_packed_path_gru_two_stream_forward_is_the_same_function(monkeypatch):
     assert torch.equal(res[0][0], res[1][0])
     for k in res[0][1]:
         torch.testing.assert_close(res[0][1][k], res[1][1][k], rtol=1e-5, atol=1e-6, msg=lambda s_, k=k: "%s: %s" % (k, s_))
+
+
+def test_packed_path_gru_ignores_the_hn_recompute_switch_and_handles_its_edge_cases(monkeypatch):
+    """ADVICE round 5.  (i) GTOS_GRU_RECOMPUTE_HN=1 belongs to the per-row / trie evaluations, whose backward hands the step kernel
+    w_hn / b_hn; the packed path's backward launches READ the saved hn block, so its forward stores it whatever the switch says: same
+    bits in the outputs and in every gradient with the switch on.  (ii) A second backward raises a clear error (the saved gates are
+    released during the first).  (iii) A bank without an active step (every path empty) gives zero vectors and no gradient."""
+    from gtos_amd import gru, ops
+    bank, length = _relenc_case(R=900, L=7, V=86)
+    ref, m = _relenc_pair(bank, length, hid=64)
+    m.compute_dtype = torch.bfloat16
+    m.dropout = 0.25
+    m.train()
+    wout = torch.randn(bank.shape[1], 64, generator=torch.Generator().manual_seed(1)).to(dev())
+    res = []
+    for flag in (False, True):
+        monkeypatch.setattr(gru, "RECOMPUTE_HN", flag)
+        ops.set_seed(31)
+        m.zero_grad()
+        out = m(bank.to(dev()), length.to(dev()))
+        loss = (out.float() * wout).sum()
+        loss.backward()
+        ops.join_side()
+        torch.cuda.synchronize()
+        res.append((out.detach().clone(), _grads_of(m)))
+    assert torch.equal(res[0][0], res[1][0])
+    for k in res[0][1]:
+        assert torch.isfinite(res[1][1][k]).all(), k
+        torch.testing.assert_close(res[0][1][k], res[1][1][k], rtol=1e-5, atol=1e-6, msg=lambda s_, k=k: "%s: %s" % (k, s_))
+    monkeypatch.setattr(gru, "RECOMPUTE_HN", False)
+    with pytest.raises(RuntimeError, match="second time"):
+        loss.backward()
+    # (iii) straight at the function: a plan with no step
+    plan = gru.PackPlan([], torch.zeros(5, dtype=torch.int32, device=dev()))
+    assert plan.L == 0
+    table = torch.randn(86, 20, device=dev(), requires_grad=True)
+    ws = [p.detach() for n_, p in m.rnn.named_parameters()]
+    fin = gru.packed_path_gru(torch.zeros(7, 5, dtype=torch.int64, device=dev()), plan, table, 64, 0.1, 64, 0.1, ws)
+    assert fin.shape == (5, 128) and float(fin.abs().max()) == 0
+    fin.sum().backward()
+    assert table.grad is None or float(table.grad.abs().max()) == 0

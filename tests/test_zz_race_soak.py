@@ -8,7 +8,7 @@ other waves may still read them is launched >= 30 times on the same inputs at th
 that keeps HBM busy (latency under load is what moves such races), and every output is compared bit for bit with the first launch.
 
   forward GRU step   gru_step_fwd_a2w3_kernel (default), gru_step_fwd_dbuf_kernel, gru_step_fwd_ring_kernel
-  backward GRU step  gru_step_bwd_pw_kernel (round 6: persistent, the default), gru_step_bwd8_kernel (256-row tiles), gru_step_bwd_kernel with role B (kloop_a2)
+  backward GRU step  gru_step_bwd_kernel with role B (kloop_a2: the row panel one stage ahead)
   GEMM               gemm256p_nt_kernel, gemm256p_tn_kernel (split-K), the grouped TN product of gtos_gru_weight_grads
   whole function     the packed-path RelationEncoder over the whole C2 bank, training mode, DENSE upstream gradient, run twice
 
@@ -115,12 +115,8 @@ def test_soak_forward_gru_step(rows, layer, form):
 
 @pytest.mark.parametrize("rows,rows_prev", [(C2_ROWS, C2_ROWS), (MID_ROWS, 50001), (50001, MID_ROWS), (C5_ROWS, C5_ROWS - 12345)])
 @pytest.mark.parametrize("layer", [0, 1])
-@pytest.mark.parametrize("kernel", [2, 1, 0])
-def test_soak_backward_gru_step_with_input_gradient_role(rows, rows_prev, layer, kernel):
-    from gtos_amd._lib import call
+def test_soak_backward_gru_step_with_input_gradient_role(rows, rows_prev, layer):
     from gtos_amd.gru import _step_bwd_fused, N_BIAS_PARTIALS
-    if rows == C5_ROWS and kernel != 2:
-        pytest.skip("C5's widest step runs the default kernel only")
     torch.manual_seed(rows % 1000 + layer)
     hs, n_in = 256, (128, 512)[layer]
     d4_prev, wh_t, wi_t = r_(rows_prev, 4 * hs), r_(hs, 3 * hs, scale=0.1), r_(n_in, 3 * hs, scale=0.1)
@@ -130,14 +126,11 @@ def test_soak_backward_gru_step_with_input_gradient_role(rows, rows_prev, layer,
     dh, d4 = torch.empty_like(dh0), torch.empty(rows, 4 * hs, device=dev(), dtype=torch.bfloat16)
     dinp = torch.empty(rows_prev, n_in, device=dev(), dtype=torch.bfloat16)
     bpart = torch.zeros(N_BIAS_PARTIALS, 4 * hs, device=dev())
-    call("gtos_gru_bwd_config", kernel, -1)
-    try:
-        def launch():
-            _step_bwd_fused(rows, hs, d4_prev, rows_prev, wh_t, gates, hprev, None if dy is None else dy.data_ptr(), 2 * hs, dh, d4,
-                            0.2 if dy is not None else 0.0, 17, 0, bpart, wi_t=wi_t, dinp=dinp, n_in=n_in, p_in=0.2 if layer == 0 else 0.0, seed_in=5)
-        soak("bwd step %s L%d rows %d/%d" % (("128-row", "256-row", "persistent")[kernel], layer, rows, rows_prev), launch, [dh, d4, dinp], reset=lambda: dh.copy_(dh0))
-    finally:
-        call("gtos_gru_bwd_config", 2, -1)
+
+    def launch():
+        _step_bwd_fused(rows, hs, d4_prev, rows_prev, wh_t, gates, hprev, None if dy is None else dy.data_ptr(), 2 * hs, dh, d4,
+                        0.2 if dy is not None else 0.0, 17, 0, bpart, wi_t=wi_t, dinp=dinp, n_in=n_in, p_in=0.2 if layer == 0 else 0.0, seed_in=5)
+    soak("bwd step L%d rows %d/%d" % (layer, rows, rows_prev), launch, [dh, d4, dinp], reset=lambda: dh.copy_(dh0))
 
 
 @pytest.mark.parametrize("M,N,K", [(C2_ROWS, 1024, 4096), (C2_ROWS, 512, 8192), (C2_ROWS, 1024, 1024), (MID_ROWS, 512, 2016)])

@@ -166,17 +166,13 @@ def main():
         for fused in (False, True):
             if a.only and "bwd" not in a.only:
                 continue
-            for wide in (0, 1, 2):                         # gru_step_bwd_kernel (128-row tiles, a workgroup per role) / gru_step_bwd8_kernel / gru_step_bwd_pw_kernel (round 6)
-                call("gtos_gru_bwd_config", wide, -1)
-                for acc in ((False, True) if fused else (False,)):
-                    kw = dict(wi_t=wi_t, dinp=dinp, n_in=ind, dinp_acc=acc) if fused else {}
-                    us = timed(lambda: gru._step_bwd_fused(A, hs, d4p, A, wh_t, gts, h_in, None if dy is None else dy.data_ptr(), 2 * hs, dh, d4, 0.0, 0, 0, bpart, **kw), a.reps)
-                    nbb = 2 * (A * (11 * hs + (hs if dy is not None else 0)) + A * (4 if fused else 3) * hs + (A * ind * (2 if acc else 1) if fused else 0))
-                    flb = 2.0 * A * 3 * hs * (hs + (ind if fused else 0))
-                    print("bwd  L%d  rows %d %-9s %-8s %-10s: %8.1f us  %7.1f GB/s (%.3f of 8 TB/s)  %7.1f TF/s" % (
-                        layer, A, "cell+dinp" if fused else "cell only", ("128-row", "256-row", "persist")[wide], "accumulate" if acc else "", us, nbb / us / 1e3,
-                        nbb / us / 8e6, flb / us / 1e6), flush=True)
-            call("gtos_gru_bwd_config", 2, -1)
+            for acc in ((False, True) if fused else (False,)):
+                kw = dict(wi_t=wi_t, dinp=dinp, n_in=ind, dinp_acc=acc) if fused else {}
+                us = timed(lambda: gru._step_bwd_fused(A, hs, d4p, A, wh_t, gts, h_in, None if dy is None else dy.data_ptr(), 2 * hs, dh, d4, 0.0, 0, 0, bpart, **kw), a.reps)
+                nbb = 2 * (A * (11 * hs + (hs if dy is not None else 0)) + A * (4 if fused else 3) * hs + (A * ind * (2 if acc else 1) if fused else 0))
+                flb = 2.0 * A * 3 * hs * (hs + (ind if fused else 0))
+                print("bwd  L%d  rows %d %-9s %-10s: %8.1f us  %7.1f GB/s (%.3f of 8 TB/s)  %7.1f TF/s" % (
+                    layer, A, "cell+dinp" if fused else "cell only", "accumulate" if acc else "", us, nbb / us / 1e3, nbb / us / 8e6, flb / us / 1e6), flush=True)
         if not a.only or "dinp" in a.only:
             us = timed(lambda: gru._step_bwd_fused(0, hs, d4p, A, wh_t, None, None, None, 2 * hs, None, None, 0.0, 0, 0, None, wi_t=wi_t, dinp=dinp, n_in=ind), a.reps)
             print("dinp L%d  rows %d role B alone: %8.1f us  %7.1f TF/s;" % (layer, A, us, 2.0 * A * 3 * hs * ind / us / 1e6), end=" ", flush=True)
