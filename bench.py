@@ -44,6 +44,11 @@ def host_cores():
     return max(1, n)
 
 
+def rank_cores(world):
+    """Host threads one of `world` ranks on this box may use: its share of the usable cores, at least one."""
+    return max(1, host_cores() // max(1, world))
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -59,6 +64,9 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=2, help="timed CPU steps of the full-step leg (after 1 warm-up; time-capped)")
     ap.add_argument("--cpu-budget", type=float, default=45.0, help="wall-clock cap of the CPU baseline in seconds")
     ap.add_argument("--cpu-warmup", type=int, default=1, help="untimed CPU warm-up steps (SURVEY 8d: 2)")
+    ap.add_argument("--cpu-protocol", action="store_true",
+                    help="SURVEY 8d's CPU protocol live in this run: --cpu-graphs 8 --cpu-warmup 2 --cpu-steps 5 --cpu-budget 600 (about five "
+                         "minutes of host time on 16 cores: more than the default run may take, hence a flag)")
     ap.add_argument("--decode", action="store_true",
                     help="secondary benchmark (SURVEY 8f rank 2): beam search over the K/V-cached decoder instead of the train step")
     ap.add_argument("--beam", type=int, default=8)
@@ -197,6 +205,23 @@ def cpu_baseline(cfg_name, graphs, steps, budget_s=75.0, warmup=1):
 MFMA_PEAK_TFS = 2500.0
 
 
+def step_ceiling(cfg, stats, s_el=2):
+    """SURVEY.md section 8(d), "per-step graphs/s roofline", for THIS batch's n, B, R and mean path length:
+        sum over the graph-encoder layers of (Stage R flops + the small GEMMs) / MFMA peak + Stage A fwd+bwd bytes / HBM peak,
+        plus Stage G (RelationEncoder, fwd + bwd = 3 x R * len * 3.45 MFLOP) / MFMA peak
+    -- the DENSE-signature figures, before decoder and optimizer, as the survey states them (C2: ~20 ms).  Returns (ms, parts)."""
+    n, B, d, ff, L = stats["n"], stats["B"], cfg["d"], cfg["ff"], cfg["layers"]
+    P = n * n * B
+    stage_r = 12.0 * P * d * d                                  # relation projection, fwd + bwd, per layer
+    small = 3.0 * 2.0 * n * B * d * (3 * d + d + 2 * ff)        # QKV, output and feed-forward products, fwd + bwd, per layer
+    stage_a = 3.0 * P * 2 * d * s_el + 10.0 * n * B * d * s_el  # relation attention, fwd + bwd bytes, per layer
+    stage_g = 3.0 * stats["R"] * stats["mean_path_len"] * 3.45e6
+    ms_r = L * (stage_r + small) / (MFMA_PEAK_TFS * 1e12) * 1e3
+    ms_a = L * stage_a / (HBM_PEAK_GBS * 1e9) * 1e3
+    ms_g = stage_g / (MFMA_PEAK_TFS * 1e12) * 1e3
+    return ms_r + ms_a + ms_g, {"stage_R_and_small_gemms_ms": round(ms_r, 2), "stage_A_ms": round(ms_a, 2), "stage_G_ms": round(ms_g, 2)}
+
+
 def build_roofline(a, cfg, stats, model, trainer, batch, prof, dev, cd, detail=True):
     """roofline object of the JSON line.  Headline (SURVEY 8d "Stage A"): the relation-attention forward kernel on the
     reference's DENSE relation signature (rarb[n,n,B,2d] = relation_in_proj(relation) materialised), measured live here with
@@ -287,8 +312,12 @@ def build_roofline(a, cfg, stats, model, trainer, batch, prof, dev, cd, detail=T
         dp, gp = ops.PROFILE, ops.GEMM_PROFILE
         ops.PROFILE, ops.PROFILE_DETAIL, ops.GEMM_PROFILE = None, False, None
         ops.BWD_SIDE, ops.PROJ_SIDE = side_was, proj_was
-        if overlapped:               # the kernel's own duration inside a training step: the detail pass runs it alone
-            roof["in_step"] = in_step_of(dp, "the detail pass (2 extra training steps, auxiliary-stream overlap off: the kernel alone)") or in_step
+        if overlapped and roof["in_step"] is not None:
+            # the figure above is the launch as the step runs it (beside the auxiliary stream's projection GEMMs); the detail pass runs the
+            # kernel alone: what the overlap costs it is the difference
+            alone = in_step_of(dp, "the detail pass (2 extra training steps, auxiliary-stream overlap off: the kernel alone)")
+            if alone:
+                roof["in_step"]["alone"] = {k: alone[k] for k in ("measured_in", "launches", "avg_us", "achieved", "frac")}
 
         def hbm_row(name, label, bytes_per_launch=None, bytes_per_unit=None, note=""):
             ms, cnt, units, tot = span(dp, name)
@@ -502,6 +531,8 @@ def make_feed(a, cfg, rank, B_rank, dev, asm_times, free_b=0):
 
 def main():
     a = parse()
+    if a.cpu_protocol:
+        a.cpu_graphs, a.cpu_warmup, a.cpu_steps, a.cpu_budget = 8, 2, 5, 600.0
     if a.decode:
         torch.cuda.set_device(0)
         return decode_bench(a)
@@ -527,10 +558,15 @@ def main():
             dist.all_reduce(t)
             assert int(t.item()) == world
             dist.destroy_process_group()
-        print("dry-launch rank %d of %d ok" % (rank, world), flush=True)
+        print("dry-launch rank %d of %d ok (host threads per rank %d of %d usable cores)" % (rank, world, rank_cores(world), host_cores()), flush=True)
         return
     if os.environ.get("GTOS_ONE_DEVICE"):      # functional check of the N>1 path on a 1-GPU box: every rank on cuda:0, gloo
         local = 0
+    # N ranks share the host: each keeps to its share of the usable cores (torch's intra-op pool defaults to ALL of them per process;
+    # 8 ranks x (launch thread + loader worker + upload thread) on a 16-core quota would otherwise fight over them)
+    cores_rank = rank_cores(world)
+    torch.set_num_threads(cores_rank)
+    a.relbatch_threads = max(1, min(a.relbatch_threads, cores_rank - 1))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if (a.fresh_batches or not a.no_loader_leg) and not os.environ.get("GTOS_BENCH_NO_ROUNDUP"):
@@ -835,6 +871,15 @@ def main():
         # N > 1: no detail pass (its extra training steps would issue collectives the other ranks do not join)
         roofline = build_roofline(a, cfg, stats, model, trainer, batch, prof, dev, cd,
                                   detail=(world == 1 and not os.environ.get("GTOS_BENCH_NO_DETAIL")))
+    if rank == 0 and roofline is not None:
+        ceil_ms, parts = step_ceiling(cfg, stats, s_el)
+        roofline["step_ceiling_ms"] = round(ceil_ms, 2)
+        roofline["step_frac"] = round(ceil_ms / (1e3 * elapsed / a.steps), 4)
+        roofline["step_ceiling_parts"] = parts
+        roofline["step_ceiling_note"] = ("SURVEY 8d's per-step roofline for this batch (n=%d, B=%d, R=%d, mean path length %.2f): graph-encoder layers at the "
+                                         "MFMA peak (Stage R + small GEMMs) and the HBM peak (Stage A fwd+bwd, dense signature) plus Stage G at the MFMA "
+                                         "peak; decoder, optimizer and host not included; step_frac = step_ceiling_ms / ms_per_step" % (
+                                             n, B, R, stats["mean_path_len"]))
     if rank == 0:
         metric = ("graphs/sec training step (100-node AMR, batch 64)" if a.config in ("C2", "C4") else
                   "graphs/sec training step (%s: %d-node %s graphs, batch %d)" % (a.config, cfg["N"], cfg["kind"], B))
@@ -871,6 +916,11 @@ def main():
                "other_scaling": other_scaling, "collectives": rccl_info}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.config, a.cpu_graphs, a.cpu_steps, a.cpu_budget, a.cpu_warmup)
+            out["cpu_baseline"]["leg"] = (
+                "SURVEY 8d protocol, live in this run (8 graphs, 2 warm-up + 5 timed steps)" if a.cpu_graphs >= 8 and a.cpu_steps >= 5 else
+                "BOUNDED leg (%d graphs, %d warm-up + <= %d timed steps, <= %.0f s): the default run must finish within minutes and SURVEY 8d's "
+                "protocol (8 graphs, 2 + 5 steps) takes about five on this host; `python bench.py --cpu-protocol` runs it live, the newest "
+                "committed record of that run is quoted as protocol_8d" % (a.cpu_graphs, a.cpu_warmup, a.cpu_steps, a.cpu_budget))
             # SURVEY 8d's protocol (8 graphs, 2 warm-up + >= 5 timed steps: five minutes of host time) is a run of its own
             # (--cpu-graphs 8 --cpu-steps 5 --cpu-warmup 2 --cpu-budget 600); the newest committed record of it is quoted beside the bounded leg
             import glob

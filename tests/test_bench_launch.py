@@ -19,6 +19,17 @@ def test_bench_self_launches_two_ranks():
     assert "dry-launch rank 0 of 2 ok" in r.stdout and "dry-launch rank 1 of 2 ok" in r.stdout
 
 
+def test_bench_self_launches_eight_ranks_with_per_rank_thread_caps():
+    """`python bench.py --gpus 8 --dry-launch`: the driver's 8-GPU command shape on this box (gloo rendezvous of eight ranks), and every
+    rank reports its share of the usable host cores (bench.rank_cores: torch's intra-op pool and the loader threads are capped to it)."""
+    import re
+    r = _run(["--gpus", "8", "--dry-launch"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    seen = re.findall(r"dry-launch rank (\d) of 8 ok \(host threads per rank (\d+) of (\d+) usable cores\)", r.stdout)
+    assert sorted(int(x[0]) for x in seen) == list(range(8)), r.stdout
+    assert all(int(x[1]) == max(1, int(x[2]) // 8) for x in seen)
+
+
 def test_bench_rejects_mismatched_world_size():
     r = _run(["--gpus", "2", "--dry-launch"], env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)

@@ -291,7 +291,7 @@ def test_trainer_construction_broadcasts_rank0_parameters():
 # The PRODUCT Generator data-parallel on two gloo ranks, under tests/dryrun.py: every kernel launch is recorded instead of executed
 # (numbers are meaningless), but the segment markers of gtos_amd/generator.py, the parameter -> segment map, the async all-reduces
 # launched from inside the real model's backward, the collective flag and the optimizer's joins are all the product's own code.
-def _product_worker(rank, world, port, q, steps):
+def _product_worker(rank, world, port, q, steps, b_rank=4):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from dryrun import DryRun
@@ -326,7 +326,7 @@ def _product_worker(rank, world, port, q, steps):
         model.set_compute_dtype(torch.bfloat16)
         model.train()
         trainer = train_mod.Trainer(model, synth.CONFIGS["C1"]["d"], warmup_steps=1, compute_dtype=torch.bfloat16, world_size=world, rank=rank)
-        batch, _ = synth.make_config_batch("C1", rank=rank, B=4)            # rank r holds graphs [4 r, 4 r + 4)
+        batch, _ = synth.make_config_batch("C1", rank=rank, B=b_rank)       # rank r holds graphs [b r, b r + b)
         attach_relation_index(attach_path_trie(batch))
         launches = []
         for _ in range(steps):
@@ -339,36 +339,51 @@ def _product_worker(rank, world, port, q, steps):
     dist.destroy_process_group()
 
 
-def test_product_generator_two_ranks_collective_sequence_under_dry_run():
-    world, port, steps = 2, _free_port(), 3
+def _check_product_generator(world, steps, b_rank):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_product_worker, args=(r, world, port, q, steps)) for r in range(world)]
+    procs = [ctx.Process(target=_product_worker, args=(r, world, port, q, steps, b_rank)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda r: r[0])
+    res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda r: r[0])
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
-    (_, log0, seg0, launches0, overlap0, sig0), (_, log1, seg1, launches1, overlap1, sig1) = res
-    assert overlap0 and overlap1 and seg0 == seg1 and len(seg0) == 4 and all(s > 0 for s in seg0)
-    assert sig0 != sig1                                                   # the ranks hold different graphs
-    assert [e for e in log0 if e[0] != "backward_end"] == [e for e in log1 if e[0] != "backward_end"]    # same collectives, same order
-    per_step, cur = [], None
-    for e in log0:
-        if e == ("step_begin",):
-            cur = []
-            per_step.append(cur)
-        else:
-            cur.append(e)
-    assert len(per_step) == steps
-    for s, ev in enumerate(per_step):
-        flags = [e for e in ev if e[0] == "all_reduce" and e[2] == "max"]
-        sums = [e for e in ev if e[0] == "all_reduce" and e[2] == "sum"]
-        assert len(flags) <= 1                                            # the collective abnormal-loss flag (after the warm-up steps)
-        assert [e[1] for e in sums] == seg0 and all(e[3] for e in sums)   # the four gradient segments, in order, async
-        k = ev.index(("backward_end",))
-        inside = [e for e in ev[:k] if e[0] == "all_reduce" and e[2] == "sum"]
-        assert [e[1] for e in inside] == seg0[:3], (s, ev)               # three of them launched from INSIDE the real model's backward
-    # each rank repeats its own launch plan every step; the two plans differ (rank-local graphs: other trie depths), the collectives do not
-    assert len(set(launches0)) == 1 and len(set(launches1)) == 1 and min(launches0 + launches1) > 300
+    _, log0, seg0, launches0, overlap0, sig0 = res[0]
+    assert len(seg0) == 4 and all(s > 0 for s in seg0)
+    assert len(set(r[5] for r in res)) == world                           # the ranks hold different graphs
+    coll0 = [e for e in log0 if e[0] != "backward_end"]
+    for r, log_r, seg_r, launches_r, overlap_r, _ in res:
+        assert overlap_r and seg_r == seg0
+        assert [e for e in log_r if e[0] != "backward_end"] == coll0, "rank %d issues another collective sequence than rank 0" % r
+        # each rank repeats its own launch plan every step (the plans differ between ranks: rank-local graphs, other trie depths)
+        assert len(set(launches_r)) == 1 and launches_r[0] > 300
+        per_step, cur = [], None
+        for e in log_r:
+            if e == ("step_begin",):
+                cur = []
+                per_step.append(cur)
+            else:
+                cur.append(e)
+        assert len(per_step) == steps
+        for s, ev in enumerate(per_step):
+            flags = [e for e in ev if e[0] == "all_reduce" and e[2] == "max"]
+            sums = [e for e in ev if e[0] == "all_reduce" and e[2] == "sum"]
+            # the collective abnormal-loss flag: one MAX all-reduce of ONE word per step once steps_issued (= s before the step) > warmup_steps (= 1)
+            assert len(flags) == (1 if s >= 2 else 0) and all(e[1] == 1 for e in flags), (r, s, flags)
+            assert [e[1] for e in sums] == seg0 and all(e[3] for e in sums)   # the four gradient segments, in order, async
+            k = ev.index(("backward_end",))
+            inside = [e for e in ev[:k] if e[0] == "all_reduce" and e[2] == "sum"]
+            assert [e[1] for e in inside] == seg0[:3], (r, s, ev)            # three of them launched from INSIDE the real model's backward
+
+
+def test_product_generator_two_ranks_collective_sequence_under_dry_run():
+    _check_product_generator(world=2, steps=3, b_rank=4)
+
+
+def test_product_generator_eight_ranks_collective_sequence_under_dry_run():
+    """C4's rank count (8 x MI355X, generator/train.py:167-190) on gloo: eight processes of the PRODUCT Generator under the dry run, one
+    graph each -- every rank must issue the same collectives in the same order with the same sizes (four gradient segments, three of them
+    from inside backward, the one-word flag all-reduce after the warm-up step): a rank that skipped or reordered one would hang RCCL."""
+    _check_product_generator(world=8, steps=3, b_rank=1)

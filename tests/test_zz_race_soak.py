@@ -101,10 +101,11 @@ def test_soak_forward_gru_step(rows, layer, form):
     x, h_in, wi, wh = r_(rows, ind), r_(rows, hs), r_(3 * hs, ind, scale=0.1), r_(3 * hs, hs, scale=0.1)
     bi, bh = torch.randn(3 * hs, device=dev()) * 0.1, torch.randn(3 * hs, device=dev()) * 0.1
     n_out = rows - rows // 7                                # some rows finish at this step
-    h_out = torch.empty(rows, hs, device=dev(), dtype=torch.bfloat16)
-    h_fin = torch.empty(rows, hs, device=dev(), dtype=torch.bfloat16)
-    gates = torch.empty(rows, 4 * hs, device=dev(), dtype=torch.bfloat16)
-    y = torch.empty(rows, 2 * hs, device=dev(), dtype=torch.bfloat16) if layer == 0 else None
+    # (zeros: a row goes EITHER to h_out (m < n_out) or to h_fin, and y is a column block -- the untouched parts must compare equal too)
+    h_out = torch.zeros(rows, hs, device=dev(), dtype=torch.bfloat16)
+    h_fin = torch.zeros(rows, hs, device=dev(), dtype=torch.bfloat16)
+    gates = torch.zeros(rows, 4 * hs, device=dev(), dtype=torch.bfloat16)
+    y = torch.zeros(rows, 2 * hs, device=dev(), dtype=torch.bfloat16) if layer == 0 else None
     field = {"a2w3": 7, "dbuf": 2, "ring": 8}[form]        # per-launch kernel form (bits 16-19 of save_hn; gtos_hip.h)
 
     def launch():
