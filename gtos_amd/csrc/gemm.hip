@@ -734,15 +734,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_nt_kernel(GemmArgs a) {
 //      * Rows past the end re-read the last valid row (their products are never stored); stages past the end of K
 //        re-read the last stage (never multiplied), so the number of DMAs in flight is the same in every step.
 constexpr int ROW3 = 64, A3 = BM2 * ROW3, ST3 = (BM2 + BN2) * ROW3;
-const int g_min_k256 = getenv("GTOS_GEMM256_MINK") ? atoi(getenv("GTOS_GEMM256_MINK")) : 2048;   // A/B switch (tools/bench_gemm.py)
+constexpr int g_min_k256 = 2048;                     // (rounds 3-5 swept these thresholds with environment switches: profiles/r3..r5_ab_switches.txt)
 const bool g_use_pipe = !(getenv("GTOS_GEMM_PIPE") && getenv("GTOS_GEMM_PIPE")[0] == '0');
 const bool g_use_pipe_tn = !(getenv("GTOS_GEMM_PIPE_TN") && getenv("GTOS_GEMM_PIPE_TN")[0] == '0');
-const int g_max_npipe = getenv("GTOS_GEMM_PIPE_MAXN") ? atoi(getenv("GTOS_GEMM_PIPE_MAXN")) : 2048;
-const int g_min_kpipe = getenv("GTOS_GEMM_PIPE_MINK") ? atoi(getenv("GTOS_GEMM_PIPE_MINK")) : 1024;
-// Small products (a few thousand rows: the graph layers' and the decoder's projections) leave the single-stage 128x128 kernel with
-// less than one workgroup per CU, so nothing covers its load latency: 16 k tiles = 16 exposed round trips, 20-27 us for 3 GFLOP.
-// The four-stage kernel keeps its own loads in flight; with <= g_pipe_small_max macro tiles it runs them on a few dozen CUs.
-const int g_pipe_small_max = getenv("GTOS_GEMM_PIPE_SMALL") ? atoi(getenv("GTOS_GEMM_PIPE_SMALL")) : 0;
+constexpr int g_max_npipe = 2048;
+constexpr int g_min_kpipe = 1024;
+// (Small products -- a few thousand rows: the graph layers' and the decoder's projections -- on this kernel: 17-25 us against 10-19 us on the
+// single-stage 128x128 kernel, step +1.1 ms; measured in round 3, never enabled.)
 
 #define GTOS_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))
 
@@ -1187,7 +1185,7 @@ extern "C" int gtos_gemm(int in_dtype, int out_dtype, int transA, int transB, in
         // K % 32 == 0 and enough macro tiles: the software-pipelined 256x256 kernel
         if (g_use_pipe && !transA && transB && a.vecA && a.vecB && a.vecC && splitk == 1 && N >= 256 && N <= g_max_npipe && K % 32 == 0 &&
             lda < (1 << 22) && ldb < (1 << 22) &&
-            ((t256 >= 512 && K >= g_min_kpipe) || (t256 <= g_pipe_small_max && K >= 256 && M >= 256)))
+            (t256 >= 512 && K >= g_min_kpipe))
             return launch256p(a, s);
         if (g_use256 && !transA && transB && a.vecA && a.vecB && a.vecC && splitk == 1 && t256 >= 1024 && N >= 256 && K >= g_min_k256)
             return launch256(a, s);

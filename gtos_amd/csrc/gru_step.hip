@@ -29,7 +29,13 @@ __attribute__((visibility("hidden"))) const void* gtos_zero_block();      // gem
 // queued when another wave, past the barrier, starts the DMA into that slot.  (Found by test_gru_backward_step_input_gradient_role_vs_torch
 // on the backward step's pipelined k loop, whose weight rows come back from L1 within the time a queued ds_read waits: 1,200 of 40,000 rows
 // differed from run to run.  The forward kernels' operands take an L2 / HBM round trip and never showed it; they wait the same way now.)
+#ifndef GTOS_RACE_DEMO
 #define GTOS_VMCNT_LDS(n) __builtin_amdgcn_s_waitcnt(0x0070 | ((n) & 15) | (((n) >> 4) << 14))
+#define GTOS_LGKM0() __builtin_amdgcn_s_waitcnt(0xc07f)
+#else      // tools/race_demo.sh only: the waits as they were before that fix, to show tests/test_zz_race_soak.py catching the race
+#define GTOS_VMCNT_LDS(n) GTOS_VMCNT(n)
+#define GTOS_LGKM0()
+#endif
 
 namespace {
 
@@ -48,8 +54,6 @@ struct StepArgs {
     int64_t ld_fin; const int* fin_idx;            // a finished row m goes to h_fin[(fin_idx ? fin_idx[m] : m) * ld_fin + channel]
     float p_drop; uint64_t seed; int64_t drop_base;
     int rows, hs; const void* zeros;
-    int save_hn;                                   // 0: the hn block of `gates` is not written (backward recomputes it: StepBwdArgs.w_hn)
-    int dbg_delay;                                 // measuring switches 5 / 6 of the ring kernel: start delay of some first-generation workgroups, 10 ns ticks
 };
 
 // 128 activation rows x 64 k
@@ -203,6 +207,84 @@ __device__ __forceinline__ float fast_tanh(float x) {
     return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
 }
 
+// The cell of a 128-row x 64-channel tile on the accumulators of the gate products (shared by the step kernels below): lane (fr, fq)
+// holds rows m0 + wave*32 + mt*16 + fr, channels cb .. cb+15 (index nt*4 + e) of accumulator groups r, z, (n_x,) n_h.
+template <int MODE>
+__device__ __forceinline__ void step_cell(const StepArgs& a, f32x4_t (&acc)[2][(MODE == 1 ? 4 : 3) * 4], int m0, int c0, int wave, int fr, int fq) {
+    constexpr bool HAS_X = MODE == 1;
+    constexpr int GH = HAS_X ? 3 : 2;
+    // ---- cell: lane (fr, fq) holds rows m0 + wave*32 + mt*16 + fr, channels cb .. cb+15 (index nt*4 + e)
+    const int cb = c0 + fq * 16, hs = a.hs;
+    float bhr[16], bhz[16], bhn[16];
+    ldf16(a.b_hh + cb, bhr); ldf16(a.b_hh + hs + cb, bhz); ldf16(a.b_hh + 2 * hs + cb, bhn);
+    if constexpr (MODE != 0) {                   // b_ih of r and z joins b_hh; the n part is added to the input-side term below
+        float t[16];
+        ldf16(a.b_ih + cb, t);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bhr[i] += t[i];
+        ldf16(a.b_ih + hs + cb, t);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bhz[i] += t[i];
+    }
+    const float ks = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int m = m0 + wave * 32 + mt * 16 + fr;
+        if (m >= a.rows) continue;
+        float xr[16], xz[16], xn[16], hp[16];
+        if constexpr (HAS_X) {
+            ldf16(a.b_ih + 2 * hs + cb, xn);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { xr[i] = 0.f; xz[i] = 0.f; xn[i] += acc[mt][8 + (i >> 2)][i & 3]; }
+        } else if constexpr (MODE == 2) {
+            const bf16_t* fp = a.gf + (int64_t)a.gf_idx[m] * 3 * hs + cb;
+            const bf16_t* bp = a.gb + (int64_t)a.gb_idx[m] * 3 * hs + cb;
+            float t[16];
+            ld16(fp, xr); ld16(bp, t);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) xr[i] += t[i];
+            ld16(fp + hs, xz); ld16(bp + hs, t);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) xz[i] += t[i];
+            ld16(fp + 2 * hs, xn); ld16(bp + 2 * hs, t);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) xn[i] += t[i];
+            ldf16(a.b_ih + 2 * hs + cb, t);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) xn[i] += t[i];
+        } else {
+            const bf16_t* xp = a.xg + (int64_t)m * 3 * hs + cb;
+            ld16(xp, xr); ld16(xp + hs, xz); ld16(xp + 2 * hs, xn);
+        }
+        ld16(a.h_in + (int64_t)(a.h_idx ? a.h_idx[m] : m) * hs + cb, hp);
+        float gr[16], gz[16], gn[16], hn[16], o[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            gr[i] = 1.f / (1.f + __expf(-(xr[i] + acc[mt][(i >> 2)][i & 3] + bhr[i])));
+            gz[i] = 1.f / (1.f + __expf(-(xz[i] + acc[mt][4 + (i >> 2)][i & 3] + bhz[i])));
+            hn[i] = acc[mt][GH * 4 + (i >> 2)][i & 3] + bhn[i];
+            // the saved hn is what backward multiplies by: round it first so that forward and backward agree
+            hn[i] = bf2f(f2bf(hn[i]));
+            gn[i] = fast_tanh(xn[i] + gr[i] * hn[i]);
+            o[i] = (1.f - gz[i]) * gn[i] + gz[i] * hp[i];
+        }
+        bf16_t* gp = a.gates + (int64_t)m * 4 * hs + cb;
+        st16(gp, gr); st16(gp + hs, gz); st16(gp + 2 * hs, gn);
+        st16(gp + 3 * hs, hn);
+        bf16_t* hdst = m < a.n_out ? a.h_out + (int64_t)m * hs + cb
+                                   : a.h_fin + (int64_t)(a.fin_idx ? a.fin_idx[m] : m) * a.ld_fin + cb;
+        st16(hdst, o);
+        if (a.y) {
+            if (a.p_drop > 0.f) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    o[i] = drop_keep(a.seed, (uint64_t)(a.drop_base + (int64_t)m * a.ldy + cb + i), a.p_drop) ? o[i] * ks : 0.f;
+            }
+            st16(a.y + (int64_t)m * a.ldy + cb, o);
+        }
+    }
+}
+
 // MODE 0: input gates read from xg; 1: x W_ih^T computed here (HAS_X); 2: input gates gathered from two bf16 tables
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void gru_step_fwd_kernel(StepArgs a) {
@@ -250,524 +332,25 @@ __global__ __launch_bounds__(256, 2) void gru_step_fwd_kernel(StepArgs a) {
         }
     }
 
-    // ---- cell: lane (fr, fq) holds rows m0 + wave*32 + mt*16 + fr, channels cb .. cb+15 (index nt*4 + e)
-    const int cb = c0 + fq * 16, hs = a.hs;
-    float bhr[16], bhz[16], bhn[16];
-    ldf16(a.b_hh + cb, bhr); ldf16(a.b_hh + hs + cb, bhz); ldf16(a.b_hh + 2 * hs + cb, bhn);
-    if constexpr (MODE != 0) {                   // b_ih of r and z joins b_hh; the n part is added to the input-side term below
-        float t[16];
-        ldf16(a.b_ih + cb, t);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) bhr[i] += t[i];
-        ldf16(a.b_ih + hs + cb, t);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) bhz[i] += t[i];
-    }
-    const float ks = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int m = m0 + wave * 32 + mt * 16 + fr;
-        if (m >= a.rows) continue;
-        float xr[16], xz[16], xn[16], hp[16];
-        if constexpr (HAS_X) {
-            ldf16(a.b_ih + 2 * hs + cb, xn);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { xr[i] = 0.f; xz[i] = 0.f; xn[i] += acc[mt][8 + (i >> 2)][i & 3]; }
-        } else if constexpr (MODE == 2) {
-            const bf16_t* fp = a.gf + (int64_t)a.gf_idx[m] * 3 * hs + cb;
-            const bf16_t* bp = a.gb + (int64_t)a.gb_idx[m] * 3 * hs + cb;
-            float t[16];
-            ld16(fp, xr); ld16(bp, t);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) xr[i] += t[i];
-            ld16(fp + hs, xz); ld16(bp + hs, t);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) xz[i] += t[i];
-            ld16(fp + 2 * hs, xn); ld16(bp + 2 * hs, t);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) xn[i] += t[i];
-            ldf16(a.b_ih + 2 * hs + cb, t);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) xn[i] += t[i];
-        } else {
-            const bf16_t* xp = a.xg + (int64_t)m * 3 * hs + cb;
-            ld16(xp, xr); ld16(xp + hs, xz); ld16(xp + 2 * hs, xn);
-        }
-        ld16(a.h_in + (int64_t)(a.h_idx ? a.h_idx[m] : m) * hs + cb, hp);
-        float gr[16], gz[16], gn[16], hn[16], o[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            gr[i] = 1.f / (1.f + __expf(-(xr[i] + acc[mt][(i >> 2)][i & 3] + bhr[i])));
-            gz[i] = 1.f / (1.f + __expf(-(xz[i] + acc[mt][4 + (i >> 2)][i & 3] + bhz[i])));
-            hn[i] = acc[mt][GH * 4 + (i >> 2)][i & 3] + bhn[i];
-            // the saved hn is what backward multiplies by: round it first so that forward and backward agree
-            hn[i] = bf2f(f2bf(hn[i]));
-            gn[i] = fast_tanh(xn[i] + gr[i] * hn[i]);
-            o[i] = (1.f - gz[i]) * gn[i] + gz[i] * hp[i];
-        }
-        bf16_t* gp = a.gates + (int64_t)m * 4 * hs + cb;
-        st16(gp, gr); st16(gp + hs, gz); st16(gp + 2 * hs, gn);
-        if (a.save_hn) st16(gp + 3 * hs, hn);
-        bf16_t* hdst = m < a.n_out ? a.h_out + (int64_t)m * hs + cb
-                                   : a.h_fin + (int64_t)(a.fin_idx ? a.fin_idx[m] : m) * a.ld_fin + cb;
-        st16(hdst, o);
-        if (a.y) {
-            if (a.p_drop > 0.f) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    o[i] = drop_keep(a.seed, (uint64_t)(a.drop_base + (int64_t)m * a.ldy + cb + i), a.p_drop) ? o[i] * ks : 0.f;
-            }
-            st16(a.y + (int64_t)m * a.ldy + cb, o);
-        }
-    }
-}
-
-
-// The cell of a 128-row x 64-channel tile on the accumulators of the gate products (shared by the step kernels below): lane (fr, fq)
-// holds rows m0 + wave*32 + mt*16 + fr, channels cb .. cb+15 (index nt*4 + e) of accumulator groups r, z, (n_x,) n_h.
-// LINES (a TIMING experiment only, measuring switches 8 / 9 of gru_step_fwd_dbuf_kernel: the values land in the wrong places): the same
-// loads and stores with the addresses of a lane -> memory map in which 8 consecutive lanes cover one 128-byte row segment (8 rows x 128 B
-// per instruction) instead of 16 rows x four 16-byte pieces at a 32-byte stride.
-template <bool LINES>
-__device__ __forceinline__ void st16x(bf16_t* base, int64_t ld, int64_t m, int col, int row0, int c0, int lane, const float (&v)[16]) {
-    if constexpr (LINES) {
-        bf16_t* p0 = base + (int64_t)(row0 + (lane >> 3)) * ld + c0 + (lane & 7) * 8;
-        *reinterpret_cast<uint4*>(p0) = make_uint4(pack_bf(v[0], v[1]), pack_bf(v[2], v[3]), pack_bf(v[4], v[5]), pack_bf(v[6], v[7]));
-        *reinterpret_cast<uint4*>(p0 + 8 * ld) = make_uint4(pack_bf(v[8], v[9]), pack_bf(v[10], v[11]), pack_bf(v[12], v[13]), pack_bf(v[14], v[15]));
-    } else {
-        st16(base + m * ld + col, v);
-    }
-}
-template <int MODE, bool LINES = false>
-__device__ __forceinline__ void step_cell(const StepArgs& a, f32x4_t (&acc)[2][(MODE == 1 ? 4 : 3) * 4], int m0, int c0, int wave, int fr, int fq) {
-    constexpr bool HAS_X = MODE == 1;
-    const int lane_ = fq * 16 + fr;
-    constexpr int GH = HAS_X ? 3 : 2;
-    // ---- cell: lane (fr, fq) holds rows m0 + wave*32 + mt*16 + fr, channels cb .. cb+15 (index nt*4 + e)
-    const int cb = c0 + fq * 16, hs = a.hs;
-    float bhr[16], bhz[16], bhn[16];
-    ldf16(a.b_hh + cb, bhr); ldf16(a.b_hh + hs + cb, bhz); ldf16(a.b_hh + 2 * hs + cb, bhn);
-    if constexpr (MODE != 0) {                   // b_ih of r and z joins b_hh; the n part is added to the input-side term below
-        float t[16];
-        ldf16(a.b_ih + cb, t);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) bhr[i] += t[i];
-        ldf16(a.b_ih + hs + cb, t);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) bhz[i] += t[i];
-    }
-    const float ks = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int m = m0 + wave * 32 + mt * 16 + fr;
-        if (m >= a.rows) continue;
-        float xr[16], xz[16], xn[16], hp[16];
-        if constexpr (HAS_X) {
-            ldf16(a.b_ih + 2 * hs + cb, xn);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { xr[i] = 0.f; xz[i] = 0.f; xn[i] += acc[mt][8 + (i >> 2)][i & 3]; }
-        } else if constexpr (MODE == 2) {
-            const bf16_t* fp = a.gf + (int64_t)a.gf_idx[m] * 3 * hs + cb;
-            const bf16_t* bp = a.gb + (int64_t)a.gb_idx[m] * 3 * hs + cb;
-            float t[16];
-            ld16(fp, xr); ld16(bp, t);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) xr[i] += t[i];
-            ld16(fp + hs, xz); ld16(bp + hs, t);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) xz[i] += t[i];
-            ld16(fp + 2 * hs, xn); ld16(bp + 2 * hs, t);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) xn[i] += t[i];
-            ldf16(a.b_ih + 2 * hs + cb, t);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) xn[i] += t[i];
-        } else {
-            const bf16_t* xp = a.xg + (int64_t)m * 3 * hs + cb;
-            ld16(xp, xr); ld16(xp + hs, xz); ld16(xp + 2 * hs, xn);
-        }
-        if constexpr (LINES) {
-            const bf16_t* p0 = a.h_in + (int64_t)(m0 + wave * 32 + mt * 16 + (lane_ >> 3)) * hs + c0 + (lane_ & 7) * 8;
-            const uint4 u = *reinterpret_cast<const uint4*>(p0), w = *reinterpret_cast<const uint4*>(p0 + 8 * hs);
-            hp[0] = lo_bf(u.x); hp[1] = hi_bf(u.x); hp[2] = lo_bf(u.y); hp[3] = hi_bf(u.y); hp[4] = lo_bf(u.z); hp[5] = hi_bf(u.z); hp[6] = lo_bf(u.w); hp[7] = hi_bf(u.w);
-            hp[8] = lo_bf(w.x); hp[9] = hi_bf(w.x); hp[10] = lo_bf(w.y); hp[11] = hi_bf(w.y); hp[12] = lo_bf(w.z); hp[13] = hi_bf(w.z); hp[14] = lo_bf(w.w); hp[15] = hi_bf(w.w);
-        } else
-        ld16(a.h_in + (int64_t)(a.h_idx ? a.h_idx[m] : m) * hs + cb, hp);
-        float gr[16], gz[16], gn[16], hn[16], o[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            gr[i] = 1.f / (1.f + __expf(-(xr[i] + acc[mt][(i >> 2)][i & 3] + bhr[i])));
-            gz[i] = 1.f / (1.f + __expf(-(xz[i] + acc[mt][4 + (i >> 2)][i & 3] + bhz[i])));
-            hn[i] = acc[mt][GH * 4 + (i >> 2)][i & 3] + bhn[i];
-            // the saved hn is what backward multiplies by: round it first so that forward and backward agree
-            hn[i] = bf2f(f2bf(hn[i]));
-            gn[i] = fast_tanh(xn[i] + gr[i] * hn[i]);
-            o[i] = (1.f - gz[i]) * gn[i] + gz[i] * hp[i];
-        }
-        if constexpr (LINES) {
-            const int r0_ = m0 + wave * 32 + mt * 16;
-            st16x<true>(a.gates, 4 * (int64_t)hs, m, cb, r0_, c0, lane_, gr); st16x<true>(a.gates + hs, 4 * (int64_t)hs, m, cb, r0_, c0, lane_, gz);
-            st16x<true>(a.gates + 2 * hs, 4 * (int64_t)hs, m, cb, r0_, c0, lane_, gn);
-            if (a.save_hn) st16x<true>(a.gates + 3 * hs, 4 * (int64_t)hs, m, cb, r0_, c0, lane_, hn);
-            st16x<true>(a.h_out, hs, m, cb, r0_, c0, lane_, o);
-        } else {
-        bf16_t* gp = a.gates + (int64_t)m * 4 * hs + cb;
-        st16(gp, gr); st16(gp + hs, gz); st16(gp + 2 * hs, gn);
-        if (a.save_hn) st16(gp + 3 * hs, hn);
-        bf16_t* hdst = m < a.n_out ? a.h_out + (int64_t)m * hs + cb
-                                   : a.h_fin + (int64_t)(a.fin_idx ? a.fin_idx[m] : m) * a.ld_fin + cb;
-        st16(hdst, o);
-        }
-        if (a.y) {
-            if (a.p_drop > 0.f) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    o[i] = drop_keep(a.seed, (uint64_t)(a.drop_base + (int64_t)m * a.ldy + cb + i), a.p_drop) ? o[i] * ks : 0.f;
-            }
-            if constexpr (LINES) st16x<true>(a.y, a.ldy, m, cb, m0 + wave * 32 + mt * 16, c0, lane_, o);
-            else st16(a.y + (int64_t)m * a.ldy + cb, o);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Round 5: the fused forward step (MODE 1: input product inside) with a THREE-slot ring of 32-k stages instead of one 64-k stage.
-// gru_step_fwd_kernel<1> walks load -> barrier -> MFMA -> barrier per k tile with nothing in flight while it multiplies; the
-// per-(path, position) evaluation of the reference's dropout semantics spent 18 ms per C2 step in it at a quarter of either roofline
-// (VERDICT round 4).  Here a wave keeps its pieces of TWO stages in flight while it multiplies a third:
-//   * stage = TMW activation rows + 192 weight rows x 32 k in 64-byte rows (chunk c of row r at c ^ ((-(r >> 2)) & 3), as
-//     gemm256p_nt_kernel): 20 KB = 20 LDS-DMA pieces for a 128-row panel (5 per wave), 28 KB for a 256-row panel (4 per wave, see
-//     below); three slots in SEPARATE static arrays (hipcc's wait-count pass tracks LDS-DMA per LDS object); the waits are explicit
-//     (vmcnt(pieces per stage): the newest stage stays in flight);
-//   * the k axis is [x | h]: stages 0 .. in_dim/32 read x rows and W_ih (n -> accumulator group 2), the rest h_in rows and W_hh
-//     (n -> group 3); stage s+2 goes into the slot of stage s-1, which every wave has finished reading by then;
-//   * same lane -> channel map, same k order and the same cell (step_cell<1>) as gru_step_fwd_kernel<1>: bit-identical results
-//     (tests/test_hip_parity.py::test_gru_forward_ring_kernel_bit_identical_to_single_stage, all three kernels).
-// Needs in_dim % 32 == 0 (the packed path pads the label width to 64).
-// MEASURED (profiles/r5_ab_switches.txt; 434,624 rows per launch): the ring alone changed nothing (883 vs 895 us for layer 1), nor did 30 %
-// less LDS-DMA per row (256-row panels: k loop alone 581 vs 595 us) or the ping-pong below (558 vs 581 us); the launch is the SUM of its k
-// loop alone (324-356 / 558-595 us for layer 0 / 1) and its cell alone (461 / 381 us), see DESIGN.md section 5.  Kept because the pieces
-// are each slightly ahead in the step (forward 19.5 -> 18.6 ms together with the cheap tanh) and because the switches say where the time is.
-constexpr int RROW = 64;                                                      // bytes per LDS row: 32 k
-
-// NW waves of 32 rows each: 4 (128-row panels, two workgroups per CU, one barrier per stage) or 8 (256-row panels, one workgroup per CU,
-// ping-pong: the 192 weight rows of a stage serve twice the activation rows).  DBG: measuring switches (GTOS_GRU_DBG) as separate
-// instantiations: 0 production, 1 no k loop, 2 no cell; eight waves only: 3 = the k loop's DMA alone (no fragment reads, no MFMAs),
-// 4 = its fragment reads and MFMAs alone (no DMA: the slots hold whatever they hold).
-template <int DBG, int NW>
-__global__ __launch_bounds__(64 * NW, 2) void gru_step_fwd_ring_kernel(StepArgs a) {
-    constexpr int TMW = 32 * NW, RAW = TMW * RROW, RSTW = (TMW + WROWS) * RROW;
-    if (a.p_drop > 0.f) a.seed = live_seed(a.seed);
-    __shared__ __attribute__((aligned(16))) char sl0[RSTW];
-    __shared__ __attribute__((aligned(16))) char sl1[RSTW];
-    __shared__ __attribute__((aligned(16))) char sl2[RSTW];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int fr = lane & 15, fq = lane >> 4;
-    const int hs = a.hs, nC = hs / TC;
-    const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
-    const int m0 = ((sq / nC) * 8 + xcd) * TMW, c0 = (sq % nC) * TC;
-    if (m0 >= a.rows) return;
-    if constexpr (DBG == 5 || DBG == 6) {                  // phase offset between the workgroups that share a CU (two per CU with four waves)
-        const bool late = DBG == 5 ? (blockIdx.x >= 256 && blockIdx.x < 512) : (blockIdx.x < 512 && ((blockIdx.x >> 3) & 1));
-        if (late) {
-            const uint64_t t0 = wall_clock64();
-            while (wall_clock64() - t0 < (uint64_t)a.dbg_delay) __builtin_amdgcn_s_sleep(64);
-        }
-    }
-    const int nkx = a.in_dim / 32, nk = DBG == 1 ? 0 : nkx + hs / 32;
-    // DMA: a wave instruction fills 1 KB = 16 rows x 64 B; lane l -> row l >> 2, physical chunk l & 3 (logical chunk below)
-    const int drow = lane >> 2;
-    const uint32_t dchunk = (uint32_t)(((lane & 3) ^ ((-(lane >> 4)) & 3)) << 4);
-    // wave w owns pieces w, w + NW of the activation rows and w, w + NW, .. of the weight rows -- 3 each with four waves, 2 each with
-    // eight, where waves 4-7 (whose second piece would be 12..15: there are 12) fetch their first piece twice: every wave issues the same
-    // number of DMAs per stage, so one wait count serves all (a conditional DMA made hipcc drain vmcnt(0) in front of the fragment
-    // reads).  Rows past the end re-read the last valid row (their results are never stored).
-    constexpr int NBP = (12 + NW - 1) / NW;
-    uint32_t axo[2], aho[2], bxo[NBP], bho[NBP], bdst[NBP];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = min(m0 + (wave + NW * i) * 16 + drow, a.rows - 1) - m0;
-        axo[i] = (uint32_t)r * (uint32_t)(a.ldx * 2) + dchunk;
-        aho[i] = (uint32_t)r * (uint32_t)(hs * 2) + dchunk;
-    }
-#pragma unroll
-    for (int i = 0; i < NBP; ++i) {
-        const int piece = wave + NW * i < 12 ? wave + NW * i : wave;
-        bdst[i] = (uint32_t)piece * 1024u;
-        const int rl = piece * 16 + drow;                                      // LDS weight row -> (gate, channel) as in dma_weights
-        const int g = rl >> 6, nt = (rl >> 4) & 3, q = (rl >> 2) & 3, e = rl & 3;
-        const int wrow = g * hs + c0 + q * 16 + nt * 4 + e;
-        bxo[i] = (uint32_t)wrow * (uint32_t)(a.in_dim * 2) + dchunk;
-        bho[i] = (uint32_t)wrow * (uint32_t)(hs * 2) + dchunk;
-    }
-    const char* Xb = reinterpret_cast<const char*>(a.x + (int64_t)m0 * a.ldx);
-    const char* Hb = reinterpret_cast<const char*>(a.h_in + (int64_t)m0 * hs);
-    const char* Wi = reinterpret_cast<const char*>(a.w_ih);
-    const char* Wh = reinterpret_cast<const char*>(a.w_hh);
-    const int foff = fr * RROW + ((fq ^ ((-(fr >> 2)) & 3)) << 4);           // fragment reads: row (.. + fr), logical chunk fq
-
-    f32x4_t acc[2][16];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    bf16x8_t fa[2], fb[12];
-
-#define GTOS_DMA1(src, dst)                                                                                                   \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),                                    \
-                                     (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
-// this wave's pieces of stage s_ (past the end: the last stage again, never multiplied) into `slot`
-#define GTOS_RING_DMA(slot, s_)                                                                                               \
-    if constexpr (DBG != 4) {                                                                                                 \
-        const int st_ = min((s_), nk - 1);                                                                                    \
-        const bool px_ = st_ < nkx;                                                                                           \
-        const char* ab_ = px_ ? Xb + st_ * 64 : Hb + (st_ - nkx) * 64;                                                        \
-        const char* bb_ = px_ ? Wi + st_ * 64 : Wh + (st_ - nkx) * 64;                                                        \
-        GTOS_DMA1(ab_ + (px_ ? axo[0] : aho[0]), (slot) + wave * 1024);                                                       \
-        GTOS_DMA1(ab_ + (px_ ? axo[1] : aho[1]), (slot) + (wave + NW) * 1024);                                                \
-        GTOS_DMA1(bb_ + (px_ ? bxo[0] : bho[0]), (slot) + RAW + bdst[0]);                                                     \
-        GTOS_DMA1(bb_ + (px_ ? bxo[1] : bho[1]), (slot) + RAW + bdst[1]);                                                     \
-        if constexpr (NBP > 2) GTOS_DMA1(bb_ + (px_ ? bxo[2] : bho[2]), (slot) + RAW + bdst[2]);                              \
-    }
-// one stage: own pieces of stage s_ landed (vmcnt(pieces per stage): those of stage s_+1 stay in flight), barrier (everybody's landed, and
-// everybody is past its reads of stage s_-1), stage s_+2 into the slot of stage s_-1, 14 fragment reads, 24 MFMAs
-// Eight waves (two per SIMD) run it as a PING-PONG like gemm256p_nt_kernel: a step is a LOAD segment (DMA issue, the 14 fragment reads --
-// 14 KB per wave out of LDS --, the wait for the wave's own pieces of stage s_+1) and a COMPUTE segment (24 MFMAs), each closed by a
-// barrier, and waves 4-7 run one segment behind waves 0-3: on every SIMD one wave reads LDS while its partner multiplies.  With all
-// waves in the same phase (the four-wave form, or eight in lock step) a stage costs LDS time PLUS matrix time: 112 KB of fragment reads
-// and 2 x 408 cycles of MFMA per SIMD measured ~1900 cycles per stage, the k loop alone 581 us per 434 k-row launch whatever the DMA volume.
-#define GTOS_RING_STEP(slot_s, slot_d, s_)                                                                                    \
-    {                                                                                                                         \
-        if constexpr (NW == 4) {                                                                                              \
-            GTOS_VMCNT(2 + NBP);                                                                                              \
-            __builtin_amdgcn_s_barrier();                                                                                     \
-        }                                                                                                                     \
-        GTOS_RING_DMA(slot_d, (s_) + 2);                                                                                      \
-        if constexpr (DBG != 3) {                                                                                             \
-            _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                                  \
-                fa[mt] = *reinterpret_cast<const bf16x8_t*>((slot_s) + (wave * 32 + mt * 16) * RROW + foff);                  \
-            _Pragma("unroll") for (int t = 0; t < 12; ++t)                                                                    \
-                fb[t] = *reinterpret_cast<const bf16x8_t*>((slot_s) + RAW + (t * 16) * RROW + foff);                           \
-        }                                                                                                                     \
-        if constexpr (NW == 4) {                                                                                              \
-            __builtin_amdgcn_s_waitcnt(0xc07f);            /* lgkmcnt(0) */                                                   \
-        } else {                                           /* fragments here AND own pieces of stage s_+1 landed, then everybody's */ \
-            __builtin_amdgcn_s_waitcnt(0x0070 | ((2 + NBP) & 15));                                                            \
-            __builtin_amdgcn_s_barrier();                                                                                     \
-        }                                                                                                                     \
-        __builtin_amdgcn_sched_barrier(0);                                                                                    \
-        if constexpr (DBG != 3)                                                                                               \
-        _Pragma("unroll") for (int g = 0; g < 2; ++g)                                                                         \
-            _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                                  \
-                _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                              \
-                    acc[mt][g * 4 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[g * 4 + nt], fa[mt], acc[mt][g * 4 + nt], 0, 0, 0); \
-        if constexpr (DBG == 3) {                                                                                             \
-        } else if ((s_) < nkx) {                                                                                              \
-            _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                                  \
-                _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                              \
-                    acc[mt][8 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[8 + nt], fa[mt], acc[mt][8 + nt], 0, 0, 0);  \
-        } else {                                                                                                              \
-            _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                                  \
-                _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                              \
-                    acc[mt][12 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[8 + nt], fa[mt], acc[mt][12 + nt], 0, 0, 0); \
-        }                                                                                                                     \
-        __builtin_amdgcn_sched_barrier(0);                                                                                    \
-        if constexpr (NW == 8) __builtin_amdgcn_s_barrier();                                                                  \
-    }
-
-    if (nk > 0) {
-        GTOS_RING_DMA(sl0, 0);
-        GTOS_RING_DMA(sl1, 1);
-        if constexpr (NW == 8) {
-            GTOS_VMCNT(2 + NBP);                           // own pieces of stage 0
-            __builtin_amdgcn_s_barrier();                  // everybody's
-            if (wave >= 4) __builtin_amdgcn_s_barrier();   // the second wave of every SIMD starts one segment late
-        }
-    }
-    int s = 0;
-    for (; s + 3 <= nk; s += 3) {                          // whole triples: one path through the body for the wait-count pass
-        GTOS_RING_STEP(sl0, sl2, s);
-        GTOS_RING_STEP(sl1, sl0, s + 1);
-        GTOS_RING_STEP(sl2, sl1, s + 2);
-    }
-    if (s < nk) {
-        GTOS_RING_STEP(sl0, sl2, s);
-        if (s + 1 < nk) GTOS_RING_STEP(sl1, sl0, s + 1);
-    }
-    if constexpr (NW == 8) { if (nk > 0 && wave < 4) __builtin_amdgcn_s_barrier(); }     // same number of barriers for both halves
-    GTOS_VMCNT(0);                                         // the dummy prefetches of the last two stages
-#undef GTOS_RING_STEP
-#undef GTOS_RING_DMA
-#undef GTOS_DMA1
-    if constexpr (DBG >= 2 && DBG <= 4) {                  // k loop alone (3: its DMA only, 4: its LDS reads + MFMAs only): one store per lane keeps the accumulators alive
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-        if (t == 123.456f) a.gates[threadIdx.x] = f2bf(t);
-        return;
-    }
-    step_cell<1>(a, acc, m0, c0, wave, fr, fq);
+    step_cell<MODE>(a, acc, m0, c0, wave, fr, fq);
 }
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Round 5, last: the same fused forward step with TWO slots of 64-k stages -- whole 128-byte lines per operand row and DMA instruction
-// (8 rows x 128 B) where the three-slot ring above fetches 16 rows x 64 B, i.e. asks for every cache line twice, a stage apart (round 4
-// measured what that costs a GEMM k loop: 8192^3 0.63 -> 1.05 PF/s) -- and the next stage in flight while this one is multiplied, which
-// gru_step_fwd_kernel<1> (128-byte rows, one stage) does not have.  Eight waves, 256 rows x 64 channels per workgroup, 2 x 56 KB of LDS, one
-// workgroup per CU; per stage a wave issues 7 DMAs (4 of activation rows, 3 of weight rows), waits for its own pieces of the stage it is
-// about to read, meets the others at ONE barrier (everybody's pieces landed, everybody past its reads of the previous stage = the other
-// slot is free), starts the next stage into the other slot and runs two 32-k sub-steps of 14 fragment reads + 24 MFMAs.  Same lane ->
-// channel map, k order and cell as the other two kernels: bit-identical.  in_dim % 64 == 0.  DBG as above (0 production, 1 no k loop,
-// 2 no cell, 3 DMA alone, 4 reads + MFMAs alone); 7 mixed roles, 8 / 9 line-wise cell accesses, 10 DMA alone with two stages in flight.
-// What bounds the k loop (profiles/r5_ab_switches.txt, calls 19-24): its DMA alone takes 434 us per 434 k-row launch of layer 1 with ONE
-// 56 KB stage per CU in flight and 309 us with two (switch 10) -- a round trip per stage, not a bandwidth -- but a third 56 KB slot does not
-// fit the 160 KB of LDS, and four 28 KB stages of 32 k in flight (a five-slot ring, built and measured: DMA alone 436 us, launch 839 vs 792,
-// RelationEncoder forward 19.8 vs 18.2 ms in the step) do not deliver faster than two: half-line rows gain nothing from depth.
-// The cell with line-wise global accesses FOR REAL (every array through a wave-private, swizzled 2 KB LDS area and out as 8 rows x 128
-// contiguous bytes per instruction; the entering state in the same way; bit-identical; call 27): the cell alone 385 -> 255 us as the timing
-// experiment (switches 8 / 9) had said, but the launch only 543 -> 533 / 818 -> 808 us and the step 80.02 / 80.07 -> 79.99 / 79.96 ms.  Removed.
-template <int DBG, int NW>
-__global__ __launch_bounds__(64 * NW, 2) void gru_step_fwd_dbuf_kernel(StepArgs a) {
-    constexpr int TMW = 32 * NW, AW = TMW * ROWB, SLOT = AW + B_BYTES, NBP = 24 / NW;      // eight waves: 32 KB + 24 KB per slot
-    if (a.p_drop > 0.f) a.seed = live_seed(a.seed);
-    __shared__ __attribute__((aligned(16))) char sd0[SLOT];
-    __shared__ __attribute__((aligned(16))) char sd1[SLOT];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int fr = lane & 15, fq = lane >> 4;
-    const int hs = a.hs, nC = hs / TC;
-    const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
-    const int m0 = ((sq / nC) * 8 + xcd) * TMW, c0 = (sq % nC) * TC;
-    if (m0 >= a.rows) return;
-    // DBG 7: MIXED roles in one launch -- workgroups with bit 5 of their per-XCD index set run the k loop's DMA alone, the others the cell
-    // alone (each CU's first two workgroups, or neighbouring CUs with eight waves, get one of each): do the two phases share a resource?
-    const bool dma_role = DBG == 7 && ((sq >> 5) & 1);
-    const int nkx = a.in_dim / BK, nk = (DBG == 1 || DBG == 8 || (DBG == 7 && !dma_role)) ? 0 : nkx + hs / BK;
-    // per-lane source offsets, once: wave w owns 1 KB blocks w, w + 8, .. (8 rows x 128 B each) of both operands
-    uint32_t axo[4], aho[4], bxo[NBP], bho[NBP];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int rl = (i * NW + wave) * 8 + (lane >> 3);
-        const int r = min(m0 + rl, a.rows - 1) - m0;                          // rows past the end re-read the last valid row (never stored)
-        const uint32_t c = (uint32_t)(((lane & 7) ^ swz(rl)) << 4);
-        axo[i] = (uint32_t)r * (uint32_t)(a.ldx * 2) + c;
-        aho[i] = (uint32_t)r * (uint32_t)(hs * 2) + c;
-    }
-#pragma unroll
-    for (int i = 0; i < NBP; ++i) {
-        const int rl = (i * NW + wave) * 8 + (lane >> 3);
-        const int g = rl >> 6, nt = (rl >> 4) & 3, q = (rl >> 2) & 3, e = rl & 3;
-        const int wrow = g * hs + c0 + q * 16 + nt * 4 + e;
-        const uint32_t c = (uint32_t)(((lane & 7) ^ swz(rl)) << 4);
-        bxo[i] = (uint32_t)wrow * (uint32_t)(a.in_dim * 2) + c;
-        bho[i] = (uint32_t)wrow * (uint32_t)(hs * 2) + c;
-    }
-    const char* Xb = reinterpret_cast<const char*>(a.x + (int64_t)m0 * a.ldx);
-    const char* Hb = reinterpret_cast<const char*>(a.h_in + (int64_t)m0 * hs);
-    const char* Wi = reinterpret_cast<const char*>(a.w_ih);
-    const char* Wh = reinterpret_cast<const char*>(a.w_hh);
-
-    f32x4_t acc[2][16];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-#define GTOS_DMA1(src, dst)                                                                                                   \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),                                    \
-                                     (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
-// this wave's 7 pieces of stage s_ (past the end: the last stage again, never multiplied) into `slot`
-#define GTOS_DBUF_DMA(slot, s_)                                                                                               \
-    if constexpr (DBG != 4) {                                                                                                 \
-        const int st_ = min((s_), nk - 1);                                                                                    \
-        const bool px_ = st_ < nkx;                                                                                           \
-        const char* ab_ = px_ ? Xb + st_ * ROWB : Hb + (st_ - nkx) * ROWB;                                                    \
-        const char* bb_ = px_ ? Wi + st_ * ROWB : Wh + (st_ - nkx) * ROWB;                                                    \
-        GTOS_DMA1(ab_ + (px_ ? axo[0] : aho[0]), (slot) + (0 * NW + wave) * 1024);                                             \
-        GTOS_DMA1(ab_ + (px_ ? axo[1] : aho[1]), (slot) + (1 * NW + wave) * 1024);                                             \
-        GTOS_DMA1(ab_ + (px_ ? axo[2] : aho[2]), (slot) + (2 * NW + wave) * 1024);                                             \
-        GTOS_DMA1(ab_ + (px_ ? axo[3] : aho[3]), (slot) + (3 * NW + wave) * 1024);                                             \
-        GTOS_DMA1(bb_ + (px_ ? bxo[0] : bho[0]), (slot) + AW + (0 * NW + wave) * 1024);                                        \
-        GTOS_DMA1(bb_ + (px_ ? bxo[1] : bho[1]), (slot) + AW + (1 * NW + wave) * 1024);                                        \
-        GTOS_DMA1(bb_ + (px_ ? bxo[2] : bho[2]), (slot) + AW + (2 * NW + wave) * 1024);                                        \
-        if constexpr (NBP > 3) {                                                                                              \
-            GTOS_DMA1(bb_ + (px_ ? bxo[3] : bho[3]), (slot) + AW + (3 * NW + wave) * 1024);                                   \
-            GTOS_DMA1(bb_ + (px_ ? bxo[4] : bho[4]), (slot) + AW + (4 * NW + wave) * 1024);                                   \
-            GTOS_DMA1(bb_ + (px_ ? bxo[5] : bho[5]), (slot) + AW + (5 * NW + wave) * 1024);                                   \
-        }                                                                                                                     \
-    }
-#define GTOS_DBUF_STEP(slot_s, slot_d, s_)                                                                                    \
-    {                                                                                                                         \
-        if constexpr (DBG == 10) { GTOS_VMCNT(4 + NBP); }  /* (DMA alone with TWO stages in flight: nobody reads what lands) */  \
-        else { GTOS_VMCNT_LDS(0); }                        /* own pieces of stage s_; own fragment reads of stage s_ - 1 done */ \
-        __builtin_amdgcn_s_barrier();                      /* everybody's; and everybody is past its reads of stage s_ - 1 */ \
-        GTOS_DBUF_DMA(slot_d, (s_) + 1);                                                                                      \
-        if constexpr (DBG != 3 && DBG != 7 && DBG != 10) {                                                                             \
-            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                                \
-                bf16x8_t fa[2], fb[12];                                                                                       \
-                _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                              \
-                    fa[mt] = *reinterpret_cast<const bf16x8_t*>((slot_s) + lds_off(wave * 32 + mt * 16 + fr, ks * 4 + fq));   \
-                _Pragma("unroll") for (int t = 0; t < 12; ++t)                                                                \
-                    fb[t] = *reinterpret_cast<const bf16x8_t*>((slot_s) + AW + lds_off(t * 16 + fr, ks * 4 + fq));            \
-                _Pragma("unroll") for (int g = 0; g < 2; ++g)                                                                 \
-                    _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                          \
-                        _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                      \
-                            acc[mt][g * 4 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[g * 4 + nt], fa[mt], acc[mt][g * 4 + nt], 0, 0, 0); \
-                if ((s_) < nkx) {                                                                                             \
-                    _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                          \
-                        _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                      \
-                            acc[mt][8 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[8 + nt], fa[mt], acc[mt][8 + nt], 0, 0, 0); \
-                } else {                                                                                                      \
-                    _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                          \
-                        _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                      \
-                            acc[mt][12 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[8 + nt], fa[mt], acc[mt][12 + nt], 0, 0, 0); \
-                }                                                                                                             \
-            }                                                                                                                 \
-        }                                                                                                                     \
-    }
-
-    if (nk > 0) GTOS_DBUF_DMA(sd0, 0);
-    int s = 0;
-    for (; s + 2 <= nk; s += 2) {                          // whole pairs: every code location has its slot (the compiler's wait-count pass)
-        GTOS_DBUF_STEP(sd0, sd1, s);
-        GTOS_DBUF_STEP(sd1, sd0, s + 1);
-    }
-    if (s < nk) GTOS_DBUF_STEP(sd0, sd1, s);
-    GTOS_VMCNT(0);                                         // the dummy prefetch of the last stage
-#undef GTOS_DBUF_STEP
-#undef GTOS_DBUF_DMA
-#undef GTOS_DMA1
-    if (DBG == 7 && dma_role) return;
-    if constexpr ((DBG >= 2 && DBG <= 4) || DBG == 10) {   // measuring switches: one store per lane keeps the accumulators alive
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-        if (t == 123.456f) a.gates[threadIdx.x] = f2bf(t);
-        return;
-    }
-    if constexpr (DBG == 8 || DBG == 9) { if (m0 + TMW <= a.rows) step_cell<1, true>(a, acc, m0, c0, wave, fr, fq); }   // (whole panels only: timing)
-    else step_cell<1>(a, acc, m0, c0, wave, fr, fq);
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------------
-// The two-slot kernel with MORE IN FLIGHT (the default where it applies).  What bounds gru_step_fwd_dbuf_kernel's k loop is the round trip of
-// the ONE 56 KB stage a CU has in flight (its DMA alone: 434 us per 434 k-row launch of layer 1; with two stages in flight and nobody reading
-// them: 309 us), and a third 56 KB slot does not fit the LDS -- but the two operands of a stage need not have the same number of slots:
-//   A3 (default): THREE slots of activation rows (32 KB each) and two of weight rows (24 KB): 144 KB of LDS; per stage a wave issues its 3
-//       pieces of W(s+1) and THEN its 4 of A(s+2); loads complete in order, so "all but the newest four" (vmcnt(4)) is exactly "W(s) and A(s)
-//       have landed, A(s+1) may still fly" -- while stage s is multiplied, A(s+1), W(s+1) and A(s+2) are under way: 88 KB per CU;
-//   !A3: two slots of activation rows and three of weight rows (136 KB; A(s+1) then W(s+2) per stage, vmcnt(3); 80 KB in flight).
-// Measured (call 31, 434 k rows, layer 1 / layer 0): DMA alone 433 -> 405 (!A3) -> 332 us (A3) / 222 -> 215 -> 183; launch 804 -> 760 -> 730 /
-// 544 -> 541 -> 524 us; in the step RelationEncoder forward 18.2 -> 16.9 -> 16.6 ms, step 80.4 -> 79.2 -> 79.0 ms.
-// Slots are static arrays (hipcc's wait-count pass tracks LDS-DMA per LDS object): the body is unrolled over lcm(2, 3) = 6 stages, so the stage
-// count must be a multiple of 6 (in_dim 128: 2 + 4; in_dim 512: 8 + 4; the host falls back to the two-slot kernel otherwise).  Eight waves,
-// 256 rows x 64 channels, same lane -> channel map, k order and cell: the same bits.  DBG: 0 production, 1 no k loop, 2 no cell, 3 DMA alone.
-template <int DBG, bool A3>
+// The fused forward step (input product inside) for production-sized launches: 256 rows x 64 channels on eight waves, the k axis [x | h]
+// in 64-k stages of whole 128-byte lines per operand row and DMA instruction, THREE slots of activation rows (3 x 32 KB) and two of weight
+// rows (2 x 24 KB) = 144 KB of LDS.  Per stage a wave issues its 3 pieces of W(s+1) and THEN its 4 of A(s+2); loads complete in order, so
+// "all but the newest four" (vmcnt(4)) is exactly "W(s) and A(s) have landed, A(s+1) may still fly": while stage s is multiplied, A(s+1),
+// W(s+1) and A(s+2) are under way -- 88 KB per CU in flight.  One wait + one barrier per stage; lgkmcnt(0) in front of the barrier: hipcc
+// sinks a stage's last MFMAs, and the wait of their fragment reads, below it (GTOS_VMCNT_LDS).
+// How it got here (round 5; each form bit-identical to the single-stage gru_step_fwd_kernel<1>, all but this one removed in round 6 -- their
+// measurements are in DESIGN.md section 5): one 64-k stage ~895 us per 434 k-row launch of layer 1 -> a three-slot ring of 32-k stages
+// 870-914 -> two slots of whole 64-k stages 792-826 -> this 730 (layer 0: 524).  The k loop is bound by the round trip of what a CU keeps
+// in flight (its DMA alone: 434 us with one 56 KB stage in flight, 332 here), the cell by its stores, and the two add up.
+// Slots are static arrays (hipcc's wait-count pass tracks LDS-DMA per LDS object): the body is unrolled over lcm(2, 3) = 6 stages, so the
+// stage count (in_dim + hs) / 64 must be a multiple of 6 -- true for both layers of every BASELINE config (2 + 4, 8 + 4); the host sends
+// everything else, and launches under 8192 rows, to gru_step_fwd_kernel<1>.  Same lane -> channel map, k order and cell: the same bits
+// (tests/test_hip_parity.py::test_gru_forward_pipelined_kernel_bit_identical_to_single_stage).
 __global__ __launch_bounds__(512, 2) void gru_step_fwd_a2w3_kernel(StepArgs a) {
     constexpr int TMW = 256, AW = TMW * ROWB;                                  // 32 KB of activation rows, B_BYTES = 24 KB of weight rows
     if (a.p_drop > 0.f) a.seed = live_seed(a.seed);
@@ -775,15 +358,14 @@ __global__ __launch_bounds__(512, 2) void gru_step_fwd_a2w3_kernel(StepArgs a) {
     __shared__ __attribute__((aligned(16))) char sa1[AW];
     __shared__ __attribute__((aligned(16))) char sw0[B_BYTES];
     __shared__ __attribute__((aligned(16))) char sw1[B_BYTES];
-    __shared__ __attribute__((aligned(16))) char sw2[A3 ? 16 : B_BYTES];
-    __shared__ __attribute__((aligned(16))) char sa2[A3 ? AW : 16];
+    __shared__ __attribute__((aligned(16))) char sa2[AW];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fr = lane & 15, fq = lane >> 4;
     const int hs = a.hs, nC = hs / TC;
     const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
     const int m0 = ((sq / nC) * 8 + xcd) * TMW, c0 = (sq % nC) * TC;
     if (m0 >= a.rows) return;
-    const int nkx = a.in_dim / BK, nk = DBG == 1 ? 0 : nkx + hs / BK;
+    const int nkx = a.in_dim / BK, nk = nkx + hs / BK;
     uint32_t axo[4], aho[4], bxo[3], bho[3];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -836,19 +418,14 @@ __global__ __launch_bounds__(512, 2) void gru_step_fwd_a2w3_kernel(StepArgs a) {
         GTOS_DMA1(bb_ + (px_ ? bxo[1] : bho[1]), (slot) + (1 * 8 + wave) * 1024);                                             \
         GTOS_DMA1(bb_ + (px_ ? bxo[2] : bho[2]), (slot) + (2 * 8 + wave) * 1024);                                             \
     }
-// stage s_: A in sa_, W in sw_; A(s_+1) goes to sa_n (held A(s_-1)), W(s_+2) to sw_n (held W(s_-1))
+// stage s_: A in sa_, W in sw_; W(s_+1) goes to sw_n (held W(s_-1)), A(s_+2) to sa_n (held A(s_-1))
 #define GTOS_A2W3_STEP(sa_, sw_, sa_n, sw_n, s_)                                                                              \
     {                                                                                                                         \
-        if constexpr (A3) { GTOS_VMCNT_LDS(4); } else { GTOS_VMCNT_LDS(3); }   /* own pieces of A(s_), W(s_) (the newest stage issued may still fly); own reads of s_ - 1 done */ \
+        GTOS_VMCNT_LDS(4);                                 /* own pieces of A(s_), W(s_) landed (A(s_+1) may still fly); own reads of s_ - 1 done */ \
         __builtin_amdgcn_s_barrier();                      /* everybody's; and everybody is past its reads of stage s_ - 1 */ \
-        if constexpr (A3) {                                                                                                   \
-            GTOS_A2W3_DMA_W(sw_n, (s_) + 1);                                                                                  \
-            GTOS_A2W3_DMA_A(sa_n, (s_) + 2);                                                                                  \
-        } else {                                                                                                              \
-            GTOS_A2W3_DMA_A(sa_n, (s_) + 1);                                                                                  \
-            GTOS_A2W3_DMA_W(sw_n, (s_) + 2);                                                                                  \
-        }                                                                                                                     \
-        if constexpr (DBG != 3) {                                                                                             \
+        GTOS_A2W3_DMA_W(sw_n, (s_) + 1);                                                                                      \
+        GTOS_A2W3_DMA_A(sa_n, (s_) + 2);                                                                                      \
+        {                                                                                                                     \
             _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                                \
                 bf16x8_t fa[2], fb[12];                                                                                       \
                 _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                              \
@@ -875,39 +452,22 @@ __global__ __launch_bounds__(512, 2) void gru_step_fwd_a2w3_kernel(StepArgs a) {
     if (nk > 0) {                                          // the loop's invariant from the start: the newest pieces are one whole stage of one operand
         GTOS_A2W3_DMA_A(sa0, 0);
         GTOS_A2W3_DMA_W(sw0, 0);
-        if constexpr (A3) { GTOS_A2W3_DMA_A(sa1, 1); } else { GTOS_A2W3_DMA_W(sw1, 1); }
+        GTOS_A2W3_DMA_A(sa1, 1);
     }
     for (int s = 0; s + 6 <= nk; s += 6) {                 // (nk % 6 == 0: checked by the host)
-        if constexpr (A3) {                                // A(s) in slot s % 3, W(s) in slot s % 2; A(s+2) -> (s+2) % 3, W(s+1) -> (s+1) % 2
-            GTOS_A2W3_STEP(sa0, sw0, sa2, sw1, s);
-            GTOS_A2W3_STEP(sa1, sw1, sa0, sw0, s + 1);
-            GTOS_A2W3_STEP(sa2, sw0, sa1, sw1, s + 2);
-            GTOS_A2W3_STEP(sa0, sw1, sa2, sw0, s + 3);
-            GTOS_A2W3_STEP(sa1, sw0, sa0, sw1, s + 4);
-            GTOS_A2W3_STEP(sa2, sw1, sa1, sw0, s + 5);
-        } else {                                           // A(s) in slot s % 2, W(s) in slot s % 3; A(s+1) -> (s+1) % 2, W(s+2) -> (s+2) % 3
-            GTOS_A2W3_STEP(sa0, sw0, sa1, sw2, s);
-            GTOS_A2W3_STEP(sa1, sw1, sa0, sw0, s + 1);
-            GTOS_A2W3_STEP(sa0, sw2, sa1, sw1, s + 2);
-            GTOS_A2W3_STEP(sa1, sw0, sa0, sw2, s + 3);
-            GTOS_A2W3_STEP(sa0, sw1, sa1, sw0, s + 4);
-            GTOS_A2W3_STEP(sa1, sw2, sa0, sw1, s + 5);
-        }
+        // A(s) in slot s % 3, W(s) in slot s % 2; A(s+2) -> (s+2) % 3, W(s+1) -> (s+1) % 2
+        GTOS_A2W3_STEP(sa0, sw0, sa2, sw1, s);
+        GTOS_A2W3_STEP(sa1, sw1, sa0, sw0, s + 1);
+        GTOS_A2W3_STEP(sa2, sw0, sa1, sw1, s + 2);
+        GTOS_A2W3_STEP(sa0, sw1, sa2, sw0, s + 3);
+        GTOS_A2W3_STEP(sa1, sw0, sa0, sw1, s + 4);
+        GTOS_A2W3_STEP(sa2, sw1, sa1, sw0, s + 5);
     }
     GTOS_VMCNT(0);                                         // the dummy prefetches of the last stages
 #undef GTOS_A2W3_STEP
 #undef GTOS_A2W3_DMA_W
 #undef GTOS_A2W3_DMA_A
 #undef GTOS_DMA1
-    if constexpr (DBG >= 2) {                              // measuring switches: one store per lane keeps the accumulators alive
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-        if (t == 123.456f) a.gates[threadIdx.x] = f2bf(t);
-        return;
-    }
     step_cell<1>(a, acc, m0, c0, wave, fr, fq);
 }
 
@@ -1058,7 +618,7 @@ __global__ __launch_bounds__(256, 1) void gru_l1_fwd_persistent_kernel(StepArgs 
             if (m < a.rows) {
                 bf16_t* gp = a.gates + (int64_t)m * 4 * HS + cb;
                 st16(gp, gr); st16(gp + HS, gz); st16(gp + 2 * HS, gn);
-                if (a.save_hn) st16(gp + 3 * HS, hn);
+                st16(gp + 3 * HS, hn);
                 bf16_t* hdst = m < a.n_out ? a.h_out + (int64_t)m * HS + cb
                                            : a.h_fin + (int64_t)(a.fin_idx ? a.fin_idx[m] : m) * a.ld_fin + cb;
                 st16(hdst, o);
@@ -1088,8 +648,6 @@ struct StepBwdArgs {
     int zero_row;                                  //   sum_idx value that stands for "all zero" (a leaf): nothing is fetched for it
     float p_drop; uint64_t seed; int64_t drop_base;
     int rows, hs; const void* zeros;
-    const bf16_t* w_hn; const float* b_hn;         // optional: rows [2hs, 3hs) of W_hh (K-contiguous, ld hs) and of b_hh: hn = h_prev W_hn^T + b_hn is
-                                                   //   RECOMPUTED here instead of read from the gates buffer (the forward did not store it)
     // Role B (round 5): workgroups of the SAME launch that turn the d4 rows of the step processed just before into that step's INPUT
     // gradient, dinp[rows_prev, n_in] = d4_prev[:, 0:3hs] (d r | d z | d n_x) x W_ih -- the product nn.GRU's autograd runs as one
     // [N,3hs] x [3hs,in] GEMM per direction after BPTT.  They read the rows the recurrent product of role A reads, at the same time and
@@ -1120,11 +678,6 @@ __device__ __forceinline__ void dma_wt(const bf16_t* __restrict__ w, int64_t ld,
     }
 }
 
-// Round 4, hn recompute (a.w_hn != NULL): the forward leaves the hn block of the gates unwritten -- on this chip a saved byte costs a
-// write at 4.4 TB/s plus a read at 6.2, and hn is 1/4 of the 2 KB a row saves -- and this kernel rebuilds it before everything else:
-// hn[128 rows x 64 channels] = h_prev[128 x hs] W_hn[64 x hs]^T + b_hn on the MFMA (hs/64 more k tiles in front of the 3hs/64 of the
-// state-gradient product), rounded to bf16 exactly like the forward rounded the value it used (same operands, same k order: identical),
-// parked in LDS (a lane reads back only what it wrote), so the register budget and the three workgroups per CU stay.
 // Role B of the backward step launch (StepBwdArgs.dinp): one 128-row x 128-column tile of the previous step's input gradient,
 // dinp[m0.., n0..] = d4_prev[m0.., 0:3hs] x wi_t[n0.., 0:3hs]^T.  Same single-stage k loop as the recurrent product of role A (the two
 // 64-row weight blocks in the permuted order of dma_wt, so a lane ends up with 16 consecutive columns of each half).
@@ -1135,7 +688,7 @@ __device__ __forceinline__ void dma_wt(const bf16_t* __restrict__ w, int64_t ld,
 // W(s), A(s+1) goes into the other slot, the stage is multiplied, and a second barrier frees the weight slot.  Same stage and k order as the
 // single-stage loop: the same bits.  SKIP: the A operand skips the d n_x block of d4 (the recurrent product).  nsub <= NB weight pieces are
 // valid (uniform per workgroup); the pieces past them are neither fetched nor multiplied.
-// Measured against the single-stage loops (GTOS_GRU_BWD_DBG=3) on one box, call 36: 1065 vs 1080 us (layer 1) and 882 vs 874 us (layer 0) per
+// Measured against single-stage loops on one box (round 5, call 36): 1065 vs 1080 us (layer 1) and 882 vs 874 us (layer 0) per
 // 434 k-row launch alone, GRU backward 29.9 vs 30.3 ms and the step 78.6 / 78.8 vs 78.8 / 79.2 ms.
 template <int NB, bool SKIP>
 __device__ __forceinline__ void kloop_a2(const bf16_t* __restrict__ A, int64_t lda, int rows_total, int m0, const bf16_t* __restrict__ W,
@@ -1169,7 +722,7 @@ __device__ __forceinline__ void kloop_a2(const bf16_t* __restrict__ A, int64_t l
                 }                                                                                                             \
             }                                                                                                                 \
         }                                                                                                                     \
-        __builtin_amdgcn_s_waitcnt(0xc07f);                /* lgkmcnt(0): this wave's fragment reads have COMPLETED, not just been issued */ \
+        GTOS_LGKM0();                                      /* lgkmcnt(0): this wave's fragment reads have COMPLETED, not just been issued */ \
         __builtin_amdgcn_s_barrier();                      /* the weight slot (and this panel slot) are free again */         \
     }
     GTOS_KA_A(a0, 0);
@@ -1185,7 +738,7 @@ __device__ __forceinline__ void kloop_a2(const bf16_t* __restrict__ A, int64_t l
 #undef GTOS_KA_A
 }
 
-template <int DBG, int NS, bool PIPE>
+template <int NS>
 __device__ __forceinline__ void dinp_tile(const StepBwdArgs& a, int m0, int n0, char* As, char* Bs, char* A1, int wave, int lane) {
     if (m0 >= a.rows_prev) return;
     const int fr = lane & 15, fq = lane >> 4, hs = a.hs;
@@ -1196,45 +749,7 @@ __device__ __forceinline__ void dinp_tile(const StepBwdArgs& a, int m0, int n0, 
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < NS * 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    if constexpr (PIPE) {
-        if constexpr (DBG != 1)
-            kloop_a2<NS, false>(a.d4_prev, 4 * (int64_t)hs, a.rows_prev, m0, a.wi_t, 3 * (int64_t)hs, n0, nsub, hs, Z, As, A1, Bs, acc, wave, lane);
-    } else
-    for (int kk = 0; kk < (DBG == 1 ? 0 : 3 * hs); kk += BK) {
-        dma_rows(a.d4_prev, Z, 4 * (int64_t)hs, a.rows_prev, m0, kk, kk + BK, As, wave, lane);
-#pragma unroll
-        for (int h = 0; h < NS; ++h)
-            if (h < nsub) dma_wt(a.wi_t, 3 * (int64_t)hs, n0 + h * TC, kk, Bs + h * TC * ROWB, wave, lane);
-        __syncthreads();
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8_t fa[2], fb[4];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) fa[mt] = *reinterpret_cast<const bf16x8_t*>(As + lds_off(wave * 32 + mt * 16 + fr, ks * 4 + fq));
-#pragma unroll
-            for (int h = 0; h < NS; ++h) {
-                if (h < nsub) {
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) fb[nt] = *reinterpret_cast<const bf16x8_t*>(Bs + h * TC * ROWB + lds_off(nt * 16 + fr, ks * 4 + fq));
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < 4; ++nt)
-                            acc[mt][h * 4 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][h * 4 + nt], 0, 0, 0);
-                }
-            }
-        }
-        __syncthreads();
-    }
-    if constexpr (DBG == 2) {                              // measuring switch: the product alone
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < NS * 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-        if (t == 123.456f) a.dinp[threadIdx.x] = f2bf(t);
-        return;
-    }
+    kloop_a2<NS, false>(a.d4_prev, 4 * (int64_t)hs, a.rows_prev, m0, a.wi_t, 3 * (int64_t)hs, n0, nsub, hs, Z, As, A1, Bs, acc, wave, lane);
     const float ks_in = a.p_in > 0.f ? 1.f / (1.f - a.p_in) : 1.f;
     const uint64_t seed_in = a.p_in > 0.f ? live_seed(a.seed_in) : 0;
     // direction 1 adds to what direction 0 wrote: all of a lane's pieces in flight before the first is used (round 6; one dependent
@@ -1277,27 +792,23 @@ __device__ __forceinline__ void dinp_tile(const StepBwdArgs& a, int m0, int n0, 
     }
 }
 
-// HN: the hn recompute of round 4 (a.w_hn != NULL, opt-in) -- its 16 KB LDS park for the rebuilt values exists in that instantiation only.
 // NS: 64-column pieces per input-gradient tile (role B): 2 = 128 columns (32 KB of LDS with the row panel).  4 = 256 columns (the previous
 // step's rows fetched half as often) was built and measured in round 5: role B alone 400 vs 409-432 us per 434 k-row launch of layer 1, the
 // whole launch 1128 vs 1046-1059 us at two workgroups per CU (202 registers) and 2314 us at three (124 bytes of scratch per lane): fewer
-// fetched bytes do not shorten these k loops (profiles/r5_ab_switches.txt, call 21).
-// DBG: measuring switches (GTOS_GRU_BWD_DBG, packed-path launches): 1 = no k loops, 2 = the k loops alone, 3 = the production code with the
-// single-stage k loops (what ran until the end of round 5).  Call 18 (single-stage loops), 434,624 rows: layer 1 1040 us = 530 (no k loops) +
-// 528 (k loops alone); layer 0 860 = 524 + 363 -- the launch costs the sum of its two parts here as well.
-// Fully double-buffered k loops (two 32 KB slots per role: 64 KB of LDS = two workgroups per CU) were built and measured (call 22): 1098-1126
-// vs 1072-1082 us (layer 1), 901-928 vs 867 (layer 0), 31.8 vs 30.2 ms of GRU backward in the step -- the third workgroup per CU is worth
-// more than the second weight slot.  What runs now keeps it: kloop_a2 above.
-template <bool HN, int DBG, int NS = 2>
+// fetched bytes do not shorten these k loops.  Fully double-buffered k loops (two 32 KB slots per role: 64 KB of LDS = two workgroups per CU):
+// 1098-1126 vs 1072-1082 us -- the third workgroup per CU is worth more than the second weight slot; what runs keeps it: kloop_a2 above.
+// Round 6 built two more forms, both bit-identical, both slower, both removed again (profiles/r6_gru_bwd_forms.txt):
+// 256-row panels on eight waves with BOTH roles fed from one walk over d4_prev (-42 % LDS-DMA bytes, 88 KB in flight; 1,098-1,107 vs
+// 1,062-1,070 us) and persistent workgroups with a 96-column weight slice resident in LDS and decoupled waves (1,224-1,319 us).
+// Measured split of this kernel at 434,624 rows of layer 1: 520 us without its k loops + 566 us of k loops alone = 1,070 together.
+template <int NS = 2>
 __global__ __launch_bounds__(256, 3) void gru_step_bwd_kernel(StepBwdArgs a) {
-    constexpr bool PIPE = !HN && DBG != 3;                 // the row panel one stage ahead (kloop_a2); DBG 3: the single-stage loops, for comparison
     if (a.p_drop > 0.f) a.seed = live_seed(a.seed);
     // separate LDS objects for the row-panel slots and the weight slot: hipcc's wait-count pass tracks LDS-DMA per object (with the weight rows
     // behind the panel in one array it drained vmcnt(0) in front of every fragment read of the weights while the next panel was in flight)
     __shared__ __attribute__((aligned(16))) char lds[A_BYTES];
     __shared__ __attribute__((aligned(16))) char lds_w[NS * TC * ROWB];
-    __shared__ __attribute__((aligned(16))) char lds_a1[PIPE ? A_BYTES : 16];      // the second slot of the row panel
-    __shared__ __attribute__((aligned(16))) char hn_lds[HN ? 256 * 2 * 32 : 16];  // per lane 2 row blocks x 16 channels bf16 (16 KB)
+    __shared__ __attribute__((aligned(16))) char lds_a1[A_BYTES];                   // the second slot of the row panel
     __shared__ float btab[4 * TC];
     char* As = lds;
     char* Bs = lds_w;
@@ -1308,7 +819,7 @@ __global__ __launch_bounds__(256, 3) void gru_step_bwd_kernel(StepBwdArgs a) {
     const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
     // the workgroups of a 128-row panel -- nC cell tiles (role A), then nB input-gradient tiles (role B) -- run back to back on one XCD
     const int m0 = ((sq / per) * 8 + xcd) * TM, role = sq % per;
-    if (role >= nC) { dinp_tile<DBG, NS, PIPE>(a, m0, (role - nC) * NS * TC, As, Bs, lds_a1, wave, lane); return; }
+    if (role >= nC) { dinp_tile<NS>(a, m0, (role - nC) * NS * TC, As, Bs, lds_a1, wave, lane); return; }
     const int c0 = role * TC;
     if (m0 >= a.rows) return;
     const U128* Z = static_cast<const U128*>(a.zeros);
@@ -1319,38 +830,6 @@ __global__ __launch_bounds__(256, 3) void gru_step_bwd_kernel(StepBwdArgs a) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    if (HN && a.w_hn) {
-        const RowSrc hsrc = row_src(a.hprev, hs, a.rows, m0, wave, lane, a.hprev_idx);
-        for (int kk = 0; kk < hs; kk += BK) {
-            dma_rows_at(hsrc, Z, kk, hs, As, wave);
-            dma_wt(a.w_hn, hs, c0, kk, Bs, wave, lane);
-            __syncthreads();
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8_t fa[2], fb[4];
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) fa[mt] = *reinterpret_cast<const bf16x8_t*>(As + lds_off(wave * 32 + mt * 16 + fr, ks * 4 + fq));
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) fb[nt] = *reinterpret_cast<const bf16x8_t*>(Bs + lds_off(nt * 16 + fr, ks * 4 + fq));
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
-            }
-            __syncthreads();
-        }
-        float bn[16];
-        ldf16(a.b_hn + c0 + fq * 16, bn);
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            float v[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { v[i] = acc[mt][i >> 2][i & 3] + bn[i]; acc[mt][i >> 2][i & 3] = 0.f; }
-            st16(reinterpret_cast<bf16_t*>(hn_lds + (threadIdx.x * 2 + mt) * 32), v);          // (st16 rounds to bf16: the forward's rounding)
-        }
-    }
 
     if (a.d4_prev && a.sum_idx) {
         // trie: operand rows through the children-sum indirection; the per-lane source addresses are computed once
@@ -1375,42 +854,12 @@ __global__ __launch_bounds__(256, 3) void gru_step_bwd_kernel(StepBwdArgs a) {
             }
             __syncthreads();
         }
-    } else if (PIPE && DBG != 1 && a.d4_prev && m0 < a.rows_prev) {
+    } else if (a.d4_prev && m0 < a.rows_prev) {            // the packed rows: the row panel one stage ahead
         kloop_a2<1, true>(a.d4_prev, 4 * (int64_t)hs, a.rows_prev, m0, a.wh_t, 3 * (int64_t)hs, c0, 1, hs, Z, As, lds_a1, Bs, acc, wave, lane);
-    } else if (DBG != 1 && a.d4_prev && m0 < a.rows_prev) {
-        for (int kk = 0; kk < 3 * hs; kk += BK) {
-            const int ak = kk < 2 * hs ? kk : kk + hs;                 // skip the d n_x block of d4
-            dma_rows(a.d4_prev, Z, 4 * (int64_t)hs, a.rows_prev, m0, ak, ak + BK, As, wave, lane);
-            dma_wt(a.wh_t, 3 * (int64_t)hs, c0, kk, Bs, wave, lane);
-            __syncthreads();
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8_t fa[2], fb[4];
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) fa[mt] = *reinterpret_cast<const bf16x8_t*>(As + lds_off(wave * 32 + mt * 16 + fr, ks * 4 + fq));
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) fb[nt] = *reinterpret_cast<const bf16x8_t*>(Bs + lds_off(nt * 16 + fr, ks * 4 + fq));
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
-            }
-            __syncthreads();
-        }
     } else if (a.bias_part) {
         __syncthreads();                                               // btab zeroed before anyone adds to it
     }
 
-    if constexpr (DBG == 2) {
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-        if (t == 123.456f) a.d4[threadIdx.x] = f2bf(t);
-        return;
-    }
     const int cb = c0 + fq * 16;
     const float ks = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
 #pragma unroll
@@ -1423,8 +872,7 @@ __global__ __launch_bounds__(256, 3) void gru_step_bwd_kernel(StepBwdArgs a) {
         float gr[16], gz[16], gn[16], hn[16], hp[16], g[16];
         const bf16_t* gp = a.gates + (int64_t)m * 4 * hs + cb;
         ld16(gp, gr); ld16(gp + hs, gz); ld16(gp + 2 * hs, gn);
-        if (HN && a.w_hn) ld16(reinterpret_cast<const bf16_t*>(hn_lds + (threadIdx.x * 2 + mt) * 32), hn);
-        else ld16(gp + 3 * hs, hn);
+        ld16(gp + 3 * hs, hn);
         ld16(a.hprev + (int64_t)(a.hprev_idx ? a.hprev_idx[m] : m) * hs + cb, hp);
         float* dhp = static_cast<float*>(a.dh) + (int64_t)m * a.ld_dh + cb;
         bf16_t* dhb = static_cast<bf16_t*>(a.dh) + (int64_t)m * a.ld_dh + cb;
@@ -1501,7 +949,7 @@ extern "C" int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, i
                                  const void* xg, const void* gf, const int* gf_idx, const void* gb, const int* gb_idx,
                                  const void* h_in, const int* h_idx, const void* w_hh, const float* b_hh,
                                  void* h_out, int n_out, void* h_fin, int64_t ld_fin, const int* fin_idx, void* gates, void* y, int64_t ldy,
-                                 float p_drop, uint64_t seed, int64_t drop_base, int save_hn, void* stream) {
+                                 float p_drop, uint64_t seed, int64_t drop_base, void* stream) {
     if (rows <= 0) return 0;
     if (hs <= 0 || hs % TC) return -22;
     if (!h_in || !w_hh || !b_hh || !gates) return -23;
@@ -1523,21 +971,13 @@ extern "C" int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, i
     a.h_out = (bf16_t*)h_out; a.n_out = n_out; a.h_fin = (bf16_t*)h_fin; a.gates = (bf16_t*)gates; a.y = (bf16_t*)y; a.ldy = ldy;
     a.ld_fin = ld_fin; a.fin_idx = fin_idx;
     a.p_drop = p_drop; a.seed = seed; a.drop_base = drop_base; a.rows = rows; a.hs = hs;
-    static const int env_dbg = getenv("GTOS_GRU_DBG") ? atoi(getenv("GTOS_GRU_DBG")) : 0;
-    // tools/bench_gru_step.py passes measuring switches per launch above the flag: bits 8-15 the switch, 16-19 the wave count, 20+ a delay in us
-    const int dbg = ((save_hn >> 8) & 0xff) ? ((save_hn >> 8) & 0xff) : env_dbg;
-    const int nw_launch = (save_hn >> 16) & 0xf;
-    a.dbg_delay = (save_hn >> 20) * 100;
-    save_hn &= 0xff;
-    a.save_hn = save_hn;
     a.zeros = gtos_zero_block();
     if (!a.zeros) return -5;
     const long long nM = (rows + TM - 1) / TM, nC = hs / TC;
     const long long nblk = ((nM + 7) / 8) * 8 * nC;
     if (nblk > 0x7fffffffLL) return -6;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    static const bool use_persistent = !(getenv("GTOS_GRU_PERSISTENT") && getenv("GTOS_GRU_PERSISTENT")[0] == '0');
-    if (mode == 2 && use_persistent && hs == 256 && !h_idx && !y && rows >= 16384) {
+    if (mode == 2 && hs == 256 && !h_idx && !y && rows >= 16384) {                      // trie evaluation, layer 1: W_hh slice resident in LDS
         constexpr int KT = 4;
         const size_t lds_bytes = (size_t)KT * B_BYTES + 4 * KT * P_ROWS * ROWB;        // 96 KB + 64 KB
         static bool configured = false;
@@ -1551,69 +991,12 @@ extern "C" int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, i
         GTOS_CHECK_LAUNCH();
         return 0;
     }
-    // GTOS_GRU_FWD_RING (round 5; 0 = the single-stage kernel): the three-slot ring of 32-k stages for the fused input product;
-    // GTOS_GRU_FWD_NW = 4 / 8 waves per workgroup (128- / 256-row panels)
-    static const bool use_ring = !(getenv("GTOS_GRU_FWD_RING") && getenv("GTOS_GRU_FWD_RING")[0] == '0');
-    static const int ring_nw = getenv("GTOS_GRU_FWD_NW") ? atoi(getenv("GTOS_GRU_FWD_NW")) : 8;
-    if (mode == 1 && use_ring && in_dim % 32 == 0 && !h_idx && ldx < (1 << 20) && (int64_t)3 * hs * (in_dim > hs ? in_dim : hs) * 2 < (1LL << 31))
-    {
-        const int nw_env = ring_nw ? ring_nw : (in_dim <= 128 ? 4 : 8);                 // 0: by the input width
-        // GTOS_GRU_FWD_DBUF (default 1; 0 = the ring; 4 = four waves, 128-row panels, two workgroups per CU at exactly 2 x 80 KB of LDS:
-        // ahead in isolated launches, 82.2 / 79.9 ms in the step against 80.3 / 80.1 -- not stable): two slots of 64-k stages, 128-byte rows.
-        // (Per launch, tools/bench_gru_step.py: wave-count field 2 = eight waves, 3 = four.)
-        static const bool use_dbuf = !(getenv("GTOS_GRU_FWD_DBUF") && getenv("GTOS_GRU_FWD_DBUF")[0] == '0');
-        static const int dbuf_nw = (getenv("GTOS_GRU_FWD_DBUF") && getenv("GTOS_GRU_FWD_DBUF")[0] == '4') ? 4 : 8;
-        const int db = nw_launch ? (nw_launch == 2 ? 8 : nw_launch == 3 ? 4 : 0) : (use_dbuf ? dbuf_nw : 0);
-        // GTOS_GRU_FWD_A2W3 (default 2): separate slot counts for the two operands of the two-slot kernel's stages -- 2 = THREE slots of activation
-        // rows and two of weight rows (88 KB per CU in flight, 144 KB of LDS), 1 = two and three (80 KB, 136 KB), 0 = two and two (56 KB: the
-        // kernel above).  Needs a stage count that is a multiple of 6; same bits.  Same box, the step: 80.46 / 80.31 (0), 79.10 / 79.33 (1), 78.72 / 79.21 ms (2).
-        static const int a2w3_mode = getenv("GTOS_GRU_FWD_A2W3") ? atoi(getenv("GTOS_GRU_FWD_A2W3")) : 2;
-        const int a2w3 = nw_launch ? (nw_launch == 6 ? 1 : nw_launch == 7 ? 2 : 0) : (use_dbuf ? a2w3_mode : 0);     // 1: A two / W three slots, 2: A three / W two
-        if (a2w3 && in_dim % 64 == 0 && (in_dim / 64 + hs / 64) % 6 == 0 && rows >= 8192) {
-            const long long nM8 = (rows + 255) / 256, nblk8 = ((nM8 + 7) / 8) * 8 * nC;
-            if (a2w3 == 2) {
-                if (dbg == 1) hipLaunchKernelGGL((gru_step_fwd_a2w3_kernel<1, true>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
-                else if (dbg == 2) hipLaunchKernelGGL((gru_step_fwd_a2w3_kernel<2, true>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
-                else if (dbg == 3) hipLaunchKernelGGL((gru_step_fwd_a2w3_kernel<3, true>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
-                else hipLaunchKernelGGL((gru_step_fwd_a2w3_kernel<0, true>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
-            }
-            else if (dbg == 1) hipLaunchKernelGGL((gru_step_fwd_a2w3_kernel<1, false>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
-            else if (dbg == 2) hipLaunchKernelGGL((gru_step_fwd_a2w3_kernel<2, false>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
-            else if (dbg == 3) hipLaunchKernelGGL((gru_step_fwd_a2w3_kernel<3, false>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
-            else hipLaunchKernelGGL((gru_step_fwd_a2w3_kernel<0, false>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
-        }
-        else if (db == 8 && in_dim % 64 == 0 && rows >= 8192) {
-            const long long nM8 = (rows + 255) / 256, nblk8 = ((nM8 + 7) / 8) * 8 * nC;
-            if (dbg == 1) hipLaunchKernelGGL((gru_step_fwd_dbuf_kernel<1, 8>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
-            else if (dbg == 2) hipLaunchKernelGGL((gru_step_fwd_dbuf_kernel<2, 8>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
-            else if (dbg == 3) hipLaunchKernelGGL((gru_step_fwd_dbuf_kernel<3, 8>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
-            else if (dbg == 7) hipLaunchKernelGGL((gru_step_fwd_dbuf_kernel<7, 8>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
-            else if (dbg == 10) hipLaunchKernelGGL((gru_step_fwd_dbuf_kernel<10, 8>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
-            else if (dbg == 8) hipLaunchKernelGGL((gru_step_fwd_dbuf_kernel<8, 8>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
-            else if (dbg == 9) hipLaunchKernelGGL((gru_step_fwd_dbuf_kernel<9, 8>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
-            else hipLaunchKernelGGL((gru_step_fwd_dbuf_kernel<0, 8>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
-        }
-        else if (db == 4 && in_dim % 64 == 0) {
-            if (dbg == 1) hipLaunchKernelGGL((gru_step_fwd_dbuf_kernel<1, 4>), dim3((unsigned)nblk), dim3(256), 0, s, a);
-            else if (dbg == 2) hipLaunchKernelGGL((gru_step_fwd_dbuf_kernel<2, 4>), dim3((unsigned)nblk), dim3(256), 0, s, a);
-            else if (dbg == 3) hipLaunchKernelGGL((gru_step_fwd_dbuf_kernel<3, 4>), dim3((unsigned)nblk), dim3(256), 0, s, a);
-            else if (dbg == 7) hipLaunchKernelGGL((gru_step_fwd_dbuf_kernel<7, 4>), dim3((unsigned)nblk), dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((gru_step_fwd_dbuf_kernel<0, 4>), dim3((unsigned)nblk), dim3(256), 0, s, a);
-        }
-        else
-        if ((nw_launch ? nw_launch : nw_env) == 8 && rows >= 8192) {                    // (small launches: more, smaller workgroups fill the chip better)
-            const long long nM8 = (rows + 255) / 256, nblk8 = ((nM8 + 7) / 8) * 8 * nC;
-            if (dbg == 1) hipLaunchKernelGGL((gru_step_fwd_ring_kernel<1, 8>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
-            else if (dbg == 2) hipLaunchKernelGGL((gru_step_fwd_ring_kernel<2, 8>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
-            else if (dbg == 3) hipLaunchKernelGGL((gru_step_fwd_ring_kernel<3, 8>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
-            else if (dbg == 4) hipLaunchKernelGGL((gru_step_fwd_ring_kernel<4, 8>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
-            else hipLaunchKernelGGL((gru_step_fwd_ring_kernel<0, 8>), dim3((unsigned)nblk8), dim3(512), 0, s, a);
-        }
-        else if (dbg == 1) hipLaunchKernelGGL((gru_step_fwd_ring_kernel<1, 4>), dim3((unsigned)nblk), dim3(256), 0, s, a);
-        else if (dbg == 2) hipLaunchKernelGGL((gru_step_fwd_ring_kernel<2, 4>), dim3((unsigned)nblk), dim3(256), 0, s, a);
-        else if (dbg == 5) hipLaunchKernelGGL((gru_step_fwd_ring_kernel<5, 4>), dim3((unsigned)nblk), dim3(256), 0, s, a);
-        else if (dbg == 6) hipLaunchKernelGGL((gru_step_fwd_ring_kernel<6, 4>), dim3((unsigned)nblk), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((gru_step_fwd_ring_kernel<0, 4>), dim3((unsigned)nblk), dim3(256), 0, s, a);
+    // GTOS_GRU_FWD_A2W3=0: never the pipelined kernel (the tests compare it with the single-stage one bit for bit)
+    static const bool use_a2w3 = !(getenv("GTOS_GRU_FWD_A2W3") && getenv("GTOS_GRU_FWD_A2W3")[0] == '0');
+    if (mode == 1 && use_a2w3 && rows >= 8192 && in_dim % 64 == 0 && (in_dim / 64 + hs / 64) % 6 == 0 && !h_idx && ldx < (1 << 20) &&
+        (int64_t)3 * hs * (in_dim > hs ? in_dim : hs) * 2 < (1LL << 31)) {
+        const long long nM8 = (rows + 255) / 256, nblk8 = ((nM8 + 7) / 8) * 8 * nC;
+        hipLaunchKernelGGL(gru_step_fwd_a2w3_kernel, dim3((unsigned)nblk8), dim3(512), 0, s, a);
     }
     else if (mode == 1) hipLaunchKernelGGL(gru_step_fwd_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, s, a);
     else if (mode == 2) hipLaunchKernelGGL(gru_step_fwd_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, s, a);
@@ -1626,19 +1009,18 @@ extern "C" int gtos_gru_step_bwd_fused(int rows, int hs, const void* d4_prev, in
                                        const void* gates, const void* hprev, const int* hprev_idx, const void* dy, int64_t ldy,
                                        void* dh, int dh_dtype, int64_t ld_dh, void* d4, float p_drop, uint64_t seed, int64_t drop_base,
                                        float* bias_partials, int n_partials, void* hprev_out, const int* sum_idx, const void* dh_src,
-                                       int zero_row, const void* w_hn, const float* b_hn,
+                                       int zero_row,
                                        const void* w_ih_t, void* dinp, int64_t ld_dinp, int n_in, int dinp_accumulate, float p_in,
                                        uint64_t seed_in, int64_t in_drop_base, void* stream) {
     const bool role_b = dinp != nullptr && d4_prev != nullptr && rows_prev > 0;
     if (rows <= 0 && !role_b) return 0;
     if (hs <= 0 || hs % TC) return -22;
     if (rows > 0) {
-        if (!gates || !hprev || !dh || !d4 || (d4_prev && !w_hh_t) || (w_hn && !b_hn)) return -23;
+        if (!gates || !hprev || !dh || !d4 || (d4_prev && !w_hh_t)) return -23;
         if (sum_idx && (!dh_src || (uintptr_t)dh_src % 16)) return -23;
     }
     if (dinp && (!d4_prev || !w_ih_t || sum_idx)) return -23;                 // role B reads the previous step's rows in place
     if (dinp && (n_in <= 0 || n_in % TC || ld_dinp < n_in || ld_dinp % 8 || (uintptr_t)dinp % 16 || (uintptr_t)w_ih_t % 16)) return -27;
-    if ((uintptr_t)w_hn % 16 || (uintptr_t)b_hn % 16) return -25;
     if (bias_partials && n_partials < 1) return -26;
     if ((uintptr_t)d4_prev % 16 || (uintptr_t)w_hh_t % 16 || (uintptr_t)gates % 16 || (uintptr_t)hprev % 16 || (uintptr_t)dh % 16 ||
         (uintptr_t)d4 % 16 || (dy && ((uintptr_t)dy % 16 || ldy % 8)) || (rows > 0 && (ld_dh < hs || ld_dh % 8)) ||
@@ -1648,7 +1030,6 @@ extern "C" int gtos_gru_step_bwd_fused(int rows, int hs, const void* d4_prev, in
     a.gates = (const bf16_t*)gates; a.hprev = (const bf16_t*)hprev; a.hprev_idx = hprev_idx; a.dy = (const bf16_t*)dy; a.ldy = ldy;
     a.dh = dh; a.dh_bf16 = dh_dtype == GTOS_BF16; a.ld_dh = ld_dh; a.d4 = (bf16_t*)d4; a.bias_part = bias_partials; a.n_partials = n_partials;
     a.hp_out = (bf16_t*)hprev_out; a.sum_idx = sum_idx; a.dh_src = dh_src; a.zero_row = sum_idx ? zero_row : -1;
-    a.w_hn = (const bf16_t*)w_hn; a.b_hn = b_hn;
     a.wi_t = (const bf16_t*)w_ih_t; a.dinp = role_b ? (bf16_t*)dinp : nullptr; a.ld_dinp = ld_dinp; a.n_in = n_in; a.dinp_acc = dinp_accumulate;
     a.p_in = p_in; a.seed_in = seed_in; a.in_drop_base = in_drop_base;
     a.p_drop = p_drop; a.seed = seed; a.drop_base = drop_base; a.rows = rows > 0 ? rows : 0; a.hs = hs;
@@ -1658,16 +1039,7 @@ extern "C" int gtos_gru_step_bwd_fused(int rows, int hs, const void* d4_prev, in
     const long long nM = (cover + TM - 1) / TM, per = hs / TC + (role_b ? (n_in + 2 * TC - 1) / (2 * TC) : 0);
     const long long nblk = ((nM + 7) / 8) * 8 * per;
     if (nblk > 0x7fffffffLL) return -6;
-    static const int bwd_dbg = getenv("GTOS_GRU_BWD_DBG") ? atoi(getenv("GTOS_GRU_BWD_DBG")) : 0;
-    const int dbg = (w_hn || sum_idx) ? 0 : bwd_dbg;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-#define GTOS_BWD_LAUNCH(HN_, D_) hipLaunchKernelGGL((gru_step_bwd_kernel<HN_, D_>), dim3((unsigned)nblk), dim3(256), 0, st, a)
-    if (w_hn) GTOS_BWD_LAUNCH(true, 0);
-    else if (dbg == 1) GTOS_BWD_LAUNCH(false, 1);
-    else if (dbg == 2) GTOS_BWD_LAUNCH(false, 2);
-    else if (dbg == 3) GTOS_BWD_LAUNCH(false, 3);
-    else GTOS_BWD_LAUNCH(false, 0);
-#undef GTOS_BWD_LAUNCH
+    hipLaunchKernelGGL(gru_step_bwd_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     GTOS_CHECK_LAUNCH();
     return 0;
 }
@@ -1675,10 +1047,9 @@ extern "C" int gtos_gru_step_bwd_fused(int rows, int hs, const void* d4_prev, in
 extern "C" int gtos_gru_step_bwd(int rows, int hs, const void* d4_prev, int rows_prev, const void* w_hh_t,
                                  const void* gates, const void* hprev, const int* hprev_idx, const void* dy, int64_t ldy, void* dh, int dh_dtype,
                                  int64_t ld_dh, void* d4, float p_drop, uint64_t seed, int64_t drop_base, float* bias_partials,
-                                 int n_partials, void* hprev_out, const int* sum_idx, const void* dh_src, int zero_row,
-                                 const void* w_hn, const float* b_hn, void* stream) {
+                                 int n_partials, void* hprev_out, const int* sum_idx, const void* dh_src, int zero_row, void* stream) {
     return gtos_gru_step_bwd_fused(rows, hs, d4_prev, rows_prev, w_hh_t, gates, hprev, hprev_idx, dy, ldy, dh, dh_dtype, ld_dh, d4,
-                                   p_drop, seed, drop_base, bias_partials, n_partials, hprev_out, sum_idx, dh_src, zero_row, w_hn, b_hn,
+                                   p_drop, seed, drop_base, bias_partials, n_partials, hprev_out, sum_idx, dh_src, zero_row,
                                    nullptr, nullptr, 0, 0, 0, 0.f, 0, 0, stream);
 }
 

@@ -764,7 +764,6 @@ extern "C" int gtos_rel_attn_bwd_bank(int dtype, int n, int B, int H, int d,
     a.xcd_off = xcd_off;
     a.hd = d / H; a.nhs = geo.nhs; a.lr = geo.lr;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    static const bool np4 = getenv("GTOS_BANK_NP") && getenv("GTOS_BANK_NP")[0] == '4';
     int grid = (nchunks + 3) / 4; if (grid > 4096) grid = 4096;
     if (xcd_off) grid = (grid + 7) / 8 * 8;
     const dim3 g2(grid, geo.slices);
@@ -774,8 +773,7 @@ extern "C" int gtos_rel_attn_bwd_bank(int dtype, int n, int B, int H, int d,
             if (dtype == GTOS_BF16) hipLaunchKernelGGL((rel_attn_bwd_bank_kernel<bf16_t, LH, true, 4>), g2, dim3(256), 0, s, a);
             else hipLaunchKernelGGL((rel_attn_bwd_bank_kernel<float, LH, true, 4>), g2, dim3(256), 0, s, a);
         } else {
-            if (dtype == GTOS_BF16 && np4) hipLaunchKernelGGL((rel_attn_bwd_bank_kernel<bf16_t, LH, false, 4>), g2, dim3(256), 0, s, a);
-            else if (dtype == GTOS_BF16) hipLaunchKernelGGL((rel_attn_bwd_bank_kernel<bf16_t, LH, false, 2>), g2, dim3(256), 0, s, a);
+            if (dtype == GTOS_BF16) hipLaunchKernelGGL((rel_attn_bwd_bank_kernel<bf16_t, LH, false, 2>), g2, dim3(256), 0, s, a);
             else hipLaunchKernelGGL((rel_attn_bwd_bank_kernel<float, LH, false, 4>), g2, dim3(256), 0, s, a);
         }
         GTOS_CHECK_LAUNCH();

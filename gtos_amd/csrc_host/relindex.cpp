@@ -76,7 +76,7 @@ extern "C" gtos_relindex* gtos_relindex_build(int n, int B, int64_t R, const int
         // light types: one chunk of <= `chunk` pairs; heavy types (more than `chunk` pairs): chunks of 4 * chunk pairs -- fewer
         // fp32-atomic flushes into the shared slot (65 k pairs of <TL>: 512, not 2048) without turning one wave's serial walk
         // over its chunk into the kernel's critical path (16 * chunk measured 390 us per launch for 0.44 GB of traffic)
-        static const int64_t mult = getenv("GTOS_HEAVY_CHUNK_MULT") ? atoi(getenv("GTOS_HEAVY_CHUNK_MULT")) : 4;
+        constexpr int64_t mult = 4;                                          // (round 3: 4 -> 800, 2 -> 890, 1 -> 1,120 us for the attention backward)
         const int64_t csz = hi - lo > chunk ? mult * (int64_t)chunk : chunk;
         const int64_t nch = hi > lo ? (hi - lo + csz - 1) / csz : 1;          // a type without pairs still writes its zero row
         int32_t slot = -1;
@@ -100,12 +100,10 @@ extern "C" gtos_relindex* gtos_relindex_build(int n, int B, int64_t R, const int
     // and a wave could meet two 128-pair chunks (chains of 122 rounds where the mean is 31).  Now: a chunk whose pairs all live
     // on one XCD stays there (its q/k rows are in that XCD's L2); a chunk that spans XCDs has no home and goes to the XCD with the
     // fewest rounds so far, the longest first; inside an XCD the long chunks (> 8 pairs) come first, longest first, so each
-    // starts a different wave's chain, and the short ones follow in (graph, key row) order as before.  GTOS_BANK_BALANCE=0: round 2's order.
-    static const bool balance = !(getenv("GTOS_BANK_BALANCE") && getenv("GTOS_BANK_BALANCE")[0] == '0');
-    static const bool heavy_first = getenv("GTOS_HEAVY_FIRST") && getenv("GTOS_HEAVY_FIRST")[0] == '1';
+    // starts a different wave's chain, and the short ones follow in (graph, key row) order as before (268-288 -> 202-206 us per launch).
     auto cost = [](const Chunk& c) { return (int64_t)(c.cnt + 3) / 4 + 1; };
     std::vector<int32_t> home(chunks.size());
-    if (balance) {
+    {
         int64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         std::vector<int32_t> roam;
         for (size_t c = 0; c < chunks.size(); ++c) {
@@ -122,12 +120,6 @@ extern "C" gtos_relindex* gtos_relindex_build(int n, int B, int64_t R, const int
             const int64_t lng = chunks[c].cnt > 8 ? 0 : 1;                     // long chunks first, longest first
             const int64_t rank = lng ? chunks[c].key : (int64_t)(0xfffff - std::min<int32_t>(chunks[c].cnt, 0xfffff)) << 20;
             chunks[c].key = ((int64_t)home[c] << 42) | (lng << 41) | rank;
-        }
-    } else {
-        for (size_t c = 0; c < chunks.size(); ++c) {
-            const int64_t late = (heavy_first && chunks[c].slot < 0) ? 1 : 0;
-            home[c] = chunks[c].x_first;
-            chunks[c].key = ((int64_t)home[c] << 42) | (late << 41) | chunks[c].key;
         }
     }
     std::stable_sort(chunks.begin(), chunks.end(), [](const Chunk& a, const Chunk& b) { return a.key < b.key; });

@@ -34,27 +34,21 @@ N_BIAS_PARTIALS = 1024
 
 # Forward time step on bf16: "x" = input AND recurrent gate products + cell in ONE kernel (gtos_gru_step_fwd),
 # "h" = recurrent product + cell fused, input gates by one big GEMM, "off" = GEMM + cell kernel per step (the fp32 path).
-FUSE = os.environ.get("GTOS_GRU_FUSE", "x")
+FUSE = "x"                       # (a module constant: the parity tests run the lower fusion levels through monkeypatch)
 # Backward: run the weight-gradient GEMMs of one direction on a second HIP stream while the (memory-bound) BPTT steps of
 # the next direction occupy the main stream: the step kernels are limited to 2 waves per SIMD by registers, an MFMA GEMM
 # wave fits beside them.
 SIDE_STREAM = os.environ.get("GTOS_GRU_SIDE", "1") != "0"
 SIDE_MIN_ROWS = 200000          # below this the GEMMs are launch-bound and the stream hand-over costs more than it hides
-# Round 4, the MEASUREMENT behind "recomputing gates does not pay" (rounds 2-3 had rejected it on paper): with GTOS_GRU_RECOMPUTE_HN=1 the
-# fused step kernels do not store hn = W_hn h + b_hn -- the cheapest quarter of the saved gates to rebuild: one [128 x hs] x [64 x hs]^T
-# product more per workgroup, operands the kernel reads anyway -- and the backward step recomputes it on the MFMA (bit-identical: parity
-# tests green under both settings).  C2, same box, alternating: layer-1 forward step 419 / 422 -> 402 / 406 us per launch (-0.3 ms per
-# step), backward step 487 / 483 -> 536 / 539 us (+0.8 ms), training step 61.38 / 61.30 -> 62.12 / 62.18 ms; with the reference's masks
-# (per-row path) 86.2 -> 86.9 ms.  The saved bytes (0.5 KB written + 0.5 KB read per row) are worth less than four more k tiles in a
-# kernel that already sits at the chip's read + write ceiling.  Off by default.
-RECOMPUTE_HN = os.environ.get("GTOS_GRU_RECOMPUTE_HN", "0") == "1"
+# (Round 4 measured GTOS_GRU_RECOMPUTE_HN -- the forward not storing hn = W_hn h + b_hn, the backward step rebuilding it on the MFMA: layer-1
+# forward step 419 -> 402 us per launch, backward step 487 -> 536 us, training step 61.3 -> 62.1 ms.  The saved bytes are worth less than four
+# more k tiles in a kernel at the chip's read + write ceiling; the switch and its kernel instantiation were removed in round 6.)
 
 
 def _step_fwd(A, hs, x, xg, h_in, wi, b_ih, wh, b_hh, h_out, n_out, h_fin, gates, y, y_off_elems, ldy, p, seed, drop_base,
-              h_idx=None, gf=None, gf_idx=None, gb=None, gb_idx=None, fin_idx=None, tag=None, save_hn=None):
+              h_idx=None, gf=None, gf_idx=None, gb=None, gb_idx=None, fin_idx=None, tag=None):
     """``h_fin``: [*, hs] or a column block of a wider matrix (its row stride is passed on); ``fin_idx``: int32 row map of the
-    finished rows (packed row m -> row fin_idx[m] of h_fin).  ``save_hn``: None = by RECOMPUTE_HN (the callers whose backward passes the
-    kernel w_hn / b_hn); True = always store the hn block (the packed path: its backward launches read it)."""
+    finished rows (packed row m -> row fin_idx[m] of h_fin)."""
     yp = None if y is None else y.data_ptr() + y_off_elems * y.element_size()
     need_bi = x is not None or gf is not None
     # ``tag`` (bench.py's per-kernel rows): the span is recorded under that name with its ALGORITHMIC bytes as units -- per active row the
@@ -63,31 +57,27 @@ def _step_fwd(A, hs, x, xg, h_in, wi, b_ih, wh, b_hh, h_out, n_out, h_fin, gates
     units = A if tag is None else A * 2 * (x.shape[1] + hs + 4 * hs + hs + (hs if y is not None else 0))
     with _Timed(name, detail=True, units=units):
         _step_fwd_call(A, hs, x, xg, h_in, wi, b_ih, wh, b_hh, h_out, n_out, h_fin, gates, yp, ldy, p, seed, drop_base,
-                       h_idx, gf, gf_idx, gb, gb_idx, need_bi, fin_idx, save_hn)
+                       h_idx, gf, gf_idx, gb, gb_idx, need_bi, fin_idx)
 
 
 def _step_fwd_call(A, hs, x, xg, h_in, wi, b_ih, wh, b_hh, h_out, n_out, h_fin, gates, yp, ldy, p, seed, drop_base,
-                   h_idx, gf, gf_idx, gb, gb_idx, need_bi, fin_idx=None, save_hn=None):
-    if save_hn is None:
-        save_hn = not RECOMPUTE_HN
+                   h_idx, gf, gf_idx, gb, gb_idx, need_bi, fin_idx=None):
     call("gtos_gru_step_fwd", A, hs, ptr(x), 0 if x is None else x.stride(0), 0 if x is None else x.shape[1],
          ptr(wi) if x is not None else None, ptr(b_ih) if need_bi else None, ptr(xg),
          ptr(gf), ptr(gf_idx), ptr(gb), ptr(gb_idx), ptr(h_in), ptr(h_idx), ptr(wh), ptr(b_hh),
          ptr(h_out), n_out, ptr(h_fin), hs if h_fin is None else h_fin.stride(0), ptr(fin_idx), ptr(gates), yp, ldy,
-         float(p), seed, drop_base, 1 if save_hn else 0, stream())
+         float(p), seed, drop_base, stream())
 
 
 def _step_bwd(A, hs, d4_prev, rows_prev, wh_t, gates, hprev, dy_ptr, ldy, dh, d4, p, seed, drop_base, bpart, hprev_idx=None, hp_out=None,
-              sum_idx=None, dh_src=None, zero_row=-1, wh=None, b_hh=None):
-    """``wh`` / ``b_hh``: the direction's recurrent weight (compute dtype, [3hs, hs]) and bias -- with RECOMPUTE_HN the kernel rebuilds hn
-    from their n rows.  ``dh``: [rows, hs] or a column block of a wider matrix (row stride passed on); ``hp_out``: [rows, hs] receiving the
+              sum_idx=None, dh_src=None, zero_row=-1):
+    """``dh``: [rows, hs] or a column block of a wider matrix (row stride passed on); ``hp_out``: [rows, hs] receiving the
     (gathered) entering state rows; ``sum_idx`` / ``dh_src``: per-row source rows of the recurrent operand (in d4_prev) and of the
     incoming state gradient (in dh_src) -- the trie's children-sum indirection."""
     with _Timed("gru_step_bwd_%s" % ("trie" if hprev_idx is not None else "rows"), detail=True, units=A):
         call("gtos_gru_step_bwd", A, hs, ptr(d4_prev), rows_prev if d4_prev is not None else 0, ptr(wh_t), ptr(gates), ptr(hprev),
              ptr(hprev_idx), dy_ptr, ldy, ptr(dh), dt(dh), dh.stride(0), ptr(d4), float(p), seed, drop_base,
-             ptr(bpart), N_BIAS_PARTIALS if bpart is not None else 0, ptr(hp_out), ptr(sum_idx), ptr(dh_src), int(zero_row),
-             ptr(wh[2 * hs:]) if RECOMPUTE_HN else None, ptr(b_hh[2 * hs:]) if RECOMPUTE_HN else None, stream())
+             ptr(bpart), N_BIAS_PARTIALS if bpart is not None else 0, ptr(hp_out), ptr(sum_idx), ptr(dh_src), int(zero_row), stream())
 
 
 def _cell_bwd(A, hs, gates, hprev, dy, dy_off_elems, ldy, dh, dxg, dhg, p, seed, drop_base, bpart):
@@ -206,7 +196,7 @@ class BiGRUFinalFn(torch.autograd.Function):
                         dyp = None if dY is None else dY.data_ptr() + (off * 2 * hs + direction * hs) * dY.element_size()
                         _step_bwd(A, hs, None if prev is None else d4[offs[prev]:], 0 if prev is None else batch_sizes[prev], wh_t,
                                   gates[off:off + A], hprev[off:off + A], dyp, 2 * hs, dh, d4[off:off + A], pl, seed,
-                                  off * 2 * hs + direction * hs, bpart, wh=compute_weight(w_hh, dtp), b_hh=b_hh.detach())
+                                  off * 2 * hs + direction * hs, bpart)
                         prev = t
                     dxg = d4[:, :3 * hs]
                     w_jobs = ((w_hh, d4[:, :2 * hs], hprev, 1, slice(0, 2 * hs)), (w_hh, d4[:, 3 * hs:], hprev, 1, slice(2 * hs, 3 * hs)),
@@ -327,21 +317,18 @@ def _step_bwd_fused(A, hs, d4_prev, rows_prev, wh_t, gates, hprev, dy_ptr, ldy, 
     with _Timed(tag, detail=True, units=nbytes):
         call("gtos_gru_step_bwd_fused", A, hs, ptr(d4_prev), rows_prev if d4_prev is not None else 0, ptr(wh_t), ptr(gates), ptr(hprev), None,
              dy_ptr, ldy, ptr(dh), 0 if dh is None else dt(dh), hs if dh is None else dh.stride(0), ptr(d4), float(p), seed, drop_base,
-             ptr(bpart), N_BIAS_PARTIALS if bpart is not None else 0, None, None, None, -1, None, None,
+             ptr(bpart), N_BIAS_PARTIALS if bpart is not None else 0, None, None, None, -1,
              ptr(wi_t), ptr(dinp), 0 if dinp is None else dinp.stride(0), n_in, int(dinp_acc), float(p_in), seed_in, in_drop_base, stream())
 
 
-# A/B switches of the round-5 path (each measured on the same box: profiles/r5_*):
-FUSE_DINP = os.environ.get("GTOS_GRU_FUSE_DINP", "1") != "0"      # layer input gradients inside the backward step launches (0: one GEMM per direction)
-MERGE_DW = os.environ.get("GTOS_GRU_MERGE_DW", "1") != "0"        # both weight gradients of a (layer, direction) as one grouped product (0: three GEMMs)
-# forward: direction 1 on the auxiliary stream beside direction 0.  MEASURED, no gain (same box, alternating: 86.66 / 84.89 ms with, 84.65 / 84.50
-# without; profiles/r5_ab_switches.txt): off.  See the comment in PackedPathGRUFn.forward for what it was meant to overlap and why it cannot.
+# (Round 5 measured, same box each, and round 6 removed the switches: the layers' input gradients as one GEMM per direction instead of role-B
+# tiles of the backward step launches 84.25 vs 81.70 ms per step; three weight-gradient GEMMs per (layer, direction) instead of the grouped
+# product 82.84 vs 81.70; the forward's direction 1 on the auxiliary stream beside direction 0 84.9-86.7 vs 84.5-84.7: profiles/r5_ab_switches.txt.)
 # packed path, backward: d4 written over the saved gates -- "1" always, "0" never, default: when the buffer is at least D4_INPLACE_MIN_BYTES
 # (measured, call 26: C2 -- 5 GB per buffer -- 80.7 vs 80.3 ms per step in place, reserved 64 vs 71 GB; C5 -- 18 GB -- 275.7 vs 276.5-277.2 ms,
 # reserved 145 vs 161-163 GB: worth it where memory is what is short)
 D4_INPLACE = os.environ.get("GTOS_GRU_D4_INPLACE", "auto")
 D4_INPLACE_MIN_BYTES = 8 << 30
-FWD_OVERLAP = os.environ.get("GTOS_GRU_FWD_OVERLAP", "0") == "1"
 
 
 class PackedPathGRUFn(torch.autograd.Function):
@@ -372,15 +359,8 @@ class PackedPathGRUFn(torch.autograd.Function):
         fin = (torch.empty if bs[0] == R else torch.zeros)((R, 2 * hs), dtype=dtp, device=dev)      # (an empty path keeps a zero vector)
         park = [torch.empty((bs[0], hs), dtype=dtp, device=dev) for _ in (0, 1)]   # where layer 0's finished rows land (nobody reads them)
         inp, saved = X, []
-        # The two directions of a layer are independent; FWD_OVERLAP=1 (opt-in) runs direction 1 on the auxiliary stream beside direction 0.
-        # What it was for: a step workgroup is a k loop followed by a cell that streams 2.5-3 KB per row out, and a launch measured alone
-        # costs the SUM of the two parts (gru_step_fwd_ring_kernel's measuring switches, L1 at 434 k rows: 593 us of k loop alone + 437 us of
-        # cell alone = 978 us together), not their maximum -- so workgroups of two launches, out of phase on a CU, might have overlapped one's
-        # stores with the other's products.  They do not (no gain, measured): the k loop is bound by operand delivery into LDS (6.5 GB of
-        # LDS-DMA per launch at the ~10.7 TB/s the chip sustains = the 593 us) and the cell by its stores, and both go through the CUs' one
-        # vector-memory pipe -- the phases add up however they are interleaved.  What shortens a launch is fewer bytes through that pipe.
-        main = torch.cuda.current_stream(dev)
-        aux = _side_stream(dev) if (FWD_OVERLAP and table.is_cuda and side_ok(dev) and N >= SIDE_MIN_ROWS) else main
+        # (The two directions of a layer are independent; running direction 1 on the auxiliary stream beside direction 0 was measured in
+        # round 5 and bought nothing -- a launch costs its k loop PLUS its cell however the launches are interleaved)
         for l in range(2):
             last = l == 1
             Y = None if last else torch.empty((N, 2 * hs), dtype=dtp, device=dev)
@@ -398,10 +378,7 @@ class PackedPathGRUFn(torch.autograd.Function):
                 else:
                     wi_t = weight_t(w_ih, wi)
                 wts.append((wi, wh, wi_t, weight_t(w_hh, wh), b_ih.detach(), b_hh.detach()))
-            if aux is not main:
-                aux.wait_stream(main)
             for direction in (0, 1):
-              with torch.cuda.stream(aux if direction == 1 else main):
                 wi, wh, wi_t, wh_t, bi, bh = wts[direction]
                 gates, hprev = bufs[direction]
                 if direction == 0:
@@ -421,11 +398,8 @@ class PackedPathGRUFn(torch.autograd.Function):
                         h_out, n_out = None, 0
                     _step_fwd(A, hs, inp[off:off + A], None, hprev[off:off + A], wi, bi, wh, bh, h_out, n_out, h_fin, gates[off:off + A],
                               Y, off * 2 * hs + direction * hs, 2 * hs, pl, seed, off * 2 * hs + direction * hs,
-                              fin_idx=plan.order32 if last else None, tag="gru_step_fwd_packed_l%d" % l,
-                              save_hn=True)           # (_step_bwd_fused reads the hn block: GTOS_GRU_RECOMPUTE_HN does not apply here)
+                              fin_idx=plan.order32 if last else None, tag="gru_step_fwd_packed_l%d" % l)
                 layer_saved.append((wi_t, wh_t, gates, hprev))
-            if aux is not main:
-                main.wait_stream(aux)
             saved.append((inp, seed, pl, layer_saved))
             inp = Y
         ctx.cfg = (plan, table, dim_pad, p_embed, seed_e, hs, weights, saved, onehot, tokens)
@@ -484,7 +458,7 @@ class PackedPathGRUFn(torch.autograd.Function):
                 note_memory(dev)
                 bpart = torch.zeros((N_BIAS_PARTIALS, 4 * hs), dtype=torch.float32, device=dev) if want_bias else None
                 rb = dict(wi_t=wi_t, n_in=n_in, dinp_acc=direction == 1, p_in=p_embed if l == 0 else 0.0,
-                          seed_in=seed_e if l == 0 else 0) if (want_dinp and FUSE_DINP) else None
+                          seed_in=seed_e if l == 0 else 0) if want_dinp else None
                 tag = "gru_step_bwd_packed_l%d" % l
                 prev = None
                 for t in (range(L - 1, -1, -1) if direction == 0 else range(L)):
@@ -498,14 +472,6 @@ class PackedPathGRUFn(torch.autograd.Function):
                 if rb is not None:                    # the input gradient of the step processed last: role B workgroups only
                     _step_bwd_fused(0, hs, d4[offs[prev]:], bs[prev], wh_t, None, None, None, 2 * hs, None, None, 0.0, 0, 0, None, tag=tag,
                                     **dict(rb, dinp=d_in[offs[prev]:], in_drop_base=offs[prev] * n_in))
-                elif want_dinp:
-                    pe = p_embed if l == 0 else 0.0
-                    if direction == 0:
-                        gemm(d4[:, :3 * hs], wi_t, trans_b=True, out=d_in, p_drop=pe, seed=seed_e if l == 0 else 0)
-                    elif pe > 0:                       # (the GEMM epilogue masks its product only, not the accumulated sum)
-                        d_in += gemm(d4[:, :3 * hs], wi_t, trans_b=True, p_drop=pe, seed=seed_e)
-                    else:
-                        gemm(d4[:, :3 * hs], wi_t, trans_b=True, out=d_in, accumulate=True)
                 del gates                              # the steps were their last reader
                 # Parameter gradients over all steps at once, on the auxiliary stream beside the NEXT direction's steps.  No record_stream:
                 # a block freed on one stream while another still reads it can only be recycled once the device has passed the free, and
@@ -525,12 +491,15 @@ class PackedPathGRUFn(torch.autograd.Function):
                     tg_hh = _grad_target(w_hh) if w_hh.requires_grad else None
                     tg_ih = grads[base] if (tg_ih is None and w_ih.requires_grad) else tg_ih
                     tg_hh = grads[base + 1] if (tg_hh is None and w_hh.requires_grad) else tg_hh
-                    if MERGE_DW and tg_ih is not None and tg_hh is not None and w_ih.shape[1] % 4 == 0:
+                    # both weight gradients of the (layer, direction) as ONE grouped product d4^T [x | h_prev]; a frozen weight gets a scratch target
+                    scr_ih = torch.zeros(w_ih.shape, dtype=torch.float32, device=dev) if tg_ih is None else tg_ih
+                    scr_hh = torch.zeros(w_hh.shape, dtype=torch.float32, device=dev) if tg_hh is None else tg_hh
+                    if (tg_ih is not None or tg_hh is not None) and w_ih.shape[1] % 4 == 0:
                         with _Timed("gru_dw_grouped_l%d" % l, detail=True, units=2 * N * 3 * hs * (w_ih.shape[1] + hs)):      # (units: useful flops)
                             ws = _workspace(dev)
                             call("gtos_gru_weight_grads", N, hs, n_in, w_ih.shape[1], ptr(d4), ptr(inp), inp.stride(0), ptr(hprev), hprev.stride(0),
-                                 ptr(tg_ih), tg_ih.stride(0), ptr(tg_hh), tg_hh.stride(0), ptr(ws), ws.numel() * 4, stream())
-                    else:
+                                 ptr(scr_ih), scr_ih.stride(0), ptr(scr_hh), scr_hh.stride(0), ptr(ws), ws.numel() * 4, stream())
+                    elif tg_ih is not None or tg_hh is not None:               # a label width that is no multiple of 4: per-matrix products
                         for (tg, dyv, xin, rows) in ((tg_hh, d4[:, :2 * hs], hprev, slice(0, 2 * hs)), (tg_hh, d4[:, 3 * hs:], hprev, slice(2 * hs, 3 * hs)),
                                                      (tg_ih, d4[:, :3 * hs], inp, slice(0, 3 * hs))):
                             if tg is None:
@@ -600,20 +569,20 @@ TRIE = os.environ.get("GTOS_GRU_TRIE", "1") != "0"
 # Trie backward: its GEMMs on the auxiliary stream beside the BPTT steps.  Measured at C2: no gain (73.6 vs 73.7 ms/step -- the
 # step kernels slow down by what the GEMMs gain once the per-row work is gone), so it is off by default and the profile stays
 # one kernel at a time.
-TRIE_SIDE = os.environ.get("GTOS_GRU_TRIE_SIDE", "0") == "1"
+TRIE_SIDE = False                # (module constant; tests/test_hip_parity.py runs both settings through monkeypatch)
 # Layer 0 walks each trie level by level (<= 8 small launches per trie, the first levels far too small to fill the chip); the
 # prefix and the suffix trie are independent, so the suffix side runs on the auxiliary stream beside the prefix side.
-TRIE_L0_OVERLAP = os.environ.get("GTOS_GRU_L0_OVERLAP", "1") != "0"
-# Layer 1, forward: the input-gate table products of the reverse direction on the auxiliary stream beside the forward direction's steps.
-TRIE_L1_TABLE_OVERLAP = os.environ.get("GTOS_GRU_L1_TABLES", "0") == "1"     # measured at C2: 64.28 vs 64.29 ms per step -- no gain, off
+TRIE_L0_OVERLAP = True
+# (Layer 1, forward: the input-gate table products of the reverse direction on the auxiliary stream beside the forward direction's steps were
+# measured at C2 in round 3: 64.28 vs 64.29 ms per step; removed in round 6.)
 # Label-embedding gradient of the trie path as two GEMMs (one-hot product) instead of the LDS-atomics scatter kernel.
-EMBED_GRAD_GEMM = os.environ.get("GTOS_EMBED_GEMM", "1") != "0"
+EMBED_GRAD_GEMM = True           # (False: 63.29 vs 62.8 ms per step, round 3)
 # Layer 0, backward: children -> parent sums through the row indirection of pathtrie.TrieSide.sum_idx (0: a summed row per node).
-TRIE_SUM_INDEX = os.environ.get("GTOS_GRU_SUMIDX", "1") != "0"
+TRIE_SUM_INDEX = True            # (False: 64.65 vs 64.29 ms per step, round 3)
 
 
 # Segmented sums of the gate gradients by the streaming kernel (a wave per range of ~256 rows) instead of a wave per chunk.
-SEG_STREAM = os.environ.get("GTOS_SEG_STREAM", "1") != "0"
+SEG_STREAM = True                # (False: 1,142-1,156 vs 1,077-1,094 us per launch, round 3; tests and tools/bench_segsum.py flip it)
 
 
 def _seg_rows(side, src, width, dst, src2=None, dst2=None):
@@ -722,26 +691,17 @@ class TrieBiGRUFn(torch.autograd.Function):
         # where the two MFMA-bound products run beside direction 0's (HBM-bound) recurrent steps.  Their buffers come from the
         # main stream's pool (the consumer's), the auxiliary stream only fills them.
         tables = []
-        t_aux = _side_stream(dev) if (TRIE_L1_TABLE_OVERLAP and table.is_cuda and side_ok(dev) and N >= SIDE_MIN_ROWS) else None
         for d in (0, 1):
             wi = compute_weight(weights[8 + d * 4], dtp)
             Gf = torch.empty((sides[0].n_nodes, 3 * hs), dtype=dtp, device=dev)      # [nodes of the prefix trie, 3hs]
             Gb = torch.empty((sides[1].n_nodes, 3 * hs), dtype=dtp, device=dev)      # [nodes of the suffix trie, 3hs]
-            if d == 1 and t_aux is not None:
-                t_aux.wait_stream(main)
-                with torch.cuda.stream(t_aux):
-                    gemm(src[0], wi[:, :hs], trans_b=True, out=Gf)
-                    gemm(src[1], wi[:, hs:], trans_b=True, out=Gb)
-            else:
-                gemm(src[0], wi[:, :hs], trans_b=True, out=Gf)
-                gemm(src[1], wi[:, hs:], trans_b=True, out=Gb)
+            gemm(src[0], wi[:, :hs], trans_b=True, out=Gf)
+            gemm(src[1], wi[:, hs:], trans_b=True, out=Gb)
             tables.append((Gf, Gb))
         for d in (0, 1):
             w_ih, w_hh, b_ih, b_hh = weights[8 + d * 4: 8 + d * 4 + 4]
             wi, wh = compute_weight(w_ih, dtp), compute_weight(w_hh, dtp)
             Gf, Gb = tables[d]
-            if d == 1 and t_aux is not None:
-                main.wait_stream(t_aux)
             gates = torch.empty((N, 4 * hs), dtype=dtp, device=dev)
             hprev = torch.empty((N, hs), dtype=dtp, device=dev)
             h = fin[:, d * hs:(d + 1) * hs]
@@ -824,8 +784,7 @@ class TrieBiGRUFn(torch.autograd.Function):
             for t in (range(L - 1, -1, -1) if d == 0 else range(L)):
                 A, off = bs[t], offs[t]
                 _step_bwd(A, hs, None if prev is None else d4[offs[prev]:], 0 if prev is None else bs[prev], wh_t,
-                          gates[off:off + A], hprev[off:off + A], None, hs, dh, d4[off:off + A], 0.0, 0, 0, bpart,
-                          wh=compute_weight(w_hh, dtp), b_hh=b_hh.detach())
+                          gates[off:off + A], hprev[off:off + A], None, hs, dh, d4[off:off + A], 0.0, 0, 0, bpart)
                 prev = t
             with on_side(d4, hprev, bpart):
                 _acc_weight_grad(grads, base + 1, w_hh, d4[:, :2 * hs], hprev, rows=slice(0, 2 * hs))
@@ -900,7 +859,7 @@ class TrieBiGRUFn(torch.autograd.Function):
                         _seg_ranges(mhi - mlo, rng_, dhx, hs, dhx[n + 1 + mlo:])
                     _step_bwd(A, hs, d4x if has_kids else None, n + 1 + nm, wh_t, gates[lo:hi], H, dy.data_ptr() + lo * hs * dy.element_size(),
                               hs, dhx[lo:hi], d4[lo:hi], p_layer, seed_y, lo * hs, bpart, hprev_idx=side.par[lo:hi], hp_out=hp[lo:hi],
-                              sum_idx=side.sum_idx[lo:hi], dh_src=dhx, zero_row=n, wh=compute_weight(w_hh, dtp), b_hh=b_hh.detach())
+                              sum_idx=side.sum_idx[lo:hi], dh_src=dhx, zero_row=n)
                 held = (d4x, dhx, bpart, hp)
             else:                                      # GTOS_GRU_SUMIDX=0: a summed row per node of every level (round-2 form)
                 d4 = torch.empty((n, 4 * hs), dtype=dtp, device=dev)
@@ -918,8 +877,7 @@ class TrieBiGRUFn(torch.autograd.Function):
                         _seg_ranges(A, rng_, d4, 4 * hs, S)
                         _seg_ranges(A, rng_, dhz, hs, dhz[lo:hi])
                     _step_bwd(A, hs, S if has_kids else None, A, wh_t, gates[lo:hi], H, dy.data_ptr() + lo * hs * dy.element_size(), hs,
-                              dhz[lo:hi], d4[lo:hi], p_layer, seed_y, lo * hs, bpart, hprev_idx=side.par[lo:hi], hp_out=hp[lo:hi],
-                              wh=compute_weight(w_hh, dtp), b_hh=b_hh.detach())
+                              dhz[lo:hi], d4[lo:hi], p_layer, seed_y, lo * hs, bpart, hprev_idx=side.par[lo:hi], hp_out=hp[lo:hi])
                 held = (d4, dhz, S, bpart, hp)
             with (on_side(d4, hp, X, bpart) if use_side else contextlib.nullcontext()):
                 _acc_weight_grad(grads, base + 1, w_hh, d4[:, :2 * hs], hp, rows=slice(0, 2 * hs))

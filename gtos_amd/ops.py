@@ -110,7 +110,7 @@ _SIDE = {}
 PROJ_SIDE = os.environ.get("GTOS_PROJ_SIDE", "1") != "0"
 # ... as long as all the layers' projections together stay small beside the rest of the step (7 GB at C2).  At C5 (R = 1.84 M:
 # 30 GB of projections alive at once on top of a 150 GB step) the prefetch made the step time scatter between 215 and 330 ms.
-PROJ_SIDE_MAX_BYTES = int(os.environ.get("GTOS_PROJ_SIDE_MAX_GB", "16")) << 30
+PROJ_SIDE_MAX_BYTES = 16 << 30
 # GTOS_PROJ_RECOMPUTE=1 (opt-in): the attention core does not keep a layer's projected bank [R, 2d] for its backward but recomputes it
 # there from the bank and the layer's weight (the same GEMM, the same bits).  C5: 3.8 GB per layer, 26 GB of the 93.6 GB peak, for one
 # more [R,d]x[d,2d] product per layer and step.
@@ -316,7 +316,7 @@ BATCH_DX = os.environ.get("GTOS_BATCH_DX", "1") != "0"
 # 2 layers (K = 2048 each, launched from inside backward on the auxiliary stream) were measured at C2: the products leave the
 # critical path but compete with the HBM-bound attention-backward kernels they run beside (4 x 1.45 ms of GEMM instead of 3.1 ms,
 # attention backward +1.2 ms per step): 66.23 vs 66.09 ms per step on the same box -- no gain, so the single rounding stays.
-DX_CHUNK = int(os.environ.get("GTOS_DX_CHUNK", "0"))
+DX_CHUNK = 0
 # ... as long as the slab stays small beside the step's memory (7 GB at C2); above this the layers fall back to one K = 2d product each
 # with a single [R, 2d] output gradient alive at a time (C5: R = 1.88 M, the slab would be 30 GB).
 SLAB_MAX_BYTES = int(os.environ.get("GTOS_SLAB_MAX_GB", "16")) << 30
@@ -326,8 +326,8 @@ SLAB_MAX_BYTES = int(os.environ.get("GTOS_SLAB_MAX_GB", "16")) << 30
 # bank's gradient.  MEASURED (round 4, same box, two alternating pairs, profiles/r4f_*): 61.14 / 61.21 ms per step WITH it against
 # 60.67 / 60.55 without -- the main stream does start the RelationEncoder's backward ~3 ms earlier, but the 3.65 TFLOP product then
 # competes with the HBM-bound GRU kernels it was meant to hide behind (its 128 KB-LDS workgroups wait for whole CUs) and the step gets
-# 0.55 ms LONGER: the step is work-conserving, not latency-bound, at this point.  Off by default; GTOS_BATCH_DW=1 enables it.
-BATCH_DW = os.environ.get("GTOS_BATCH_DW", "0") == "1"
+# 0.55 ms LONGER: the step is work-conserving, not latency-bound, at this point.  Off (a module constant since round 6; the parity test of the batched weight gradient sets it).
+BATCH_DW = False
 
 
 class GradAccumGroup:
@@ -609,8 +609,8 @@ def layer_norm_residual(x, r, gamma, beta, p_drop=0.0, eps=1e-5):
 # bf16 activations on an fp32 residual stream (round 4).  The reference's post-LN layers keep x = LayerNorm(x + sublayer(x)) in fp32;
 # storing that stream in bf16 costs one rounding of an |x| <= 4 value per layer (1.6e-2 absolute) that the next layer's residual add
 # carries on -- the measured bf16 output error of the graph encoder (8e-3 .. 1.3e-2 relative) came from there, not from the bf16
-# MFMA operands.  The stream is [rows, d]: 6.6 MB per layer at C2 next to a 0.9 GB relation stream.  GTOS_FP32_STREAM=0: bf16 stream.
-FP32_STREAM = os.environ.get("GTOS_FP32_STREAM", "1") != "0"
+# MFMA operands.  The stream is [rows, d]: 6.6 MB per layer at C2 next to a 0.9 GB relation stream.  (False = the bf16 stream of rounds 1-3: graph-encoder output error 8e-3..1.3e-2 instead of 1.1e-3..1.8e-3 at the same step time.)
+FP32_STREAM = True
 
 
 def split_stream(x, cd):

@@ -72,10 +72,7 @@ class HipBackend(object):
 
 
 def build_relation_index_staged(relation, R, backend, chunk=CHUNK):
-    """relation: int64 [n,n,B] type ids in [0,R) on the backend's device.  ValueError outside the covered case (ids out of range; the
-    GTOS_BANK_BALANCE=0 / GTOS_HEAVY_FIRST=1 orders of the host builder)."""
-    if os.environ.get("GTOS_BANK_BALANCE", "1")[:1] == "0" or os.environ.get("GTOS_HEAVY_FIRST", "0")[:1] == "1":
-        raise ValueError("the staged index builder implements the default chunk order only")
+    """relation: int64 [n,n,B] type ids in [0,R) on the backend's device.  ValueError outside the covered case (ids out of range)."""
     relation = relation.to(torch.int64).contiguous()
     n, n2, B = relation.shape
     assert n == n2
@@ -84,7 +81,7 @@ def build_relation_index_staged(relation, R, backend, chunk=CHUNK):
     if P > 0x7fffffff or R > 0x7fffffff or R < 1 or n >= 1 << 20:
         raise ValueError("relation tensor outside the builder's range")
     dev = relation.device
-    mult = int(os.environ.get("GTOS_HEAVY_CHUNK_MULT", "4"))
+    mult = 4                                        # heavy types: chunks of 4 * chunk pairs (csrc_host/relindex.cpp)
     geom = dict(n=n, B=B, chunk=chunk, mult=mult, R=R, P=P)
     i32, i64 = torch.int32, torch.int64
     NC = R + P // chunk + 1

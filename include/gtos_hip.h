@@ -195,14 +195,11 @@ int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, int in_dim, 
                       const void* xg, const void* gf, const int* gf_idx, const void* gb, const int* gb_idx,
                       const void* h_in, const int* h_idx, const void* w_hh, const float* b_hh,
                       void* h_out, int n_out, void* h_fin, int64_t ld_fin, const int* fin_idx, void* gates, void* y, int64_t ldy,
-                      float p_drop, uint64_t seed, int64_t drop_base, int save_hn, void* stream);
-/* save_hn = 0 (round 4): the hn block of `gates` (columns 3hs..4hs) is left unwritten; gtos_gru_step_bwd then gets w_hn / b_hn = rows
- * [2hs, 3hs) of W_hh ([hs, hs], K-contiguous) and of b_hh and recomputes hn = h_prev W_hn^T + b_hn on the MFMA, rounded like the forward's.
- * Only bit 0..7 of save_hn are the flag; bits 8 and up are ZERO for every product call (tools/bench_gru_step.py passes the step kernels'
- * measuring switches there: bits 8-15 the switch, 16-19 the kernel form, 20+ a delay in us -- results are garbage under a switch).
- * Which k loop runs for x != NULL (all give the same bits): gru_step_fwd_a2w3_kernel (64-k stages, three slots of activation rows + two of
- * weight rows, 256-row panels; rows >= 8192 and (in_dim + hs) / 64 a multiple of 6), else gru_step_fwd_dbuf_kernel (two slots of whole stages;
- * in_dim % 64 == 0), else gru_step_fwd_ring_kernel (in_dim % 32 == 0), else gru_step_fwd_kernel<1>; GTOS_GRU_FWD_A2W3 / _DBUF / _RING / _NW. */
+                      float p_drop, uint64_t seed, int64_t drop_base, void* stream);
+/* Which kernel runs for x != NULL (both give the same bits): gru_step_fwd_a2w3_kernel (64-k stages, three slots of activation rows + two of
+ * weight rows in flight, 256-row panels on eight waves) for launches of >= 8192 rows with in_dim % 64 == 0 and (in_dim + hs) / 64 a multiple of 6
+ * -- both layers of every BASELINE config --, else the single-stage gru_step_fwd_kernel<1>; GTOS_GRU_FWD_A2W3=0: always the latter.
+ * Round 6 removed the other forms of round 5 (three-slot ring of 32-k stages, two whole-stage slots, the hn-recompute flag `save_hn`). */
 
 /* Fused backward GRU step, bf16 only, hs % 64 == 0 (gru_step.hip).  d4 [rows,4hs] = d r | d z | d n_x | d n_h in ONE
  * buffer (d(xg) = columns 0..3hs, d(hg) = columns 0..2hs and 3hs..4hs).  First adds d(hg) W_hh of the step processed
@@ -220,7 +217,7 @@ int gtos_gru_step_fwd(int rows, int hs, const void* x, int64_t ldx, int in_dim, 
 int gtos_gru_step_bwd(int rows, int hs, const void* d4_prev, int rows_prev, const void* w_hh_t,
                       const void* gates, const void* hprev, const int* hprev_idx, const void* dy, int64_t ldy, void* dh, int dh_dtype,
                       int64_t ld_dh, void* d4, float p_drop, uint64_t seed, int64_t drop_base, float* bias_partials, int n_partials,
-                      void* hprev_out, const int* sum_idx, const void* dh_src, int zero_row, const void* w_hn, const float* b_hn, void* stream);
+                      void* hprev_out, const int* sum_idx, const void* dh_src, int zero_row, void* stream);
 
 /* gtos_gru_step_bwd with a second role in the same launch (round 5; gtos_gru_step_bwd forwards here with w_ih_t = dinp = NULL).  With dinp,
  * additional workgroups turn the d4 rows of the step processed just before into THAT step's input gradient,
@@ -234,7 +231,7 @@ int gtos_gru_step_bwd(int rows, int hs, const void* d4_prev, int rows_prev, cons
 int gtos_gru_step_bwd_fused(int rows, int hs, const void* d4_prev, int rows_prev, const void* w_hh_t,
                             const void* gates, const void* hprev, const int* hprev_idx, const void* dy, int64_t ldy, void* dh, int dh_dtype,
                             int64_t ld_dh, void* d4, float p_drop, uint64_t seed, int64_t drop_base, float* bias_partials, int n_partials,
-                            void* hprev_out, const int* sum_idx, const void* dh_src, int zero_row, const void* w_hn, const float* b_hn,
+                            void* hprev_out, const int* sum_idx, const void* dh_src, int zero_row,
                             const void* w_ih_t, void* dinp, int64_t ld_dinp, int n_in, int dinp_accumulate, float p_in, uint64_t seed_in,
                             int64_t in_drop_base, void* stream);
 

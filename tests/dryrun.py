@@ -188,10 +188,8 @@ class Recorder(object):
             (rows, hs, d4_prev, rows_prev, w_hh_t, gates, hprev, hprev_idx, dy, ldy, dh, dh_dtype, ld_dh, d4, p_drop, seed, drop_base,
              bias_partials, n_partials, hprev_out, sum_idx, dh_src, zero_row) = a[:23]
             W = name + ": "
-            self._rows(W + "w_hn", a[23], hs, hs, hs, 2)
-            self._rows(W + "b_hn", a[24], 1, hs, hs, 4)
             if name == "gtos_gru_step_bwd_fused":
-                w_ih_t, dinp, ld_dinp, n_in, acc, p_in, seed_in, in_drop_base = a[25:33]
+                w_ih_t, dinp, ld_dinp, n_in, acc, p_in, seed_in, in_drop_base = a[23:31]
                 if dinp is not None:
                     assert d4_prev is not None and sum_idx is None and n_in % 64 == 0 and rows_prev > 0, W + "role B arguments"
                     self._rows(W + "w_ih_t", w_ih_t, n_in, 3 * hs, 3 * hs, 2)

@@ -1447,9 +1447,7 @@ def test_gru_layer1_step_kernel_vs_torch(rows):
     n = torch.tanh(xg[:, 2 * hs:] + r * hn)
     o = (1 - z) * n + z * h.float()
     want = torch.cat([r, z, n, hn], 1)
-    from gtos_amd import gru as _g
-    keep = 4 * hs if not _g.RECOMPUTE_HN else 3 * hs       # (GTOS_GRU_RECOMPUTE_HN=1: the forward leaves the hn block unwritten)
-    torch.testing.assert_close(gates.float()[:, :keep], want[:, :keep], rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(gates.float(), want, rtol=2e-2, atol=2e-2)
     got_h = torch.cat([h_out[:n_out], h_fin[n_out:]]).float()
     torch.testing.assert_close(got_h, o, rtol=2e-2, atol=2e-2)
     assert float(h_fin[:n_out].float().abs().max()) == 0.0 and float(h_out[n_out:].float().abs().max()) == 0.0
@@ -2070,27 +2068,23 @@ torch.save(out.cpu(), sys.argv[1])
 
 
 @pytest.mark.parametrize("ind", [128, 512])
-def test_gru_forward_ring_kernel_bit_identical_to_single_stage(ind, tmp_path):
-    """The fused forward step's k loops -- gru_step_fwd_a2w3_kernel (the default: three slots of activation rows + two of weight rows per 64-k
-    stage, and its two + three form), gru_step_fwd_dbuf_kernel (two slots of whole stages, whole 128-byte lines per DMA row,
-    the next stage in flight; 256-row panels on eight waves for launches of at least 8192 rows, and the four-wave form), gru_step_fwd_ring_kernel
-    (three-slot ring of 32-k stages; eight and four waves) -- against gru_step_fwd_kernel<1> (one 64-k stage): same lane -> channel map, same
-    k order, same cell -> the SAME bits, through two GRU layers with inter-layer dropout, ragged lengths (steps of 20,011 .. ~4,000 rows: both
-    panel sizes run), a partial last row panel.  The switches are read once per process: seven child processes."""
+def test_gru_forward_pipelined_kernel_bit_identical_to_single_stage(ind, tmp_path):
+    """The fused forward step's pipelined k loop -- gru_step_fwd_a2w3_kernel: three slots of activation rows + two of weight rows per 64-k
+    stage, 256-row panels on eight waves; launches of at least 8192 rows -- against gru_step_fwd_kernel<1> (one 64-k stage, 128-row panels):
+    same lane -> channel map, same k order, same cell -> the SAME bits, through two GRU layers with inter-layer dropout, ragged lengths
+    (steps of 20,011 .. ~4,000 rows: both kernels run in the default process), a partial last row panel.  The switch is read once per
+    process: two child processes.  (Round 5 compared seven forms this way; round 6 removed all but these two.)"""
     import subprocess
     import sys
     outs = []
-    for a2w3, dbuf, ring, nw in (("2", "1", "1", "8"), ("1", "1", "1", "8"), ("0", "1", "1", "8"), ("0", "4", "1", "8"), ("0", "0", "1", "8"),
-                                 ("0", "0", "1", "4"), ("0", "0", "0", "4")):
-        f = str(tmp_path / ("a%s_dbuf%s_ring%s_%s.pt" % (a2w3, dbuf, ring, nw)))
-        env = dict(os.environ, GTOS_GRU_FWD_A2W3=a2w3, GTOS_GRU_FWD_DBUF=dbuf, GTOS_GRU_FWD_RING=ring, GTOS_GRU_FWD_NW=nw,
-                   PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    for a2w3 in ("1", "0"):
+        f = str(tmp_path / ("a%s.pt" % a2w3))
+        env = dict(os.environ, GTOS_GRU_FWD_A2W3=a2w3, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         r = subprocess.run([sys.executable, "-c", _RING_CHILD, f, str(ind)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
         assert r.returncode == 0, r.stdout.decode(errors="replace")[-3000:]
         outs.append(torch.load(f))
     assert torch.isfinite(outs[0].float()).all() and float(outs[0].float().abs().max()) > 0.05
-    for o in outs[1:]:
-        assert torch.equal(outs[0], o)
+    assert torch.equal(outs[0], outs[1])
 
 
 def test_packed_path_gru_backward_d4_in_place_is_the_same_function(monkeypatch):
@@ -2123,42 +2117,10 @@ def test_packed_path_gru_backward_d4_in_place_is_the_same_function(monkeypatch):
     assert float(max(v.abs().max() for v in res[0][1].values())) > 0
 
 
-def test_packed_path_gru_two_stream_forward_is_the_same_function(monkeypatch):
-    """GTOS_GRU_FWD_OVERLAP=1 (opt-in, measured: no gain): the packed path's forward with direction 1 on the auxiliary stream beside
-    direction 0 -- every buffer allocated on the main stream, the auxiliary stream joined before the next layer -- gives bit-identical
-    outputs and gradients (same kernels, same operands, another interleaving)."""
-    from gtos_amd import encoder, gru, ops
-    g = torch.Generator().manual_seed(9)
-    length = torch.randint(1, 9, (3000,), generator=g)
-    bank = torch.randint(1, 90, (8, 3000), generator=g)
-    for r in range(3000):
-        bank[int(length[r]):, r] = 0
-    ref, m = _relenc_pair(bank, length, hid=64)
-    m.compute_dtype = torch.bfloat16
-    m.dropout = 0.25
-    m.train()
-    wout = torch.randn(bank.shape[1], 64, generator=torch.Generator().manual_seed(1)).to(dev())
-    monkeypatch.setattr(gru, "SIDE_MIN_ROWS", 0)            # (small bank: let the stream logic engage)
-    res = []
-    for overlap in (False, True):
-        monkeypatch.setattr(gru, "FWD_OVERLAP", overlap)
-        ops.set_seed(77)
-        m.zero_grad()
-        out = m(bank.to(dev()), length.to(dev()))
-        (out.float() * wout).sum().backward()
-        ops.join_side()
-        torch.cuda.synchronize()
-        res.append((out.detach().clone(), _grads_of(m)))
-    assert torch.equal(res[0][0], res[1][0])
-    for k in res[0][1]:
-        torch.testing.assert_close(res[0][1][k], res[1][1][k], rtol=1e-5, atol=1e-6, msg=lambda s_, k=k: "%s: %s" % (k, s_))
-
-
-def test_packed_path_gru_ignores_the_hn_recompute_switch_and_handles_its_edge_cases(monkeypatch):
-    """ADVICE round 5.  (i) GTOS_GRU_RECOMPUTE_HN=1 belongs to the per-row / trie evaluations, whose backward hands the step kernel
-    w_hn / b_hn; the packed path's backward launches READ the saved hn block, so its forward stores it whatever the switch says: same
-    bits in the outputs and in every gradient with the switch on.  (ii) A second backward raises a clear error (the saved gates are
-    released during the first).  (iii) A bank without an active step (every path empty) gives zero vectors and no gradient."""
+def test_packed_path_gru_edge_cases():
+    """ADVICE round 5.  (i) A second backward raises a clear error (the saved gates are released during the first).  (ii) A bank without an
+    active step (every path empty) gives zero vectors and no gradient.  (The third finding -- GTOS_GRU_RECOMPUTE_HN left the packed path's
+    hn block unwritten -- is gone with the switch: round 6 removed it and its kernel instantiation.)"""
     from gtos_amd import gru, ops
     bank, length = _relenc_case(R=900, L=7, V=86)
     ref, m = _relenc_pair(bank, length, hid=64)
@@ -2166,25 +2128,16 @@ def test_packed_path_gru_ignores_the_hn_recompute_switch_and_handles_its_edge_ca
     m.dropout = 0.25
     m.train()
     wout = torch.randn(bank.shape[1], 64, generator=torch.Generator().manual_seed(1)).to(dev())
-    res = []
-    for flag in (False, True):
-        monkeypatch.setattr(gru, "RECOMPUTE_HN", flag)
-        ops.set_seed(31)
-        m.zero_grad()
-        out = m(bank.to(dev()), length.to(dev()))
-        loss = (out.float() * wout).sum()
-        loss.backward()
-        ops.join_side()
-        torch.cuda.synchronize()
-        res.append((out.detach().clone(), _grads_of(m)))
-    assert torch.equal(res[0][0], res[1][0])
-    for k in res[0][1]:
-        assert torch.isfinite(res[1][1][k]).all(), k
-        torch.testing.assert_close(res[0][1][k], res[1][1][k], rtol=1e-5, atol=1e-6, msg=lambda s_, k=k: "%s: %s" % (k, s_))
-    monkeypatch.setattr(gru, "RECOMPUTE_HN", False)
+    ops.set_seed(31)
+    out = m(bank.to(dev()), length.to(dev()))
+    loss = (out.float() * wout).sum()
+    loss.backward()
+    ops.join_side()
+    torch.cuda.synchronize()
+    for k, g in _grads_of(m).items():
+        assert torch.isfinite(g).all(), k
     with pytest.raises(RuntimeError, match="second time"):
         loss.backward()
-    # (iii) straight at the function: a plan with no step
     plan = gru.PackPlan([], torch.zeros(5, dtype=torch.int32, device=dev()))
     assert plan.L == 0
     table = torch.randn(86, 20, device=dev(), requires_grad=True)

@@ -56,9 +56,6 @@ def test_staged_relation_index_on_amr_batches_and_limits(monkeypatch):
         assert _same_object(host, build_relation_index_staged(batch["relation"], R, EmulBackend())) == []
     with pytest.raises(ValueError):
         build_relation_index_staged(torch.full((2, 2, 2), 7), 5, EmulBackend())
-    monkeypatch.setenv("GTOS_BANK_BALANCE", "0")
-    with pytest.raises(ValueError):
-        build_relation_index_staged(torch.zeros((2, 2, 2), dtype=torch.int64), 5, EmulBackend())
 
 
 def test_staged_builders_equal_the_host_builders_property_based():
