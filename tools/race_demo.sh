@@ -9,7 +9,9 @@ export PYTHONPATH=$PWD
 C=gtos_amd/csrc
 cp $C/libgtos_hip.so /tmp/libgtos_hip.good.so
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffast-math -fno-finite-math-only -DGTOS_RACE_DEMO -c $C/gru_step.hip -o /tmp/gru_step_race.o || exit 1
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls $C/*.o | grep -v gru_step.o) /tmp/gru_step_race.o -o $C/libgtos_hip.so || exit 1
+OBJS=$(python -c "from gtos_amd import build; print(' '.join('$C/' + s.replace('.hip', '.o') for s in build.SOURCES if s != 'gru_step.hip'))")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS /tmp/gru_step_race.o -o /tmp/libgtos_hip.race.so || exit 1
+cp /tmp/libgtos_hip.race.so $C/libgtos_hip.so
 echo "== soak with the pre-fix waits (expected: FAILURES) =="
 GTOS_SOAK_REPS=${GTOS_SOAK_REPS:-60} timeout 600 python -m pytest tests/test_zz_race_soak.py -q --tb=line -p no:cacheprovider -k "gru_step" 2>&1 | tail -25
 cp /tmp/libgtos_hip.good.so $C/libgtos_hip.so
