@@ -340,9 +340,9 @@ def build_roofline(a, cfg, stats, model, trainer, batch, prof, dev, cd, detail=T
         # the reference's dropout semantics (library default): one GRU row per (path, position) in both layers (gtos_amd.gru.PackedPathGRUFn);
         # these spans carry their launches' algorithmic bytes as units (gtos_amd/gru.py: _step_fwd / _step_bwd_fused)
         dp_ = (-100) % 64 + 100
-        hbm_row("gru_step_fwd_packed_l0", "gru_step_fwd_a2w3_kernel (launches under 8192 rows: gru_step_fwd_ring_kernel), GRU layer 0 (input product fused: label rows x W_ih inside)", bytes_per_unit=1,
+        hbm_row("gru_step_fwd_packed_l0", "gru_step_fwd_a2w3_kernel (launches under 8192 rows: the single-stage gru_step_fwd_kernel<1>), GRU layer 0 (input product fused: label rows x W_ih inside)", bytes_per_unit=1,
                 note="per active row: label-embedding row %d*2 B + entering state h read; gates 4h + new state h + dropped copy h written (h = %d bf16)" % (dp_, hs))
-        hbm_row("gru_step_fwd_packed_l1", "gru_step_fwd_a2w3_kernel (launches under 8192 rows: gru_step_fwd_ring_kernel), GRU layer 1 (input product fused: layer-0 output rows x W_ih inside)", bytes_per_unit=1,
+        hbm_row("gru_step_fwd_packed_l1", "gru_step_fwd_a2w3_kernel (launches under 8192 rows: the single-stage gru_step_fwd_kernel<1>), GRU layer 1 (input product fused: layer-0 output rows x W_ih inside)", bytes_per_unit=1,
                 note="per active row: layer-0 output row 2h + entering state h read; gates 4h + new state h written")
         hbm_row("gru_step_bwd_packed_l1", "gru_step_bwd_kernel, GRU layer 1: cell tiles + the previous step's input-gradient tiles in one launch",
                 bytes_per_unit=1,

@@ -88,6 +88,25 @@ def _splitk(M, N, K):
     return max(1, sk)
 
 
+# A split-K weight gradient launched on the AUXILIARY stream beside the main chain: its workgroups are long-running (one 256x256 tile over
+# K / splits rows: ~360 us for the relation projection's dW at C2), take a whole CU each (128 KB of LDS, 2 x 232 registers per SIMD) and
+# cannot be preempted, so with 8 tiles x 32 splits = 256 of them the main stream's next launches -- a handful of small kernels between two
+# attention backward passes -- wait for the whole product: 0.33 ms per graph-encoder layer at C2 (profiles/r6z_step_phases.txt: the 6,464-row
+# in-projection dW on the main stream takes 351 us beside it, 25 us alone).  Capping the product at SIDE_GEMM_MAX_WGS workgroups leaves CUs
+# to the main stream; the product gets longer by the same factor and still ends before the next layer's.  (0 = no cap.)
+SIDE_GEMM_MAX_WGS = int(os.environ.get("GTOS_SIDE_GEMM_WGS", "192"))
+
+
+def _splitk_side(M, N, K):
+    """_splitk for a product that runs on the auxiliary stream beside latency-critical main-stream work (see SIDE_GEMM_MAX_WGS)."""
+    sk = _splitk(M, N, K)
+    if SIDE_GEMM_MAX_WGS > 0 and sk >= 16:
+        tiles = ((M + 255) // 256) * ((N + 255) // 256)
+        while sk > 8 and tiles * sk > SIDE_GEMM_MAX_WGS:
+            sk -= 8
+    return sk
+
+
 _WS = {}
 WORKSPACE_BYTES = 256 << 20
 
@@ -505,7 +524,7 @@ class LinearFn(torch.autograd.Function):
                     tgt = _grad_target(weight)
                     if rows is not None:
                         tgt = tgt[rows[0]:rows[1]]
-                    gemm(dy2, x2, trans_a=True, out=tgt, accumulate=True, splitk=_splitk(n_out, x2.shape[1], dy2.shape[0]))
+                    gemm(dy2, x2, trans_a=True, out=tgt, accumulate=True, splitk=_splitk_side(n_out, x2.shape[1], dy2.shape[0]))
             if dx is not None:
                 main.wait_stream(side)           # the main chain continues behind the input gradient ...
                 dx.record_stream(main)

@@ -34,7 +34,7 @@ DB=$(find $O/prof -name "*.db" | head -1)
 python tools/rocpd_stats.py $DB $O/kernel_stats.csv > /dev/null
 python tools/rocpd_stats.py $DB $O/kernel_stats_by_grid.csv --by-grid > /dev/null
 python tools/rocpd_sequence.py $DB --step 3 > $O/step_sequence.txt; head -1 $O/step_sequence.txt
-python tools/step_phases.py $DB > $O/step_phases.txt 2>&1 || python tools/rocpd_timeline.py $DB > $O/timeline.txt 2>&1 || true
+python tools/step_phases.py $O/step_sequence.txt > $O/step_phases.txt 2>&1; python tools/rocpd_timeline.py $DB > $O/timeline.txt 2>&1 || true
 rm -rf $O/prof
 head -16 $O/kernel_stats.csv | cut -c1-150
 # counters: the attention kernels per operand mode, then the default step by kernel
