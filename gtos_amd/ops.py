@@ -97,6 +97,11 @@ def _splitk(M, N, K):
 SIDE_GEMM_MAX_WGS = int(os.environ.get("GTOS_SIDE_GEMM_WGS", "192"))
 
 
+# (WHEN it runs was tried too: deferred to the start of the NEXT layer's attention backward, so that it runs beside those three HBM-bound
+# kernels instead of the layer's small ones: 79.1-79.8 ms per step against 77.1-77.5 launched in place, caps of 96-192 -- the long MFMA
+# workgroups cost the attention kernels more CUs than the small kernels lose; profiles/r6_ab_switches.txt.)
+
+
 def _splitk_side(M, N, K):
     """_splitk for a product that runs on the auxiliary stream beside latency-critical main-stream work (see SIDE_GEMM_MAX_WGS)."""
     sk = _splitk(M, N, K)
