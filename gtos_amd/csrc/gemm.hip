@@ -1231,6 +1231,8 @@ extern "C" int gtos_gru_weight_grads(int rows, int hs, int in_dim, int in_valid,
     const int ktiles = (rows + 63) / 64;
     const long long tile_bytes = (long long)BM2 * BN2 * 4;
     long long sk = 8LL * (32 / nt > 0 ? 32 / nt : 1);
+    // (a cap on this product's workgroups -- 96 .. 192 instead of its 216-240 -- was measured in round 6: no gain, 77.8-79.1 vs 77.6-77.9 ms per
+    //  step; beside the step kernels of the other stream the two are work-conserving.  profiles/r6_ab_switches.txt)
     if (sk > ktiles / 4) sk = ktiles / 4;
     if (sk * nt * tile_bytes > workspace_bytes) sk = workspace_bytes / (nt * tile_bytes);
     if (sk < 1) { if (nt * tile_bytes > workspace_bytes) return -4; sk = 1; }
