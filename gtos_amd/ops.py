@@ -201,7 +201,7 @@ def side_stream(device):
     """One auxiliary HIP stream per device for work that is independent of the main chain (see gru.py, FactoredRelation)."""
     s = _SIDE.get(device)
     if s is None:
-        s = _SIDE[device] = torch.cuda.Stream(device=device)
+        s = _SIDE[device] = torch.cuda.Stream(device=device)       # (a high-priority auxiliary stream measured no different: profiles/r6_ab_switches.txt)
     return s
 
 
