@@ -737,7 +737,7 @@ constexpr int ROW3 = 64, A3 = BM2 * ROW3, ST3 = (BM2 + BN2) * ROW3;
 constexpr int g_min_k256 = 2048;                     // (rounds 3-5 swept these thresholds with environment switches: profiles/r3..r5_ab_switches.txt)
 const bool g_use_pipe = !(getenv("GTOS_GEMM_PIPE") && getenv("GTOS_GEMM_PIPE")[0] == '0');
 const bool g_use_pipe_tn = !(getenv("GTOS_GEMM_PIPE_TN") && getenv("GTOS_GEMM_PIPE_TN")[0] == '0');
-constexpr int g_max_npipe = 2048;
+constexpr int g_max_npipe = 2048;                    // gemm256p_nt_kernel only (64-byte rows); the 8-phase kernel takes any N >= 256
 constexpr int g_min_kpipe = 1024;
 // (Small products -- a few thousand rows: the graph layers' and the decoder's projections -- on this kernel: 17-25 us against 10-19 us on the
 // single-stage 128x128 kernel, step +1.1 ms; measured in round 3, never enabled.)
@@ -899,11 +899,208 @@ __global__ __launch_bounds__(512) void gemm256p_nt_kernel(GemmArgs a) {
 //  findings: a 1 KB LDS-DMA piece costs its wave ~60 issue cycles whether it hits or not, whole 128-byte rows per stage matter).  They
 //  are not part of the library any more; the last commit that carries them is 4bd4edb.)
 
+// ---- gemm256q_nt_kernel (round 6): the same 256x256 tile / 8 waves (2 x 4, 128 x 64 each) on 64-k tiles cut into HALF-TILES, eight
+//      phases per two k tiles.  Against gemm256p_nt_kernel: (1) a DMA piece is 8 rows x 128 bytes -- whole cache lines -- where the 32-k
+//      stages fetch 16 rows x 64 bytes (half lines: twice the line requests on the CU's vector-memory path for the same bytes; what the
+//      forward GRU step gained by moving to 64-k stages, and what profiles/r6p_gru_bwd_regfed.txt lost by fetching half lines); (2) a
+//      compute segment is 16 MFMAs on one 64 x 32 quadrant of the wave tile, its fragment reads 4..12 ds_read_b128 (quadrant order
+//      (0,0) (0,1) (1,1) (1,0): one operand's fragments stay in registers from phase to phase), so the partner wave of a SIMD loads in
+//      shorter, more even segments.
+//      Measured (round 6, call r6q, same box, old -> new; hipBLASLt beside): [434624,4096]x[1024,4096]^T 1061 -> 1158 TF/s (1168);
+//      [434624,8192]x[512,8192]^T 1130 -> 1265-1290 (1335); 8192^3 1100 (two-stage kernel) -> 1265-1335 (1285-1325); K = 1024 820 -> 850-875
+//      (880-940); at K = 512 713 against 727-760 for the 128x128 kernel (four workgroups per CU overlap their output writes): the
+//      threshold stays at K >= 1024.  s_setprio around the MFMAs and a lookahead of five half-tiles measured the same and are not kept.
+//      * Half-tiles: A-half h = rows {0..63, 128..191} + 64 h of the tile (the rows quadrant row h of BOTH wave rows needs), B-half h =
+//        columns {0..31, 64..95, 128..159, 192..223} + 32 h; 128 rows x 128 bytes = 16 KB each, 8 separate LDS objects [k tile parity][A0 B0
+//        B1 A1] (hipcc tracks LDS-DMA per object).  Load order per k tile A0 B0 B1 A1 = the order the phases first read them.
+//      * One half-tile (2 pieces per wave) is issued per phase, four half-tiles ahead (H(g + 4) in phase g): a buffer is refilled at
+//        least two phases after its last read.  Before a phase's first barrier a wave waits vmcnt(4): everything up to H(g + 2) -- what
+//        phase g + 1 reads -- has landed; the barrier makes that true for every wave ONE PHASE BEFORE the read.
+//      * Waves 4-7 run one barrier behind waves 0-3 (the two waves of a SIMD alternate between loading and multiplying).
+//      * LDS rows are 128 bytes; chunk c of row r sits at c ^ ((r >> 1) & 7) (conflict-free ds_read_b128, see swz; the (r >> 4) term of
+//        swz is not needed without transposed writes): a per-lane constant, so fragment addresses are two lane offsets (ks = 0, 1) plus
+//        immediates and the DMA sources a per-lane offset per piece.
+//      * K % 64 == 0.  Rows / columns past the end re-read the last valid one; half-tiles past the end of K re-read the last k tile (never
+//        multiplied): the number of DMAs in flight is the same in every phase.
+constexpr int HB = 128 * ROWB;                             // half-tile: 128 rows x 128 bytes
+constexpr int HB_EPI = 4 * 32 * (64 * 2 + 16);             // the two buffers the epilogue stages its rows in
+const bool g_use_q = !(getenv("GTOS_GEMM_8PHASE") && getenv("GTOS_GEMM_8PHASE")[0] == '0');     // 0: K % 64 == 0 products stay on gemm256p_nt_kernel
+
+__global__ __launch_bounds__(512) void gemm256q_nt_kernel(GemmArgs a) {
+    if (a.p_drop > 0.f) a.seed = live_seed(a.seed);
+    __shared__ __attribute__((aligned(16))) char a00[HB_EPI];
+    __shared__ __attribute__((aligned(16))) char a01[HB];
+    __shared__ __attribute__((aligned(16))) char b00[HB_EPI];
+    __shared__ __attribute__((aligned(16))) char b01[HB];
+    __shared__ __attribute__((aligned(16))) char a10[HB];
+    __shared__ __attribute__((aligned(16))) char a11[HB];
+    __shared__ __attribute__((aligned(16))) char b10[HB];
+    __shared__ __attribute__((aligned(16))) char b11[HB];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int wm = wr * 128, wn = wc * 64;
+    const int nN = (a.N + BN2 - 1) / BN2;
+    const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
+    const int m0 = ((sq / nN) * 8 + xcd) * BM2, n0 = (sq % nN) * BN2;
+    if (m0 >= a.M) return;
+    const char* Ab = reinterpret_cast<const char*>(static_cast<const bf16_t*>(a.A) + (int64_t)m0 * a.lda);
+    const char* Bb = reinterpret_cast<const char*>(static_cast<const bf16_t*>(a.B) + (int64_t)n0 * a.ldb);
+    const int amax = a.M - 1 - m0, bmax = a.N - 1 - n0;
+    const uint32_t lda2 = (uint32_t)a.lda * 2u, ldb2 = (uint32_t)a.ldb * 2u;
+    const int nk = a.K / 64;
+    // DMA: piece p (= wave, wave + 8) of a half-tile = buffer rows p*8 .. p*8+7; lane l -> row p*8 + (l >> 3), physical chunk l & 7
+    uint32_t aoff[2][2], boff[2][2];                       // [half][piece]
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int rb = (wave + 8 * j) * 8 + (lane >> 3);                                   // buffer row
+        const uint32_t ch = (uint32_t)(((lane & 7) ^ ((rb >> 1) & 7)) << 4);              // source chunk of this LDS position
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            aoff[h][j] = (uint32_t)min((rb >> 6) * 128 + h * 64 + (rb & 63), amax) * lda2 + ch;
+            boff[h][j] = (uint32_t)min((rb >> 5) * 64 + h * 32 + (rb & 31), bmax) * ldb2 + ch;
+        }
+    }
+    // fragment reads: buffer row (.. + fr), logical chunk ks*4 + fq
+    const int fo0 = fr * ROWB + ((fq ^ ((fr >> 1) & 7)) << 4), fo1 = fr * ROWB + (((4 + fq) ^ ((fr >> 1) & 7)) << 4);
+    const int fa_base = wr * 64 * ROWB, fb_base = wc * 32 * ROWB;
+
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    bf16x8_t fa[4][2], fb[2][2];
+
+#define GTOS_QDMA(src, dst)                                                                                                   \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),                                    \
+                                     (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+// half-tile j (0 A0, 1 B0, 2 B1, 3 A1) of k tile kt_ into buf
+#define GTOS_QISSUE(buf, isA, h, kt_)                                                                                         \
+    {                                                                                                                         \
+        const int kb_ = min((kt_), nk - 1) * 128;                                                                             \
+        GTOS_QDMA(((isA) ? Ab : Bb) + kb_ + ((isA) ? aoff[h][0] : boff[h][0]), (buf) + wave * 1024);                          \
+        GTOS_QDMA(((isA) ? Ab : Bb) + kb_ + ((isA) ? aoff[h][1] : boff[h][1]), (buf) + (8 + wave) * 1024);                    \
+    }
+#define GTOS_QREAD_A(buf)                                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                           \
+        fa[i][0] = *reinterpret_cast<const bf16x8_t*>((buf) + fa_base + i * 16 * ROWB + fo0);                                 \
+        fa[i][1] = *reinterpret_cast<const bf16x8_t*>((buf) + fa_base + i * 16 * ROWB + fo1);                                 \
+    }
+#define GTOS_QREAD_B(buf)                                                                                                     \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                           \
+        fb[j][0] = *reinterpret_cast<const bf16x8_t*>((buf) + fb_base + j * 16 * ROWB + fo0);                                 \
+        fb[j][1] = *reinterpret_cast<const bf16x8_t*>((buf) + fb_base + j * 16 * ROWB + fo1);                                 \
+    }
+// one phase: READS (this phase's new fragments), the DMA of the half-tile four ahead, the counted wait, barrier, 16 MFMAs on
+// quadrant (mh, nh), barrier
+#define GTOS_QPHASE(READS, ISSUE, mh, nh)                                                                                     \
+    {                                                                                                                         \
+        READS;                                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                                    \
+        ISSUE;                                                                                                                \
+        GTOS_VMCNT(4);                                     /* this wave's pieces of everything the NEXT phase reads */        \
+        __builtin_amdgcn_s_barrier();                                                                                         \
+        __builtin_amdgcn_s_waitcnt(0xc07f);                /* lgkmcnt(0): this phase's fragments */                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                                    \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                      \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                     \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                 \
+                    acc[(mh) * 4 + i][(nh) * 2 + j] =                                                                         \
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][ks], fa[i][ks], acc[(mh) * 4 + i][(nh) * 2 + j], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                                                    \
+        __builtin_amdgcn_s_barrier();                                                                                         \
+    }
+// the four phases of k tile kt_ held in buffers (A0_, B0_, B1_, A1_); the half-tiles of k tile kt_ + 1 go into (nA0, nB0, nB1, nA1)
+#define GTOS_QTILE(A0_, B0_, B1_, A1_, nA0, nB0, nB1, nA1, kt_)                                                               \
+    GTOS_QPHASE({ GTOS_QREAD_B(B0_); __builtin_amdgcn_sched_barrier(0); GTOS_QREAD_A(A0_); }, GTOS_QISSUE(nA0, true, 0, (kt_) + 1), 0, 0); \
+    GTOS_QPHASE({ GTOS_QREAD_B(B1_); }, GTOS_QISSUE(nB0, false, 0, (kt_) + 1), 0, 1);                                         \
+    GTOS_QPHASE({ GTOS_QREAD_A(A1_); }, GTOS_QISSUE(nB1, false, 1, (kt_) + 1), 1, 1);                                         \
+    GTOS_QPHASE({ GTOS_QREAD_B(B0_); }, GTOS_QISSUE(nA1, true, 1, (kt_) + 1), 1, 0);
+
+    GTOS_QISSUE(a00, true, 0, 0);
+    GTOS_QISSUE(b00, false, 0, 0);
+    GTOS_QISSUE(b01, false, 1, 0);
+    GTOS_QISSUE(a01, true, 1, 0);
+    GTOS_VMCNT(4);                                         // own pieces of A0, B0 of k tile 0
+    __builtin_amdgcn_s_barrier();                          // everybody's
+    if (wave >= 4) __builtin_amdgcn_s_barrier();           // the second wave of every SIMD runs one barrier behind
+    int kt = 0;
+    for (; kt + 2 <= nk; kt += 2) {
+        GTOS_QTILE(a00, b00, b01, a01, a10, b10, b11, a11, kt);
+        GTOS_QTILE(a10, b10, b11, a11, a00, b00, b01, a01, kt + 1);
+    }
+    if (kt < nk) { GTOS_QTILE(a00, b00, b01, a01, a10, b10, b11, a11, kt); }
+    if (wave < 4) __builtin_amdgcn_s_barrier();            // same number of barriers for both halves
+    GTOS_VMCNT(0);                                         // the dummy prefetches of the last phases
+    __syncthreads();                                       // every wave is done with the buffers: a00 / b00 become the output staging
+#undef GTOS_QTILE
+#undef GTOS_QPHASE
+#undef GTOS_QREAD_A
+#undef GTOS_QREAD_B
+#undef GTOS_QISSUE
+#undef GTOS_QDMA
+
+    // ---- epilogue (bf16 out), as in gemm256_nt_kernel: 32 rows x 64 columns of the wave tile at a time through LDS
+    bf16_t* C = static_cast<bf16_t*>(a.C);
+    const float keep_scale = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
+    constexpr int CP = 64 * 2 + 16;
+    char* cs = (wave < 4 ? a00 : b00) + (wave & 3) * 32 * CP;
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int mt = q4 * 2 + mh;
+                const int m = m0 + wm + mt * 16 + fr, n = n0 + wn + nt * 16 + fq * 4;
+                float v[4] = {acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (a.bias && n + i < a.N) v[i] += a.bias[n + i];
+                    if (a.relu) v[i] = fmaxf(v[i], 0.f);
+                    if (a.p_drop > 0.f)
+                        v[i] = drop_keep(a.seed, (uint64_t)m * (uint64_t)a.N + (uint64_t)(n + i), a.p_drop) ? v[i] * keep_scale : 0.f;
+                }
+                *reinterpret_cast<uint2*>(cs + (mh * 16 + fr) * CP + (nt * 16 + fq * 4) * 2) = make_uint2(pack_bf(v[0], v[1]), pack_bf(v[2], v[3]));
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0)
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int row = pass * 8 + (lane >> 3), col = (lane & 7) * 8;
+            const int m = m0 + wm + q4 * 32 + row, n = n0 + wn + col;
+            if (m >= a.M || n >= a.N) continue;
+            uint4 val = *reinterpret_cast<const uint4*>(cs + row * CP + col * 2);
+            bf16_t* cp = C + (int64_t)m * a.ldc + n;
+            if (n + 8 <= a.N) {
+                if (a.accumulate) {
+                    const uint4 old = *reinterpret_cast<const uint4*>(cp);
+                    val = make_uint4(pack_bf(lo_bf(val.x) + lo_bf(old.x), hi_bf(val.x) + hi_bf(old.x)),
+                                     pack_bf(lo_bf(val.y) + lo_bf(old.y), hi_bf(val.y) + hi_bf(old.y)),
+                                     pack_bf(lo_bf(val.z) + lo_bf(old.z), hi_bf(val.z) + hi_bf(old.z)),
+                                     pack_bf(lo_bf(val.w) + lo_bf(old.w), hi_bf(val.w) + hi_bf(old.w)));
+                }
+                *reinterpret_cast<uint4*>(cp) = val;
+            } else {
+                const bf16_t* e = reinterpret_cast<const bf16_t*>(cs + row * CP + col * 2);
+                for (int i = 0; i < 8 && n + i < a.N; ++i) {
+                    float o = bf2f(e[i]);
+                    if (a.accumulate) o += bf2f(cp[i]);
+                    cp[i] = f2bf(o);
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+    }
+}
+
 int launch256p(const GemmArgs& a, hipStream_t s) {
     const long long nMt = (a.M + BM2 - 1) / BM2, nNt = (a.N + BN2 - 1) / BN2;
     const long long nblk = ((nMt + 7) / 8) * 8 * nNt;
     if (nblk > 0x7fffffffLL) return -6;
-    hipLaunchKernelGGL(gemm256p_nt_kernel, dim3((unsigned)nblk), dim3(512), 0, s, a);
+    if (g_use_q && a.K % 64 == 0) hipLaunchKernelGGL(gemm256q_nt_kernel, dim3((unsigned)nblk), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL(gemm256p_nt_kernel, dim3((unsigned)nblk), dim3(512), 0, s, a);
     GTOS_CHECK_LAUNCH();
     return 0;
 }
@@ -1183,7 +1380,8 @@ extern "C" int gtos_gemm(int in_dtype, int out_dtype, int transA, int transB, in
         // big forward-shaped products go to the 256x256 macro tile (enough tiles to give every CU several)
         const long long t256 = ((long long)(M + BM2 - 1) / BM2) * ((N + BN2 - 1) / BN2);
         // K % 32 == 0 and enough macro tiles: the software-pipelined 256x256 kernel
-        if (g_use_pipe && !transA && transB && a.vecA && a.vecB && a.vecC && splitk == 1 && N >= 256 && N <= g_max_npipe && K % 32 == 0 &&
+        if (g_use_pipe && !transA && transB && a.vecA && a.vecB && a.vecC && splitk == 1 && N >= 256 && K % 32 == 0 &&
+            (N <= g_max_npipe || (g_use_q && K % 64 == 0)) &&
             lda < (1 << 22) && ldb < (1 << 22) &&
             (t256 >= 512 && K >= g_min_kpipe))
             return launch256p(a, s);
