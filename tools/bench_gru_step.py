@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--rows", type=int, default=434624)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--only", default="")
+    ap.add_argument("--p-drop", type=float, default=0.0, help="dropout probability of the backward legs (layer 0: output mask and embedding mask)")
     a = ap.parse_args()
     dev, bf = torch.device("cuda:0"), torch.bfloat16
     A, hs = a.rows, 256
@@ -61,7 +62,10 @@ def main():
                 continue
             for acc in ((False, True) if fused else (False,)):
                 kw = dict(wi_t=wi_t, dinp=dinp, n_in=ind, dinp_acc=acc) if fused else {}
-                us = timed(lambda: gru._step_bwd_fused(A, hs, d4p, A, wh_t, gts, h_in, None if dy is None else dy.data_ptr(), 2 * hs, dh, d4, 0.0, 0, 0, bpart, **kw), a.reps)
+                pdrop = a.p_drop if dy is not None else 0.0            # (the layer-output dropout mask is re-drawn per element in the cell)
+                if fused and layer == 0:
+                    kw.update(p_in=a.p_drop, seed_in=5)
+                us = timed(lambda: gru._step_bwd_fused(A, hs, d4p, A, wh_t, gts, h_in, None if dy is None else dy.data_ptr(), 2 * hs, dh, d4, pdrop, 17, 0, bpart, **kw), a.reps)
                 nbb = 2 * (A * (11 * hs + (hs if dy is not None else 0)) + A * (4 if fused else 3) * hs + (A * ind * (2 if acc else 1) if fused else 0))
                 flb = 2.0 * A * 3 * hs * (hs + (ind if fused else 0))
                 print("bwd  L%d  rows %d %-9s %-10s: %8.1f us  %7.1f GB/s (%.3f of 8 TB/s)  %7.1f TF/s" % (
