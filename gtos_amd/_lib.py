@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgtos_hip.so")
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 c_p, c_i, c_l, c_f, c_u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_uint64
 
@@ -48,6 +48,7 @@ SIGNATURES = {
     "gtos_gru_step_bwd_fused": [c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_l, c_p, c_i, c_l, c_p, c_f, c_u64, c_l, c_p, c_i, c_p, c_p, c_p, c_i,
                                 c_p, c_p, c_l, c_i, c_i, c_f, c_u64, c_l, c_p],
     "gtos_gru_weight_grads": [c_i, c_i, c_i, c_i, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p],
+    "gtos_gemm_tn_batch": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],      # n, 10 host arrays of n entries, stream
     "gtos_embed_packed_paths": [c_i, c_i, c_i, c_l, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_f, c_u64, c_p, c_i, c_p, c_p],
     "gtos_segment_sum_rows": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_p, c_p, c_l, c_p, c_p, c_p],
     "gtos_segment_sum_stream": [c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_i, c_p, c_l, c_p, c_p],

@@ -1124,8 +1124,17 @@ struct TnGroup {
     int tmn[64];                                   // tile t: A column block (bits 0-7), B operand (8-15), its column block (16-23), x 256
 };
 
-template <bool GROUPED>
-__global__ __launch_bounds__(512) void gemm256p_tn_kernel(GemmArgs a, TnGroup g) {
+//      BATCH (round 6, MODE 2): the tiles of one launch come from a table of INDEPENDENT products -- the weight gradients of the model's small linear
+//      layers (dY^T X over a few thousand rows: 63 such launches of ~22 us each per C2 step, each followed by a split-K reduction, a bias column
+//      sum and often a fill: 3.6 ms of latency-bound launches on the main stream).  A workgroup takes one 256x256 tile of one job over the job's
+//      WHOLE K (no split: nobody else writes the tile) and adds it to the job's fp32 target in place.
+struct TnJob { const bf16_t* A; const bf16_t* B; float* C; int lda, ldb, ldc, M, N, K, tile_end, nN; };     // tile_end: exclusive prefix sum of the jobs' tile counts
+constexpr int TN_MAX_JOBS = 48;
+struct TnBatch { int njobs, ntiles; TnJob job[TN_MAX_JOBS]; };
+
+template <int MODE, typename G>
+__global__ __launch_bounds__(512) void gemm256p_tn_kernel(GemmArgs a, G g) {
+    constexpr bool GROUPED = MODE == 1;
     __shared__ __attribute__((aligned(16))) char st0[ST3];
     __shared__ __attribute__((aligned(16))) char st1[ST3];
     __shared__ __attribute__((aligned(16))) char st2[ST3];
@@ -1133,15 +1142,28 @@ __global__ __launch_bounds__(512) void gemm256p_tn_kernel(GemmArgs a, TnGroup g)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fr = lane & 15, fq = lane >> 4;
     const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
-    const int nN = (a.N + BN2 - 1) / BN2, nM = (a.M + BM2 - 1) / BM2, tiles = GROUPED ? g.tiles : nM * nN;
+    const int nN = (a.N + BN2 - 1) / BN2, nM = (a.M + BM2 - 1) / BM2;
+    int tiles = nM * nN;
+    if constexpr (GROUPED) tiles = g.tiles;
+    if constexpr (MODE == 2) tiles = 1;
     const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
-    const int bz = (sq / tiles) * 8 + xcd, t_ = sq % tiles;        // all tiles of one K split on one XCD
+    int bz = (sq / tiles) * 8 + xcd, t_ = sq % tiles;              // all tiles of one K split on one XCD
+    if constexpr (MODE == 2) { bz = 0; t_ = blockIdx.x; if (t_ >= g.ntiles) return; }
     if (bz >= a.splitk) return;
     int m0, n0, Nv;
     const bf16_t* Bp;
     int64_t ldb, wld;
     float* wst;                                                    // this split's partial tile: element (m, n) at wst[(m - m0) * wld + n - n0]
-    if constexpr (GROUPED) {
+    if constexpr (MODE == 2) {
+        int j = 0;
+        while (j + 1 < g.njobs && t_ >= g.job[j].tile_end) ++j;
+        const TnJob& jb = g.job[j];
+        const int tl = t_ - (j ? g.job[j - 1].tile_end : 0);
+        m0 = (tl / jb.nN) * BM2; n0 = (tl % jb.nN) * BN2;
+        a.A = jb.A; a.lda = jb.lda; a.M = jb.M; a.K = jb.K; a.splitk = 1;
+        Bp = jb.B; ldb = jb.ldb; Nv = jb.N;
+        wst = jb.C + (int64_t)m0 * jb.ldc + n0; wld = jb.ldc;
+    } else if constexpr (GROUPED) {
         const int e = g.tmn[t_], src = (e >> 8) & 255;
         m0 = (e & 255) * BM2; n0 = ((e >> 16) & 255) * BN2;
         Bp = src ? g.B1 : static_cast<const bf16_t*>(a.B); ldb = src ? g.ldb1 : a.ldb; Nv = src ? g.N1 : a.N;
@@ -1250,9 +1272,46 @@ __global__ __launch_bounds__(512) void gemm256p_tn_kernel(GemmArgs a, TnGroup g)
         for (int nt = 0; nt < 4; ++nt) {
             const int n = n0 + wn + nt * 16 + fq * 4;
             if (n >= Nv) continue;
-            *reinterpret_cast<float4*>(wst + (int64_t)(m - m0) * wld + (n - n0)) =
-                make_float4(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]);
+            float4* dst = reinterpret_cast<float4*>(wst + (int64_t)(m - m0) * wld + (n - n0));
+            if constexpr (MODE == 2) {                     // the job's gradient itself: this workgroup is the tile's only writer
+                const float4 o = *dst;
+                *dst = make_float4(o.x + acc[mt][nt][0], o.y + acc[mt][nt][1], o.z + acc[mt][nt][2], o.w + acc[mt][nt][3]);
+            } else {
+                *dst = make_float4(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]);
+            }
         }
+    }
+}
+
+// column sums of the A operands of a batch (the layers' bias gradients): block (x, y) of job j sums rows y*rpb .. of columns x*512 .. x*512+511
+struct ColJob { const bf16_t* A; float* out; int lda, M, K, blk_end, gx; };
+struct ColBatch { int njobs, nblocks, rpb; ColJob job[TN_MAX_JOBS]; };
+__global__ __launch_bounds__(256) void colsum_batch_kernel(ColBatch g) {
+    __shared__ float red[4][64][8];
+    int t_ = blockIdx.x, j = 0;
+    if (t_ >= g.nblocks) return;
+    while (j + 1 < g.njobs && t_ >= g.job[j].blk_end) ++j;
+    const ColJob& jb = g.job[j];
+    const int tl = t_ - (j ? g.job[j - 1].blk_end : 0);
+    const int bx = tl % jb.gx, by = tl / jb.gx;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = (bx * 64 + lane) * 8;
+    const int r0 = by * g.rpb, r1 = min(jb.K, r0 + g.rpb);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (c < jb.M) {                                        // M % 8 == 0: whole vectors
+        for (int r = r0 + w; r < r1; r += 4) {
+            float v[8];
+            Vec8<bf16_t>::load(jb.A + (int64_t)r * jb.lda + c, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += v[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[w][lane][e] = acc[e];
+    __syncthreads();
+    if (w == 0 && c < jb.M) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicAdd(jb.out + c + e, red[0][lane][e] + red[1][lane][e] + red[2][lane][e] + red[3][lane][e]);
     }
 }
 
@@ -1288,7 +1347,7 @@ int launch256p_tn(const GemmArgs& a, hipStream_t s) {
     const long long tiles = ((long long)(a.M + BM2 - 1) / BM2) * ((a.N + BN2 - 1) / BN2);
     const long long nblk = tiles * 8 * ((a.splitk + 7) / 8);
     if (nblk > 0x7fffffffLL) return -6;
-    hipLaunchKernelGGL(gemm256p_tn_kernel<false>, dim3((unsigned)nblk), dim3(512), 0, s, a, TnGroup{});
+    hipLaunchKernelGGL((gemm256p_tn_kernel<0, TnGroup>), dim3((unsigned)nblk), dim3(512), 0, s, a, TnGroup{});
     GTOS_CHECK_LAUNCH();
     return 0;
 }
@@ -1439,11 +1498,60 @@ extern "C" int gtos_gru_weight_grads(int rows, int hs, int in_dim, int in_valid,
     a.ws = static_cast<float*>(workspace);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long long nblk = (long long)nt * 8 * ((a.splitk + 7) / 8);
-    hipLaunchKernelGGL(gemm256p_tn_kernel<true>, dim3((unsigned)nblk), dim3(512), 0, s, a, g);
+    hipLaunchKernelGGL((gemm256p_tn_kernel<1, TnGroup>), dim3((unsigned)nblk), dim3(512), 0, s, a, g);
     GTOS_CHECK_LAUNCH();
     GruDwOut o{dwih, ld_dwih, dwhh, ld_dwhh, hs, in_valid};            // columns in_valid .. in_dim of x are the zero padding of its rows
     hipLaunchKernelGGL(gru_dw_reduce_kernel, dim3((unsigned)(nt * 64)), dim3(256), 0, s, a.ws, a.splitk, g, o);
     GTOS_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gtos_gemm_tn_batch(int n, const void* const* A, const int64_t* lda, const int* M, const void* const* B, const int64_t* ldb,
+                                  const int* N, const int* K, float* const* C, const int64_t* ldc, float* const* bias, void* stream) {
+    if (n <= 0) return 0;
+    if (!A || !lda || !M || !B || !ldb || !N || !K || !C || !ldc) return -23;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const void* zeros = zero_block();
+    if (!zeros) return -5;
+    for (int j = 0; j < n; ++j) {
+        if (M[j] < 8 || M[j] % 8 || N[j] < 8 || N[j] % 8 || K[j] < 1 || lda[j] < M[j] || lda[j] % 8 || ldb[j] < N[j] || ldb[j] % 8 || ldc[j] < N[j] ||
+            ldc[j] % 4 || lda[j] >= (1LL << 31) || ldb[j] >= (1LL << 31) || ldc[j] >= (1LL << 31)) return -22;
+        if (!A[j] || !B[j] || !C[j] || (uintptr_t)A[j] % 16 || (uintptr_t)B[j] % 16 || (uintptr_t)C[j] % 16) return -25;
+        if (bias && bias[j] && (uintptr_t)bias[j] % 4) return -25;
+    }
+    for (int j0 = 0; j0 < n; j0 += TN_MAX_JOBS) {
+        const int nj = n - j0 < TN_MAX_JOBS ? n - j0 : TN_MAX_JOBS;
+        TnBatch tb{};
+        ColBatch cb{};
+        int tiles = 0, blocks = 0, ncol = 0;
+        cb.rpb = 512;
+        for (int j = 0; j < nj; ++j) {
+            const int q = j0 + j;
+            TnJob& t = tb.job[j];
+            t.A = static_cast<const bf16_t*>(A[q]); t.B = static_cast<const bf16_t*>(B[q]); t.C = C[q];
+            t.lda = (int)lda[q]; t.ldb = (int)ldb[q]; t.ldc = (int)ldc[q]; t.M = M[q]; t.N = N[q]; t.K = K[q];
+            t.nN = (N[q] + BN2 - 1) / BN2;
+            tiles += ((M[q] + BM2 - 1) / BM2) * t.nN;
+            t.tile_end = tiles;
+            if (bias && bias[q]) {
+                ColJob& c = cb.job[ncol++];
+                c.A = t.A; c.out = bias[q]; c.lda = t.lda; c.M = t.M; c.K = t.K;
+                c.gx = (t.M + 511) / 512;
+                blocks += c.gx * ((t.K + cb.rpb - 1) / cb.rpb);
+                c.blk_end = blocks;
+            }
+        }
+        tb.njobs = nj; tb.ntiles = tiles;
+        GemmArgs a{};
+        a.splitk = 1; a.zeros = zeros; a.vecA = a.vecB = 1; a.accumulate = 1;
+        hipLaunchKernelGGL((gemm256p_tn_kernel<2, TnBatch>), dim3((unsigned)tiles), dim3(512), 0, s, a, tb);
+        GTOS_CHECK_LAUNCH();
+        if (ncol) {
+            cb.njobs = ncol; cb.nblocks = blocks;
+            hipLaunchKernelGGL(colsum_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, s, cb);
+            GTOS_CHECK_LAUNCH();
+        }
+    }
     return 0;
 }
 

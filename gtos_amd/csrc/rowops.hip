@@ -1240,6 +1240,6 @@ extern "C" int gtos_set_seed_epoch(const void* epoch) {
     return rc;
 }
 
-extern "C" int gtos_abi_version(void) { return 20; }
+extern "C" int gtos_abi_version(void) { return 21; }
 
 GTOS_SEED_EPOCH_SETTER(rowops)

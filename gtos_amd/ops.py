@@ -3,6 +3,7 @@
 Each ``torch.autograd.Function`` here is the MI355X counterpart of one ATen op sequence of the reference
 (cited per function).  Tensors provide device memory; kernels are enqueued on torch's current HIP stream.
 """
+import contextlib
 import os
 
 import torch
@@ -142,6 +143,49 @@ PROJ_RECOMPUTE = os.environ.get("GTOS_PROJ_RECOMPUTE", "0") == "1"
 # Backward of the relation projections on the side stream (see LinearFn.backward): overlaps only backward kernels.
 BWD_SIDE = os.environ.get("GTOS_BWD_SIDE", "1") != "0"
 BWD_SIDE_MIN_ROWS = 100000
+# Weight (and bias) gradients of the model's SMALL linear layers -- dY^T X over the n*B = 6,464 rows of a graph layer or the T*B = 3,200 rows
+# of a decoder layer -- are not launched where autograd reaches them (63 split-K products of ~22 us per C2 step, each with its partial-tile
+# reduction, a bias column sum and often a fill: 270 latency-bound launches, 3.6 ms of the main stream) but noted and launched TOGETHER as one
+# batched product (gtos_gemm_tn_batch: a workgroup per 256x256 tile of one job over its whole K, added to the flat gradient in place, plus one
+# batched column-sum launch) when the gradient bucket is about to be read: flush_dw() from join_side() and, data parallel, in front of every
+# segment's all-reduce (train.GradSync.segment_ready).  The operands stay referenced until then.
+DW_BATCH = os.environ.get("GTOS_DW_BATCH", "1") != "0"
+DW_BATCH_MAX_ROWS = 32768
+_DW_PENDING = {}                  # device -> [(dy2, x2, weight-gradient target, bias-gradient target or None)]
+
+
+def _dw_batchable(dy2, x2, tgt, btgt):
+    ok = (DW_BATCH and dy2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16 and tgt.dtype == torch.float32 and 0 < dy2.shape[0] <= DW_BATCH_MAX_ROWS
+          and dy2.shape[1] % 8 == 0 and x2.shape[1] % 8 == 0 and dy2.stride(1) == 1 and x2.stride(1) == 1 and tgt.stride(1) == 1
+          and dy2.stride(0) % 8 == 0 and x2.stride(0) % 8 == 0 and tgt.stride(0) % 4 == 0 and dy2.stride(0) >= dy2.shape[1]
+          and x2.stride(0) >= x2.shape[1] and tgt.stride(0) >= tgt.shape[1]
+          and dy2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0 and tgt.data_ptr() % 16 == 0)
+    return ok and (btgt is None or (btgt.dtype == torch.float32 and btgt.is_contiguous()))
+
+
+def flush_dw(device=None):
+    """Launch the noted small weight gradients of ``device`` (all devices: None) on the current stream, in the order they were noted."""
+    import ctypes
+    for dev in list(_DW_PENDING):
+        if device is not None and dev != device:
+            continue
+        jobs = _DW_PENDING.pop(dev)
+        n = len(jobs)
+        if not n:
+            continue
+        vp, i64, i32 = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int * n
+        A = vp(*[j[0].data_ptr() for j in jobs]); B = vp(*[j[1].data_ptr() for j in jobs]); C = vp(*[j[2].data_ptr() for j in jobs])
+        bias = vp(*[(j[3].data_ptr() if j[3] is not None else None) for j in jobs])
+        lda = i64(*[j[0].stride(0) for j in jobs]); ldb = i64(*[j[1].stride(0) for j in jobs]); ldc = i64(*[j[2].stride(0) for j in jobs])
+        M = i32(*[j[0].shape[1] for j in jobs]); N = i32(*[j[1].shape[1] for j in jobs]); K = i32(*[j[0].shape[0] for j in jobs])
+        for j in jobs:
+            for t_ in j:
+                ptr(t_)                      # (the dry-run recorder learns the storages behind the table's pointers)
+        with _Timed("gemm_tn_batch", detail=True, units=sum(2 * j[0].shape[0] * j[0].shape[1] * j[1].shape[1] for j in jobs)):
+            with torch.cuda.device(dev) if dev.type == "cuda" else contextlib.nullcontext():
+                call("gtos_gemm_tn_batch", n, ctypes.addressof(A), ctypes.addressof(lda), ctypes.addressof(M), ctypes.addressof(B), ctypes.addressof(ldb),
+                     ctypes.addressof(N), ctypes.addressof(K), ctypes.addressof(C), ctypes.addressof(ldc), ctypes.addressof(bias), stream())
+        del jobs
 
 
 # The auxiliary stream has a price in memory: the caching allocator keeps one pool per stream, blocks freed on one stream never serve the
@@ -231,7 +275,9 @@ def behind_side(device):
 
 
 def join_side(device=None):
-    """Make the current stream wait for deferred side-stream work (no-op when there is none)."""
+    """Make the current stream wait for deferred side-stream work (no-op when there is none); the noted small weight gradients go out first."""
+    if _DW_PENDING:
+        flush_dw(device)
     for dev in list(_PENDING_SIDE):
         if device is None or dev == device:
             torch.cuda.current_stream(dev).wait_stream(side_stream(dev))
@@ -540,16 +586,26 @@ class LinearFn(torch.autograd.Function):
             return dx, None, None, None, None, None, None
         if ctx.needs_input_grad[0]:
             dx = group.add(dy2, wt, shp) if group is not None else gemm(dy2, wt, trans_b=True).view(shp)
+        noted = False
         if ctx.needs_input_grad[1]:
             tgt = _grad_target(weight)
             M, N, K = n_out, x2.shape[1], dy2.shape[0]
             sk = _splitk(M, N, K)
+            in_bucket = tgt is not None
             if tgt is None:
                 tgt = dw = torch.zeros(weight.shape, dtype=torch.float32, device=dy2.device)
             if rows is not None:
                 tgt = tgt[rows[0]:rows[1]]
-            gemm(dy2, x2, trans_a=True, out=tgt, accumulate=True, splitk=sk)
-        if bias is not None and ctx.needs_input_grad[2]:
+            btgt = None
+            if bias is not None and ctx.needs_input_grad[2] and _grad_target(bias) is not None:
+                btgt = _grad_target(bias)
+                btgt = btgt[rows[0]:rows[1]] if rows is not None else btgt
+            if in_bucket and _dw_batchable(dy2, x2, tgt, btgt):      # a small layer: with the other small layers' gradients at flush_dw()
+                _DW_PENDING.setdefault(dy2.device, []).append((dy2, x2, tgt, btgt))
+                noted = True
+            else:
+                gemm(dy2, x2, trans_a=True, out=tgt, accumulate=True, splitk=sk)
+        if bias is not None and ctx.needs_input_grad[2] and not (noted and _grad_target(bias) is not None):
             tgt = _grad_target(bias)
             if tgt is None:
                 tgt = db = torch.zeros(bias.shape, dtype=torch.float32, device=dy2.device)

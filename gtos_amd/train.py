@@ -99,6 +99,8 @@ class Trainer:
 
     def segment_ready(self, seg):
         """Segments 0..seg hold final gradients: put their all-reduce in flight (once, in segment order on every rank)."""
+        if self._launched <= seg and self.collective:
+            ops.flush_dw(self.flat.grad.device)        # the small layers' batched weight gradients (ops.DW_BATCH) belong to the segment
         while self._launched <= seg and self._launched < len(self.flat.segments):
             lo, hi = self.flat.segments[self._launched]
             self._launched += 1

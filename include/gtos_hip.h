@@ -245,6 +245,16 @@ int gtos_gru_step_bwd_fused(int rows, int hs, const void* d4_prev, int rows_prev
 int gtos_gru_weight_grads(int rows, int hs, int in_dim, int in_valid, const void* d4, const void* x, int64_t ldx, const void* hprev, int64_t ldh,
                           float* dwih, int64_t ld_dwih, float* dwhh, int64_t ld_dwhh, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Weight gradients of n independent SMALL linear layers in one launch (round 6; the reference's autograd runs one mm per nn.Linear:
+ * generator/graph_transformer.py:61-63,106-122,166, transformer.py: the same per decoder layer).  All ten arguments after n are HOST arrays of n
+ * entries.  For job j:  C[j] [M[j], N[j]] (fp32, row stride ldc[j]) += A[j]^T B[j]  with A[j] [K[j], M[j]] = dY and B[j] [K[j], N[j]] = X (bf16,
+ * row strides lda[j], ldb[j]), and, where bias != NULL and bias[j] != NULL,  bias[j][M[j]] (fp32) += column sums of A[j].  One workgroup per
+ * 256x256 tile of one job over the job's whole K on the ping-pong TN kernel (no split-K: the tile has one writer, so the result is
+ * deterministic), then one batched column-sum launch (fp32 atomics across row blocks).  M, N % 8 == 0, leading dimensions % 8 (ldc % 4),
+ * A / B / C 16-byte aligned; anything else returns -22 / -25 and launches nothing. */
+int gtos_gemm_tn_batch(int n, const void* const* A, const int64_t* lda, const int* M, const void* const* B, const int64_t* ldb, const int* N,
+                       const int* K, float* const* C, const int64_t* ldc, float* const* bias, void* stream);
+
 /* Segmented row sums for the trie-evaluated RelationEncoder's backward (generator/encoder.py:93-111 runs every path
  * separately; here the gradient of a shared trie node is the sum over the rows that share it).  bf16 rows, fp32
  * accumulation, bf16 result.  _rows: chunk c adds the rows rows[chunk_start[c] .. +chunk_cnt[c]) of src into node

@@ -121,7 +121,22 @@ class Recorder(object):
 
     def _check_other(self, name, a):
         es = lambda dtc: (4, 2)[dtc]                                          # noqa: E731
-        if name == "gtos_rel_attn_fwd":
+        if name == "gtos_gemm_tn_batch":                                      # ten host arrays of n entries: read them back
+            import ctypes as ct_
+            n = a[0]
+            vp = lambda addr: list((ct_.c_void_p * n).from_address(addr))      # noqa: E731
+            i64 = lambda addr: list((ct_.c_int64 * n).from_address(addr))      # noqa: E731
+            i32 = lambda addr: list((ct_.c_int * n).from_address(addr))        # noqa: E731
+            A, lda, M, B, ldb, N, K, C, ldc, bias = vp(a[1]), i64(a[2]), i32(a[3]), vp(a[4]), i64(a[5]), i32(a[6]), i32(a[7]), vp(a[8]), i64(a[9]), vp(a[10])
+            for j in range(n):
+                assert M[j] % 8 == 0 and N[j] % 8 == 0 and K[j] > 0, (M[j], N[j], K[j])
+                self._rows("gtos_gemm_tn_batch: dY of job %d" % j, A[j], K[j], M[j], lda[j], 2)
+                self._rows("gtos_gemm_tn_batch: X of job %d" % j, B[j], K[j], N[j], ldb[j], 2)
+                self._rows("gtos_gemm_tn_batch: dW of job %d" % j, C[j], M[j], N[j], ldc[j], 4)
+                if bias[j]:
+                    self._rows("gtos_gemm_tn_batch: db of job %d" % j, bias[j], 1, M[j], M[j], 4)
+                self.extent_checks += 1                                        # (one checked product per job, like the gtos_gemm call it replaces)
+        elif name == "gtos_rel_attn_fwd":
             dtc, mode, T, S, B, H, d = a[:7]
             for what, p, ld, rows in (("q", a[7], a[8], T * B), ("k", a[9], a[10], S * B), ("v", a[11], a[12], S * B), ("o", a[20], a[21], T * B)):
                 self._rows("gtos_rel_attn_fwd: " + what, p, rows, d, ld, es(dtc))

@@ -49,7 +49,7 @@ def test_training_step_launch_plan_c1_bf16_trie_factored():
     assert plan_a == plan_b                                       # same batch, same plan (shapes, flags, split-K factors, launch order)
     # every operand of the GEMM / attention (incl. the bank-gradient chunk lists) / LayerNorm / column-sum / GRU-step / segment-sum
     # launches of the three steps lay inside its tensor's storage, every gathered row index inside its table (real index arrays)
-    assert rec.extent_checks > 1200 and rec.unknown_ptrs == 0
+    assert rec.extent_checks > 1000 and rec.unknown_ptrs == 0     # (1,074 since round 6: a small layer's weight AND bias gradient are one checked job of gtos_gemm_tn_batch)
     L = synth.CONFIGS["C1"]["layers"]
     # the production path of DESIGN.md: factored attention (one bank-gradient launch per graph layer), the RelationEncoder with the
     # reference's dropout semantics on the packed-path kernels (round 5: one embedding launch off the batch's own sort order, fused steps

@@ -118,6 +118,76 @@ def test_gemm_pipelined_256_tile(M, N, K):
     assert torch.equal(small == 0, big[:300] == 0)
 
 
+def test_gemm_tn_batch_small_weight_gradients_vs_torch():
+    """gtos_gemm_tn_batch (round 6): the weight and bias gradients of many small linear layers in one launch -- dW_j += dY_j^T X_j, db_j += column
+    sums of dY_j -- against fp32 matmul of the same bf16 operands: the shapes of a C2 step's graph and decoder layers, ragged M / N (multiples of 8),
+    K that is no multiple of the 32-row stage, strided operands (column blocks of a wider buffer), a job without a bias, targets that already hold
+    values (the kernel accumulates), more jobs than one launch's table holds (48), and a second call on top (gradient accumulation)."""
+    import ctypes
+    from gtos_amd._lib import call, stream
+    torch.manual_seed(5)
+    shapes = [(6464, 1536, 512), (6464, 512, 512), (6464, 1024, 512), (6464, 512, 1024), (3200, 512, 512), (3200, 1024, 512), (3200, 264, 520),
+              (1000, 8, 8), (77, 520, 72), (6464, 1536, 512)] + [(3200 - 8 * i, 512, 256 + 8 * i) for i in range(45)]
+    jobs, keep = [], []
+    for q, (K, M, N) in enumerate(shapes):
+        wide = (torch.randn(K, M + 16, device=dev()) * 0.5).to(torch.bfloat16)
+        dy = wide[:, 8:8 + M] if q % 3 == 0 else wide[:, :M].contiguous()
+        x = (torch.randn(K, N, device=dev()) * 0.5).to(torch.bfloat16)
+        base = torch.randn(M, N, device=dev())
+        bias0 = torch.randn(M, device=dev()) if q % 4 != 1 else None
+        jobs.append((dy, x, base.clone(), None if bias0 is None else bias0.clone(), base, bias0))
+    n = len(jobs)
+    vp, i64, i32 = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int * n
+    A = vp(*[j[0].data_ptr() for j in jobs]); B = vp(*[j[1].data_ptr() for j in jobs]); C = vp(*[j[2].data_ptr() for j in jobs])
+    bias = vp(*[(j[3].data_ptr() if j[3] is not None else None) for j in jobs])
+    lda = i64(*[j[0].stride(0) for j in jobs]); ldb = i64(*[j[1].stride(0) for j in jobs]); ldc = i64(*[j[2].stride(0) for j in jobs])
+    M_ = i32(*[j[0].shape[1] for j in jobs]); N_ = i32(*[j[1].shape[1] for j in jobs]); K_ = i32(*[j[0].shape[0] for j in jobs])
+    args = (n, ctypes.addressof(A), ctypes.addressof(lda), ctypes.addressof(M_), ctypes.addressof(B), ctypes.addressof(ldb), ctypes.addressof(N_),
+            ctypes.addressof(K_), ctypes.addressof(C), ctypes.addressof(ldc), ctypes.addressof(bias), stream())
+    for rep in (1, 2):
+        call("gtos_gemm_tn_batch", *args)
+        torch.cuda.synchronize()
+        for q, (dy, x, out, b_out, base, bias0) in enumerate(jobs):
+            want = base + rep * (dy.float().t() @ x.float())
+            torch.testing.assert_close(out, want, rtol=2e-3, atol=2e-3 * dy.shape[0] ** 0.5, msg=lambda m: "job %d %s: %s" % (q, tuple(dy.shape), m))
+            if b_out is not None:
+                torch.testing.assert_close(b_out, bias0 + rep * dy.float().sum(0), rtol=2e-3, atol=2e-3 * dy.shape[0] ** 0.5)
+    # a job the kernel cannot take launches nothing and says so
+    bad = i32(*([7] + [8] * (n - 1)))
+    with pytest.raises(Exception):
+        call("gtos_gemm_tn_batch", n, ctypes.addressof(A), ctypes.addressof(lda), ctypes.addressof(bad), ctypes.addressof(B), ctypes.addressof(ldb),
+             ctypes.addressof(N_), ctypes.addressof(K_), ctypes.addressof(C), ctypes.addressof(ldc), ctypes.addressof(bias), stream())
+
+
+def test_small_weight_gradients_batched_equal_launched_in_place(monkeypatch):
+    """ops.DW_BATCH: a model's small weight / bias gradients noted during backward and launched together at ops.join_side() are the gradients the
+    per-layer split-K products + column sums give (fp32 accumulation in another order: 1e-5 relative)."""
+    from gtos_amd import ops
+    torch.manual_seed(3)
+    lin = [torch.nn.Linear(512, 1536), torch.nn.Linear(1536, 512), torch.nn.Linear(512, 264)]
+    x0 = (torch.randn(3200, 512) * 0.5)
+    res = []
+    for mode in (True, False):
+        monkeypatch.setattr(ops, "DW_BATCH", mode)
+        ws = [(l.weight.detach().clone().to(dev()).requires_grad_(), l.bias.detach().clone().to(dev()).requires_grad_()) for l in lin]
+        flat = torch.zeros(sum(w.numel() + b.numel() for w, b in ws), device=dev())
+        off = 0
+        for w, b in ws:                                   # gradients land in views of a flat fp32 bucket, like FlatParams
+            for t in (w, b):
+                t.grad = flat[off:off + t.numel()].view(t.shape)
+                off += t.numel()
+        h = x0.to(dev()).to(torch.bfloat16)
+        for w, b in ws:
+            h = ops.linear(h, w, b)
+        h.float().square().sum().backward()
+        ops.join_side()
+        torch.cuda.synchronize()
+        assert float(flat.abs().max()) > 0
+        res.append(flat.clone())
+    torch.testing.assert_close(res[0], res[1], rtol=1e-4, atol=1e-2)
+    assert not ops._DW_PENDING
+
+
 @pytest.mark.parametrize("M,N,K,sk", [(768, 512, 300040, 43), (256, 256, 100000, 64), (1024, 512, 6464, 12), (512, 264, 70008, 16)])
 def test_gemm_weight_gradient_long_k_splitk(M, N, K, sk):
     """dW = A^T B with K in the hundreds of thousands: transpose-read operand path + split-K partial tiles reduced
