@@ -396,8 +396,8 @@ def _gemm_kernel_name(lay, nn, kk, sk, long_dim):
     and kk is K, for TN kk is M and `long_dim` is K."""
     if lay == "NT":
         tiles256 = -(-long_dim // 256) * -(-nn // 256)
-        if tiles256 >= 512 and 256 <= nn <= 2048 and kk >= 1024 and kk % 32 == 0:
-            return "gemm256p_nt_kernel"
+        if tiles256 >= 512 and nn >= 256 and kk >= 1024 and kk % 32 == 0:
+            return "gemm256q_nt_kernel"
         if tiles256 >= 1024 and nn >= 256 and kk >= 2048:
             return "gemm256_nt_kernel"
     if lay == "TN" and sk > 1 and nn >= 256 and kk >= 256 and long_dim // sk >= 256:

@@ -713,185 +713,25 @@ __global__ __launch_bounds__(512, 2) void gemm256_nt_kernel(GemmArgs a) {
     }
 }
 
-// ---- gemm256p_nt_kernel: the same 256x256 tile / 8 waves with FOUR 32-k LDS stages and a ping-pong schedule, for
-//      K % 32 == 0, K >= 1024, N <= 2048 (measured: 1.18 vs 1.10 PF/s at [434624,4096]x[1024,4096]^T, +9..11 % over the
-//      128x128 kernel at K = 1024..2016; below K ~ 700 the 128x128 kernel's four co-resident workgroups win, and with a
-//      wide N (8192^3) the 64-byte rows cost L2 efficiency: those shapes stay on the kernels above).
-//      * The stages are SEPARATE static LDS arrays: hipcc's wait-count pass tracks LDS-DMA per underlying LDS object, so
-//        a ds_read of one stage does not wait for the DMA in flight into the others (with ONE LDS array it drains
-//        vmcnt(0) in front of every ds_read -- what limits gemm256_nt_kernel to one tile of prefetch, issued after the
-//        fragment reads).  The waits are explicit: s_waitcnt vmcnt(8) leaves a wave's 8 newest DMA instructions (its
-//        pieces of two stages) in flight; hipcc accepts it and adds none of its own (checked in the ISA).
-//      * A step of a wave = a LOAD segment (its 4 DMA pieces of stage s+3 into the slot of stage s-1, the 12 fragment
-//        reads of stage s, the wait that retires its pieces of stage s+1) and a COMPUTE segment (32 MFMAs), each closed
-//        by s_barrier.  Waves 4-7 run one segment behind waves 0-3: on every SIMD one wave multiplies while its partner
-//        issues DMA / LDS reads (a DMA piece costs its wave 60-180 issue cycles).  Three stages (96 KB) in flight per CU.
-//      * LDS rows are 64 bytes (32 k); 16-byte chunk c of row r sits at chunk c ^ ((-(r >> 2)) & 3): the 16 accesses the
-//        LDS serves together (rows {0-3,12-15} of one chunk, rows {4-11} of the next) hit 16 different 16-byte slots.
-//        The swizzle is a per-lane constant for both the DMA source address and the fragment reads (row offsets are
-//        multiples of 16): fragments are one address register + immediate offsets, DMA sources uniform base + 32-bit
-//        lane offset.
-//      * Rows past the end re-read the last valid row (their products are never stored); stages past the end of K
-//        re-read the last stage (never multiplied), so the number of DMAs in flight is the same in every step.
-constexpr int ROW3 = 64, A3 = BM2 * ROW3, ST3 = (BM2 + BN2) * ROW3;
+// ---- Software-pipelined 256x256 kernels (gemm256q_nt_kernel below, gemm256p_tn_kernel further down).  Two findings of round 2 make them possible:
+//      * hipcc's wait-count pass tracks LDS-DMA per underlying LDS OBJECT: with the stages / half-tiles as SEPARATE static __shared__ arrays a
+//        ds_read of one does not wait for the DMA in flight into the others (with ONE LDS array it drains vmcnt(0) in front of every ds_read --
+//        what limits gemm256_nt_kernel to one tile of prefetch, issued after the fragment reads).  The waits are explicit counted vmcnt(n);
+//        hipcc accepts them and adds none of its own (checked in the ISA).
+//      * Waves 4-7 run one barrier behind waves 0-3: on every SIMD one wave multiplies while its partner issues DMA pieces (60-180 issue
+//        cycles each) and fragment reads.
+//      Round 2's NT kernel of this family -- gemm256p_nt_kernel: four 32-k stages of 64-byte rows, 32 MFMAs per compute segment, 1.06-1.18 PF/s on
+//      deep K -- was replaced by the 8-phase kernel in round 6 (+10-16 %: whole-line DMA pieces, shorter load segments; K % 64 == 32 through a
+//      zero-filled half of the last k tile) and removed; the TN kernel keeps the four-stage form (its stage rows are 512 bytes: whole lines already).
+constexpr int ROW3 = 64, A3 = BM2 * ROW3, ST3 = (BM2 + BN2) * ROW3;      // the TN kernel's stage: [32 k][256 m] + [32 k][256 n]
 constexpr int g_min_k256 = 2048;                     // (rounds 3-5 swept these thresholds with environment switches: profiles/r3..r5_ab_switches.txt)
 const bool g_use_pipe = !(getenv("GTOS_GEMM_PIPE") && getenv("GTOS_GEMM_PIPE")[0] == '0');
 const bool g_use_pipe_tn = !(getenv("GTOS_GEMM_PIPE_TN") && getenv("GTOS_GEMM_PIPE_TN")[0] == '0');
-constexpr int g_max_npipe = 2048;                    // gemm256p_nt_kernel only (64-byte rows); the 8-phase kernel takes any N >= 256
 constexpr int g_min_kpipe = 1024;
-// (Small products -- a few thousand rows: the graph layers' and the decoder's projections -- on this kernel: 17-25 us against 10-19 us on the
+// (Small products -- a few thousand rows: the graph layers' and the decoder's projections -- on a 256x256 kernel: 17-25 us against 10-19 us on the
 // single-stage 128x128 kernel, step +1.1 ms; measured in round 3, never enabled.)
 
 #define GTOS_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))
-
-__global__ __launch_bounds__(512) void gemm256p_nt_kernel(GemmArgs a) {
-    if (a.p_drop > 0.f) a.seed = live_seed(a.seed);
-    __shared__ __attribute__((aligned(16))) char st0[ST3];
-    __shared__ __attribute__((aligned(16))) char st1[ST3];
-    __shared__ __attribute__((aligned(16))) char st2[ST3];
-    __shared__ __attribute__((aligned(16))) char st3[ST3];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int fr = lane & 15, fq = lane >> 4;
-    const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
-    const int nN = (a.N + BN2 - 1) / BN2;
-    const int xcd = blockIdx.x & 7, sq = blockIdx.x >> 3;
-    const int m0 = ((sq / nN) * 8 + xcd) * BM2, n0 = (sq % nN) * BN2;
-    if (m0 >= a.M) return;
-    const char* Ab = reinterpret_cast<const char*>(static_cast<const bf16_t*>(a.A) + (int64_t)m0 * a.lda);
-    const char* Bb = reinterpret_cast<const char*>(static_cast<const bf16_t*>(a.B) + (int64_t)n0 * a.ldb);
-    const int amax = a.M - 1 - m0, bmax = a.N - 1 - n0;
-    const uint32_t lda2 = (uint32_t)a.lda * 2u, ldb2 = (uint32_t)a.ldb * 2u;
-    const int nk = a.K / 32;
-    // DMA: a wave instruction fills 1 KB = 16 rows x 64 B; lane l -> row l >> 2, physical chunk l & 3
-    const int drow = lane >> 2;
-    const uint32_t dchunk = (uint32_t)(((lane & 3) ^ ((-(lane >> 4)) & 3)) << 4);
-    const uint32_t aoff0 = (uint32_t)min(wave * 16 + drow, amax) * lda2 + dchunk;
-    const uint32_t aoff1 = (uint32_t)min((8 + wave) * 16 + drow, amax) * lda2 + dchunk;
-    const uint32_t boff0 = (uint32_t)min(wave * 16 + drow, bmax) * ldb2 + dchunk;
-    const uint32_t boff1 = (uint32_t)min((8 + wave) * 16 + drow, bmax) * ldb2 + dchunk;
-    // fragment reads: row (.. + fr), logical chunk fq
-    const int foff = fr * ROW3 + ((fq ^ ((-(fr >> 2)) & 3)) << 4);
-
-    f32x4_t acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    bf16x8_t fa[8], fb[4];
-
-#define GTOS_DMA1(src, dst)                                                                                                   \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),                                    \
-                                     (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
-#define GTOS_DMA4(stage, s_)                                                                                                  \
-    {                                                                                                                         \
-        const int kb_ = min((s_), nk - 1) * 64;            /* byte offset of the stage's k range; past the end: dummy re-read */ \
-        GTOS_DMA1(Ab + kb_ + aoff0, (stage) + wave * 1024);                                                                   \
-        GTOS_DMA1(Ab + kb_ + aoff1, (stage) + (8 + wave) * 1024);                                                             \
-        GTOS_DMA1(Bb + kb_ + boff0, (stage) + A3 + wave * 1024);                                                              \
-        GTOS_DMA1(Bb + kb_ + boff1, (stage) + A3 + (8 + wave) * 1024);                                                        \
-    }
-// one step of one wave = a LOAD segment (this wave's four DMA pieces of stage s_+3 into the slot of stage s_-1, the 12
-// fragment reads of stage s_, then the wait that retires this wave's pieces of stage s_+1) and a COMPUTE segment (32
-// MFMAs), each closed by a barrier.  Waves 4-7 run one segment behind waves 0-3, so on every SIMD one wave computes
-// while its partner loads.
-#define GTOS_STEP(slot_s, slot_d, s_)                                                                                         \
-    {                                                                                                                         \
-        GTOS_DMA4(slot_d, (s_) + 3);                                                                                          \
-        _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                                         \
-            fb[t] = *reinterpret_cast<const bf16x8_t*>((slot_s) + A3 + (wn + t * 16) * ROW3 + foff);                          \
-        _Pragma("unroll") for (int t = 0; t < 8; ++t)                                                                         \
-            fa[t] = *reinterpret_cast<const bf16x8_t*>((slot_s) + (wm + t * 16) * ROW3 + foff);                               \
-        __builtin_amdgcn_s_waitcnt(0x0078);                /* vmcnt(8) lgkmcnt(0): fragments here, own pieces of s_+1 landed */ \
-        __builtin_amdgcn_s_barrier();                                                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                                                                    \
-        _Pragma("unroll") for (int mt = 0; mt < 8; ++mt)                                                                      \
-            _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                                  \
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);                  \
-        __builtin_amdgcn_sched_barrier(0);                                                                                    \
-        __builtin_amdgcn_s_barrier();                                                                                         \
-    }
-
-    GTOS_DMA4(st0, 0);
-    GTOS_DMA4(st1, 1);
-    GTOS_DMA4(st2, 2);
-    GTOS_VMCNT(8);                                         // own pieces of stage 0
-    __builtin_amdgcn_s_barrier();                          // everybody's
-    if (wave >= 4) __builtin_amdgcn_s_barrier();           // the second wave of every SIMD starts one segment late
-    int s = 0;
-    for (; s + 4 <= nk; s += 4) {                          // whole quads only: one path through the body, so the wait-count
-        GTOS_STEP(st0, st3, s);                            // pass sees the same DMA order on the back edge as on entry
-        GTOS_STEP(st1, st0, s + 1);
-        GTOS_STEP(st2, st1, s + 2);
-        GTOS_STEP(st3, st2, s + 3);
-    }
-    if (s < nk) {
-        GTOS_STEP(st0, st3, s);
-        if (s + 1 < nk) {
-            GTOS_STEP(st1, st0, s + 1);
-            if (s + 2 < nk) GTOS_STEP(st2, st1, s + 2);
-        }
-    }
-    if (wave < 4) __builtin_amdgcn_s_barrier();            // same number of barriers for both halves
-    GTOS_VMCNT(0);                                         // the dummy prefetches of the last steps
-    __syncthreads();                                       // every wave is done with the stages: st0 / st1 become the output staging
-#undef GTOS_STEP
-#undef GTOS_READ
-#undef GTOS_DMA4
-#undef GTOS_DMA1
-
-    // ---- epilogue (bf16 out), as in gemm256_nt_kernel: 32 rows x 64 columns of the wave tile at a time through LDS
-    bf16_t* C = static_cast<bf16_t*>(a.C);
-    const float keep_scale = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
-    constexpr int CP = 64 * 2 + 16;
-    char* cs = (wave < 4 ? st0 : st1) + (wave & 3) * 32 * CP;
-#pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) {
-#pragma unroll
-        for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const int mt = q4 * 2 + mh;
-                const int m = m0 + wm + mt * 16 + fr, n = n0 + wn + nt * 16 + fq * 4;
-                float v[4] = {acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (a.bias && n + i < a.N) v[i] += a.bias[n + i];
-                    if (a.relu) v[i] = fmaxf(v[i], 0.f);
-                    if (a.p_drop > 0.f)
-                        v[i] = drop_keep(a.seed, (uint64_t)m * (uint64_t)a.N + (uint64_t)(n + i), a.p_drop) ? v[i] * keep_scale : 0.f;
-                }
-                *reinterpret_cast<uint2*>(cs + (mh * 16 + fr) * CP + (nt * 16 + fq * 4) * 2) = make_uint2(pack_bf(v[0], v[1]), pack_bf(v[2], v[3]));
-            }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0)
-#pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-            const int row = pass * 8 + (lane >> 3), col = (lane & 7) * 8;
-            const int m = m0 + wm + q4 * 32 + row, n = n0 + wn + col;
-            if (m >= a.M || n >= a.N) continue;
-            uint4 val = *reinterpret_cast<const uint4*>(cs + row * CP + col * 2);
-            bf16_t* cp = C + (int64_t)m * a.ldc + n;
-            if (n + 8 <= a.N) {
-                if (a.accumulate) {
-                    const uint4 old = *reinterpret_cast<const uint4*>(cp);
-                    val = make_uint4(pack_bf(lo_bf(val.x) + lo_bf(old.x), hi_bf(val.x) + hi_bf(old.x)),
-                                     pack_bf(lo_bf(val.y) + lo_bf(old.y), hi_bf(val.y) + hi_bf(old.y)),
-                                     pack_bf(lo_bf(val.z) + lo_bf(old.z), hi_bf(val.z) + hi_bf(old.z)),
-                                     pack_bf(lo_bf(val.w) + lo_bf(old.w), hi_bf(val.w) + hi_bf(old.w)));
-                }
-                *reinterpret_cast<uint4*>(cp) = val;
-            } else {
-                const bf16_t* e = reinterpret_cast<const bf16_t*>(cs + row * CP + col * 2);
-                for (int i = 0; i < 8 && n + i < a.N; ++i) {
-                    float o = bf2f(e[i]);
-                    if (a.accumulate) o += bf2f(cp[i]);
-                    cp[i] = f2bf(o);
-                }
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-    }
-}
 
 // (Round 4's two opt-in experiments lived here: gemm_p2_nt_kernel -- two role-split 4-wave workgroups per CU on 128x256 tiles for
 //  K <= 1023 -- and gemm_w4_nt_kernel -- one wave per SIMD with a 256-register accumulator named by hand.  Both were bit-checked on the
@@ -900,7 +740,7 @@ __global__ __launch_bounds__(512) void gemm256p_nt_kernel(GemmArgs a) {
 //  are not part of the library any more; the last commit that carries them is 4bd4edb.)
 
 // ---- gemm256q_nt_kernel (round 6): the same 256x256 tile / 8 waves (2 x 4, 128 x 64 each) on 64-k tiles cut into HALF-TILES, eight
-//      phases per two k tiles.  Against gemm256p_nt_kernel: (1) a DMA piece is 8 rows x 128 bytes -- whole cache lines -- where the 32-k
+//      phases per two k tiles.  Against round 2's four-stage kernel (gemm256p_nt_kernel, removed): (1) a DMA piece is 8 rows x 128 bytes -- whole cache lines -- where the 32-k
 //      stages fetch 16 rows x 64 bytes (half lines: twice the line requests on the CU's vector-memory path for the same bytes; what the
 //      forward GRU step gained by moving to 64-k stages, and what profiles/r6p_gru_bwd_regfed.txt lost by fetching half lines); (2) a
 //      compute segment is 16 MFMAs on one 64 x 32 quadrant of the wave tile, its fragment reads 4..12 ds_read_b128 (quadrant order
@@ -920,11 +760,11 @@ __global__ __launch_bounds__(512) void gemm256p_nt_kernel(GemmArgs a) {
 //      * LDS rows are 128 bytes; chunk c of row r sits at c ^ ((r >> 1) & 7) (conflict-free ds_read_b128, see swz; the (r >> 4) term of
 //        swz is not needed without transposed writes): a per-lane constant, so fragment addresses are two lane offsets (ks = 0, 1) plus
 //        immediates and the DMA sources a per-lane offset per piece.
-//      * K % 64 == 0.  Rows / columns past the end re-read the last valid one; half-tiles past the end of K re-read the last k tile (never
-//        multiplied): the number of DMAs in flight is the same in every phase.
+//      * K % 32 == 0; with K % 64 == 32 the lanes that would fetch the upper four chunks of the last k tile fetch a block of zeros instead
+//        ([434624,2016]x[1024,2016]^T: 838 TF/s on the four-stage kernel -> 970, hipBLASLt 980-1005).  Rows / columns past the end re-read the last
+//        valid one; half-tiles past the end of K re-read the last k tile (never multiplied): the number of DMAs in flight is the same in every phase.
 constexpr int HB = 128 * ROWB;                             // half-tile: 128 rows x 128 bytes
 constexpr int HB_EPI = 4 * 32 * (64 * 2 + 16);             // the two buffers the epilogue stages its rows in
-const bool g_use_q = !(getenv("GTOS_GEMM_8PHASE") && getenv("GTOS_GEMM_8PHASE")[0] == '0');     // 0: K % 64 == 0 products stay on gemm256p_nt_kernel
 
 __global__ __launch_bounds__(512) void gemm256q_nt_kernel(GemmArgs a) {
     if (a.p_drop > 0.f) a.seed = live_seed(a.seed);
@@ -948,13 +788,17 @@ __global__ __launch_bounds__(512) void gemm256q_nt_kernel(GemmArgs a) {
     const char* Bb = reinterpret_cast<const char*>(static_cast<const bf16_t*>(a.B) + (int64_t)n0 * a.ldb);
     const int amax = a.M - 1 - m0, bmax = a.N - 1 - n0;
     const uint32_t lda2 = (uint32_t)a.lda * 2u, ldb2 = (uint32_t)a.ldb * 2u;
-    const int nk = a.K / 64;
+    const int nk = (a.K + 63) / 64;
+    const bool tail32 = (a.K & 63) != 0;                   // K % 64 == 32: the upper four chunks of the last k tile come from the block of zeros
+    const char* Zl = static_cast<const char*>(a.zeros) + (lane & 15) * 16;
+    bool hi[2];
     // DMA: piece p (= wave, wave + 8) of a half-tile = buffer rows p*8 .. p*8+7; lane l -> row p*8 + (l >> 3), physical chunk l & 7
     uint32_t aoff[2][2], boff[2][2];                       // [half][piece]
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int rb = (wave + 8 * j) * 8 + (lane >> 3);                                   // buffer row
         const uint32_t ch = (uint32_t)(((lane & 7) ^ ((rb >> 1) & 7)) << 4);              // source chunk of this LDS position
+        hi[j] = ch >= 64;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             aoff[h][j] = (uint32_t)min((rb >> 6) * 128 + h * 64 + (rb & 63), amax) * lda2 + ch;
@@ -979,8 +823,11 @@ __global__ __launch_bounds__(512) void gemm256q_nt_kernel(GemmArgs a) {
 #define GTOS_QISSUE(buf, isA, h, kt_)                                                                                         \
     {                                                                                                                         \
         const int kb_ = min((kt_), nk - 1) * 128;                                                                             \
-        GTOS_QDMA(((isA) ? Ab : Bb) + kb_ + ((isA) ? aoff[h][0] : boff[h][0]), (buf) + wave * 1024);                          \
-        GTOS_QDMA(((isA) ? Ab : Bb) + kb_ + ((isA) ? aoff[h][1] : boff[h][1]), (buf) + (8 + wave) * 1024);                    \
+        const bool tl_ = tail32 && (kt_) >= nk - 1;                                                                           \
+        const char* s0_ = ((isA) ? Ab : Bb) + kb_ + ((isA) ? aoff[h][0] : boff[h][0]);                                        \
+        const char* s1_ = ((isA) ? Ab : Bb) + kb_ + ((isA) ? aoff[h][1] : boff[h][1]);                                        \
+        GTOS_QDMA((tl_ && hi[0]) ? Zl : s0_, (buf) + wave * 1024);                                                            \
+        GTOS_QDMA((tl_ && hi[1]) ? Zl : s1_, (buf) + (8 + wave) * 1024);                                                      \
     }
 #define GTOS_QREAD_A(buf)                                                                                                     \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                           \
@@ -1099,15 +946,14 @@ int launch256p(const GemmArgs& a, hipStream_t s) {
     const long long nMt = (a.M + BM2 - 1) / BM2, nNt = (a.N + BN2 - 1) / BN2;
     const long long nblk = ((nMt + 7) / 8) * 8 * nNt;
     if (nblk > 0x7fffffffLL) return -6;
-    if (g_use_q && a.K % 64 == 0) hipLaunchKernelGGL(gemm256q_nt_kernel, dim3((unsigned)nblk), dim3(512), 0, s, a);
-    else hipLaunchKernelGGL(gemm256p_nt_kernel, dim3((unsigned)nblk), dim3(512), 0, s, a);
+    hipLaunchKernelGGL(gemm256q_nt_kernel, dim3((unsigned)nblk), dim3(512), 0, s, a);
     GTOS_CHECK_LAUNCH();
     return 0;
 }
 
 // ---- gemm256p_tn_kernel: the weight-gradient shape dW = A^T B (A [K, M], B [K, N] row-major, K in the hundreds of
 //      thousands, split-K into the fp32 partial-tile workspace) on the same 256x256 tile, four 32-k stages and ping-pong
-//      schedule as gemm256p_nt_kernel.  A 256x256 tile re-reads each operand row from L2 half as often as the 128x128
+//      schedule as round 2's NT kernel (see the family comment above).  A 256x256 tile re-reads each operand row from L2 half as often as the 128x128
 //      tile (these products stream both operands from HBM once and are bound by the L2 -> LDS amplification).
 //      A stage holds [32 k][256 m] + [32 k][256 n] (512-byte k-rows); MFMA fragments (8 consecutive k of one column) come
 //      from ds_read_b64_tr_b16 as in gemm_kernel's transpose path: 32-byte granules XOR-swizzled with (k & 3), applied
@@ -1440,7 +1286,6 @@ extern "C" int gtos_gemm(int in_dtype, int out_dtype, int transA, int transB, in
         const long long t256 = ((long long)(M + BM2 - 1) / BM2) * ((N + BN2 - 1) / BN2);
         // K % 32 == 0 and enough macro tiles: the software-pipelined 256x256 kernel
         if (g_use_pipe && !transA && transB && a.vecA && a.vecB && a.vecC && splitk == 1 && N >= 256 && K % 32 == 0 &&
-            (N <= g_max_npipe || (g_use_q && K % 64 == 0)) &&
             lda < (1 << 22) && ldb < (1 << 22) &&
             (t256 >= 512 && K >= g_min_kpipe))
             return launch256p(a, s);

@@ -91,11 +91,10 @@ def test_gemm_256_macro_tile(M, N, K):
 @pytest.mark.parametrize("M,N,K", [(140037, 1000, 1056), (66000, 520, 1024), (70003, 264, 1088), (66000, 512, 1120), (70000, 1024, 4096),
                                    (8300, 4200, 1152), (33000, 1000, 1216)])
 def test_gemm_pipelined_256_tile(M, N, K):
-    """Forward-shaped products with K >= 1024 and >= 512 macro tiles take the software-pipelined 256x256 NT kernels: K % 64 == 0 the
-    8-phase half-tile kernel (gemm256q_nt_kernel, round 6: K/64 = 16, 17, 18, 19, 64 -- both parities of its two-k-tile loop --, any N
-    including N > 2048), K % 64 == 32 the four-stage ping-pong kernel (gemm256p_nt_kernel: K/32 = 33, 35 of its 4-step loop, N <= 2048).
-    Ragged M / N tails (rows past the end are re-read, never stored), strided A, fused bias + ReLU, bf16 accumulate; against fp32 matmul
-    of the same bf16 operands."""
+    """Forward-shaped products with K >= 1024, K % 32 == 0 and >= 512 macro tiles take the 8-phase half-tile kernel (gemm256q_nt_kernel, round 6):
+    K/64 = 16, 17, 18, 19, 64 -- both parities of its two-k-tile loop --, K % 64 == 32 (K = 1056, 1120: the upper half of the last k tile comes
+    from a block of zeros), any N including N > 2048.  Ragged M / N tails (rows past the end are re-read, never stored), strided A, fused bias +
+    ReLU, bf16 accumulate; against fp32 matmul of the same bf16 operands."""
     from gtos_amd import ops
     torch.manual_seed(M % 89)
     wide = (torch.randn(M, K + 64, device=dev()) * 0.5).to(torch.bfloat16)

@@ -9,7 +9,7 @@ that keeps HBM busy (latency under load is what moves such races), and every out
 
   forward GRU step   gru_step_fwd_a2w3_kernel (three slots of activation rows + two of weight rows per 64-k stage)
   backward GRU step  gru_step_bwd_kernel with role B (kloop_a2: the row panel one stage ahead)
-  GEMM               gemm256q_nt_kernel, gemm256p_nt_kernel, gemm256p_tn_kernel (split-K), the grouped TN product of gtos_gru_weight_grads
+  GEMM               gemm256q_nt_kernel, gemm256p_tn_kernel (split-K), the grouped TN product of gtos_gru_weight_grads
   whole function     the packed-path RelationEncoder over the whole C2 bank, training mode, DENSE upstream gradient, run twice
 
 `tools/race_demo.sh` rebuilds the library with -DGTOS_RACE_DEMO (the waits as they were before commit 9d39564) and shows this file failing."""
@@ -133,7 +133,7 @@ def test_soak_backward_gru_step_with_input_gradient_role(rows, rows_prev, layer)
 @pytest.mark.parametrize("M,N,K", [(C2_ROWS, 1024, 4096), (C2_ROWS, 512, 8192), (C2_ROWS, 1024, 1024), (MID_ROWS, 512, 2016)])
 def test_soak_gemm_nt_pingpong(M, N, K):
     """gemm256q_nt_kernel (K % 64 == 0: eight half-tile buffers refilled by DMA two phases after their last read) at the bank-gradient
-    slab shape, the relation-projection backward and a deep K; gemm256p_nt_kernel (four 32-k stages, ping-pong) at a K % 64 == 32."""
+    slab shape, the relation-projection backward, a deep K and a K % 64 == 32 (the zero-filled half of the last k tile)."""
     from gtos_amd import ops
     torch.manual_seed(K)
     a, b = r_(M, K), r_(N, K, scale=0.1)

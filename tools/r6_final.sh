@@ -3,7 +3,7 @@
 # secondary legs), the decode record, the other BASELINE configs in the default mode with their device memory, the kernel trace / timeline of
 # the default step, the counter profiles (attention kernels per operand mode; the step by kernel), every GEMM shape against hipBLASLt.
 #     gpurun --timeout 2700 -- 'bash tools/r6_final.sh'        (about 14 GPU-minutes; PROTOCOL=1 adds SURVEY 8d's live CPU protocol, +6)
-O=gpurun_out/r6z; mkdir -p $O
+O=gpurun_out/${OUT:-r6zz}; mkdir -p $O
 export PYTHONPATH=$PWD
 R=$PWD
 ( time timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -s > $O/gpu_tests.log 2>&1 ) 2> $O/gpu_tests.time
