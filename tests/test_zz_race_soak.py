@@ -9,7 +9,7 @@ that keeps HBM busy (latency under load is what moves such races), and every out
 
   forward GRU step   gru_step_fwd_a2w3_kernel (three slots of activation rows + two of weight rows per 64-k stage)
   backward GRU step  gru_step_bwd_kernel with role B (kloop_a2: the row panel one stage ahead)
-  GEMM               gemm256q_nt_kernel, gemm256p_tn_kernel (split-K), the grouped TN product of gtos_gru_weight_grads
+  GEMM               gemm256q_nt_kernel, gemm256p_tn_kernel (split-K), the grouped TN product of gtos_gru_weight_grads, the batched one of gtos_gemm_tn_batch
   whole function     the packed-path RelationEncoder over the whole C2 bank, training mode, DENSE upstream gradient, run twice
 
 `tools/race_demo.sh` rebuilds the library with -DGTOS_RACE_DEMO (the waits as they were before commit 9d39564) and shows this file failing."""
@@ -166,6 +166,28 @@ def test_soak_grouped_weight_gradients(layer):
     def launch():
         call("gtos_gru_weight_grads", N, hs, ind, valid, ptr(d4), ptr(x), ind, ptr(hp), hs, ptr(gi), valid, ptr(gh), hs, ptr(ws), ws.numel() * 4, stream())
     soak("grouped dW L%d" % layer, launch, [gi, gh], reps=max(10, REPS // 3))
+
+
+def test_soak_batched_small_weight_gradients():
+    """gtos_gemm_tn_batch (round 6: gemm256p_tn_kernel in its job-table mode): the weight gradients of a C2 step's graph and decoder layers -- 36
+    jobs, the row counts and shapes ops.flush_dw() hands it -- launched repeatedly on the same operands into zeroed targets: no split-K, one
+    writer per tile, so every target must be the same bits every time (the bias column sums go through fp32 atomics and are left out)."""
+    import ctypes
+    from gtos_amd._lib import call, stream
+    torch.manual_seed(9)
+    shapes = [(6464, 1536, 512), (6464, 512, 512), (6464, 1024, 512), (6464, 512, 1024)] * 6 + [(3200, 512, 512), (3200, 1024, 512), (3200, 1536, 512)] * 4
+    jobs = [(r_(K, M), r_(K, N), torch.zeros(M, N, device=dev())) for K, M, N in shapes]
+    n = len(jobs)
+    vp, i64, i32 = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int * n
+    A = vp(*[j[0].data_ptr() for j in jobs]); B = vp(*[j[1].data_ptr() for j in jobs]); C = vp(*[j[2].data_ptr() for j in jobs])
+    nob = vp(*[None] * n)
+    lda = i64(*[j[0].stride(0) for j in jobs]); ldb = i64(*[j[1].stride(0) for j in jobs]); ldc = i64(*[j[2].stride(0) for j in jobs])
+    M_ = i32(*[j[0].shape[1] for j in jobs]); N_ = i32(*[j[1].shape[1] for j in jobs]); K_ = i32(*[j[0].shape[0] for j in jobs])
+
+    def launch():
+        call("gtos_gemm_tn_batch", n, ctypes.addressof(A), ctypes.addressof(lda), ctypes.addressof(M_), ctypes.addressof(B), ctypes.addressof(ldb),
+             ctypes.addressof(N_), ctypes.addressof(K_), ctypes.addressof(C), ctypes.addressof(ldc), ctypes.addressof(nob), stream())
+    soak("batched small dW", launch, [j[2] for j in jobs])
 
 
 def test_soak_c2_full_size_packed_path_backward_dense_upstream_run_to_run():
